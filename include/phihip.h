@@ -1,0 +1,160 @@
+/*
+ * phihip.h -- C ABI of libphihip.so: the MI355X (gfx950) backend for PhiFlow's incompressible-fluid time step.
+ *
+ * Drop-in boundary. PhiFlow (reference: /root/reference, v3.4.0) is pure Python and has no FFI of its own; the
+ * interface it calls on this path is PhiML's Python backend API. Each entry point below replaces one PhiFlow-level
+ * operation; a maintainer binds it with ctypes. Citations are `file:line` in /root/reference.
+ *
+ * Conventions
+ *   - All field buffers are DEVICE pointers owned by the caller (e.g. torch-ROCm tensor.data_ptr()); the library owns
+ *     only its context / workspace. Nothing is allocated inside the CG loop.
+ *   - Arrays are dense C-contiguous (batch, x, y[, z]); the LAST spatial axis is the fast one
+ *     (phi/field/_field.py:160-180). `batch` independent simulations share one grid description (PhiML batch dims).
+ *   - Velocity = StaggeredGrid (phi/field/_grid.py:89-176): one array per component d with
+ *     shape res + (lo+up-1)*e_d where (lo,up) = valid_outer_faces(d):
+ *         PHIHIP_BC_PERIODIC -> (1,0)   N_d   faces (lower face of each cell)
+ *         PHIHIP_BC_CLOSED   -> (0,0)   N_d-1 faces (wall faces carry the constant boundary value, not stored)
+ *         PHIHIP_BC_OPEN     -> (1,1)   N_d+1 faces
+ *     (tests/commit/field/test__grid.py:25-36). Use phihip_component_shape().
+ *   - Pressure / divergence / scalars = CenteredGrid, shape res.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) except
+ *     phihip_cg_solve / phihip_make_incompressible when `info != NULL`, which synchronise the stream to report.
+ *   - Return value: 0 on success, negative phihip_status otherwise; phihip_last_error() gives a thread-local message.
+ *     Numerical non-convergence is NOT an error: it is reported in phihip_solve_info and the Python layer raises
+ *     NotConverged / Diverged like phiml.math.solve_linear does (tests/commit/physics/test_diffuse.py:60-66).
+ *   - There is no CPU fallback: without a HIP device phihip_ctx_create fails with PHIHIP_ERR_NO_DEVICE.
+ */
+#ifndef PHIHIP_H
+#define PHIHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHIHIP_VERSION 100 /* 0.1.0 */
+
+typedef enum phihip_status {
+    PHIHIP_OK = 0,
+    PHIHIP_ERR_BAD_ARG = -1,
+    PHIHIP_ERR_HIP = -2,
+    PHIHIP_ERR_UNSUPPORTED = -3,
+    PHIHIP_ERR_NO_DEVICE = -4,
+    PHIHIP_ERR_ALLOC = -5
+} phihip_status;
+
+typedef enum phihip_dtype { PHIHIP_F32 = 0, PHIHIP_F64 = 1 } phihip_dtype;
+
+/* velocity extrapolation per axis side (phiml.math.extrapolation): PERIODIC / ConstantExtrapolation / BOUNDARY */
+typedef enum phihip_bc { PHIHIP_BC_PERIODIC = 0, PHIHIP_BC_CLOSED = 1, PHIHIP_BC_OPEN = 2 } phihip_bc;
+
+/* UniformGrid + velocity Extrapolation (phi/geom/_grid.py:41-122). Unused trailing axis entries (rank 2) are ignored. */
+typedef struct phihip_grid {
+    int32_t rank;             /* 2 or 3 */
+    int32_t dtype;            /* phihip_dtype */
+    int32_t batch;            /* number of independent simulations (>= 1) */
+    int32_t res[3];           /* cells per axis x, y[, z] */
+    double lower[3];          /* Box bounds */
+    double upper[3];
+    int32_t bc[3][2];         /* [axis][0 = lower side, 1 = upper side] phihip_bc; periodic must be set on both sides */
+    double bc_val[3][2][3];   /* [axis][side][component] constant velocity on CLOSED sides (ZERO -> 0) */
+} phihip_grid;
+
+/* phiml.math.Solve subset used by fluid.make_incompressible (phi/physics/fluid.py:96,145-156) */
+typedef struct phihip_solve {
+    double rel_tol;           /* stop when ||r||^2 <= max(rel_tol^2 ||rhs||^2, abs_tol^2) (per batch entry) */
+    double abs_tol;
+    int32_t max_iterations;
+    int32_t refresh_every;    /* recompute r = y - A x every n-th iteration (PhiML: 50); 0 = never */
+    int32_t check_every;      /* host polls the device-side continue flags every n iterations; 0 = only at the end */
+    int32_t reserved;
+} phihip_solve;
+
+/* per batch entry result of the linear solve (phiml SolveInfo: iterations, residual, converged, diverged) */
+typedef struct phihip_solve_info {
+    double residual_sq;
+    double rhs_sq;
+    int32_t iterations;
+    int32_t converged;
+    int32_t diverged;
+    int32_t reserved;
+} phihip_solve_info;
+
+typedef struct phihip_ctx phihip_ctx;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------------- */
+int phihip_version(void);
+const char* phihip_last_error(void);
+/* replaces: backend selection `with backend:` / set_default_device('GPU') (phi/torch/flow.py:31-32, demos/Top_Opt/Top_Opt3D.py:190) */
+int phihip_ctx_create(int device, phihip_ctx** out);
+int phihip_ctx_destroy(phihip_ctx* ctx);
+/* bytes of device workspace the context currently holds (grows on demand, never inside the CG loop) */
+int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes);
+/* stored shape of velocity component `comp` (phi/geom/_grid.py:204-209) */
+int phihip_component_shape(const phihip_grid* grid, int comp, int32_t shape[3]);
+
+/* ---- a1: advect.semi_lagrangian with euler back-trace (phi/physics/advect.py:156-179, :20-24) ------------------ */
+/* staggered `field` advected by staggered `velocity` (pass the same pointers for self-advection); out must not alias */
+int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3],
+                            const void* const velocity[3], void* const out[3], double dt, void* stream);
+/* centred scalar (e.g. smoke) advected by the staggered velocity; s_bc/s_val = the scalar's own extrapolation
+ * (PERIODIC wrap / OPEN zero-gradient / CLOSED constant s_val) */
+int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                           const double s_val[3][2], const void* const velocity[3], void* out, double dt, void* stream);
+
+/* ---- a7: obstacle masks (phi/physics/fluid.py:130-137) ---------------------------------------------------------- */
+/* Packs per-cell stencil flags (1 byte / cell): bit 2*axis+side = the face on that side is open for flux
+ * (hard_bcs = min(accessible_L, accessible_R), outside cells: periodic wrap / OPEN 1 / CLOSED 0), bit 6 = active.
+ * accessible / active: uint8 per cell (1 = fluid) or NULL (= all ones). mask_batch = 1 (shared) or grid->batch. */
+int phihip_build_cellflags(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* accessible, const uint8_t* active,
+                           int mask_batch, uint8_t* flags, void* stream);
+
+/* ---- a2/a3: field.divergence (phi/field/_field_math.py:589,617-626) and fluid._balance_divergence (fluid.py:205-209) */
+/* div = divergence(v) [* active]; flags may be NULL. balance != 0 additionally subtracts mean (active-weighted). */
+int phihip_divergence(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], const uint8_t* flags,
+                      int mask_batch, int balance, void* div, void* stream);
+
+/* ---- a4: fluid.masked_laplace (phi/physics/fluid.py:165-202), matrix-free 5/7-point operator ------------------- */
+int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch,
+                         const void* p, void* out, void* stream);
+
+/* ---- a5: math.solve_linear(masked_laplace, rhs, Solve('CG', ...)) (phi/physics/fluid.py:156) ------------------- */
+/* x holds x0 on entry and the solution on exit. info: array of grid->batch entries or NULL (no host sync). */
+int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* rhs,
+                    void* x, const phihip_solve* solve, phihip_solve_info* info, void* stream);
+
+/* ---- a6: v -= hard_bcs * spatial_gradient(p, at=face) (phi/physics/fluid.py:158-161) ---------------------------- */
+/* in-place on velocity */
+int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,
+                         void* const velocity[3], void* stream);
+
+/* ---- fluid.make_incompressible (phi/physics/fluid.py:94-162), fused a2..a6 ------------------------------------- */
+/* velocity is projected in place; pressure holds x0 on entry and p on exit; div_out (optional) receives the rhs.
+ * soft_mask (optional): per-component face factors (1 - obstacle mask) applied first (apply_boundary_conditions). */
+int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* const velocity[3],
+                               const void* const soft_mask[3], const uint8_t* flags, int mask_batch, int balance,
+                               void* pressure, void* div_out, const phihip_solve* solve, phihip_solve_info* info,
+                               void* stream);
+
+/* ---- f1: diffuse.explicit order 2 on the staggered velocity (phi/physics/diffuse.py:13-60) ---------------------- */
+int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3],
+                            void* const out[3], double diffusivity_dt, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------------------ */
+/* Kernel families timed with hipEvent pairs on the solve stream while profiling is enabled. */
+typedef enum phihip_kernel_id {
+    PHIHIP_K_ADVECT = 0, PHIHIP_K_DIVERGENCE = 1, PHIHIP_K_CG_RESIDUAL = 2, PHIHIP_K_CG_MATVEC_DOT = 3,
+    PHIHIP_K_CG_UPDATE = 4, PHIHIP_K_CG_SCALAR = 5, PHIHIP_K_GRAD_SUBTRACT = 6, PHIHIP_K_OTHER = 7, PHIHIP_K_COUNT = 8
+} phihip_kernel_id;
+int phihip_profile_enable(phihip_ctx* ctx, int enable);
+/* synchronises, then returns launches and summed milliseconds per family since the last reset */
+int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], double total_ms[PHIHIP_K_COUNT], int reset);
+/* tile configuration of the CG marching kernels: rows per thread (1,2,4) and threads per row (16,32,64); 0 = auto */
+int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHIHIP_H */

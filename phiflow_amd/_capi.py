@@ -1,0 +1,239 @@
+"""
+ctypes binding of ``libphihip.so`` (C ABI declared in ``include/phihip.h``).
+
+This is the only place the package touches native code. There is **no CPU fallback**: if the shared library is
+missing `load_default_library()` raises `PhiHipLibraryError`, and creating a context without a HIP device fails with
+``PHIHIP_ERR_NO_DEVICE``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_size_t, c_uint8, c_void_p
+from typing import Optional, Sequence
+
+PHIHIP_F32, PHIHIP_F64 = 0, 1
+BC_PERIODIC, BC_CLOSED, BC_OPEN = 0, 1, 2
+
+K_NAMES = ("advect", "divergence", "cg_residual", "cg_matvec_dot", "cg_update", "cg_scalar", "grad_subtract", "other")
+K_COUNT = len(K_NAMES)
+
+STATUS_NAMES = {0: "PHIHIP_OK", -1: "PHIHIP_ERR_BAD_ARG", -2: "PHIHIP_ERR_HIP", -3: "PHIHIP_ERR_UNSUPPORTED",
+                -4: "PHIHIP_ERR_NO_DEVICE", -5: "PHIHIP_ERR_ALLOC"}
+
+EXPORTED_SYMBOLS = (
+    "phihip_version", "phihip_last_error", "phihip_ctx_create", "phihip_ctx_destroy", "phihip_workspace_bytes",
+    "phihip_component_shape", "phihip_advect_staggered", "phihip_advect_centered", "phihip_build_cellflags",
+    "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_grad_subtract",
+    "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
+    "phihip_set_tuning",
+)
+
+
+class PhiHipError(RuntimeError):
+    """ A libphihip call returned a negative status. """
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class PhiHipLibraryError(ImportError):
+    """ libphihip.so could not be loaded (not built, or ROCm runtime missing). """
+
+
+class Grid(ctypes.Structure):
+    """ mirrors ``phihip_grid`` """
+    _fields_ = [("rank", c_int32), ("dtype", c_int32), ("batch", c_int32), ("res", c_int32 * 3),
+                ("lower", c_double * 3), ("upper", c_double * 3), ("bc", (c_int32 * 2) * 3),
+                ("bc_val", ((c_double * 3) * 2) * 3)]
+
+
+class Solve(ctypes.Structure):
+    """ mirrors ``phihip_solve`` """
+    _fields_ = [("rel_tol", c_double), ("abs_tol", c_double), ("max_iterations", c_int32), ("refresh_every", c_int32),
+                ("check_every", c_int32), ("reserved", c_int32)]
+
+
+class SolveInfo(ctypes.Structure):
+    """ mirrors ``phihip_solve_info`` """
+    _fields_ = [("residual_sq", c_double), ("rhs_sq", c_double), ("iterations", c_int32), ("converged", c_int32),
+                ("diverged", c_int32), ("reserved", c_int32)]
+
+
+_Ptr3 = c_void_p * 3
+
+
+def ptr3(ptrs: Optional[Sequence[int]]):
+    """ array of three device pointers (unused trailing entries NULL) or None """
+    if ptrs is None:
+        return None
+    arr = _Ptr3()
+    for i in range(3):
+        arr[i] = ptrs[i] if i < len(ptrs) and ptrs[i] else None
+    return arr
+
+
+def make_grid(rank: int, dtype: int, batch: int, res, lower, upper, bc, bc_val=None) -> Grid:
+    g = Grid()
+    g.rank, g.dtype, g.batch = int(rank), int(dtype), int(batch)
+    for d in range(rank):
+        g.res[d] = int(res[d])
+        g.lower[d] = float(lower[d])
+        g.upper[d] = float(upper[d])
+        for s in range(2):
+            g.bc[d][s] = int(bc[d][s])
+            for c in range(rank):
+                g.bc_val[d][s][c] = float(bc_val[d][s][c]) if bc_val is not None else 0.0
+    return g
+
+
+class Library:
+    """ typed function table of one loaded libphihip """
+
+    def __init__(self, path: str):
+        self.path = os.path.abspath(path)
+        try:
+            self.dll = ctypes.CDLL(self.path)
+        except OSError as exc:
+            raise PhiHipLibraryError(f"cannot load {self.path}: {exc}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                     f"(hipcc --offload-arch=gfx950); there is no CPU fallback.") from exc
+        missing = [s for s in EXPORTED_SYMBOLS if not hasattr(self.dll, s)]
+        if missing:
+            raise PhiHipLibraryError(f"{self.path} lacks symbols declared in include/phihip.h: {missing}")
+        d = self.dll
+        d.phihip_version.restype = c_int
+        d.phihip_last_error.restype = c_char_p
+        d.phihip_ctx_create.argtypes = [c_int, POINTER(c_void_p)]
+        d.phihip_ctx_destroy.argtypes = [c_void_p]
+        d.phihip_workspace_bytes.argtypes = [c_void_p, POINTER(c_size_t)]
+        d.phihip_component_shape.argtypes = [POINTER(Grid), c_int, POINTER(c_int32 * 3)]
+        d.phihip_advect_staggered.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
+        d.phihip_advect_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
+                                             POINTER(_Ptr3), c_void_p, c_double, c_void_p]
+        d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+        d.phihip_divergence.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p, c_void_p]
+        d.phihip_laplace_apply.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+        d.phihip_cg_solve.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
+        d.phihip_grad_subtract.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, POINTER(_Ptr3), c_void_p]
+        d.phihip_make_incompressible.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p,
+                                                 c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
+        d.phihip_diffuse_explicit.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
+        d.phihip_profile_enable.argtypes = [c_void_p, c_int]
+        d.phihip_profile_read.argtypes = [c_void_p, POINTER(c_int32 * K_COUNT), POINTER(c_double * K_COUNT), c_int]
+        d.phihip_set_tuning.argtypes = [c_void_p, c_int, c_int, c_int]
+        for name in EXPORTED_SYMBOLS:
+            if name not in ("phihip_version", "phihip_last_error"):
+                getattr(d, name).restype = c_int
+
+    def check(self, status: int):
+        if status != 0:
+            raise PhiHipError(status, (self.dll.phihip_last_error() or b"").decode(errors="replace"))
+
+    def version(self) -> int:
+        return self.dll.phihip_version()
+
+
+class Context:
+    """ owns one ``phihip_ctx`` (device + workspace). Not thread-safe; one per (process, device). """
+
+    def __init__(self, lib: Library, device: int = 0):
+        self.lib = lib
+        self.handle = c_void_p()
+        lib.check(lib.dll.phihip_ctx_create(int(device), ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.dll.phihip_ctx_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thin typed wrappers (pointers are plain ints) ----
+    def component_shape(self, grid: Grid, comp: int):
+        out = (c_int32 * 3)()
+        self.lib.check(self.lib.dll.phihip_component_shape(ctypes.byref(grid), comp, ctypes.byref(out)))
+        return tuple(out[d] for d in range(grid.rank))
+
+    def advect_staggered(self, grid, field, velocity, out, dt, stream=0):
+        self.lib.check(self.lib.dll.phihip_advect_staggered(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)),
+                                                            ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(out)), float(dt), stream or None))
+
+    def advect_centered(self, grid, s, s_bc, s_val, velocity, out, dt, stream=0):
+        bc = ((c_int32 * 2) * 3)()
+        val = ((c_double * 2) * 3)()
+        for d in range(grid.rank):
+            for side in range(2):
+                bc[d][side] = int(s_bc[d][side])
+                val[d][side] = float(s_val[d][side]) if s_val is not None else 0.0
+        self.lib.check(self.lib.dll.phihip_advect_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
+                                                           ctypes.byref(ptr3(velocity)), out, float(dt), stream or None))
+
+    def build_cellflags(self, grid, accessible, active, mask_batch, flags, stream=0):
+        self.lib.check(self.lib.dll.phihip_build_cellflags(self.handle, ctypes.byref(grid), accessible or None, active or None,
+                                                           int(mask_batch), flags, stream or None))
+
+    def divergence(self, grid, velocity, flags, mask_batch, balance, div, stream=0):
+        self.lib.check(self.lib.dll.phihip_divergence(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), flags or None,
+                                                      int(mask_batch), int(bool(balance)), div, stream or None))
+
+    def laplace_apply(self, grid, flags, mask_batch, p, out, stream=0):
+        self.lib.check(self.lib.dll.phihip_laplace_apply(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), p, out,
+                                                         stream or None))
+
+    def cg_solve(self, grid, flags, mask_batch, rhs, x, solve: Solve, want_info=True, stream=0):
+        info = (SolveInfo * grid.batch)() if want_info else None
+        self.lib.check(self.lib.dll.phihip_cg_solve(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), rhs, x,
+                                                    ctypes.byref(solve), info, stream or None))
+        return list(info) if want_info else None
+
+    def grad_subtract(self, grid, flags, mask_batch, p, velocity, stream=0):
+        self.lib.check(self.lib.dll.phihip_grad_subtract(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), p,
+                                                         ctypes.byref(ptr3(velocity)), stream or None))
+
+    def make_incompressible(self, grid, velocity, soft_mask, flags, mask_batch, balance, pressure, div_out, solve: Solve,
+                            want_info=True, stream=0):
+        info = (SolveInfo * grid.batch)() if want_info else None
+        sm = ptr3(soft_mask)
+        self.lib.check(self.lib.dll.phihip_make_incompressible(
+            self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), ctypes.byref(sm) if sm is not None else None, flags or None,
+            int(mask_batch), int(bool(balance)), pressure, div_out or None, ctypes.byref(solve), info, stream or None))
+        return list(info) if want_info else None
+
+    def diffuse_explicit(self, grid, velocity, out, diffusivity_dt, stream=0):
+        self.lib.check(self.lib.dll.phihip_diffuse_explicit(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)),
+                                                            ctypes.byref(ptr3(out)), float(diffusivity_dt), stream or None))
+
+    def profile_enable(self, enable: bool):
+        self.lib.check(self.lib.dll.phihip_profile_enable(self.handle, int(bool(enable))))
+
+    def profile_read(self, reset=True):
+        launches = (c_int32 * K_COUNT)()
+        ms = (c_double * K_COUNT)()
+        self.lib.check(self.lib.dll.phihip_profile_read(self.handle, ctypes.byref(launches), ctypes.byref(ms), int(bool(reset))))
+        return {K_NAMES[k]: (launches[k], ms[k]) for k in range(K_COUNT)}
+
+    def set_tuning(self, rows_per_thread=0, threads_per_row=0, chunk_planes=0):
+        self.lib.check(self.lib.dll.phihip_set_tuning(self.handle, int(rows_per_thread), int(threads_per_row), int(chunk_planes)))
+
+    def workspace_bytes(self) -> int:
+        out = c_size_t()
+        self.lib.check(self.lib.dll.phihip_workspace_bytes(self.handle, ctypes.byref(out)))
+        return out.value
+
+
+DEFAULT_LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libphihip.so")
+_default_library: Optional[Library] = None
+
+
+def load_default_library() -> Library:
+    """ loads phiflow_amd/lib/libphihip.so (built by ``__graft_entry__.build()``); raises `PhiHipLibraryError` if absent. """
+    global _default_library
+    if _default_library is None:
+        if not os.path.exists(DEFAULT_LIBRARY_PATH):
+            raise PhiHipLibraryError(f"{DEFAULT_LIBRARY_PATH} does not exist. Build the HIP extension first "
+                                     f"(`make -C phiflow_amd/csrc` or `__graft_entry__.build()`); phiflow_amd has no CPU fallback.")
+        _default_library = Library(DEFAULT_LIBRARY_PATH)
+    return _default_library

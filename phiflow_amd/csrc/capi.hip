@@ -1,0 +1,372 @@
+// capi.hip -- extern "C" surface of libphihip.so (declared in include/phihip.h) + context / workspace / profiling plumbing.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace phihip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int make_view(const phihip_grid* grid, GridView* out) {
+    PHIHIP_REQUIRE(grid != nullptr, "grid is NULL");
+    PHIHIP_REQUIRE(grid->rank == 2 || grid->rank == 3, "grid.rank must be 2 or 3 (got %d)", grid->rank);
+    PHIHIP_REQUIRE(grid->dtype == PHIHIP_F32 || grid->dtype == PHIHIP_F64, "grid.dtype must be PHIHIP_F32 or PHIHIP_F64");
+    PHIHIP_REQUIRE(grid->batch >= 1, "grid.batch must be >= 1");
+    GridView v;
+    memset(&v, 0, sizeof(v));
+    v.rank = grid->rank;
+    v.ax0 = 3 - grid->rank;
+    v.dtype = grid->dtype;
+    v.batch = grid->batch;
+    for (int ax = 0; ax < 3; ++ax) {
+        v.n[ax] = 1;
+        v.bc[ax][0] = v.bc[ax][1] = PHIHIP_BC_PERIODIC;
+        v.lower[ax] = 0;
+        v.dx[ax] = 1;
+    }
+    for (int d = 0; d < grid->rank; ++d) {
+        const int ax = d + v.ax0;
+        PHIHIP_REQUIRE(grid->res[d] >= 1, "grid.res[%d] must be >= 1", d);
+        PHIHIP_REQUIRE(grid->upper[d] > grid->lower[d], "grid bounds must have positive size along axis %d", d);
+        v.n[ax] = grid->res[d];
+        v.lower[ax] = grid->lower[d];
+        v.dx[ax] = (grid->upper[d] - grid->lower[d]) / grid->res[d];
+        for (int s = 0; s < 2; ++s) {
+            const int code = grid->bc[d][s];
+            PHIHIP_REQUIRE(code >= PHIHIP_BC_PERIODIC && code <= PHIHIP_BC_OPEN, "grid.bc[%d][%d] invalid", d, s);
+            v.bc[ax][s] = code;
+            for (int c = 0; c < grid->rank; ++c) v.bcv[ax][s][c + v.ax0] = grid->bc_val[d][s][c];
+        }
+        PHIHIP_REQUIRE((v.bc[ax][0] == PHIHIP_BC_PERIODIC) == (v.bc[ax][1] == PHIHIP_BC_PERIODIC),
+                       "axis %d: PERIODIC must be set on both sides", d);
+    }
+    v.cells = (long long)v.n[0] * v.n[1] * v.n[2];
+    for (int ca = 0; ca < 3; ++ca) {
+        const bool lo_valid = v.bc[ca][0] != PHIHIP_BC_CLOSED;
+        const bool hi_valid = v.bc[ca][1] == PHIHIP_BC_OPEN;
+        v.off[ca] = lo_valid ? 0 : 1;
+        for (int ax = 0; ax < 3; ++ax) v.cn[ca][ax] = v.n[ax];
+        if (ca >= v.ax0) v.cn[ca][ca] = v.n[ca] + (int)lo_valid + (int)hi_valid - 1;
+        v.ccells[ca] = (long long)v.cn[ca][0] * v.cn[ca][1] * v.cn[ca][2];
+        if (ca >= v.ax0) PHIHIP_REQUIRE(v.cn[ca][ca] >= 1, "axis %d has no stored faces (resolution too small)", ca - v.ax0);
+    }
+    *out = v;
+    return PHIHIP_OK;
+}
+
+VelGrid make_velgrid(const GridView& v) {
+    VelGrid g;
+    memset(&g, 0, sizeof(g));
+    for (int a = 0; a < 3; ++a) {
+        g.n[a] = v.n[a];
+        g.off[a] = v.off[a];
+        g.dx[a] = v.dx[a];
+        g.ccells[a] = v.ccells[a];
+        for (int s = 0; s < 2; ++s) {
+            g.bc[a][s] = v.bc[a][s];
+            for (int c = 0; c < 3; ++c) g.bcv[a][s][c] = v.bcv[a][s][c];
+        }
+        for (int c = 0; c < 3; ++c) g.cn[a][c] = v.cn[a][c];
+    }
+    g.ax0 = v.ax0;
+    g.cells = v.cells;
+    return g;
+}
+
+int ensure_buffer(DeviceBuffer& buf, size_t bytes) {
+    if (buf.bytes >= bytes && buf.ptr) return PHIHIP_OK;
+    if (buf.ptr) {
+        PHIHIP_CHECK_HIP(hipFree(buf.ptr));
+        buf.ptr = nullptr;
+        buf.bytes = 0;
+    }
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&buf.ptr, bytes);
+    if (e != hipSuccess) {
+        buf.ptr = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return PHIHIP_ERR_ALLOC;
+    }
+    buf.bytes = bytes;
+    return PHIHIP_OK;
+}
+
+int profile_begin(phihip_ctx* ctx, int kid, hipStream_t s, int* slot) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        phihip_ctx::EventPair p;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return PHIHIP_ERR_HIP;
+        ctx->ev_pool.push_back(p);
+    }
+    *slot = (int)ctx->ev_used++;
+    ctx->ev_pool[*slot].kid = kid;
+    hipEventRecord(ctx->ev_pool[*slot].a, s);
+    return PHIHIP_OK;
+}
+
+int profile_end(phihip_ctx* ctx, int slot, hipStream_t s) {
+    hipEventRecord(ctx->ev_pool[slot].b, s);
+    return PHIHIP_OK;
+}
+
+int profile_collect(phihip_ctx* ctx) {
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        auto& p = ctx->ev_pool[i];
+        PHIHIP_CHECK_HIP(hipEventSynchronize(p.b));
+        float ms = 0;
+        PHIHIP_CHECK_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+        ctx->prof_launches[p.kid] += 1;
+        ctx->prof_ms[p.kid] += ms;
+    }
+    ctx->ev_used = 0;
+    return PHIHIP_OK;
+}
+
+static void remap3(const GridView& v, const void* const in[3], const void* out[3]) {
+    out[0] = out[1] = out[2] = nullptr;
+    for (int d = 0; d < v.rank; ++d) out[d + v.ax0] = in ? in[d] : nullptr;
+}
+static void remap3w(const GridView& v, void* const in[3], void* out[3]) {
+    out[0] = out[1] = out[2] = nullptr;
+    for (int d = 0; d < v.rank; ++d) out[d + v.ax0] = in ? in[d] : nullptr;
+}
+
+static int check_ptrs(const GridView& v, const void* const p[3], const char* what) {
+    PHIHIP_REQUIRE(p != nullptr, "%s is NULL", what);
+    for (int d = 0; d < v.rank; ++d) PHIHIP_REQUIRE(p[d] != nullptr, "%s[%d] is NULL", what, d);
+    return PHIHIP_OK;
+}
+
+}  // namespace phihip
+
+using namespace phihip;
+
+extern "C" {
+
+int phihip_version(void) { return PHIHIP_VERSION; }
+
+const char* phihip_last_error(void) { return g_err; }
+
+int phihip_ctx_create(int device, phihip_ctx** out) {
+    PHIHIP_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libphihip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+        return PHIHIP_ERR_NO_DEVICE;
+    }
+    PHIHIP_REQUIRE(device >= 0 && device < count, "device %d out of range (have %d)", device, count);
+    PHIHIP_CHECK_HIP(hipSetDevice(device));
+    phihip_ctx* ctx = new phihip_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return PHIHIP_OK;
+}
+
+int phihip_ctx_destroy(phihip_ctx* ctx) {
+    if (!ctx) return PHIHIP_OK;
+    hipSetDevice(ctx->device);
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs};
+    for (DeviceBuffer* b : bufs)
+        if (b->ptr) hipFree(b->ptr);
+    if (ctx->host_state) hipHostFree(ctx->host_state);
+    for (auto& p : ctx->ev_pool) {
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    delete ctx;
+    return PHIHIP_OK;
+}
+
+int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
+    PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
+    *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes;
+    return PHIHIP_OK;
+}
+
+int phihip_component_shape(const phihip_grid* grid, int comp, int32_t shape[3]) {
+    GridView v;
+    PHIHIP_TRY(make_view(grid, &v));
+    PHIHIP_REQUIRE(comp >= 0 && comp < v.rank, "component %d out of range", comp);
+    PHIHIP_REQUIRE(shape != nullptr, "shape is NULL");
+    shape[0] = shape[1] = shape[2] = 1;
+    for (int d = 0; d < v.rank; ++d) shape[d] = v.cn[comp + v.ax0][d + v.ax0];
+    return PHIHIP_OK;
+}
+
+#define PHIHIP_ENTER(ctx, grid)                        \
+    PHIHIP_REQUIRE((ctx) != nullptr, "ctx is NULL");   \
+    GridView v;                                        \
+    PHIHIP_TRY(make_view((grid), &v));                 \
+    PHIHIP_CHECK_HIP(hipSetDevice((ctx)->device));     \
+    hipStream_t s = (hipStream_t)stream;
+
+int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3], const void* const velocity[3],
+                            void* const out[3], double dt, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, field, "field"));
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)out, "out"));
+    for (int d = 0; d < v.rank; ++d)
+        PHIHIP_REQUIRE(out[d] != field[d] && out[d] != velocity[d], "advect: out[%d] must not alias an input", d);
+    const void *f[3], *u[3];
+    void* o[3];
+    remap3(v, field, f);
+    remap3(v, velocity, u);
+    remap3w(v, out, o);
+    return run_advect_staggered(ctx, v, f, u, o, dt, s);
+}
+
+int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                           const double s_val[3][2], const void* const velocity[3], void* out, double dt, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && out && s_bc, "advect_centered: NULL argument");
+    PHIHIP_REQUIRE(sfield != out, "advect_centered: out must not alias the input");
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    for (int d = 0; d < v.rank; ++d)
+        PHIHIP_REQUIRE((s_bc[d][0] == PHIHIP_BC_PERIODIC) == (s_bc[d][1] == PHIHIP_BC_PERIODIC) &&
+                           (s_bc[d][0] == PHIHIP_BC_PERIODIC) == (v.bc[d + v.ax0][0] == PHIHIP_BC_PERIODIC),
+                       "advect_centered: periodicity of the scalar must match the grid along axis %d", d);
+    const void* u[3];
+    remap3(v, velocity, u);
+    return run_advect_centered(ctx, v, sfield, s_bc, s_val, u, out, dt, s);
+}
+
+int phihip_build_cellflags(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* accessible, const uint8_t* active, int mask_batch,
+                           uint8_t* flags, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(flags != nullptr, "flags is NULL");
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    return run_build_cellflags(ctx, v, accessible, active, mask_batch, flags, s);
+}
+
+int phihip_divergence(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], const uint8_t* flags, int mask_batch,
+                      int balance, void* div, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_REQUIRE(div != nullptr, "div is NULL");
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    const void* u[3];
+    remap3(v, velocity, u);
+    return run_divergence(ctx, v, u, flags, mask_batch, balance, div, s);
+}
+
+int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p, void* out,
+                         void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(p && out && p != out, "laplace_apply: p / out NULL or aliased");
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    return run_laplace_apply(ctx, v, flags, mask_batch, p, out, s);
+}
+
+static int check_solve(const phihip_solve* solve) {
+    PHIHIP_REQUIRE(solve != nullptr, "solve is NULL");
+    PHIHIP_REQUIRE(solve->max_iterations >= 0, "solve.max_iterations must be >= 0");
+    PHIHIP_REQUIRE(solve->rel_tol >= 0 && solve->abs_tol >= 0, "solve tolerances must be >= 0");
+    PHIHIP_REQUIRE(solve->refresh_every >= 0 && solve->check_every >= 0, "solve.refresh_every / check_every must be >= 0");
+    return PHIHIP_OK;
+}
+
+int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+                    const phihip_solve* solve, phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(rhs && x && rhs != x, "cg_solve: rhs / x NULL or aliased");
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    PHIHIP_TRY(check_solve(solve));
+    return run_cg(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+}
+
+int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,
+                         void* const velocity[3], void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(p != nullptr, "p is NULL");
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)velocity, "velocity"));
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    void* u[3];
+    remap3w(v, velocity, u);
+    return run_grad_subtract(ctx, v, flags, mask_batch, p, u, s);
+}
+
+int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* const velocity[3], const void* const soft_mask[3],
+                               const uint8_t* flags, int mask_batch, int balance, void* pressure, void* div_out,
+                               const phihip_solve* solve, phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)velocity, "velocity"));
+    PHIHIP_REQUIRE(pressure != nullptr, "pressure is NULL");
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    PHIHIP_TRY(check_solve(solve));
+    void* u[3];
+    remap3w(v, velocity, u);
+    if (soft_mask) {
+        PHIHIP_TRY(check_ptrs(v, soft_mask, "soft_mask"));
+        const void* m[3];
+        remap3(v, soft_mask, m);
+        PHIHIP_TRY(run_scale_faces(ctx, v, u, m, s));
+    }
+    void* div = div_out;
+    if (!div) {
+        const size_t bytes = (size_t)v.batch * v.cells * (v.dtype == PHIHIP_F64 ? 8 : 4);
+        PHIHIP_TRY(ensure_buffer(ctx->ws_rhs, bytes));
+        div = ctx->ws_rhs.ptr;
+    }
+    const void* cu[3] = {u[0], u[1], u[2]};
+    PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, balance, div, s));
+    PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, div, pressure, solve, info, s));
+    PHIHIP_TRY(run_grad_subtract(ctx, v, flags, mask_batch, pressure, u, s));
+    return PHIHIP_OK;
+}
+
+int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3],
+                            double diffusivity_dt, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)out, "out"));
+    for (int d = 0; d < v.rank; ++d) PHIHIP_REQUIRE(out[d] != velocity[d], "diffuse: out[%d] must not alias the input", d);
+    const void* u[3];
+    void* o[3];
+    remap3(v, velocity, u);
+    remap3w(v, out, o);
+    return run_diffuse(ctx, v, u, o, diffusivity_dt, s);
+}
+
+int phihip_profile_enable(phihip_ctx* ctx, int enable) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->profiling = enable != 0;
+    return PHIHIP_OK;
+}
+
+int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], double total_ms[PHIHIP_K_COUNT], int reset) {
+    PHIHIP_REQUIRE(ctx && launches && total_ms, "profile_read: NULL argument");
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIHIP_TRY(profile_collect(ctx));
+    for (int k = 0; k < PHIHIP_K_COUNT; ++k) {
+        launches[k] = ctx->prof_launches[k];
+        total_ms[k] = ctx->prof_ms[k];
+        if (reset) {
+            ctx->prof_launches[k] = 0;
+            ctx->prof_ms[k] = 0;
+        }
+    }
+    return PHIHIP_OK;
+}
+
+int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
+    ctx->tuning.rows = rows_per_thread;
+    ctx->tuning.tpr = threads_per_row;
+    ctx->tuning.chunk = chunk_planes;
+    return PHIHIP_OK;
+}
+
+}  // extern "C"

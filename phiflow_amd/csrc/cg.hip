@@ -1,0 +1,294 @@
+// cg.hip -- matrix-free conjugate gradients on the masked 5/7-point Laplacian.
+// Replaces math.solve_linear(masked_laplace, div, Solve('CG', ...)) (/root/reference phi/physics/fluid.py:156) whose
+// PhiML implementation assembles a sparse matrix per call and runs {SpMV, 2 dots, 3 AXPY} as separate array passes.
+// Here one iteration = MATVEC (d = r + beta d ; dq = d.Ad) -> scalar -> UPDATE (x += a d ; r -= a Ad ; rsq) -> scalar.
+// Alpha / beta / per-batch continue flags never leave the device; the host only enqueues launches.
+#include "common.hpp"
+#include "march_dispatch.hpp"
+
+namespace phihip {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// planning
+// ---------------------------------------------------------------------------------------------------------------------
+int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchConfig* c, MarchGrid* g) {
+    const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
+    const int vmax = 16 / esize;
+    memset(g, 0, sizeof(*g));
+    g->n0 = v.n[0]; g->n1 = v.n[1]; g->n2 = v.n[2];
+    g->cells = v.cells;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int s = 0; s < 2; ++s) {
+            const int code = v.bc[ax][s];
+            g->nb[ax][s] = code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_CLOSED ? NB_CLAMP : NB_ZERO);
+        }
+    g->flags_per_batch = mask_batch > 1 ? 1 : 0;
+    c->batch = v.batch;
+    c->vec = (v.n[2] % vmax == 0) ? vmax : 1;
+    const Tuning& t = ctx->tuning;
+    const long long target_blocks = 4LL * ctx->num_cu;
+    auto blocks_for = [&](int id, int chunk) -> long long {
+        const int t1 = kBlock / kTileShapes[id].tpr * kTileShapes[id].rows, t2 = kTileShapes[id].tpr * c->vec;
+        return (long long)ceil_div(v.n[1], t1) * ceil_div(v.n[2], t2) * ceil_div(v.n[0], chunk) * v.batch;
+    };
+    int id = -1;
+    if (c->vec == 1) {
+        id = 5;   // (1, 64): the only scalar instantiation
+    } else if (t.rows > 0 && t.tpr > 0) {
+        for (int k = 0; k < kNumTileConfigs; ++k)
+            if (kTileShapes[k].rows == t.rows && kTileShapes[k].tpr == t.tpr) id = k;
+        if (id < 0) {
+            set_error("tuning: no tile config with rows=%d threads_per_row=%d", t.rows, t.tpr);
+            return PHIHIP_ERR_BAD_ARG;
+        }
+    } else {
+        // largest tile (least halo traffic) that still yields enough workgroups with chunks of >= 16 planes
+        const int pref[4] = {3, 2, 1, 0};
+        id = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int cand = pref[k];
+            const int t1 = kBlock / kTileShapes[cand].tpr * kTileShapes[cand].rows, t2 = kTileShapes[cand].tpr * c->vec;
+            if (t1 > 2 * v.n[1] || t2 > 2 * v.n[2]) continue;   // mostly empty tile
+            if (blocks_for(cand, v.rank == 3 ? 16 : 1) >= target_blocks || cand == 0) {
+                id = cand;
+                break;
+            }
+        }
+    }
+    c->id = id;
+    const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
+    c->t1 = kBlock / tpr * rows;
+    c->t2 = tpr * c->vec;
+    int chunk = 1;
+    if (v.rank == 3) {
+        if (t.chunk > 0) {
+            chunk = t.chunk;
+        } else {
+            chunk = 64;
+            while (chunk > 8 && blocks_for(id, chunk) < target_blocks) chunk /= 2;
+        }
+        if (chunk > v.n[0]) chunk = v.n[0];
+    }
+    c->chunk = chunk;
+    g->tiles1 = ceil_div(v.n[1], c->t1);
+    g->tiles2 = ceil_div(v.n[2], c->t2);
+    g->chunks0 = ceil_div(v.n[0], chunk);
+    g->chunk = chunk;
+    g->nblk = g->tiles1 * g->tiles2 * g->chunks0;
+    return PHIHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// single-block scalar kernels: reduce the per-workgroup partial sums in a fixed order (deterministic) and advance the
+// per-batch CG control block. One block per batch entry.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double reduce_partials(const double* part, int n, double* red) {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) s += part[i];
+    return block_sum(s, red);
+}
+
+__global__ __launch_bounds__(kBlock) void cg_scalar_init(CgState* st, const double* part_rr, const double* part_yy, int nblk,
+                                                         double rtol, double atol, int max_iter) {
+    __shared__ double red[kBlock / kWave];
+    const int b = blockIdx.x;
+    const double rsq = reduce_partials(part_rr + (long long)b * nblk, nblk, red);
+    const double ysq = reduce_partials(part_yy + (long long)b * nblk, nblk, red);
+    if (threadIdx.x == 0) {
+        CgState s;
+        s.alpha = 0; s.beta = 0; s.dq = 0;
+        s.rsq = rsq; s.rsq0 = rsq; s.rhs_sq = ysq;
+        const double t1 = rtol * rtol * ysq, t2 = atol * atol;
+        s.tol_sq = t1 > t2 ? t1 : t2;
+        s.iterations = 0;
+        s.diverged = !(rsq == rsq && rsq <= 1.7e308) ? 1 : 0;   // NaN / inf
+        s.converged = rsq <= s.tol_sq ? 1 : 0;
+        s.cont = (!s.converged && !s.diverged && max_iter > 0) ? 1 : 0;
+        st[b] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_scalar_alpha(CgState* st, const double* part_dq, int nblk) {
+    __shared__ double red[kBlock / kWave];
+    const int b = blockIdx.x;
+    if (st[b].cont == 0) return;
+    const double dq = reduce_partials(part_dq + (long long)b * nblk, nblk, red);
+    if (threadIdx.x == 0) {
+        st[b].iterations += 1;
+        st[b].dq = dq;
+        st[b].alpha = dq != 0 ? st[b].rsq / dq : 0;   // divide_no_nan
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_scalar_beta(CgState* st, const double* part_rr, int nblk, int max_iter) {
+    __shared__ double red[kBlock / kWave];
+    const int b = blockIdx.x;
+    if (st[b].cont == 0) return;
+    const double rsq = reduce_partials(part_rr + (long long)b * nblk, nblk, red);
+    if (threadIdx.x == 0) {
+        CgState s = st[b];
+        s.beta = s.rsq != 0 ? rsq / s.rsq : 0;
+        s.rsq = rsq;
+        const bool finite = (rsq == rsq) && rsq <= 1.7e308;
+        s.diverged = (!finite || (s.rsq0 > 0 && rsq / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
+        s.converged = rsq <= s.tol_sq ? 1 : 0;
+        s.cont = (!s.converged && !s.diverged && s.iterations < max_iter) ? 1 : 0;
+        st[b] = s;
+    }
+}
+
+// x += alpha * d for the true-residual refresh iterations (PhiML recomputes r = y - A x every 50th iteration)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const CgState* st, long long cells) {
+    const int b = blockIdx.y;
+    if (st[b].cont == 0) return;
+    const T alpha = (T)st[b].alpha;
+    const long long base = (long long)b * cells;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock)
+        x[base + i] = fma(alpha, d[base + i], x[base + i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// drivers
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int laplace_apply_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* out,
+                           hipStream_t s) {
+    MarchConfig c;
+    MarchGrid g;
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, &c, &g));
+    MarchArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.a = (const T*)p;
+    a.o1 = (T*)out;
+    a.flags = flags;
+    a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY, flags != nullptr, g, a, s));
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_laplace_apply(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* out,
+                      hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? laplace_apply_t<double>(ctx, v, flags, mask_batch, p, out, s)
+                                 : laplace_apply_t<float>(ctx, v, flags, mask_batch, p, out, s);
+}
+
+template <typename T>
+static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+                const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    MarchConfig c;
+    MarchGrid g;
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, &c, &g));
+    const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
+    const size_t part_n = (size_t)v.batch * g.nblk;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * part_n * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)v.batch * sizeof(CgState)));
+    if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
+        if (ctx->host_state) hipHostFree(ctx->host_state);
+        ctx->host_state = nullptr;
+        ctx->host_state_bytes = 0;
+        PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));
+        ctx->host_state_bytes = (size_t)v.batch * sizeof(CgState);
+    }
+    T* r = (T*)ctx->ws_r.ptr;
+    T* d[2] = {(T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr};
+    double* part_rr = (double*)ctx->ws_part.ptr;
+    double* part_dq = part_rr + part_n;
+    double* part_yy = part_dq + part_n;
+    CgState* st = (CgState*)ctx->ws_state.ptr;
+    const bool has_flags = flags != nullptr;
+
+    MarchArgs<T> base;
+    memset(&base, 0, sizeof(base));
+    base.flags = flags;
+    base.st = st;
+    base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+
+    auto resid = [&](bool respect_cont, double* p_yy) -> int {
+        MarchArgs<T> a = base;
+        a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = r;
+        a.part1 = part_rr; a.part2 = p_yy;
+        MarchGrid gg = g;
+        gg.respect_cont = respect_cont ? 1 : 0;
+        LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
+        return launch_march_any<T>(v, c, MODE_RESID, has_flags, gg, a, s);
+    };
+
+    // ---- r0 = y - A x0, d0 = r0 (beta = 0 on a zeroed d buffer) ----
+    PHIHIP_CHECK_HIP(hipMemsetAsync(d[0], 0, vec_bytes, s));
+    PHIHIP_TRY(resid(false, part_yy));
+    {
+        LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+        hipLaunchKernelGGL(cg_scalar_init, dim3(v.batch), dim3(kBlock), 0, s, st, part_rr, part_yy, g.nblk, solve->rel_tol,
+                           solve->abs_tol, solve->max_iterations);
+    }
+    MarchGrid gc = g;
+    gc.respect_cont = 1;
+    const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
+    CgState* hst = (CgState*)ctx->host_state;
+    for (int k = 1; k <= solve->max_iterations; ++k) {
+        T* d_old = d[(k - 1) & 1];
+        T* d_new = d[k & 1];
+        {
+            MarchArgs<T> a = base;
+            a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq;
+            LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_MATVEC, has_flags, gc, a, s));
+        }
+        {
+            LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+            hipLaunchKernelGGL(cg_scalar_alpha, dim3(v.batch), dim3(kBlock), 0, s, st, part_dq, g.nblk);
+        }
+        if (solve->refresh_every > 0 && k % solve->refresh_every == 0) {
+            {
+                LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+                hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new,
+                                   (const CgState*)st, v.cells);
+            }
+            PHIHIP_TRY(resid(true, part_dq /* scratch: sum y^2 is not needed again */));
+        } else {
+            MarchArgs<T> a = base;
+            a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr;
+            LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_UPDATE, has_flags, gc, a, s));
+        }
+        {
+            LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+            hipLaunchKernelGGL(cg_scalar_beta, dim3(v.batch), dim3(kBlock), 0, s, st, part_rr, g.nblk, solve->max_iterations);
+        }
+        if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
+            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+            PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+            bool any = false;
+            for (int b = 0; b < v.batch; ++b) any = any || hst[b].cont;
+            if (!any) break;
+        }
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    if (info) {
+        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+        PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < v.batch; ++b) {
+            info[b].residual_sq = hst[b].rsq;
+            info[b].rhs_sq = hst[b].rhs_sq;
+            info[b].iterations = hst[b].iterations;
+            info[b].converged = hst[b].converged;
+            info[b].diverged = hst[b].diverged;
+            info[b].reserved = 0;
+        }
+    }
+    return PHIHIP_OK;
+}
+
+int run_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+           const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? cg_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, info, s)
+                                 : cg_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+}
+
+}  // namespace phihip

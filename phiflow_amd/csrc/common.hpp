@@ -1,0 +1,137 @@
+// common.hpp -- context, error reporting, launch + profiling helpers of libphihip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/phihip.h"
+#include "stencil_march.hpp"
+
+namespace phihip {
+
+void set_error(const char* fmt, ...);
+
+#define PHIHIP_CHECK_HIP(expr)                                                                   \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            phihip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PHIHIP_ERR_HIP;                                                               \
+        }                                                                                        \
+    } while (0)
+
+#define PHIHIP_REQUIRE(cond, ...)               \
+    do {                                        \
+        if (!(cond)) {                          \
+            phihip::set_error(__VA_ARGS__);     \
+            return PHIHIP_ERR_BAD_ARG;          \
+        }                                       \
+    } while (0)
+
+#define PHIHIP_TRY(expr)             \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != PHIHIP_OK) return _s; \
+    } while (0)
+
+// Internal view of a phihip_grid: always three axes (a0 slow .. a2 fast). Rank-2 grids (x, y) map to (a1, a2), n0 = 1.
+struct GridView {
+    int rank, ax0;             // ax0 = 3 - rank : first used internal axis
+    int dtype, batch;
+    int n[3];                  // cells
+    int bc[3][2];              // velocity boundary codes (unused axis: periodic)
+    double bcv[3][2][3];       // [axis][side][component axis]
+    double lower[3], dx[3];
+    int cn[3][3];              // [component axis][axis] stored faces
+    int off[3];                // physical face number of stored index 0 per component
+    long long cells;           // n0*n1*n2
+    long long ccells[3];       // cells per stored component
+};
+
+int make_view(const phihip_grid* grid, GridView* out);
+
+// by-value kernel parameter describing the staggered layout
+struct VelGrid {
+    int n[3];
+    int cn[3][3];
+    int off[3];
+    int bc[3][2];
+    double bcv[3][2][3];
+    double dx[3];
+    int ax0;
+    long long cells;
+    long long ccells[3];
+};
+
+VelGrid make_velgrid(const GridView& v);
+
+struct Tuning {
+    int rows = 0, tpr = 0, chunk = 0;   // 0 = auto
+};
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace phihip
+
+struct phihip_ctx {
+    int device = 0;
+    int num_cu = 256;
+    phihip::Tuning tuning;
+    // workspace (grown on demand, reused between calls)
+    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs;
+    void* host_state = nullptr;   // pinned readback buffer
+    size_t host_state_bytes = 0;
+    // profiling
+    bool profiling = false;
+    struct EventPair {
+        hipEvent_t a, b;
+        int kid;
+    };
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    int32_t prof_launches[PHIHIP_K_COUNT] = {0};
+    double prof_ms[PHIHIP_K_COUNT] = {0};
+};
+
+namespace phihip {
+
+int ensure_buffer(DeviceBuffer& buf, size_t bytes);
+int profile_begin(phihip_ctx* ctx, int kid, hipStream_t s, int* slot);
+int profile_end(phihip_ctx* ctx, int slot, hipStream_t s);
+int profile_collect(phihip_ctx* ctx);
+
+// RAII-free helper: wraps one launch in an event pair when profiling is on
+struct LaunchScope {
+    phihip_ctx* ctx;
+    hipStream_t s;
+    int slot = -1;
+    LaunchScope(phihip_ctx* c, int kid, hipStream_t st) : ctx(c), s(st) {
+        if (ctx && ctx->profiling) profile_begin(ctx, kid, s, &slot);
+    }
+    ~LaunchScope() {
+        if (slot >= 0) profile_end(ctx, slot, s);
+    }
+};
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- phases implemented in the .hip files ---------------------------------------------------------------------------
+int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
+int run_advect_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
+                        const void* const v[3], void* out, double dt, hipStream_t);
+int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);
+int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const uint8_t* flags, int mask_batch, int balance, void* div, hipStream_t);
+int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);
+int run_grad_subtract(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* const v[3], hipStream_t);
+int run_diffuse(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double kdt, hipStream_t);
+int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
+int run_cg(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, phihip_solve_info*, hipStream_t);
+
+}  // namespace phihip

@@ -1,0 +1,59 @@
+// march_inst.hip -- explicit instantiation + dispatch of march_kernel for one (element type, dimensionality) pair.
+// Compiled four times (-DPHIHIP_INST_F64=0|1 -DPHIHIP_INST_DIM3=0|1) so the ~50 kernels per pair build in parallel.
+#include "common.hpp"
+#include "march_dispatch.hpp"
+
+namespace phihip {
+
+#if PHIHIP_INST_F64
+using InstT = double;
+#else
+using InstT = float;
+#endif
+constexpr bool kInstDim3 = PHIHIP_INST_DIM3 != 0;
+constexpr int kVmax = 16 / sizeof(InstT);
+
+template <int V, int R, int TPR, int MODE, bool FLAGS>
+static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3>), grid, dim3(kBlock), 0, s, g, a);
+}
+
+template <int V, int R, int TPR>
+static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
+#define PHIHIP_MODE_CASE(M)                                                \
+    case M:                                                                \
+        if (flags) launch_one<V, R, TPR, M, true>(g, a, grid, s);          \
+        else launch_one<V, R, TPR, M, false>(g, a, grid, s);               \
+        break;
+    switch (mode) {
+        PHIHIP_MODE_CASE(MODE_APPLY)
+        PHIHIP_MODE_CASE(MODE_RESID)
+        PHIHIP_MODE_CASE(MODE_MATVEC)
+        PHIHIP_MODE_CASE(MODE_UPDATE)
+        default:
+            set_error("march: bad mode %d", mode);
+            return PHIHIP_ERR_BAD_ARG;
+    }
+#undef PHIHIP_MODE_CASE
+    return PHIHIP_OK;
+}
+
+template <>
+int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, const MarchGrid& g,
+                                   const MarchArgs<InstT>& a, hipStream_t s) {
+    dim3 grid(g.nblk, c.batch);
+    if (c.vec == 1) return launch_cfg<1, 1, 64>(mode, flags, g, a, grid, s);
+    switch (c.id) {
+        case 0: return launch_cfg<kVmax, 1, 16>(mode, flags, g, a, grid, s);
+        case 1: return launch_cfg<kVmax, 2, 16>(mode, flags, g, a, grid, s);
+        case 2: return launch_cfg<kVmax, 2, 32>(mode, flags, g, a, grid, s);
+        case 3: return launch_cfg<kVmax, 4, 32>(mode, flags, g, a, grid, s);
+        case 4: return launch_cfg<kVmax, 4, 64>(mode, flags, g, a, grid, s);
+        case 5: return launch_cfg<kVmax, 1, 64>(mode, flags, g, a, grid, s);
+        default:
+            set_error("march: bad tile config %d", c.id);
+            return PHIHIP_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace phihip

@@ -1,0 +1,360 @@
+// stencil_march.hpp -- the 5/7-point pressure operator (fluid.masked_laplace, /root/reference phi/physics/fluid.py:165-202)
+// as a matrix-free plane-marching kernel for gfx950, shared by every phase of the CG loop.
+//
+// One 256-thread workgroup owns a (T1 x T2) tile of the two fast axes and marches over a chunk of planes of the slow
+// axis a0. Per plane each thread owns R consecutive rows x one 16-byte vector of the fast axis:
+//   * a0 neighbours live in registers (previous / current / next plane are rotated, every plane is read from HBM once),
+//   * a1 / a2 neighbours of the current plane come from an LDS copy of the tile (+ a one-cell halo ring that designated
+//     threads fetch with the boundary rule applied: wrap / clamp / zero), double buffered => one barrier per plane,
+//   * loads of plane i+1 are issued before the LDS phase of plane i (software prefetch distance: one plane).
+// The "source" S whose Laplacian is taken and the epilogue differ per MODE:
+//   APPLY   S = p                  out = A S
+//   RESID   S = x                  r = y - A S                     sum r^2, sum y^2
+//   MATVEC  S = r + beta * d_old   d_new = S                       sum S * (A S)        (q = A d is never stored)
+//   UPDATE  S = d                  x += alpha S ; r -= alpha A S   sum r_new^2          (q recomputed from d)
+// so one CG iteration moves 3 + 5 = 8 words per cell through HBM instead of the textbook 10-11.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace phihip {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2 };
+enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3 };
+
+// per batch entry CG control block (device memory); written only by the single-block scalar kernels
+struct CgState {
+    double alpha, beta;
+    double rsq, rsq0, rhs_sq, tol_sq, dq;
+    int32_t cont, iterations, converged, diverged;
+};
+
+struct MarchGrid {
+    int n0, n1, n2;        // cells per internal axis (n0 == 1 for 2-D grids)
+    int nb[3][2];          // NeighbourRule per internal axis / side for the pressure
+    long long cells;       // n0 * n1 * n2
+    int tiles1, tiles2, chunks0, chunk, nblk;
+    int flags_per_batch;   // 1: flags array has a batch dimension, 0: shared by all batch entries
+    int respect_cont;      // skip batch entries whose CgState.cont == 0
+};
+
+template <typename T>
+struct MarchArgs {
+    const T* a;            // APPLY p | RESID x | MATVEC r     | UPDATE d
+    const T* b;            //         | RESID y | MATVEC d_old |
+    T* o1;                 // APPLY out | RESID r | MATVEC d_new | UPDATE x (in/out)
+    T* o2;                 //                                     | UPDATE r (in/out)
+    const uint8_t* flags;  // per-cell stencil flags or nullptr
+    const CgState* st;     // [batch]
+    double* part1;         // [batch][nblk]
+    double* part2;         // [batch][nblk]
+    T w0, w1, w2;          // 1 / dx^2 per internal axis
+};
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Vec {
+    T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> vec_zero() {
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = T(0);
+    return r;
+}
+
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> vec_load(const T* p) {
+    return *reinterpret_cast<const Vec<T, V>*>(p);
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void vec_store(T* p, const Vec<T, V>& x) {
+    *reinterpret_cast<Vec<T, V>*>(p) = x;
+}
+
+// index of the neighbour one step outside [0, n): wrap / clamp / zero ghost
+__device__ __forceinline__ int nb_index(int i, int n, int rule_lo, int rule_hi, bool& zero) {
+    if (i < 0) {
+        if (rule_lo == NB_WRAP) return i + n;
+        if (rule_lo == NB_ZERO) zero = true;
+        return 0;
+    }
+    if (i >= n) {
+        if (rule_hi == NB_WRAP) return i - n;
+        if (rule_hi == NB_ZERO) zero = true;
+        return n - 1;
+    }
+    return i;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// sum over the 256 threads of a block; result valid in thread 0. `red` = kBlock / kWave doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) s += red[w];
+    }
+    return s;
+}
+
+template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3>
+__global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T> p) {
+    constexpr int TR = kBlock / TPR;   // thread rows
+    constexpr int T1 = TR * R;         // tile rows (axis a1)
+    constexpr int T2 = TPR * V;        // tile columns (axis a2)
+    constexpr int LS = T2 + 2 * V;     // LDS row stride; interior starts at column V so vector accesses stay aligned
+    constexpr int LROWS = T1 + 2;
+    static_assert(2 * TPR + 2 * T1 <= kBlock, "halo items must fit one per thread");
+    using VT = Vec<T, V>;
+    using VF = Vec<uint8_t, V>;
+
+    __shared__ __attribute__((aligned(16))) T lds[2][LROWS * LS];
+    __shared__ double red[kBlock / kWave];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    if (g.respect_cont && p.st[b].cont == 0) return;
+
+    // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
+    int bid = blockIdx.x;
+    if ((g.nblk & 7) == 0) bid = (bid & 7) * (g.nblk >> 3) + (bid >> 3);
+    const int t2 = bid % g.tiles2;
+    const int t1 = (bid / g.tiles2) % g.tiles1;
+    const int c0 = bid / (g.tiles2 * g.tiles1);
+
+    const int tx = tid % TPR, ty = tid / TPR;
+    const int j2 = t2 * T2 + tx * V;
+    const int j1b = t1 * T1 + ty * R;
+    const int i_begin = c0 * g.chunk;
+    const int i_end = min(i_begin + g.chunk, g.n0);
+    const long long base = (long long)b * g.cells;
+    const long long fbase = g.flags_per_batch ? base : 0;
+    const int n1 = g.n1, n2 = g.n2;
+
+    T alpha = T(0), beta = T(0);
+    if (MODE == MODE_UPDATE) alpha = (T)p.st[b].alpha;
+    if (MODE == MODE_MATVEC) beta = (T)p.st[b].beta;
+
+    bool ok[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) ok[rr] = (j2 < n2) && (j1b + rr < n1);
+
+    // ---- source loaders ---------------------------------------------------------------------------------------------
+    auto src_vec = [&](long long off) -> VT {
+        VT s = vec_load<T, V>(p.a + base + off);
+        if (MODE == MODE_MATVEC) {
+            VT d = vec_load<T, V>(p.b + base + off);
+#pragma unroll
+            for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
+        }
+        return s;
+    };
+    auto src_one = [&](long long off) -> T {
+        T s = p.a[base + off];
+        if (MODE == MODE_MATVEC) s = fma(beta, p.b[base + off], s);
+        return s;
+    };
+    auto load_plane = [&](int i, VT (&S)[R]) {
+        bool zero = false;
+        const int ii = DIM3 ? nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero) : 0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (ok[rr] && !zero)
+                S[rr] = src_vec(((long long)ii * n1 + (j1b + rr)) * n2 + j2);
+            else
+                S[rr] = vec_zero<T, V>();
+        }
+    };
+
+    // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
+    // vector items: rows just below / above the tile; scalar items: columns just left / right of the tile
+    const bool hv_role = tid < 2 * TPR;
+    const int hv_side = tid / TPR, hv_col = tid % TPR;
+    const int hs_idx = tid - 2 * TPR;
+    const bool hs_role = hs_idx >= 0 && hs_idx < 2 * T1;
+    const int hs_side = hs_idx / T1, hs_row = hs_idx % T1;
+    const int rows_here = min(T1, n1 - t1 * T1);   // valid rows of this tile
+    const int cols_here = min(T2, n2 - t2 * T2);   // valid columns of this tile
+    bool hv_ok = false, hv_zero = false, hs_ok = false, hs_zero = false;
+    int hv_lrow = 0, hs_lcol = 0;
+    long long hv_off = 0, hs_off = 0;   // offsets within a plane
+    if (hv_role) {
+        const int jh2 = t2 * T2 + hv_col * V;
+        const int jh1 = hv_side == 0 ? t1 * T1 - 1 : t1 * T1 + rows_here;
+        hv_lrow = hv_side == 0 ? 0 : rows_here + 1;
+        const int jt1 = nb_index(jh1, n1, g.nb[1][0], g.nb[1][1], hv_zero);
+        hv_ok = jh2 < n2;
+        hv_off = (long long)jt1 * n2 + jh2;
+    }
+    if (hs_role) {
+        const int jh1 = t1 * T1 + hs_row;
+        const int jh2 = hs_side == 0 ? t2 * T2 - 1 : t2 * T2 + cols_here;
+        hs_lcol = hs_side == 0 ? V - 1 : V + cols_here;
+        const int jt2 = nb_index(jh2, n2, g.nb[2][0], g.nb[2][1], hs_zero);
+        hs_ok = jh1 < n1;
+        hs_off = (long long)jh1 * n2 + jt2;
+    }
+    auto load_halo = [&](int i, VT& hv, T& hs) {
+        const long long poff = (long long)i * n1 * n2;
+        hv = vec_zero<T, V>();
+        hs = T(0);
+        if (hv_ok && !hv_zero) hv = src_vec(poff + hv_off);
+        if (hs_ok && !hs_zero) hs = src_one(poff + hs_off);
+    };
+
+    // ---- per-plane extra operands (own cells only) --------------------------------------------------------------------
+    struct Extra {
+        VT e1[R];   // RESID: y      UPDATE: x
+        VT e2[R];   //               UPDATE: r
+        VF fl[R];   // stencil flags
+    };
+    auto load_extra = [&](int i, Extra& E) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (!ok[rr]) continue;
+            const long long off = ((long long)i * n1 + (j1b + rr)) * n2 + j2;
+            if (MODE == MODE_RESID) E.e1[rr] = vec_load<T, V>(p.b + base + off);
+            if (MODE == MODE_UPDATE) {
+                E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
+                E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
+            }
+            if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + fbase + off);
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------
+    VT Sp[R], Sc[R], Sn[R];
+    VT hv_c, hv_n;
+    T hs_c, hs_n;
+    Extra Ec, En;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        Sp[rr] = vec_zero<T, V>();
+        Sn[rr] = vec_zero<T, V>();
+    }
+    if (DIM3) load_plane(i_begin - 1, Sp);
+    load_plane(i_begin, Sc);
+    load_halo(i_begin, hv_c, hs_c);
+    load_extra(i_begin, Ec);
+    hv_n = hv_c; hs_n = hs_c; En = Ec;
+
+    T acc1 = T(0), acc2 = T(0);
+    int buf = 0;
+    const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
+    const int lcol = V + tx * V;             // LDS column of this thread's vector
+
+    for (int i = i_begin; i < i_end; ++i) {
+        if (DIM3) load_plane(i + 1, Sn);
+        if (i + 1 < i_end) {
+            load_halo(i + 1, hv_n, hs_n);
+            load_extra(i + 1, En);
+        }
+        T* L = lds[buf];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+            if (ok[rr]) vec_store<T, V>(L + (lrow0 + rr) * LS + lcol, Sc[rr]);
+        if (hv_ok) vec_store<T, V>(L + hv_lrow * LS + V + hv_col * V, hv_c);
+        if (hs_ok) L[(hs_row + 1) * LS + hs_lcol] = hs_c;
+        __syncthreads();
+
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (!ok[rr]) continue;
+            const int lr = lrow0 + rr;
+            VT up, dn;
+            if (rr > 0) up = Sc[rr - 1]; else up = vec_load<T, V>(L + (lr - 1) * LS + lcol);
+            bool dn_reg = false;
+            if (rr < R - 1) dn_reg = (j1b + rr + 1 < n1);
+            if (dn_reg) dn = Sc[rr < R - 1 ? rr + 1 : rr]; else dn = vec_load<T, V>(L + (lr + 1) * LS + lcol);
+            const T lf = L[lr * LS + lcol - 1];
+            const T rt = L[lr * LS + lcol + V];
+            VT q;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const T c = Sc[rr].v[v];
+                const T lo2 = v > 0 ? Sc[rr].v[v > 0 ? v - 1 : 0] : lf;
+                const T hi2 = v < V - 1 ? Sc[rr].v[v < V - 1 ? v + 1 : v] : rt;
+                T r;
+                if (FLAGS) {
+                    const unsigned f = Ec.fl[rr].v[v];
+                    r = T(0);
+                    if (DIM3) {
+                        if (f & 1u) r += (Sp[rr].v[v] - c) * p.w0;
+                        if (f & 2u) r += (Sn[rr].v[v] - c) * p.w0;
+                    }
+                    if (f & 4u) r += (up.v[v] - c) * p.w1;
+                    if (f & 8u) r += (dn.v[v] - c) * p.w1;
+                    if (f & 16u) r += (lo2 - c) * p.w2;
+                    if (f & 32u) r += (hi2 - c) * p.w2;
+                    if (!(f & 64u)) r = c;   // inactive cell: identity row (fluid.py:202)
+                } else {
+                    r = (lo2 + hi2 - T(2) * c) * p.w2 + (up.v[v] + dn.v[v] - T(2) * c) * p.w1;
+                    if (DIM3) r += (Sp[rr].v[v] + Sn[rr].v[v] - T(2) * c) * p.w0;
+                }
+                q.v[v] = r;
+            }
+            const long long off = base + ((long long)i * n1 + (j1b + rr)) * n2 + j2;
+            if (MODE == MODE_APPLY) {
+                vec_store<T, V>(p.o1 + off, q);
+            } else if (MODE == MODE_RESID) {
+                VT r;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const T y = Ec.e1[rr].v[v];
+                    r.v[v] = y - q.v[v];
+                    acc1 += r.v[v] * r.v[v];
+                    acc2 += y * y;
+                }
+                vec_store<T, V>(p.o1 + off, r);
+            } else if (MODE == MODE_MATVEC) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) acc1 += Sc[rr].v[v] * q.v[v];
+                vec_store<T, V>(p.o1 + off, Sc[rr]);
+            } else {
+                VT xn, rn;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
+                    rn.v[v] = Ec.e2[rr].v[v] - alpha * q.v[v];
+                    acc1 += rn.v[v] * rn.v[v];
+                }
+                vec_store<T, V>(p.o1 + off, xn);
+                vec_store<T, V>(p.o2 + off, rn);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            Sp[rr] = Sc[rr];
+            Sc[rr] = Sn[rr];
+        }
+        hv_c = hv_n; hs_c = hs_n; Ec = En;
+        buf ^= 1;
+    }
+
+    if (MODE != MODE_APPLY) {
+        const double s1 = block_sum((double)acc1, red);
+        if (tid == 0) p.part1[(long long)b * g.nblk + blockIdx.x] = s1;
+        if (MODE == MODE_RESID) {
+            const double s2 = block_sum((double)acc2, red);
+            if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
+        }
+    }
+}
+
+}  // namespace phihip

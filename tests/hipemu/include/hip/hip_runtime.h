@@ -1,0 +1,105 @@
+// TEST INFRASTRUCTURE ONLY -- a minimal single-threaded emulation of the HIP execution model (fibers per thread of a
+// workgroup, __syncthreads / wave shuffles as fiber barriers) so that the indexing / halo / boundary logic of the
+// kernels in phiflow_amd/csrc can be exercised in a container without a GPU. It is never shipped, never loaded by the
+// package `phiflow_amd` (which loads phiflow_amd/lib/libphihip.so only and fails loudly without a HIP device), and it
+// says nothing about performance. Build: tests/hipemu/build_emu.sh -> tests/hipemu/libphihip_emu.so
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+
+using std::max;
+using std::min;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef void* hipStream_t;
+typedef struct hipemu_event* hipEvent_t;
+enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+#define hipHostMallocDefault 0
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+    char name[64];
+};
+
+namespace hipemu {
+struct Fiber;
+extern Fiber* g_cur;
+extern dim3 g_block_idx, g_block_dim, g_grid_dim;
+dim3& cur_thread_idx();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+void sync_wave();
+void* wave_slot(int lane);   // 16-byte exchange slot of `lane` in the calling fiber's wave
+int cur_lane();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur_thread_idx())
+#define blockIdx (hipemu::g_block_idx)
+#define blockDim (hipemu::g_block_dim)
+#define gridDim (hipemu::g_grid_dim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::sync_block(); }
+
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    static_assert(sizeof(T) <= 16, "shuffle payload too large");
+    const int lane = hipemu::cur_lane();
+    memcpy(hipemu::wave_slot(lane), &v, sizeof(T));
+    hipemu::sync_wave();
+    T r = v;
+    const int src = lane + (int)delta;
+    if (src / width == lane / width && src < 64) memcpy(&r, hipemu::wave_slot(src), sizeof(T));
+    hipemu::sync_wave();
+    return r;
+}
+
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    const int lane = hipemu::cur_lane();
+    memcpy(hipemu::wave_slot(lane), &v, sizeof(T));
+    hipemu::sync_wave();
+    T r = v;
+    const int src = lane ^ mask;
+    if (src / width == lane / width && src < 64) memcpy(&r, hipemu::wave_slot(src), sizeof(T));
+    hipemu::sync_wave();
+    return r;
+}
+
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int d);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
