@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""
+bench.py -- cell-updates/sec of PhiFlow's incompressible-fluid step on MI355X (BASELINE.json metric).
+
+One "step" = semi-Lagrangian self-advection of the staggered velocity + pressure projection with EXACTLY `--cg-iters`
+(100) CG iterations (tolerances 0, true-residual refresh every 50 like PhiML) + gradient subtraction, fp32, on the 3-D
+periodic Taylor-Green configuration 256^3 (BASELINE.json configs[1]). Inputs are resident in HBM before the timed region.
+N > 1: batch-parallel replicas, one simulation per GPU (weak scaling), one RCCL all-reduce per step of the relative
+residual norm. Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from phiflow_amd import _capi as C   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_CELL = {           # algorithmic words per cell (fp32 word = 4 B)
+    "cg_matvec_dot": 4 * 4,      # pass A: read r, d; write d, q
+    "cg_update": 6 * 4,          # pass B: read x, d, r, q; write x, r
+    "cg_iteration": 10 * 4,
+    "step_non_cg": 21 * 4,
+}
+
+
+def taylor_green_velocity(n, device, dtype, batch):
+    """ 2-D Taylor-Green vortex of the reference (Taylor_Green.ipynb cell 7: u = cos x sin y, v = -sin x cos y) sampled at
+    the staggered face centres and extruded along z, w = 0; domain [0, 2 pi]^3, periodic. """
+    h = 2 * math.pi / n
+    idx = torch.arange(n, device=device, dtype=torch.float64)
+    face, cent = idx * h, (idx + 0.5) * h
+    u = (torch.cos(face)[:, None] * torch.sin(cent)[None, :])[:, :, None].expand(n, n, n)
+    v = (-torch.sin(cent)[:, None] * torch.cos(face)[None, :])[:, :, None].expand(n, n, n)
+    w = torch.zeros(n, n, n, device=device, dtype=torch.float64)
+    return [t.to(dtype).unsqueeze(0).repeat(batch, 1, 1, 1).contiguous() for t in (u, v, w)]
+
+
+class FluidStep:
+    """ the benchmarked step, driven through the C ABI with preallocated device buffers """
+
+    def __init__(self, ctx, n, batch, cg_iters, device, dtype=torch.float32, refresh=50):
+        self.ctx, self.n, self.batch = ctx, n, batch
+        self.device = device
+        code = C.PHIHIP_F64 if dtype == torch.float64 else C.PHIHIP_F32
+        L = 2 * math.pi
+        per = ((C.BC_PERIODIC, C.BC_PERIODIC),) * 3
+        self.grid = C.make_grid(3, code, batch, (n, n, n), (0, 0, 0), (L, L, L), per)
+        self.v = taylor_green_velocity(n, device, dtype, batch)
+        self.v2 = [torch.empty_like(t) for t in self.v]
+        self.p = torch.zeros(batch, n, n, n, device=device, dtype=dtype)
+        self.div = torch.empty_like(self.p)
+        self.res = torch.zeros(batch, 2, device=device, dtype=torch.float64)
+        self.solve = C.Solve(0.0, 0.0, cg_iters, refresh, 0, 0)
+        self.dt = 0.5 * L / n                         # CFL ~ 0.5
+        self.stream = int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0
+
+    def step(self, allreduce=None):
+        ctx, s = self.ctx, self.stream
+        pv, pv2 = [t.data_ptr() for t in self.v], [t.data_ptr() for t in self.v2]
+        ctx.advect_staggered(self.grid, pv, pv, pv2, self.dt, s)
+        ctx.make_incompressible(self.grid, pv2, None, 0, 1, True, self.p.data_ptr(), self.div.data_ptr(), self.solve,
+                                want_info=False, stream=s)
+        ctx.solve_residuals(self.batch, self.res.data_ptr(), s)
+        self.v, self.v2 = self.v2, self.v
+        if allreduce is not None:
+            rel = torch.sqrt(self.res[:, 0] / torch.clamp(self.res[:, 1], min=1e-300)).max().reshape(1)
+            allreduce(rel)
+            return rel
+        return None
+
+
+def cpu_baseline(n, cg_iters):
+    """ the NumPy oracle (restatement of the reference's CPU path) timed on the same step at a bounded size """
+    from oracle import phi_oracle as O
+    L = 2 * math.pi
+    dom = O.Domain((n, n, n), (0, 0, 0), (L, L, L), ((O.PERIODIC, O.PERIODIC),) * 3)
+    h = L / n
+    idx = np.arange(n)
+    face, cent = idx * h, (idx + 0.5) * h
+    u = np.broadcast_to((np.cos(face)[:, None] * np.sin(cent)[None, :])[:, :, None], (n, n, n))
+    v = np.broadcast_to((-np.sin(cent)[:, None] * np.cos(face)[None, :])[:, :, None], (n, n, n))
+    vel = [np.ascontiguousarray(a, dtype=np.float32)[None] for a in (u, v, np.zeros((n, n, n)))]
+    t0 = time.perf_counter()
+    vel = O.semi_lagrangian_staggered(vel, vel, 0.5 * h, dom)
+    O.make_incompressible(vel, dom, rtol=0.0, atol=0.0, max_iter=cg_iters, refresh=50)
+    dt = time.perf_counter() - t0
+    return {"value": n ** 3 / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"1 step of the same workload at {n}^3 fp32 ({cg_iters} CG iterations) with the NumPy oracle "
+                      f"(oracle/phi_oracle.py, single-threaded NumPy), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256, help="cells per axis (BASELINE: 256)")
+    ap.add_argument("--cg-iters", type=int, default=100)
+    ap.add_argument("--cpu-size", type=int, default=96, help="grid size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
+    ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    lib = C.load_default_library()
+    ctx = C.Context(lib, local_rank)
+    if args.tuning:
+        ctx.set_tuning(*[int(x) for x in args.tuning.split(",")])
+    n, B = args.size, 1
+    sim = FluidStep(ctx, n, B, args.cg_iters, device)
+
+    def allreduce(t):
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        sim.step(allreduce)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rel = sim.step(allreduce)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    cells = n ** 3 * B
+    value = cells * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: hipEvent pairs around every launch on the solve stream, extra profiled steps ----
+    roofline = None
+    extra = {}
+    if rank == 0 and args.profile_steps > 0:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        for _ in range(args.profile_steps):
+            sim.step(None)
+        torch.cuda.synchronize(device)
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        per = {k: (v[1] / v[0] if v[0] else None, v[0]) for k, v in prof.items()}
+        t_upd, t_mv = per["cg_update"][0], per["cg_matvec_dot"][0]
+        if t_upd:
+            achieved = ALG_BYTES_PER_CELL["cg_update"] * cells / (t_upd * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "march_kernel<MODE_UPDATE> (cg_update)", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": _pmc_traffic(n), "avg_launch_ms": round(t_upd, 5), "launches": per["cg_update"][1],
+                        "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL["cg_update"] * cells}
+        if t_upd and t_mv:
+            it = ALG_BYTES_PER_CELL["cg_iteration"] * cells / ((t_upd + t_mv) * 1e-3) / 1e9
+            extra["roofline_cg_iteration"] = {"achieved": round(it, 1), "unit": "GB/s", "frac": round(it / HBM_PEAK_GBS, 4),
+                                              "ms_matvec_dot": round(t_mv, 5), "ms_update": round(t_upd, 5),
+                                              "algorithmic_bytes": ALG_BYTES_PER_CELL["cg_iteration"] * cells}
+        extra["kernel_ms_per_launch"] = {k: (round(v[0], 5) if v[0] else None) for k, v in per.items()}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_size > 0:
+        cpu = cpu_baseline(args.cpu_size, args.cg_iters)
+
+    if rank == 0:
+        out = {
+            "metric": "cell-updates/sec (advect+100 CG iters), 256^3 fp32", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D periodic Taylor-Green {n}^3 fp32, semi-Lagrangian advect + projection with {args.cg_iters} CG "
+                                   f"iterations/step (BASELINE.json configs[1])", "cells_per_gpu": cells, "batch_per_gpu": B,
+                       "cg_iterations": args.cg_iters, "parallelism": f"batch-parallel replicas x{world}, 1 all-reduce(max residual)/step"},
+            "final_relative_residual": float(rel.item()) if rel is not None else None,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(n):
+    """ HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
+    tools/pmc_summary.py from separate --pmc runs; corrected as MI355X_MICROARCH.md prescribes). None if not collected. """
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        return data.get(f"cg_update_{n}", None)
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

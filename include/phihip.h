@@ -125,6 +125,11 @@ int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t
 int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* rhs,
                     void* x, const phihip_solve* solve, phihip_solve_info* info, void* stream);
 
+/* Device-side result of the most recent solve on this context: out[2*b] = ||r||^2, out[2*b+1] = ||rhs||^2 per batch entry,
+ * written asynchronously on `stream` into DEVICE memory (no host sync) -- the operand of the one all-reduce per step that a
+ * batch-sharded multi-GPU run performs. */
+int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void* stream);
+
 /* ---- a6: v -= hard_bcs * spatial_gradient(p, at=face) (phi/physics/fluid.py:158-161) ---------------------------- */
 /* in-place on velocity */
 int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,

@@ -1,0 +1,76 @@
+"""
+Advection schemes backed by libphihip (reference: phi/physics/advect.py).
+Implemented on the HIP backend: `semi_lagrangian` / `advect` with the `euler` integrator for StaggeredGrid and
+CenteredGrid fields advected by a StaggeredGrid velocity. Anything else raises `NotImplementedError`.
+"""
+from typing import Callable
+
+import torch
+
+from .extrapolation import ConstantExtrapolation, resolve
+from .field import Field, _ptrs
+
+
+def euler(data: Field, velocity: Field, dt: float, v0=None):
+    """ Euler integrator marker (phi/physics/advect.py:20-24). The back-trace itself is fused into the HIP kernel, so this
+    function only identifies the integrator when passed to `semi_lagrangian`. """
+    raise NotImplementedError("euler() is fused into the HIP semi-Lagrangian kernel; pass it as `integrator=euler`")
+
+
+def rk4(data, velocity, dt, v0=None):
+    raise NotImplementedError("rk4 back-tracing is not implemented on the HIP backend")
+
+
+def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callable = euler) -> Field:
+    """ Semi-Lagrangian advection with backward Euler lookup (phi/physics/advect.py:156-179).
+
+    Args:
+        field: quantity to be advected (`StaggeredGrid` or `CenteredGrid`)
+        velocity: `StaggeredGrid` on the same grid
+        dt: time increment
+        integrator: only `euler` is available on the HIP backend
+
+    Returns:
+        Field with the same sample points and boundary as `field`
+    """
+    if integrator is not euler:
+        raise NotImplementedError("HIP backend: semi_lagrangian supports integrator=euler only")
+    if not velocity.is_staggered:
+        raise NotImplementedError("HIP backend: the advecting velocity must be a StaggeredGrid")
+    assert field.resolution == velocity.resolution and field.bounds.lower == velocity.bounds.lower and \
+        field.bounds.upper == velocity.bounds.upper, "field and velocity must live on the same grid"
+    be = velocity.backend
+    assert field.dtype == velocity.dtype, "field and velocity must have the same precision"
+    B = max(field.batch_size, velocity.batch_size)
+    vel = [_expand(t, B) for t in velocity.values]
+    if field.is_staggered:
+        same_layout = [tuple(a.shape[1:]) for a in field.values] == [tuple(b.shape[1:]) for b in velocity.values]
+        if not same_layout or resolve(field.boundary, field.dims) != resolve(velocity.boundary, velocity.dims):
+            raise NotImplementedError("HIP backend: an advected StaggeredGrid must share the velocity's boundary conditions")
+        src = vel if field is velocity else [_expand(t, B) for t in field.values]
+        out = [torch.empty_like(t) for t in src]
+        be.ctx.advect_staggered(velocity.grid_struct(batch=B), _ptrs(src), _ptrs(vel), _ptrs(out), dt, be.stream())
+        return Field(field.resolution, field.bounds, field.boundary, out, True, be, field.batched or velocity.batched)
+    src = _expand(field.values, B)
+    out = torch.empty_like(src)
+    s_codes, s_vals = resolve(field.boundary, field.dims)
+    s_val = [[s_vals[a][s][0] if isinstance(field.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
+             for a, d in enumerate(field.dims)]
+    be.ctx.advect_centered(velocity.grid_struct(batch=B), src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, be.stream())
+    return Field(field.resolution, field.bounds, field.boundary, out, False, be, field.batched or velocity.batched)
+
+
+def advect(field: Field, velocity: Field, dt: float, integrator: Callable = euler) -> Field:
+    """ `advect.advect` for grids == `semi_lagrangian` (phi/physics/advect.py:50-75) """
+    return semi_lagrangian(field, velocity, dt, integrator=integrator)
+
+
+def mac_cormack(field: Field, velocity: Field, dt: float, correction_strength=1.0, integrator: Callable = euler) -> Field:
+    raise NotImplementedError("mac_cormack is a next-row item (SURVEY §8 f2) and not yet available on the HIP backend")
+
+
+def _expand(t: torch.Tensor, B: int) -> torch.Tensor:
+    if t.shape[0] == B:
+        return t.contiguous()
+    assert t.shape[0] == 1
+    return t.expand(B, *t.shape[1:]).contiguous()

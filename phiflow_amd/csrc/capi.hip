@@ -106,12 +106,12 @@ int profile_begin(phihip_ctx* ctx, int kid, hipStream_t s, int* slot) {
     }
     *slot = (int)ctx->ev_used++;
     ctx->ev_pool[*slot].kid = kid;
-    hipEventRecord(ctx->ev_pool[*slot].a, s);
+    (void)hipEventRecord(ctx->ev_pool[*slot].a, s);
     return PHIHIP_OK;
 }
 
 int profile_end(phihip_ctx* ctx, int slot, hipStream_t s) {
-    hipEventRecord(ctx->ev_pool[slot].b, s);
+    (void)hipEventRecord(ctx->ev_pool[slot].b, s);
     return PHIHIP_OK;
 }
 
@@ -174,14 +174,14 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
-    hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->device);
     DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs};
     for (DeviceBuffer* b : bufs)
-        if (b->ptr) hipFree(b->ptr);
-    if (ctx->host_state) hipHostFree(ctx->host_state);
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->host_state) (void)hipHostFree(ctx->host_state);
     for (auto& p : ctx->ev_pool) {
-        hipEventDestroy(p.a);
-        hipEventDestroy(p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
     delete ctx;
     return PHIHIP_OK;
@@ -284,6 +284,12 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
     PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
     PHIHIP_TRY(check_solve(solve));
     return run_cg(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+}
+
+int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr && out_device != nullptr && batch >= 1, "solve_residuals: bad argument");
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    return run_export_residuals(ctx, batch, out_device, (hipStream_t)stream);
 }
 
 int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,

@@ -148,6 +148,24 @@ __global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const CgSt
         x[base + i] = fma(alpha, d[base + i], x[base + i]);
 }
 
+__global__ void cg_export_residuals(const CgState* st, int batch, double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) {
+        out[2 * b] = st[b].rsq;
+        out[2 * b + 1] = st[b].rhs_sq;
+    }
+}
+
+int run_export_residuals(phihip_ctx* ctx, int batch, double* out, hipStream_t s) {
+    if (!ctx->ws_state.ptr || ctx->ws_state.bytes < (size_t)batch * sizeof(CgState)) {
+        set_error("solve_residuals: no solve with batch >= %d has run on this context", batch);
+        return PHIHIP_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(cg_export_residuals, dim3(ceil_div(batch, 64)), dim3(64), 0, s, (const CgState*)ctx->ws_state.ptr, batch, out);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // drivers
 // ---------------------------------------------------------------------------------------------------------------------
@@ -189,7 +207,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * part_n * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)v.batch * sizeof(CgState)));
     if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
-        if (ctx->host_state) hipHostFree(ctx->host_state);
+        if (ctx->host_state) (void)hipHostFree(ctx->host_state);
         ctx->host_state = nullptr;
         ctx->host_state_bytes = 0;
         PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));

@@ -132,6 +132,7 @@ int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* 
 int run_grad_subtract(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* const v[3], hipStream_t);
 int run_diffuse(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double kdt, hipStream_t);
 int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
+int run_export_residuals(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_cg(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, phihip_solve_info*, hipStream_t);
 
 }  // namespace phihip

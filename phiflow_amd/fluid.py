@@ -1,0 +1,206 @@
+"""
+Pressure projection on the HIP backend (reference: phi/physics/fluid.py).
+
+`make_incompressible` keeps the reference's signature and semantics for the order-2 StaggeredGrid path:
+    obstacle masks (host, like `with NUMPY:` fluid.py:130-137)  ->  divergence [* active]  ->  balance (non-flexible
+    boundaries)  ->  CG on the masked Laplacian from x0  ->  v -= hard_bcs * grad p.
+The linear operator is applied matrix-free by HIP kernels (the reference assembles a sparse matrix per call).
+"""
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _capi
+from .extrapolation import pressure_extrapolation
+from .field import Field, _check_pressure_padding, _ptrs, _sample_points
+from .geom import Geometry, union_lies_inside
+from .solve import Diverged, NotConverged, Solve, SolveInfo
+
+
+class Obstacle:
+    """ Stationary obstacle (phi/physics/fluid.py:21-91). Moving / rotating obstacles are a next-row item. """
+
+    def __init__(self, geometry: Geometry, velocity=0, angular_velocity=0):
+        if velocity not in (0, 0.0) or angular_velocity not in (0, 0.0):
+            raise NotImplementedError("HIP backend: only stationary obstacles are supported")
+        self.geometry = geometry
+        self.velocity = 0
+        self.angular_velocity = 0
+
+    @property
+    def is_stationary(self):
+        return True
+
+
+def _get_obstacles_for(obstacles, velocity: Field) -> List[Obstacle]:
+    if obstacles is None:
+        return []
+    if isinstance(obstacles, (Obstacle, Geometry)):
+        obstacles = [obstacles]
+    out = []
+    for ob in obstacles:
+        ob = ob if isinstance(ob, Obstacle) else Obstacle(ob)
+        assert set(ob.geometry.dims) == set(velocity.dims), \
+            f"Obstacles must live in the same physical space as the velocity field {velocity.dims} but got {ob.geometry.dims}"
+        out.append(ob)
+    return out
+
+
+class _MaskCache:
+    """ obstacle masks depend only on (grid, boundary, obstacle geometry): rasterise once, keep on the device """
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, velocity: Field, obstacles: Sequence[Obstacle], user_active: Optional[Field]):
+        key = (repr(velocity.resolution), repr(velocity.bounds), repr(velocity.boundary), tuple(repr(o.geometry) for o in obstacles),
+               velocity.dtype, id(user_active) if user_active is not None else None, id(velocity.backend))
+        if key not in self.entries or user_active is not None:
+            self.entries[key] = _build_masks(velocity, obstacles, user_active)
+        return self.entries[key]
+
+
+_MASKS = _MaskCache()
+
+
+def _reordered_points(velocity: Field, comp: Optional[int], geometry: Geometry):
+    pts = _sample_points(velocity.resolution, velocity.bounds, comp, velocity.boundary)
+    return [pts[velocity.dims.index(d)] for d in geometry.dims]
+
+
+def _build_masks(velocity: Field, obstacles: Sequence[Obstacle], user_active: Optional[Field]):
+    """ accessible (cells), soft face factors 1 - mask (faces) on the host; packed stencil flags on the device. """
+    be = velocity.backend
+    res = tuple(velocity.resolution.values())
+    accessible_t = None
+    soft = None
+    if obstacles:
+        inside = np.zeros(res, dtype=bool)
+        for ob in obstacles:
+            inside |= ob.geometry.lies_inside(_reordered_points(velocity, None, ob.geometry))
+        accessible_t = be.as_tensor((~inside).astype(np.uint8), torch.uint8)
+        # soft mask, balance = 1: clip(1 - sdf / r, 0, 1) with r = bounding radius of a face cell (phi/geom/_geom.py:302-308)
+        radius = float(np.sqrt(sum((0.5 * h) ** 2 for h in velocity.dx)))
+        soft = []
+        for d in range(velocity.spatial_rank):
+            m = None
+            for ob in obstacles:
+                frac = np.clip(1.0 - ob.geometry.approximate_signed_distance(_reordered_points(velocity, d, ob.geometry)) / radius, 0, 1)
+                m = frac if m is None else np.maximum(m, frac)
+            soft.append(be.as_tensor(1.0 - m, velocity.dtype))
+    active_t = None
+    if user_active is not None:
+        assert user_active.is_centered and user_active.resolution == velocity.resolution
+        assert not user_active.batched, "HIP backend: batched `active` masks are not supported yet"
+        active_t = (user_active.values[0] != 0).to(torch.uint8).contiguous()
+    flags = be.empty(res, torch.uint8)
+    be.ctx.build_cellflags(velocity.grid_struct(batch=1), accessible_t.data_ptr() if accessible_t is not None else 0,
+                           active_t.data_ptr() if active_t is not None else 0, 1, flags.data_ptr(), be.stream())
+    return flags, soft
+
+
+def make_incompressible(velocity: Field,
+                        obstacles: Union[Obstacle, Geometry, tuple, list] = (),
+                        solve: Solve = Solve(),
+                        active: Optional[Field] = None,
+                        order: int = 2,
+                        correct_skew=False,
+                        wide_stencil: bool = None) -> Tuple[Field, Field]:
+    """
+    Projects the given velocity field by solving for the pressure and subtracting its spatial_gradient
+    (phi/physics/fluid.py:94-162).
+
+    Args:
+        velocity: `StaggeredGrid`.
+        obstacles: `Obstacle` or `Geometry` or tuple/list thereof (stationary).
+        solve: `Solve` object specifying tolerances, `x0` (pressure guess) and `max_iterations`.
+        active: (Optional) `CenteredGrid` mask for which cells the pressure should be solved. If given, the total
+            divergence is never subtracted, even if all values are 1.
+        order: only 2 is implemented on the HIP backend.
+
+    Returns:
+        velocity: divergence-free velocity of type `type(velocity)`
+        pressure: solved pressure field, `CenteredGrid`
+    """
+    assert not correct_skew
+    if order != 2:
+        raise NotImplementedError("HIP backend: make_incompressible implements order=2 only")
+    if not velocity.is_staggered or wide_stencil:
+        raise NotImplementedError("HIP backend: make_incompressible implements the StaggeredGrid path (wide_stencil=False) only")
+    if solve.method not in ('auto', 'CG'):
+        raise NotImplementedError(f"HIP backend: Solve(method={solve.method!r}) is not available, use 'CG' or 'auto'")
+    obstacles = _get_obstacles_for(obstacles, velocity)
+    be = velocity.backend
+    all_active = active is None
+    flags = soft = None
+    if obstacles or active is not None:
+        flags, soft = _MASKS.get(velocity, obstacles, active)
+    fp64 = velocity.dtype == torch.float64
+    solve = solve.with_defaults(fp64)
+    balance = (not velocity.boundary.is_flexible) and all_active   # fluid.py:145
+    p_ext = pressure_extrapolation(velocity.boundary, velocity.dims)
+    B = velocity.batch_size
+    res_shape = tuple(velocity.resolution.values())
+    if solve.x0 is None:
+        pressure = be.zeros((B,) + res_shape, velocity.dtype)
+    else:
+        x0 = solve.x0
+        assert isinstance(x0, Field) and x0.is_centered and x0.resolution == velocity.resolution, "x0 must be a CenteredGrid on the same grid"
+        _check_pressure_padding(x0.boundary, velocity.boundary, velocity.dims)
+        pressure = x0.values.to(velocity.dtype)
+        pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()
+    new_v = [t.clone() for t in velocity.values]
+    csolve = _capi.Solve(solve.rel_tol, solve.abs_tol, int(solve.max_iterations), int(solve.refresh_every), int(solve.check_every), 0)
+    infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), _ptrs(soft) if soft is not None else None,
+                                       flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
+                                       True, be.stream())
+    info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+    _raise_if_failed(info)
+    v_out = Field(velocity.resolution, velocity.bounds, velocity.boundary, new_v, True, be, velocity.batched)
+    p_out = Field(velocity.resolution, velocity.bounds, p_ext, pressure, False, be, velocity.batched)
+    p_out.solve_info = info
+    return v_out, p_out
+
+
+def _raise_if_failed(info: SolveInfo):
+    """ phiml.math.solve_linear raises Diverged / NotConverged unless suppressed """
+    suppress = tuple(info.solve.suppress or ())
+    if any(info.diverged):
+        info.msg = f"CG diverged (residual^2 {info.residual_sq}, rhs^2 {info.rhs_sq}, iterations {info.iterations})"
+        if Diverged not in suppress:
+            raise Diverged(info)
+    elif not all(info.converged):
+        info.msg = f"CG did not converge to rel_tol={info.solve.rel_tol}, abs_tol={info.solve.abs_tol} within " \
+                   f"{info.solve.max_iterations} iterations (residual^2 {info.residual_sq}, rhs^2 {info.rhs_sq})"
+        if NotConverged not in suppress:
+            raise NotConverged(info)
+
+
+def apply_boundary_conditions(velocity: Field, obstacles) -> Field:
+    """ Enforces velocity boundary conditions of stationary obstacles: v *= 1 - soft mask (phi/physics/fluid.py:212-240) """
+    obstacles = _get_obstacles_for(obstacles, velocity)
+    if not obstacles:
+        return velocity
+    _, soft = _MASKS.get(velocity, obstacles, None)
+    return velocity.with_values([torch.where(m == 0, torch.zeros_like(v), v * m) for v, m in zip(velocity.values, soft)])
+
+
+def masked_laplace(pressure: Field, v_boundary, hard_bcs=None, active=None, flags: Optional[torch.Tensor] = None) -> Field:
+    """ `fluid.masked_laplace` (phi/physics/fluid.py:165-202) applied matrix-free. `flags` = packed obstacle flags from
+    `phihip_build_cellflags` (replaces the reference's `hard_bcs` / `active` fields). """
+    if hard_bcs is not None or active is not None:
+        raise NotImplementedError("pass packed `flags` instead of hard_bcs / active fields on the HIP backend")
+    from .extrapolation import as_extrapolation
+    vb = as_extrapolation(v_boundary)
+    _check_pressure_padding(pressure.boundary, vb, pressure.dims)
+    be = pressure.backend
+    proto = Field(pressure.resolution, pressure.bounds, vb, None, True, be, pressure.batched)
+    grid = _capi.make_grid(pressure.spatial_rank, _capi.PHIHIP_F64 if pressure.dtype == torch.float64 else _capi.PHIHIP_F32,
+                           pressure.batch_size, list(pressure.resolution.values()), pressure.bounds.lower, pressure.bounds.upper,
+                           proto._codes, proto._bc_val)
+    out = torch.empty_like(pressure.values)
+    be.ctx.laplace_apply(grid, flags.data_ptr() if flags is not None else 0, 1, pressure.values.contiguous().data_ptr(), out.data_ptr(),
+                         be.stream())
+    return pressure.with_values(out)

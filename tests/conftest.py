@@ -1,0 +1,55 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+EMU_LIB = os.path.join(EMU_DIR, "libphihip_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def _emu_is_stale():
+    if not os.path.exists(EMU_LIB):
+        return True
+    t = os.path.getmtime(EMU_LIB)
+    srcs = [os.path.join(ROOT, "phiflow_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "phiflow_amd", "csrc"))
+            if f.endswith((".hip", ".hpp"))]
+    srcs += [os.path.join(ROOT, "include", "phihip.h"), os.path.join(EMU_DIR, "hipemu.cpp"),
+             os.path.join(EMU_DIR, "include", "hip", "hip_runtime.h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+@pytest.fixture(scope="session")
+def emu_library():
+    """ TEST INFRASTRUCTURE: the kernel sources compiled with g++ against the fiber emulation (tests/hipemu). """
+    from phiflow_amd import _capi
+    if _emu_is_stale():
+        subprocess.run(["bash", os.path.join(EMU_DIR, "build_emu.sh")], check=True, stdout=subprocess.DEVNULL)
+    return _capi.Library(EMU_LIB)
+
+
+@pytest.fixture(scope="session")
+def emu_ctx(emu_library):
+    from phiflow_amd import _capi
+    return _capi.Context(emu_library, 0)
+
+
+@pytest.fixture(scope="session")
+def emu_backend(emu_library):
+    from phiflow_amd.backend import HipBackend
+    return HipBackend(library=emu_library, device="cpu")
+
+
+@pytest.fixture(scope="session")
+def gpu_backend():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from phiflow_amd.backend import HipBackend
+    return HipBackend()   # loads phiflow_amd/lib/libphihip.so; raises if it is missing

@@ -1,0 +1,264 @@
+"""
+Shared parity cases: every function drives libphihip through the C ABI (ctypes) and compares with the NumPy oracle on the
+same seeded inputs. Used twice:
+  * tests/test_emu_kernels.py  -- kernel sources compiled against the fiber emulation (CPU, `-m "not gpu"`)
+  * tests/test_gpu_parity.py   -- the real gfx950 library on a MI355X (`-m gpu`)
+The harness only abstracts where "device" memory lives.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import phi_oracle as O   # noqa: E402  (test infrastructure: the checker)
+from phiflow_amd import _capi as C   # noqa: E402
+
+PER, CLO, OPN = O.PERIODIC, O.CLOSED, O.OPEN
+
+# fp32 tolerances (relative to max |reference|); fp64 tolerances are ~1e-12
+TOL32 = dict(stencil=5e-6, advect=2e-5, cg_rel_l2=1e-4)
+TOL64 = dict(stencil=1e-13, advect=1e-12, cg_rel_l2=1e-9)
+
+
+class NumpyMem:
+    """ emulation: 'device' pointers are host pointers of numpy arrays """
+    def to_dev(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def empty(self, shape, dtype):
+        return np.full(shape, np.nan, dtype=dtype) if np.issubdtype(dtype, np.floating) else np.zeros(shape, dtype=dtype)
+
+    def ptr(self, h):
+        return h.ctypes.data
+
+    def to_host(self, h):
+        return np.array(h)
+
+    def sync(self):
+        pass
+
+
+class TorchMem:
+    """ real GPU: torch-ROCm tensors own the device memory """
+    def __init__(self, device='cuda:0'):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+
+    def to_dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def empty(self, shape, dtype):
+        t = self.torch.empty(tuple(shape), dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+        if t.is_floating_point():
+            t.fill_(float('nan'))
+        else:
+            t.zero_()
+        return t
+
+    def ptr(self, h):
+        return h.data_ptr()
+
+    def to_host(self, h):
+        return h.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def make_case(res, bc, dtype, batch=1, lower=None, upper=None, bc_val=None):
+    D = len(res)
+    lower = lower or (0.0,) * D
+    upper = upper or tuple(float(r) for r in res)
+    dom = O.Domain(res, lower, upper, bc, bc_val)
+    code = C.PHIHIP_F64 if np.dtype(dtype) == np.float64 else C.PHIHIP_F32
+    grid = C.make_grid(D, code, batch, res, lower, upper, bc, dom.bc_val)
+    return dom, grid
+
+
+def random_velocity(dom, batch, dtype, rng, scale=1.0):
+    return [(rng.standard_normal((batch,) + dom.comp_shape(d)) * scale).astype(dtype) for d in range(dom.rank)]
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def demean(a):
+    return a - a.mean(axis=tuple(range(1, a.ndim)), keepdims=True)
+
+
+def tol(dtype):
+    return TOL64 if np.dtype(dtype) == np.float64 else TOL32
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def check_component_shapes(ctx, dom, grid):
+    for d in range(dom.rank):
+        assert tuple(ctx.component_shape(grid, d)) == dom.comp_shape(d)
+
+
+def check_laplace(ctx, mem, dom, grid, dtype, rng, flags_np=None, hard=None, active=None):
+    B = grid.batch
+    p = rng.standard_normal((B,) + dom.res).astype(dtype)
+    dp, dout = mem.to_dev(p), mem.empty(p.shape, dtype)
+    dflags = mem.to_dev(flags_np) if flags_np is not None else None
+    ctx.laplace_apply(grid, mem.ptr(dflags) if dflags is not None else 0, 1, mem.ptr(dp), mem.ptr(dout))
+    mem.sync()
+    ref = O.masked_laplace(p, dom, hard, active)
+    err = rel_err(mem.to_host(dout), ref)
+    assert err <= tol(dtype)['stencil'], f"laplace rel err {err}"
+
+
+def check_divergence(ctx, mem, dom, grid, dtype, rng, balance):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    dv = [mem.to_dev(a) for a in v]
+    ddiv = mem.empty((B,) + dom.res, dtype)
+    ctx.divergence(grid, [mem.ptr(a) for a in dv], 0, 1, balance, mem.ptr(ddiv))
+    mem.sync()
+    ref = O.divergence(v, dom)
+    if balance:
+        ref = O.balance_divergence(ref, None)
+    err = rel_err(mem.to_host(ddiv), ref)
+    assert err <= tol(dtype)['stencil'], f"divergence rel err {err}"
+    if balance:
+        m = np.abs(mem.to_host(ddiv).reshape(B, -1).mean(axis=1)).max()
+        assert m <= (1e-6 if np.dtype(dtype) == np.float32 else 1e-14) * max(1.0, np.abs(ref).max())
+
+
+def check_grad_subtract(ctx, mem, dom, grid, dtype, rng):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    p = rng.standard_normal((B,) + dom.res).astype(dtype)
+    dv = [mem.to_dev(a) for a in v]
+    dp = mem.to_dev(p)
+    ctx.grad_subtract(grid, 0, 1, mem.ptr(dp), [mem.ptr(a) for a in dv])
+    mem.sync()
+    ref = O.gradient_subtract(v, p, dom)
+    for d in range(dom.rank):
+        err = rel_err(mem.to_host(dv[d]), ref[d])
+        assert err <= tol(dtype)['stencil'], f"grad_subtract[{d}] rel err {err}"
+
+
+def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng, scale)
+    dv = [mem.to_dev(a) for a in v]
+    dout = [mem.empty(a.shape, dtype) for a in v]
+    ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
+    mem.sync()
+    ref = O.semi_lagrangian_staggered(v, v, dt, dom)
+    for d in range(dom.rank):
+        err = rel_err(mem.to_host(dout[d]), ref[d])
+        assert err <= tol(dtype)['advect'], f"advect[{d}] rel err {err}"
+
+
+def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=0.9):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    s = rng.standard_normal((B,) + dom.res).astype(dtype)
+    dv = [mem.to_dev(a) for a in v]
+    ds, dout = mem.to_dev(s), mem.empty(s.shape, dtype)
+    ctx.advect_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), dt)
+    mem.sync()
+    ref = O.semi_lagrangian_centered(s, v, dt, dom, s_codes, s_consts)
+    err = rel_err(mem.to_host(dout), ref)
+    assert err <= tol(dtype)['advect'], f"advect_centered rel err {err}"
+
+
+def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    dv = [mem.to_dev(a) for a in v]
+    dout = [mem.empty(a.shape, dtype) for a in v]
+    ctx.diffuse_explicit(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], kdt)
+    mem.sync()
+    ref = O.diffuse_explicit(v, kdt, 1.0, dom)
+    for d in range(dom.rank):
+        err = rel_err(mem.to_host(dout[d]), ref[d])
+        assert err <= tol(dtype)['stencil'] * 4, f"diffuse[{d}] rel err {err}"
+
+
+def solve_params(dtype, max_iter=1000, rtol=None, atol=0.0, refresh=50, check=10):
+    rtol = rtol if rtol is not None else (1e-5 if np.dtype(dtype) == np.float32 else 1e-10)
+    return C.Solve(rtol, atol, max_iter, refresh, check, 0)
+
+
+def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=50, flags_np=None, hard=None, active=None,
+             fixed_iterations=False):
+    """ CG on a consistent rhs (balanced divergence of a random velocity) from x0 = 0; compares the pressure with the
+    oracle's CG modulo its mean and checks the iteration counts. """
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    div = O.divergence(v, dom)
+    if active is not None:
+        div = div * active
+    rhs = div if dom.flexible() else O.balance_divergence(div, active)
+    s = solve_params(dtype, max_iter, 0.0 if fixed_iterations else rtol, 0.0, refresh, 0 if fixed_iterations else 10)
+    drhs, dx = mem.to_dev(rhs.astype(dtype)), mem.to_dev(np.zeros_like(rhs))
+    dflags = mem.to_dev(flags_np) if flags_np is not None else None
+    info = ctx.cg_solve(grid, mem.ptr(dflags) if dflags is not None else 0, 1, mem.ptr(drhs), mem.ptr(dx), s)
+    mem.sync()
+    A = lambda q: O.masked_laplace(q, dom, hard, active)
+    xo, io = O.cg(A, rhs.astype(dtype), np.zeros_like(rhs), s.rel_tol, 0.0, max_iter, refresh)
+    x = mem.to_host(dx)
+    singular = not dom.flexible()
+    a, b = (demean(x), demean(xo)) if singular and active is None else (x, xo)
+    err = rel_l2(a, b)
+    its = [i.iterations for i in info]
+    if fixed_iterations:
+        assert its == [max_iter] * B, its
+    else:
+        assert all(i.converged for i in info), [(i.iterations, i.residual_sq, i.rhs_sq) for i in info]
+        assert all(abs(k - int(ko)) <= max(2, int(0.05 * ko)) for k, ko in zip(its, io.iterations)), (its, io.iterations)
+    assert err <= tol(dtype)['cg_rel_l2'], f"CG pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
+    return x, info
+
+
+def check_make_incompressible(ctx, mem, dom, grid, dtype, rng, obstacles=(), max_div=5e-5, x0=None):
+    """ full projection vs oracle + the reference's own criterion: max |div(v)| <= 5e-5 (tests/commit/physics/test_fluid.py:28) """
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng, scale=0.1)
+    flags_np = soft = hard = active = None
+    dflags = None
+    if obstacles:
+        active, hard, soft = O.obstacle_masks(obstacles, dom, dtype)
+        acc = (active[0] > 0).astype(np.uint8)
+        dacc = mem.to_dev(acc)
+        dflags = mem.empty(dom.res, np.uint8)
+        g1 = C.make_grid(dom.rank, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+        ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    dv = [mem.to_dev(a) for a in v]
+    dsoft = [mem.to_dev((1 - m[0]).astype(dtype)) for m in soft] if soft is not None else None
+    dp = mem.to_dev(np.zeros((B,) + dom.res, dtype) if x0 is None else x0.astype(dtype))
+    ddiv = mem.empty((B,) + dom.res, dtype)
+    s = solve_params(dtype)
+    balance = not dom.flexible()
+    info = ctx.make_incompressible(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dsoft] if dsoft else None,
+                                   mem.ptr(dflags) if dflags is not None else 0, 1, balance, mem.ptr(dp), mem.ptr(ddiv), s)
+    mem.sync()
+    vo, po, io, rhs_o = O.make_incompressible(v, dom, obstacles, x0=x0, rtol=s.rel_tol, atol=0.0, max_iter=1000)
+    assert all(i.converged for i in info)
+    assert rel_err(mem.to_host(ddiv), rhs_o) <= tol(dtype)['stencil'] * 4
+    v_new = [mem.to_host(a) for a in dv]
+    p_new = mem.to_host(dp)
+    div_after = O.divergence(v_new, dom)
+    if active is not None:
+        div_after = div_after * active
+    assert np.abs(div_after).max() <= max_div, f"max |div| after projection = {np.abs(div_after).max()}"
+    singular = not dom.flexible()
+    a, b = (demean(p_new), demean(po)) if singular and not obstacles else (p_new, po)
+    assert rel_l2(a, b) <= 20 * tol(dtype)['cg_rel_l2'], f"pressure rel-L2 {rel_l2(a, b)}"
+    for d in range(dom.rank):
+        scale = max(np.abs(vo[d]).max(), 1e-30)
+        assert np.abs(v_new[d] - vo[d]).max() <= 1e-4 * scale + (1e-5 if np.dtype(dtype) == np.float32 else 1e-9)
+    return info

@@ -1,0 +1,162 @@
+"""
+Kernel LOGIC tests without a GPU: the HIP sources of phiflow_amd/csrc are compiled with g++ against a fiber emulation of
+the HIP execution model (tests/hipemu) and driven through the same C ABI + ctypes binding as on the GPU; results are
+compared with the NumPy oracle. This guards indexing / halo / boundary-condition logic; the `-m gpu` tests in
+test_gpu_parity.py repeat the same cases on the real gfx950 library.
+"""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from parity_cases import CLO, OPN, PER
+
+MEM = pc.NumpyMem()
+
+GRIDS_2D = [
+    ((16, 20), ((CLO, CLO), (CLO, CLO))),
+    ((16, 20), ((OPN, OPN), (OPN, OPN))),
+    ((16, 20), ((PER, PER), (PER, PER))),
+    ((16, 20), ((OPN, OPN), (CLO, OPN))),      # combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY)), test_fluid.py:51
+    ((7, 13), ((CLO, OPN), (PER, PER))),       # ragged: scalar fallback path (n2 % 4 != 0)
+]
+GRIDS_3D = [
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER))),
+    ((9, 7, 10), ((CLO, CLO), (OPN, OPN), (CLO, OPN))),
+    ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO))),   # more than one tile along a2, partial tiles
+]
+
+
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_stencils_match_oracle(emu_ctx, res, bc, dtype):
+    rng = np.random.default_rng(1)
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    pc.check_component_shapes(emu_ctx, dom, grid)
+    pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, rng)
+    pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=False)
+    pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=True)
+    pc.check_grad_subtract(emu_ctx, MEM, dom, grid, dtype, rng)
+    pc.check_diffuse(emu_ctx, MEM, dom, grid, dtype, rng)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)
+def test_advection_matches_oracle(emu_ctx, res, bc):
+    rng = np.random.default_rng(2)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=0.7)
+        pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.9)   # CFL ~ 3: taps several cells away
+        s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+        s_consts = [(0.0, 0.25)] * len(res)
+        pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
+
+
+def test_advection_with_wall_velocity(emu_ctx):
+    """ lid-driven cavity boundary: tangential wall velocity on one side (Lid_Driven_Cavity.ipynb cell 5) """
+    rng = np.random.default_rng(3)
+    bcv = np.zeros((3, 2, 3)); bcv[2, 1, 0] = 1.0; bcv[0, 0, 0] = 0.3   # z+ lid moves in x; x- inflow
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((8, 8, 8), ((CLO, CLO), (CLO, CLO), (CLO, CLO)), dtype, batch=1, bc_val=bcv)
+        pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=1.3)
+        pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=False)
+        pc.check_diffuse(emu_ctx, MEM, dom, grid, dtype, rng)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:2])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_matches_oracle(emu_ctx, res, bc, dtype):
+    rng = np.random.default_rng(4)
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    pc.check_cg(emu_ctx, MEM, dom, grid, dtype, rng)
+
+
+def test_cg_fixed_iterations_and_refresh(emu_ctx):
+    """ benchmark mode: tolerances 0, exactly max_iterations; refresh every 7 exercises the true-residual branch """
+    rng = np.random.default_rng(5)
+    dom, grid = pc.make_case((8, 8, 16), ((PER, PER),) * 3, np.float32, batch=2)
+    pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, rng, max_iter=20, refresh=7, fixed_iterations=True)
+
+
+def test_batch_entries_converge_independently(emu_ctx):
+    """ per-batch alpha / beta / stop (PhiML batch dims): a zero rhs entry stops at iteration 0, the other runs on """
+    dtype = np.float32
+    dom, grid = pc.make_case((16, 16), ((CLO, CLO), (CLO, CLO)), dtype, batch=2)
+    rng = np.random.default_rng(6)
+    rhs = pc.O.balance_divergence(rng.standard_normal((2, 16, 16)).astype(dtype), None)
+    rhs[0] = 0
+    x = np.zeros_like(rhs)
+    info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x.ctypes.data, pc.solve_params(dtype))
+    assert info[0].iterations == 0 and info[0].converged == 1
+    assert info[1].iterations > 5 and info[1].converged == 1
+    assert np.all(x[0] == 0)
+
+
+def test_cg_reports_not_converged_and_diverged(emu_ctx):
+    dtype = np.float32
+    dom, grid = pc.make_case((16, 16), ((PER, PER), (PER, PER)), dtype, batch=1)
+    rng = np.random.default_rng(7)
+    rhs = pc.O.balance_divergence(rng.standard_normal((1, 16, 16)).astype(dtype), None)
+    x = np.zeros_like(rhs)
+    info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x.ctypes.data, pc.solve_params(dtype, max_iter=3))
+    assert info[0].iterations == 3 and not info[0].converged and not info[0].diverged
+    rhs2 = rhs + 1.0                      # inconsistent rhs on a singular (periodic) system
+    x = np.zeros_like(rhs)
+    info = emu_ctx.cg_solve(grid, 0, 1, rhs2.ctypes.data, x.ctypes.data, pc.solve_params(dtype, max_iter=300, rtol=1e-9))
+    assert not info[0].converged
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_obstacles(emu_ctx, dtype):
+    """ config-5 style: closed box with a solid box obstacle; flags kernel, masked Laplacian, CG and the projection """
+    rng = np.random.default_rng(8)
+    dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, dtype, batch=1)
+    obstacles = [pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))]
+    active, hard, soft = pc.O.obstacle_masks(obstacles, dom, dtype)
+    acc = (active[0] > 0).astype(np.uint8)
+    flags = np.zeros(dom.res, np.uint8)
+    g1 = pc.C.make_grid(3, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    emu_ctx.build_cellflags(g1, acc.ctypes.data, 0, 1, flags.ctypes.data)
+    # flags agree with the oracle's hard_bcs / active
+    assert np.array_equal((flags >> 6) & 1, acc)
+    for d in range(3):
+        lo_bit = (flags >> (2 * d)) & 1
+        h = hard[d][0]      # faces 1..N-1 (closed)
+        sl = [slice(None)] * 3; sl[d] = slice(1, None)
+        assert np.array_equal(lo_bit[tuple(sl)], h.astype(np.uint8))
+    pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, rng, flags_np=flags, hard=hard, active=active)
+    pc.check_cg(emu_ctx, MEM, dom, grid, dtype, rng, flags_np=flags, hard=hard, active=active)
+    pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, rng, obstacles=obstacles)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS_2D[:4] + GRIDS_3D[:2])
+def test_make_incompressible_matches_oracle_and_is_divergence_free(emu_ctx, res, bc):
+    rng = np.random.default_rng(9)
+    dtype = np.float32
+    dom, grid = pc.make_case(res, bc, dtype, batch=2, upper=tuple(100.0 for _ in res))
+    pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, rng)
+
+
+def test_tile_configurations_agree(emu_ctx):
+    """ every tile configuration of the marching kernel computes the same operator """
+    rng = np.random.default_rng(10)
+    dtype = np.float32
+    dom, grid = pc.make_case((5, 36, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
+    try:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
+            for chunk in (2, 5):
+                emu_ctx.set_tuning(rows, tpr, chunk)
+                pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(11))
+        emu_ctx.set_tuning(4, 32, 3)
+        pc.check_cg(emu_ctx, MEM, dom, grid, dtype, rng, max_iter=8, fixed_iterations=True)
+    finally:
+        emu_ctx.set_tuning(0, 0, 0)
+
+
+def test_bad_arguments_are_reported(emu_ctx, emu_library):
+    dom, grid = pc.make_case((8, 8), ((PER, PER), (PER, PER)), np.float32)
+    with pytest.raises(pc.C.PhiHipError) as e:
+        emu_ctx.laplace_apply(grid, 0, 1, 0, 0)
+    assert e.value.status == -1 and "NULL" in str(e.value)
+    bad = pc.C.make_grid(2, 0, 1, (8, 8), (0, 0), (8, 8), ((PER, CLO), (PER, PER)))
+    with pytest.raises(pc.C.PhiHipError):
+        emu_ctx.component_shape(bad, 0)

@@ -1,0 +1,240 @@
+"""
+`-m gpu`: the real gfx950 library on a MI355X, driven through the C ABI (ctypes) and compared with the NumPy oracle on
+the same seeded inputs, plus size-independent properties at BASELINE.json's full sizes.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from parity_cases import CLO, OPN, PER
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_backend):
+    return gpu_backend.ctx
+
+
+@pytest.fixture(scope="module")
+def mem(gpu_backend):
+    return pc.TorchMem(str(gpu_backend.device))
+
+
+GRIDS = [
+    ((16, 20), ((CLO, CLO), (CLO, CLO))),
+    ((16, 20), ((OPN, OPN), (OPN, OPN))),
+    ((16, 20), ((PER, PER), (PER, PER))),
+    ((16, 20), ((OPN, OPN), (CLO, OPN))),
+    ((7, 13), ((CLO, OPN), (PER, PER))),
+    ((64, 128), ((CLO, CLO), (CLO, CLO))),
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER))),
+    ((9, 7, 10), ((CLO, CLO), (OPN, OPN), (CLO, OPN))),
+    ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO))),
+    ((48, 40, 136), ((PER, PER), (CLO, CLO), (OPN, OPN))),
+    ((33, 31, 29), ((CLO, CLO), (CLO, CLO), (CLO, CLO))),
+]
+
+
+@pytest.mark.parametrize("res,bc", GRIDS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_stencils_match_oracle(ctx, mem, res, bc, dtype):
+    rng = np.random.default_rng(1)
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    pc.check_component_shapes(ctx, dom, grid)
+    pc.check_laplace(ctx, mem, dom, grid, dtype, rng)
+    pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=False)
+    pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=True)
+    pc.check_grad_subtract(ctx, mem, dom, grid, dtype, rng)
+    pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS)
+def test_advection_matches_oracle(ctx, mem, res, bc):
+    rng = np.random.default_rng(2)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        pc.check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7)
+        pc.check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=2.9)
+        s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+        pc.check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, [(0.0, 0.25)] * len(res))
+
+
+def test_reference_known_answer_self_advection(ctx, mem):
+    """ /root/reference tests/commit/physics/test_advect.py:41-45 -- the only stored known answer on the path """
+    dom, grid = pc.make_case((4, 3), ((CLO, CLO), (CLO, CLO)), np.float32)
+    vx = np.zeros((1, 3, 3), np.float32)
+    vy = np.zeros((1, 4, 2), np.float32)
+    vy[0, 1:3, :] = 1
+    dv = [mem.to_dev(vx), mem.to_dev(vy)]
+    out = [mem.empty(vx.shape, np.float32), mem.empty(vy.shape, np.float32)]
+    ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in out], 1.0)
+    mem.sync()
+    np.testing.assert_allclose(mem.to_host(out[0]), 0, atol=1e-6)
+    np.testing.assert_allclose(mem.to_host(out[1])[0].T, [[0, 0, 0, 0], [0, 1, 1, 0]], rtol=1e-5, atol=1e-6)
+
+
+def test_identity_advection(ctx, mem):
+    """ test_advect.py:12-18: adv(v, v, 0) == adv(v, 0, 1) == v """
+    rng = np.random.default_rng(3)
+    for res, bc in GRIDS[:4] + GRIDS[6:8]:
+        dom, grid = pc.make_case(res, bc, np.float32)
+        v = pc.random_velocity(dom, 1, np.float32, rng)
+        dv = [mem.to_dev(a) for a in v]
+        zero = [mem.to_dev(np.zeros_like(a)) for a in v]
+        out = [mem.empty(a.shape, np.float32) for a in v]
+        ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in out], 0.0)
+        mem.sync()
+        for a, b in zip(out, v):
+            np.testing.assert_allclose(mem.to_host(a), b, atol=1e-5)
+        ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in zero], [mem.ptr(a) for a in out], 1.0)
+        mem.sync()
+        for a, b in zip(out, v):
+            np.testing.assert_allclose(mem.to_host(a), b, atol=1e-5)
+
+
+def test_advection_with_wall_velocity(ctx, mem):
+    rng = np.random.default_rng(3)
+    bcv = np.zeros((3, 2, 3)); bcv[2, 1, 0] = 1.0; bcv[0, 0, 0] = 0.3
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((8, 8, 8), ((CLO, CLO),) * 3, dtype, batch=1, bc_val=bcv)
+        pc.check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=1.3)
+        pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=False)
+        pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS[:9])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_matches_oracle(ctx, mem, res, bc, dtype):
+    rng = np.random.default_rng(4)
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    pc.check_cg(ctx, mem, dom, grid, dtype, rng)
+
+
+def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):
+    """ the benchmark mode (tolerances 0, exactly 100 iterations, refresh at 50) at 64^3 periodic fp32:
+    pressure within 1e-4 rel-L2 of the NumPy oracle (north-star tolerance) """
+    rng = np.random.default_rng(5)
+    dom, grid = pc.make_case((64, 64, 64), ((PER, PER),) * 3, np.float32, upper=(2 * math.pi,) * 3)
+    pc.check_cg(ctx, mem, dom, grid, np.float32, rng, max_iter=100, refresh=50, fixed_iterations=True)
+
+
+def test_batch_entries_converge_independently(ctx, mem):
+    dtype = np.float32
+    dom, grid = pc.make_case((16, 16), ((CLO, CLO), (CLO, CLO)), dtype, batch=2)
+    rng = np.random.default_rng(6)
+    rhs = pc.O.balance_divergence(rng.standard_normal((2, 16, 16)).astype(dtype), None)
+    rhs[0] = 0
+    drhs, dx = mem.to_dev(rhs), mem.to_dev(np.zeros_like(rhs))
+    info = ctx.cg_solve(grid, 0, 1, mem.ptr(drhs), mem.ptr(dx), pc.solve_params(dtype))
+    assert info[0].iterations == 0 and info[0].converged == 1
+    assert info[1].iterations > 5 and info[1].converged == 1
+    assert np.all(mem.to_host(dx)[0] == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_obstacles(ctx, mem, dtype):
+    rng = np.random.default_rng(8)
+    dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, dtype, batch=1)
+    obstacles = [pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))]
+    active, hard, soft = pc.O.obstacle_masks(obstacles, dom, dtype)
+    acc = (active[0] > 0).astype(np.uint8)
+    dacc, dflags = mem.to_dev(acc), mem.empty(dom.res, np.uint8)
+    g1 = pc.C.make_grid(3, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    mem.sync()
+    flags = mem.to_host(dflags)
+    assert np.array_equal((flags >> 6) & 1, acc)
+    pc.check_laplace(ctx, mem, dom, grid, dtype, rng, flags_np=flags, hard=hard, active=active)
+    pc.check_cg(ctx, mem, dom, grid, dtype, rng, flags_np=flags, hard=hard, active=active)
+    pc.check_make_incompressible(ctx, mem, dom, grid, dtype, rng, obstacles=obstacles)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS[:4] + GRIDS[6:9])
+def test_make_incompressible_matches_oracle_and_is_divergence_free(ctx, mem, res, bc):
+    """ tests/commit/physics/test_fluid.py:19-53: closed / open / periodic / mixed, batched; max|div| <= 5e-5 """
+    rng = np.random.default_rng(9)
+    dom, grid = pc.make_case(res, bc, np.float32, batch=3, upper=tuple(100.0 for _ in res))
+    pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, rng)
+
+
+def test_tile_configurations_agree(ctx, mem):
+    rng = np.random.default_rng(10)
+    dtype = np.float32
+    dom, grid = pc.make_case((20, 72, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
+    try:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
+            for chunk in (3, 20):
+                ctx.set_tuning(rows, tpr, chunk)
+                pc.check_laplace(ctx, mem, dom, grid, dtype, np.random.default_rng(11))
+        ctx.set_tuning(4, 32, 7)
+        pc.check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=8, fixed_iterations=True)
+    finally:
+        ctx.set_tuning(0, 0, 0)
+
+
+# ---- full-size properties (BASELINE.json sizes; the oracle is too slow there) ----------------------------------------
+def _eigen_rhs(n, dtype):
+    """ rhs = lambda_h sin x sin y sin z at cell centres: exact discrete solution p = sin x sin y sin z """
+    h = 2 * math.pi / n
+    c = (np.arange(n) + 0.5) * h
+    s = np.sin(c)
+    lam = 3 * (2 * math.cos(h) - 2) / h ** 2
+    p = (s[:, None, None] * s[None, :, None] * s[None, None, :])
+    return (lam * p).astype(dtype)[None], p.astype(dtype)[None]
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_full_size_eigenfunction_solve(ctx, mem, n):
+    """ 256^3 / 512^3 fp32 periodic: CG on the discrete eigenfunction rhs converges in one iteration to the exact solution """
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(2 * math.pi,) * 3)
+    rhs, p_exact = _eigen_rhs(n, np.float32)
+    drhs, dx = mem.to_dev(rhs), mem.to_dev(np.zeros_like(rhs))
+    info = ctx.cg_solve(grid, 0, 1, mem.ptr(drhs), mem.ptr(dx), pc.solve_params(np.float32, max_iter=20, rtol=1e-4))
+    x = mem.to_host(dx)
+    assert info[0].converged and info[0].iterations <= 3, (info[0].iterations, info[0].residual_sq, info[0].rhs_sq)
+    assert pc.rel_l2(x, p_exact) < 1e-4
+
+
+def test_full_size_projection_is_divergence_free_and_linear(ctx, mem):
+    """ 256^3 fp32 periodic: after projection to rel_tol 1e-5 the discrete divergence vanishes (<= 5e-5, the reference's own
+    criterion) and the operator is linear: A(a p + q) == a A p + A q """
+    import torch
+    n = 256
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(2 * math.pi,) * 3)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    v = [torch.randn(1, n, n, n, generator=g).mul_(0.05) for _ in range(3)]
+    dv = [t.to(mem.device) for t in v]
+    p = torch.zeros(1, n, n, n, device=mem.device)
+    div = torch.empty_like(p)
+    info = ctx.make_incompressible(grid, [t.data_ptr() for t in dv], None, 0, 1, True, p.data_ptr(), div.data_ptr(),
+                                   pc.solve_params(np.float32, max_iter=2000, rtol=1e-5))
+    assert info[0].converged
+    ctx.divergence(grid, [t.data_ptr() for t in dv], 0, 1, False, div.data_ptr())
+    mem.sync()
+    assert float(div.abs().max()) <= 5e-5 * (n / (2 * math.pi)) * 0.05 * 10, float(div.abs().max())
+    a = 0.37
+    q = torch.randn(1, n, n, n, generator=g).to(mem.device)
+    out1, out2, out3 = torch.empty_like(p), torch.empty_like(p), torch.empty_like(p)
+    comb = (a * p + q).contiguous()
+    ctx.laplace_apply(grid, 0, 1, comb.data_ptr(), out1.data_ptr())
+    ctx.laplace_apply(grid, 0, 1, p.data_ptr(), out2.data_ptr())
+    ctx.laplace_apply(grid, 0, 1, q.data_ptr(), out3.data_ptr())
+    mem.sync()
+    ref = a * out2 + out3
+    assert float((out1 - ref).abs().max() / ref.abs().max()) < 1e-5
+    # self-adjointness: <q, A p> == <A q, p>
+    lhs = float((q.double() * out2.double()).sum())
+    rhs = float((out3.double() * p.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0)
+
+
+def test_fp64_cavity_with_obstacle_small(ctx, mem):
+    """ config-5 flavour at a size the oracle can check: closed box, lid velocity on z+, solid box obstacle, fp64 """
+    rng = np.random.default_rng(12)
+    bcv = np.zeros((3, 2, 3)); bcv[2, 1, 0] = 1.0
+    dom, grid = pc.make_case((24, 24, 24), ((CLO, CLO),) * 3, np.float64, batch=1, bc_val=bcv, upper=(1.0, 1.0, 1.0))
+    obstacles = [pc.O.BoxObstacle((0.4, 0.4, 0.4), (0.6, 0.6, 0.6))]
+    pc.check_make_incompressible(ctx, mem, dom, grid, np.float64, rng, obstacles=obstacles, max_div=1e-7)
