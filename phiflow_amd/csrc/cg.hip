@@ -1,8 +1,9 @@
 // cg.hip -- matrix-free conjugate gradients on the masked 5/7-point Laplacian.
 // Replaces math.solve_linear(masked_laplace, div, Solve('CG', ...)) (/root/reference phi/physics/fluid.py:156) whose
 // PhiML implementation assembles a sparse matrix per call and runs {SpMV, 2 dots, 3 AXPY} as separate array passes.
-// Here one iteration = MATVEC (d = r + beta d ; dq = d.Ad) -> scalar -> UPDATE (x += a d ; r -= a Ad ; rsq) -> scalar.
-// Alpha / beta / per-batch continue flags never leave the device; the host only enqueues launches.
+// Here one iteration = TWO launches: MATVEC (d = r + beta d ; dq = d.Ad) and UPDATE (x += a d ; r -= a Ad ; rsq); each
+// reduces its predecessor's partial sums in its prologue (stencil_march.hpp), so alpha / beta / the per-batch continue
+// flags never leave the device and no scalar kernel sits between the phases. The host only enqueues launches.
 #include "common.hpp"
 #include "march_dispatch.hpp"
 
@@ -68,6 +69,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchCo
             while (chunk > 8 && blocks_for(id, chunk) < target_blocks) chunk /= 2;
         }
         if (chunk > v.n[0]) chunk = v.n[0];
+        // every workgroup of the next kernel re-reduces all partial sums of a batch entry: keep that list short
+        auto nblk_for = [&](int ch) { return (long long)ceil_div(v.n[1], c->t1) * ceil_div(v.n[2], c->t2) * ceil_div(v.n[0], ch); };
+        while (t.chunk == 0 && chunk < v.n[0] && nblk_for(chunk) > 4096) chunk = chunk * 2 < v.n[0] ? chunk * 2 : v.n[0];
     }
     c->chunk = chunk;
     g->tiles1 = ceil_div(v.n[1], c->t1);
@@ -79,70 +83,25 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchCo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// single-block scalar kernels: reduce the per-workgroup partial sums in a fixed order (deterministic) and advance the
-// per-batch CG control block. One block per batch entry.
+// control-block kernels outside the iteration: finalize / peek (one block per batch entry) and the refresh AXPY
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double reduce_partials(const double* part, int n, double* red) {
-    double s = 0;
-    for (int i = threadIdx.x; i < n; i += kBlock) s += part[i];
-    return block_sum(s, red);
-}
-
-__global__ __launch_bounds__(kBlock) void cg_scalar_init(CgState* st, const double* part_rr, const double* part_yy, int nblk,
-                                                         double rtol, double atol, int max_iter) {
+__global__ __launch_bounds__(kBlock) void cg_state_kernel(int kind, const CgState* st_in, CgState* st_out, const double* pin1,
+                                                          const double* pin2, int nblk, CgParams prm) {
     __shared__ double red[kBlock / kWave];
-    const int b = blockIdx.x;
-    const double rsq = reduce_partials(part_rr + (long long)b * nblk, nblk, red);
-    const double ysq = reduce_partials(part_yy + (long long)b * nblk, nblk, red);
-    if (threadIdx.x == 0) {
-        CgState s;
-        s.alpha = 0; s.beta = 0; s.dq = 0;
-        s.rsq = rsq; s.rsq0 = rsq; s.rhs_sq = ysq;
-        const double t1 = rtol * rtol * ysq, t2 = atol * atol;
-        s.tol_sq = t1 > t2 ? t1 : t2;
-        s.iterations = 0;
-        s.diverged = !(rsq == rsq && rsq <= 1.7e308) ? 1 : 0;   // NaN / inf
-        s.converged = rsq <= s.tol_sq ? 1 : 0;
-        s.cont = (!s.converged && !s.diverged && max_iter > 0) ? 1 : 0;
-        st[b] = s;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void cg_scalar_alpha(CgState* st, const double* part_dq, int nblk) {
-    __shared__ double red[kBlock / kWave];
-    const int b = blockIdx.x;
-    if (st[b].cont == 0) return;
-    const double dq = reduce_partials(part_dq + (long long)b * nblk, nblk, red);
-    if (threadIdx.x == 0) {
-        st[b].iterations += 1;
-        st[b].dq = dq;
-        st[b].alpha = dq != 0 ? st[b].rsq / dq : 0;   // divide_no_nan
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void cg_scalar_beta(CgState* st, const double* part_rr, int nblk, int max_iter) {
-    __shared__ double red[kBlock / kWave];
-    const int b = blockIdx.x;
-    if (st[b].cont == 0) return;
-    const double rsq = reduce_partials(part_rr + (long long)b * nblk, nblk, red);
-    if (threadIdx.x == 0) {
-        CgState s = st[b];
-        s.beta = s.rsq != 0 ? rsq / s.rsq : 0;
-        s.rsq = rsq;
-        const bool finite = (rsq == rsq) && rsq <= 1.7e308;
-        s.diverged = (!finite || (s.rsq0 > 0 && rsq / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
-        s.converged = rsq <= s.tol_sq ? 1 : 0;
-        s.cont = (!s.converged && !s.diverged && s.iterations < max_iter) ? 1 : 0;
-        st[b] = s;
-    }
+    __shared__ CgState sh;
+    cg_prologue(kind, st_in, st_out, pin1, pin2, nblk, prm, blockIdx.x, true, red, &sh);
 }
 
 // x += alpha * d for the true-residual refresh iterations (PhiML recomputes r = y - A x every 50th iteration)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const CgState* st, long long cells) {
+__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const CgState* st_in, CgState* st_out, const double* part_dq, int nblk,
+                                                    CgParams prm, long long cells) {
+    __shared__ double red[kBlock / kWave];
+    __shared__ CgState sh;
     const int b = blockIdx.y;
-    if (st[b].cont == 0) return;
-    const T alpha = (T)st[b].alpha;
+    const CgState S = cg_prologue(PRO_ALPHA, st_in, st_out, part_dq, nullptr, nblk, prm, b, blockIdx.x == 0, red, &sh);
+    if (S.cont == 0) return;
+    const T alpha = (T)S.alpha;
     const long long base = (long long)b * cells;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock)
         x[base + i] = fma(alpha, d[base + i], x[base + i]);
@@ -157,11 +116,11 @@ __global__ void cg_export_residuals(const CgState* st, int batch, double* out) {
 }
 
 int run_export_residuals(phihip_ctx* ctx, int batch, double* out, hipStream_t s) {
-    if (!ctx->ws_state.ptr || ctx->ws_state.bytes < (size_t)batch * sizeof(CgState)) {
+    if (!ctx->last_state || ctx->last_state_batch < batch) {
         set_error("solve_residuals: no solve with batch >= %d has run on this context", batch);
         return PHIHIP_ERR_BAD_ARG;
     }
-    hipLaunchKernelGGL(cg_export_residuals, dim3(ceil_div(batch, 64)), dim3(64), 0, s, (const CgState*)ctx->ws_state.ptr, batch, out);
+    hipLaunchKernelGGL(cg_export_residuals, dim3(ceil_div(batch, 64)), dim3(64), 0, s, (const CgState*)ctx->last_state, batch, out);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
@@ -181,6 +140,7 @@ static int laplace_apply_t(phihip_ctx* ctx, const GridView& v, const uint8_t* fl
     a.o1 = (T*)out;
     a.flags = flags;
     a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    a.prologue = PRO_NONE;
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY, flags != nullptr, g, a, s));
     PHIHIP_CHECK_HIP(hipGetLastError());
@@ -205,7 +165,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * part_n * sizeof(double)));
-    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)v.batch * sizeof(CgState)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)3 * v.batch * sizeof(CgState)));
     if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
         if (ctx->host_state) (void)hipHostFree(ctx->host_state);
         ctx->host_state = nullptr;
@@ -218,35 +178,30 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     double* part_rr = (double*)ctx->ws_part.ptr;
     double* part_dq = part_rr + part_n;
     double* part_yy = part_dq + part_n;
-    CgState* st = (CgState*)ctx->ws_state.ptr;
+    CgState* st[2] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch};
+    CgState* st_peek = (CgState*)ctx->ws_state.ptr + 2 * v.batch;
+    int cur = 0;   // slot holding the most recent control block
     const bool has_flags = flags != nullptr;
+    CgParams prm;
+    prm.rtol = solve->rel_tol; prm.atol = solve->abs_tol; prm.max_iter = solve->max_iterations; prm.pad = 0;
 
     MarchArgs<T> base;
     memset(&base, 0, sizeof(base));
     base.flags = flags;
-    base.st = st;
+    base.prm = prm;
     base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
 
-    auto resid = [&](bool respect_cont, double* p_yy) -> int {
+    // ---- r0 = y - A x0 ; d0 = r0 (beta = 0 on a zeroed d buffer) ----
+    PHIHIP_CHECK_HIP(hipMemsetAsync(d[0], 0, vec_bytes, s));
+    {
         MarchArgs<T> a = base;
         a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = r;
-        a.part1 = part_rr; a.part2 = p_yy;
-        MarchGrid gg = g;
-        gg.respect_cont = respect_cont ? 1 : 0;
+        a.part1 = part_rr; a.part2 = part_yy;
+        a.prologue = PRO_NONE;
         LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
-        return launch_march_any<T>(v, c, MODE_RESID, has_flags, gg, a, s);
-    };
-
-    // ---- r0 = y - A x0, d0 = r0 (beta = 0 on a zeroed d buffer) ----
-    PHIHIP_CHECK_HIP(hipMemsetAsync(d[0], 0, vec_bytes, s));
-    PHIHIP_TRY(resid(false, part_yy));
-    {
-        LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-        hipLaunchKernelGGL(cg_scalar_init, dim3(v.batch), dim3(kBlock), 0, s, st, part_rr, part_yy, g.nblk, solve->rel_tol,
-                           solve->abs_tol, solve->max_iterations);
+        PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
     }
-    MarchGrid gc = g;
-    gc.respect_cont = 1;
+    bool first = true;
     const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
     CgState* hst = (CgState*)ctx->host_state;
     for (int k = 1; k <= solve->max_iterations; ++k) {
@@ -255,41 +210,61 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         {
             MarchArgs<T> a = base;
             a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq;
+            a.prologue = first ? PRO_FIRST : PRO_BETA;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = part_yy;
             LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_MATVEC, has_flags, gc, a, s));
-        }
-        {
-            LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-            hipLaunchKernelGGL(cg_scalar_alpha, dim3(v.batch), dim3(kBlock), 0, s, st, part_dq, g.nblk);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_MATVEC, has_flags, g, a, s));
+            cur ^= 1;
+            first = false;
         }
         if (solve->refresh_every > 0 && k % solve->refresh_every == 0) {
             {
                 LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
                 hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new,
-                                   (const CgState*)st, v.cells);
+                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, g.nblk, prm, v.cells);
+                cur ^= 1;
             }
-            PHIHIP_TRY(resid(true, part_dq /* scratch: sum y^2 is not needed again */));
+            MarchArgs<T> a = base;
+            a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = r;
+            a.part1 = part_rr; a.part2 = part_yy;   // sum y^2 is not needed again: part_yy is scratch from now on
+            a.prologue = PRO_CONT;
+            a.st_in = st[cur];
+            LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
         } else {
             MarchArgs<T> a = base;
             a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr;
+            a.prologue = PRO_ALPHA;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq;
             LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_UPDATE, has_flags, gc, a, s));
-        }
-        {
-            LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-            hipLaunchKernelGGL(cg_scalar_beta, dim3(v.batch), dim3(kBlock), 0, s, st, part_rr, g.nblk, solve->max_iterations);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_UPDATE, has_flags, g, a, s));
+            cur ^= 1;
         }
         if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
-            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+            // peek at the decision the next MATVEC prologue will take, without advancing the chain
+            {
+                LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur], st_peek,
+                                   (const double*)part_rr, (const double*)part_yy, g.nblk, prm);
+            }
+            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st_peek, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
             PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
             bool any = false;
             for (int b = 0; b < v.batch; ++b) any = any || hst[b].cont;
             if (!any) break;
         }
     }
+    {   // fold the last reduction into the control block (or build it when no iteration ran)
+        LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+        hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : PRO_BETA), (const CgState*)st[cur],
+                           st[cur ^ 1], (const double*)part_rr, (const double*)part_yy, g.nblk, prm);
+        cur ^= 1;
+    }
+    ctx->last_state = st[cur];
+    ctx->last_state_batch = v.batch;
     PHIHIP_CHECK_HIP(hipGetLastError());
     if (info) {
-        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st[cur], (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
         PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
         for (int b = 0; b < v.batch; ++b) {
             info[b].residual_sq = hst[b].rsq;

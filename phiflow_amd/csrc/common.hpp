@@ -86,6 +86,8 @@ struct phihip_ctx {
     phihip::Tuning tuning;
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs;
+    void* last_state = nullptr;   // device control blocks of the most recent solve
+    int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
     size_t host_state_bytes = 0;
     // profiling

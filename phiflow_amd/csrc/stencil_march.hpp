@@ -25,12 +25,59 @@ constexpr int kWave = 64;
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2 };
 enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3 };
 
-// per batch entry CG control block (device memory); written only by the single-block scalar kernels
+// Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
+// iteration: every workgroup of the NEXT kernel re-reduces the previous kernel's per-workgroup partial sums in a fixed order
+// (deterministic, no atomics / fences -- the kernel boundary orders the data) and advances the control block in registers;
+// workgroup 0 stores it to the other of two slots for the kernel after that.
 struct CgState {
     double alpha, beta;
     double rsq, rsq0, rhs_sq, tol_sq, dq;
     int32_t cont, iterations, converged, diverged;
 };
+
+struct CgParams {
+    double rtol, atol;
+    int32_t max_iter, pad;
+};
+
+enum CgPrologue {
+    PRO_NONE = 0,       // no control block involved (APPLY, initial residual)
+    PRO_CONT = 1,       // read the continue flag only (true-residual refresh)
+    PRO_FIRST = 2,      // build the control block from the initial residual's sums (rr, yy); beta = 0
+    PRO_BETA = 3,       // rsq_new from the UPDATE / refresh partials: beta, convergence flags
+    PRO_ALPHA = 4       // dq from the MATVEC partials: alpha, iteration count
+};
+
+__device__ __forceinline__ bool cg_finite(double v) { return (v == v) && v <= 1.7e308 && v >= -1.7e308; }
+
+// PhiML's cg loop body bookkeeping, split at its two reductions
+__device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, double sum2, const CgParams& prm) {
+    if (kind == PRO_FIRST) {
+        s.alpha = 0; s.beta = 0; s.dq = 0;
+        s.rsq = sum1; s.rsq0 = sum1; s.rhs_sq = sum2;
+        const double t1 = prm.rtol * prm.rtol * sum2, t2 = prm.atol * prm.atol;
+        s.tol_sq = t1 > t2 ? t1 : t2;
+        s.iterations = 0;
+        s.diverged = cg_finite(sum1) ? 0 : 1;
+        s.converged = sum1 <= s.tol_sq ? 1 : 0;
+        s.cont = (!s.converged && !s.diverged && prm.max_iter > 0) ? 1 : 0;
+    } else if (kind == PRO_BETA) {
+        if (s.cont) {
+            s.beta = s.rsq != 0 ? sum1 / s.rsq : 0;   // divide_no_nan
+            s.rsq = sum1;
+            s.diverged = (!cg_finite(sum1) || (s.rsq0 > 0 && sum1 / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
+            s.converged = sum1 <= s.tol_sq ? 1 : 0;
+            s.cont = (!s.converged && !s.diverged && s.iterations < prm.max_iter) ? 1 : 0;
+        }
+    } else if (kind == PRO_ALPHA) {
+        if (s.cont) {
+            s.iterations += 1;
+            s.dq = sum1;
+            s.alpha = sum1 != 0 ? s.rsq / sum1 : 0;
+        }
+    }
+    return s;
+}
 
 struct MarchGrid {
     int n0, n1, n2;        // cells per internal axis (n0 == 1 for 2-D grids)
@@ -38,7 +85,6 @@ struct MarchGrid {
     long long cells;       // n0 * n1 * n2
     int tiles1, tiles2, chunks0, chunk, nblk;
     int flags_per_batch;   // 1: flags array has a batch dimension, 0: shared by all batch entries
-    int respect_cont;      // skip batch entries whose CgState.cont == 0
 };
 
 template <typename T>
@@ -48,9 +94,14 @@ struct MarchArgs {
     T* o1;                 // APPLY out | RESID r | MATVEC d_new | UPDATE x (in/out)
     T* o2;                 //                                     | UPDATE r (in/out)
     const uint8_t* flags;  // per-cell stencil flags or nullptr
-    const CgState* st;     // [batch]
-    double* part1;         // [batch][nblk]
+    const CgState* st_in;  // [batch] control block written by the previous kernel
+    CgState* st_out;       // [batch] slot for the next kernel (written by workgroup 0)
+    const double* pin1;    // [batch][nblk] partial sums to reduce in the prologue
+    const double* pin2;    //               (PRO_FIRST: sum y^2)
+    double* part1;         // [batch][nblk] partial sums produced by this kernel
     double* part2;         // [batch][nblk]
+    CgParams prm;
+    int prologue;          // CgPrologue
     T w0, w1, w2;          // 1 / dx^2 per internal axis
 };
 
@@ -113,6 +164,30 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return s;
 }
 
+// fixed-order sum of n partials by the whole block; valid in thread 0
+__device__ __forceinline__ double reduce_partials(const double* part, int n, double* red) {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) s += part[i];
+    return block_sum(s, red);
+}
+
+// Prologue shared by every kernel of the CG loop: returns the advanced control block to all threads of the workgroup.
+__device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, CgState* st_out, const double* pin1, const double* pin2,
+                                              int nblk, const CgParams& prm, int b, bool writer, double* red, CgState* sh) {
+    double s1 = 0, s2 = 0;
+    if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
+    if (kind == PRO_FIRST) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
+    if (threadIdx.x == 0) {
+        CgState s;
+        if (kind == PRO_FIRST) { s = CgState(); } else { s = st_in[b]; }
+        s = cg_advance(kind, s, s1, s2, prm);
+        *sh = s;
+        if (writer && kind >= PRO_FIRST) st_out[b] = s;
+    }
+    __syncthreads();
+    return *sh;
+}
+
 template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3>
 __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T> p) {
     constexpr int TR = kBlock / TPR;   // thread rows
@@ -126,10 +201,17 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     __shared__ __attribute__((aligned(16))) T lds[2][LROWS * LS];
     __shared__ double red[kBlock / kWave];
+    __shared__ CgState sh_state;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    if (g.respect_cont && p.st[b].cont == 0) return;
+    T alpha = T(0), beta = T(0);
+    if (p.prologue != PRO_NONE) {
+        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, g.nblk, p.prm, b, blockIdx.x == 0, red, &sh_state);
+        if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
+        alpha = (T)S.alpha;
+        beta = (T)S.beta;
+    }
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
@@ -146,10 +228,6 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const long long base = (long long)b * g.cells;
     const long long fbase = g.flags_per_batch ? base : 0;
     const int n1 = g.n1, n2 = g.n2;
-
-    T alpha = T(0), beta = T(0);
-    if (MODE == MODE_UPDATE) alpha = (T)p.st[b].alpha;
-    if (MODE == MODE_MATVEC) beta = (T)p.st[b].beta;
 
     bool ok[R];
 #pragma unroll

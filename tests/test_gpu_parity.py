@@ -194,7 +194,8 @@ def test_full_size_eigenfunction_solve(ctx, mem, n):
     drhs, dx = mem.to_dev(rhs), mem.to_dev(np.zeros_like(rhs))
     info = ctx.cg_solve(grid, 0, 1, mem.ptr(drhs), mem.ptr(dx), pc.solve_params(np.float32, max_iter=20, rtol=1e-4))
     x = mem.to_host(dx)
-    assert info[0].converged and info[0].iterations <= 3, (info[0].iterations, info[0].residual_sq, info[0].rhs_sq)
+    # exact arithmetic: 1 iteration; fp32 round-off of the 134 M-term dot products adds a few clean-up iterations at 512^3
+    assert info[0].converged and info[0].iterations <= 6, (info[0].iterations, info[0].residual_sq, info[0].rhs_sq)
     assert pc.rel_l2(x, p_exact) < 1e-4
 
 

@@ -1,0 +1,170 @@
+"""
+Pins the NumPy oracle (oracle/phi_oracle.py) against every known-answer / property test the REFERENCE holds for the hot
+path (/root/reference tests/commit/...) and against two independent solvers (discrete-FFT Poisson,
+SciPy sparse direct solve of the assembled operator). The reference itself cannot be imported (phiml absent).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from oracle import phi_oracle as O
+
+PER, CLO, OPN = O.PERIODIC, O.CLOSED, O.OPEN
+
+
+def test_reference_known_answer_self_advect_staggered():
+    """ tests/commit/physics/test_advect.py:41-45
+    v0 = StaggeredGrid(Box(x=(.9,2.6), y=(.9,2)), 0, x=4, y=3) * (0, 1); v = semi_lagrangian(v0, v0, 1)
+    => v['x'] == 0 and v['y'] == [[0,0,0,0],[0,1,1,0]] (dims y,x) """
+    dom = O.Domain((4, 3), (0, 0), (4, 3), ((CLO, CLO), (CLO, CLO)))
+    vx = np.zeros((1,) + dom.comp_shape(0), np.float32)
+    vy = np.zeros((1,) + dom.comp_shape(1), np.float32)
+    # the Box mask sampled at the y-faces (x centres .5,1.5,2.5,3.5; y faces 1,2): inside for x in {1.5,2.5}
+    vy[0, 1:3, :] = 1
+    out = O.semi_lagrangian_staggered([vx, vy], [vx, vy], 1.0, dom)
+    np.testing.assert_allclose(out[0], 0, atol=1e-7)
+    np.testing.assert_allclose(out[1][0].T, [[0, 0, 0, 0], [0, 1, 1, 0]], rtol=1e-5)
+
+
+@pytest.mark.parametrize("bc", [((CLO, CLO), (CLO, CLO)), ((OPN, OPN), (OPN, OPN)), ((PER, PER), (PER, PER))])
+def test_reference_identity_advection(bc):
+    """ tests/commit/physics/test_advect.py:12-18: adv(s, v, 0) == adv(s, v*0, 1) == s for centred and staggered fields """
+    rng = np.random.default_rng(0)
+    dom = O.Domain((4, 3), (0, 0), (4, 3), bc)
+    v = [rng.standard_normal((1,) + dom.comp_shape(d)).astype(np.float32) for d in range(2)]
+    zero = [np.zeros_like(a) for a in v]
+    s = rng.standard_normal((1, 4, 3)).astype(np.float32)
+    for a, b in zip(O.semi_lagrangian_staggered(v, v, 0.0, dom), v):
+        np.testing.assert_allclose(a, b, atol=1e-5)
+    for a, b in zip(O.semi_lagrangian_staggered(v, zero, 1.0, dom), v):
+        np.testing.assert_allclose(a, b, atol=1e-5)
+    np.testing.assert_allclose(O.semi_lagrangian_centered(s, v, 0.0, dom, bc), s, atol=1e-5)
+    np.testing.assert_allclose(O.semi_lagrangian_centered(s, zero, 1.0, dom, bc), s, atol=1e-5)
+
+
+def test_reference_staggered_storage_sizes():
+    """ tests/commit/field/test__grid.py:25-36: x-component has x=19 (ZERO), 20 (PERIODIC), 21 (BOUNDARY) for x=20, y=10 """
+    for code, expect in ((CLO, 19), (PER, 20), (OPN, 21)):
+        dom = O.Domain((20, 10), (0, 0), (20, 10), ((code, code), (code, code)))
+        assert dom.comp_shape(0) == (expect, 10)
+        assert dom.comp_shape(1) == (20, expect - 10)
+
+
+def test_reference_laplace_stencil_values():
+    """ tests/commit/physics/test_diffuse.py:68-72: diffuse.explicit(impulse, 1, 1) on a ZERO-padded grid with dx = 1 gives
+    [[0,1,0],[1,-3,1],[0,1,0]] (impulse + 5-point Laplacian). Same stencil applied here to a velocity component. """
+    dom = O.Domain((4, 4), (0, 0), (4, 4), ((CLO, CLO), (CLO, CLO)))
+    vx = np.zeros((1, 3, 4), np.float32)     # x-component faces: 3 x 4
+    vx[0, 1, 1] = 1
+    vy = np.zeros((1, 4, 3), np.float32)
+    out = O.diffuse_explicit([vx, vy], 1.0, 1.0, dom)
+    np.testing.assert_allclose(out[0][0, 0:3, 0:3], [[0, 1, 0], [1, -3, 1], [0, 1, 0]])
+    np.testing.assert_allclose(out[1], 0)
+
+
+def _buoyancy_faces(smoke, dom):
+    sp_ = O.pad_scalar(smoke, [(0, 0), (1, 1)], dom.bc)
+    faces = 0.5 * (sp_[:, :, 1:] + sp_[:, :, :-1])
+    off, n = dom.face_offset(1), dom.comp_shape(1)[1]
+    return faces[:, :, off:off + n]
+
+
+@pytest.mark.parametrize("name,bc", [("closed", ((CLO, CLO), (CLO, CLO))), ("open", ((OPN, OPN), (OPN, OPN))),
+                                     ("periodic", ((PER, PER), (PER, PER))), ("mixed", ((OPN, OPN), (CLO, OPN)))])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_reference_make_incompressible_divergence_free(name, bc, batch):
+    """ tests/commit/physics/test_fluid.py:19-53: 16x20 cells on Box[0:100, 0:100], smoke sphere source, two rounds of
+    (buoyancy, make_incompressible with default Solve()); asserts |div| <= 5e-5 (test_fluid.py:28). Batched variants use
+    different source positions per batch entry. """
+    rng = np.random.default_rng(0)
+    for dtype in (np.float32, np.float64):
+        dom = O.Domain((16, 20), (0, 0), (100, 100), bc)
+        cp = O.cell_positions(dom, np.float64)
+        xs = rng.uniform(0, 100, size=batch)
+        smoke = np.stack([(((cp[0] - x0) ** 2 + (cp[1] - 10) ** 2) <= 25).astype(dtype) for x0 in xs])
+        v = [np.zeros((batch,) + dom.comp_shape(d), dtype) for d in range(2)]
+        for _ in range(2):
+            v[1] = v[1] + dtype(0.1) * _buoyancy_faces(smoke, dom).astype(dtype)
+            v, p, info, _ = O.make_incompressible(v, dom, rtol=1e-5, atol=0.0)
+        assert info.converged.all()
+        assert np.abs(O.divergence(v, dom)).max() <= 5e-5
+
+
+def test_cg_agrees_with_fft_poisson_solve_periodic():
+    """ independent check: periodic discrete Poisson problem solved by FFT with the DISCRETE eigenvalues
+    (cf. the FFT solver of tests/commit/test_poisson_solver.py:9-19, which uses the continuous spectrum) """
+    rng = np.random.default_rng(1)
+    n = (16, 12, 20)
+    L = (2.0, 1.5, 3.0)
+    dom = O.Domain(n, (0, 0, 0), L, ((PER, PER),) * 3)
+    rhs = rng.standard_normal((1,) + n)
+    rhs -= rhs.mean()
+    x, info = O.cg(lambda p: O.masked_laplace(p, dom), rhs, np.zeros_like(rhs), 1e-12, 0, 5000)
+    lam = 0
+    for a in range(3):
+        k = np.fft.fftfreq(n[a]) * 2 * np.pi
+        shape = [1, 1, 1]; shape[a] = n[a]
+        lam = lam + ((2 * np.cos(k) - 2) / dom.dx[a] ** 2).reshape(shape)
+    lam[0, 0, 0] = np.inf
+    x_fft = np.real(np.fft.ifftn(np.fft.fftn(rhs[0]) / lam))
+    assert info.converged.all()
+    np.testing.assert_allclose(x[0] - x[0].mean(), x_fft - x_fft.mean(), atol=1e-9)
+
+
+def _assemble(dom, hard=None, active=None):
+    """ dense probing of the oracle operator -> sparse matrix """
+    N = int(np.prod(dom.res))
+    cols = []
+    for j in range(N):
+        e = np.zeros((1, N)); e[0, j] = 1
+        cols.append(O.masked_laplace(e.reshape((1,) + dom.res), dom, hard, active).reshape(N))
+    return sp.csc_matrix(np.stack(cols, axis=1))
+
+
+@pytest.mark.parametrize("bc", [((OPN, OPN), (OPN, OPN)), ((OPN, OPN), (CLO, OPN)), ((CLO, OPN), (PER, PER))])
+def test_cg_agrees_with_sparse_direct_solve(bc):
+    """ independent check on non-singular systems: assemble the operator by probing and solve with SciPy's direct solver """
+    rng = np.random.default_rng(2)
+    dom = O.Domain((7, 9), (0, 0), (3.0, 2.0), bc)
+    A = _assemble(dom)
+    assert abs(A - A.T).max() < 1e-12            # symmetric
+    rhs = rng.standard_normal((1, 7, 9))
+    x, info = O.cg(lambda p: O.masked_laplace(p, dom), rhs, np.zeros_like(rhs), 1e-13, 0, 5000)
+    x_direct = spla.spsolve(A, rhs.reshape(-1)).reshape(7, 9)
+    assert info.converged.all()
+    np.testing.assert_allclose(x[0], x_direct, rtol=1e-8, atol=1e-10)
+
+
+def test_obstacle_operator_is_symmetric_and_negative_semidefinite():
+    dom = O.Domain((8, 8), (0, 0), (8, 8), ((CLO, CLO), (CLO, CLO)))
+    active, hard, soft = O.obstacle_masks([O.BoxObstacle((3, 3), (5, 6))], dom, np.float64)
+    A = _assemble(dom, hard, active).toarray()
+    assert np.abs(A - A.T).max() < 1e-12
+    act = active.reshape(-1) > 0
+    w = np.linalg.eigvalsh(A[np.ix_(act, act)])
+    assert w.max() < 1e-10
+    assert np.allclose(A[~act][:, ~act], np.eye((~act).sum()))          # identity rows on inactive cells (fluid.py:202)
+    # soft mask: 1 deep inside, 0 far away
+    assert soft[0].max() == 1 and soft[0].min() == 0
+
+
+def test_pressure_boundary_rules():
+    """ fluid._pressure_extrapolation (fluid.py:264-274): closed wall -> zero normal gradient, open -> zero ghost """
+    dom = O.Domain((4,  4), (0, 0), (4, 4), ((CLO, CLO), (OPN, OPN)))
+    p = np.ones((1, 4, 4))
+    g = O.pressure_gradient(p, dom)
+    assert g[0].shape == (1, 3, 4) and np.all(g[0] == 0)
+    assert g[1].shape == (1, 4, 5) and np.all(g[1][:, :, 0] == 1) and np.all(g[1][:, :, -1] == -1) and np.all(g[1][:, :, 1:-1] == 0)
+
+
+def test_mixed_boundary_corner_padding_order():
+    """ sequential padding (x, then y): outside both an x-constant and a y-constant side the LAST axis wins """
+    bcv = np.zeros((2, 2, 2)); bcv[0, 1, 0] = 7.0; bcv[1, 1, 0] = 3.0
+    dom = O.Domain((3, 3), (0, 0), (3, 3), ((CLO, CLO), (CLO, CLO)), bcv)
+    a = np.zeros((1,) + dom.comp_shape(0))
+    codes, consts = O._comp_codes(dom, 0)
+    val = O.grid_sample(a, [np.array([[5.0]]), np.array([[5.0]])], codes, consts)
+    assert val[0, 0] == 3.0
+    padded = O.pad_component(a, 0, [(0, 2), (0, 2)], dom)
+    assert padded[0, -1, -1] == 3.0 and padded[0, -1, 0] == 7.0

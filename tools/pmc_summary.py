@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""
+Summarise rocprofv3 PMC passes into HBM bytes per launch (profiles/pmc_traffic.json + a readable table).
+Usage: python tools/pmc_summary.py <dir with *_counter_collection.csv files> [out.json]
+
+Per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KiB-like units of the L2's memory-side request counters; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled here; WRITE_SIZE is
+"uncalibrated", so both counters are additionally calibrated against a streaming copy of known size in the same run
+(tools/pmc_workload.py step 1) and the calibrated figures are reported next to the prescribed ones.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def classify(name):
+    if "march_kernel" in name:
+        m = re.search(r"march_kernel<\s*(\w+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", name)
+        mode = {0: "laplace_apply", 1: "cg_residual", 2: "cg_matvec_dot", 3: "cg_update"}.get(int(m.group(5)), "march") if m else "march"
+        return mode
+    if "elementwise" in name.lower() or "copy" in name.lower():
+        return "calib_copy"
+    return None
+
+
+def main():
+    src = sys.argv[1]
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    rows = []
+    for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            rows += list(csv.DictReader(f))
+    per = defaultdict(lambda: defaultdict(list))   # (kind, grid) -> counter -> values
+    for r in rows:
+        kind = classify(r.get("Kernel_Name", ""))
+        if not kind:
+            continue
+        grid = r.get("Grid_Size", "")
+        per[(kind, grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    table = {}
+    for (kind, grid), counters in sorted(per.items()):
+        entry = {"launches": max(len(v) for v in counters.values())}
+        for cname, vals in counters.items():
+            entry[cname] = sum(vals) / len(vals)
+        table[f"{kind}|grid={grid}"] = entry
+    # calibration from the copy kernel (512 MiB read + 512 MiB written per launch)
+    known = 512.0 * 1024 * 1024
+    cal = [e for k, e in table.items() if k.startswith("calib_copy") and e.get("FETCH_SIZE", 0) > 1e4]
+    fetch_unit = write_unit = None
+    if cal:
+        c = max(cal, key=lambda e: e.get("FETCH_SIZE", 0))
+        if c.get("FETCH_SIZE"):
+            fetch_unit = known / c["FETCH_SIZE"]       # bytes per counter unit (expected ~2048 = 2 x 1 KiB)
+        if c.get("WRITE_SIZE"):
+            write_unit = known / c["WRITE_SIZE"]
+    result = {"units": {"fetch_bytes_per_unit_calibrated": fetch_unit, "write_bytes_per_unit_calibrated": write_unit,
+                        "fetch_bytes_per_unit_prescribed": 2048.0, "write_bytes_per_unit_prescribed": 1024.0}, "kernels": {}}
+    for k, e in table.items():
+        f, w = e.get("FETCH_SIZE"), e.get("WRITE_SIZE")
+        rec = dict(e)
+        if f is not None:
+            rec["read_bytes_prescribed"] = f * 2048.0
+            if fetch_unit:
+                rec["read_bytes_calibrated"] = f * fetch_unit
+        if w is not None:
+            rec["write_bytes_prescribed"] = w * 1024.0
+            if write_unit:
+                rec["write_bytes_calibrated"] = w * write_unit
+        result["kernels"][k] = rec
+    print(json.dumps(result, indent=1))
+    if out_path:
+        with open(out_path, "w") as fo:
+            json.dump(result, fo, indent=1)
+
+
+if __name__ == "__main__":
+    main()

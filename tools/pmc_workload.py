@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""
+Workload for the rocprofv3 PMC passes (run once per counter set, see tools/gpu_session.sh):
+  1. calibration: a plain 16 B/lane streaming copy of a known size (torch copy_ of 512 MiB fp32) -- known bytes read/written
+  2. the CG loop at 512^3 and 256^3 fp32 (a few iterations, default tile configuration)
+The summary (tools/pmc_summary.py) turns FETCH_SIZE / WRITE_SIZE per dispatch into HBM bytes per launch.
+"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phiflow_amd import _capi as C   # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    a = torch.randn(128 * 1024 * 1024, device=dev)       # 512 MiB
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    del a, b
+    lib = C.load_default_library()
+    ctx = C.Context(lib, 0)
+    L = 2 * math.pi
+    for n, iters in ((512, 4), (256, 6)):
+        grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rhs = torch.randn(1, n, n, n, generator=g)
+        rhs -= rhs.mean()
+        rhs = rhs.to(dev)
+        x = torch.zeros_like(rhs)
+        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 0, 0, 0), want_info=False)
+        torch.cuda.synchronize()
+        del rhs, x
+
+
+if __name__ == "__main__":
+    main()
