@@ -382,8 +382,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     if (f & 32u) r += (hi2 - c) * p.w2;
                     if (!(f & 64u)) r = c;   // inactive cell: identity row (fluid.py:202)
                 } else {
-                    r = (lo2 + hi2 - T(2) * c) * p.w2 + (up.v[v] + dn.v[v] - T(2) * c) * p.w1;
-                    if (DIM3) r += (Sp[rr].v[v] + Sn[rr].v[v] - T(2) * c) * p.w0;
+                    // flux form like the reference (differences of neighbours first, then the difference of the two face
+                    // fluxes): the rounding error scales with |grad p| instead of |p| -- with (lo + hi - 2c) CG stagnates
+                    // an order of magnitude above the reference's residual floor in fp32.
+                    const T t2 = ((hi2 - c) - (c - lo2)) * p.w2;
+                    const T t1 = ((dn.v[v] - c) - (c - up.v[v])) * p.w1;
+                    if (DIM3) r = ((Sn[rr].v[v] - c) - (c - Sp[rr].v[v])) * p.w0 + t1 + t2;
+                    else r = t1 + t2;
                 }
                 q.v[v] = r;
             }

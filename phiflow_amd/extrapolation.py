@@ -139,6 +139,9 @@ def as_extrapolation(obj) -> Extrapolation:
         return obj
     if obj is None:
         return ZERO
+    from .geom import Vector
+    if isinstance(obj, Vector):
+        return ConstantExtrapolation(dict(obj))
     if isinstance(obj, dict):
         sides: Dict[str, list] = {}
         for key, val in obj.items():

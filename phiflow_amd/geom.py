@@ -8,9 +8,13 @@ from typing import Dict, Sequence, Tuple
 import numpy as np
 
 
-def vec(**components) -> Dict[str, float]:
+class Vector(dict):
+    """ named vector `vec(x=1, y=0)` """
+
+
+def vec(**components) -> Vector:
     """ `vec(x=1, y=0)`: named vector, e.g. a wall velocity for a constant extrapolation """
-    return dict(components)
+    return Vector(components)
 
 
 class Geometry:

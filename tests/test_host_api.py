@@ -1,0 +1,175 @@
+"""
+The phi-level mirror (`phiflow_amd.flow`) exercised the way the reference's own tests exercise PhiFlow
+(/root/reference tests/commit/physics/test_fluid.py, test_advect.py, tests/commit/field/test__grid.py). Runs on CPU with the
+kernel sources under the fiber emulation (test infrastructure); tests/test_gpu_api.py repeats the core of it on the MI355X.
+"""
+import numpy as np
+import pytest
+
+from phiflow_amd import _capi
+from phiflow_amd.flow import (BOUNDARY, PERIODIC, ZERO, Box, CenteredGrid, Diverged, NotConverged, Obstacle, Solve, Sphere,
+                              StaggeredGrid, advect, combine_sides, diffuse, divergence, fluid, spatial_gradient, vec)
+
+
+def test_staggered_storage_sizes(emu_backend):
+    """ tests/commit/field/test__grid.py:25-36 """
+    for ext, nx in ((ZERO, 19), (PERIODIC, 20), (BOUNDARY, 21)):
+        v = StaggeredGrid(0, ext, x=20, y=10, backend=emu_backend)
+        assert v['x'].values.shape[1:] == (nx, 10)
+        assert v['y'].values.shape[1:] == (20, nx - 10)
+        assert v.resolution == {'x': 20, 'y': 10}
+
+
+def test_with_extrapolation_restores_wall_faces(emu_backend):
+    """ tests/commit/field/test__grid.py:85-94: BOUNDARY -> ZERO -> BOUNDARY leaves zeros on the wall faces """
+    rng = np.random.default_rng(0)
+    vals = [rng.standard_normal((21, 10)).astype(np.float32), rng.standard_normal((20, 11)).astype(np.float32)]
+    grid = StaggeredGrid(vals, BOUNDARY, x=20, y=10, backend=emu_backend)
+    grid_0 = grid.with_extrapolation(ZERO)
+    assert grid_0['x'].values.shape[1:] == (19, 10)
+    grid_ = grid_0.with_extrapolation(BOUNDARY)
+    assert grid_.resolution == grid.resolution
+    vx, vy = grid_.numpy()
+    assert np.all(vx[0] == 0) and np.all(vx[-1] == 0) and np.all(vy[:, 0] == 0) and np.all(vy[:, -1] == 0)
+    np.testing.assert_array_equal(vx[1:-1], vals[0][1:-1])
+
+
+def test_self_advect_staggered_known_answer(emu_backend):
+    """ tests/commit/physics/test_advect.py:41-45 """
+    v0 = StaggeredGrid(Box(x=(.9, 2.6), y=(.9, 2)), 0, x=4, y=3, backend=emu_backend) * (0, 1)
+    v = advect.semi_lagrangian(v0, v0, 1)
+    np.testing.assert_allclose(v['x'].numpy(), 0, atol=1e-6)
+    np.testing.assert_allclose(v['y'].numpy().T, [[0, 0, 0, 0], [0, 1, 1, 0]], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("ext", [ZERO, BOUNDARY, PERIODIC])
+def test_identity_advection(emu_backend, ext):
+    """ tests/commit/physics/test_advect.py:12-18 """
+    rng = np.random.default_rng(1)
+    shapes = StaggeredGrid(0, ext, x=4, y=3, backend=emu_backend).component_shapes
+    sv = StaggeredGrid([rng.standard_normal(s).astype(np.float32) for s in shapes], ext, x=4, y=3, backend=emu_backend)
+    s = CenteredGrid(rng.standard_normal((4, 3)).astype(np.float32), ext, x=4, y=3, backend=emu_backend)
+    for adv in (advect.advect, advect.semi_lagrangian):
+        for a, b in zip(adv(sv, sv, 0).numpy(), sv.numpy()):
+            np.testing.assert_allclose(a, b, atol=1e-5)
+        for a, b in zip(adv(sv, sv * 0, 1).numpy(), sv.numpy()):
+            np.testing.assert_allclose(a, b, atol=1e-5)
+        np.testing.assert_allclose(adv(s, sv, 0).numpy(), s.numpy(), atol=1e-5)
+        np.testing.assert_allclose(adv(s, sv * 0, 1).numpy(), s.numpy(), atol=1e-5)
+
+
+def _test_make_incompressible(backend, extrapolation, batch=None):
+    """ tests/commit/physics/test_fluid.py:19-32 """
+    rng = np.random.default_rng(2)
+    bounds = Box['x,y', 0:100, 0:100]
+    xs = rng.uniform(0, 100, size=batch or 1)
+    smoke_vals = np.stack([CenteredGrid(Sphere(x=x0, y=10, radius=5), extrapolation, bounds, x=16, y=20, backend=backend).numpy() for x0 in xs])
+    smoke = CenteredGrid(smoke_vals if batch else smoke_vals[0], extrapolation, bounds, x=16, y=20, backend=backend)
+    velocity = StaggeredGrid(0, extrapolation, bounds, x=16, y=20, batch=batch, backend=backend)
+    for _ in range(2):
+        velocity += smoke * (0, 0.1) @ velocity
+        velocity, pressure = fluid.make_incompressible(velocity)
+    assert np.abs(divergence(velocity).numpy()).max() <= 5e-5
+    assert pressure.is_centered and pressure.resolution == velocity.resolution
+    return velocity
+
+
+@pytest.mark.parametrize("name,ext", [("closed", ZERO), ("open", BOUNDARY), ("periodic", PERIODIC),
+                                      ("mixed", combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY)))])
+def test_make_incompressible_staggered(emu_backend, name, ext):
+    """ tests/commit/physics/test_fluid.py:38-53 (unbatched and with a batch of 3) """
+    _test_make_incompressible(emu_backend, ext)
+    _test_make_incompressible(emu_backend, ext, batch=3)
+
+
+def test_make_incompressible_matches_oracle(emu_backend):
+    from oracle import phi_oracle as O
+    rng = np.random.default_rng(3)
+    bounds = Box['x,y', 0:100, 0:100]
+    ext = combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY))
+    shapes = StaggeredGrid(0, ext, bounds, x=16, y=20, backend=emu_backend).component_shapes
+    vals = [rng.standard_normal(s).astype(np.float32) * 0.1 for s in shapes]
+    v, p = fluid.make_incompressible(StaggeredGrid(vals, ext, bounds, x=16, y=20, backend=emu_backend), (), Solve('CG', 1e-5, 0))
+    dom = O.Domain((16, 20), (0, 0), (100, 100), ((O.OPEN, O.OPEN), (O.CLOSED, O.OPEN)))
+    vo, po, info, _ = O.make_incompressible([a[None] for a in vals], dom, rtol=1e-5, atol=0)
+    assert p.solve_info.iterations[0] == int(info.iterations[0])
+    np.testing.assert_allclose(p.numpy(), po[0], atol=2e-4 * np.abs(po).max())
+    for a, b in zip(v.numpy(), vo):
+        np.testing.assert_allclose(a, b[0], atol=1e-5)
+
+
+def test_obstacles_and_x0(emu_backend):
+    """ Batched_Smoke / Lid_Driven_Cavity style: box obstacle in a closed domain, warm start from the previous pressure """
+    rng = np.random.default_rng(4)
+    bounds = Box(x=32, y=32)
+    shapes = StaggeredGrid(0, ZERO, bounds, x=32, y=32, backend=emu_backend).component_shapes
+    v = StaggeredGrid([rng.standard_normal(s).astype(np.float32) * 0.1 for s in shapes], ZERO, bounds, x=32, y=32, backend=emu_backend)
+    obstacle = Obstacle(Box(x=(12, 20), y=(10, 16)))
+    v1, p1 = fluid.make_incompressible(v, obstacle, Solve('CG', 1e-5, 0))
+    vx, vy = v1.numpy()
+    # faces inside / on the obstacle carry no flow
+    assert np.abs(vx[12:20, 10:16]).max() == 0
+    div = divergence(v1).numpy()
+    active = np.ones((32, 32), bool); active[12:20, 10:16] = False
+    assert np.abs(div[active]).max() <= 5e-5
+    it_cold = p1.solve_info.iterations[0]
+    v2, p2 = fluid.make_incompressible(v, [obstacle], Solve('CG', 1e-5, 0, x0=p1))
+    assert p2.solve_info.iterations[0] <= max(2, it_cold // 4)       # warm start converges almost immediately
+    np.testing.assert_allclose(p2.numpy(), p1.numpy(), atol=1e-3 * np.abs(p1.numpy()).max())
+
+
+def test_convergence_exceptions(emu_backend):
+    """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
+    rng = np.random.default_rng(5)
+    shapes = StaggeredGrid(0, PERIODIC, x=16, y=16, backend=emu_backend).component_shapes
+    v = StaggeredGrid([rng.standard_normal(s).astype(np.float32) for s in shapes], PERIODIC, x=16, y=16, backend=emu_backend)
+    with pytest.raises(NotConverged) as e:
+        fluid.make_incompressible(v, (), Solve('CG', 1e-6, 0, max_iterations=2))
+    assert e.value.result.iterations == [2]
+    v2, p2 = fluid.make_incompressible(v, (), Solve('CG', 0, 0, max_iterations=7, suppress=[NotConverged]))   # benchmark mode
+    assert p2.solve_info.iterations == [7]
+    with pytest.raises(NotImplementedError):
+        fluid.make_incompressible(v, (), Solve('biCG-stab(2)', 1e-5))
+    with pytest.raises(NotImplementedError):
+        fluid.make_incompressible(v, (), order=4)
+
+
+def test_lid_driven_cavity_boundaries_and_diffusion(emu_backend):
+    """ Lid_Driven_Cavity.ipynb cell 5 boundary: {'x': 0, 'y-': 0, 'y+': vec(x=1, y=0)}; diffuse.explicit pads with it """
+    from oracle import phi_oracle as O
+    boundary = {'x': 0, 'y-': 0, 'y+': vec(x=1, y=0)}
+    v = StaggeredGrid(0, boundary, x=8, y=8, backend=emu_backend)
+    v = diffuse.explicit(v, 0.1, 1.0)
+    vx, vy = v.numpy()
+    bcv = np.zeros((2, 2, 2)); bcv[1, 1, 0] = 1.0
+    dom = O.Domain((8, 8), (0, 0), (8, 8), ((O.CLOSED, O.CLOSED),) * 2, bcv)
+    ref = O.diffuse_explicit([np.zeros((1, 7, 8), np.float32), np.zeros((1, 8, 7), np.float32)], 0.1, 1.0, dom)
+    np.testing.assert_allclose(vx, ref[0][0], atol=1e-7)
+    np.testing.assert_allclose(vy, ref[1][0], atol=1e-7)
+    assert vx[:, -1].max() > 0 and np.all(vx[:, :-1] == 0)       # the lid drags the top row of x-faces
+    v, p = fluid.make_incompressible(advect.semi_lagrangian(v, v, 0.5), (), Solve('CG', 1e-5, 0))
+    assert np.abs(divergence(v).numpy()).max() <= 5e-5
+
+
+def test_spatial_gradient_at_faces(emu_backend):
+    from oracle import phi_oracle as O
+    from phiflow_amd.extrapolation import pressure_extrapolation
+    rng = np.random.default_rng(6)
+    vb = combine_sides(x=PERIODIC, y=(ZERO, BOUNDARY))
+    p = CenteredGrid(rng.standard_normal((8, 6)).astype(np.float32), pressure_extrapolation(vb, ('x', 'y')), Box(x=4, y=3), x=8, y=6,
+                     backend=emu_backend)
+    g = spatial_gradient(p, vb, at='face')
+    dom = O.Domain((8, 6), (0, 0), (4, 3), ((O.PERIODIC, O.PERIODIC), (O.CLOSED, O.OPEN)))
+    ref = O.pressure_gradient(p.numpy()[None], dom)
+    for a, b in zip(g.numpy(), ref):
+        np.testing.assert_allclose(a, b[0], rtol=1e-5, atol=1e-6)
+
+
+def test_fp64_precision_context(emu_backend):
+    from phiflow_amd.flow import precision
+    import torch
+    with precision(64):
+        v = StaggeredGrid(lambda x, y: (np.sin(x), np.cos(y)), PERIODIC, Box(x=2 * np.pi, y=2 * np.pi), x=16, y=16, backend=emu_backend)
+        assert v.dtype == torch.float64
+        v, p = fluid.make_incompressible(v, (), Solve('CG', 1e-12, 1e-12))
+        assert np.abs(divergence(v).numpy()).max() <= 1e-10

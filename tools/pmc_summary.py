@@ -21,7 +21,7 @@ def classify(name):
     if "march_kernel" in name:
         m = re.search(r"march_kernel<\s*(\w+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", name)
         mode = {0: "laplace_apply", 1: "cg_residual", 2: "cg_matvec_dot", 3: "cg_update"}.get(int(m.group(5)), "march") if m else "march"
-        return mode
+        return f"{mode}<{m.group(1)},V{m.group(2)},R{m.group(3)},TPR{m.group(4)}>" if m else mode
     if "elementwise" in name.lower() or "copy" in name.lower():
         return "calib_copy"
     return None
