@@ -44,42 +44,55 @@ __device__ __forceinline__ T fetch_comp(const T* C, const VelGrid& g, int ca, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // divergence (phi/field/_field_math.py:617-626 with bake_extrapolation :20-39)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+constexpr int kMaxPartialBlocks = 2048;   // grid-stride kernels: bounded number of per-block partial sums
+
+template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
-                                                            T* div, double* part_sum, double* part_act, int nblk) {
+                                                            T* __restrict__ div, double* part_sum, double* part_act, int nblk) {
+    constexpr int A0 = 3 - DIM;
     __shared__ double red[kBlock / kWave];
     const int b = blockIdx.y;
-    const long long cell = (long long)blockIdx.x * kBlock + threadIdx.x;
-    T val = T(0);
-    T act = T(0);
-    if (cell < g.cells) {
-        const int i2 = (int)(cell % g.n[2]);
-        const int i1 = (int)((cell / g.n[2]) % g.n[1]);
-        const int i0 = (int)(cell / ((long long)g.n[2] * g.n[1]));
-        const int idx[3] = {i0, i1, i2};
+    const int cells = (int)g.cells;
+    const int n1 = g.n[1], n2 = g.n[2];
+    T acc_val = T(0), acc_act = T(0);
+    for (int cell = blockIdx.x * kBlock + threadIdx.x; cell < cells; cell += gridDim.x * kBlock) {
+        int idx[3];
+        idx[2] = cell % n2;
+        const int t = cell / n2;
+        idx[1] = t % n1;
+        idx[0] = t / n1;
         T sum = T(0);
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            if (ax < g.ax0) continue;
-            int lo[3] = {i0, i1, i2}, hi[3] = {i0, i1, i2};
-            lo[ax] = idx[ax] - g.off[ax];
-            hi[ax] = idx[ax] + 1 - g.off[ax];
-            const long long bb = (long long)b * g.ccells[ax];
-            const T vl = fetch_comp<T>(v.p[ax], g, ax, bb, lo[0], lo[1], lo[2]);
-            const T vh = fetch_comp<T>(v.p[ax], g, ax, bb, hi[0], hi[1], hi[2]);
+        for (int ax = A0; ax < 3; ++ax) {
+            const int c1 = g.cn[ax][1], c2 = g.cn[ax][2];
+            const int stride = ax == 0 ? c1 * c2 : (ax == 1 ? c2 : 1);
+            const int lo = idx[ax] - g.off[ax], hi = lo + 1;
+            const T* __restrict__ C = v.p[ax] + (long long)b * g.ccells[ax];
+            T vl, vh;
+            if (lo >= 0 && hi < g.cn[ax][ax]) {   // interior: both faces stored
+                const int base = (idx[0] * c1 + idx[1]) * c2 + idx[2] - idx[ax] * stride;
+                vl = C[base + lo * stride];
+                vh = C[base + hi * stride];
+            } else {
+                int l[3] = {idx[0], idx[1], idx[2]}, h[3] = {idx[0], idx[1], idx[2]};
+                l[ax] = lo; h[ax] = hi;
+                vl = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], l[0], l[1], l[2]);
+                vh = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], h[0], h[1], h[2]);
+            }
             sum += (vh - vl) / (T)g.dx[ax];
         }
-        act = T(1);
+        T act = T(1);
         if (flags) {
-            const unsigned f = flags[(flags_per_batch ? (long long)b * g.cells : 0) + cell];
+            const unsigned f = flags[(flags_per_batch ? (long long)b * cells : 0) + cell];
             act = (f & 64u) ? T(1) : T(0);
             sum *= act;
         }
-        div[(long long)b * g.cells + cell] = sum;
-        val = sum;
+        div[(long long)b * cells + cell] = sum;
+        acc_val += sum;
+        acc_act += act;
     }
-    const double s1 = block_sum((double)val, red);
-    const double s2 = block_sum((double)act, red);
+    const double s1 = block_sum((double)acc_val, red);
+    const double s2 = block_sum((double)acc_act, red);
     if (threadIdx.x == 0) {
         part_sum[(long long)b * nblk + blockIdx.x] = s1;
         part_act[(long long)b * nblk + blockIdx.x] = s2;
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void balance_scalar_kernel(const double* pa
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void balance_apply_kernel(T* div, const uint8_t* flags, int flags_per_batch, const double* shift,
+__global__ __launch_bounds__(kBlock) void balance_apply_kernel(T* __restrict__ div, const uint8_t* flags, int flags_per_batch, const double* shift,
                                                                long long cells) {
     const int b = blockIdx.y;
     const T sh = (T)shift[b];
@@ -112,10 +125,21 @@ __global__ __launch_bounds__(kBlock) void balance_apply_kernel(T* div, const uin
     }
 }
 
+template <typename T, int DIM>
+static void launch_divergence(const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
+                              double* part_sum, double* part_act, int nblk, hipStream_t s) {
+    CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk);
+}
+
 int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const uint8_t* flags, int mask_batch, int balance,
                    void* div, hipStream_t s) {
+    if (v.cells >= (1LL << 31)) {
+        set_error("divergence: more than 2^31 cells per batch entry are not supported");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
     const VelGrid g = make_velgrid(v);
-    const int nblk = ceil_div(v.cells, kBlock);
+    const int nblk = ceil_div(v.cells, kBlock) < kMaxPartialBlocks ? ceil_div(v.cells, kBlock) : kMaxPartialBlocks;
     PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
     double* part_sum = (double*)ctx->ws_div.ptr;
@@ -125,20 +149,18 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
     {
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         if (v.dtype == PHIHIP_F64) {
-            CComp3<double> c{{(const double*)vel[0], (const double*)vel[1], (const double*)vel[2]}};
-            hipLaunchKernelGGL(divergence_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (double*)div,
-                               part_sum, part_act, nblk);
+            if (v.rank == 3) launch_divergence<double, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
+            else launch_divergence<double, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
         } else {
-            CComp3<float> c{{(const float*)vel[0], (const float*)vel[1], (const float*)vel[2]}};
-            hipLaunchKernelGGL(divergence_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (float*)div,
-                               part_sum, part_act, nblk);
+            if (v.rank == 3) launch_divergence<float, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
+            else launch_divergence<float, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
         }
     }
     if (balance) {
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         hipLaunchKernelGGL(balance_scalar_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)part_sum, (const double*)part_act,
                            nblk, shift);
-        const int nb2 = nblk < 4096 ? nblk : 4096;
+        const int nb2 = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
         if (v.dtype == PHIHIP_F64)
             hipLaunchKernelGGL(balance_apply_kernel<double>, dim3(nb2, v.batch), dim3(kBlock), 0, s, (double*)div, flags, fpb,
                                (const double*)shift, v.cells);
@@ -153,55 +175,71 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
 // ---------------------------------------------------------------------------------------------------------------------
 // v_d[f] -= h_f (p_R - p_L) / dx_d   (phi/physics/fluid.py:158-161; stagger :535-581)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, int ca, T* vc, const T* p, const uint8_t* flags,
+template <typename T, int DIM, int CA>
+__global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, T* __restrict__ vc, const T* __restrict__ p, const uint8_t* flags,
                                                                int flags_per_batch) {
+    constexpr int ca = CA;
     const int b = blockIdx.y;
-    const long long total = g.ccells[ca];
+    const int total = (int)g.ccells[ca];
     const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
-    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
+    const int n = g.n[ca];
+    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
+    const T* __restrict__ P = p + (long long)b * g.cells;
+    const uint8_t* F = flags ? flags + (flags_per_batch ? (long long)b * g.cells : 0) : nullptr;
+    T* __restrict__ V = vc + (long long)b * total;
+    const T dx = (T)g.dx[ca];
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
         int idx[3];
-        idx[2] = (int)(f % c2);
-        idx[1] = (int)((f / c2) % c1);
-        idx[0] = (int)(f / ((long long)c2 * c1));
+        idx[2] = f % c2;
+        const int t = f / c2;
+        idx[1] = t % c1;
+        idx[0] = t / c1;
         const int phys = idx[ca] + g.off[ca];
-        const int n = g.n[ca];
-        int L[3] = {idx[0], idx[1], idx[2]}, Rr[3] = {idx[0], idx[1], idx[2]};
         int l = phys - 1, r = phys;
-        bool zl = false, zr = false, l_in = l >= 0, r_in = r < n;
-        if (l < 0) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
-        if (r >= n) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
-        L[ca] = l; Rr[ca] = r;
-        const long long pb = (long long)b * g.cells;
-        const long long offL = ((long long)L[0] * g.n[1] + L[1]) * g.n[2] + L[2];
-        const long long offR = ((long long)Rr[0] * g.n[1] + Rr[1]) * g.n[2] + Rr[2];
-        const T pl = zl ? T(0) : p[pb + offL];
-        const T pr = zr ? T(0) : p[pb + offR];
+        bool zl = false, zr = false;
+        const bool l_in = l >= 0, r_in = r < n;
+        if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
+        if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
+        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;   // other axes coincide with cell indices
+        const int offL = rest + l * pstride, offR = rest + r * pstride;
+        const T pl = zl ? T(0) : P[offL];
+        const T pr = zr ? T(0) : P[offR];
         T h = T(1);
-        if (flags) {
-            const long long fb = flags_per_batch ? pb : 0;
+        if (F) {
             // the face is the lower face of cell R (if R exists in the domain or by wrap) else the upper face of cell L
-            if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) h = (flags[fb + offR] >> (2 * ca)) & 1u ? T(1) : T(0);
-            else if (l_in) h = (flags[fb + offL] >> (2 * ca + 1)) & 1u ? T(1) : T(0);
+            if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) h = (F[offR] >> (2 * ca)) & 1u ? T(1) : T(0);
+            else if (l_in) h = (F[offL] >> (2 * ca + 1)) & 1u ? T(1) : T(0);
         }
-        const long long vo = (long long)b * total + f;
-        vc[vo] = vc[vo] - h * ((pr - pl) / (T)g.dx[ca]);
+        V[f] = V[f] - h * ((pr - pl) / dx);
     }
+}
+
+template <typename T, int DIM>
+static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint8_t* flags, int fpb, const void* p, void* const vel[3],
+                                 hipStream_t s) {
+    auto nb = [&](int ca) { return ceil_div(v.ccells[ca], kBlock) < 16384 ? ceil_div(v.ccells[ca], kBlock) : 16384; };
+    if (DIM == 3)
+        hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 0>), dim3(nb(0), v.batch), dim3(kBlock), 0, s, g, (T*)vel[0], (const T*)p, flags, fpb);
+    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 1>), dim3(nb(1), v.batch), dim3(kBlock), 0, s, g, (T*)vel[1], (const T*)p, flags, fpb);
+    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 2>), dim3(nb(2), v.batch), dim3(kBlock), 0, s, g, (T*)vel[2], (const T*)p, flags, fpb);
 }
 
 int run_grad_subtract(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* const vel[3],
                       hipStream_t s) {
+    for (int ca = v.ax0; ca < 3; ++ca)
+        if (v.ccells[ca] >= (1LL << 31)) {
+            set_error("grad_subtract: more than 2^31 samples per component and batch entry are not supported");
+            return PHIHIP_ERR_UNSUPPORTED;
+        }
     const VelGrid g = make_velgrid(v);
     const int fpb = mask_batch > 1 ? 1 : 0;
     LaunchScope ls(ctx, PHIHIP_K_GRAD_SUBTRACT, s);
-    for (int ca = v.ax0; ca < 3; ++ca) {
-        const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
-        if (v.dtype == PHIHIP_F64)
-            hipLaunchKernelGGL(grad_subtract_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (double*)vel[ca],
-                               (const double*)p, flags, fpb);
-        else
-            hipLaunchKernelGGL(grad_subtract_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (float*)vel[ca],
-                               (const float*)p, flags, fpb);
+    if (v.dtype == PHIHIP_F64) {
+        if (v.rank == 3) launch_grad_subtract<double, 3>(v, g, flags, fpb, p, vel, s);
+        else launch_grad_subtract<double, 2>(v, g, flags, fpb, p, vel, s);
+    } else {
+        if (v.rank == 3) launch_grad_subtract<float, 3>(v, g, flags, fpb, p, vel, s);
+        else launch_grad_subtract<float, 2>(v, g, flags, fpb, p, vel, s);
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

@@ -20,6 +20,9 @@ if [[ "$STEPS" == *all* || "$STEPS" == *sweep* ]]; then
   echo "== sweep 256"; timeout 300 python tools/sweep_cg.py --size 256 --iters 10 > gpurun_out/sweep_256.jsonl 2> gpurun_out/sweep_256.err; echo "rc=$?"
   echo "== sweep 512"; timeout 300 python tools/sweep_cg.py --size 512 --iters 6 > gpurun_out/sweep_512.jsonl 2> gpurun_out/sweep_512.err; echo "rc=$?"
 fi
+if [[ "$STEPS" == *all* || "$STEPS" == *configs* ]]; then
+  echo "== configs 3/4/5"; timeout 600 python tools/bench_configs.py > gpurun_out/configs.jsonl 2> gpurun_out/configs.err; echo "rc=$?"; cat gpurun_out/configs.jsonl; tail -3 gpurun_out/configs.err
+fi
 if [[ "$STEPS" == *all* || "$STEPS" == *prof* ]]; then
   echo "== rocprofv3 stats (bench)"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-size 0 --profile-steps 0 > "$REPO/gpurun_out/rocprof_bench.log" 2>&1); echo "rc=$?"
