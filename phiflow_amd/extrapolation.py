@@ -81,6 +81,12 @@ class ConstantExtrapolation(Extrapolation):
     """ constant value outside; `value` is a number or a per-component vector (dict dim->value or sequence) """
 
     def __init__(self, value: Union[float, Dict[str, float], Sequence[float]]):
+        if isinstance(value, dict):
+            value = {k: float(v) for k, v in value.items()}
+        elif isinstance(value, (tuple, list)):
+            value = tuple(float(v) for v in value)
+        else:
+            value = float(value)
         self.value = value
 
     def component_value(self, comp: int, comp_name: Optional[str]) -> float:
