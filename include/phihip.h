@@ -104,6 +104,23 @@ int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void
 int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
                            const double s_val[3][2], const void* const velocity[3], void* out, double dt, void* stream);
 
+/* ---- f2: advect.mac_cormack (phi/physics/advect.py:182-215) -------------------------------------------------------- */
+/* forward + backward semi-Lagrangian pass, `fwd + correction_strength * 0.5 * (field - bwd)`, clamped to the min / max of
+ * the grid values around the backward lookup (Field.closest_values, phi/field/_field.py:409-429). out must not alias. */
+int phihip_mac_cormack_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3],
+                                 const void* const velocity[3], void* const out[3], double dt, double correction_strength,
+                                 void* stream);
+int phihip_mac_cormack_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                const double s_val[3][2], const void* const velocity[3], void* out, double dt,
+                                double correction_strength, void* stream);
+
+/* ---- f2: resample(s * vector, to=velocity) / `s * vector @ velocity` (phi/field/_resample.py:156-157,272-276;
+ *          buoyancy in Smoke_Plume.ipynb cell 5, tests/commit/physics/test_fluid.py:26) -------------------------------- */
+/* out_d = mean of the two cells adjacent to each stored d-face of (s * vector[d]); accumulate != 0 adds to out instead */
+int phihip_centered_to_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                 const double s_val[3][2], const double vector[3], int accumulate, void* const out[3],
+                                 void* stream);
+
 /* ---- a7: obstacle masks (phi/physics/fluid.py:130-137) ---------------------------------------------------------- */
 /* Packs per-cell stencil flags (1 byte / cell): bit 2*axis+side = the face on that side is open for flux
  * (hard_bcs = min(accessible_L, accessible_R), outside cells: periodic wrap / OPEN 1 / CLOSED 0), bit 6 = active.

@@ -358,6 +358,99 @@ def semi_lagrangian_centered(s: np.ndarray, velocity: List[np.ndarray], dt: floa
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# f2: MacCormack advection (phi/physics/advect.py:182-215) and centred -> staggered resampling (buoyancy)
+# --------------------------------------------------------------------------------------------------------------------
+def closest_limits(a: np.ndarray, coords: List[np.ndarray], codes, consts):
+    """ min / max over the 2^D grid values surrounding the fractional index coordinates: `Field.closest_values`
+    (phi/field/_field.py:409-429 -> phiml closest_grid_values: the floor / floor+1 taps, outside taps from the
+    extrapolation) reduced with math.min / math.max over the `closest_<dim>` dims (advect.py:210-212). """
+    D = a.ndim - 1
+    i0 = [np.floor(c).astype(np.int64) for c in coords]
+    lo = hi = None
+    for corner in range(1 << D):
+        idx = [i0[axis] + ((corner >> axis) & 1) for axis in range(D)]
+        t = _tap(a, idx, codes, consts)
+        lo = t if lo is None else np.minimum(lo, t)
+        hi = t if hi is None else np.maximum(hi, t)
+    return lo, hi
+
+
+def _centered_lookup_coords(velocity: List[np.ndarray], dt: float, dom: Domain, dtype):
+    """ index coordinates of `cell centre + dt * v0`, v0 = staggered velocity at the centres (euler, advect.py:20-24) """
+    pts = cell_positions(dom, dtype)
+    u = staggered_at_centers(velocity, dom)
+    coords = []
+    for a in range(dom.rank):
+        look = pts[a][None] + u[a] * dtype(dt)
+        coords.append((look - dtype(dom.lower[a])) / dtype(dom.upper[a] - dom.lower[a]) * dtype(dom.res[a]) - dtype(0.5))
+    return coords
+
+
+def mac_cormack_centered(s: np.ndarray, velocity: List[np.ndarray], dt: float, dom: Domain, s_codes, s_consts=None,
+                         correction_strength: float = 1.0):
+    """ advect.mac_cormack for a centred scalar (advect.py:203-215): forward + backward semi-Lagrangian pass, error
+    correction `fwd + strength * 0.5 * (field - bwd)`, clamped to the closest grid values of the backward lookup. """
+    D = dom.rank
+    dtype = s.dtype.type
+    consts = s_consts if s_consts is not None else [(0.0, 0.0)] * D
+    c_bwd = _centered_lookup_coords(velocity, -dt, dom, dtype)
+    c_fwd = _centered_lookup_coords(velocity, dt, dom, dtype)
+    fwd_adv = grid_sample(s, c_bwd, s_codes, consts)
+    bwd_adv = grid_sample(fwd_adv, c_fwd, s_codes, consts)
+    new = fwd_adv + dtype(correction_strength * 0.5) * (s - bwd_adv)
+    lo, hi = closest_limits(s, c_bwd, s_codes, consts)
+    return np.clip(new, lo, hi)
+
+
+def mac_cormack_staggered(field: List[np.ndarray], velocity: List[np.ndarray], dt: float, dom: Domain,
+                          correction_strength: float = 1.0):
+    """ advect.mac_cormack for a StaggeredGrid advected by a StaggeredGrid with the same boundary (advect.py:203-215).
+    Note on the limiter: `Field.closest_values` (phi/field/_field.py:427-429) returns from its "CenteredGrid" branch for
+    every field, i.e. it converts the lookup points with the CELL grid's box and resolution (`box.global_to_local(points)
+    * resolution - 0.5`) also for staggered components. Along its own axis d a face with physical number m therefore gets
+    the index coordinate m - 0.5 instead of its stored index m - off_d: the clamp window of component d is shifted by
+    half a cell. This restatement follows the reference literally (the staggered branch below that return is dead code). """
+    D = dom.rank
+    dtype = field[0].dtype.type
+    out = []
+    for d in range(D):
+        pts = face_positions(d, dom, dtype)
+        u = [velocity[d] if c == d else component_at_faces(velocity, c, d, dom) for c in range(D)]
+        p_bwd = [pts[a][None] + u[a] * dtype(-dt) for a in range(D)]
+        p_fwd = [pts[a][None] + u[a] * dtype(dt) for a in range(D)]
+        codes, consts = _comp_codes(dom, d)
+        fwd_adv = grid_sample(field[d], _index_coords(p_bwd, d, dom, dtype), codes, consts)
+        bwd_adv = grid_sample(fwd_adv, _index_coords(p_fwd, d, dom, dtype), codes, consts)
+        new = fwd_adv + dtype(correction_strength * 0.5) * (field[d] - bwd_adv)
+        cell_frame = [(p_bwd[a] - dtype(dom.lower[a])) / dtype(dom.upper[a] - dom.lower[a]) * dtype(dom.res[a]) - dtype(0.5)
+                      for a in range(D)]
+        lo, hi = closest_limits(field[d], cell_frame, codes, consts)
+        out.append(np.clip(new, lo, hi))
+    return out
+
+
+def centered_to_staggered(s: np.ndarray, dom: Domain, s_codes, s_consts=None, vector: Optional[Sequence[float]] = None):
+    """ `resample(s * vector, to=velocity)` / `s * vector @ velocity` (Smoke_Plume.ipynb cell 5, test_fluid.py:26):
+    sample_grid_at_faces (phi/field/_resample.py:272-276) -> per component the mean of the two cells adjacent to each
+    stored face, cells outside the domain from the scalar's extrapolation; then times the constant vector component. """
+    D = dom.rank
+    dtype = s.dtype.type
+    vector = [1.0] * D if vector is None else vector
+    out = []
+    for d in range(D):
+        widths = [(0, 0)] * D
+        widths[d] = (1, 1)
+        p = pad_scalar(s, widths, s_codes, s_consts)
+        lo = [slice(None)] * (D + 1); hi = [slice(None)] * (D + 1)
+        off = dom.face_offset(d)
+        n = dom.comp_shape(d)[d]
+        lo[d + 1] = slice(off, off + n); hi[d + 1] = slice(off + 1, off + 1 + n)
+        p = p * dtype(vector[d])     # `s * vector` is formed first, then resampled
+        out.append(p[tuple(lo)] * dtype(0.5) + p[tuple(hi)] * dtype(0.5))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # a2: divergence (phi/field/_field_math.py:589,617-626)
 # --------------------------------------------------------------------------------------------------------------------
 def divergence(v: List[np.ndarray], dom: Domain):

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "phihip_component_shape", "phihip_advect_staggered", "phihip_advect_centered", "phihip_build_cellflags",
     "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_grad_subtract",
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
-    "phihip_set_tuning",
+    "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
 )
 
 
@@ -109,6 +109,12 @@ class Library:
         d.phihip_advect_staggered.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
         d.phihip_advect_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
                                              POINTER(_Ptr3), c_void_p, c_double, c_void_p]
+        d.phihip_mac_cormack_staggered.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_double,
+                                                   c_void_p]
+        d.phihip_mac_cormack_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
+                                                  POINTER(_Ptr3), c_void_p, c_double, c_double, c_void_p]
+        d.phihip_centered_to_staggered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
+                                                   POINTER(c_double * 3), c_int, POINTER(_Ptr3), c_void_p]
         d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         d.phihip_divergence.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p, c_void_p]
         d.phihip_laplace_apply.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
@@ -162,15 +168,38 @@ class Context:
         self.lib.check(self.lib.dll.phihip_advect_staggered(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)),
                                                             ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(out)), float(dt), stream or None))
 
-    def advect_centered(self, grid, s, s_bc, s_val, velocity, out, dt, stream=0):
+    @staticmethod
+    def _scalar_bc(grid, s_bc, s_val):
         bc = ((c_int32 * 2) * 3)()
         val = ((c_double * 2) * 3)()
         for d in range(grid.rank):
             for side in range(2):
                 bc[d][side] = int(s_bc[d][side])
                 val[d][side] = float(s_val[d][side]) if s_val is not None else 0.0
+        return bc, val
+
+    def advect_centered(self, grid, s, s_bc, s_val, velocity, out, dt, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
         self.lib.check(self.lib.dll.phihip_advect_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
                                                            ctypes.byref(ptr3(velocity)), out, float(dt), stream or None))
+
+    def mac_cormack_staggered(self, grid, field, velocity, out, dt, correction_strength=1.0, stream=0):
+        self.lib.check(self.lib.dll.phihip_mac_cormack_staggered(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)),
+                                                                 ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(out)), float(dt),
+                                                                 float(correction_strength), stream or None))
+
+    def mac_cormack_centered(self, grid, s, s_bc, s_val, velocity, out, dt, correction_strength=1.0, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        self.lib.check(self.lib.dll.phihip_mac_cormack_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
+                                                                ctypes.byref(ptr3(velocity)), out, float(dt), float(correction_strength),
+                                                                stream or None))
+
+    def centered_to_staggered(self, grid, s, s_bc, s_val, vector, accumulate, out, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        vec = (c_double * 3)(*([float(x) for x in vector] + [0.0] * (3 - len(vector))))
+        self.lib.check(self.lib.dll.phihip_centered_to_staggered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
+                                                                 ctypes.byref(vec), int(bool(accumulate)), ctypes.byref(ptr3(out)),
+                                                                 stream or None))
 
     def build_cellflags(self, grid, accessible, active, mask_batch, flags, stream=0):
         self.lib.check(self.lib.dll.phihip_build_cellflags(self.handle, ctypes.byref(grid), accessible or None, active or None,

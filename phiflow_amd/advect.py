@@ -1,7 +1,7 @@
 """
 Advection schemes backed by libphihip (reference: phi/physics/advect.py).
-Implemented on the HIP backend: `semi_lagrangian` / `advect` with the `euler` integrator for StaggeredGrid and
-CenteredGrid fields advected by a StaggeredGrid velocity. Anything else raises `NotImplementedError`.
+Implemented on the HIP backend: `semi_lagrangian` / `advect` / `mac_cormack` with the `euler` integrator for StaggeredGrid
+and CenteredGrid fields advected by a StaggeredGrid velocity. Anything else raises `NotImplementedError`.
 """
 from typing import Callable
 
@@ -33,8 +33,20 @@ def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callab
     Returns:
         Field with the same sample points and boundary as `field`
     """
+    return _advect(field, velocity, dt, integrator, None)
+
+
+def _scalar_boundary(field: Field):
+    s_codes, s_vals = resolve(field.boundary, field.dims)
+    s_val = [[s_vals[a][s][0] if isinstance(field.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
+             for a, d in enumerate(field.dims)]
+    return s_codes, s_val
+
+
+def _advect(field: Field, velocity: Field, dt: float, integrator: Callable, correction_strength) -> Field:
+    """ shared argument handling of semi_lagrangian (correction_strength None) and mac_cormack """
     if integrator is not euler:
-        raise NotImplementedError("HIP backend: semi_lagrangian supports integrator=euler only")
+        raise NotImplementedError("HIP backend: grid advection supports integrator=euler only")
     if not velocity.is_staggered:
         raise NotImplementedError("HIP backend: the advecting velocity must be a StaggeredGrid")
     assert field.resolution == velocity.resolution and field.bounds.lower == velocity.bounds.lower and \
@@ -43,20 +55,25 @@ def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callab
     assert field.dtype == velocity.dtype, "field and velocity must have the same precision"
     B = max(field.batch_size, velocity.batch_size)
     vel = [_expand(t, B) for t in velocity.values]
+    grid = velocity.grid_struct(batch=B)
     if field.is_staggered:
         same_layout = [tuple(a.shape[1:]) for a in field.values] == [tuple(b.shape[1:]) for b in velocity.values]
         if not same_layout or resolve(field.boundary, field.dims) != resolve(velocity.boundary, velocity.dims):
             raise NotImplementedError("HIP backend: an advected StaggeredGrid must share the velocity's boundary conditions")
         src = vel if field is velocity else [_expand(t, B) for t in field.values]
         out = [torch.empty_like(t) for t in src]
-        be.ctx.advect_staggered(velocity.grid_struct(batch=B), _ptrs(src), _ptrs(vel), _ptrs(out), dt, be.stream())
+        if correction_strength is None:
+            be.ctx.advect_staggered(grid, _ptrs(src), _ptrs(vel), _ptrs(out), dt, be.stream())
+        else:
+            be.ctx.mac_cormack_staggered(grid, _ptrs(src), _ptrs(vel), _ptrs(out), dt, correction_strength, be.stream())
         return Field(field.resolution, field.bounds, field.boundary, out, True, be, field.batched or velocity.batched)
     src = _expand(field.values, B)
     out = torch.empty_like(src)
-    s_codes, s_vals = resolve(field.boundary, field.dims)
-    s_val = [[s_vals[a][s][0] if isinstance(field.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
-             for a, d in enumerate(field.dims)]
-    be.ctx.advect_centered(velocity.grid_struct(batch=B), src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, be.stream())
+    s_codes, s_val = _scalar_boundary(field)
+    if correction_strength is None:
+        be.ctx.advect_centered(grid, src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, be.stream())
+    else:
+        be.ctx.mac_cormack_centered(grid, src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, correction_strength, be.stream())
     return Field(field.resolution, field.bounds, field.boundary, out, False, be, field.batched or velocity.batched)
 
 
@@ -66,7 +83,17 @@ def advect(field: Field, velocity: Field, dt: float, integrator: Callable = eule
 
 
 def mac_cormack(field: Field, velocity: Field, dt: float, correction_strength=1.0, integrator: Callable = euler) -> Field:
-    raise NotImplementedError("mac_cormack is a next-row item (SURVEY §8 f2) and not yet available on the HIP backend")
+    """ MacCormack advection (phi/physics/advect.py:182-215): forward + backward semi-Lagrangian lookups estimate the first-order
+    error, the corrected value is clamped to the grid values around the backward lookup.
+
+    Args:
+        field: `CenteredGrid` or `StaggeredGrid` to be advected
+        velocity: `StaggeredGrid` on the same grid
+        dt: time increment
+        correction_strength: factor on the error estimate (0 = semi-Lagrangian)
+        integrator: only `euler` is available on the HIP backend
+    """
+    return _advect(field, velocity, dt, integrator, float(correction_strength))
 
 
 def _expand(t: torch.Tensor, B: int) -> torch.Tensor:

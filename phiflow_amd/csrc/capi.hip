@@ -80,6 +80,17 @@ VelGrid make_velgrid(const GridView& v) {
     return g;
 }
 
+ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const double s_val[3][2]) {
+    ScalarBc sb;
+    memset(&sb, 0, sizeof(sb));
+    for (int d = 0; d < v.rank; ++d)
+        for (int side = 0; side < 2; ++side) {
+            sb.bc[d + v.ax0][side] = s_bc[d][side];
+            sb.val[d + v.ax0][side] = s_val ? s_val[d][side] : 0.0;
+        }
+    return sb;
+}
+
 int ensure_buffer(DeviceBuffer& buf, size_t bytes) {
     if (buf.bytes >= bytes && buf.ptr) return PHIHIP_OK;
     if (buf.ptr) {
@@ -175,7 +186,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -190,7 +201,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes;
     return PHIHIP_OK;
 }
 
@@ -227,19 +238,71 @@ int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void
     return run_advect_staggered(ctx, v, f, u, o, dt, s);
 }
 
+static int check_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const char* what);
+
 int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
                            const double s_val[3][2], const void* const velocity[3], void* out, double dt, void* stream) {
     PHIHIP_ENTER(ctx, grid);
     PHIHIP_REQUIRE(sfield && out && s_bc, "advect_centered: NULL argument");
     PHIHIP_REQUIRE(sfield != out, "advect_centered: out must not alias the input");
     PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
-    for (int d = 0; d < v.rank; ++d)
-        PHIHIP_REQUIRE((s_bc[d][0] == PHIHIP_BC_PERIODIC) == (s_bc[d][1] == PHIHIP_BC_PERIODIC) &&
-                           (s_bc[d][0] == PHIHIP_BC_PERIODIC) == (v.bc[d + v.ax0][0] == PHIHIP_BC_PERIODIC),
-                       "advect_centered: periodicity of the scalar must match the grid along axis %d", d);
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "advect_centered"));
     const void* u[3];
     remap3(v, velocity, u);
     return run_advect_centered(ctx, v, sfield, s_bc, s_val, u, out, dt, s);
+}
+
+static int check_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const char* what) {
+    for (int d = 0; d < v.rank; ++d) {
+        for (int side = 0; side < 2; ++side)
+            PHIHIP_REQUIRE(s_bc[d][side] >= PHIHIP_BC_PERIODIC && s_bc[d][side] <= PHIHIP_BC_OPEN, "%s: s_bc[%d][%d] invalid", what, d, side);
+        PHIHIP_REQUIRE((s_bc[d][0] == PHIHIP_BC_PERIODIC) == (s_bc[d][1] == PHIHIP_BC_PERIODIC) &&
+                           (s_bc[d][0] == PHIHIP_BC_PERIODIC) == (v.bc[d + v.ax0][0] == PHIHIP_BC_PERIODIC),
+                       "%s: periodicity of the scalar must match the grid along axis %d", what, d);
+    }
+    return PHIHIP_OK;
+}
+
+int phihip_mac_cormack_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3], const void* const velocity[3],
+                                 void* const out[3], double dt, double correction_strength, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, field, "field"));
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)out, "out"));
+    for (int d = 0; d < v.rank; ++d)
+        PHIHIP_REQUIRE(out[d] != field[d] && out[d] != velocity[d], "mac_cormack: out[%d] must not alias an input", d);
+    const void *f[3], *u[3];
+    void* o[3];
+    remap3(v, field, f);
+    remap3(v, velocity, u);
+    remap3w(v, out, o);
+    return run_mac_cormack_staggered(ctx, v, f, u, o, dt, correction_strength, s);
+}
+
+int phihip_mac_cormack_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                                const double s_val[3][2], const void* const velocity[3], void* out, double dt,
+                                double correction_strength, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && out && s_bc, "mac_cormack_centered: NULL argument");
+    PHIHIP_REQUIRE(sfield != out, "mac_cormack_centered: out must not alias the input");
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "mac_cormack_centered"));
+    const void* u[3];
+    remap3(v, velocity, u);
+    return run_mac_cormack_centered(ctx, v, sfield, s_bc, s_val, u, out, dt, correction_strength, s);
+}
+
+int phihip_centered_to_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                                 const double s_val[3][2], const double vector[3], int accumulate, void* const out[3], void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && s_bc && vector, "centered_to_staggered: NULL argument");
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)out, "out"));
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "centered_to_staggered"));
+    double vec[3] = {0, 0, 0};
+    for (int d = 0; d < v.rank; ++d) vec[d + v.ax0] = vector[d];
+    void* o[3];
+    remap3w(v, out, o);
+    return run_centered_to_staggered(ctx, v, sfield, s_bc, s_val, vec, accumulate, o, s);
 }
 
 int phihip_build_cellflags(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* accessible, const uint8_t* active, int mask_batch,

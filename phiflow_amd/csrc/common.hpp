@@ -69,6 +69,14 @@ struct VelGrid {
 
 VelGrid make_velgrid(const GridView& v);
 
+// extrapolation of a centred scalar per internal axis / side: PERIODIC wrap, OPEN = zero-gradient, CLOSED = constant val
+struct ScalarBc {
+    int bc[3][2];
+    double val[3][2];
+};
+
+ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const double s_val[3][2]);
+
 struct Tuning {
     int rows = 0, tpr = 0, chunk = 0;   // 0 = auto
 };
@@ -85,7 +93,7 @@ struct phihip_ctx {
     int num_cu = 256;
     phihip::Tuning tuning;
     // workspace (grown on demand, reused between calls)
-    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs;
+    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv;
     void* last_state = nullptr;   // device control blocks of the most recent solve
     int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
@@ -128,6 +136,12 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
 int run_advect_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
                         const void* const v[3], void* out, double dt, hipStream_t);
+int run_mac_cormack_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt,
+                              double strength, hipStream_t);
+int run_mac_cormack_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
+                             const void* const v[3], void* out, double dt, double strength, hipStream_t);
+int run_centered_to_staggered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
+                              const double vector[3], int accumulate, void* const out[3], hipStream_t);
 int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);
 int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const uint8_t* flags, int mask_batch, int balance, void* div, hipStream_t);
 int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);

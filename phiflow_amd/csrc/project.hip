@@ -274,6 +274,64 @@ int run_scale_faces(phihip_ctx* ctx, const GridView& v, void* const vel[3], cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// resample(s * vector, to=velocity): centred scalar times a constant vector sampled at the stored faces
+// (sample_grid_at_faces, phi/field/_resample.py:272-276): mean of the two adjacent cells, outside cells from the scalar's
+// extrapolation. accumulate != 0: out += value (buoyancy: v + resample(smoke * (0, 0.1), to=v), Smoke_Plume.ipynb cell 5)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void centered_to_staggered_kernel(VelGrid g, ScalarBc sb, int ca, const T* __restrict__ sfield,
+                                                                       T* __restrict__ out, T scale, int accumulate) {
+    const int b = blockIdx.y;
+    const int total = (int)g.ccells[ca];
+    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const int n = g.n[ca];
+    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
+    const T* __restrict__ S = sfield + (long long)b * g.cells;
+    T* __restrict__ O = out + (long long)b * total;
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        int idx[3];
+        idx[2] = f % c2;
+        const int t = f / c2;
+        idx[1] = t % c1;
+        idx[0] = t / c1;
+        const int phys = idx[ca] + g.off[ca];
+        int l = phys - 1, r = phys;
+        bool cl = false, cr = false;
+        if (l < 0) { if (sb.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { cl = sb.bc[ca][0] == PHIHIP_BC_CLOSED; l = 0; } }
+        if (r >= n) { if (sb.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { cr = sb.bc[ca][1] == PHIHIP_BC_CLOSED; r = n - 1; } }
+        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;
+        const T sl = (cl ? (T)sb.val[ca][0] : S[rest + l * pstride]) * scale;
+        const T sr = (cr ? (T)sb.val[ca][1] : S[rest + r * pstride]) * scale;
+        const T val = sl * T(0.5) + sr * T(0.5);
+        O[f] = accumulate ? O[f] + val : val;
+    }
+}
+
+int run_centered_to_staggered(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
+                              const double vector[3], int accumulate, void* const out[3], hipStream_t s) {
+    for (int ca = v.ax0; ca < 3; ++ca)
+        if (v.ccells[ca] >= (1LL << 31) || v.cells >= (1LL << 31)) {
+            set_error("centered_to_staggered: more than 2^31 samples per batch entry are not supported");
+            return PHIHIP_ERR_UNSUPPORTED;
+        }
+    const VelGrid g = make_velgrid(v);
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        if (accumulate && vector[ca] == 0.0) continue;   // adding 0 * s leaves the component as it is
+        const int nblk = ceil_div(v.ccells[ca], kBlock) < 16384 ? ceil_div(v.ccells[ca], kBlock) : 16384;
+        if (v.dtype == PHIHIP_F64)
+            hipLaunchKernelGGL(centered_to_staggered_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ca, (const double*)sfield,
+                               (double*)out[ca], vector[ca], accumulate);
+        else
+            hipLaunchKernelGGL(centered_to_staggered_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ca, (const float*)sfield,
+                               (float*)out[ca], (float)vector[ca], accumulate);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // obstacle flags (fluid.py:130-137: accessible, hard_bcs = stagger(accessible, minimum), active)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void cellflags_kernel(VelGrid g, const uint8_t* accessible, const uint8_t* active, int per_batch,

@@ -382,40 +382,30 @@ def mean(field: Field):
 
 
 def resample(value: Field, to: Field) -> Field:
-    """ `resample(value, to=target)`; implemented: centred vector-free scalar x constant vector is handled by the caller,
-    centred scalar -> staggered faces (mean of the two adjacent cells, padded with the scalar's extrapolation;
-    phi/field/_resample.py:272-276,341-364). Next-row functionality: device glue, not a tuned kernel. """
+    """ `resample(value, to=target)` / `value @ target` (phi/field/_resample.py:13-63). Implemented: same sample points (boundary
+    change only) and centred scalar [x constant vector] -> staggered faces on the same grid (sample_grid_at_faces,
+    phi/field/_resample.py:272-276: mean of the two adjacent cells, padded with the scalar's extrapolation) as one HIP kernel
+    per component (`phihip_centered_to_staggered`). """
     if value.is_staggered == to.is_staggered and value.resolution == to.resolution:
         if value.is_staggered and value.boundary != to.boundary:
             return value.with_boundary(to.boundary)
         return Field(value.resolution, value.bounds, to.boundary, value.values, value.is_staggered, value.backend, value.batched)
     if value.is_centered and to.is_staggered and value.resolution == to.resolution:
-        comps = []
+        be = value.backend
         scale = getattr(value, '_vector_scale', None) or [1.0] * value.spatial_rank
-        for d, dim in enumerate(value.dims):
-            comps.append(_centered_to_faces(value, d, to.boundary) * scale[d])
-        return Field(to.resolution, to.bounds, to.boundary, comps, True, value.backend, value.batched or to.batched)
+        B = max(value.batch_size, to.batch_size)
+        src = value.values if value.batch_size == B else value.values.expand(B, *value.values.shape[1:])
+        src = src.contiguous()
+        proto = Field(to.resolution, to.bounds, to.boundary, None, True, be, False)
+        grid = _capi.make_grid(value.spatial_rank, _torch_dtype_code(value.dtype), B, list(to.resolution.values()), to.bounds.lower,
+                               to.bounds.upper, proto._codes, proto._bc_val)
+        comps = [be.empty((B,) + component_shape(to.resolution, to.boundary, d), value.dtype) for d in range(value.spatial_rank)]
+        s_codes, s_vals = resolve(value.boundary, value.dims)
+        s_val = [[s_vals[a][s][0] if isinstance(value.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
+                 for a, d in enumerate(value.dims)]
+        be.ctx.centered_to_staggered(grid, src.data_ptr(), s_codes, s_val, scale, False, _ptrs(comps), be.stream())
+        return Field(to.resolution, to.bounds, to.boundary, comps, True, be, value.batched or to.batched)
     raise NotImplementedError("resample: only centred -> staggered on the same grid is implemented")
-
-
-def _centered_to_faces(s: Field, d: int, target_boundary: Extrapolation) -> torch.Tensor:
-    t = s.values
-    ax = 1 + d
-    dim = s.dims[d]
-    n = t.shape[ax]
-    lo_e, up_e = s.boundary.side(dim, False), s.boundary.side(dim, True)
-
-    def ghost(e, lower):
-        if e == PERIODIC:
-            return t.narrow(ax, n - 1, 1) if lower else t.narrow(ax, 0, 1)
-        if isinstance(e, ConstantExtrapolation):
-            return torch.full_like(t.narrow(ax, 0, 1), e.component_value(0, dim))
-        return t.narrow(ax, 0 if lower else n - 1, 1)
-    padded = torch.cat([ghost(lo_e, True), t, ghost(up_e, False)], dim=ax)
-    faces = 0.5 * (padded.narrow(ax, 0, n + 1) + padded.narrow(ax, 1, n + 1))   # all n+1 faces
-    lo, up = target_boundary.valid_outer_faces(dim)
-    start, stop = (0 if lo else 1), (n + 1 if up else n)
-    return faces.narrow(ax, start, stop - start).contiguous()
 
 
 def vector_scaled(s: Field, vector: Sequence[float]) -> Field:

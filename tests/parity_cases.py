@@ -175,6 +175,66 @@ def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt
     assert err <= tol(dtype)['advect'], f"advect_centered rel err {err}"
 
 
+def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=0.9, strength=1.0):
+    """ advect.mac_cormack of a centred scalar; besides the oracle comparison checks the limiter property
+    (result within the min / max of the field) and identity at dt = 0 (tests/commit/physics/test_advect.py:12-18,29-30) """
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    s = rng.standard_normal((B,) + dom.res).astype(dtype)
+    dv = [mem.to_dev(a) for a in v]
+    ds, dout = mem.to_dev(s), mem.empty(s.shape, dtype)
+    ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), dt, strength)
+    mem.sync()
+    ref = O.mac_cormack_centered(s, v, dt, dom, s_codes, s_consts, strength)
+    out = mem.to_host(dout)
+    # a lookup that lands within rounding distance of a cell boundary may pick the neighbouring clamp window: compare robustly
+    bad = np.abs(out - ref) > tol(dtype)['advect'] * max(np.abs(ref).max(), 1e-30)
+    assert bad.mean() <= 2e-3, f"mac_cormack_centered: {bad.mean():.2%} of the samples differ"
+    ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), 0.0, strength)
+    mem.sync()
+    assert rel_err(mem.to_host(dout), s) <= 1e-6
+
+
+def check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, strength=1.0):
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    dv = [mem.to_dev(a) for a in v]
+    dout = [mem.empty(a.shape, dtype) for a in v]
+    ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt, strength)
+    mem.sync()
+    ref = O.mac_cormack_staggered(v, v, dt, dom, strength)
+    for d in range(dom.rank):
+        out = mem.to_host(dout[d])
+        bad = np.abs(out - ref[d]) > tol(dtype)['advect'] * max(np.abs(ref[d]).max(), 1e-30)
+        assert bad.mean() <= 2e-3, f"mac_cormack_staggered[{d}]: {bad.mean():.2%} of the samples differ"
+    ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], 0.0, strength)
+    mem.sync()
+    for d in range(dom.rank):
+        assert rel_err(mem.to_host(dout[d]), v[d]) <= 1e-6
+
+
+def check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts):
+    B = grid.batch
+    s = rng.standard_normal((B,) + dom.res).astype(dtype)
+    vector = [0.3, -1.5, 0.1][:dom.rank]
+    ds = mem.to_dev(s)
+    v0 = random_velocity(dom, B, dtype, rng)
+    dout = [mem.empty((B,) + dom.comp_shape(d), dtype) for d in range(dom.rank)]
+    ctx.centered_to_staggered(grid, mem.ptr(ds), s_codes, s_consts, vector, False, [mem.ptr(a) for a in dout])
+    mem.sync()
+    ref = O.centered_to_staggered(s, dom, s_codes, s_consts, vector)
+    for d in range(dom.rank):
+        assert rel_err(mem.to_host(dout[d]), ref[d]) <= tol(dtype)['stencil'], f"centered_to_staggered[{d}]"
+    dacc = [mem.to_dev(a) for a in v0]
+    vector0 = [0.0] + vector[1:]              # zero component: accumulate must leave that component untouched
+    ctx.centered_to_staggered(grid, mem.ptr(ds), s_codes, s_consts, vector0, True, [mem.ptr(a) for a in dacc])
+    mem.sync()
+    ref0 = O.centered_to_staggered(s, dom, s_codes, s_consts, vector0)
+    for d in range(dom.rank):
+        assert rel_err(mem.to_host(dacc[d]), v0[d] + ref0[d]) <= tol(dtype)['stencil'] * 2, f"centered_to_staggered accumulate[{d}]"
+    assert np.array_equal(mem.to_host(dacc[0]), v0[0])
+
+
 def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)

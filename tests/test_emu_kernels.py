@@ -51,6 +51,20 @@ def test_advection_matches_oracle(emu_ctx, res, bc):
         pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)
+def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
+    """ advect.mac_cormack (centred + staggered) and the centred -> staggered resample used for buoyancy """
+    rng = np.random.default_rng(12)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+        s_consts = [(0.0, 0.25)] * len(res)
+        pc.check_mac_cormack_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
+        pc.check_mac_cormack_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts, dt=2.3, strength=0.6)
+        pc.check_mac_cormack_staggered(emu_ctx, MEM, dom, grid, dtype, rng)
+        pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
+
+
 def test_advection_with_wall_velocity(emu_ctx):
     """ lid-driven cavity boundary: tangential wall velocity on one side (Lid_Driven_Cavity.ipynb cell 5) """
     rng = np.random.default_rng(3)

@@ -15,6 +15,13 @@ def test_golden_smoke_plume(gpu_backend):
     golden_cases.run_smoke_plume(gpu_backend)
 
 
+def test_golden_smoke_plume_mac_cormack_50_steps(gpu_backend):
+    """ BASELINE configs[0]: the reference's CPU-runnable case, all 50 steps against the oracle's trajectory """
+    report = {}
+    golden_cases.run_smoke_plume_mac_cormack(gpu_backend, report=report)
+    print("config-1 rel-L2 errors vs oracle:", report)
+
+
 def test_golden_taylor_green(gpu_backend):
     golden_cases.run_taylor_green(gpu_backend)
 

@@ -62,6 +62,20 @@ def test_advection_matches_oracle(ctx, mem, res, bc):
         pc.check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, [(0.0, 0.25)] * len(res))
 
 
+@pytest.mark.parametrize("res,bc", GRIDS)
+def test_mac_cormack_and_resample_match_oracle(ctx, mem, res, bc):
+    """ advect.mac_cormack (centred + staggered) and the centred -> staggered resample used for buoyancy """
+    rng = np.random.default_rng(12)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+        s_consts = [(0.0, 0.25)] * len(res)
+        pc.check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
+        pc.check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=2.3, strength=0.6)
+        pc.check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng)
+        pc.check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
+
+
 def test_reference_known_answer_self_advection(ctx, mem):
     """ /root/reference tests/commit/physics/test_advect.py:41-45 -- the only stored known answer on the path """
     dom, grid = pc.make_case((4, 3), ((CLO, CLO), (CLO, CLO)), np.float32)

@@ -44,12 +44,12 @@ def test_self_advect_staggered_known_answer(emu_backend):
 
 @pytest.mark.parametrize("ext", [ZERO, BOUNDARY, PERIODIC])
 def test_identity_advection(emu_backend, ext):
-    """ tests/commit/physics/test_advect.py:12-18 """
+    """ tests/commit/physics/test_advect.py:12-18 with the three schemes of :23-30 (advect, semi_lagrangian, mac_cormack) """
     rng = np.random.default_rng(1)
     shapes = StaggeredGrid(0, ext, x=4, y=3, backend=emu_backend).component_shapes
     sv = StaggeredGrid([rng.standard_normal(s).astype(np.float32) for s in shapes], ext, x=4, y=3, backend=emu_backend)
     s = CenteredGrid(rng.standard_normal((4, 3)).astype(np.float32), ext, x=4, y=3, backend=emu_backend)
-    for adv in (advect.advect, advect.semi_lagrangian):
+    for adv in (advect.advect, advect.semi_lagrangian, advect.mac_cormack):
         for a, b in zip(adv(sv, sv, 0).numpy(), sv.numpy()):
             np.testing.assert_allclose(a, b, atol=1e-5)
         for a, b in zip(adv(sv, sv * 0, 1).numpy(), sv.numpy()):
