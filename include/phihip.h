@@ -175,6 +175,12 @@ int phihip_profile_enable(phihip_ctx* ctx, int enable);
 int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], double total_ms[PHIHIP_K_COUNT], int reset);
 /* tile configuration of the CG marching kernels: rows per thread (1,2,4) and threads per row (16,32,64); 0 = auto */
 int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes);
+/* the same for one kernel family only: 0 = operator apply / residual, 1 = MATVEC (d = r + beta d; d.Ad), 2 = UPDATE (x, r) */
+int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes);
+
+/* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
+ * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
+int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);
 
 #ifdef __cplusplus
 }

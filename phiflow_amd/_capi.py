@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_grad_subtract",
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
     "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
+    "phihip_set_tuning_kernel", "phihip_query_plan",
 )
 
 
@@ -127,6 +128,8 @@ class Library:
         d.phihip_profile_enable.argtypes = [c_void_p, c_int]
         d.phihip_profile_read.argtypes = [c_void_p, POINTER(c_int32 * K_COUNT), POINTER(c_double * K_COUNT), c_int]
         d.phihip_set_tuning.argtypes = [c_void_p, c_int, c_int, c_int]
+        d.phihip_set_tuning_kernel.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+        d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
         for name in EXPORTED_SYMBOLS:
             if name not in ("phihip_version", "phihip_last_error"):
                 getattr(d, name).restype = c_int
@@ -251,6 +254,16 @@ class Context:
 
     def set_tuning(self, rows_per_thread=0, threads_per_row=0, chunk_planes=0):
         self.lib.check(self.lib.dll.phihip_set_tuning(self.handle, int(rows_per_thread), int(threads_per_row), int(chunk_planes)))
+
+    def set_tuning_kernel(self, family, rows_per_thread=0, threads_per_row=0, chunk_planes=0):
+        """ family: 0 = apply / residual, 1 = MATVEC, 2 = UPDATE """
+        self.lib.check(self.lib.dll.phihip_set_tuning_kernel(self.handle, int(family), int(rows_per_thread), int(threads_per_row),
+                                                             int(chunk_planes)))
+
+    def query_plan(self, grid, has_flags=False, family=1) -> dict:
+        out = (c_int32 * 6)()
+        self.lib.check(self.lib.dll.phihip_query_plan(self.handle, ctypes.byref(grid), int(bool(has_flags)), int(family), ctypes.byref(out)))
+        return dict(rows=out[0], tpr=out[1], chunk=out[2], nblk=out[3], occupancy=out[4], vec=out[5])
 
     def workspace_bytes(self) -> int:
         out = c_size_t()

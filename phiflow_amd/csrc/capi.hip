@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.hpp"
+#include "march_dispatch.hpp"
 
 namespace phihip {
 
@@ -408,6 +409,24 @@ int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void
     return run_diffuse(ctx, v, u, o, diffusivity_dt, s);
 }
 
+int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]) {
+    PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "query_plan: NULL argument");
+    PHIHIP_REQUIRE(family >= 0 && family < 3, "tuning family must be 0 (apply / residual), 1 (matvec) or 2 (update)");
+    GridView v;
+    PHIHIP_TRY(make_view(grid, &v));
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    MarchConfig c;
+    MarchGrid g;
+    PHIHIP_TRY(plan_march(ctx, v, 1, has_flags != 0, family, &c, &g));
+    out[0] = c.vec == 1 ? 1 : kTileShapes[c.id].rows;
+    out[1] = c.vec == 1 ? 64 : kTileShapes[c.id].tpr;
+    out[2] = c.chunk;
+    out[3] = g.nblk;
+    out[4] = march_occupancy_any(v, c.id, c.vec, family_mode(family), has_flags != 0);
+    out[5] = c.vec;
+    return PHIHIP_OK;
+}
+
 int phihip_profile_enable(phihip_ctx* ctx, int enable) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->profiling = enable != 0;
@@ -432,9 +451,21 @@ int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], doubl
 int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
-    ctx->tuning.rows = rows_per_thread;
-    ctx->tuning.tpr = threads_per_row;
-    ctx->tuning.chunk = chunk_planes;
+    for (int f = 0; f < 3; ++f) {
+        ctx->tuning[f].rows = rows_per_thread;
+        ctx->tuning[f].tpr = threads_per_row;
+        ctx->tuning[f].chunk = chunk_planes;
+    }
+    return PHIHIP_OK;
+}
+
+int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    PHIHIP_REQUIRE(family >= 0 && family < 3, "tuning family must be 0 (apply / residual), 1 (matvec) or 2 (update)");
+    PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
+    ctx->tuning[family].rows = rows_per_thread;
+    ctx->tuning[family].tpr = threads_per_row;
+    ctx->tuning[family].chunk = chunk_planes;
     return PHIHIP_OK;
 }
 

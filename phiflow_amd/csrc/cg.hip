@@ -4,6 +4,8 @@
 // Here one iteration = TWO launches: MATVEC (d = r + beta d ; dq = d.Ad) and UPDATE (x += a d ; r -= a Ad ; rsq); each
 // reduces its predecessor's partial sums in its prologue (stencil_march.hpp), so alpha / beta / the per-batch continue
 // flags never leave the device and no scalar kernel sits between the phases. The host only enqueues launches.
+#include <math.h>
+
 #include "common.hpp"
 #include "march_dispatch.hpp"
 
@@ -12,7 +14,17 @@ namespace phihip {
 // ---------------------------------------------------------------------------------------------------------------------
 // planning
 // ---------------------------------------------------------------------------------------------------------------------
-int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchConfig* c, MarchGrid* g) {
+// Launch plan of one kernel family. Measured on MI355X (profiles/r01_sweep_family*.jsonl): a grid that needs 1 < rounds < 2
+// of resident workgroups costs almost two full rounds, chunks longer than 64 planes starve the chip, short chunks re-read two
+// halo planes of the stencil source per chunk, and the families prefer different tiles -- MATVEC (2 loads / cell, 76-138
+// VGPRs) wants >= 3 medium workgroups per CU, UPDATE (3 loads, 2 stores, up to 224 VGPRs) the largest tile. So every (tile,
+// chunk) candidate gets   score = slot efficiency / relative traffic
+//     slot efficiency = rounds / ceil(rounds)            (rounds = workgroups * batch / (occupancy(kernel) * CUs) > 1)
+//                     = min(1, workgroups / min(slots, 4 [MATVEC] or 2 [UPDATE, residual] per CU))      (one round)
+//     relative traffic = 1 + (2 / chunk) * (source words / all words)
+// MATVEC takes the first tile of its preference list that scores >= 0.8, UPDATE / residual the best score (x a small bonus
+// for large tiles).
+int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
     const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const int vmax = 16 / esize;
     memset(g, 0, sizeof(*g));
@@ -26,15 +38,53 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchCo
     g->flags_per_batch = mask_batch > 1 ? 1 : 0;
     c->batch = v.batch;
     c->vec = (v.n[2] % vmax == 0) ? vmax : 1;
-    const Tuning& t = ctx->tuning;
-    const long long target_blocks = 4LL * ctx->num_cu;
-    auto blocks_for = [&](int id, int chunk) -> long long {
-        const int t1 = kBlock / kTileShapes[id].tpr * kTileShapes[id].rows, t2 = kTileShapes[id].tpr * c->vec;
-        return (long long)ceil_div(v.n[1], t1) * ceil_div(v.n[2], t2) * ceil_div(v.n[0], chunk) * v.batch;
+    const Tuning& t = ctx->tuning[family];
+    const int mode = family_mode(family);
+    const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : 1.0 / 3.0);
+
+    auto tile_of = [&](int id, int* t1, int* t2) {
+        const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
+        *t1 = kBlock / tpr * rows;
+        *t2 = tpr * c->vec;
     };
-    int id = -1;
+    auto tiles_of = [&](int id) -> long long {
+        int t1, t2;
+        tile_of(id, &t1, &t2);
+        return (long long)ceil_div(v.n[1], t1) * ceil_div(v.n[2], t2);
+    };
+    // best chunk of a tile configuration and its score
+    auto best_chunk = [&](int cand, double* score_out) -> int {
+        const double slots = (double)march_occupancy_any(v, cand, c->vec, mode, flags) * ctx->num_cu;
+        const double tiles = (double)tiles_of(cand) * v.batch;
+        if (v.rank != 3) {
+            const double rounds = tiles / slots;
+            const double per_cu = family == FAM_MATVEC ? 4.0 : 2.0;
+            const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
+            *score_out = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
+            return 1;
+        }
+        static const int kChunks[7] = {64, 48, 32, 24, 16, 12, 8};
+        int best = 0;
+        double best_score = -1.0;
+        const double per_cu = family == FAM_MATVEC ? 4.0 : 2.0;
+        const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
+        for (int k = 0; k < 7; ++k) {
+            const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
+            const double blocks = tiles * ceil_div(v.n[0], ch);
+            const double rounds = blocks / slots;
+            const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < wanted ? blocks / wanted : 1.0);
+            const double score = eff / (1.0 + 2.0 / ch * src_share);
+            if (score > best_score * 1.0001) { best_score = score; best = ch; }
+        }
+        *score_out = best_score;
+        return best;
+    };
+
+    int id = -1, chunk = 1;
+    double score = 0;
     if (c->vec == 1) {
         id = 5;   // (1, 64): the only scalar instantiation
+        chunk = best_chunk(id, &score);
     } else if (t.rows > 0 && t.tpr > 0) {
         for (int k = 0; k < kNumTileConfigs; ++k)
             if (kTileShapes[k].rows == t.rows && kTileShapes[k].tpr == t.tpr) id = k;
@@ -42,37 +92,31 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchCo
             set_error("tuning: no tile config with rows=%d threads_per_row=%d", t.rows, t.tpr);
             return PHIHIP_ERR_BAD_ARG;
         }
+        chunk = best_chunk(id, &score);
     } else {
-        // largest tile (least halo traffic) that still yields enough workgroups with chunks of >= 16 planes
-        const int pref[4] = {3, 2, 1, 0};
-        id = 0;
-        for (int k = 0; k < 4; ++k) {
+        static const int pref_mv[6] = {2, 1, 0, 5, 3, 4}, pref_up[6] = {4, 3, 2, 1, 0, 5};
+        static const double bonus_up[6] = {1.0, 1.0, 0.98, 0.98, 0.97, 0.97};   // large tiles win at equal chunk length (512^3 sweep)
+        const int* pref = family == FAM_MATVEC ? pref_mv : pref_up;
+        double best_score = -1.0;
+        for (int k = 0; k < 6; ++k) {
             const int cand = pref[k];
-            const int t1 = kBlock / kTileShapes[cand].tpr * kTileShapes[cand].rows, t2 = kTileShapes[cand].tpr * c->vec;
-            if (t1 > 2 * v.n[1] || t2 > 2 * v.n[2]) continue;   // mostly empty tile
-            if (blocks_for(cand, v.rank == 3 ? 16 : 1) >= target_blocks || cand == 0) {
-                id = cand;
-                break;
-            }
+            int t1, t2;
+            tile_of(cand, &t1, &t2);
+            const double waste = (double)tiles_of(cand) * t1 * t2 / ((double)v.n[1] * v.n[2]);
+            double sc;
+            const int ch = best_chunk(cand, &sc);
+            sc /= waste;
+            if (family != FAM_MATVEC) sc *= bonus_up[k];
+            if (sc > best_score) { best_score = sc; id = cand; chunk = ch; }
+            // MATVEC: the first acceptable tile of the list; UPDATE / residual: the best score (chunk length matters more there)
+            if (family == FAM_MATVEC && sc >= 0.8) break;
         }
     }
+    if (v.rank == 3 && t.chunk > 0) chunk = t.chunk < v.n[0] ? t.chunk : v.n[0];
+    tile_of(id, &c->t1, &c->t2);
+    // every workgroup of the next kernel re-reduces all partial sums of its batch entry: keep that list short
+    while (v.rank == 3 && t.chunk == 0 && chunk < v.n[0] && tiles_of(id) * ceil_div(v.n[0], chunk) > 8192) chunk = chunk * 2 < v.n[0] ? chunk * 2 : v.n[0];
     c->id = id;
-    const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
-    c->t1 = kBlock / tpr * rows;
-    c->t2 = tpr * c->vec;
-    int chunk = 1;
-    if (v.rank == 3) {
-        if (t.chunk > 0) {
-            chunk = t.chunk;
-        } else {
-            chunk = 64;
-            while (chunk > 8 && blocks_for(id, chunk) < target_blocks) chunk /= 2;
-        }
-        if (chunk > v.n[0]) chunk = v.n[0];
-        // every workgroup of the next kernel re-reduces all partial sums of a batch entry: keep that list short
-        auto nblk_for = [&](int ch) { return (long long)ceil_div(v.n[1], c->t1) * ceil_div(v.n[2], c->t2) * ceil_div(v.n[0], ch); };
-        while (t.chunk == 0 && chunk < v.n[0] && nblk_for(chunk) > 4096) chunk = chunk * 2 < v.n[0] ? chunk * 2 : v.n[0];
-    }
     c->chunk = chunk;
     g->tiles1 = ceil_div(v.n[1], c->t1);
     g->tiles2 = ceil_div(v.n[2], c->t2);
@@ -133,7 +177,7 @@ static int laplace_apply_t(phihip_ctx* ctx, const GridView& v, const uint8_t* fl
                            hipStream_t s) {
     MarchConfig c;
     MarchGrid g;
-    PHIHIP_TRY(plan_march(ctx, v, mask_batch, &c, &g));
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));
     MarchArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.a = (const T*)p;
@@ -156,11 +200,14 @@ int run_laplace_apply(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
 template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
                 const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
-    MarchConfig c;
-    MarchGrid g;
-    PHIHIP_TRY(plan_march(ctx, v, mask_batch, &c, &g));
+    MarchConfig c, c_mv, c_up;   // residual / MATVEC / UPDATE may run different tile shapes
+    MarchGrid g, g_mv, g_up;
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_MATVEC, &c_mv, &g_mv));
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE, &c_up, &g_up));
     const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
-    const size_t part_n = (size_t)v.batch * g.nblk;
+    const int nblk_max = g.nblk > g_mv.nblk ? (g.nblk > g_up.nblk ? g.nblk : g_up.nblk) : (g_mv.nblk > g_up.nblk ? g_mv.nblk : g_up.nblk);
+    const size_t part_n = (size_t)v.batch * nblk_max;
     PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
@@ -202,6 +249,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
     }
     bool first = true;
+    int nblk_rr = g.nblk;   // workgroup count of the kernel that last wrote part_rr (RESID or UPDATE)
     const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
     CgState* hst = (CgState*)ctx->host_state;
     for (int k = 1; k <= solve->max_iterations; ++k) {
@@ -211,9 +259,9 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             MarchArgs<T> a = base;
             a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq;
             a.prologue = first ? PRO_FIRST : PRO_BETA;
-            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = part_yy;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = part_yy; a.nblk_in = nblk_rr;
             LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_MATVEC, has_flags, g, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, c_mv, MODE_MATVEC, has_flags, g_mv, a, s));
             cur ^= 1;
             first = false;
         }
@@ -221,7 +269,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             {
                 LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
                 hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new,
-                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, g.nblk, prm, v.cells);
+                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, g_mv.nblk, prm, v.cells);
                 cur ^= 1;
             }
             MarchArgs<T> a = base;
@@ -231,21 +279,23 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             a.st_in = st[cur];
             LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
             PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
+            nblk_rr = g.nblk;
         } else {
             MarchArgs<T> a = base;
             a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr;
             a.prologue = PRO_ALPHA;
-            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq; a.nblk_in = g_mv.nblk;
             LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_UPDATE, has_flags, g, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, c_up, MODE_UPDATE, has_flags, g_up, a, s));
             cur ^= 1;
+            nblk_rr = g_up.nblk;
         }
         if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
             // peek at the decision the next MATVEC prologue will take, without advancing the chain
             {
                 LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
                 hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur], st_peek,
-                                   (const double*)part_rr, (const double*)part_yy, g.nblk, prm);
+                                   (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
             }
             PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st_peek, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
             PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
@@ -257,7 +307,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     {   // fold the last reduction into the control block (or build it when no iteration ran)
         LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
         hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : PRO_BETA), (const CgState*)st[cur],
-                           st[cur ^ 1], (const double*)part_rr, (const double*)part_yy, g.nblk, prm);
+                           st[cur ^ 1], (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
         cur ^= 1;
     }
     ctx->last_state = st[cur];

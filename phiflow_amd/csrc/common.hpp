@@ -91,7 +91,7 @@ struct DeviceBuffer {
 struct phihip_ctx {
     int device = 0;
     int num_cu = 256;
-    phihip::Tuning tuning;
+    phihip::Tuning tuning[3];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv;
     void* last_state = nullptr;   // device control blocks of the most recent solve

@@ -15,12 +15,31 @@ struct MarchConfig {
     int id;      // index into kTileShapes (ignored when vec == 1)
     int vec;     // elements per thread along the fast axis: 16 B / sizeof(T), or 1 when n2 is not a multiple of it
     int t1, t2;  // tile extent
-    int chunk;   // planes per workgroup
+    int chunk;   // planes per workgroup (pieces of the linearised (tile, plane) space)
     int batch;
 };
 
-// choose tile + chunk for a grid (honours ctx->tuning) and fill the decomposition fields of MarchGrid
-int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, MarchConfig* cfg, MarchGrid* g);
+inline int family_mode(int family) { return family == 1 ? MODE_MATVEC : (family == 2 ? MODE_UPDATE : MODE_RESID); }
+
+// kernel families that may use different tile shapes (phihip_set_tuning_kernel)
+enum MarchFamily { FAM_APPLY = 0, FAM_MATVEC = 1, FAM_UPDATE = 2 };
+
+// choose tile + chunk for a grid (honours ctx->tuning[family]) and fill the decomposition fields of MarchGrid
+int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* cfg, MarchGrid* g);
+
+// resident workgroups per CU of one march_kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor, cached)
+template <typename T, bool DIM3>
+int march_occupancy(int id, int vec, int mode, bool flags);
+
+template <> int march_occupancy<float, false>(int id, int vec, int mode, bool flags);
+template <> int march_occupancy<float, true>(int id, int vec, int mode, bool flags);
+template <> int march_occupancy<double, false>(int id, int vec, int mode, bool flags);
+template <> int march_occupancy<double, true>(int id, int vec, int mode, bool flags);
+
+inline int march_occupancy_any(const GridView& v, int id, int vec, int mode, bool flags) {
+    if (v.dtype == PHIHIP_F64) return v.rank == 3 ? march_occupancy<double, true>(id, vec, mode, flags) : march_occupancy<double, false>(id, vec, mode, flags);
+    return v.rank == 3 ? march_occupancy<float, true>(id, vec, mode, flags) : march_occupancy<float, false>(id, vec, mode, flags);
+}
 
 template <typename T, bool DIM3>
 int launch_march(const MarchConfig& c, int mode, bool flags, const MarchGrid& g, const MarchArgs<T>& a, hipStream_t s);

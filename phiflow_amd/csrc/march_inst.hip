@@ -38,6 +38,45 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
     return PHIHIP_OK;
 }
 
+template <int V, int R, int TPR, int MODE, bool FLAGS>
+static int occupancy_one() {
+    static int cached = 0;
+    if (cached == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+        cached = n > 8 ? 8 : n;
+    }
+    return cached;
+}
+
+template <int V, int R, int TPR>
+static int occupancy_cfg(int mode, bool flags) {
+#define PHIHIP_OCC_CASE(M) \
+    case M: return flags ? occupancy_one<V, R, TPR, M, true>() : occupancy_one<V, R, TPR, M, false>();
+    switch (mode) {
+        PHIHIP_OCC_CASE(MODE_APPLY)
+        PHIHIP_OCC_CASE(MODE_RESID)
+        PHIHIP_OCC_CASE(MODE_MATVEC)
+        PHIHIP_OCC_CASE(MODE_UPDATE)
+        default: return 1;
+    }
+#undef PHIHIP_OCC_CASE
+}
+
+template <>
+int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
+    if (vec == 1) return occupancy_cfg<1, 1, 64>(mode, flags);
+    switch (id) {
+        case 0: return occupancy_cfg<kVmax, 1, 16>(mode, flags);
+        case 1: return occupancy_cfg<kVmax, 2, 16>(mode, flags);
+        case 2: return occupancy_cfg<kVmax, 2, 32>(mode, flags);
+        case 3: return occupancy_cfg<kVmax, 4, 32>(mode, flags);
+        case 4: return occupancy_cfg<kVmax, 4, 64>(mode, flags);
+        case 5: return occupancy_cfg<kVmax, 1, 64>(mode, flags);
+        default: return 1;
+    }
+}
+
 template <>
 int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, const MarchGrid& g,
                                    const MarchArgs<InstT>& a, hipStream_t s) {

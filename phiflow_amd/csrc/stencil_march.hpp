@@ -102,6 +102,7 @@ struct MarchArgs {
     double* part2;         // [batch][nblk]
     CgParams prm;
     int prologue;          // CgPrologue
+    int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
     T w0, w1, w2;          // 1 / dx^2 per internal axis
 };
 
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int b = blockIdx.y;
     T alpha = T(0), beta = T(0);
     if (p.prologue != PRO_NONE) {
-        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, g.nblk, p.prm, b, blockIdx.x == 0, red, &sh_state);
+        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state);
         if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
         alpha = (T)S.alpha;
         beta = (T)S.beta;

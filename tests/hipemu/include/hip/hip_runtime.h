@@ -98,6 +98,9 @@ const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int d);
+// emulation: pretend 4 resident workgroups per CU for every kernel
+template <typename F>
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 4; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--configs", default="")
+    ap.add_argument("--family", type=int, default=-1, help="-1: all kernels share the configuration; 1 = MATVEC only, 2 = UPDATE only")
     args = ap.parse_args()
     n = args.size
     dev = torch.device("cuda:0")
@@ -45,7 +46,11 @@ def main():
     configs = [(0, 0, 0)] + configs
     cells = n ** 3
     for rows, tpr, chunk in configs:
-        ctx.set_tuning(rows, tpr, chunk)
+        if args.family < 0:
+            ctx.set_tuning(rows, tpr, chunk)
+        else:
+            ctx.set_tuning(0, 0, 0)
+            ctx.set_tuning_kernel(args.family, rows, tpr, chunk)
         x.zero_()
         ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, 0), want_info=False)   # warm-up
         torch.cuda.synchronize()
@@ -68,7 +73,8 @@ def main():
         up = prof["cg_update"][1] / max(1, prof["cg_update"][0])
         sc = prof["cg_scalar"][1] / max(1, prof["cg_scalar"][0])
         words = esize
-        out = {"size": n, "dtype": args.dtype, "rows": rows, "tpr": tpr, "chunk": chunk,
+        plans = {f: ctx.query_plan(grid, False, f) for f in (1, 2)}
+        out = {"size": n, "dtype": args.dtype, "family": args.family, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
                "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_scalar": round(sc, 5),
                "ms_iter_events": round(mv + up + 2 * sc, 5), "ms_iter_wall": round(wall_ms / args.iters, 5),
                "alg_GBs_iter_wall": round(10 * words * cells / (wall_ms / args.iters * 1e-3) / 1e9, 1),
