@@ -128,6 +128,30 @@ int phihip_centered_to_staggered(phihip_ctx* ctx, const phihip_grid* grid, const
 int phihip_build_cellflags(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* accessible, const uint8_t* active,
                            int mask_batch, uint8_t* flags, void* stream);
 
+/* ---- f3: obstacles rasterised on the device (phi/physics/fluid.py:130-137, 212-240; phi/geom/_box.py:174-185,217-236;
+ *          phi/geom/_sphere.py:107-120; phi/field/_angular_velocity.py:10-47) ------------------------------------------- */
+typedef enum phihip_obstacle_kind { PHIHIP_OBSTACLE_BOX = 0, PHIHIP_OBSTACLE_SPHERE = 1 } phihip_obstacle_kind;
+/* Obstacle(geometry, velocity, angular_velocity) with geometry = Box / Cuboid (center, half_size) or Sphere (center, radius) */
+typedef struct phihip_obstacle {
+    int32_t kind;                 /* phihip_obstacle_kind */
+    int32_t reserved;
+    double center[3];             /* x, y[, z] */
+    double half_size[3];          /* box: half extents; sphere: half_size[0] = radius */
+    double velocity[3];           /* linear velocity of the obstacle */
+    double angular_velocity[3];   /* rank 2: [0] = scalar rotation speed; rank 3: rotation vector */
+    double rotation[9];           /* box orientation: row-major matrix R (box frame -> world), local = R^T (x - center)
+                                   * (Box.rotated, phi/geom/_box.py:127-152); all zero = identity */
+} phihip_obstacle;
+/* accessible[cell] = 1 unless the cell centre lies inside any obstacle (`~union(geometries)` sampled at the centres,
+ * fluid.py:133); feed it to phihip_build_cellflags. `obstacles` is a HOST array; accessible is a device uint8 array [cells]. */
+int phihip_obstacle_accessible(phihip_ctx* ctx, const phihip_grid* grid, const phihip_obstacle* obstacles, int count,
+                               uint8_t* accessible, void* stream);
+/* fluid.apply_boundary_conditions (fluid.py:212-240), in place on the staggered velocity: for every obstacle in order
+ *   m = clip(1 - sdf(x_face) / bounding_radius(face cell), 0, 1)           (resample(geometry, velocity, soft=True, balance=1))
+ *   v = safe_mul(1 - m, v) + safe_mul(m, (angular_velocity x (x_face - center) + velocity) . e_d)   (second term: moving only) */
+int phihip_apply_obstacles(phihip_ctx* ctx, const phihip_grid* grid, const phihip_obstacle* obstacles, int count,
+                           void* const velocity[3], void* stream);
+
 /* ---- a2/a3: field.divergence (phi/field/_field_math.py:589,617-626) and fluid._balance_divergence (fluid.py:205-209) */
 /* div = divergence(v) [* active]; flags may be NULL. balance != 0 additionally subtracts mean (active-weighted). */
 int phihip_divergence(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], const uint8_t* flags,

@@ -585,21 +585,34 @@ def cg(apply_A, y: np.ndarray, x0: np.ndarray, rtol: float, atol: float, max_ite
 class BoxObstacle:
     lower: Tuple[float, ...]
     upper: Tuple[float, ...]
+    velocity: Optional[Tuple[float, ...]] = None           # Obstacle.velocity (fluid.py:27-37)
+    angular_velocity: Optional[object] = None              # scalar (2-D) or vector (3-D)
+    rotation: Optional[np.ndarray] = None                  # (D, D) matrix box frame -> world (Box.rotated, _box.py:127-152)
+
+    @property
+    def center(self):
+        return tuple((l + u) / 2 for l, u in zip(self.lower, self.upper))
+
+    def _local(self, pts):
+        """ global_to_local(scale=False, origin='center'): R^T (x - center) """
+        r = [p - c for p, c in zip(pts, self.center)]
+        if self.rotation is None:
+            return r
+        R = np.asarray(self.rotation, dtype=float)
+        return [sum(R[c][a] * r[c] for c in range(len(r))) for a in range(len(r))]
 
     def lies_inside(self, pts):
-        center = [(l + u) / 2 for l, u in zip(self.lower, self.upper)]
         half = [(u - l) / 2 for l, u in zip(self.lower, self.upper)]
         ok = np.ones(pts[0].shape, dtype=bool)
-        for a, p in enumerate(pts):
-            ok &= np.abs(p - center[a]) <= half[a]
+        for a, p in enumerate(self._local(pts)):
+            ok &= np.abs(p) <= half[a]
         return ok
 
     def sdf(self, pts):
-        center = [(l + u) / 2 for l, u in zip(self.lower, self.upper)]
         half = [(u - l) / 2 for l, u in zip(self.lower, self.upper)]
         dist = None
-        for a, p in enumerate(pts):
-            da = np.abs(p - center[a]) - half[a]
+        for a, p in enumerate(self._local(pts)):
+            da = np.abs(p) - half[a]
             dist = da if dist is None else np.maximum(dist, da)
         return dist
 
@@ -608,6 +621,8 @@ class BoxObstacle:
 class SphereObstacle:
     center: Tuple[float, ...]
     radius: float
+    velocity: Optional[Tuple[float, ...]] = None
+    angular_velocity: Optional[object] = None
 
     def lies_inside(self, pts):
         d2 = sum((p - c) ** 2 for p, c in zip(pts, self.center))
@@ -650,13 +665,48 @@ def obstacle_masks(obstacles, dom: Domain, dtype=np.float32):
         W[d] = wu
         upper = pad_scalar(active, W, acc_codes, acc_consts)
         hard.append(np.minimum(lower, upper))
+        # factor that apply_boundary_conditions multiplies stationary velocities with: the obstacles are applied one after
+        # the other (fluid.py:225-239), i.e. prod_i (1 - mask_i); returned as soft = 1 - prod for the callers' `1 - soft`
         fpts = face_positions(d, dom, dt)
-        m = np.zeros(dom.comp_shape(d), dtype=dt)
+        keep = np.ones(dom.comp_shape(d), dtype=dtype)
         for ob in obstacles:
-            frac = np.clip(1.0 - ob.sdf(fpts) / radius, 0, 1)
-            m = np.maximum(m, frac)
-        soft.append(m.astype(dtype)[None])
+            frac = np.clip(1.0 - ob.sdf(fpts) / radius, 0, 1).astype(dtype)
+            keep = keep * (1 - frac)
+        soft.append((1 - keep)[None])
     return active, hard, soft
+
+
+def apply_boundary_conditions(v: List[np.ndarray], obstacles, dom: Domain):
+    """ fluid.apply_boundary_conditions (fluid.py:212-240): per obstacle, in order,
+        mask = resample(geometry, velocity, soft=True, balance=1) = clip(1 - sdf(face) / bounding_radius(face cell), 0, 1)
+        v = safe_mul(1 - mask, v) [+ safe_mul(mask, angular_velocity x (x - center) + velocity) for moving obstacles]
+    (AngularVelocity without falloff: cross(strength, distances), phi/field/_angular_velocity.py:40-46). """
+    D = dom.rank
+    dtype = v[0].dtype.type
+    radius = float(np.sqrt(sum((0.5 * h) ** 2 for h in dom.dx)))
+    out = []
+    for d in range(D):
+        fpts = face_positions(d, dom, np.float64)
+        val = v[d].copy()
+        for ob in obstacles:
+            m = np.clip(1.0 - ob.sdf(fpts) / radius, 0, 1).astype(dtype)[None]
+            keep = 1 - m
+            val = np.where(keep == 0, dtype(0), keep * val)
+            lin = ob.velocity if ob.velocity is not None else (0.0,) * D
+            ang = ob.angular_velocity if ob.angular_velocity is not None else 0.0
+            moving = any(float(c) != 0 for c in lin) or np.any(np.asarray(ang, dtype=float) != 0)
+            if moving:
+                r = [fpts[a] - ob.center[a] for a in range(D)]
+                if D == 2:
+                    w = float(np.asarray(ang, dtype=float).reshape(-1)[0])
+                    u = (-w * r[1], w * r[0])[d]
+                else:
+                    w = np.broadcast_to(np.asarray(ang, dtype=float), (3,)) if np.ndim(ang) == 0 else np.asarray(ang, dtype=float)
+                    u = (w[1] * r[2] - w[2] * r[1], w[2] * r[0] - w[0] * r[2], w[0] * r[1] - w[1] * r[0])[d]
+                u = (u + float(lin[d])).astype(dtype)[None]
+                val = val + np.where(m == 0, dtype(0), m * u)
+        out.append(val)
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -685,7 +735,7 @@ def make_incompressible(v: List[np.ndarray], dom: Domain, obstacles=(), x0: Opti
     hard = active = None
     if obstacles:
         active, hard, soft = obstacle_masks(obstacles, dom, dtype.type)
-        v = [vd * (1 - m) for vd, m in zip(v, soft)]        # apply_boundary_conditions, stationary obstacles
+        v = apply_boundary_conditions(v, obstacles, dom)
     div = divergence(v, dom)
     if active is not None:
         div = div * active

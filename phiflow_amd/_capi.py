@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_grad_subtract",
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
     "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
-    "phihip_set_tuning_kernel", "phihip_query_plan",
+    "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
 )
 
 
@@ -46,6 +46,36 @@ class Grid(ctypes.Structure):
     _fields_ = [("rank", c_int32), ("dtype", c_int32), ("batch", c_int32), ("res", c_int32 * 3),
                 ("lower", c_double * 3), ("upper", c_double * 3), ("bc", (c_int32 * 2) * 3),
                 ("bc_val", ((c_double * 3) * 2) * 3)]
+
+
+class ObstacleStruct(ctypes.Structure):
+    """ phihip_obstacle """
+    _fields_ = [("kind", c_int32), ("reserved", c_int32), ("center", c_double * 3), ("half_size", c_double * 3),
+                ("velocity", c_double * 3), ("angular_velocity", c_double * 3), ("rotation", c_double * 9)]
+
+
+OBSTACLE_BOX, OBSTACLE_SPHERE = 0, 1
+
+
+def make_obstacles(items) -> "ctypes.Array":
+    """ items: sequence of dicts(kind, center, half_size, velocity, angular_velocity) -> ctypes array of phihip_obstacle """
+    arr = (ObstacleStruct * max(1, len(items)))()
+    for k, it in enumerate(items):
+        arr[k].kind = int(it["kind"])
+        for d, val in enumerate(it["center"]):
+            arr[k].center[d] = float(val)
+        for d, val in enumerate(it["half_size"]):
+            arr[k].half_size[d] = float(val)
+        for d, val in enumerate(it.get("velocity", ())):
+            arr[k].velocity[d] = float(val)
+        for d, val in enumerate(it.get("angular_velocity", ())):
+            arr[k].angular_velocity[d] = float(val)
+        rot = it.get("rotation")
+        if rot is not None:   # (rank x rank) matrix, box frame -> world
+            for a, row in enumerate(rot):
+                for c, val in enumerate(row):
+                    arr[k].rotation[3 * a + c] = float(val)
+    return arr
 
 
 class Solve(ctypes.Structure):
@@ -116,6 +146,8 @@ class Library:
                                                   POINTER(_Ptr3), c_void_p, c_double, c_double, c_void_p]
         d.phihip_centered_to_staggered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
                                                    POINTER(c_double * 3), c_int, POINTER(_Ptr3), c_void_p]
+        d.phihip_obstacle_accessible.argtypes = [c_void_p, POINTER(Grid), POINTER(ObstacleStruct), c_int, c_void_p, c_void_p]
+        d.phihip_apply_obstacles.argtypes = [c_void_p, POINTER(Grid), POINTER(ObstacleStruct), c_int, POINTER(_Ptr3), c_void_p]
         d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         d.phihip_divergence.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p, c_void_p]
         d.phihip_laplace_apply.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
@@ -203,6 +235,13 @@ class Context:
         self.lib.check(self.lib.dll.phihip_centered_to_staggered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
                                                                  ctypes.byref(vec), int(bool(accumulate)), ctypes.byref(ptr3(out)),
                                                                  stream or None))
+
+    def obstacle_accessible(self, grid, obstacles, count, accessible, stream=0):
+        self.lib.check(self.lib.dll.phihip_obstacle_accessible(self.handle, ctypes.byref(grid), obstacles, int(count), accessible, stream or None))
+
+    def apply_obstacles(self, grid, obstacles, count, velocity, stream=0):
+        self.lib.check(self.lib.dll.phihip_apply_obstacles(self.handle, ctypes.byref(grid), obstacles, int(count), ctypes.byref(ptr3(velocity)),
+                                                           stream or None))
 
     def build_cellflags(self, grid, accessible, active, mask_batch, flags, stream=0):
         self.lib.check(self.lib.dll.phihip_build_cellflags(self.handle, ctypes.byref(grid), accessible or None, active or None,

@@ -306,6 +306,37 @@ int phihip_centered_to_staggered(phihip_ctx* ctx, const phihip_grid* grid, const
     return run_centered_to_staggered(ctx, v, sfield, s_bc, s_val, vec, accumulate, o, s);
 }
 
+static int check_obstacles(const GridView& v, const phihip_obstacle* obstacles, int count) {
+    PHIHIP_REQUIRE(count >= 0, "obstacle count must be >= 0");
+    PHIHIP_REQUIRE(count == 0 || obstacles != nullptr, "obstacles is NULL");
+    for (int k = 0; k < count; ++k) {
+        PHIHIP_REQUIRE(obstacles[k].kind == PHIHIP_OBSTACLE_BOX || obstacles[k].kind == PHIHIP_OBSTACLE_SPHERE, "obstacle %d: unknown kind %d", k,
+                       obstacles[k].kind);
+        const int nh = obstacles[k].kind == PHIHIP_OBSTACLE_SPHERE ? 1 : v.rank;
+        for (int d = 0; d < nh; ++d) PHIHIP_REQUIRE(obstacles[k].half_size[d] >= 0, "obstacle %d: negative size", k);
+    }
+    return PHIHIP_OK;
+}
+
+int phihip_obstacle_accessible(phihip_ctx* ctx, const phihip_grid* grid, const phihip_obstacle* obstacles, int count, uint8_t* accessible,
+                               void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(accessible != nullptr, "accessible is NULL");
+    PHIHIP_TRY(check_obstacles(v, obstacles, count));
+    return run_obstacle_accessible(ctx, v, obstacles, count, accessible, s);
+}
+
+int phihip_apply_obstacles(phihip_ctx* ctx, const phihip_grid* grid, const phihip_obstacle* obstacles, int count, void* const velocity[3],
+                           void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)velocity, "velocity"));
+    PHIHIP_TRY(check_obstacles(v, obstacles, count));
+    if (count == 0) return PHIHIP_OK;
+    void* u[3];
+    remap3w(v, velocity, u);
+    return run_apply_obstacles(ctx, v, obstacles, count, u, s);
+}
+
 int phihip_build_cellflags(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* accessible, const uint8_t* active, int mask_batch,
                            uint8_t* flags, void* stream) {
     PHIHIP_ENTER(ctx, grid);

@@ -142,6 +142,8 @@ int run_mac_cormack_centered(phihip_ctx*, const GridView&, const void* s, const 
                              const void* const v[3], void* out, double dt, double strength, hipStream_t);
 int run_centered_to_staggered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
                               const double vector[3], int accumulate, void* const out[3], hipStream_t);
+int run_obstacle_accessible(phihip_ctx*, const GridView&, const phihip_obstacle* obs, int count, uint8_t* accessible, hipStream_t);
+int run_apply_obstacles(phihip_ctx*, const GridView&, const phihip_obstacle* obs, int count, void* const v[3], hipStream_t);
 int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);
 int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const uint8_t* flags, int mask_batch, int balance, void* div, hipStream_t);
 int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);

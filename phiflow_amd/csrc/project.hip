@@ -332,6 +332,198 @@ int run_centered_to_staggered(phihip_ctx* ctx, const GridView& v, const void* sf
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// obstacles rasterised on the device: hard cell mask and apply_boundary_conditions with moving obstacles.
+// The reference evaluates these on NumPy every step (`with NUMPY:` fluid.py:132); here the obstacle list travels as kernel
+// arguments, nothing is rasterised on the host. Positions and distances are computed in double.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kObstaclesPerLaunch = 16;
+
+struct ObstacleSet {
+    int count;
+    int kind[kObstaclesPerLaunch];
+    double center[kObstaclesPerLaunch][3];   // internal axis order
+    double half[kObstaclesPerLaunch][3];
+    double vel[kObstaclesPerLaunch][3];
+    double ang[kObstaclesPerLaunch][3];
+    double rot[kObstaclesPerLaunch][3][3];   // box frame -> world, internal axis order
+    int moving[kObstaclesPerLaunch];
+    int rotated[kObstaclesPerLaunch];
+};
+
+static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* obs, int first, int count) {
+    ObstacleSet s;
+    memset(&s, 0, sizeof(s));
+    s.count = count;
+    for (int k = 0; k < count; ++k) {
+        const phihip_obstacle& o = obs[first + k];
+        s.kind[k] = o.kind;
+        bool moving = false;
+        for (int d = 0; d < v.rank; ++d) {
+            s.center[k][d + v.ax0] = o.center[d];
+            s.half[k][d + v.ax0] = o.kind == PHIHIP_OBSTACLE_SPHERE ? o.half_size[0] : o.half_size[d];
+            s.vel[k][d + v.ax0] = o.velocity[d];
+            moving = moving || o.velocity[d] != 0.0;
+        }
+        if (v.rank == 2) {
+            s.ang[k][0] = o.angular_velocity[0];   // rotation about the missing axis a0
+            moving = moving || o.angular_velocity[0] != 0.0;
+        } else {
+            for (int d = 0; d < 3; ++d) {
+                s.ang[k][d] = o.angular_velocity[d];
+                moving = moving || o.angular_velocity[d] != 0.0;
+            }
+        }
+        s.moving[k] = moving ? 1 : 0;
+        bool any = false;
+        for (int i = 0; i < 9; ++i) any = any || o.rotation[i] != 0.0;
+        bool identity = true;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) s.rot[k][a][c] = a == c ? 1.0 : 0.0;
+        if (any)
+            for (int a = 0; a < v.rank; ++a)
+                for (int c = 0; c < v.rank; ++c) {
+                    s.rot[k][a + v.ax0][c + v.ax0] = o.rotation[a * 3 + c];
+                    identity = identity && o.rotation[a * 3 + c] == (a == c ? 1.0 : 0.0);
+                }
+        s.rotated[k] = (any && !identity && o.kind == PHIHIP_OBSTACLE_BOX) ? 1 : 0;
+    }
+    return s;
+}
+
+// box-frame coordinates of x - center: R^T (x - c)  (Box.global_to_local(scale=False, origin='center'), phi/geom/_box.py:134-152)
+__device__ __forceinline__ void obstacle_local(const ObstacleSet& s, int k, const double (&x)[3], int ax0, double (&loc)[3]) {
+    double r[3] = {0, 0, 0};
+    for (int a = ax0; a < 3; ++a) r[a] = x[a] - s.center[k][a];
+    if (!s.rotated[k]) {
+        for (int a = 0; a < 3; ++a) loc[a] = r[a];
+        return;
+    }
+    for (int a = 0; a < 3; ++a) {
+        loc[a] = 0;
+        for (int c = ax0; c < 3; ++c) loc[a] += s.rot[k][c][a] * r[c];
+    }
+}
+
+// lies_inside: box |x - c| <= half (inclusive, phi/geom/_box.py:174-185); sphere |x - c|^2 <= r^2
+__device__ __forceinline__ bool obstacle_inside(const ObstacleSet& s, int k, const double (&x)[3], int ax0) {
+    if (s.kind[k] == PHIHIP_OBSTACLE_SPHERE) {
+        double d2 = 0;
+        for (int a = ax0; a < 3; ++a) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
+        return d2 <= s.half[k][ax0] * s.half[k][ax0];
+    }
+    double loc[3];
+    obstacle_local(s, k, x, ax0, loc);
+    bool in = true;
+    for (int a = ax0; a < 3; ++a) in = in && (fabs(loc[a]) <= s.half[k][a]);
+    return in;
+}
+
+// approximate_signed_distance: box = L-infinity distance to the surface (phi/geom/_box.py:217-236), sphere = |x - c| - r
+__device__ __forceinline__ double obstacle_sdf(const ObstacleSet& s, int k, const double (&x)[3], int ax0) {
+    if (s.kind[k] == PHIHIP_OBSTACLE_SPHERE) {
+        double d2 = 0;
+        for (int a = ax0; a < 3; ++a) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
+        return sqrt(d2) - s.half[k][ax0];
+    }
+    double loc[3];
+    obstacle_local(s, k, x, ax0, loc);
+    double dist = -1e300;
+    for (int a = ax0; a < 3; ++a) {
+        const double da = fabs(loc[a]) - s.half[k][a];
+        dist = da > dist ? da : dist;
+    }
+    return dist;
+}
+
+__global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s,
+                                                                     int first_launch, uint8_t* accessible) {
+    const double lower[3] = {lower0, lower1, lower2};
+    for (long long cell = (long long)blockIdx.x * kBlock + threadIdx.x; cell < g.cells; cell += (long long)gridDim.x * kBlock) {
+        const int idx[3] = {(int)(cell / ((long long)g.n[2] * g.n[1])), (int)((cell / g.n[2]) % g.n[1]), (int)(cell % g.n[2])};
+        double x[3] = {0, 0, 0};
+        for (int a = g.ax0; a < 3; ++a) x[a] = lower[a] + (idx[a] + 0.5) * g.dx[a];
+        bool inside = false;
+        for (int k = 0; k < s.count; ++k) inside = inside || obstacle_inside(s, k, x, g.ax0);
+        const uint8_t prev = first_launch ? (uint8_t)1 : accessible[cell];
+        accessible[cell] = inside ? (uint8_t)0 : prev;
+    }
+}
+
+int run_obstacle_accessible(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, uint8_t* accessible, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    const int nblk = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    int first = 0;
+    do {
+        const int n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
+        const ObstacleSet set = make_obstacle_set(v, obs, first, n);
+        hipLaunchKernelGGL(obstacle_accessible_kernel, dim3(nblk), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set,
+                           first == 0 ? 1 : 0, accessible);
+        first += n;
+    } while (first < count);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s, int ca,
+                                                                 T* __restrict__ vc) {
+    const double lower[3] = {lower0, lower1, lower2};
+    const int b = blockIdx.y;
+    const long long total = g.ccells[ca];
+    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    double r2 = 0;   // bounding radius of a face cell: |half size of a grid cell|
+    for (int a = g.ax0; a < 3; ++a) r2 += 0.25 * g.dx[a] * g.dx[a];
+    const double radius = sqrt(r2);
+    T* __restrict__ V = vc + (long long)b * total;
+    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
+        const int idx[3] = {(int)(f / ((long long)c2 * c1)), (int)((f / c2) % c1), (int)(f % c2)};
+        double x[3] = {0, 0, 0};
+        for (int a = g.ax0; a < 3; ++a) x[a] = a == ca ? lower[a] + (double)(idx[a] + g.off[a]) * g.dx[a] : lower[a] + (idx[a] + 0.5) * g.dx[a];
+        T val = V[f];
+        for (int k = 0; k < s.count; ++k) {
+            double m = 1.0 - obstacle_sdf(s, k, x, g.ax0) / radius;
+            m = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+            const T mt = (T)m, keep = T(1) - mt;
+            val = keep == T(0) ? T(0) : keep * val;   // safe_mul(1 - mask, velocity)
+            if (s.moving[k]) {
+                double r[3] = {0, 0, 0};
+                for (int a = g.ax0; a < 3; ++a) r[a] = x[a] - s.center[k][a];
+                double u;
+                if (g.ax0 == 1)   // rank 2: cross(w, r) = (-w r_y, w r_x)
+                    u = ca == 1 ? -s.ang[k][0] * r[2] : s.ang[k][0] * r[1];
+                else
+                    u = ca == 0 ? s.ang[k][1] * r[2] - s.ang[k][2] * r[1]
+                                : (ca == 1 ? s.ang[k][2] * r[0] - s.ang[k][0] * r[2] : s.ang[k][0] * r[1] - s.ang[k][1] * r[0]);
+                u += s.vel[k][ca];
+                if (mt != T(0)) val += mt * (T)u;     // safe_mul(mask, angular_velocity + obstacle.velocity)
+            }
+        }
+        V[f] = val;
+    }
+}
+
+int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, void* const vel[3], hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    for (int first = 0; first < count; first += kObstaclesPerLaunch) {
+        const int n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
+        const ObstacleSet set = make_obstacle_set(v, obs, first, n);
+        for (int ca = v.ax0; ca < 3; ++ca) {
+            const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
+            if (v.dtype == PHIHIP_F64)
+                hipLaunchKernelGGL(apply_obstacles_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
+                                   v.lower[2], set, ca, (double*)vel[ca]);
+            else
+                hipLaunchKernelGGL(apply_obstacles_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
+                                   v.lower[2], set, ca, (float*)vel[ca]);
+        }
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // obstacle flags (fluid.py:130-137: accessible, hard_bcs = stagger(accessible, minimum), active)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void cellflags_kernel(VelGrid g, const uint8_t* accessible, const uint8_t* active, int per_batch,

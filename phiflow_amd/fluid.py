@@ -2,7 +2,7 @@
 Pressure projection on the HIP backend (reference: phi/physics/fluid.py).
 
 `make_incompressible` keeps the reference's signature and semantics for the order-2 StaggeredGrid path:
-    obstacle masks (host, like `with NUMPY:` fluid.py:130-137)  ->  divergence [* active]  ->  balance (non-flexible
+    obstacle masks (device kernels; the reference: `with NUMPY:` fluid.py:130-137)  ->  divergence [* active]  ->  balance (non-flexible
     boundaries)  ->  CG on the masked Laplacian from x0  ->  v -= hard_bcs * grad p.
 The linear operator is applied matrix-free by HIP kernels (the reference assembles a sparse matrix per call).
 """
@@ -14,23 +14,56 @@ import torch
 from . import _capi
 from .extrapolation import pressure_extrapolation
 from .field import Field, _check_pressure_padding, _ptrs, _sample_points
-from .geom import Geometry, union_lies_inside
+from .geom import Box, Geometry, Sphere
 from .solve import Diverged, NotConverged, Solve, SolveInfo
 
 
 class Obstacle:
-    """ Stationary obstacle (phi/physics/fluid.py:21-91). Moving / rotating obstacles are a next-row item. """
+    """ An obstacle defines boundary conditions inside a geometry; it can have a linear and an angular velocity
+    (phi/physics/fluid.py:21-91). Geometries: `Box` / `Cuboid` and `Sphere`. """
 
     def __init__(self, geometry: Geometry, velocity=0, angular_velocity=0):
-        if velocity not in (0, 0.0) or angular_velocity not in (0, 0.0):
-            raise NotImplementedError("HIP backend: only stationary obstacles are supported")
         self.geometry = geometry
-        self.velocity = 0
-        self.angular_velocity = 0
+        D = len(geometry.dims)
+        if isinstance(velocity, dict):
+            velocity = [velocity.get(d, 0.0) for d in geometry.dims]
+        self.velocity = tuple(float(c) for c in velocity) if isinstance(velocity, (tuple, list)) else (float(velocity),) * D
+        if isinstance(angular_velocity, dict):
+            angular_velocity = [angular_velocity.get(d, 0.0) for d in geometry.dims]
+        if isinstance(angular_velocity, (tuple, list)):
+            assert D == 3 and len(angular_velocity) == 3, "a vector-valued angular velocity needs a 3-D geometry"
+            self.angular_velocity = tuple(float(c) for c in angular_velocity)
+        else:
+            assert D == 2 or float(angular_velocity) == 0.0, "3-D obstacles rotate about a vector: pass angular_velocity=(wx, wy, wz)"
+            self.angular_velocity = (float(angular_velocity), 0.0, 0.0) if D == 2 else (0.0, 0.0, 0.0)
+
+    @property
+    def is_rotating(self):
+        return any(c != 0 for c in self.angular_velocity)
+
+    @property
+    def is_moving(self):
+        return any(c != 0 for c in self.velocity)
 
     @property
     def is_stationary(self):
-        return True
+        return not self.is_moving and not self.is_rotating
+
+    def with_geometry(self, geometry):
+        return Obstacle(geometry, self.velocity, self.angular_velocity if len(geometry.dims) == 3 else self.angular_velocity[0])
+
+    def shifted(self, delta):
+        return self.with_geometry(self.geometry.shifted(delta))
+
+    def at(self, position):
+        return self.with_geometry(self.geometry.at(position))
+
+    def rotated(self, angle):
+        return self.with_geometry(self.geometry.rotated(angle))
+
+    def __eq__(self, other):
+        return isinstance(other, Obstacle) and repr(self.geometry) == repr(other.geometry) and self.velocity == other.velocity and \
+            self.angular_velocity == other.angular_velocity
 
 
 def _get_obstacles_for(obstacles, velocity: Field) -> List[Obstacle]:
@@ -47,57 +80,65 @@ def _get_obstacles_for(obstacles, velocity: Field) -> List[Obstacle]:
     return out
 
 
+def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field):
+    """ ctypes array of `phihip_obstacle` in the velocity's dimension order """
+    items = []
+    for ob in obstacles:
+        geo = ob.geometry
+        order = [geo.dims.index(d) for d in velocity.dims]
+        if isinstance(geo, Sphere):
+            kind, half = _capi.OBSTACLE_SPHERE, [geo.radius] * len(order)
+        elif isinstance(geo, Box):
+            kind, half = _capi.OBSTACLE_BOX, [geo.half_size[i] for i in order]
+        else:
+            raise NotImplementedError(f"HIP backend: obstacle geometry {type(geo).__name__} is not supported (Box / Cuboid / Sphere)")
+        ang = ob.angular_velocity if len(order) == 2 else [ob.angular_velocity[i] for i in order]
+        rot = None
+        if isinstance(geo, Box) and geo.rot is not None:
+            rot = [[geo.rot[i][j] for j in order] for i in order]
+        items.append(dict(kind=kind, center=[geo.center[i] for i in order], half_size=half, velocity=[ob.velocity[i] for i in order],
+                          angular_velocity=ang, rotation=rot))
+    return _capi.make_obstacles(items)
+
+
 class _MaskCache:
-    """ obstacle masks depend only on (grid, boundary, obstacle geometry): rasterise once, keep on the device """
+    """ packed stencil flags depend only on (grid, boundary, obstacle geometry): rasterise once per configuration, on the device """
 
     def __init__(self):
         self.entries = {}
 
     def get(self, velocity: Field, obstacles: Sequence[Obstacle], user_active: Optional[Field]):
         key = (repr(velocity.resolution), repr(velocity.bounds), repr(velocity.boundary), tuple(repr(o.geometry) for o in obstacles),
-               velocity.dtype, id(user_active) if user_active is not None else None, id(velocity.backend))
+               id(user_active) if user_active is not None else None, id(velocity.backend))
         if key not in self.entries or user_active is not None:
-            self.entries[key] = _build_masks(velocity, obstacles, user_active)
+            if len(self.entries) > 64:
+                self.entries.clear()   # moving obstacles produce a new key every step
+            self.entries[key] = _build_flags(velocity, obstacles, user_active)
         return self.entries[key]
 
 
 _MASKS = _MaskCache()
 
 
-def _reordered_points(velocity: Field, comp: Optional[int], geometry: Geometry):
-    pts = _sample_points(velocity.resolution, velocity.bounds, comp, velocity.boundary)
-    return [pts[velocity.dims.index(d)] for d in geometry.dims]
-
-
-def _build_masks(velocity: Field, obstacles: Sequence[Obstacle], user_active: Optional[Field]):
-    """ accessible (cells), soft face factors 1 - mask (faces) on the host; packed stencil flags on the device. """
+def _build_flags(velocity: Field, obstacles: Sequence[Obstacle], user_active: Optional[Field]) -> torch.Tensor:
+    """ accessible = ~union(obstacles) at the cell centres and hard_bcs / active packed into one byte per cell -- both kernels
+    (the reference evaluates this part `with NUMPY:`, fluid.py:130-136) """
     be = velocity.backend
     res = tuple(velocity.resolution.values())
+    grid1 = velocity.grid_struct(batch=1)
     accessible_t = None
-    soft = None
     if obstacles:
-        inside = np.zeros(res, dtype=bool)
-        for ob in obstacles:
-            inside |= ob.geometry.lies_inside(_reordered_points(velocity, None, ob.geometry))
-        accessible_t = be.as_tensor((~inside).astype(np.uint8), torch.uint8)
-        # soft mask, balance = 1: clip(1 - sdf / r, 0, 1) with r = bounding radius of a face cell (phi/geom/_geom.py:302-308)
-        radius = float(np.sqrt(sum((0.5 * h) ** 2 for h in velocity.dx)))
-        soft = []
-        for d in range(velocity.spatial_rank):
-            m = None
-            for ob in obstacles:
-                frac = np.clip(1.0 - ob.geometry.approximate_signed_distance(_reordered_points(velocity, d, ob.geometry)) / radius, 0, 1)
-                m = frac if m is None else np.maximum(m, frac)
-            soft.append(be.as_tensor(1.0 - m, velocity.dtype))
+        accessible_t = be.empty(res, torch.uint8)
+        be.ctx.obstacle_accessible(grid1, _obstacle_array(obstacles, velocity), len(obstacles), accessible_t.data_ptr(), be.stream())
     active_t = None
     if user_active is not None:
         assert user_active.is_centered and user_active.resolution == velocity.resolution
         assert not user_active.batched, "HIP backend: batched `active` masks are not supported yet"
         active_t = (user_active.values[0] != 0).to(torch.uint8).contiguous()
     flags = be.empty(res, torch.uint8)
-    be.ctx.build_cellflags(velocity.grid_struct(batch=1), accessible_t.data_ptr() if accessible_t is not None else 0,
+    be.ctx.build_cellflags(grid1, accessible_t.data_ptr() if accessible_t is not None else 0,
                            active_t.data_ptr() if active_t is not None else 0, 1, flags.data_ptr(), be.stream())
-    return flags, soft
+    return flags
 
 
 def make_incompressible(velocity: Field,
@@ -113,7 +154,7 @@ def make_incompressible(velocity: Field,
 
     Args:
         velocity: `StaggeredGrid`.
-        obstacles: `Obstacle` or `Geometry` or tuple/list thereof (stationary).
+        obstacles: `Obstacle` or `Geometry` or tuple/list thereof (Box / Cuboid / Sphere; stationary, moving or rotating).
         solve: `Solve` object specifying tolerances, `x0` (pressure guess) and `max_iterations`.
         active: (Optional) `CenteredGrid` mask for which cells the pressure should be solved. If given, the total
             divergence is never subtracted, even if all values are 1.
@@ -133,9 +174,9 @@ def make_incompressible(velocity: Field,
     obstacles = _get_obstacles_for(obstacles, velocity)
     be = velocity.backend
     all_active = active is None
-    flags = soft = None
+    flags = None
     if obstacles or active is not None:
-        flags, soft = _MASKS.get(velocity, obstacles, active)
+        flags = _MASKS.get(velocity, obstacles, active)
     fp64 = velocity.dtype == torch.float64
     solve = solve.with_defaults(fp64)
     balance = (not velocity.boundary.is_flexible) and all_active   # fluid.py:145
@@ -151,8 +192,10 @@ def make_incompressible(velocity: Field,
         pressure = x0.values.to(velocity.dtype)
         pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()
     new_v = [t.clone() for t in velocity.values]
+    if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
+        be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
     csolve = _capi.Solve(solve.rel_tol, solve.abs_tol, int(solve.max_iterations), int(solve.refresh_every), int(solve.check_every), 0)
-    infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), _ptrs(soft) if soft is not None else None,
+    infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
                                        flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
                                        True, be.stream())
     info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
@@ -179,12 +222,15 @@ def _raise_if_failed(info: SolveInfo):
 
 
 def apply_boundary_conditions(velocity: Field, obstacles) -> Field:
-    """ Enforces velocity boundary conditions of stationary obstacles: v *= 1 - soft mask (phi/physics/fluid.py:212-240) """
+    """ Enforces velocity boundary conditions on a velocity grid (phi/physics/fluid.py:212-240): cells inside obstacles get their
+    velocity from the obstacle movement (linear + angular), cells far away are unaffected; soft transition over one cell. """
     obstacles = _get_obstacles_for(obstacles, velocity)
     if not obstacles:
         return velocity
-    _, soft = _MASKS.get(velocity, obstacles, None)
-    return velocity.with_values([torch.where(m == 0, torch.zeros_like(v), v * m) for v, m in zip(velocity.values, soft)])
+    be = velocity.backend
+    new_v = [t.clone() for t in velocity.values]
+    be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
+    return velocity.with_values(new_v)
 
 
 def masked_laplace(pressure: Field, v_boundary, hard_bcs=None, active=None, flags: Optional[torch.Tensor] = None) -> Field:

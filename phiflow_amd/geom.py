@@ -1,7 +1,8 @@
 """
-Geometry subset needed by the grid fluid step: `Box` (domain bounds and box obstacles) and `Sphere`
-(reference: phi/geom/_box.py:46-236, phi/geom/_sphere.py). Geometries are only ever *rasterised to masks on the host*
--- exactly what PhiFlow does (`with NUMPY:` in phi/physics/fluid.py:132).
+Geometry subset needed by the grid fluid step: `Box` / `Cuboid` (domain bounds and box obstacles, optionally rotated) and
+`Sphere` (reference: phi/geom/_box.py:46-236, phi/geom/_sphere.py). Obstacles are rasterised by device kernels
+(`phihip_obstacle_accessible`, `phihip_apply_obstacles`); the host-side `lies_inside` / `approximate_signed_distance` below only
+serve field initialisers such as `CenteredGrid(Sphere(...))`.
 """
 from typing import Dict, Sequence, Tuple
 
@@ -9,7 +10,25 @@ import numpy as np
 
 
 class Vector(dict):
-    """ named vector `vec(x=1, y=0)` """
+    """ named vector `vec(x=1, y=0)` with elementwise arithmetic (`center + velocity * dt`, `x % domain.size`) """
+
+    def _zip(self, other, fn):
+        if isinstance(other, dict):
+            return Vector({k: fn(v, other[k]) for k, v in self.items()})
+        if isinstance(other, (tuple, list)):
+            assert len(other) == len(self)
+            return Vector({k: fn(v, o) for (k, v), o in zip(self.items(), other)})
+        return Vector({k: fn(v, other) for k, v in self.items()})
+
+    def __add__(self, o): return self._zip(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._zip(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._zip(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._zip(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._zip(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
+    def __mod__(self, o): return self._zip(o, lambda a, b: a % b)
+    def __neg__(self): return Vector({k: -v for k, v in self.items()})
 
 
 def vec(**components) -> Vector:
@@ -40,12 +59,14 @@ class _BoxType(type):
 
 
 class Box(Geometry, metaclass=_BoxType):
-    """ axis-aligned box; `Box(x=100, y=(10, 20))`: a number means (0, number) """
+    """ box; `Box(x=100, y=(10, 20))`: a number means (0, number). `rot`: optional (D, D) matrix box frame -> world
+    (set by `rotated`); bounds describe the box in its own frame around `center`. """
 
-    def __init__(self, **bounds):
+    def __init__(self, _rot=None, **bounds):
         self.dims = tuple(bounds.keys())
         self.lower = tuple(float(b[0]) if isinstance(b, (tuple, list)) else 0.0 for b in bounds.values())
         self.upper = tuple(float(b[1]) if isinstance(b, (tuple, list)) else float(b) for b in bounds.values())
+        self.rot = None if _rot is None else np.asarray(_rot, dtype=float)
 
     @property
     def size(self):
@@ -59,26 +80,60 @@ class Box(Geometry, metaclass=_BoxType):
     def half_size(self):
         return tuple((u - l) / 2 for l, u in zip(self.lower, self.upper))
 
+    def _local(self, points):
+        """ global_to_local(scale=False, origin='center') = R^T (x - center)  (phi/geom/_box.py:134-152) """
+        r = [points[a] - self.center[a] for a in range(len(self.dims))]
+        if self.rot is None:
+            return r
+        return [sum(self.rot[c][a] * r[c] for c in range(len(r))) for a in range(len(r))]
+
     def lies_inside(self, points):
-        """ |x - c| <= half, inclusive (phi/geom/_box.py:174-185) """
-        ok = np.ones(points[0].shape, dtype=bool)
-        for a in range(len(self.dims)):
-            ok &= np.abs(points[a] - self.center[a]) <= self.half_size[a]
+        """ |local| <= half, inclusive (phi/geom/_box.py:174-185) """
+        ok = np.ones(np.shape(points[0]), dtype=bool)
+        for a, p in enumerate(self._local(points)):
+            ok &= np.abs(p) <= self.half_size[a]
         return ok
 
     def approximate_signed_distance(self, points):
         """ L-infinity distance to the surface (phi/geom/_box.py:217-236) """
         dist = None
-        for a in range(len(self.dims)):
-            da = np.abs(points[a] - self.center[a]) - self.half_size[a]
+        for a, p in enumerate(self._local(points)):
+            da = np.abs(p) - self.half_size[a]
             dist = da if dist is None else np.maximum(dist, da)
         return dist
 
+    def rotated(self, angle):
+        """ `Box.rotated(angle)` (phi/geom/_box.py:127-129): 2-D: counter-clockwise angle in radians; 3-D: a (3, 3) rotation matrix """
+        if len(self.dims) == 2:
+            c, s = float(np.cos(angle)), float(np.sin(angle))
+            R = np.array([[c, -s], [s, c]])
+        else:
+            R = np.asarray(angle, dtype=float)
+            assert R.shape == (3, 3), "3-D boxes rotate by a (3, 3) rotation matrix"
+        rot = R if self.rot is None else self.rot @ R
+        return Box(_rot=rot, **{d: (l, u) for d, l, u in zip(self.dims, self.lower, self.upper)})
+
+    def shifted(self, delta):
+        """ `geometry.shifted(delta)`; delta: sequence or dict dim -> offset """
+        delta = [delta.get(d, 0.0) for d in self.dims] if isinstance(delta, dict) else list(delta)
+        return Box(_rot=self.rot, **{d: (l + dd, u + dd) for d, l, u, dd in zip(self.dims, self.lower, self.upper, delta)})
+
+    def at(self, center):
+        center = [center.get(d, c) for d, c in zip(self.dims, self.center)] if isinstance(center, dict) else list(center)
+        return Box(_rot=self.rot, **{d: (c - h, c + h) for d, c, h in zip(self.dims, center, self.half_size)})
+
     def __repr__(self):
-        return "Box(" + ", ".join(f"{d}=({l}, {u})" for d, l, u in zip(self.dims, self.lower, self.upper)) + ")"
+        rot = "" if self.rot is None else ", rot=" + np.array2string(self.rot, precision=12, separator=",").replace("\n", "")
+        return "Box(" + ", ".join(f"{d}=({l}, {u})" for d, l, u in zip(self.dims, self.lower, self.upper)) + rot + ")"
 
 
-Cuboid = Box
+def Cuboid(center=None, **size) -> Box:
+    """ `Cuboid(vec(x=20, y=80), x=20, y=20)`: box given by centre and edge lengths (phi/geom/_box.py:418); without a centre the
+    arguments are bounds like `Box(...)` """
+    if center is None:
+        return Box(**size)
+    c = [center[d] for d in size] if isinstance(center, dict) else list(center)
+    return Box(**{d: (ci - float(s) / 2, ci + float(s) / 2) for (d, s), ci in zip(size.items(), c)})
 
 
 class Sphere(Geometry):
@@ -96,6 +151,14 @@ class Sphere(Geometry):
     def approximate_signed_distance(self, points):
         d2 = sum((p - c) ** 2 for p, c in zip(points, self.center))
         return np.sqrt(d2) - self.radius
+
+    def shifted(self, delta):
+        delta = [delta.get(d, 0.0) for d in self.dims] if isinstance(delta, dict) else list(delta)
+        return Sphere(self.radius, **{d: c + dd for d, c, dd in zip(self.dims, self.center, delta)})
+
+    def at(self, center):
+        center = [center.get(d, c) for d, c in zip(self.dims, self.center)] if isinstance(center, dict) else list(center)
+        return Sphere(self.radius, **dict(zip(self.dims, center)))
 
     def __repr__(self):
         return f"Sphere({dict(zip(self.dims, self.center))}, radius={self.radius})"

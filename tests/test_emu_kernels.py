@@ -142,6 +142,25 @@ def test_obstacles(emu_ctx, dtype):
     pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, rng, obstacles=obstacles)
 
 
+def test_obstacle_rasterisation_and_moving_obstacles(emu_ctx):
+    """ overlapping box + sphere, linear and angular obstacle velocities, 2-D and 3-D, more than one launch worth """
+    rng = np.random.default_rng(13)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((24, 20), ((CLO, CLO), (OPN, OPN)), dtype, batch=2)
+        obstacles = [pc.O.BoxObstacle((4.0, 3.0), (10.0, 9.5), velocity=(0.5, -0.25), angular_velocity=0.3,
+                                       rotation=[[np.cos(0.4), -np.sin(0.4)], [np.sin(0.4), np.cos(0.4)]]),
+                     pc.O.SphereObstacle((9.0, 9.0), 3.0),
+                     pc.O.SphereObstacle((17.0, 12.0), 2.5, angular_velocity=-1.0)]
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng, obstacles)
+        dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO), (PER, PER), (CLO, OPN)), dtype, batch=1)
+        obstacles = [pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0), angular_velocity=(0.1, -0.2, 0.3)),
+                     pc.O.SphereObstacle((6.0, 6.0, 9.0), 3.0, velocity=(1.0, 0.0, -1.0))]
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng, obstacles)
+    dom, grid = pc.make_case((32, 32), ((CLO, CLO), (CLO, CLO)), np.float32, batch=1)
+    many = [pc.O.SphereObstacle((2.0 + 1.5 * k, 3.0 + 1.2 * k), 1.0, velocity=(0.1 * k, 0.0)) for k in range(20)]   # > 16: two launches
+    pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, many)
+
+
 @pytest.mark.parametrize("res,bc", GRIDS_2D[:4] + GRIDS_3D[:2])
 def test_make_incompressible_matches_oracle_and_is_divergence_free(emu_ctx, res, bc):
     rng = np.random.default_rng(9)

@@ -76,6 +76,25 @@ def test_mac_cormack_and_resample_match_oracle(ctx, mem, res, bc):
         pc.check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+def test_obstacle_rasterisation_and_moving_obstacles(ctx, mem):
+    """ hard cell mask + apply_boundary_conditions with moving / rotating Box and Sphere obstacles on the device """
+    rng = np.random.default_rng(13)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((96, 80), ((CLO, CLO), (OPN, OPN)), dtype, batch=2)
+        obstacles = [pc.O.BoxObstacle((14.0, 13.0), (40.0, 39.5), velocity=(0.5, -0.25), angular_velocity=0.3,
+                                       rotation=[[np.cos(0.4), -np.sin(0.4)], [np.sin(0.4), np.cos(0.4)]]),
+                     pc.O.SphereObstacle((39.0, 39.0), 13.0),
+                     pc.O.SphereObstacle((67.0, 52.0), 12.5, angular_velocity=-1.0)]
+        pc.check_obstacle_kernels(ctx, mem, dom, grid, dtype, rng, obstacles)
+        dom, grid = pc.make_case((48, 40, 64), ((CLO, CLO), (PER, PER), (CLO, OPN)), dtype, batch=1)
+        obstacles = [pc.O.BoxObstacle((14.0, 13.0, 15.0), (28.0, 27.0, 41.0), angular_velocity=(0.1, -0.2, 0.3)),
+                     pc.O.SphereObstacle((26.0, 26.0, 39.0), 13.0, velocity=(1.0, 0.0, -1.0))]
+        pc.check_obstacle_kernels(ctx, mem, dom, grid, dtype, rng, obstacles)
+    dom, grid = pc.make_case((32, 32), ((CLO, CLO), (CLO, CLO)), np.float32, batch=1)
+    many = [pc.O.SphereObstacle((2.0 + 1.5 * k, 3.0 + 1.2 * k), 1.0, velocity=(0.1 * k, 0.0)) for k in range(20)]
+    pc.check_obstacle_kernels(ctx, mem, dom, grid, np.float32, rng, many)
+
+
 def test_reference_known_answer_self_advection(ctx, mem):
     """ /root/reference tests/commit/physics/test_advect.py:41-45 -- the only stored known answer on the path """
     dom, grid = pc.make_case((4, 3), ((CLO, CLO), (CLO, CLO)), np.float32)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from phiflow_amd import _capi
-from phiflow_amd.flow import (BOUNDARY, PERIODIC, ZERO, Box, CenteredGrid, Diverged, NotConverged, Obstacle, Solve, Sphere,
+from phiflow_amd.flow import (ZERO_GRADIENT, BOUNDARY, PERIODIC, ZERO, Box, CenteredGrid, Diverged, NotConverged, Obstacle, Solve, Sphere,
                               StaggeredGrid, advect, combine_sides, diffuse, divergence, fluid, spatial_gradient, vec)
 
 
@@ -116,6 +116,54 @@ def test_obstacles_and_x0(emu_backend):
     v2, p2 = fluid.make_incompressible(v, [obstacle], Solve('CG', 1e-5, 0, x0=p1))
     assert p2.solve_info.iterations[0] <= max(2, it_cold // 4)       # warm start converges almost immediately
     np.testing.assert_allclose(p2.numpy(), p1.numpy(), atol=1e-3 * np.abs(p1.numpy()).max())
+
+
+def test_moving_and_rotating_obstacles(emu_backend):
+    """ Moving_Obstacles.ipynb cells 3, 7 and Rotating_Bar.ipynb cells 3, 5 (two steps each) against the oracle:
+    obstacles move / rotate between steps, mac_cormack self-advection, projection with Solve(x0=p) """
+    from oracle import phi_oracle as O
+    from phiflow_amd.flow import Cuboid
+    n = 32
+    # --- moving box + sphere in a periodic domain ---
+    bounds = Box(x=100, y=100)
+    obstacles = [Obstacle(Cuboid(vec(x=20, y=80), x=20, y=20), velocity=vec(x=5., y=0)),
+                 Obstacle(Sphere(x=20, y=20, radius=10), velocity=vec(x=1, y=4))]
+    dom = O.Domain((n, n), (0, 0), (100, 100), ((O.PERIODIC, O.PERIODIC),) * 2)
+    o_obs = [O.BoxObstacle((10, 70), (30, 90), velocity=(5., 0.)), O.SphereObstacle((20, 20), 10, velocity=(1., 4.))]
+    v = StaggeredGrid(0, PERIODIC, bounds, x=n, y=n, backend=emu_backend)
+    vo = [np.zeros((1,) + dom.comp_shape(d), np.float32) for d in range(2)]
+    p, po, dt = None, None, 0.5
+    for _ in range(2):
+        obstacles = [ob.at([(c + u * dt) % 100 for c, u in zip(ob.geometry.center, ob.velocity)]) for ob in obstacles]
+        o_obs = [O.BoxObstacle(tuple(l + u * dt for l, u in zip(ob.lower, ob.velocity)), tuple(h + u * dt for h, u in zip(ob.upper, ob.velocity)),
+                               velocity=ob.velocity) if isinstance(ob, O.BoxObstacle) else
+                 O.SphereObstacle(tuple(c + u * dt for c, u in zip(ob.center, ob.velocity)), ob.radius, velocity=ob.velocity) for ob in o_obs]
+        v = advect.mac_cormack(v, v, dt)
+        v, p = fluid.make_incompressible(v, obstacles, Solve('CG', 1e-4, 0, x0=p))
+        vo = O.mac_cormack_staggered(vo, vo, dt, dom)
+        vo, po, info, _ = O.make_incompressible(vo, dom, o_obs, x0=po, rtol=1e-4, atol=0)
+        assert abs(p.solve_info.iterations[0] - int(info.iterations[0])) <= max(3, 0.1 * int(info.iterations[0]))   # warm-started
+    for a, b in zip(v.numpy(), vo):
+        np.testing.assert_allclose(a, b[0], atol=1e-3 * np.abs(b).max())
+    assert np.abs(vo[0]).max() > 1.0        # the moving obstacles did stir the fluid
+    # --- rotating bar, open domain ---
+    bar = Obstacle(Cuboid(vec(x=50, y=50), x=6, y=60), angular_velocity=0.05)
+    dom = O.Domain((n, n), (0, 0), (100, 100), ((O.OPEN, O.OPEN),) * 2)
+    v = StaggeredGrid(0, ZERO_GRADIENT, bounds, x=n, y=n, backend=emu_backend)
+    vo = [np.zeros((1,) + dom.comp_shape(d), np.float32) for d in range(2)]
+    p, po, angle = None, None, 0.0
+    for _ in range(2):
+        bar = bar.rotated(bar.angular_velocity[0] * 1.0)
+        angle += 0.05
+        R = [[np.cos(angle), -np.sin(angle)], [np.sin(angle), np.cos(angle)]]
+        o_bar = [O.BoxObstacle((47, 20), (53, 80), angular_velocity=0.05, rotation=R)]
+        v = advect.mac_cormack(v, v, 1.0)
+        v, p = fluid.make_incompressible(v, bar, Solve('CG', 1e-4, 0, x0=p))
+        vo = O.mac_cormack_staggered(vo, vo, 1.0, dom)
+        vo, po, info, _ = O.make_incompressible(vo, dom, o_bar, x0=po, rtol=1e-4, atol=0)
+    for a, b in zip(v.numpy(), vo):
+        np.testing.assert_allclose(a, b[0], atol=1e-3 * np.abs(b).max())
+    assert np.abs(vo[1]).max() > 0.5
 
 
 def test_convergence_exceptions(emu_backend):

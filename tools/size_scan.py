@@ -21,9 +21,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="128,160,192,224,256,288,320,384,448,512")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    ctx = C.Context(C.load_default_library(), 0)
+    ctx = C.Context(C.Library(args.lib) if args.lib else C.load_default_library(), 0)
     L = 2 * math.pi
     for n in [int(v) for v in args.sizes.split(",")]:
         grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
@@ -45,7 +46,7 @@ def main():
         up = prof["cg_update"][1] / max(1, prof["cg_update"][0])
         cells = n ** 3
         plans = {f: ctx.query_plan(grid, False, f) for f in (1, 2)}
-        print(json.dumps({"size": n, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "working_set_MB": round(4 * 4 * cells / 2 ** 20, 1), "ms_matvec": round(mv, 5), "ms_update": round(up, 5),
+        print(json.dumps({"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "working_set_MB": round(4 * 4 * cells / 2 ** 20, 1), "ms_matvec": round(mv, 5), "ms_update": round(up, 5),
                           "actual_GBs_matvec": round(12 * cells / mv / 1e6, 1), "actual_GBs_update": round(20 * cells / up / 1e6, 1),
                           "alg_GBs_iter": round(40 * cells / (mv + up) / 1e6, 1)}), flush=True)
         del rhs, x

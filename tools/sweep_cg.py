@@ -23,11 +23,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--configs", default="")
+    ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
     ap.add_argument("--family", type=int, default=-1, help="-1: all kernels share the configuration; 1 = MATVEC only, 2 = UPDATE only")
     args = ap.parse_args()
     n = args.size
     dev = torch.device("cuda:0")
-    lib = C.load_default_library()
+    lib = C.Library(args.lib) if args.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
@@ -74,7 +75,7 @@ def main():
         sc = prof["cg_scalar"][1] / max(1, prof["cg_scalar"][0])
         words = esize
         plans = {f: ctx.query_plan(grid, False, f) for f in (1, 2)}
-        out = {"size": n, "dtype": args.dtype, "family": args.family, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
+        out = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "family": args.family, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
                "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_scalar": round(sc, 5),
                "ms_iter_events": round(mv + up + 2 * sc, 5), "ms_iter_wall": round(wall_ms / args.iters, 5),
                "alg_GBs_iter_wall": round(10 * words * cells / (wall_ms / args.iters * 1e-3) / 1e9, 1),
