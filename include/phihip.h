@@ -188,6 +188,23 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
 int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3],
                             void* const out[3], double diffusivity_dt, void* stream);
 
+/* ---- f5: backward passes (vector-Jacobian products) -- PhiFlow is differentiable through its backends' autodiff
+ *          (tests/commit/physics/test_fluid.py:55-73, tests/commit/test_colab_fluids_tutorial.py:11-34) ------------------- */
+/* Gradients are ACCUMULATED (+=) into grad_* buffers (zero them first); NULL skips that gradient. */
+int phihip_advect_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3],
+                                     const void* const velocity[3], const void* const grad_out[3], double dt,
+                                     void* const grad_field[3], void* const grad_velocity[3], void* stream);
+int phihip_advect_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                    const double s_val[3][2], const void* const velocity[3], const void* grad_out, double dt,
+                                    void* grad_s, void* const grad_velocity[3], void* stream);
+int phihip_centered_to_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const int32_t s_bc[3][2],
+                                          const double vector[3], const void* const grad_out[3], void* grad_s, void* stream);
+/* adjoint of phihip_make_incompressible (implicit-function gradient of the linear solve like phiml's solve_linear backward):
+ * grad_velocity holds dL/dv_out on entry and dL/dv_in (before soft masks) on exit; grad_pressure = dL/dp or NULL. */
+int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch,
+                                        int balance, void* const grad_velocity[3], const void* grad_pressure,
+                                        const phihip_solve* solve, phihip_solve_info* info, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------------------------ */
 /* Kernel families timed with hipEvent pairs on the solve stream while profiling is enabled. */
 typedef enum phihip_kernel_id {

@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
     "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
     "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
+    "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
+    "phihip_make_incompressible_backward",
 )
 
 
@@ -148,6 +150,14 @@ class Library:
                                                    POINTER(c_double * 3), c_int, POINTER(_Ptr3), c_void_p]
         d.phihip_obstacle_accessible.argtypes = [c_void_p, POINTER(Grid), POINTER(ObstacleStruct), c_int, c_void_p, c_void_p]
         d.phihip_apply_obstacles.argtypes = [c_void_p, POINTER(Grid), POINTER(ObstacleStruct), c_int, POINTER(_Ptr3), c_void_p]
+        d.phihip_advect_staggered_backward.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double,
+                                                       POINTER(_Ptr3), POINTER(_Ptr3), c_void_p]
+        d.phihip_advect_centered_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
+                                                      POINTER(_Ptr3), c_void_p, c_double, c_void_p, POINTER(_Ptr3), c_void_p]
+        d.phihip_centered_to_staggered_backward.argtypes = [c_void_p, POINTER(Grid), POINTER((c_int32 * 2) * 3), POINTER(c_double * 3),
+                                                            POINTER(_Ptr3), c_void_p, c_void_p]
+        d.phihip_make_incompressible_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_int, POINTER(_Ptr3), c_void_p,
+                                                          POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         d.phihip_divergence.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p, c_void_p]
         d.phihip_laplace_apply.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
@@ -235,6 +245,33 @@ class Context:
         self.lib.check(self.lib.dll.phihip_centered_to_staggered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
                                                                  ctypes.byref(vec), int(bool(accumulate)), ctypes.byref(ptr3(out)),
                                                                  stream or None))
+
+    def advect_staggered_backward(self, grid, field, velocity, grad_out, dt, grad_field, grad_velocity, stream=0):
+        gf, gv = ptr3(grad_field), ptr3(grad_velocity)
+        self.lib.check(self.lib.dll.phihip_advect_staggered_backward(
+            self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)), ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(grad_out)), float(dt),
+            ctypes.byref(gf) if gf is not None else None, ctypes.byref(gv) if gv is not None else None, stream or None))
+
+    def advect_centered_backward(self, grid, s, s_bc, s_val, velocity, grad_out, dt, grad_s, grad_velocity, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        gv = ptr3(grad_velocity)
+        self.lib.check(self.lib.dll.phihip_advect_centered_backward(
+            self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), ctypes.byref(ptr3(velocity)), grad_out, float(dt),
+            grad_s or None, ctypes.byref(gv) if gv is not None else None, stream or None))
+
+    def centered_to_staggered_backward(self, grid, s_bc, vector, grad_out, grad_s, stream=0):
+        bc, _ = self._scalar_bc(grid, s_bc, None)
+        vec = (c_double * 3)(*([float(x) for x in vector] + [0.0] * (3 - len(vector))))
+        self.lib.check(self.lib.dll.phihip_centered_to_staggered_backward(self.handle, ctypes.byref(grid), ctypes.byref(bc), ctypes.byref(vec),
+                                                                          ctypes.byref(ptr3(grad_out)), grad_s, stream or None))
+
+    def make_incompressible_backward(self, grid, flags, mask_batch, balance, grad_velocity, grad_pressure, solve: Solve, want_info=True,
+                                     stream=0):
+        info = (SolveInfo * grid.batch)() if want_info else None
+        self.lib.check(self.lib.dll.phihip_make_incompressible_backward(
+            self.handle, ctypes.byref(grid), flags or None, int(mask_batch), int(bool(balance)), ctypes.byref(ptr3(grad_velocity)),
+            grad_pressure or None, ctypes.byref(solve), info, stream or None))
+        return list(info) if want_info else None
 
     def obstacle_accessible(self, grid, obstacles, count, accessible, stream=0):
         self.lib.check(self.lib.dll.phihip_obstacle_accessible(self.handle, ctypes.byref(grid), obstacles, int(count), accessible, stream or None))

@@ -1,0 +1,375 @@
+// adjoint.hip -- backward passes (vector-Jacobian products) of the fluid step, SURVEY §8 f5: PhiFlow is differentiable through
+// its backends' autodiff (/root/reference tests/commit/physics/test_fluid.py:55-73, tests/commit/test_colab_fluids_tutorial.py:11-34);
+// here every forward kernel gets a hand-written adjoint:
+//   * semi-Lagrangian advection: the gather becomes a scatter-add (atomicAdd) into the advected field AND, through the lookup
+//     coordinates x* = x - dt u, into the advecting velocity (own component + the 4-point means of the others);
+//   * centred -> staggered resample: adjoint scatter into the cells;
+//   * make_incompressible: the implicit-function adjoint of the linear solve (A is symmetric: one more CG solve with the
+//     same matrix-free operator), divergence and gradient swap roles (G^T = -D with homogeneous boundary values).
+// Every kernel recomputes the forward quantities it needs; nothing is taped on the device.
+#include "advect_common.hpp"
+#include "march_dispatch.hpp"
+
+namespace phihip {
+
+template <typename T>
+struct Comp3w {
+    T* p[3];
+};
+
+// d(out)/d(frac_a) of the multilinear gather and scatter of g * w into the taps of the field gradient
+template <typename T, int DIM>
+__device__ __forceinline__ void gather_adjoint(const T* __restrict__ F, T* __restrict__ gF, const AxisPair<T> (&ax)[3], const T (&fr)[3], T g,
+                                               T (&dfr)[3]) {
+    dfr[0] = dfr[1] = dfr[2] = T(0);
+#pragma unroll
+    for (int corner = 0; corner < (1 << DIM); ++corner) {
+        const int b0 = DIM == 3 ? (corner & 1) : 0;
+        const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
+        const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
+        const T w0 = DIM == 3 ? (b0 ? fr[0] : (T(1) - fr[0])) : T(1);
+        const T w1 = b1 ? fr[1] : (T(1) - fr[1]);
+        const T w2 = b2 ? fr[2] : (T(1) - fr[2]);
+        T val;
+        bool is_const = true;
+        if (ax[2].cst[b2]) val = ax[2].cv[b2];
+        else if (ax[1].cst[b1]) val = ax[1].cv[b1];
+        else if (DIM == 3 && ax[0].cst[b0]) val = ax[0].cv[b0];
+        else {
+            is_const = false;
+            const int off = (DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2];
+            val = F[off];
+            if (gF) atomicAdd(gF + off, g * (w0 * w1 * w2));
+        }
+        (void)is_const;
+        if (DIM == 3) dfr[0] += val * (b0 ? T(1) : T(-1)) * w1 * w2;
+        dfr[1] += val * (b1 ? T(1) : T(-1)) * w0 * w2;
+        dfr[2] += val * (b2 ? T(1) : T(-1)) * w0 * w1;
+    }
+}
+
+// adjoint of face_velocity: du[cb] (physical units) scattered into the velocity gradient
+template <typename T, int DIM, int CA>
+__device__ __forceinline__ void face_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], int f, const T (&du)[3]) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+#pragma unroll
+    for (int cb = A0; cb < 3; ++cb) {
+        if (cb == ca) {
+            atomicAdd(gvel.p[ca] + (long long)b * g.ccells[ca] + f, du[cb]);
+        } else {
+            const int m = idx[ca] + g.off[ca];
+            const int s = idx[cb] - g.off[cb];
+            const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
+            const int stride[3] = {n1 * n2, n2, 1};
+            T* __restrict__ C = gvel.p[cb] + (long long)b * g.ccells[cb];
+            const AxisPair<T> pa = make_pair<T>(m - 1, g.cn[cb][ca], stride[ca], g.bc[ca][0], g.bc[ca][1], (T)g.bcv[ca][0][cb], (T)g.bcv[ca][1][cb]);
+            const AxisPair<T> pb = make_pair<T>(s, g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
+            int rest = 0;
+#pragma unroll
+            for (int ax = A0; ax < 3; ++ax)
+                if (ax != ca && ax != cb) rest += idx[ax] * stride[ax];
+            const T q = du[cb] * T(0.25);
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    if (!pa.cst[ia] && !pb.cst[ib]) atomicAdd(C + rest + pa.off[ia] + pb.off[ib], q);
+        }
+    }
+}
+
+template <typename T, int DIM>
+__device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], const T (&du)[3]) {
+    constexpr int A0 = 3 - DIM;
+#pragma unroll
+    for (int cb = A0; cb < 3; ++cb) {
+        const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
+        const int stride[3] = {n1 * n2, n2, 1};
+        T* __restrict__ C = gvel.p[cb] + (long long)b * g.ccells[cb];
+        const AxisPair<T> pb = make_pair<T>(idx[cb] - g.off[cb], g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
+        int rest = 0;
+#pragma unroll
+        for (int ax = A0; ax < 3; ++ax)
+            if (ax != cb) rest += idx[ax] * stride[ax];
+        if (!pb.cst[0]) atomicAdd(C + rest + pb.off[0], du[cb] * T(0.5));
+        if (!pb.cst[1]) atomicAdd(C + rest + pb.off[1], du[cb] * T(0.5));
+    }
+}
+
+template <typename T, int DIM, int CA>
+__global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g, CComp3a<T> field, CComp3a<T> vel, const T* __restrict__ gout,
+                                                                      T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel, T dt) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+    const int b = blockIdx.y;
+    const int total = (int)g.ccells[ca];
+    const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
+    const T* __restrict__ F = field.p[ca] + (long long)b * total;
+    T* __restrict__ GF = gfield ? gfield + (long long)b * total : nullptr;
+    int bc[3][2];
+    T cv[3][2];
+    comp_rule<T>(g, ca, bc, cv);
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
+        T coord[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - dt * u[a] / (T)g.dx[a];
+        AxisPair<T> ax[3];
+        T fr[3], dfr[3];
+        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
+        if (want_gvel) {
+            T du[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * (-dt / (T)g.dx[a]);   // coord_a = idx_a - dt u_a / dx_a
+            face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du);
+        }
+    }
+}
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ sfield, CComp3a<T> vel,
+                                                                     const T* __restrict__ gout, T* __restrict__ gs, Comp3w<T> gvel, int want_gvel,
+                                                                     T dt) {
+    constexpr int A0 = 3 - DIM;
+    const int b = blockIdx.y;
+    const int total = (int)g.cells;
+    const int n[3] = {g.n[0], g.n[1], g.n[2]};
+    const T* __restrict__ F = sfield + (long long)b * total;
+    T* __restrict__ GF = gs ? gs + (long long)b * total : nullptr;
+    int bc[3][2];
+    T cv[3][2];
+    scalar_rule<T>(sb, bc, cv);
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        center_velocity<T, DIM>(g, vel, b, idx, u);
+        T coord[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - dt * u[a] / (T)g.dx[a];
+        AxisPair<T> ax[3];
+        T fr[3], dfr[3];
+        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
+        if (want_gvel) {
+            T du[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * (-dt / (T)g.dx[a]);
+            center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
+        }
+    }
+}
+
+// adjoint of centered_to_staggered_kernel: gs[cell] += 0.5 * scale * gout[face] for both cells of every stored face
+template <typename T>
+__global__ __launch_bounds__(kBlock) void c2s_bwd_kernel(VelGrid g, ScalarBc sb, int ca, const T* __restrict__ gout, T* __restrict__ gs, T scale) {
+    const int b = blockIdx.y;
+    const int total = (int)g.ccells[ca];
+    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const int n = g.n[ca];
+    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
+    T* __restrict__ S = gs + (long long)b * g.cells;
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        int idx[3];
+        unravel(f, c1, c2, idx);
+        const int phys = idx[ca] + g.off[ca];
+        int l = phys - 1, r = phys;
+        bool cl = false, cr = false;
+        if (l < 0) { if (sb.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { cl = sb.bc[ca][0] == PHIHIP_BC_CLOSED; l = 0; } }
+        if (r >= n) { if (sb.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { cr = sb.bc[ca][1] == PHIHIP_BC_CLOSED; r = n - 1; } }
+        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;
+        const T q = gout[(long long)b * total + f] * T(0.5) * scale;
+        if (!cl) atomicAdd(S + rest + l * pstride, q);
+        if (!cr) atomicAdd(S + rest + r * pstride, q);
+    }
+}
+
+static inline int bwd_blocks(long long total) {
+    const long long nb = (total + kBlock - 1) / kBlock;
+    return (int)(nb < 65536 ? nb : 65536);
+}
+
+template <typename T, int DIM>
+static void launch_advect_staggered_bwd(const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3],
+                                        const void* const gout[3], void* const gf[3], void* const gv[3], double dt, hipStream_t s) {
+    CComp3a<T> ff{{(const T*)f[0], (const T*)f[1], (const T*)f[2]}};
+    CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
+    const int want = gv ? 1 : 0;
+    if (DIM == 3)
+        hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 0>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                           (const T*)gout[0], gf ? (T*)gf[0] : nullptr, gg, want, (T)dt);
+    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 1>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                       (const T*)gout[1], gf ? (T*)gf[1] : nullptr, gg, want, (T)dt);
+    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 2>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                       (const T*)gout[2], gf ? (T*)gf[2] : nullptr, gg, want, (T)dt);
+}
+
+int run_advect_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3], const void* const gout[3],
+                             void* const gf[3], void* const gv[3], double dt, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    if (v.dtype == PHIHIP_F64) {
+        if (v.rank == 3) launch_advect_staggered_bwd<double, 3>(v, g, f, vel, gout, gf, gv, dt, s);
+        else launch_advect_staggered_bwd<double, 2>(v, g, f, vel, gout, gf, gv, dt, s);
+    } else {
+        if (v.rank == 3) launch_advect_staggered_bwd<float, 3>(v, g, f, vel, gout, gf, gv, dt, s);
+        else launch_advect_staggered_bwd<float, 2>(v, g, f, vel, gout, gf, gv, dt, s);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+template <typename T, int DIM>
+static void launch_advect_centered_bwd(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
+                                       const void* gout, void* gs, void* const gv[3], double dt, hipStream_t s) {
+    CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
+    hipLaunchKernelGGL((advect_centered_bwd_kernel<T, DIM>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
+                       (const T*)gout, (T*)gs, gg, gv ? 1 : 0, (T)dt);
+}
+
+int run_advect_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
+                            const void* const vel[3], const void* gout, void* gs, void* const gv[3], double dt, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    if (v.dtype == PHIHIP_F64) {
+        if (v.rank == 3) launch_advect_centered_bwd<double, 3>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+        else launch_advect_centered_bwd<double, 2>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+    } else {
+        if (v.rank == 3) launch_advect_centered_bwd<float, 3>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+        else launch_advect_centered_bwd<float, 2>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_centered_to_staggered_bwd(phihip_ctx* ctx, const GridView& v, const int32_t s_bc[3][2], const double vector[3],
+                                  const void* const gout[3], void* gs, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    const ScalarBc sb = make_scalar_bc(v, s_bc, nullptr);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        if (vector[ca] == 0.0) continue;
+        if (v.dtype == PHIHIP_F64)
+            hipLaunchKernelGGL(c2s_bwd_kernel<double>, dim3(bwd_blocks(v.ccells[ca]), v.batch), dim3(kBlock), 0, s, g, sb, ca, (const double*)gout[ca],
+                               (double*)gs, vector[ca]);
+        else
+            hipLaunchKernelGGL(c2s_bwd_kernel<float>, dim3(bwd_blocks(v.ccells[ca]), v.batch), dim3(kBlock), 0, s, g, sb, ca, (const float*)gout[ca],
+                               (float*)gs, (float)vector[ca]);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// make_incompressible backward. Forward (fluid.py:138-161):  b = a (D v' + c) ;  rhs = P b ;  p = A^-1 rhs ;  v_out = v' - H G p
+// with a = active, H = hard_bcs, P = balance, c = boundary-value terms. With upstream gradients g_v (of v_out), g_p (of p):
+//     pbar = g_p + D0 (H g_v)                [G^T = -D0 : divergence with homogeneous boundary values]
+//     lam  = A^-1 P (a pbar)                 [A symmetric; P projects onto its range when the system is singular]
+//     g_v' = g_v - G0 P (a lam)              [D^T = -G0 : gradient at the stored faces, no H]
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int CA>
+__global__ __launch_bounds__(kBlock) void mask_faces_kernel(VelGrid g, const T* __restrict__ in, T* __restrict__ out, const uint8_t* flags,
+                                                            int flags_per_batch) {
+    constexpr int ca = CA;
+    const int b = blockIdx.y;
+    const int total = (int)g.ccells[ca];
+    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const int n = g.n[ca];
+    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
+    const uint8_t* F = flags + (flags_per_batch ? (long long)b * g.cells : 0);
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        int idx[3];
+        unravel(f, c1, c2, idx);
+        const int phys = idx[ca] + g.off[ca];
+        int l = phys - 1, r = phys;
+        const bool l_in = l >= 0, r_in = r < n;
+        if (!l_in) l = g.bc[ca][0] == PHIHIP_BC_PERIODIC ? l + n : 0;
+        if (!r_in) r = g.bc[ca][1] == PHIHIP_BC_PERIODIC ? r - n : n - 1;
+        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;
+        T h = T(1);
+        if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) h = (F[rest + r * pstride] >> (2 * ca)) & 1u ? T(1) : T(0);
+        else if (l_in) h = (F[rest + l * pstride] >> (2 * ca + 1)) & 1u ? T(1) : T(0);
+        out[(long long)b * total + f] = h * in[(long long)b * total + f];
+    }
+}
+
+// x = active * (x + add)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mask_cells_kernel(T* __restrict__ x, const T* __restrict__ add, const uint8_t* flags, int flags_per_batch,
+                                                            long long cells) {
+    const int b = blockIdx.y;
+    for (long long c = (long long)blockIdx.x * kBlock + threadIdx.x; c < cells; c += (long long)gridDim.x * kBlock) {
+        T val = x[(long long)b * cells + c];
+        if (add) val += add[(long long)b * cells + c];
+        if (flags && !(flags[(flags_per_batch ? (long long)b * cells : 0) + c] & 64u)) val = T(0);
+        x[(long long)b * cells + c] = val;
+    }
+}
+
+int run_balance(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, void* x, hipStream_t s);
+
+template <typename T>
+static int project_bwd_t(phihip_ctx* ctx, const GridView& v0, const uint8_t* flags, int mask_batch, int balance, void* const gv[3],
+                         const void* gp, const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    GridView v = v0;   // homogeneous boundary values: the constants do not depend on the inputs
+    memset(v.bcv, 0, sizeof(v.bcv));
+    const VelGrid g = make_velgrid(v);
+    const int fpb = mask_batch > 1 ? 1 : 0;
+    const size_t cell_bytes = (size_t)v.batch * v.cells * sizeof(T);
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adj_q, cell_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adj_l, cell_bytes));
+    T* q = (T*)ctx->ws_adj_q.ptr;
+    T* lam = (T*)ctx->ws_adj_l.ptr;
+    const void* src[3] = {gv[0], gv[1], gv[2]};
+    if (flags) {   // t = H g_v
+        size_t offs[3] = {0, 0, 0}, total = 0;
+        for (int ca = v.ax0; ca < 3; ++ca) {
+            offs[ca] = total;
+            total += (((size_t)v.batch * v.ccells[ca] * sizeof(T) + 255) / 256) * 256;
+        }
+        PHIHIP_TRY(ensure_buffer(ctx->ws_adv, total));
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        for (int ca = v.ax0; ca < 3; ++ca) {
+            T* t = (T*)((char*)ctx->ws_adv.ptr + offs[ca]);
+            const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);
+            if (ca == 0) hipLaunchKernelGGL((mask_faces_kernel<T, 0>), grid, dim3(kBlock), 0, s, g, (const T*)gv[0], t, flags, fpb);
+            if (ca == 1) hipLaunchKernelGGL((mask_faces_kernel<T, 1>), grid, dim3(kBlock), 0, s, g, (const T*)gv[1], t, flags, fpb);
+            if (ca == 2) hipLaunchKernelGGL((mask_faces_kernel<T, 2>), grid, dim3(kBlock), 0, s, g, (const T*)gv[2], t, flags, fpb);
+            src[ca] = t;
+        }
+    }
+    PHIHIP_TRY(run_divergence(ctx, v, src, nullptr, 1, 0, q, s));                      // q = D0 (H g_v)
+    if (gp || flags) {
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        hipLaunchKernelGGL(mask_cells_kernel<T>, dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, q, (const T*)gp, flags, fpb, v.cells);
+    }
+    if (balance) PHIHIP_TRY(run_balance(ctx, v, flags, mask_batch, q, s));             // q = P (a pbar)
+    PHIHIP_CHECK_HIP(hipMemsetAsync(lam, 0, cell_bytes, s));
+    PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, q, lam, solve, info, s));             // lam = A^-1 q
+    if (flags) {
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        hipLaunchKernelGGL(mask_cells_kernel<T>, dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, lam, (const T*)nullptr, flags, fpb, v.cells);
+    }
+    if (balance) PHIHIP_TRY(run_balance(ctx, v, flags, mask_batch, lam, s));           // P (a lam)
+    PHIHIP_TRY(run_grad_subtract(ctx, v, nullptr, 1, lam, gv, s));                     // g_v' = g_v - G0 (...)
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_project_bwd(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, int balance, void* const gv[3], const void* gp,
+                    const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? project_bwd_t<double>(ctx, v, flags, mask_batch, balance, gv, gp, solve, info, s)
+                                 : project_bwd_t<float>(ctx, v, flags, mask_batch, balance, gv, gp, solve, info, s);
+}
+
+}  // namespace phihip

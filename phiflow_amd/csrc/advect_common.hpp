@@ -1,0 +1,222 @@
+// advect_common.hpp -- device helpers shared by the advection kernels (advect.hip) and their adjoints (adjoint.hip):
+// boundary-resolved tap pairs, multilinear gather, velocity at faces / centres (phi/field/_resample.py:158-161,241-287,341-364).
+#pragma once
+#include "common.hpp"
+
+namespace phihip {
+
+template <typename T>
+struct CComp3a {
+    const T* p[3];
+};
+
+// one axis of a multilinear tap pair / stencil pair: resolved indices + "outside a constant side" flags
+template <typename T>
+struct AxisPair {
+    int off[2];     // element offset contribution (index * stride), valid when !cst
+    bool cst[2];
+    T cv[2];
+};
+
+template <typename T>
+__device__ __forceinline__ void resolve_axis(int i, int n, int stride, int code_lo, int code_hi, T c_lo, T c_hi, int& off, bool& cst, T& cv) {
+    cst = false;
+    cv = T(0);
+    if (i < 0) {
+        if (code_lo == PHIHIP_BC_PERIODIC) { i %= n; if (i < 0) i += n; }
+        else if (code_lo == PHIHIP_BC_CLOSED) { cst = true; cv = c_lo; i = 0; }
+        else i = 0;
+    } else if (i >= n) {
+        if (code_hi == PHIHIP_BC_PERIODIC) i %= n;
+        else if (code_hi == PHIHIP_BC_CLOSED) { cst = true; cv = c_hi; i = n - 1; }
+        else i = n - 1;
+    }
+    off = i * stride;
+}
+
+template <typename T>
+__device__ __forceinline__ AxisPair<T> make_pair(int i_lo, int n, int stride, int code_lo, int code_hi, T c_lo, T c_hi) {
+    AxisPair<T> a;
+    if (i_lo >= 0 && i_lo + 1 < n) {   // interior fast path
+        a.off[0] = i_lo * stride; a.off[1] = a.off[0] + stride;
+        a.cst[0] = a.cst[1] = false;
+        a.cv[0] = a.cv[1] = T(0);
+    } else {
+        resolve_axis<T>(i_lo, n, stride, code_lo, code_hi, c_lo, c_hi, a.off[0], a.cst[0], a.cv[0]);
+        resolve_axis<T>(i_lo + 1, n, stride, code_lo, code_hi, c_lo, c_hi, a.off[1], a.cst[1], a.cv[1]);
+    }
+    return a;
+}
+
+// multilinear interpolation from per-axis pairs; constant sides follow PhiML's sequential padding: the LAST axis that lies
+// outside a constant side decides. Weights: prod(where(bit, frac, 1 - frac)) summed in corner order (a0 = lowest bit).
+template <typename T, int DIM>
+__device__ __forceinline__ T gather_multilinear(const T* __restrict__ F, const AxisPair<T> (&ax)[3], const T (&fr)[3]) {
+    constexpr int A0 = 3 - DIM;
+    const bool any_const = ax[2].cst[0] | ax[2].cst[1] | ax[1].cst[0] | ax[1].cst[1] | (DIM == 3 ? (ax[0].cst[0] | ax[0].cst[1]) : false);
+    T out = T(0);
+#pragma unroll
+    for (int corner = 0; corner < (1 << DIM); ++corner) {
+        const int b0 = DIM == 3 ? (corner & 1) : 0;
+        const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
+        const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
+        T w = T(1);
+        if (DIM == 3) w *= b0 ? fr[0] : (T(1) - fr[0]);
+        w *= b1 ? fr[1] : (T(1) - fr[1]);
+        w *= b2 ? fr[2] : (T(1) - fr[2]);
+        T val;
+        if (!any_const) {
+            val = F[(DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2]];
+        } else if (ax[2].cst[b2]) {
+            val = ax[2].cv[b2];
+        } else if (ax[1].cst[b1]) {
+            val = ax[1].cv[b1];
+        } else if (DIM == 3 && ax[0].cst[b0]) {
+            val = ax[0].cv[b0];
+        } else {
+            val = F[(DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2]];
+        }
+        out += val * w;
+    }
+    (void)A0;
+    return out;
+}
+
+// min / max over the 2^D taps of a lookup (Field.closest_values + math.min / math.max, advect.py:210-212); same tap
+// resolution as gather_multilinear
+template <typename T, int DIM>
+__device__ __forceinline__ void gather_minmax(const T* __restrict__ F, const AxisPair<T> (&ax)[3], T& lo, T& hi) {
+#pragma unroll
+    for (int corner = 0; corner < (1 << DIM); ++corner) {
+        const int b0 = DIM == 3 ? (corner & 1) : 0;
+        const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
+        const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
+        T val;
+        if (ax[2].cst[b2]) val = ax[2].cv[b2];
+        else if (ax[1].cst[b1]) val = ax[1].cv[b1];
+        else if (DIM == 3 && ax[0].cst[b0]) val = ax[0].cv[b0];
+        else val = F[(DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2]];
+        lo = corner == 0 ? val : (val < lo ? val : lo);
+        hi = corner == 0 ? val : (val > hi ? val : hi);
+    }
+}
+
+// velocity at the stored face `idx` of component CA: own component + 4-point
+// means of the others (sample(velocity, field.geometry, at='face'), phi/field/_resample.py:158-161,279-287,341-364)
+template <typename T, int DIM, int CA>
+__device__ __forceinline__ void face_velocity(const VelGrid& g, const CComp3a<T>& vel, int b, const int (&idx)[3], int f, T (&u)[3]) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+    u[0] = u[1] = u[2] = T(0);
+#pragma unroll
+    for (int cb = A0; cb < 3; ++cb) {
+        if (cb == ca) {
+            u[cb] = vel.p[ca][(long long)b * g.ccells[ca] + f];
+        } else {
+            // component cb at this ca-face: cells (m-1, m) along ca, physical faces (i, i+1) along cb
+            const int m = idx[ca] + g.off[ca];
+            const int s = idx[cb] - g.off[cb];
+            const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
+            const int stride[3] = {n1 * n2, n2, 1};
+            const T* __restrict__ C = vel.p[cb] + (long long)b * g.ccells[cb];
+            const AxisPair<T> pa = make_pair<T>(m - 1, g.cn[cb][ca], stride[ca], g.bc[ca][0], g.bc[ca][1], (T)g.bcv[ca][0][cb], (T)g.bcv[ca][1][cb]);
+            const AxisPair<T> pb = make_pair<T>(s, g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
+            int rest = 0;
+#pragma unroll
+            for (int ax = A0; ax < 3; ++ax)
+                if (ax != ca && ax != cb) rest += idx[ax] * stride[ax];
+            // the later axis of (ca, cb) wins when both lie outside a constant side
+            const bool a_last = ca > cb;
+            T v[2][2];   // [ca offset][cb offset]
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    const bool ca_c = pa.cst[ia], cb_c = pb.cst[ib];
+                    if (ca_c || cb_c) {
+                        if (a_last) v[ia][ib] = ca_c ? pa.cv[ia] : pb.cv[ib];
+                        else v[ia][ib] = cb_c ? pb.cv[ib] : pa.cv[ia];
+                    } else {
+                        v[ia][ib] = C[rest + pa.off[ia] + pb.off[ib]];
+                    }
+                }
+            // sample_subgrid lerps axis after axis in spatial order with weights (0.5, 0.5)
+            if (ca < cb) {
+                const T a0 = v[1][0] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[0][1] * T(0.5);
+                u[cb] = a1 * T(0.5) + a0 * T(0.5);
+            } else {
+                const T a0 = v[0][1] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[1][0] * T(0.5);
+                u[cb] = a1 * T(0.5) + a0 * T(0.5);
+            }
+        }
+    }
+}
+
+// staggered velocity at a cell centre: mean of the cell's two cb-faces (missing ones from padding)
+template <typename T, int DIM>
+__device__ __forceinline__ void center_velocity(const VelGrid& g, const CComp3a<T>& vel, int b, const int (&idx)[3], T (&u)[3]) {
+    constexpr int A0 = 3 - DIM;
+    u[0] = u[1] = u[2] = T(0);
+#pragma unroll
+    for (int cb = A0; cb < 3; ++cb) {
+        const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
+        const int stride[3] = {n1 * n2, n2, 1};
+        const T* __restrict__ C = vel.p[cb] + (long long)b * g.ccells[cb];
+        const AxisPair<T> pb = make_pair<T>(idx[cb] - g.off[cb], g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
+        int rest = 0;
+#pragma unroll
+        for (int ax = A0; ax < 3; ++ax)
+            if (ax != cb) rest += idx[ax] * stride[ax];
+        const T lo = pb.cst[0] ? pb.cv[0] : C[rest + pb.off[0]];
+        const T hi = pb.cst[1] ? pb.cv[1] : C[rest + pb.off[1]];
+        u[cb] = hi * T(0.5) + lo * T(0.5);
+    }
+}
+
+// AxisPairs + fractions of a lookup at fractional index coordinates `coord` into an array of shape n[] (strides from n)
+template <typename T, int DIM>
+__device__ __forceinline__ void lookup_pairs(const T (&coord)[3], const int (&n)[3], const int (&bc)[3][2], const T (&cv)[3][2],
+                                             AxisPair<T> (&ax)[3], T (&fr)[3]) {
+    constexpr int A0 = 3 - DIM;
+    const int stride[3] = {n[1] * n[2], n[2], 1};
+    fr[0] = fr[1] = fr[2] = T(0);
+#pragma unroll
+    for (int a = A0; a < 3; ++a) {
+        const T fl = floor(coord[a]);
+        fr[a] = coord[a] - fl;
+        ax[a] = make_pair<T>((int)fl, n[a], stride[a], bc[a][0], bc[a][1], cv[a][0], cv[a][1]);
+    }
+    if (DIM == 2) { ax[0].off[0] = ax[0].off[1] = 0; ax[0].cst[0] = ax[0].cst[1] = false; ax[0].cv[0] = ax[0].cv[1] = T(0); }
+}
+
+// component boundary rule as the (codes, constants) pair lookup_pairs wants
+template <typename T>
+__device__ __forceinline__ void comp_rule(const VelGrid& g, int comp, int (&bc)[3][2], T (&cv)[3][2]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bc[a][s] = g.bc[a][s];
+            cv[a][s] = (T)g.bcv[a][s][comp];
+        }
+}
+
+template <typename T>
+__device__ __forceinline__ void scalar_rule(const ScalarBc& sb, int (&bc)[3][2], T (&cv)[3][2]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bc[a][s] = sb.bc[a][s];
+            cv[a][s] = (T)sb.val[a][s];
+        }
+}
+
+__device__ __forceinline__ void unravel(int f, int c1, int c2, int (&idx)[3]) {
+    idx[2] = f % c2;
+    const int t = f / c2;
+    idx[1] = t % c1;
+    idx[0] = t / c1;
+}
+
+}  // namespace phihip

@@ -187,7 +187,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adj_q, &ctx->ws_adj_l};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -202,7 +202,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes;
     return PHIHIP_OK;
 }
 
@@ -425,6 +425,65 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
     PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, div, pressure, solve, info, s));
     PHIHIP_TRY(run_grad_subtract(ctx, v, flags, mask_batch, pressure, u, s));
     return PHIHIP_OK;
+}
+
+int phihip_advect_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3], const void* const velocity[3],
+                                     const void* const grad_out[3], double dt, void* const grad_field[3], void* const grad_velocity[3],
+                                     void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, field, "field"));
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, grad_out, "grad_out"));
+    if (grad_field) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_field, "grad_field"));
+    if (grad_velocity) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_velocity, "grad_velocity"));
+    const void *f[3], *u[3], *go[3];
+    void *gf[3], *gu[3];
+    remap3(v, field, f);
+    remap3(v, velocity, u);
+    remap3(v, grad_out, go);
+    remap3w(v, grad_field, gf);
+    remap3w(v, grad_velocity, gu);
+    return run_advect_staggered_bwd(ctx, v, f, u, go, grad_field ? gf : nullptr, grad_velocity ? gu : nullptr, dt, s);
+}
+
+int phihip_advect_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                                    const double s_val[3][2], const void* const velocity[3], const void* grad_out, double dt, void* grad_s,
+                                    void* const grad_velocity[3], void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && grad_out && s_bc, "advect_centered_backward: NULL argument");
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "advect_centered_backward"));
+    if (grad_velocity) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_velocity, "grad_velocity"));
+    const void* u[3];
+    void* gu[3];
+    remap3(v, velocity, u);
+    remap3w(v, grad_velocity, gu);
+    return run_advect_centered_bwd(ctx, v, sfield, s_bc, s_val, u, grad_out, grad_s, grad_velocity ? gu : nullptr, dt, s);
+}
+
+int phihip_centered_to_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const int32_t s_bc[3][2], const double vector[3],
+                                          const void* const grad_out[3], void* grad_s, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(s_bc && vector && grad_s, "centered_to_staggered_backward: NULL argument");
+    PHIHIP_TRY(check_ptrs(v, grad_out, "grad_out"));
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "centered_to_staggered_backward"));
+    double vec[3] = {0, 0, 0};
+    for (int d = 0; d < v.rank; ++d) vec[d + v.ax0] = vector[d];
+    const void* go[3];
+    remap3(v, grad_out, go);
+    return run_centered_to_staggered_bwd(ctx, v, s_bc, vec, go, grad_s, s);
+}
+
+int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, int balance,
+                                        void* const grad_velocity[3], const void* grad_pressure, const phihip_solve* solve,
+                                        phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_velocity, "grad_velocity"));
+    PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    PHIHIP_TRY(check_solve(solve));
+    void* gu[3];
+    remap3w(v, grad_velocity, gu);
+    return run_project_bwd(ctx, v, flags, mask_batch, balance, gu, grad_pressure, solve, info, s);
 }
 
 int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3],

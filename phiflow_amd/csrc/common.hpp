@@ -93,7 +93,7 @@ struct phihip_ctx {
     int num_cu = 256;
     phihip::Tuning tuning[3];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE
     // workspace (grown on demand, reused between calls)
-    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv;
+    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adj_q, ws_adj_l;
     void* last_state = nullptr;   // device control blocks of the most recent solve
     int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
@@ -144,6 +144,15 @@ int run_centered_to_staggered(phihip_ctx*, const GridView&, const void* s, const
                               const double vector[3], int accumulate, void* const out[3], hipStream_t);
 int run_obstacle_accessible(phihip_ctx*, const GridView&, const phihip_obstacle* obs, int count, uint8_t* accessible, hipStream_t);
 int run_apply_obstacles(phihip_ctx*, const GridView&, const phihip_obstacle* obs, int count, void* const v[3], hipStream_t);
+int run_balance(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, void* x, hipStream_t);
+int run_advect_staggered_bwd(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], const void* const gout[3],
+                             void* const gf[3], void* const gv[3], double dt, hipStream_t);
+int run_advect_centered_bwd(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
+                            const void* const v[3], const void* gout, void* gs, void* const gv[3], double dt, hipStream_t);
+int run_centered_to_staggered_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double vector[3], const void* const gout[3],
+                                  void* gs, hipStream_t);
+int run_project_bwd(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, int balance, void* const gv[3], const void* gp,
+                    const phihip_solve*, phihip_solve_info*, hipStream_t);
 int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);
 int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const uint8_t* flags, int mask_batch, int balance, void* div, hipStream_t);
 int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);

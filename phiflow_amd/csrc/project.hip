@@ -125,6 +125,48 @@ __global__ __launch_bounds__(kBlock) void balance_apply_kernel(T* __restrict__ d
     }
 }
 
+// standalone balance: x -= active * sum(x) / sum(active)   (fluid._balance_divergence on an arbitrary cell field)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void sum_cells_kernel(const T* __restrict__ x, const uint8_t* flags, int flags_per_batch, long long cells,
+                                                           double* part_sum, double* part_act, int nblk) {
+    __shared__ double red[kBlock / kWave];
+    const int b = blockIdx.y;
+    double sx = 0, sa = 0;
+    for (long long c = (long long)blockIdx.x * kBlock + threadIdx.x; c < cells; c += (long long)gridDim.x * kBlock) {
+        sx += (double)x[(long long)b * cells + c];
+        sa += flags ? ((flags[(flags_per_batch ? (long long)b * cells : 0) + c] & 64u) ? 1.0 : 0.0) : 1.0;
+    }
+    const double s1 = block_sum(sx, red);
+    const double s2 = block_sum(sa, red);
+    if (threadIdx.x == 0) {
+        part_sum[(long long)b * nblk + blockIdx.x] = s1;
+        part_act[(long long)b * nblk + blockIdx.x] = s2;
+    }
+}
+
+int run_balance(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, void* x, hipStream_t s) {
+    const int nblk = ceil_div(v.cells, kBlock) < kMaxPartialBlocks ? ceil_div(v.cells, kBlock) : kMaxPartialBlocks;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
+    double* part_sum = (double*)ctx->ws_div.ptr;
+    double* part_act = part_sum + (size_t)v.batch * nblk;
+    double* shift = (double*)ctx->ws_scalars.ptr;
+    const int fpb = mask_batch > 1 ? 1 : 0;
+    LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
+    const int nb2 = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    if (v.dtype == PHIHIP_F64) {
+        hipLaunchKernelGGL(sum_cells_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, (const double*)x, flags, fpb, v.cells, part_sum, part_act, nblk);
+        hipLaunchKernelGGL(balance_scalar_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)part_sum, (const double*)part_act, nblk, shift);
+        hipLaunchKernelGGL(balance_apply_kernel<double>, dim3(nb2, v.batch), dim3(kBlock), 0, s, (double*)x, flags, fpb, (const double*)shift, v.cells);
+    } else {
+        hipLaunchKernelGGL(sum_cells_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, (const float*)x, flags, fpb, v.cells, part_sum, part_act, nblk);
+        hipLaunchKernelGGL(balance_scalar_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)part_sum, (const double*)part_act, nblk, shift);
+        hipLaunchKernelGGL(balance_apply_kernel<float>, dim3(nb2, v.batch), dim3(kBlock), 0, s, (float*)x, flags, fpb, (const double*)shift, v.cells);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 template <typename T, int DIM>
 static void launch_divergence(const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
                               double* part_sum, double* part_act, int nblk, hipStream_t s) {

@@ -5,6 +5,7 @@ import warnings
 
 import torch
 
+from . import autodiff
 from .field import Field, _ptrs
 
 
@@ -21,8 +22,14 @@ def explicit(u: Field, diffusivity: float, dt: float, substeps: int = 1, order: 
                       RuntimeWarning)
     be = u.backend
     cur = [t.contiguous() for t in u.values]
+    tracked = autodiff.needs_grad(*cur)
+    if tracked:
+        cur = list(autodiff.NotDifferentiable.apply("diffuse.explicit", *cur))
+        anchor = sum(t.reshape(-1)[0] * 0 for t in cur)
     for _ in range(substeps):
         out = [torch.empty_like(t) for t in cur]
         be.ctx.diffuse_explicit(u.grid_struct(), _ptrs(cur), _ptrs(out), amount / substeps, be.stream())
         cur = out
+    if tracked:
+        cur = [t + anchor for t in cur]
     return u.with_values(cur)

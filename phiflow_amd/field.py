@@ -403,7 +403,12 @@ def resample(value: Field, to: Field) -> Field:
         s_codes, s_vals = resolve(value.boundary, value.dims)
         s_val = [[s_vals[a][s][0] if isinstance(value.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
                  for a, d in enumerate(value.dims)]
-        be.ctx.centered_to_staggered(grid, src.data_ptr(), s_codes, s_val, scale, False, _ptrs(comps), be.stream())
+        from . import autodiff
+        if autodiff.needs_grad(src):
+            meta = dict(be=be, grid=grid, s_codes=s_codes, s_val=s_val, vector=scale, shapes=[tuple(c.shape) for c in comps], dtype=value.dtype)
+            comps = list(autodiff.CenteredToStaggered.apply(meta, src))
+        else:
+            be.ctx.centered_to_staggered(grid, src.data_ptr(), s_codes, s_val, scale, False, _ptrs(comps), be.stream())
         return Field(to.resolution, to.bounds, to.boundary, comps, True, be, value.batched or to.batched)
     raise NotImplementedError("resample: only centred -> staggered on the same grid is implemented")
 

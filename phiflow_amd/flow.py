@@ -4,6 +4,7 @@ phi/flow.py:13-28) for the part of PhiFlow that this backend accelerates: grid f
 """
 from . import advect, diffuse, fluid
 from . import extrapolation
+from .autodiff import functional_gradient, gradient, jacobian, l2_loss, stop_gradient
 from .backend import HipBackend, default_backend, precision, set_global_default_backend, set_global_precision
 from .extrapolation import BOUNDARY, ONE, PERIODIC, ZERO, ZERO_GRADIENT, ConstantExtrapolation, combine_sides
 from .field import CenteredGrid, Field, StaggeredGrid, assert_close, divergence, mean, resample, spatial_gradient
@@ -17,5 +18,6 @@ __all__ = [
     'BOUNDARY', 'ONE', 'PERIODIC', 'ZERO', 'ZERO_GRADIENT', 'ConstantExtrapolation', 'combine_sides',
     'CenteredGrid', 'Field', 'StaggeredGrid', 'assert_close', 'divergence', 'mean', 'resample', 'spatial_gradient',
     'Box', 'Cuboid', 'Sphere', 'vec', 'Obstacle',
+    'functional_gradient', 'gradient', 'jacobian', 'l2_loss', 'stop_gradient',
     'ConvergenceException', 'Diverged', 'NotConverged', 'Solve', 'SolveInfo', 'copy_with',
 ]

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
-from . import _capi
+from . import _capi, autodiff
 from .extrapolation import pressure_extrapolation
 from .field import Field, _check_pressure_padding, _ptrs, _sample_points
 from .geom import Box, Geometry, Sphere
@@ -191,13 +191,27 @@ def make_incompressible(velocity: Field,
         _check_pressure_padding(x0.boundary, velocity.boundary, velocity.dims)
         pressure = x0.values.to(velocity.dtype)
         pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()
-    new_v = [t.clone() for t in velocity.values]
-    if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
-        be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
     csolve = _capi.Solve(solve.rel_tol, solve.abs_tol, int(solve.max_iterations), int(solve.refresh_every), int(solve.check_every), 0)
-    infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
-                                       flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
-                                       True, be.stream())
+    if autodiff.needs_grad(*velocity.values):
+        # differentiable path: the same kernels behind torch.autograd.Function nodes (adjoint kernels in csrc/adjoint.hip)
+        vin = [t.contiguous() for t in velocity.values]
+        shapes = [tuple(t.shape) for t in vin]
+        if obstacles:
+            vin = list(_apply_obstacles_autograd(velocity, obstacles, vin))
+        gsolve = solve.gradient_solve if getattr(solve, 'gradient_solve', None) is not None else solve
+        csolve_bwd = _capi.Solve(gsolve.rel_tol, gsolve.abs_tol, int(gsolve.max_iterations), int(gsolve.refresh_every), int(gsolve.check_every), 0)
+        meta = dict(be=be, grid=velocity.grid_struct(), flags_ptr=flags.data_ptr() if flags is not None else 0, flags=flags, balance=balance,
+                    csolve=csolve, csolve_bwd=csolve_bwd, shapes=shapes, dtype=velocity.dtype)
+        *new_v, pressure = autodiff.MakeIncompressible.apply(meta, pressure.detach(), *vin)
+        new_v = list(new_v)
+        infos = meta['infos']
+    else:
+        new_v = [t.clone() for t in velocity.values]
+        if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
+            be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
+        infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
+                                           flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
+                                           True, be.stream())
     info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
                      [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
     _raise_if_failed(info)
@@ -205,6 +219,13 @@ def make_incompressible(velocity: Field,
     p_out = Field(velocity.resolution, velocity.bounds, p_ext, pressure, False, be, velocity.batched)
     p_out.solve_info = info
     return v_out, p_out
+
+
+def _apply_obstacles_autograd(velocity: Field, obstacles, vin):
+    still = [Obstacle(ob.geometry) for ob in obstacles]
+    meta = dict(be=velocity.backend, grid=velocity.grid_struct(), obstacles=_obstacle_array(obstacles, velocity),
+                obstacles_still=_obstacle_array(still, velocity), count=len(obstacles), shapes=[tuple(t.shape) for t in vin], dtype=velocity.dtype)
+    return autodiff.ApplyObstacles.apply(meta, *vin)
 
 
 def _raise_if_failed(info: SolveInfo):
@@ -228,6 +249,8 @@ def apply_boundary_conditions(velocity: Field, obstacles) -> Field:
     if not obstacles:
         return velocity
     be = velocity.backend
+    if autodiff.needs_grad(*velocity.values):
+        return velocity.with_values(list(_apply_obstacles_autograd(velocity, obstacles, [t.contiguous() for t in velocity.values])))
     new_v = [t.clone() for t in velocity.values]
     be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
     return velocity.with_values(new_v)

@@ -48,6 +48,7 @@ class Solve:
     preprocess_y: Optional[Callable] = None
     preprocess_y_args: tuple = ()
     rank_deficiency: Optional[int] = None
+    gradient_solve: Optional['Solve'] = None      # solve used by the backward pass (phiml: defaults to this solve)
     # backend-specific knobs (not in PhiML): how often the host polls the device-side continue flags, and the
     # true-residual refresh period of PhiML's cg (50)
     check_every: int = 10

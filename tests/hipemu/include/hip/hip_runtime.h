@@ -60,6 +60,10 @@ int cur_lane();
 
 inline void __syncthreads() { hipemu::sync_block(); }
 
+// fibers of the emulation run one at a time: a plain read-modify-write is atomic
+template <typename T>
+inline T atomicAdd(T* p, T v) { const T old = *p; *p = old + v; return old; }
+
 template <typename T>
 inline T __shfl_down(T v, unsigned delta, int width = 64) {
     static_assert(sizeof(T) <= 16, "shuffle payload too large");

@@ -270,6 +270,117 @@ def check_obstacle_kernels(ctx, mem, dom, grid, dtype, rng, obstacles):
         assert err <= tol(dtype)['stencil'], f"apply_obstacles[{d}] rel err {err}"
 
 
+# ---- adjoint kernels against directional finite differences of the ORACLE's forward functions (fp64) ----------
+def _dot(a_list, b_list):
+    return float(sum(np.vdot(a, b) for a, b in zip(a_list, b_list)))
+
+
+def _fd(fun, x_list, d_list, eps=1e-6):
+    """ central difference of the scalar function `fun` along the direction d """
+    plus = fun([x + eps * d for x, d in zip(x_list, d_list)])
+    minus = fun([x - eps * d for x, d in zip(x_list, d_list)])
+    return (plus - minus) / (2 * eps)
+
+
+def check_advect_backward(ctx, mem, dom, grid, rng, s_codes, s_consts, dt=0.7):
+    """ VJPs of semi-Lagrangian advection (staggered self-advection, centred scalar) and of the centred -> staggered resample """
+    dtype = np.float64
+    B, D = grid.batch, dom.rank
+    v = random_velocity(dom, B, dtype, rng)
+    g = random_velocity(dom, B, dtype, rng)
+    dv, dg = [mem.to_dev(a) for a in v], [mem.to_dev(a) for a in g]
+    gf = [mem.to_dev(np.zeros_like(a)) for a in v]
+    gv = [mem.to_dev(np.zeros_like(a)) for a in v]
+    P = lambda hs: [mem.ptr(h) for h in hs]
+    ctx.advect_staggered_backward(grid, P(dv), P(dv), P(dg), dt, P(gf), P(gv))
+    mem.sync()
+    grad = [mem.to_host(a) + mem.to_host(b) for a, b in zip(gf, gv)]           # self-advection: both paths
+    loss = lambda x: _dot(g, O.semi_lagrangian_staggered(x, x, dt, dom))
+    for _ in range(3):
+        d = random_velocity(dom, B, dtype, rng)
+        fd, an = _fd(loss, v, d), _dot(grad, d)
+        assert abs(fd - an) <= 2e-5 * max(abs(fd), abs(an), 1.0), f"advect_staggered_backward: fd {fd} vs adjoint {an}"
+    # field != velocity: gradient w.r.t. the field alone is linear and exact
+    f = random_velocity(dom, B, dtype, rng)
+    df = [mem.to_dev(a) for a in f]
+    gf = [mem.to_dev(np.zeros_like(a)) for a in v]
+    ctx.advect_staggered_backward(grid, P(df), P(dv), P(dg), dt, P(gf), None)
+    mem.sync()
+    d = random_velocity(dom, B, dtype, rng)
+    lin = _dot(g, O.semi_lagrangian_staggered(d, v, dt, dom)) - _dot(g, O.semi_lagrangian_staggered([np.zeros_like(a) for a in d], v, dt, dom))
+    assert abs(lin - _dot([mem.to_host(a) for a in gf], d)) <= 1e-10 * max(abs(lin), 1.0)
+    # centred scalar
+    s = rng.standard_normal((B,) + dom.res)
+    gs_up = rng.standard_normal((B,) + dom.res)
+    ds, dgo = mem.to_dev(s), mem.to_dev(gs_up)
+    gs, gv = mem.to_dev(np.zeros_like(s)), [mem.to_dev(np.zeros_like(a)) for a in v]
+    ctx.advect_centered_backward(grid, mem.ptr(ds), s_codes, s_consts, P(dv), mem.ptr(dgo), dt, mem.ptr(gs), P(gv))
+    mem.sync()
+    loss_sv = lambda xs: float(np.vdot(gs_up, O.semi_lagrangian_centered(xs[0], xs[1:], dt, dom, s_codes, s_consts)))
+    for _ in range(3):
+        d = [rng.standard_normal(s.shape)] + random_velocity(dom, B, dtype, rng)
+        fd = _fd(loss_sv, [s] + v, d)
+        an = _dot([mem.to_host(gs)] + [mem.to_host(a) for a in gv], d)
+        assert abs(fd - an) <= 2e-5 * max(abs(fd), abs(an), 1.0), f"advect_centered_backward: fd {fd} vs adjoint {an}"
+    # centred -> staggered (linear: exact)
+    vector = [0.3, -1.5, 0.1][:D]
+    gs = mem.to_dev(np.zeros_like(s))
+    ctx.centered_to_staggered_backward(grid, s_codes, vector, P(dg), mem.ptr(gs))
+    mem.sync()
+    d = rng.standard_normal(s.shape)
+    zero_c = [(0.0, 0.0)] * D     # the constant boundary values do not depend on s
+    lin = _dot(g, O.centered_to_staggered(d, dom, s_codes, zero_c, vector))
+    assert abs(lin - float(np.vdot(mem.to_host(gs), d))) <= 1e-10 * max(abs(lin), 1.0)
+
+
+def check_project_backward(ctx, mem, dom, grid, rng, obstacles=()):
+    """ VJP of make_incompressible (velocity and pressure cotangents) against the oracle's forward: the map is affine, so the
+    directional derivative is the difference of two oracle projections. """
+    dtype = np.float64
+    B, D = grid.batch, dom.rank
+    g_v = random_velocity(dom, B, dtype, rng)
+    g_p = rng.standard_normal((B,) + dom.res)
+    flags_np = active = None
+    dflags = None
+    if obstacles:
+        active, hard, soft = O.obstacle_masks(obstacles, dom, dtype)
+        acc = (active[0] > 0).astype(np.uint8)
+        dacc, dflags = mem.to_dev(acc), mem.empty(dom.res, np.uint8)
+        g1 = C.make_grid(D, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+        ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    balance = not dom.flexible()
+    if balance:
+        g_p = g_p - g_p.mean(axis=tuple(range(1, g_p.ndim)), keepdims=True) if active is None else g_p * active
+        # (the singular system fixes p only up to its null space; use cotangents that do not see it)
+        if active is not None:
+            g_p = g_p - active * (g_p.sum(axis=tuple(range(1, g_p.ndim)), keepdims=True) / active.sum())
+    dgv = [mem.to_dev(a) for a in g_v]
+    dgp = mem.to_dev(g_p)
+    s = solve_params(dtype, rtol=1e-13)
+    ctx.make_incompressible_backward(grid, mem.ptr(dflags) if dflags is not None else 0, 1, balance, [mem.ptr(a) for a in dgv], mem.ptr(dgp), s)
+    mem.sync()
+    grad = [mem.to_host(a) for a in dgv]
+
+    def forward(vel):   # projection WITHOUT the soft obstacle mask (that is a separate op with its own adjoint)
+        hard_ = act_ = None
+        if obstacles:
+            act_, hard_, _ = O.obstacle_masks(obstacles, dom, dtype)
+        div = O.divergence(vel, dom)
+        if act_ is not None:
+            div = div * act_
+        rhs = O.balance_divergence(div, act_) if balance else div
+        A = lambda q: O.masked_laplace(q, dom, hard_, act_)
+        p, _ = O.cg(A, rhs, np.zeros_like(rhs), 1e-13, 0.0, 2000, 50)
+        return O.gradient_subtract(vel, p, dom, hard_), p
+    for _ in range(2):
+        d = random_velocity(dom, B, dtype, rng)
+        zero = [np.zeros_like(a) for a in d]
+        (v1, p1), (v0, p0) = forward(d), forward(zero)
+        lin = _dot(g_v, [a - b for a, b in zip(v1, v0)]) + float(np.vdot(g_p, p1 - p0))
+        an = _dot(grad, d)
+        assert abs(lin - an) <= 1e-7 * max(abs(lin), abs(an), 1.0), f"make_incompressible_backward: oracle {lin} vs adjoint {an}"
+
+
 def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)

@@ -65,6 +65,25 @@ def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
         pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:2])
+def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
+    """ backward kernels vs finite differences / linear responses of the oracle's forward functions (fp64) """
+    rng = np.random.default_rng(14)
+    dom, grid = pc.make_case(res, bc, np.float64, batch=2)
+    s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+    s_consts = [(0.0, 0.25)] * len(res)
+    pc.check_advect_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
+    pc.check_project_backward(emu_ctx, MEM, dom, grid, rng)
+
+
+def test_adjoint_projection_with_obstacles(emu_ctx):
+    rng = np.random.default_rng(15)
+    dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float64, batch=1)
+    pc.check_project_backward(emu_ctx, MEM, dom, grid, rng, obstacles=[pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))])
+    dom, grid = pc.make_case((16, 20), ((PER, PER), (CLO, OPN)), np.float64, batch=2)
+    pc.check_project_backward(emu_ctx, MEM, dom, grid, rng, obstacles=[pc.O.SphereObstacle((8.0, 9.0), 3.5)])
+
+
 def test_advection_with_wall_velocity(emu_ctx):
     """ lid-driven cavity boundary: tangential wall velocity on one side (Lid_Driven_Cavity.ipynb cell 5) """
     rng = np.random.default_rng(3)

@@ -48,6 +48,12 @@ def test_reference_style_scenarios(gpu_backend):
     host.test_fp64_precision_context(gpu_backend)
 
 
+def test_gradients(gpu_backend):
+    """ adjoint kernels behind torch.autograd on the GPU vs finite differences of the forward path """
+    host.test_make_incompressible_gradient(gpu_backend)
+    host.test_functional_gradient_through_a_fluid_step(gpu_backend)
+
+
 def test_default_backend_is_the_gpu(gpu_backend):
     """ the product path: no explicit backend -> libphihip.so + cuda device; tensors live on the GPU """
     from phiflow_amd.flow import PERIODIC, Solve, StaggeredGrid, advect, default_backend, fluid

@@ -95,6 +95,24 @@ def test_obstacle_rasterisation_and_moving_obstacles(ctx, mem):
     pc.check_obstacle_kernels(ctx, mem, dom, grid, np.float32, rng, many)
 
 
+@pytest.mark.parametrize("res,bc", GRIDS[:5] + GRIDS[6:9])
+def test_adjoint_kernels_match_oracle_derivatives(ctx, mem, res, bc):
+    """ backward kernels (atomics on the real GPU) vs finite differences / linear responses of the oracle (fp64) """
+    rng = np.random.default_rng(14)
+    dom, grid = pc.make_case(res, bc, np.float64, batch=2)
+    s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+    pc.check_advect_backward(ctx, mem, dom, grid, rng, s_codes, [(0.0, 0.25)] * len(res))
+    pc.check_project_backward(ctx, mem, dom, grid, rng)
+
+
+def test_adjoint_projection_with_obstacles(ctx, mem):
+    rng = np.random.default_rng(15)
+    dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float64, batch=1)
+    pc.check_project_backward(ctx, mem, dom, grid, rng, obstacles=[pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))])
+    dom, grid = pc.make_case((16, 20), ((PER, PER), (CLO, OPN)), np.float64, batch=2)
+    pc.check_project_backward(ctx, mem, dom, grid, rng, obstacles=[pc.O.SphereObstacle((8.0, 9.0), 3.5)])
+
+
 def test_reference_known_answer_self_advection(ctx, mem):
     """ /root/reference tests/commit/physics/test_advect.py:41-45 -- the only stored known answer on the path """
     dom, grid = pc.make_case((4, 3), ((CLO, CLO), (CLO, CLO)), np.float32)

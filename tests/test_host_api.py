@@ -221,3 +221,74 @@ def test_fp64_precision_context(emu_backend):
         assert v.dtype == torch.float64
         v, p = fluid.make_incompressible(v, (), Solve('CG', 1e-12, 1e-12))
         assert np.abs(divergence(v).numpy()).max() <= 1e-10
+
+
+def _fd_gradient_check(loss_of_values, values, grads, rng, eps=1e-6, tol=2e-5, n_dirs=3):
+    """ directional central differences of a scalar python function of a list of float64 arrays vs analytic gradients """
+    for _ in range(n_dirs):
+        d = [rng.standard_normal(v.shape) for v in values]
+        plus = loss_of_values([v + eps * di for v, di in zip(values, d)])
+        minus = loss_of_values([v - eps * di for v, di in zip(values, d)])
+        fd = (plus - minus) / (2 * eps)
+        an = float(sum(np.vdot(g, di) for g, di in zip(grads, d)))
+        assert abs(fd - an) <= tol * max(abs(fd), abs(an), 1e-3), f"finite difference {fd} vs gradient {an}"
+
+
+def test_make_incompressible_gradient(emu_backend):
+    """ tests/commit/physics/test_fluid.py:55-73: gradient of l2_loss(make_incompressible(v)[0]) w.r.t. the velocity. The reference
+    compares its backends with each other; here the adjoint kernels are compared with finite differences of the forward path. """
+    import torch
+    from phiflow_amd.flow import jacobian, l2_loss, precision
+    rng = np.random.default_rng(20)
+    with precision(64):
+        bounds = Box['x,y', 0:100, 0:100]
+        for ext in (ZERO, PERIODIC, combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY))):
+            shapes = StaggeredGrid(0, ext, bounds, x=16, y=16, backend=emu_backend).component_shapes
+            vals = [rng.standard_normal(s) for s in shapes]
+            solve = Solve('CG', 1e-12, 0)
+
+            def sim(velocity):
+                velocity, _ = fluid.make_incompressible(velocity, (), solve)
+                loss = l2_loss(velocity)
+                assert bool(torch.isfinite(loss).all())
+                return loss
+
+            sim_grad = jacobian(sim, get_output=False)
+            grad, = sim_grad(StaggeredGrid(vals, ext, bounds, x=16, y=16, backend=emu_backend))
+            assert grad.is_staggered and all(np.isfinite(g).all() for g in grad.numpy())
+            loss_np = lambda vs: float(sim(StaggeredGrid(vs, ext, bounds, x=16, y=16, backend=emu_backend)))
+            _fd_gradient_check(loss_np, vals, grad.numpy(), rng, tol=1e-6)
+
+
+def test_functional_gradient_through_a_fluid_step(emu_backend):
+    """ tests/commit/test_colab_fluids_tutorial.py:11-34 pattern: gradient of a loss on the smoke after several steps of
+    {advect smoke, buoyancy, self-advection, projection} w.r.t. the initial velocity (semi-Lagrangian smoke advection: the
+    MacCormack adjoint is not implemented), with an obstacle in the way. """
+    from phiflow_amd.flow import functional_gradient, l2_loss, precision, resample
+    rng = np.random.default_rng(21)
+    with precision(64):
+        bounds = Box(x=32, y=40)
+        inflow = 0.6 * CenteredGrid(Sphere(x=16, y=6, radius=4), BOUNDARY, bounds, x=16, y=20, backend=emu_backend)
+        obstacle = Obstacle(Box(x=(10, 18), y=(22, 26)))
+        solve = Solve('CG', 1e-12, 0)
+
+        def simulate(velocity, smoke):
+            for _ in range(2):
+                smoke = advect.semi_lagrangian(smoke, velocity, 1.0) + inflow
+                buoyancy = resample(smoke * (0, 0.5), to=velocity)
+                velocity = advect.semi_lagrangian(velocity, velocity, 1.0) + buoyancy
+                velocity, pressure = fluid.make_incompressible(velocity, obstacle, solve)
+            return l2_loss(smoke) + 0.1 * l2_loss(velocity) + 0.01 * l2_loss(pressure), smoke, velocity
+
+        shapes = StaggeredGrid(0, 0, bounds, x=16, y=20, backend=emu_backend).component_shapes
+        v_vals = [0.3 * rng.standard_normal(s) for s in shapes]
+        s_vals = rng.random((16, 20))
+        mk = lambda vs, ss: (StaggeredGrid(vs, 0, bounds, x=16, y=20, backend=emu_backend), CenteredGrid(ss, BOUNDARY, bounds, x=16, y=20, backend=emu_backend))
+        sim_grad = functional_gradient(simulate, wrt=[0, 1], get_output=False)
+        g_v, g_s = sim_grad(*mk(v_vals, s_vals))
+        loss_np = lambda arrs: float(simulate(*mk(arrs[:2], arrs[2]))[0])
+        _fd_gradient_check(loss_np, v_vals + [s_vals], g_v.numpy() + [g_s.numpy()], rng, eps=1e-6, tol=1e-4)
+        # ops without an adjoint kernel refuse to differentiate instead of returning wrong gradients
+        bad = functional_gradient(lambda v: l2_loss(advect.mac_cormack(v, v, 1.0)), wrt=[0], get_output=False)
+        with pytest.raises(NotImplementedError):
+            bad(mk(v_vals, s_vals)[0])
