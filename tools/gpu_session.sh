@@ -27,10 +27,14 @@ if [[ "$STEPS" == *all* || "$STEPS" == *prof* ]]; then
   echo "== rocprofv3 stats (bench)"
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-size 0 --profile-steps 0 > "$REPO/gpurun_out/rocprof_bench.log" 2>&1); echo "rc=$?"
   echo "== rocprofv3 stats (512^3 CG)"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats_cg512" -o cg512 -- python "$REPO/tools/pmc_workload.py" > "$REPO/gpurun_out/rocprof_cg512.log" 2>&1); echo "rc=$?"
-  echo "== rocprofv3 pmc FETCH_SIZE"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$REPO/gpurun_out/pmc_fetch" -o fetch -- python "$REPO/tools/pmc_workload.py" > "$REPO/gpurun_out/pmc_fetch.log" 2>&1); echo "rc=$?"
-  echo "== rocprofv3 pmc WRITE_SIZE"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$REPO/gpurun_out/pmc_write" -o write -- python "$REPO/tools/pmc_workload.py" > "$REPO/gpurun_out/pmc_write.log" 2>&1); echo "rc=$?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_stats_cg512" -o cg512 -- python "$REPO/tools/pmc_workload.py" 512 > "$REPO/gpurun_out/rocprof_cg512.log" 2>&1); echo "rc=$?"
+  for SZ in 256 512; do
+    for CTR in FETCH_SIZE WRITE_SIZE; do
+      echo "== rocprofv3 pmc $CTR ($SZ^3)"
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$REPO/gpurun_out/pmc_${SZ}/$CTR" -o pmc -- python "$REPO/tools/pmc_workload.py" $SZ > "$REPO/gpurun_out/pmc_${SZ}_$CTR.log" 2>&1); echo "rc=$?"
+    done
+    python tools/pmc_summary.py gpurun_out/pmc_${SZ} gpurun_out/pmc_summary_${SZ}.json > /dev/null
+  done
+  python tools/pmc_traffic.py gpurun_out/pmc_summary_256.json gpurun_out/pmc_summary_512.json > gpurun_out/pmc_traffic.json; cat gpurun_out/pmc_traffic.json
   find gpurun_out -name "*.csv" | head -30
 fi

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""
+Collects the per-launch HBM traffic of the CG kernels from tools/pmc_summary.py outputs (one per problem size) into the small
+table bench.py reads (profiles/pmc_traffic.json):  python tools/pmc_traffic.py pmc_summary_256.json pmc_summary_512.json
+"""
+import json
+import re
+import sys
+
+
+def main():
+    out = {}
+    for path in sys.argv[1:]:
+        size = int(re.search(r"(\d+)\.json$", path).group(1))
+        data = json.load(open(path))["kernels"]
+        for key, e in data.items():
+            for mode in ("cg_update", "cg_matvec_dot", "cg_residual"):
+                if key.startswith(mode + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e:
+                    out[f"{mode}_{size}"] = int(round(e["read_bytes_prescribed"] + e["write_bytes_prescribed"]))
+                    out[f"{mode}_{size}_kernel"] = key
+    out["_note"] = ("HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, one process per size), "
+                    "FETCH_SIZE x 2048 B, WRITE_SIZE x 1024 B (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 1/2 of a wide streaming "
+                    "read); calibrated against a 512 MiB streaming copy in the same run (profiles/r01_pmc_summary_<size>.json)")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

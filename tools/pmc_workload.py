@@ -2,7 +2,8 @@
 """
 Workload for the rocprofv3 PMC passes (run once per counter set, see tools/gpu_session.sh):
   1. calibration: a plain 16 B/lane streaming copy of a known size (torch copy_ of 512 MiB fp32) -- known bytes read/written
-  2. the CG loop at 512^3 and 256^3 fp32 (a few iterations, default tile configuration)
+  2. the CG loop at the sizes given on the command line (default 512^3 and 256^3) fp32, a few iterations, default launch plan
+     -- one size per profiled process keeps kernels with identical template arguments and grids apart
 The summary (tools/pmc_summary.py) turns FETCH_SIZE / WRITE_SIZE per dispatch into HBM bytes per launch.
 """
 import math
@@ -17,6 +18,7 @@ from phiflow_amd import _capi as C   # noqa: E402
 
 
 def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [512, 256]
     dev = torch.device("cuda:0")
     a = torch.randn(128 * 1024 * 1024, device=dev)       # 512 MiB
     b = torch.empty_like(a)
@@ -27,7 +29,7 @@ def main():
     lib = C.load_default_library()
     ctx = C.Context(lib, 0)
     L = 2 * math.pi
-    for n, iters in ((512, 4), (256, 6)):
+    for n, iters in [(n, 4 if n >= 512 else 6) for n in sizes]:
         grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
         g = torch.Generator(device="cpu").manual_seed(0)
         rhs = torch.randn(1, n, n, n, generator=g)
