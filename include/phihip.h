@@ -197,6 +197,23 @@ int phihip_advect_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, c
 int phihip_advect_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
                                     const double s_val[3][2], const void* const velocity[3], const void* grad_out, double dt,
                                     void* grad_s, void* const grad_velocity[3], void* stream);
+/* MacCormack: recomputes the semi-Lagrangian intermediate, then correction-pass adjoint + semi-Lagrangian adjoint; a clamped
+ * sample passes its gradient to the extremal tap. grad_field / grad_s are required, grad_velocity may be NULL. */
+int phihip_mac_cormack_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3],
+                                          const void* const velocity[3], const void* const grad_out[3], double dt,
+                                          double correction_strength, void* const grad_field[3], void* const grad_velocity[3],
+                                          void* stream);
+int phihip_mac_cormack_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                         const double s_val[3][2], const void* const velocity[3], const void* grad_out,
+                                         double dt, double correction_strength, void* grad_s, void* const grad_velocity[3],
+                                         void* stream);
+/* adjoint of phihip_diffuse_explicit: grad_in += (I + k dt L)^T grad_out */
+int phihip_diffuse_explicit_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const grad_out[3],
+                                     void* const grad_in[3], double diffusivity_dt, void* stream);
+/* diffuse.explicit of a CenteredGrid with its own extrapolation (phi/physics/diffuse.py:13-60); adjoint != 0: `out` is the
+ * ACCUMULATED input gradient and `s` the output gradient */
+int phihip_diffuse_explicit_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                     const double s_val[3][2], void* out, double diffusivity_dt, int adjoint, void* stream);
 int phihip_centered_to_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const int32_t s_bc[3][2],
                                           const double vector[3], const void* const grad_out[3], void* grad_s, void* stream);
 /* adjoint of phihip_make_incompressible (implicit-function gradient of the linear solve like phiml's solve_linear backward):

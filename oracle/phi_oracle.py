@@ -766,6 +766,24 @@ def laplace_component(a: np.ndarray, comp: int, dom: Domain):
     return out
 
 
+def diffuse_explicit_centered(s: np.ndarray, diffusivity: float, dt: float, dom: Domain, s_codes, s_consts=None, substeps: int = 1):
+    """ diffuse.explicit of a CenteredGrid (phi/physics/diffuse.py:13-60): s += (k dt / substeps) * laplace(s), the scalar's own
+    extrapolation pads the stencil (field.laplace order 2, phi/field/_field_math.py:119-145) """
+    D = dom.rank
+    amount = s.dtype.type(diffusivity * dt / substeps)
+    for _ in range(substeps):
+        lap = np.zeros_like(s)
+        for axis in range(D):
+            widths = [(0, 0)] * D
+            widths[axis] = (1, 1)
+            p = pad_scalar(s, widths, s_codes, s_consts)
+            lo = [slice(None)] * (D + 1); mid = [slice(None)] * (D + 1); hi = [slice(None)] * (D + 1)
+            lo[axis + 1] = slice(0, -2); mid[axis + 1] = slice(1, -1); hi[axis + 1] = slice(2, None)
+            lap = lap + (p[tuple(lo)] + p[tuple(hi)] - 2 * p[tuple(mid)]) / s.dtype.type(dom.dx[axis] ** 2)
+        s = s + amount * lap
+    return s
+
+
 def diffuse_explicit(v: List[np.ndarray], diffusivity: float, dt: float, dom: Domain, substeps: int = 1):
     for _ in range(substeps):
         v = [vd + vd.dtype.type(diffusivity * dt / substeps) * laplace_component(vd, d, dom) for d, vd in enumerate(v)]

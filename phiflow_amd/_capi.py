@@ -27,7 +27,8 @@ EXPORTED_SYMBOLS = (
     "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
     "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
     "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
-    "phihip_make_incompressible_backward",
+    "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
+    "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
 )
 
 
@@ -156,6 +157,14 @@ class Library:
                                                       POINTER(_Ptr3), c_void_p, c_double, c_void_p, POINTER(_Ptr3), c_void_p]
         d.phihip_centered_to_staggered_backward.argtypes = [c_void_p, POINTER(Grid), POINTER((c_int32 * 2) * 3), POINTER(c_double * 3),
                                                             POINTER(_Ptr3), c_void_p, c_void_p]
+        d.phihip_mac_cormack_staggered_backward.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double,
+                                                            c_double, POINTER(_Ptr3), POINTER(_Ptr3), c_void_p]
+        d.phihip_mac_cormack_centered_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3),
+                                                           POINTER((c_double * 2) * 3), POINTER(_Ptr3), c_void_p, c_double, c_double, c_void_p,
+                                                           POINTER(_Ptr3), c_void_p]
+        d.phihip_diffuse_explicit_backward.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
+        d.phihip_diffuse_explicit_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
+                                                       c_void_p, c_double, c_int, c_void_p]
         d.phihip_make_incompressible_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_int, POINTER(_Ptr3), c_void_p,
                                                           POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
@@ -258,6 +267,28 @@ class Context:
         self.lib.check(self.lib.dll.phihip_advect_centered_backward(
             self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), ctypes.byref(ptr3(velocity)), grad_out, float(dt),
             grad_s or None, ctypes.byref(gv) if gv is not None else None, stream or None))
+
+    def mac_cormack_staggered_backward(self, grid, field, velocity, grad_out, dt, strength, grad_field, grad_velocity, stream=0):
+        gv = ptr3(grad_velocity)
+        self.lib.check(self.lib.dll.phihip_mac_cormack_staggered_backward(
+            self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)), ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(grad_out)), float(dt),
+            float(strength), ctypes.byref(ptr3(grad_field)), ctypes.byref(gv) if gv is not None else None, stream or None))
+
+    def mac_cormack_centered_backward(self, grid, s, s_bc, s_val, velocity, grad_out, dt, strength, grad_s, grad_velocity, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        gv = ptr3(grad_velocity)
+        self.lib.check(self.lib.dll.phihip_mac_cormack_centered_backward(
+            self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), ctypes.byref(ptr3(velocity)), grad_out, float(dt),
+            float(strength), grad_s, ctypes.byref(gv) if gv is not None else None, stream or None))
+
+    def diffuse_explicit_backward(self, grid, grad_out, grad_in, diffusivity_dt, stream=0):
+        self.lib.check(self.lib.dll.phihip_diffuse_explicit_backward(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(grad_out)),
+                                                                     ctypes.byref(ptr3(grad_in)), float(diffusivity_dt), stream or None))
+
+    def diffuse_explicit_centered(self, grid, s, s_bc, s_val, out, diffusivity_dt, adjoint=False, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        self.lib.check(self.lib.dll.phihip_diffuse_explicit_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), out,
+                                                                     float(diffusivity_dt), int(bool(adjoint)), stream or None))
 
     def centered_to_staggered_backward(self, grid, s_bc, vector, grad_out, grad_s, stream=0):
         bc, _ = self._scalar_bc(grid, s_bc, None)

@@ -64,32 +64,27 @@ def _advect(field: Field, velocity: Field, dt: float, integrator: Callable, corr
         src = vel if field is velocity else [_expand(t, B) for t in field.values]
         if autodiff.needs_grad(*src, *vel):
             if correction_strength is not None:
-                src = list(autodiff.NotDifferentiable.apply("advect.mac_cormack", *src))
-                vel = list(autodiff.NotDifferentiable.apply("advect.mac_cormack", *vel))
+                out = list(autodiff.MacCormackStaggered.apply(dict(be=be, grid=grid, dt=float(dt), strength=correction_strength), *src, *vel))
             else:
                 out = list(autodiff.SemiLagrangianStaggered.apply(dict(be=be, grid=grid, dt=float(dt)), *src, *vel))
-                return Field(field.resolution, field.bounds, field.boundary, out, True, be, field.batched or velocity.batched)
+            return Field(field.resolution, field.bounds, field.boundary, out, True, be, field.batched or velocity.batched)
         out = [torch.empty_like(t) for t in src]
         if correction_strength is None:
             be.ctx.advect_staggered(grid, _ptrs(src), _ptrs(vel), _ptrs(out), dt, be.stream())
         else:
             be.ctx.mac_cormack_staggered(grid, _ptrs(src), _ptrs(vel), _ptrs(out), dt, correction_strength, be.stream())
-            out = _reattach(out, src + vel)
         return Field(field.resolution, field.bounds, field.boundary, out, True, be, field.batched or velocity.batched)
     src = _expand(field.values, B)
     s_codes, s_val = _scalar_boundary(field)
     if autodiff.needs_grad(src, *vel):
-        if correction_strength is not None:
-            src, *vel = autodiff.NotDifferentiable.apply("advect.mac_cormack", src, *vel)
-        else:
-            out = autodiff.SemiLagrangianCentered.apply(dict(be=be, grid=grid, dt=float(dt), s_codes=s_codes, s_val=s_val), src, *vel)
-            return Field(field.resolution, field.bounds, field.boundary, out, False, be, field.batched or velocity.batched)
+        meta = dict(be=be, grid=grid, dt=float(dt), s_codes=s_codes, s_val=s_val, strength=correction_strength)
+        fn = autodiff.SemiLagrangianCentered if correction_strength is None else autodiff.MacCormackCentered
+        return Field(field.resolution, field.bounds, field.boundary, fn.apply(meta, src, *vel), False, be, field.batched or velocity.batched)
     out = torch.empty_like(src)
     if correction_strength is None:
         be.ctx.advect_centered(grid, src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, be.stream())
     else:
         be.ctx.mac_cormack_centered(grid, src.data_ptr(), s_codes, s_val, _ptrs(vel), out.data_ptr(), dt, correction_strength, be.stream())
-        out = _reattach([out], [src] + list(vel))[0]
     return Field(field.resolution, field.bounds, field.boundary, out, False, be, field.batched or velocity.batched)
 
 
@@ -110,15 +105,6 @@ def mac_cormack(field: Field, velocity: Field, dt: float, correction_strength=1.
         integrator: only `euler` is available on the HIP backend
     """
     return _advect(field, velocity, dt, integrator, float(correction_strength))
-
-
-def _reattach(outs, inputs):
-    """ ties kernel outputs without a backward kernel to the autograd graph of their inputs so that a later .backward() raises
-    (NotDifferentiable) instead of silently dropping the dependency """
-    if not autodiff.needs_grad(*inputs):
-        return outs
-    anchor = sum((t.reshape(-1)[0] * 0 for t in inputs if t.requires_grad))
-    return [o + anchor for o in outs]
 
 
 def _expand(t: torch.Tensor, B: int) -> torch.Tensor:

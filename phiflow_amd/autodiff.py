@@ -7,8 +7,9 @@ them to `torch.autograd` so that the elementwise glue between the kernels (field
 differentiate too. torch is the tape, not the arithmetic.
 
 Differentiable: `advect.semi_lagrangian` (staggered + centred), `resample` centred -> staggered (buoyancy),
-`fluid.make_incompressible` (incl. obstacles, pressure output), `fluid.apply_boundary_conditions`, field arithmetic.
-Not yet: `advect.mac_cormack`, `diffuse.explicit` (raise in backward).
+`advect.mac_cormack` (staggered + centred; a clamped sample passes its gradient to the extremal tap), `diffuse.explicit`
+(staggered + centred), `fluid.make_incompressible` (incl. obstacles, pressure output), `fluid.apply_boundary_conditions`, field
+arithmetic.
 """
 from typing import Callable, List, Sequence
 
@@ -80,6 +81,101 @@ class SemiLagrangianCentered(torch.autograd.Function):
         be.ctx.advect_centered_backward(meta['grid'], s.data_ptr(), meta['s_codes'], meta['s_val'], _ptrs(v), g.data_ptr(), meta['dt'],
                                         gs.data_ptr(), _ptrs(gv), be.stream())
         return (None, gs, *gv)
+
+
+class MacCormackStaggered(torch.autograd.Function):
+    """ out = mac_cormack(field, velocity, dt, strength); inputs like SemiLagrangianStaggered """
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        D = len(tensors) // 2
+        f, v = [t.contiguous() for t in tensors[:D]], [t.contiguous() for t in tensors[D:]]
+        out = [torch.empty_like(t) for t in f]
+        meta['be'].ctx.mac_cormack_staggered(meta['grid'], _ptrs(f), _ptrs(v), _ptrs(out), meta['dt'], meta['strength'], meta['be'].stream())
+        ctx.meta = meta
+        ctx.save_for_backward(*f, *v)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta = ctx.meta
+        saved = ctx.saved_tensors
+        D = len(saved) // 2
+        f, v = list(saved[:D]), list(saved[D:])
+        g = [_contig(gi, fi) for gi, fi in zip(grads, f)]
+        gf = [torch.zeros_like(t) for t in f]
+        gv = [torch.zeros_like(t) for t in v]
+        meta['be'].ctx.mac_cormack_staggered_backward(meta['grid'], _ptrs(f), _ptrs(v), _ptrs(g), meta['dt'], meta['strength'], _ptrs(gf), _ptrs(gv),
+                                                      meta['be'].stream())
+        return (None, *gf, *gv)
+
+
+class MacCormackCentered(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, s, *vel):
+        s = s.contiguous()
+        v = [t.contiguous() for t in vel]
+        out = torch.empty_like(s)
+        be = meta['be']
+        be.ctx.mac_cormack_centered(meta['grid'], s.data_ptr(), meta['s_codes'], meta['s_val'], _ptrs(v), out.data_ptr(), meta['dt'],
+                                    meta['strength'], be.stream())
+        ctx.meta = meta
+        ctx.save_for_backward(s, *v)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        meta = ctx.meta
+        s, *v = ctx.saved_tensors
+        be = meta['be']
+        g = _contig(grad, s)
+        gs = torch.zeros_like(s)
+        gv = [torch.zeros_like(t) for t in v]
+        be.ctx.mac_cormack_centered_backward(meta['grid'], s.data_ptr(), meta['s_codes'], meta['s_val'], _ptrs(v), g.data_ptr(), meta['dt'],
+                                             meta['strength'], gs.data_ptr(), _ptrs(gv), be.stream())
+        return (None, gs, *gv)
+
+
+class DiffuseStaggered(torch.autograd.Function):
+    """ one explicit diffusion sub-step of a staggered field: out = v + k dt laplace(v) """
+
+    @staticmethod
+    def forward(ctx, meta, *vel):
+        v = [t.contiguous() for t in vel]
+        out = [torch.empty_like(t) for t in v]
+        meta['be'].ctx.diffuse_explicit(meta['grid'], _ptrs(v), _ptrs(out), meta['kdt'], meta['be'].stream())
+        ctx.meta = meta
+        ctx.shapes = [tuple(t.shape) for t in v]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta = ctx.meta
+        be = meta['be']
+        g = [gi.contiguous() if gi is not None else be.zeros(shape, meta['dtype']) for gi, shape in zip(grads, ctx.shapes)]
+        gin = [torch.zeros_like(t) for t in g]
+        be.ctx.diffuse_explicit_backward(meta['grid'], _ptrs(g), _ptrs(gin), meta['kdt'], be.stream())
+        return (None, *gin)
+
+
+class DiffuseCentered(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, s):
+        s = s.contiguous()
+        out = torch.empty_like(s)
+        be = meta['be']
+        be.ctx.diffuse_explicit_centered(meta['grid'], s.data_ptr(), meta['s_codes'], meta['s_val'], out.data_ptr(), meta['kdt'], False, be.stream())
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        meta = ctx.meta
+        be = meta['be']
+        g = grad.contiguous()
+        gin = torch.zeros_like(g)
+        be.ctx.diffuse_explicit_centered(meta['grid'], g.data_ptr(), meta['s_codes'], meta['s_val'], gin.data_ptr(), meta['kdt'], True, be.stream())
+        return None, gin
 
 
 class CenteredToStaggered(torch.autograd.Function):

@@ -191,6 +191,94 @@ __global__ __launch_bounds__(kBlock) void c2s_bwd_kernel(VelGrid g, ScalarBc sb,
     }
 }
 
+// min / max over the taps with the offset of the extremal tap (-1: a constant boundary value, no gradient)
+template <typename T, int DIM>
+__device__ __forceinline__ void gather_minmax_arg(const T* __restrict__ F, const AxisPair<T> (&ax)[3], T& lo, T& hi, int& off_lo, int& off_hi) {
+#pragma unroll
+    for (int corner = 0; corner < (1 << DIM); ++corner) {
+        const int b0 = DIM == 3 ? (corner & 1) : 0;
+        const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
+        const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
+        T val;
+        int off = -1;
+        if (ax[2].cst[b2]) val = ax[2].cv[b2];
+        else if (ax[1].cst[b1]) val = ax[1].cv[b1];
+        else if (DIM == 3 && ax[0].cst[b0]) val = ax[0].cv[b0];
+        else {
+            off = (DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2];
+            val = F[off];
+        }
+        if (corner == 0 || val < lo) { lo = val; off_lo = off; }
+        if (corner == 0 || val > hi) { hi = val; off_hi = off; }
+    }
+}
+
+// Adjoint of the MacCormack correction pass (advect.hip MODE 1):  out = clip(fwd + ch (s - fwd(x + dt u)), lo, hi).
+// Accumulates into g_fwd (gradient of the semi-Lagrangian intermediate; a following semi-Lagrangian backward pass takes it
+// to the field and the velocity), g_field (own value / the extremal tap when clamped) and g_velocity (forward lookup).
+// STAG: staggered component CA (limiter lookup in the cell frame like the forward pass); else centred scalar.
+template <typename T, int DIM, int CA, bool STAG>
+__global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield,
+                                                                 CComp3a<T> vel, const T* __restrict__ fwd, const T* __restrict__ gout,
+                                                                 T* __restrict__ gfwd, T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel,
+                                                                 T dt, T ch) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+    const int b = blockIdx.y;
+    const int total = STAG ? (int)g.ccells[ca] : (int)g.cells;
+    const int n[3] = {STAG ? g.cn[ca][0] : g.n[0], STAG ? g.cn[ca][1] : g.n[1], STAG ? g.cn[ca][2] : g.n[2]};
+    const T* __restrict__ F = (STAG ? field.p[ca] : sfield) + (long long)b * total;
+    const T* __restrict__ W = fwd + (long long)b * total;
+    T* __restrict__ GW = gfwd + (long long)b * total;
+    T* __restrict__ GF = gfield + (long long)b * total;
+    int bc[3][2];
+    T cv[3][2];
+    if (STAG) comp_rule<T>(g, ca, bc, cv); else scalar_rule<T>(sb, bc, cv);
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        if (STAG) face_velocity<T, DIM, CA>(g, vel, b, idx, f, u); else center_velocity<T, DIM>(g, vel, b, idx, u);
+        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int a = A0; a < 3; ++a) {
+            const T sft = dt * u[a] / (T)g.dx[a];
+            cb_[a] = (T)idx[a] - sft;
+            cf_[a] = (T)idx[a] + sft;
+        }
+        AxisPair<T> ax[3];
+        T fr[3];
+        lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+        const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
+        const T nv = W[f] + ch * (F[f] - bwd);
+        AxisPair<T> axl[3];
+        T frl[3];
+        if (STAG) cb_[ca] += (T)g.off[ca] - T(0.5);
+        lookup_pairs<T, DIM>(cb_, n, bc, cv, axl, frl);
+        T lo, hi;
+        int off_lo, off_hi;
+        gather_minmax_arg<T, DIM>(F, axl, lo, hi, off_lo, off_hi);
+        if (nv < lo) {
+            if (off_lo >= 0) atomicAdd(GF + off_lo, go);
+        } else if (nv > hi) {
+            if (off_hi >= 0) atomicAdd(GF + off_hi, go);
+        } else {
+            atomicAdd(GW + f, go);
+            atomicAdd(GF + f, ch * go);
+            const T gb = -ch * go;
+            T dfr[3];
+            gather_adjoint<T, DIM>(W, GW, ax, fr, gb, dfr);
+            if (want_gvel) {
+                T du[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt / (T)g.dx[a]);   // cf_a = idx_a + dt u_a / dx_a
+                if (STAG) face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du); else center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
+            }
+        }
+    }
+}
+
 static inline int bwd_blocks(long long total) {
     const long long nb = (total + kBlock - 1) / kBlock;
     return (int)(nb < 65536 ? nb : 65536);
@@ -266,6 +354,106 @@ int run_centered_to_staggered_bwd(phihip_ctx* ctx, const GridView& v, const int3
             hipLaunchKernelGGL(c2s_bwd_kernel<float>, dim3(bwd_blocks(v.ccells[ca]), v.batch), dim3(kBlock), 0, s, g, sb, ca, (const float*)gout[ca],
                                (float*)gs, (float)vector[ca]);
     }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
+int run_advect_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2], const void* const v[3],
+                        void* out, double dt, hipStream_t);
+
+template <typename T, int DIM>
+static void launch_mc_staggered_bwd(const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3], void* const fwd[3],
+                                    const void* const gout[3], void* const gfwd[3], void* const gf[3], void* const gv[3], double dt, double ch,
+                                    hipStream_t s) {
+    CComp3a<T> ff{{(const T*)f[0], (const T*)f[1], (const T*)f[2]}};
+    CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
+    ScalarBc sb;
+    memset(&sb, 0, sizeof(sb));
+    const int want = gv ? 1 : 0;
+    if (DIM == 3)
+        hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 0, true>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                           (const T*)nullptr, vv, (const T*)fwd[0], (const T*)gout[0], (T*)gfwd[0], (T*)gf[0], gg, want, (T)dt, (T)ch);
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 1, true>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                       (const T*)nullptr, vv, (const T*)fwd[1], (const T*)gout[1], (T*)gfwd[1], (T*)gf[1], gg, want, (T)dt, (T)ch);
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, true>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                       (const T*)nullptr, vv, (const T*)fwd[2], (const T*)gout[2], (T*)gfwd[2], (T*)gf[2], gg, want, (T)dt, (T)ch);
+}
+
+// scratch layout for the MacCormack adjoints: [fwd | g_fwd] per component, 256-byte aligned
+static int mc_scratch(phihip_ctx* ctx, const GridView& v, bool staggered, void* fwd[3], void* gfwd[3]) {
+    const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
+    size_t offs[3] = {0, 0, 0}, total = 0;
+    for (int ca = staggered ? v.ax0 : 2; ca < 3; ++ca) {
+        offs[ca] = total;
+        total += (((size_t)v.batch * (staggered ? v.ccells[ca] : v.cells) * esize + 255) / 256) * 256;
+    }
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adv, 2 * total));
+    fwd[0] = fwd[1] = fwd[2] = gfwd[0] = gfwd[1] = gfwd[2] = nullptr;
+    for (int ca = staggered ? v.ax0 : 2; ca < 3; ++ca) {
+        fwd[ca] = (char*)ctx->ws_adv.ptr + offs[ca];
+        gfwd[ca] = (char*)ctx->ws_adv.ptr + total + offs[ca];
+    }
+    return PHIHIP_OK;
+}
+
+int run_mac_cormack_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3],
+                                  const void* const gout[3], void* const gf[3], void* const gv[3], double dt, double strength, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    void *fwd[3], *gfwd[3];
+    PHIHIP_TRY(mc_scratch(ctx, v, true, fwd, gfwd));
+    PHIHIP_TRY(run_advect_staggered(ctx, v, f, vel, fwd, dt, s));                                // recompute the forward intermediate
+    const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
+    for (int ca = v.ax0; ca < 3; ++ca) PHIHIP_CHECK_HIP(hipMemsetAsync(gfwd[ca], 0, (size_t)v.batch * v.ccells[ca] * esize, s));
+    {
+        LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+        if (v.dtype == PHIHIP_F64) {
+            if (v.rank == 3) launch_mc_staggered_bwd<double, 3>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+            else launch_mc_staggered_bwd<double, 2>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+        } else {
+            if (v.rank == 3) launch_mc_staggered_bwd<float, 3>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+            else launch_mc_staggered_bwd<float, 2>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+        }
+    }
+    const void* cg[3] = {gfwd[0], gfwd[1], gfwd[2]};
+    PHIHIP_TRY(run_advect_staggered_bwd(ctx, v, f, vel, cg, gf, gv, dt, s));                     // g_fwd -> field, velocity
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+template <typename T, int DIM>
+static void launch_mc_centered_bwd(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
+                                   const void* fwd, const void* gout, void* gfwd, void* gs, void* const gv[3], double dt, double ch,
+                                   hipStream_t s) {
+    CComp3a<T> none{{nullptr, nullptr, nullptr}};
+    CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, none,
+                       (const T*)sfield, vv, (const T*)fwd, (const T*)gout, (T*)gfwd, (T*)gs, gg, gv ? 1 : 0, (T)dt, (T)ch);
+}
+
+int run_mac_cormack_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
+                                 const void* const vel[3], const void* gout, void* gs, void* const gv[3], double dt, double strength,
+                                 hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    void *fwd[3], *gfwd[3];
+    PHIHIP_TRY(mc_scratch(ctx, v, false, fwd, gfwd));
+    PHIHIP_TRY(run_advect_centered(ctx, v, sfield, s_bc, s_val, vel, fwd[2], dt, s));
+    const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
+    PHIHIP_CHECK_HIP(hipMemsetAsync(gfwd[2], 0, (size_t)v.batch * v.cells * esize, s));
+    {
+        LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+        if (v.dtype == PHIHIP_F64) {
+            if (v.rank == 3) launch_mc_centered_bwd<double, 3>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+            else launch_mc_centered_bwd<double, 2>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+        } else {
+            if (v.rank == 3) launch_mc_centered_bwd<float, 3>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+            else launch_mc_centered_bwd<float, 2>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+        }
+    }
+    PHIHIP_TRY(run_advect_centered_bwd(ctx, v, sfield, s_bc, s_val, vel, gfwd[2], gs, gv, dt, s));
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }

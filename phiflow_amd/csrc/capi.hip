@@ -461,6 +461,60 @@ int phihip_advect_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, co
     return run_advect_centered_bwd(ctx, v, sfield, s_bc, s_val, u, grad_out, grad_s, grad_velocity ? gu : nullptr, dt, s);
 }
 
+int phihip_mac_cormack_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3], const void* const velocity[3],
+                                          const void* const grad_out[3], double dt, double correction_strength, void* const grad_field[3],
+                                          void* const grad_velocity[3], void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, field, "field"));
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, grad_out, "grad_out"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_field, "grad_field"));
+    if (grad_velocity) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_velocity, "grad_velocity"));
+    const void *f[3], *u[3], *go[3];
+    void *gf[3], *gu[3];
+    remap3(v, field, f);
+    remap3(v, velocity, u);
+    remap3(v, grad_out, go);
+    remap3w(v, grad_field, gf);
+    remap3w(v, grad_velocity, gu);
+    return run_mac_cormack_staggered_bwd(ctx, v, f, u, go, gf, grad_velocity ? gu : nullptr, dt, correction_strength, s);
+}
+
+int phihip_mac_cormack_centered_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                                         const double s_val[3][2], const void* const velocity[3], const void* grad_out, double dt,
+                                         double correction_strength, void* grad_s, void* const grad_velocity[3], void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && grad_out && s_bc && grad_s, "mac_cormack_centered_backward: NULL argument");
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "mac_cormack_centered_backward"));
+    if (grad_velocity) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_velocity, "grad_velocity"));
+    const void* u[3];
+    void* gu[3];
+    remap3(v, velocity, u);
+    remap3w(v, grad_velocity, gu);
+    return run_mac_cormack_centered_bwd(ctx, v, sfield, s_bc, s_val, u, grad_out, grad_s, grad_velocity ? gu : nullptr, dt, correction_strength, s);
+}
+
+int phihip_diffuse_explicit_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* const grad_out[3], void* const grad_in[3],
+                                     double diffusivity_dt, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, grad_out, "grad_out"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_in, "grad_in"));
+    const void* go[3];
+    void* gi[3];
+    remap3(v, grad_out, go);
+    remap3w(v, grad_in, gi);
+    return run_diffuse_bwd(ctx, v, go, gi, diffusivity_dt, s);
+}
+
+int phihip_diffuse_explicit_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2],
+                                     const double s_val[3][2], void* out, double diffusivity_dt, int adjoint, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && out && s_bc && sfield != out, "diffuse_explicit_centered: NULL or aliased argument");
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "diffuse_explicit_centered"));
+    return run_diffuse_centered(ctx, v, sfield, s_bc, s_val, out, diffusivity_dt, adjoint, s);
+}
+
 int phihip_centered_to_staggered_backward(phihip_ctx* ctx, const phihip_grid* grid, const int32_t s_bc[3][2], const double vector[3],
                                           const void* const grad_out[3], void* grad_s, void* stream) {
     PHIHIP_ENTER(ctx, grid);

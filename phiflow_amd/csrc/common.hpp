@@ -151,6 +151,13 @@ int run_advect_centered_bwd(phihip_ctx*, const GridView&, const void* s, const i
                             const void* const v[3], const void* gout, void* gs, void* const gv[3], double dt, hipStream_t);
 int run_centered_to_staggered_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double vector[3], const void* const gout[3],
                                   void* gs, hipStream_t);
+int run_mac_cormack_staggered_bwd(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], const void* const gout[3],
+                                  void* const gf[3], void* const gv[3], double dt, double strength, hipStream_t);
+int run_mac_cormack_centered_bwd(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
+                                 const void* const v[3], const void* gout, void* gs, void* const gv[3], double dt, double strength, hipStream_t);
+int run_diffuse_bwd(phihip_ctx*, const GridView&, const void* const gout[3], void* const gin[3], double kdt, hipStream_t);
+int run_diffuse_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2], void* out, double kdt,
+                         int adjoint, hipStream_t);
 int run_project_bwd(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, int balance, void* const gv[3], const void* gp,
                     const phihip_solve*, phihip_solve_info*, hipStream_t);
 int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);

@@ -647,6 +647,59 @@ __global__ __launch_bounds__(kBlock) void diffuse_kernel(VelGrid g, int ca, cons
     }
 }
 
+// offset of the sample fetch_comp would read, or -1 when the extrapolation supplies a constant there
+__device__ __forceinline__ long long fetch_comp_offset(const VelGrid& g, int ca, int i0, int i1, int i2) {
+    int idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int ax = 2; ax >= 0; --ax) {
+        if (ax < g.ax0) { idx[ax] = 0; continue; }
+        const int n = g.cn[ca][ax];
+        int i = idx[ax];
+        if (i < 0) {
+            const int code = g.bc[ax][0];
+            if (code == PHIHIP_BC_PERIODIC) { i %= n; if (i < 0) i += n; }
+            else if (code == PHIHIP_BC_CLOSED) return -1;
+            else i = 0;
+        } else if (i >= n) {
+            const int code = g.bc[ax][1];
+            if (code == PHIHIP_BC_PERIODIC) i %= n;
+            else if (code == PHIHIP_BC_CLOSED) return -1;
+            else i = n - 1;
+        }
+        idx[ax] = i;
+    }
+    return ((long long)idx[0] * g.cn[ca][1] + idx[1]) * g.cn[ca][2] + idx[2];
+}
+
+// adjoint of diffuse_kernel: gin += (I + k dt L)^T gout   (scatter; clamped / wrapped taps add to their source sample)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void diffuse_bwd_kernel(VelGrid g, int ca, const T* __restrict__ gout, T* __restrict__ gin, T kdt) {
+    const int b = blockIdx.y;
+    const long long total = g.ccells[ca];
+    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const long long bb = (long long)b * total;
+    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
+        const int i2 = (int)(f % c2);
+        const int i1 = (int)((f / c2) % c1);
+        const int i0 = (int)(f / ((long long)c2 * c1));
+        const T go = gout[bb + f];
+        T centre = T(1);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            if (ax < g.ax0) continue;
+            const T w = kdt / (T)(g.dx[ax] * g.dx[ax]);
+            centre -= T(2) * w;
+            int lo[3] = {i0, i1, i2}, hi[3] = {i0, i1, i2};
+            lo[ax] -= 1; hi[ax] += 1;
+            const long long ol = fetch_comp_offset(g, ca, lo[0], lo[1], lo[2]);
+            const long long oh = fetch_comp_offset(g, ca, hi[0], hi[1], hi[2]);
+            if (ol >= 0) atomicAdd(gin + bb + ol, go * w);
+            if (oh >= 0) atomicAdd(gin + bb + oh, go * w);
+        }
+        atomicAdd(gin + bb + f, go * centre);
+    }
+}
+
 int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
@@ -658,6 +711,53 @@ int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], vo
         else
             hipLaunchKernelGGL(diffuse_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const float*)vin[ca],
                                (float*)vout[ca], (float)kdt);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_diffuse_bwd(phihip_ctx* ctx, const GridView& v, const void* const gout[3], void* const gin[3], double kdt, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
+        if (v.dtype == PHIHIP_F64)
+            hipLaunchKernelGGL(diffuse_bwd_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const double*)gout[ca], (double*)gin[ca], kdt);
+        else
+            hipLaunchKernelGGL(diffuse_bwd_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const float*)gout[ca], (float*)gin[ca], (float)kdt);
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// a centred scalar with its own extrapolation viewed as "component 2" of a layout whose stored shape is the cell grid
+static VelGrid scalar_as_component(const GridView& v, const ScalarBc& sb) {
+    VelGrid g = make_velgrid(v);
+    for (int a = 0; a < 3; ++a) {
+        g.cn[2][a] = v.n[a];
+        for (int side = 0; side < 2; ++side) {
+            g.bc[a][side] = a < v.ax0 ? PHIHIP_BC_PERIODIC : sb.bc[a][side];
+            g.bcv[a][side][2] = sb.val[a][side];
+        }
+    }
+    g.ccells[2] = v.cells;
+    g.off[2] = 0;
+    return g;
+}
+
+// diffuse.explicit on a CenteredGrid (direction 1 = forward: out = s + k dt laplace(s); -1 = adjoint: gin += (...)^T gout)
+int run_diffuse_centered(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2], void* out,
+                         double kdt, int adjoint, hipStream_t s) {
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    const VelGrid g = scalar_as_component(v, sb);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    const int nblk = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    if (v.dtype == PHIHIP_F64) {
+        if (adjoint) hipLaunchKernelGGL(diffuse_bwd_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const double*)sfield, (double*)out, kdt);
+        else hipLaunchKernelGGL(diffuse_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const double*)sfield, (double*)out, kdt);
+    } else {
+        if (adjoint) hipLaunchKernelGGL(diffuse_bwd_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const float*)sfield, (float*)out, (float)kdt);
+        else hipLaunchKernelGGL(diffuse_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const float*)sfield, (float*)out, (float)kdt);
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

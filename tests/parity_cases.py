@@ -333,6 +333,64 @@ def check_advect_backward(ctx, mem, dom, grid, rng, s_codes, s_consts, dt=0.7):
     assert abs(lin - float(np.vdot(mem.to_host(gs), d))) <= 1e-10 * max(abs(lin), 1.0)
 
 
+def check_mac_cormack_and_diffuse_backward(ctx, mem, dom, grid, rng, s_codes, s_consts, dt=0.7):
+    """ VJPs of MacCormack advection (centred + staggered; piecewise smooth: clamp + min / max) and of explicit diffusion, and
+    the centred diffusion forward pass, against the oracle """
+    dtype = np.float64
+    B, D = grid.batch, dom.rank
+    P = lambda hs: [mem.ptr(h) for h in hs]
+    v = random_velocity(dom, B, dtype, rng)
+    g = random_velocity(dom, B, dtype, rng)
+    dv, dg = [mem.to_dev(a) for a in v], [mem.to_dev(a) for a in g]
+    # staggered self-advection
+    gf = [mem.to_dev(np.zeros_like(a)) for a in v]
+    gv = [mem.to_dev(np.zeros_like(a)) for a in v]
+    ctx.mac_cormack_staggered_backward(grid, P(dv), P(dv), P(dg), dt, 1.0, P(gf), P(gv))
+    mem.sync()
+    grad = [mem.to_host(a) + mem.to_host(b) for a, b in zip(gf, gv)]
+    loss = lambda x: _dot(g, O.mac_cormack_staggered(x, x, dt, dom, 1.0))
+    ok = 0
+    for _ in range(5):
+        d = random_velocity(dom, B, dtype, rng)
+        fd, an = _fd(loss, v, d, eps=1e-7), _dot(grad, d)
+        ok += abs(fd - an) <= 1e-4 * max(abs(fd), abs(an), 1.0)
+    assert ok >= 4, "mac_cormack_staggered_backward disagrees with finite differences"     # a kink may sit inside one FD stencil
+    # centred scalar
+    s = rng.standard_normal((B,) + dom.res)
+    gs_up = rng.standard_normal((B,) + dom.res)
+    ds, dgo = mem.to_dev(s), mem.to_dev(gs_up)
+    gs, gv = mem.to_dev(np.zeros_like(s)), [mem.to_dev(np.zeros_like(a)) for a in v]
+    ctx.mac_cormack_centered_backward(grid, mem.ptr(ds), s_codes, s_consts, P(dv), mem.ptr(dgo), dt, 0.8, mem.ptr(gs), P(gv))
+    mem.sync()
+    loss_sv = lambda xs: float(np.vdot(gs_up, O.mac_cormack_centered(xs[0], xs[1:], dt, dom, s_codes, s_consts, 0.8)))
+    ok = 0
+    for _ in range(5):
+        d = [rng.standard_normal(s.shape)] + random_velocity(dom, B, dtype, rng)
+        fd = _fd(loss_sv, [s] + v, d, eps=1e-7)
+        an = _dot([mem.to_host(gs)] + [mem.to_host(a) for a in gv], d)
+        ok += abs(fd - an) <= 1e-4 * max(abs(fd), abs(an), 1.0)
+    assert ok >= 4, "mac_cormack_centered_backward disagrees with finite differences"
+    # explicit diffusion: staggered adjoint (linear: exact) and the centred forward + adjoint
+    kdt = 0.1
+    gin = [mem.to_dev(np.zeros_like(a)) for a in v]
+    ctx.diffuse_explicit_backward(grid, P(dg), P(gin), kdt)
+    mem.sync()
+    d = random_velocity(dom, B, dtype, rng)
+    zero_dom = O.Domain(dom.res, dom.lower, dom.upper, dom.bc, np.zeros_like(dom.bc_val))      # constants carry no gradient
+    lin = _dot(g, O.diffuse_explicit(d, kdt, 1.0, zero_dom))
+    assert abs(lin - _dot([mem.to_host(a) for a in gin], d)) <= 1e-10 * max(abs(lin), 1.0)
+    dout = mem.empty(s.shape, dtype)
+    ctx.diffuse_explicit_centered(grid, mem.ptr(ds), s_codes, s_consts, mem.ptr(dout), kdt)
+    mem.sync()
+    assert rel_err(mem.to_host(dout), O.diffuse_explicit_centered(s, kdt, 1.0, dom, s_codes, s_consts)) <= 1e-12
+    gin_s = mem.to_dev(np.zeros_like(s))
+    ctx.diffuse_explicit_centered(grid, mem.ptr(dgo), s_codes, s_consts, mem.ptr(gin_s), kdt, adjoint=True)
+    mem.sync()
+    d = rng.standard_normal(s.shape)
+    lin = float(np.vdot(gs_up, O.diffuse_explicit_centered(d, kdt, 1.0, dom, s_codes, [(0.0, 0.0)] * D)))
+    assert abs(lin - float(np.vdot(mem.to_host(gin_s), d))) <= 1e-10 * max(abs(lin), 1.0)
+
+
 def check_project_backward(ctx, mem, dom, grid, rng, obstacles=()):
     """ VJP of make_incompressible (velocity and pressure cotangents) against the oracle's forward: the map is affine, so the
     directional derivative is the difference of two oracle projections. """

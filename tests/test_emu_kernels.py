@@ -74,6 +74,7 @@ def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
     s_consts = [(0.0, 0.25)] * len(res)
     pc.check_advect_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
     pc.check_project_backward(emu_ctx, MEM, dom, grid, rng)
+    pc.check_mac_cormack_and_diffuse_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
 
 
 def test_adjoint_projection_with_obstacles(emu_ctx):

@@ -288,7 +288,45 @@ def test_functional_gradient_through_a_fluid_step(emu_backend):
         g_v, g_s = sim_grad(*mk(v_vals, s_vals))
         loss_np = lambda arrs: float(simulate(*mk(arrs[:2], arrs[2]))[0])
         _fd_gradient_check(loss_np, v_vals + [s_vals], g_v.numpy() + [g_s.numpy()], rng, eps=1e-6, tol=1e-4)
-        # ops without an adjoint kernel refuse to differentiate instead of returning wrong gradients
-        bad = functional_gradient(lambda v: l2_loss(advect.mac_cormack(v, v, 1.0)), wrt=[0], get_output=False)
-        with pytest.raises(NotImplementedError):
-            bad(mk(v_vals, s_vals)[0])
+
+
+def test_colab_tutorial_functional_gradient(emu_backend, full=False):
+    """ tests/commit/test_colab_fluids_tutorial.py:11-34 (batch of 4 inflow locations, MacCormack smoke, buoyancy, self-advection,
+    projection, loss = l2(diffuse.explicit(smoke - stop_gradient(target)))) with `functional_gradient(simulate, wrt=[0])`; the
+    gradient w.r.t. the initial velocity is checked against finite differences in fp64. """
+    from phiflow_amd.flow import functional_gradient, l2_loss, precision, resample, stop_gradient
+    rng = np.random.default_rng(22)
+    with precision(64):
+        bounds = Box(x=32, y=40)
+        n = dict(x=16, y=20)
+        locs = [(4., 5), (8., 5), (12., 5), (16., 5)] if full else [(4., 5), (12., 5)]     # the emulated CPU run keeps it short
+        nb, steps = len(locs), (3 if full else 2)
+        inflow_vals = np.stack([0.6 * CenteredGrid(Sphere(x=x, y=y, radius=3), BOUNDARY, bounds, backend=emu_backend, **n).numpy() for x, y in locs])
+        inflow = CenteredGrid(inflow_vals, BOUNDARY, bounds, backend=emu_backend, **n)
+        solve = Solve('CG', 1e-12, 0)
+
+        frozen_target = []     # the finite differences must see the same constant target as the stop_gradient'ed run
+
+        def simulate(velocity, smoke):
+            for _ in range(steps):
+                smoke = advect.mac_cormack(smoke, velocity, dt=1) + inflow
+                buoyancy_force = smoke * (0, 0.5) @ velocity
+                velocity = advect.semi_lagrangian(velocity, velocity, dt=1) + buoyancy_force
+                velocity, _ = fluid.make_incompressible(velocity, (), solve)
+            if not frozen_target:
+                frozen_target.append(stop_gradient(smoke).values[-1:].clone())       # smoke.inflow_loc[-1], no gradient
+            diff = smoke.with_values(smoke.values - frozen_target[0])
+            loss = l2_loss(diffuse.explicit(diff, 1, 1, 10))
+            return loss, smoke, velocity
+
+        shapes = StaggeredGrid(0, 0, bounds, backend=emu_backend, **n).component_shapes
+        v_vals = [0.2 * rng.standard_normal((nb,) + s) for s in shapes]
+        smoke0 = np.zeros((nb, 16, 20))
+        mk = lambda vs: (StaggeredGrid(vs, 0, bounds, backend=emu_backend, **n), CenteredGrid(smoke0, BOUNDARY, bounds, backend=emu_backend, **n))
+        sim_grad = functional_gradient(simulate, wrt=[0], get_output=False)
+        velocity_grad, = sim_grad(*mk(v_vals))
+        assert velocity_grad.is_staggered and velocity_grad.batch_size == nb
+        loss_np = lambda arrs: float(simulate(*mk(arrs))[0].sum())
+        _fd_gradient_check(loss_np, v_vals, velocity_grad.numpy(), rng, eps=1e-6, tol=5e-4, n_dirs=2)
+        v1 = mk(v_vals)[0] - 0.01 * velocity_grad            # the tutorial's gradient-descent update
+        assert float(simulate(v1, mk(v_vals)[1])[0].sum()) < float(simulate(*mk(v_vals))[0].sum())
