@@ -222,6 +222,29 @@ int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid
                                         int balance, void* const grad_velocity[3], const void* grad_pressure,
                                         const phihip_solve* solve, phihip_solve_info* info, void* stream);
 
+/* ---- f4: ONE simulation decomposed into slabs along x over several ranks (no reference counterpart) -------
+ * Each rank calls these phases on its slab (`grid` = the LOCAL slab: res[0] = local planes, bounds = the slab's box); the host
+ * layer (phiflow_amd/slab.py) exchanges the boundary planes with the neighbour ranks into `*_lo` / `*_hi` (one plane
+ * [batch][y][z] each, used where halo_lo / halo_hi != 0 -- otherwise the grid's own boundary rule applies on that side) and
+ * all-reduces the per-batch sums between the phases (`sums` are DEVICE doubles).
+ *   residual: r = rhs - A x ; sums[0..batch) = local sum r^2, sums[batch..2 batch) = local sum rhs^2
+ *   matvec  : d_new = r + beta d_old, beta from the GLOBAL sums_in (first: sums_in = {sum r^2, sum rhs^2} of the residual phase,
+ *             afterwards the global sum r^2 of the last update); sum_out[batch] = local d_new . A d_new
+ *   update  : x += alpha d ; r -= alpha A d, alpha from the GLOBAL sum_in = d . A d ; sum_out[batch] = local sum r^2
+ *             (x_only: the true-residual refresh iteration, follow with residual(keep_going = 1))
+ *   state   : folds the last global sum r^2 into the control block and reports it (synchronises); peek != 0 leaves the chain
+ *             untouched; info[b].reserved = 1 while entry b would keep iterating */
+int phihip_slab_residual(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags, const void* x,
+                         const void* x_lo, const void* x_hi, const void* rhs, void* r, double* sums, int keep_going, void* stream);
+int phihip_slab_matvec(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags, int first,
+                       const double* sums_in, const void* r, const void* r_lo, const void* r_hi, const void* d_old,
+                       const void* d_lo, const void* d_hi, void* d_new, double* sum_out, const phihip_solve* solve, void* stream);
+int phihip_slab_update(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags,
+                       const double* sum_in, const void* d, const void* d_lo, const void* d_hi, void* x, void* r, double* sum_out,
+                       int x_only, const phihip_solve* solve, void* stream);
+int phihip_slab_state(phihip_ctx* ctx, const phihip_grid* grid, int first, const double* sums_in, const phihip_solve* solve,
+                      phihip_solve_info* info, int peek, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------------------------ */
 /* Kernel families timed with hipEvent pairs on the solve stream while profiling is enabled. */
 typedef enum phihip_kernel_id {

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
+    "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state",
 )
 
 
@@ -123,7 +124,8 @@ def make_grid(rank: int, dtype: int, batch: int, res, lower, upper, bc, bc_val=N
 class Library:
     """ typed function table of one loaded libphihip """
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, strict: bool = True):
+        """ strict=False (benchmark A/B of an older build only): symbols missing from the library are skipped """
         self.path = os.path.abspath(path)
         try:
             self.dll = ctypes.CDLL(self.path)
@@ -131,6 +133,13 @@ class Library:
             raise PhiHipLibraryError(f"cannot load {self.path}: {exc}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                      f"(hipcc --offload-arch=gfx950); there is no CPU fallback.") from exc
         missing = [s for s in EXPORTED_SYMBOLS if not hasattr(self.dll, s)]
+        if missing and not strict:
+            class _Skip:
+                argtypes = None
+                restype = None
+            for name in missing:
+                setattr(self.dll, name, _Skip())
+            missing = []
         if missing:
             raise PhiHipLibraryError(f"{self.path} lacks symbols declared in include/phihip.h: {missing}")
         d = self.dll
@@ -165,6 +174,13 @@ class Library:
         d.phihip_diffuse_explicit_backward.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
         d.phihip_diffuse_explicit_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
                                                        c_void_p, c_double, c_int, c_void_p]
+        d.phihip_slab_residual.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_void_p]
+        d.phihip_slab_matvec.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Solve), c_void_p]
+        d.phihip_slab_update.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, POINTER(Solve), c_void_p]
+        d.phihip_slab_state.argtypes = [c_void_p, POINTER(Grid), c_int, c_void_p, POINTER(Solve), POINTER(SolveInfo), c_int, c_void_p]
         d.phihip_make_incompressible_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_int, POINTER(_Ptr3), c_void_p,
                                                           POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_build_cellflags.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_void_p, c_int, c_void_p, c_void_p]
@@ -303,6 +319,27 @@ class Context:
             self.handle, ctypes.byref(grid), flags or None, int(mask_batch), int(bool(balance)), ctypes.byref(ptr3(grad_velocity)),
             grad_pressure or None, ctypes.byref(solve), info, stream or None))
         return list(info) if want_info else None
+
+    # ---- f4: slab-decomposed CG phases (see include/phihip.h) ----
+    def slab_residual(self, grid, halo, flags, x, x_halo, rhs, r, sums, keep_going=False, stream=0):
+        self.lib.check(self.lib.dll.phihip_slab_residual(self.handle, ctypes.byref(grid), int(halo[0]), int(halo[1]), flags or None, x,
+                                                         x_halo[0] or None, x_halo[1] or None, rhs, r, sums, int(bool(keep_going)), stream or None))
+
+    def slab_matvec(self, grid, halo, flags, first, sums_in, r, r_halo, d_old, d_halo, d_new, sum_out, solve: Solve, stream=0):
+        self.lib.check(self.lib.dll.phihip_slab_matvec(self.handle, ctypes.byref(grid), int(halo[0]), int(halo[1]), flags or None, int(bool(first)),
+                                                       sums_in, r, r_halo[0] or None, r_halo[1] or None, d_old, d_halo[0] or None,
+                                                       d_halo[1] or None, d_new, sum_out, ctypes.byref(solve), stream or None))
+
+    def slab_update(self, grid, halo, flags, sum_in, d, d_halo, x, r, sum_out, solve: Solve, x_only=False, stream=0):
+        self.lib.check(self.lib.dll.phihip_slab_update(self.handle, ctypes.byref(grid), int(halo[0]), int(halo[1]), flags or None, sum_in, d,
+                                                       d_halo[0] or None, d_halo[1] or None, x, r or None, sum_out or None, int(bool(x_only)),
+                                                       ctypes.byref(solve), stream or None))
+
+    def slab_state(self, grid, first, sums_in, solve: Solve, peek=False, stream=0):
+        info = (SolveInfo * grid.batch)()
+        self.lib.check(self.lib.dll.phihip_slab_state(self.handle, ctypes.byref(grid), int(bool(first)), sums_in, ctypes.byref(solve), info,
+                                                      int(bool(peek)), stream or None))
+        return list(info)
 
     def obstacle_accessible(self, grid, obstacles, count, accessible, stream=0):
         self.lib.check(self.lib.dll.phihip_obstacle_accessible(self.handle, ctypes.byref(grid), obstacles, int(count), accessible, stream or None))

@@ -381,6 +381,63 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
     return run_cg(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
 }
 
+// ---- f4: slab-decomposed CG phases -----------------------------------------------------------------------------------
+static int slab_view(const phihip_grid* grid, int halo_lo, int halo_hi, GridView* v) {
+    PHIHIP_TRY(make_view(grid, v));
+    PHIHIP_REQUIRE(v->rank == 3, "slab decomposition is implemented for 3-D grids (slabs along x)");
+    v->halo[0] = halo_lo != 0;
+    v->halo[1] = halo_hi != 0;
+    return PHIHIP_OK;
+}
+
+int phihip_slab_residual(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags, const void* x,
+                         const void* x_lo, const void* x_hi, const void* rhs, void* r, double* sums, int keep_going, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    GridView v;
+    PHIHIP_TRY(slab_view(grid, halo_lo, halo_hi, &v));
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIHIP_REQUIRE(x && rhs && r && sums, "slab_residual: NULL argument");
+    PHIHIP_REQUIRE((!halo_lo || x_lo) && (!halo_hi || x_hi), "slab_residual: halo plane missing");
+    return run_slab_residual(ctx, v, flags, 1, x, x_lo, x_hi, rhs, r, sums, keep_going, (hipStream_t)stream);
+}
+
+int phihip_slab_matvec(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags, int first,
+                       const double* sums_in, const void* r, const void* r_lo, const void* r_hi, const void* d_old, const void* d_lo,
+                       const void* d_hi, void* d_new, double* sum_out, const phihip_solve* solve, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    GridView v;
+    PHIHIP_TRY(slab_view(grid, halo_lo, halo_hi, &v));
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIHIP_REQUIRE(sums_in && r && d_old && d_new && sum_out && d_old != d_new, "slab_matvec: NULL or aliased argument");
+    PHIHIP_REQUIRE((!halo_lo || (r_lo && d_lo)) && (!halo_hi || (r_hi && d_hi)), "slab_matvec: halo plane missing");
+    PHIHIP_TRY(check_solve(solve));
+    return run_slab_matvec(ctx, v, flags, 1, first, sums_in, r, r_lo, r_hi, d_old, d_lo, d_hi, d_new, sum_out, solve, (hipStream_t)stream);
+}
+
+int phihip_slab_update(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, int halo_hi, const uint8_t* flags, const double* sum_in,
+                       const void* d, const void* d_lo, const void* d_hi, void* x, void* r, double* sum_out, int x_only,
+                       const phihip_solve* solve, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    GridView v;
+    PHIHIP_TRY(slab_view(grid, halo_lo, halo_hi, &v));
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIHIP_REQUIRE(sum_in && d && x && (x_only || (r && sum_out)), "slab_update: NULL argument");
+    PHIHIP_REQUIRE(x_only || ((!halo_lo || d_lo) && (!halo_hi || d_hi)), "slab_update: halo plane missing");
+    PHIHIP_TRY(check_solve(solve));
+    return run_slab_update(ctx, v, flags, 1, sum_in, d, d_lo, d_hi, x, r, sum_out, x_only, solve, (hipStream_t)stream);
+}
+
+int phihip_slab_state(phihip_ctx* ctx, const phihip_grid* grid, int first, const double* sums_in, const phihip_solve* solve,
+                      phihip_solve_info* info, int peek, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    GridView v;
+    PHIHIP_TRY(make_view(grid, &v));
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    PHIHIP_REQUIRE(sums_in != nullptr, "slab_state: sums_in is NULL");
+    PHIHIP_TRY(check_solve(solve));
+    return run_slab_finish(ctx, v, first, sums_in, solve, info, peek, (hipStream_t)stream);
+}
+
 int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void* stream) {
     PHIHIP_REQUIRE(ctx != nullptr && out_device != nullptr && batch >= 1, "solve_residuals: bad argument");
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));

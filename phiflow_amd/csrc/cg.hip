@@ -328,6 +328,193 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     return PHIHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Slab-decomposed CG: ONE simulation split along a0 over several ranks. Each rank runs the same kernels on its
+// slab; planes across a slab boundary come from halo buffers (NB_HALO) that the host layer fills by exchanging boundary planes
+// with the neighbouring ranks, and every dot product is completed by an all-reduce between the phases: the kernels write
+// per-workgroup partials, `sum_partials_kernel` folds them into one double per batch entry (the all-reduce operand), and the
+// next kernel's prologue reads the GLOBAL sum as a single "partial" (nblk_in = 1). The control block logic is unchanged.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sum_partials_kernel(const double* part, int nblk, double* out) {
+    __shared__ double red[kBlock / kWave];
+    const double s = reduce_partials(part + (long long)blockIdx.x * nblk, nblk, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+struct SlabSetup {
+    MarchConfig c;
+    MarchGrid g;
+    double* part1;
+    double* part2;
+    CgState* st[2];
+};
+
+static int slab_setup(phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, SlabSetup* out) {
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags, family, &out->c, &out->g));
+    for (int side = 0; side < 2; ++side)
+        if (v.halo[side]) out->g.nb[0][side] = NB_HALO;
+    const size_t part_n = (size_t)v.batch * out->g.nblk;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * ((part_n + 8191) / 8192 * 8192 + 8192) * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)3 * v.batch * sizeof(CgState)));
+    out->part1 = (double*)ctx->ws_part.ptr;
+    out->part2 = out->part1 + part_n;
+    out->st[0] = (CgState*)ctx->ws_state.ptr;
+    out->st[1] = out->st[0] + v.batch;
+    return PHIHIP_OK;
+}
+
+template <typename T>
+static MarchArgs<T> slab_args(const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
+    MarchArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.flags = flags;
+    if (solve) { a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; }
+    a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    return a;
+}
+
+// r = rhs - A x ; sums[0..batch) = local sum r^2, sums[batch..2 batch) = local sum rhs^2.  keep_going != 0: skip frozen entries
+// (true-residual refresh inside the loop; the control block of the running solve decides)
+template <typename T>
+static int slab_residual_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* x, const void* x_lo,
+                           const void* x_hi, const void* rhs, void* r, double* sums, int keep_going, hipStream_t s) {
+    SlabSetup su;
+    PHIHIP_TRY(slab_setup(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &su));
+    MarchArgs<T> a = slab_args<T>(v, flags, nullptr);
+    a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = (T*)r;
+    a.a_lo = (const T*)x_lo; a.a_hi = (const T*)x_hi;
+    a.part1 = su.part1; a.part2 = su.part2;
+    a.prologue = keep_going ? PRO_CONT : PRO_NONE;
+    a.st_in = su.st[ctx->slab_cur];
+    {
+        LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
+        PHIHIP_TRY(launch_march_any<T>(v, su.c, MODE_RESID, flags != nullptr, su.g, a, s));
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)su.part1, su.g.nblk, sums);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)su.part2, su.g.nblk, sums + v.batch);
+    if (!keep_going) ctx->slab_cur = 0;
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// d_new = r + beta d_old (beta from the GLOBAL sums_in) ; sum_out = local d_new . A d_new
+template <typename T>
+static int slab_matvec_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, int first, const double* sums_in,
+                         const void* r, const void* r_lo, const void* r_hi, const void* d_old, const void* d_lo, const void* d_hi,
+                         void* d_new, double* sum_out, const phihip_solve* solve, hipStream_t s) {
+    SlabSetup su;
+    PHIHIP_TRY(slab_setup(ctx, v, mask_batch, flags != nullptr, FAM_MATVEC, &su));
+    MarchArgs<T> a = slab_args<T>(v, flags, solve);
+    a.a = (const T*)r; a.b = (const T*)d_old; a.o1 = (T*)d_new;
+    a.a_lo = (const T*)r_lo; a.a_hi = (const T*)r_hi; a.b_lo = (const T*)d_lo; a.b_hi = (const T*)d_hi;
+    a.part1 = su.part1;
+    a.prologue = first ? PRO_FIRST : PRO_BETA;
+    a.pin1 = sums_in; a.pin2 = sums_in + v.batch; a.nblk_in = 1;
+    a.st_in = su.st[ctx->slab_cur]; a.st_out = su.st[ctx->slab_cur ^ 1];
+    {
+        LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
+        PHIHIP_TRY(launch_march_any<T>(v, su.c, MODE_MATVEC, flags != nullptr, su.g, a, s));
+    }
+    ctx->slab_cur ^= 1;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)su.part1, su.g.nblk, sum_out);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// x += alpha d ; r -= alpha A d (alpha from the GLOBAL sum_in = d . A d) ; sum_out = local sum r^2.   x_only: the true-residual
+// refresh iteration (PhiML every 50th): only x is advanced, the caller recomputes r = rhs - A x afterwards
+template <typename T>
+static int slab_update_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const double* sum_in, const void* d,
+                         const void* d_lo, const void* d_hi, void* x, void* r, double* sum_out, int x_only, const phihip_solve* solve,
+                         hipStream_t s) {
+    SlabSetup su;
+    PHIHIP_TRY(slab_setup(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE, &su));
+    CgParams prm;
+    prm.rtol = solve->rel_tol; prm.atol = solve->abs_tol; prm.max_iter = solve->max_iterations; prm.pad = 0;
+    if (x_only) {
+        const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d, (const CgState*)su.st[ctx->slab_cur],
+                           su.st[ctx->slab_cur ^ 1], sum_in, 1, prm, v.cells);
+        ctx->slab_cur ^= 1;
+        PHIHIP_CHECK_HIP(hipGetLastError());
+        return PHIHIP_OK;
+    }
+    MarchArgs<T> a = slab_args<T>(v, flags, solve);
+    a.a = (const T*)d; a.o1 = (T*)x; a.o2 = (T*)r;
+    a.a_lo = (const T*)d_lo; a.a_hi = (const T*)d_hi;
+    a.part1 = su.part1;
+    a.prologue = PRO_ALPHA;
+    a.pin1 = sum_in; a.nblk_in = 1;
+    a.st_in = su.st[ctx->slab_cur]; a.st_out = su.st[ctx->slab_cur ^ 1];
+    {
+        LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
+        PHIHIP_TRY(launch_march_any<T>(v, su.c, MODE_UPDATE, flags != nullptr, su.g, a, s));
+    }
+    ctx->slab_cur ^= 1;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)su.part1, su.g.nblk, sum_out);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_slab_residual(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* x, const void* x_lo, const void* x_hi,
+                      const void* rhs, void* r, double* sums, int keep_going, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? slab_residual_t<double>(ctx, v, flags, mask_batch, x, x_lo, x_hi, rhs, r, sums, keep_going, s)
+                                 : slab_residual_t<float>(ctx, v, flags, mask_batch, x, x_lo, x_hi, rhs, r, sums, keep_going, s);
+}
+
+int run_slab_matvec(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, int first, const double* sums_in, const void* r,
+                    const void* r_lo, const void* r_hi, const void* d_old, const void* d_lo, const void* d_hi, void* d_new, double* sum_out,
+                    const phihip_solve* solve, hipStream_t s) {
+    return v.dtype == PHIHIP_F64
+               ? slab_matvec_t<double>(ctx, v, flags, mask_batch, first, sums_in, r, r_lo, r_hi, d_old, d_lo, d_hi, d_new, sum_out, solve, s)
+               : slab_matvec_t<float>(ctx, v, flags, mask_batch, first, sums_in, r, r_lo, r_hi, d_old, d_lo, d_hi, d_new, sum_out, solve, s);
+}
+
+int run_slab_update(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const double* sum_in, const void* d, const void* d_lo,
+                    const void* d_hi, void* x, void* r, double* sum_out, int x_only, const phihip_solve* solve, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? slab_update_t<double>(ctx, v, flags, mask_batch, sum_in, d, d_lo, d_hi, x, r, sum_out, x_only, solve, s)
+                                 : slab_update_t<float>(ctx, v, flags, mask_batch, sum_in, d, d_lo, d_hi, x, r, sum_out, x_only, solve, s);
+}
+
+// folds the last GLOBAL residual sum into the control block and reports it (synchronises the stream)
+int run_slab_finish(phihip_ctx* ctx, const GridView& v, int first, const double* sums_in, const phihip_solve* solve, phihip_solve_info* info,
+                    int peek, hipStream_t s) {
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)3 * v.batch * sizeof(CgState)));
+    CgState* st[3] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch, (CgState*)ctx->ws_state.ptr + 2 * v.batch};
+    CgParams prm;
+    prm.rtol = solve->rel_tol; prm.atol = solve->abs_tol; prm.max_iter = solve->max_iterations; prm.pad = 0;
+    // peek: the decision the next MATVEC prologue will take, written to a third slot so that the chain does not advance
+    const int dst = peek ? 2 : (ctx->slab_cur ^ 1);
+    hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : PRO_BETA), (const CgState*)st[ctx->slab_cur],
+                       st[dst], sums_in, sums_in + v.batch, 1, prm);
+    if (!peek) {
+        ctx->slab_cur ^= 1;
+        ctx->last_state = st[ctx->slab_cur];
+        ctx->last_state_batch = v.batch;
+    }
+    if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
+        if (ctx->host_state) (void)hipHostFree(ctx->host_state);
+        ctx->host_state = nullptr;
+        ctx->host_state_bytes = 0;
+        PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));
+        ctx->host_state_bytes = (size_t)v.batch * sizeof(CgState);
+    }
+    CgState* hst = (CgState*)ctx->host_state;
+    PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st[peek ? 2 : ctx->slab_cur], (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+    PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+    if (info)
+        for (int b = 0; b < v.batch; ++b) {
+            info[b].residual_sq = hst[b].rsq;
+            info[b].rhs_sq = hst[b].rhs_sq;
+            info[b].iterations = hst[b].iterations;
+            info[b].converged = hst[b].converged;
+            info[b].diverged = hst[b].diverged;
+            info[b].reserved = hst[b].cont;   // 1: the entry would keep iterating (used by the host loop to stop early)
+        }
+    return PHIHIP_OK;
+}
+
 int run_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
            const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
     return v.dtype == PHIHIP_F64 ? cg_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, info, s)

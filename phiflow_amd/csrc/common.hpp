@@ -50,6 +50,7 @@ struct GridView {
     int off[3];                // physical face number of stored index 0 per component
     long long cells;           // n0*n1*n2
     long long ccells[3];       // cells per stored component
+    int halo[2];               // slab decomposition: planes beyond the lower / upper a0 side come from a neighbour rank
 };
 
 int make_view(const phihip_grid* grid, GridView* out);
@@ -94,6 +95,7 @@ struct phihip_ctx {
     phihip::Tuning tuning[3];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adj_q, ws_adj_l;
+    int slab_cur = 0;             // control-block slot of the running slab-decomposed solve
     void* last_state = nullptr;   // device control blocks of the most recent solve
     int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
@@ -160,6 +162,14 @@ int run_diffuse_centered(phihip_ctx*, const GridView&, const void* s, const int3
                          int adjoint, hipStream_t);
 int run_project_bwd(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, int balance, void* const gv[3], const void* gp,
                     const phihip_solve*, phihip_solve_info*, hipStream_t);
+int run_slab_residual(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* x, const void* x_lo, const void* x_hi,
+                      const void* rhs, void* r, double* sums, int keep_going, hipStream_t);
+int run_slab_matvec(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, int first, const double* sums_in, const void* r,
+                    const void* r_lo, const void* r_hi, const void* d_old, const void* d_lo, const void* d_hi, void* d_new, double* sum_out,
+                    const phihip_solve*, hipStream_t);
+int run_slab_update(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const double* sum_in, const void* d, const void* d_lo,
+                    const void* d_hi, void* x, void* r, double* sum_out, int x_only, const phihip_solve*, hipStream_t);
+int run_slab_finish(phihip_ctx*, const GridView&, int first, const double* sums_in, const phihip_solve*, phihip_solve_info*, int peek, hipStream_t);
 int run_build_cellflags(phihip_ctx*, const GridView&, const uint8_t* accessible, const uint8_t* active, int mask_batch, uint8_t* flags, hipStream_t);
 int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const uint8_t* flags, int mask_batch, int balance, void* div, hipStream_t);
 int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);

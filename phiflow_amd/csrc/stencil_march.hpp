@@ -22,7 +22,8 @@ namespace phihip {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
-enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2 };
+enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
+                                                                            // neighbour slab's halo buffer (MarchArgs::a_lo ...)
 enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3 };
 
 // Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
@@ -104,6 +105,10 @@ struct MarchArgs {
     int prologue;          // CgPrologue
     int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
     T w0, w1, w2;          // 1 / dx^2 per internal axis
+    // slab decomposition along a0: one plane [batch][n1][n2] of the source array(s) below plane 0 / above plane
+    // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
+    const T* a_lo; const T* a_hi;
+    const T* b_lo; const T* b_hi;
 };
 
 template <typename T, int V>
@@ -251,13 +256,34 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     };
     auto load_plane = [&](int i, VT (&S)[R]) {
         bool zero = false;
-        const int ii = DIM3 ? nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero) : 0;
+        const T* pa = p.a + base;
+        const T* pb = MODE == MODE_MATVEC ? p.b + base : nullptr;
+        int ii = 0;
+        if (DIM3) {
+            if (i < 0 && g.nb[0][0] == NB_HALO) {
+                pa = p.a_lo + (long long)b * n1 * n2;
+                if (MODE == MODE_MATVEC) pb = p.b_lo + (long long)b * n1 * n2;
+            } else if (i >= g.n0 && g.nb[0][1] == NB_HALO) {
+                pa = p.a_hi + (long long)b * n1 * n2;
+                if (MODE == MODE_MATVEC) pb = p.b_hi + (long long)b * n1 * n2;
+            } else {
+                ii = nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero);
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (ok[rr] && !zero)
-                S[rr] = src_vec(((long long)ii * n1 + (j1b + rr)) * n2 + j2);
-            else
+            if (ok[rr] && !zero) {
+                const long long off = ((long long)ii * n1 + (j1b + rr)) * n2 + j2;
+                VT sv = vec_load<T, V>(pa + off);
+                if (MODE == MODE_MATVEC) {
+                    const VT d = vec_load<T, V>(pb + off);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) sv.v[v] = fma(beta, d.v[v], sv.v[v]);
+                }
+                S[rr] = sv;
+            } else {
                 S[rr] = vec_zero<T, V>();
+            }
         }
     };
 

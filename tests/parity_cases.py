@@ -439,6 +439,39 @@ def check_project_backward(ctx, mem, dom, grid, rng, obstacles=()):
         assert abs(lin - an) <= 1e-7 * max(abs(lin), abs(an), 1.0), f"make_incompressible_backward: oracle {lin} vs adjoint {an}"
 
 
+def check_slab_halo_planes(ctx, mem, dom, dtype, rng, parts=3):
+    """ the NB_HALO path of the marching kernels -- the residual phase on x-slabs with the neighbours' boundary
+    planes as halos must equal the residual of the undivided grid (oracle operator) """
+    B = 2
+    x = rng.standard_normal((B,) + dom.res).astype(dtype)
+    rhs = rng.standard_normal((B,) + dom.res).astype(dtype)
+    ref = rhs - O.masked_laplace(x, dom)
+    n0 = dom.res[0]
+    cuts = [round(k * n0 / parts) for k in range(parts + 1)]
+    periodic = dom.bc[0][0] == PER
+    dxs = dom.dx
+    code = C.PHIHIP_F64 if np.dtype(dtype) == np.float64 else C.PHIHIP_F32
+    for k in range(parts):
+        b0, b1 = cuts[k], cuts[k + 1]
+        lo_exists = k > 0 or periodic
+        hi_exists = k < parts - 1 or periodic
+        g = C.make_grid(3, code, B, (b1 - b0,) + dom.res[1:], (dom.lower[0] + b0 * dxs[0],) + dom.lower[1:],
+                        (dom.lower[0] + b1 * dxs[0],) + dom.upper[1:], dom.bc, dom.bc_val)
+        dx_, drhs = mem.to_dev(x[:, b0:b1]), mem.to_dev(rhs[:, b0:b1])
+        lo = mem.to_dev(x[:, (b0 - 1) % n0]) if lo_exists else None
+        hi = mem.to_dev(x[:, b1 % n0]) if hi_exists else None
+        dr = mem.empty((B, b1 - b0) + dom.res[1:], dtype)
+        dsums = mem.empty((2 * B,), np.float64)
+        ctx.slab_residual(g, (lo_exists, hi_exists), 0, mem.ptr(dx_), (mem.ptr(lo) if lo is not None else 0, mem.ptr(hi) if hi is not None else 0),
+                          mem.ptr(drhs), mem.ptr(dr), mem.ptr(dsums))
+        mem.sync()
+        err = rel_err(mem.to_host(dr), ref[:, b0:b1])
+        assert err <= tol(dtype)['stencil'] * 4, f"slab {k}: residual rel err {err}"
+        sums = mem.to_host(dsums)
+        np.testing.assert_allclose(sums[:B], (ref[:, b0:b1].astype(np.float64) ** 2).sum(axis=(1, 2, 3)), rtol=1e-4)
+        np.testing.assert_allclose(sums[B:], (rhs[:, b0:b1].astype(np.float64) ** 2).sum(axis=(1, 2, 3)), rtol=1e-4)
+
+
 def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)

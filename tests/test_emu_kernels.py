@@ -85,6 +85,14 @@ def test_adjoint_projection_with_obstacles(emu_ctx):
     pc.check_project_backward(emu_ctx, MEM, dom, grid, rng, obstacles=[pc.O.SphereObstacle((8.0, 9.0), 3.5)])
 
 
+@pytest.mark.parametrize("res,bc", GRIDS_3D)
+def test_slab_halo_planes(emu_ctx, res, bc):
+    rng = np.random.default_rng(16)
+    for dtype in (np.float32, np.float64):
+        dom, _ = pc.make_case(res, bc, dtype, batch=1)
+        pc.check_slab_halo_planes(emu_ctx, MEM, dom, dtype, rng, parts=2 if res[0] < 9 else 3)
+
+
 def test_advection_with_wall_velocity(emu_ctx):
     """ lid-driven cavity boundary: tangential wall velocity on one side (Lid_Driven_Cavity.ipynb cell 5) """
     rng = np.random.default_rng(3)

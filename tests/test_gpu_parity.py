@@ -114,6 +114,14 @@ def test_adjoint_projection_with_obstacles(ctx, mem):
     pc.check_project_backward(ctx, mem, dom, grid, rng, obstacles=[pc.O.SphereObstacle((8.0, 9.0), 3.5)])
 
 
+@pytest.mark.parametrize("res,bc", GRIDS[6:])
+def test_slab_halo_planes(ctx, mem, res, bc):
+    rng = np.random.default_rng(16)
+    for dtype in (np.float32, np.float64):
+        dom, _ = pc.make_case(res, bc, dtype, batch=1)
+        pc.check_slab_halo_planes(ctx, mem, dom, dtype, rng, parts=2 if res[0] < 9 else 3)
+
+
 def test_reference_known_answer_self_advection(ctx, mem):
     """ /root/reference tests/commit/physics/test_advect.py:41-45 -- the only stored known answer on the path """
     dom, grid = pc.make_case((4, 3), ((CLO, CLO), (CLO, CLO)), np.float32)

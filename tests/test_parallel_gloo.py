@@ -1,7 +1,8 @@
 """
-N > 1 path on CPU: two processes (gloo) shard a batch of independent simulations, run the projection on their shard through
+N > 1 paths on CPU. (1) Two processes (gloo) shard a batch of independent simulations, run the projection on their shard through
 the C ABI (kernel sources under the fiber emulation -- test infrastructure) and perform the step's single all-reduce of the
-residual norm. The sharded results must equal the unsharded run bit for bit.
+residual norm. The sharded results must equal the unsharded run bit for bit. (2) Two processes split ONE simulation into
+x-slabs: halo-plane exchange + two scalar all-reduces per CG iteration reproduce the single-process solve.
 """
 import os
 import socket
@@ -74,3 +75,77 @@ def test_batch_sharding_world2_gloo(emu_library, emu_backend, tmp_path):
         rels.append(float(d["rel"][0]))
     assert rels[0] == rels[1] == pytest.approx(rel_full, rel=1e-12)      # the all-reduce delivered the global maximum
     assert 0 < rel_full <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ONE simulation decomposed into x-slabs over the ranks (halo-plane exchange + 2 scalar all-reduces per iteration)
+# ---------------------------------------------------------------------------------------------------------------------
+SLAB_CASES = {
+    "periodic": dict(res=(12, 8, 16), bc=((0, 0), (0, 0), (0, 0))),              # both slab sides are halos on every rank (wrap)
+    "closed_open": dict(res=(11, 8, 16), bc=((1, 2), (1, 1), (0, 0))),            # uneven split (6 + 5), wall / open ends on x
+}
+
+
+def _slab_problem(case, dtype=np.float32, batch=2):
+    rng = np.random.default_rng(3)
+    res, bc = SLAB_CASES[case]["res"], SLAB_CASES[case]["bc"]
+    rhs = rng.standard_normal((batch,) + res).astype(dtype)
+    if all(c != 2 for pair in bc for c in pair):          # singular (no open side): consistent right-hand side
+        rhs -= rhs.mean(axis=(1, 2, 3), keepdims=True)
+    return res, bc, rhs
+
+
+def _slab_worker(rank, world, port, emu_path, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phiflow_amd import _capi
+    from phiflow_amd.backend import HipBackend
+    from phiflow_amd.slab import SlabSolver
+    backend = HipBackend(library=_capi.Library(emu_path), device="cpu")
+    res, bc, rhs = _slab_problem(case)
+    solver = SlabSolver(backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=rhs.shape[0])
+    b0, b1 = solver.begin, solver.end
+    x = torch.zeros((rhs.shape[0], b1 - b0) + res[1:], dtype=torch.float32)
+    infos = solver.solve(torch.from_numpy(np.ascontiguousarray(rhs[:, b0:b1])), x, rel_tol=1e-5, max_iterations=60, refresh_every=7, check_every=5)
+    np.savez(os.path.join(out_dir, f"slab{rank}.npz"), x=x.numpy(), b0=b0, b1=b1, it=[i.iterations for i in infos],
+             conv=[i.converged for i in infos], rsq=[i.residual_sq for i in infos])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", list(SLAB_CASES))
+def test_slab_decomposed_cg_world2_gloo(emu_library, emu_ctx, tmp_path, case):
+    """ two ranks, each with half of the x planes, must reproduce the single-process solve (same iteration count; the dot
+    products are summed in a different order, so values agree to rounding) """
+    from phiflow_amd import _capi as C
+    world = 2
+    mp.spawn(_slab_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
+    res, bc, rhs = _slab_problem(case)
+    grid = C.make_grid(3, C.PHIHIP_F32, rhs.shape[0], res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    x_ref = np.zeros_like(rhs)
+    info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x_ref.ctypes.data, C.Solve(1e-5, 0.0, 60, 7, 5, 0))
+    parts = [np.load(tmp_path / f"slab{r}.npz") for r in range(world)]
+    assert [int(p["b0"]) for p in parts] == [0, int(parts[0]["b1"])] and int(parts[1]["b1"]) == res[0]
+    x = np.concatenate([p["x"] for p in parts], axis=1)
+    assert list(parts[0]["it"]) == list(parts[1]["it"])                     # both ranks took the same (global) decisions
+    # the dot products are summed in a different order: an entry may cross the tolerance one iteration earlier or later
+    assert all(abs(int(a) - i.iterations) <= 1 for a, i in zip(parts[0]["it"], info))
+    assert list(parts[0]["conv"]) == [i.converged for i in info]
+    scale = np.abs(x_ref).max()
+    assert np.abs(x - x_ref).max() <= 2e-4 * scale, np.abs(x - x_ref).max() / scale
+
+
+def test_slab_solver_single_rank_equals_cg(emu_backend, emu_ctx):
+    """ world size 1: the slab phases are the ordinary CG (no halos) """
+    from phiflow_amd import _capi as C
+    from phiflow_amd.slab import SlabSolver
+    res, bc, rhs = _slab_problem("closed_open")
+    solver = SlabSolver(emu_backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=rhs.shape[0])
+    x = torch.zeros(rhs.shape, dtype=torch.float32)
+    infos = solver.solve(torch.from_numpy(rhs.copy()), x, rel_tol=1e-5, max_iterations=200)
+    grid = C.make_grid(3, C.PHIHIP_F32, rhs.shape[0], res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    x_ref = np.zeros_like(rhs)
+    info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x_ref.ctypes.data, C.Solve(1e-5, 0.0, 200, 50, 10, 0))
+    assert [i.iterations for i in infos] == [i.iterations for i in info] and all(i.converged for i in infos)
+    assert np.abs(x.numpy() - x_ref).max() <= 1e-6 * np.abs(x_ref).max()

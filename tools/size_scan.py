@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    ctx = C.Context(C.Library(args.lib) if args.lib else C.load_default_library(), 0)
+    ctx = C.Context(C.Library(args.lib, strict=False) if args.lib else C.load_default_library(), 0)
     L = 2 * math.pi
     for n in [int(v) for v in args.sizes.split(",")]:
         grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)

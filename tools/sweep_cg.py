@@ -28,7 +28,7 @@ def main():
     args = ap.parse_args()
     n = args.size
     dev = torch.device("cuda:0")
-    lib = C.Library(args.lib) if args.lib else C.load_default_library()
+    lib = C.Library(args.lib, strict=False) if args.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
