@@ -13,7 +13,7 @@ import torch
 
 from . import _capi, autodiff
 from .extrapolation import pressure_extrapolation
-from .field import Field, _check_pressure_padding, _ptrs, _sample_points
+from .field import Field, _check_pressure_padding, _ptrs
 from .geom import Box, Geometry, Sphere
 from .solve import Diverged, NotConverged, Solve, SolveInfo
 

@@ -162,10 +162,3 @@ class Sphere(Geometry):
 
     def __repr__(self):
         return f"Sphere({dict(zip(self.dims, self.center))}, radius={self.radius})"
-
-
-def union_lies_inside(geometries: Sequence[Geometry], points) -> np.ndarray:
-    inside = np.zeros(points[0].shape, dtype=bool)
-    for g in geometries:
-        inside |= g.lies_inside(points)
-    return inside

@@ -299,3 +299,68 @@ def test_fp64_cavity_with_obstacle_small(ctx, mem):
     dom, grid = pc.make_case((24, 24, 24), ((CLO, CLO),) * 3, np.float64, batch=1, bc_val=bcv, upper=(1.0, 1.0, 1.0))
     obstacles = [pc.O.BoxObstacle((0.4, 0.4, 0.4), (0.6, 0.6, 0.6))]
     pc.check_make_incompressible(ctx, mem, dom, grid, np.float64, rng, obstacles=obstacles, max_div=1e-7)
+
+
+def test_full_size_advection_is_exact_translation(ctx, mem):
+    """ 256^3 fp32 periodic, unit cells, constant velocity of whole cells per step: the semi-Lagrangian lookup lands on grid
+    points, so both advection schemes must reproduce a cyclic shift of the field bit for bit (size-independent property) """
+    import torch
+    n = 256
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32)          # bounds [0, n]^3 -> dx = 1
+    g = torch.Generator(device='cpu').manual_seed(1)
+    field = [torch.randn(1, n, n, n, generator=g).to(mem.device) for _ in range(3)]
+    shift = (2.0, -1.0, 3.0)
+    vel = [torch.full((1, n, n, n), s, device=mem.device) for s in shift]
+    out = [torch.empty_like(t) for t in field]
+    P = lambda ts: [t.data_ptr() for t in ts]
+    ctx.advect_staggered(grid, P(field), P(vel), P(out), 1.0)
+    mem.sync()
+    for f, o in zip(field, out):
+        assert torch.equal(o, torch.roll(f, shifts=(2, -1, 3), dims=(1, 2, 3)))
+    ctx.mac_cormack_staggered(grid, P(field), P(vel), P(out), 1.0, 1.0)
+    mem.sync()
+    for f, o in zip(field, out):
+        assert torch.equal(o, torch.roll(f, shifts=(2, -1, 3), dims=(1, 2, 3)))
+    s = torch.randn(1, n, n, n, generator=g).to(mem.device)
+    so = torch.empty_like(s)
+    ctx.mac_cormack_centered(grid, s.data_ptr(), ((0, 0),) * 3, None, P(vel), so.data_ptr(), 1.0, 1.0)
+    mem.sync()
+    assert torch.equal(so, torch.roll(s, shifts=(2, -1, 3), dims=(1, 2, 3)))
+
+
+def test_full_size_cavity_fp64_with_obstacle(ctx, mem):
+    """ BASELINE configs[4] at full size: 384^3 fp64 closed box with a moving lid and a solid box. After the projection the
+    discrete divergence vanishes on every fluid cell, no face of the solid carries flow, and applying the projection twice
+    changes nothing (idempotence). """
+    import torch
+    n = 384
+    bcv = np.zeros((3, 2, 3)); bcv[2, 1, 0] = 1.0
+    dom, grid = pc.make_case((n, n, n), ((CLO, CLO),) * 3, np.float64, bc_val=bcv, upper=(1.0, 1.0, 1.0))
+    obstacle = pc.C.make_obstacles([dict(kind=pc.C.OBSTACLE_BOX, center=(0.5, 0.5, 0.5), half_size=(0.125, 0.125, 0.125))])
+    g1 = pc.C.make_grid(3, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    acc = torch.empty(n, n, n, dtype=torch.uint8, device=mem.device)
+    flags = torch.empty_like(acc)
+    ctx.obstacle_accessible(g1, obstacle, 1, acc.data_ptr())
+    ctx.build_cellflags(g1, acc.data_ptr(), 0, 1, flags.data_ptr())
+    lo, hi = int(0.375 * n), int(0.625 * n)
+    assert int((acc == 0).sum()) == (hi - lo) ** 3
+    gen = torch.Generator(device='cpu').manual_seed(2)
+    v = [(0.05 * torch.randn((1,) + dom.comp_shape(d), generator=gen, dtype=torch.float64)).to(mem.device) for d in range(3)]
+    P = lambda ts: [t.data_ptr() for t in ts]
+    ctx.apply_obstacles(grid, obstacle, 1, P(v))
+    p = torch.zeros(1, n, n, n, dtype=torch.float64, device=mem.device)
+    div = torch.empty_like(p)
+    solve = pc.C.Solve(1e-9, 0.0, 4000, 50, 50, 0)
+    info = ctx.make_incompressible(grid, P(v), None, flags.data_ptr(), 1, True, p.data_ptr(), div.data_ptr(), solve)
+    assert info[0].converged, (info[0].iterations, info[0].residual_sq, info[0].rhs_sq)
+    rhs_scale = float(div.abs().max())
+    ctx.divergence(grid, P(v), flags.data_ptr(), 1, False, div.data_ptr())
+    mem.sync()
+    assert float(div.abs().max()) <= 1e-6 * rhs_scale, (float(div.abs().max()), rhs_scale)
+    assert float(v[0][0, lo:hi - 1, lo:hi, lo:hi].abs().max()) == 0.0          # x-faces strictly inside the solid
+    before = [t.clone() for t in v]
+    p2 = p.clone()
+    info2 = ctx.make_incompressible(grid, P(v), None, flags.data_ptr(), 1, True, p2.data_ptr(), 0, solve)
+    mem.sync()
+    for a, b in zip(before, v):
+        assert float((a - b).abs().max()) <= 1e-7 * 0.05
