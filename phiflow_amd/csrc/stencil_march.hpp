@@ -180,12 +180,13 @@ __device__ __forceinline__ double reduce_partials(const double* part, int n, dou
 // Prologue shared by every kernel of the CG loop: returns the advanced control block to all threads of the workgroup.
 __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, CgState* st_out, const double* pin1, const double* pin2,
                                               int nblk, const CgParams& prm, int b, bool writer, double* red, CgState* sh) {
+    // the control block is fetched BEFORE the reductions so that its memory round trip overlaps theirs
+    CgState s = CgState();
+    if (threadIdx.x == 0 && kind != PRO_FIRST) s = st_in[b];
     double s1 = 0, s2 = 0;
     if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
     if (kind == PRO_FIRST) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
     if (threadIdx.x == 0) {
-        CgState s;
-        if (kind == PRO_FIRST) { s = CgState(); } else { s = st_in[b]; }
         s = cg_advance(kind, s, s1, s2, prm);
         *sh = s;
         if (writer && kind >= PRO_FIRST) st_out[b] = s;
@@ -212,12 +213,6 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     T alpha = T(0), beta = T(0);
-    if (p.prologue != PRO_NONE) {
-        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state);
-        if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
-        alpha = (T)S.alpha;
-        beta = (T)S.beta;
-    }
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
@@ -239,22 +234,9 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) ok[rr] = (j2 < n2) && (j1b + rr < n1);
 
-    // ---- source loaders ---------------------------------------------------------------------------------------------
-    auto src_vec = [&](long long off) -> VT {
-        VT s = vec_load<T, V>(p.a + base + off);
-        if (MODE == MODE_MATVEC) {
-            VT d = vec_load<T, V>(p.b + base + off);
-#pragma unroll
-            for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
-        }
-        return s;
-    };
-    auto src_one = [&](long long off) -> T {
-        T s = p.a[base + off];
-        if (MODE == MODE_MATVEC) s = fma(beta, p.b[base + off], s);
-        return s;
-    };
-    auto load_plane = [&](int i, VT (&S)[R]) {
+    // raw operands of a source plane (own cells): pointer selection incl. the slab halos, loads only. The first two planes are
+    // requested BEFORE the prologue's partial-sum reduction so that their HBM latency overlaps it; `combine` applies beta later.
+    auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R]) {
         bool zero = false;
         const T* pa = p.a + base;
         const T* pb = MODE == MODE_MATVEC ? p.b + base : nullptr;
@@ -274,17 +256,56 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         for (int rr = 0; rr < R; ++rr) {
             if (ok[rr] && !zero) {
                 const long long off = ((long long)ii * n1 + (j1b + rr)) * n2 + j2;
-                VT sv = vec_load<T, V>(pa + off);
-                if (MODE == MODE_MATVEC) {
-                    const VT d = vec_load<T, V>(pb + off);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) sv.v[v] = fma(beta, d.v[v], sv.v[v]);
-                }
-                S[rr] = sv;
+                A[rr] = vec_load<T, V>(pa + off);
+                if (MODE == MODE_MATVEC) B[rr] = vec_load<T, V>(pb + off);
             } else {
-                S[rr] = vec_zero<T, V>();
+                A[rr] = vec_zero<T, V>();
+                if (MODE == MODE_MATVEC) B[rr] = vec_zero<T, V>();
             }
         }
+    };
+    VT Ra_p[R], Rb_p[R], Ra_c[R], Rb_c[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = vec_zero<T, V>();
+    if (DIM3) load_raw(i_begin - 1, Ra_p, Rb_p);
+    load_raw(i_begin, Ra_c, Rb_c);
+
+    if (p.prologue != PRO_NONE) {
+        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state);
+        if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
+        alpha = (T)S.alpha;
+        beta = (T)S.beta;
+    }
+    auto combine = [&](const VT (&A)[R], const VT (&B)[R], VT (&S)[R]) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            S[rr] = A[rr];
+            if (MODE == MODE_MATVEC) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) S[rr].v[v] = fma(beta, B[rr].v[v], A[rr].v[v]);
+            }
+        }
+    };
+
+    // ---- source loaders ---------------------------------------------------------------------------------------------
+    auto src_vec = [&](long long off) -> VT {
+        VT s = vec_load<T, V>(p.a + base + off);
+        if (MODE == MODE_MATVEC) {
+            VT d = vec_load<T, V>(p.b + base + off);
+#pragma unroll
+            for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
+        }
+        return s;
+    };
+    auto src_one = [&](long long off) -> T {
+        T s = p.a[base + off];
+        if (MODE == MODE_MATVEC) s = fma(beta, p.b[base + off], s);
+        return s;
+    };
+    auto load_plane = [&](int i, VT (&S)[R]) {
+        VT A[R], B[R];
+        load_raw(i, A, B);
+        combine(A, B, S);
     };
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
@@ -353,8 +374,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         Sp[rr] = vec_zero<T, V>();
         Sn[rr] = vec_zero<T, V>();
     }
-    if (DIM3) load_plane(i_begin - 1, Sp);
-    load_plane(i_begin, Sc);
+    if (DIM3) combine(Ra_p, Rb_p, Sp);
+    combine(Ra_c, Rb_c, Sc);
     load_halo(i_begin, hv_c, hs_c);
     load_extra(i_begin, Ec);
     hv_n = hv_c; hs_n = hs_c; En = Ec;
