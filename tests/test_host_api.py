@@ -330,3 +330,13 @@ def test_colab_tutorial_functional_gradient(emu_backend, full=False):
         _fd_gradient_check(loss_np, v_vals, velocity_grad.numpy(), rng, eps=1e-6, tol=5e-4, n_dirs=2)
         v1 = mk(v_vals)[0] - 0.01 * velocity_grad            # the tutorial's gradient-descent update
         assert float(simulate(v1, mk(v_vals)[1])[0].sum()) < float(simulate(*mk(v_vals))[0].sum())
+
+
+def test_phiml_plugin_is_inert_without_phiml():
+    """ the PhiFlow plug-in glue imports cleanly and reports that it cannot install itself when phiml is absent (it is in this
+    environment: the reference's arithmetic dependency is not installable -- SURVEY fact 3) """
+    from phiflow_amd import phiml_plugin
+    if phiml_plugin.phiml_available():
+        pytest.skip("phiml is installed: the plug-in is exercised by PhiFlow's own tests instead")
+    assert phiml_plugin.install() is False
+    phiml_plugin.uninstall()
