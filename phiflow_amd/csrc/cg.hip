@@ -123,6 +123,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     g->chunks0 = ceil_div(v.n[0], chunk);
     g->chunk = chunk;
     g->nblk = g->tiles1 * g->tiles2 * g->chunks0;
+    // short chunks re-read a large share of source planes (2 / chunk): let neighbouring chunks meet at their common boundary
+    // (256^3 MATVEC with chunk 8: -7 %; at chunk 64 the shared planes are 3 % of the traffic and the reversal only costs)
+    g->bidir = (family == FAM_MATVEC && v.rank == 3 && chunk <= 16 && g->chunks0 > 1) ? 1 : 0;
     return PHIHIP_OK;
 }
 

@@ -15,7 +15,11 @@ constexpr int kVmax = 16 / sizeof(InstT);
 
 template <int V, int R, int TPR, int MODE, bool FLAGS>
 static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3>), grid, dim3(kBlock), 0, s, g, a);
+    // the bidirectional variant exists for 3-D MATVEC only (the phase whose traffic is dominated by the stencil source)
+    if (MODE == MODE_MATVEC && kInstDim3 && g.bidir)
+        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (MODE == MODE_MATVEC && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
+    else
+        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false>), grid, dim3(kBlock), 0, s, g, a);
 }
 
 template <int V, int R, int TPR>

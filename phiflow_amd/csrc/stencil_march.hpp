@@ -86,6 +86,7 @@ struct MarchGrid {
     long long cells;       // n0 * n1 * n2
     int tiles1, tiles2, chunks0, chunk, nblk;
     int flags_per_batch;   // 1: flags array has a batch dimension, 0: shared by all batch entries
+    int bidir;             // 1: launch the BIDIR instantiation: odd chunks march down (short chunks share their boundary planes in time)
 };
 
 template <typename T>
@@ -195,7 +196,7 @@ __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, C
     return *sh;
 }
 
-template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3>
+template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false>
 __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T> p) {
     constexpr int TR = kBlock / TPR;   // thread rows
     constexpr int T1 = TR * R;         // tile rows (axis a1)
@@ -226,6 +227,12 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int j1b = t1 * T1 + ty * R;
     const int i_begin = c0 * g.chunk;
     const int i_end = min(i_begin + g.chunk, g.n0);
+    // Odd chunks march DOWN: two neighbouring chunks of a tile then start at their common boundary, so the two planes they both
+    // need (each other's first plane as halo) are requested at the same time and are served once from HBM (L2 / Infinity Cache
+    // for the second requester) instead of once at the start of one chunk and again at the end of the other.
+    const int step = (DIM3 && BIDIR && (c0 & 1)) ? -1 : 1;   // compile-time +1 unless the BIDIR instantiation (MATVEC, short chunks)
+    const int i_first = step > 0 ? i_begin : i_end - 1;
+    const int count = i_end - i_begin;
     const long long base = (long long)b * g.cells;
     const long long fbase = g.flags_per_batch ? base : 0;
     const int n1 = g.n1, n2 = g.n2;
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     VT Ra_p[R], Rb_p[R], Ra_c[R], Rb_c[R];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = vec_zero<T, V>();
-    if (DIM3) load_raw(i_begin - 1, Ra_p, Rb_p);
-    load_raw(i_begin, Ra_c, Rb_c);
+    if (DIM3) load_raw(i_first - step, Ra_p, Rb_p);   // the plane behind the marching direction
+    load_raw(i_first, Ra_c, Rb_c);
 
     if (p.prologue != PRO_NONE) {
         const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state);
@@ -376,8 +383,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     }
     if (DIM3) combine(Ra_p, Rb_p, Sp);
     combine(Ra_c, Rb_c, Sc);
-    load_halo(i_begin, hv_c, hs_c);
-    load_extra(i_begin, Ec);
+    load_halo(i_first, hv_c, hs_c);
+    load_extra(i_first, Ec);
     hv_n = hv_c; hs_n = hs_c; En = Ec;
 
     T acc1 = T(0), acc2 = T(0);
@@ -385,11 +392,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
     const int lcol = V + tx * V;             // LDS column of this thread's vector
 
-    for (int i = i_begin; i < i_end; ++i) {
-        if (DIM3) load_plane(i + 1, Sn);
-        if (i + 1 < i_end) {
-            load_halo(i + 1, hv_n, hs_n);
-            load_extra(i + 1, En);
+    // Sp = the plane behind, Sn = the plane ahead in marching direction (the a0 stencil is symmetric in them)
+    const unsigned bit_behind = step > 0 ? 1u : 2u, bit_ahead = step > 0 ? 2u : 1u;
+    for (int k = 0, i = i_first; k < count; ++k, i += step) {
+        if (DIM3) load_plane(i + step, Sn);
+        if (k + 1 < count) {
+            load_halo(i + step, hv_n, hs_n);
+            load_extra(i + step, En);
         }
         T* L = lds[buf];
 #pragma unroll
@@ -421,8 +430,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     const unsigned f = Ec.fl[rr].v[v];
                     r = T(0);
                     if (DIM3) {
-                        if (f & 1u) r += (Sp[rr].v[v] - c) * p.w0;
-                        if (f & 2u) r += (Sn[rr].v[v] - c) * p.w0;
+                        if (f & bit_behind) r += (Sp[rr].v[v] - c) * p.w0;
+                        if (f & bit_ahead) r += (Sn[rr].v[v] - c) * p.w0;
                     }
                     if (f & 4u) r += (up.v[v] - c) * p.w1;
                     if (f & 8u) r += (dn.v[v] - c) * p.w1;
