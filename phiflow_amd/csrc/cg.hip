@@ -22,8 +22,7 @@ namespace phihip {
 //     slot efficiency = rounds / ceil(rounds)            (rounds = workgroups * batch / (occupancy(kernel) * CUs) > 1)
 //                     = min(1, workgroups / min(slots, 4 [MATVEC] or 2 [UPDATE, residual] per CU))      (one round)
 //     relative traffic = 1 + (2 / chunk) * (source words / all words)
-// MATVEC takes the first tile of its preference list that scores >= 0.8, UPDATE / residual the best score (x a small bonus
-// for large tiles).
+// and the best score (x a small per-family tile preference) wins.
 int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
     const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const int vmax = 16 / esize;
@@ -73,7 +72,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             const double blocks = tiles * ceil_div(v.n[0], ch);
             const double rounds = blocks / slots;
             const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < wanted ? blocks / wanted : 1.0);
-            const double score = eff / (1.0 + 2.0 / ch * src_share);
+            const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
+            const double score = eff / (1.0 + planes * src_share);
             if (score > best_score * 1.0001) { best_score = score; best = ch; }
         }
         *score_out = best_score;
@@ -94,9 +94,12 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         }
         chunk = best_chunk(id, &score);
     } else {
-        static const int pref_mv[6] = {2, 1, 0, 5, 3, 4}, pref_up[6] = {4, 3, 2, 1, 0, 5};
-        static const double bonus_up[6] = {1.0, 1.0, 0.98, 0.98, 0.97, 0.97};   // large tiles win at equal chunk length (512^3 sweep)
+        // candidate order + a small preference factor per family (from the family sweeps): UPDATE / residual favour large tiles
+        // at equal chunk length, MATVEC medium tiles and the full-row tile (1, 64)
+        static const int pref_mv[6] = {2, 5, 1, 0, 3, 4}, pref_up[6] = {4, 3, 2, 1, 0, 5};
+        static const double bonus_mv[6] = {1.0, 1.0, 0.98, 0.97, 0.93, 0.93}, bonus_up[6] = {1.0, 1.0, 0.98, 0.98, 0.97, 0.97};
         const int* pref = family == FAM_MATVEC ? pref_mv : pref_up;
+        const double* bonus = family == FAM_MATVEC ? bonus_mv : bonus_up;
         double best_score = -1.0;
         for (int k = 0; k < 6; ++k) {
             const int cand = pref[k];
@@ -105,11 +108,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             const double waste = (double)tiles_of(cand) * t1 * t2 / ((double)v.n[1] * v.n[2]);
             double sc;
             const int ch = best_chunk(cand, &sc);
-            sc /= waste;
-            if (family != FAM_MATVEC) sc *= bonus_up[k];
+            sc = sc / waste * bonus[k];
             if (sc > best_score) { best_score = sc; id = cand; chunk = ch; }
-            // MATVEC: the first acceptable tile of the list; UPDATE / residual: the best score (chunk length matters more there)
-            if (family == FAM_MATVEC && sc >= 0.8) break;
         }
     }
     if (v.rank == 3 && t.chunk > 0) chunk = t.chunk < v.n[0] ? t.chunk : v.n[0];
