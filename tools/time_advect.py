@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""
+Times the advection kernels (semi-Lagrangian staggered self-advection, MacCormack, centred scalar) at a cubic size with hipEvent
+pairs:  python tools/time_advect.py --size 256 [--lib other/libphihip.so]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phiflow_amd import _capi as C   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--lib", default="")
+    args = ap.parse_args()
+    n = args.size
+    dev = torch.device("cuda:0")
+    ctx = C.Context(C.Library(args.lib, strict=False) if args.lib else C.load_default_library(), 0)
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    L = 2 * math.pi
+    grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
+    g = torch.Generator().manual_seed(0)
+    v = [torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev) for _ in range(3)]
+    out = [torch.empty_like(t) for t in v]
+    s = torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev)
+    so = torch.empty_like(s)
+    P = lambda ts: [t.data_ptr() for t in ts]
+    dt = 0.5 * L / n
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.reps
+
+    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype,
+           "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
+           "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
+           "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((0, 0),) * 3, None, P(v), so.data_ptr(), dt)), 5)}
+    res["GBs_semi_lagrangian_staggered"] = round(6 * n ** 3 * (8 if args.dtype == "f64" else 4) / res["ms_semi_lagrangian_staggered"] / 1e6, 1)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
