@@ -12,6 +12,27 @@
 
 namespace phihip {
 
+// Launch geometry of the gather kernels: one sample per thread, a workgroup = 64 consecutive fast-axis samples x 4 rows; the
+// (a0, row block, column block) coordinates of a workgroup are decoded from blockIdx.x with UNIFORM integer divisions -- the
+// per-thread div / mod of a linear index cost ~80 of the ~370 VALU instructions per wave of the first version (the kernels
+// are VALU-bound: rocprofv3 SQ_INSTS_VALU, profiles/r01_advect_pmc.json).
+constexpr int kRowLanes = 64, kRowsPerBlock = kBlock / kRowLanes;
+
+__device__ __forceinline__ bool decode_sample(int n1, int n2, int (&idx)[3], int& f) {
+    const int nb2 = (n2 + kRowLanes - 1) / kRowLanes, nb1 = (n1 + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int bx = blockIdx.x;
+    const int t = bx / nb2;
+    idx[2] = (bx - t * nb2) * kRowLanes + (threadIdx.x & (kRowLanes - 1));
+    idx[0] = t / nb1;
+    idx[1] = (t - idx[0] * nb1) * kRowsPerBlock + (threadIdx.x / kRowLanes);
+    f = (idx[0] * n1 + idx[1]) * n2 + idx[2];
+    return idx[2] < n2 && idx[1] < n1;
+}
+
+static inline long long sample_blocks(const int n[3]) {
+    return (long long)((n[2] + kRowLanes - 1) / kRowLanes) * ((n[1] + kRowsPerBlock - 1) / kRowsPerBlock) * n[0];
+}
+
 // MODE 0: semi-Lagrangian  out = field(x - dt u)
 // MODE 1: MacCormack correction pass (advect.py:203-215). `field` = original field, `fwd` = the semi-Lagrangian result:
 //         out = clip(fwd + ch (field - fwd(x + dt u)), min / max of field's taps around x - dt u)
@@ -30,9 +51,9 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_kernel(VelGrid g, CCo
     int bc[3][2];
     T cv[3][2];
     comp_rule<T>(g, ca, bc, cv);
-    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
-        int idx[3];
-        unravel(f, n[1], n[2], idx);
+    {
+        int idx[3], f;
+        if (!decode_sample(n[1], n[2], idx, f)) return;
         T u[3];
         face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
         T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
@@ -73,9 +94,9 @@ __global__ __launch_bounds__(kBlock) void advect_centered_kernel(VelGrid g, Scal
     int bc[3][2];
     T cv[3][2];
     scalar_rule<T>(sb, bc, cv);
-    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
-        int idx[3];
-        unravel(f, n[1], n[2], idx);
+    {
+        int idx[3], f;
+        if (!decode_sample(n[1], n[2], idx, f)) return;
         T u[3];
         center_velocity<T, DIM>(g, vel, b, idx, u);
         T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
@@ -103,10 +124,6 @@ __global__ __launch_bounds__(kBlock) void advect_centered_kernel(VelGrid g, Scal
     }
 }
 
-static inline int advect_blocks(long long total) {
-    const long long nb = (total + kBlock - 1) / kBlock;
-    return (int)(nb < 65536 ? nb : 65536);
-}
 
 template <typename T, int DIM, int MODE>
 static void launch_advect_staggered(const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3],
@@ -114,11 +131,11 @@ static void launch_advect_staggered(const GridView& v, const VelGrid& g, const v
     CComp3a<T> ff{{(const T*)f[0], (const T*)f[1], (const T*)f[2]}};
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     if (DIM == 3)
-        hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 0, MODE>), dim3(advect_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, ff,
+        hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 0, MODE>), dim3((unsigned)sample_blocks(v.cn[0]), v.batch), dim3(kBlock), 0, s, g, ff,
                            vv, (const T*)(fwd ? fwd[0] : nullptr), (T*)out[0], (T)dt, (T)ch);
-    hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 1, MODE>), dim3(advect_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+    hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 1, MODE>), dim3((unsigned)sample_blocks(v.cn[1]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
                        (const T*)(fwd ? fwd[1] : nullptr), (T*)out[1], (T)dt, (T)ch);
-    hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 2, MODE>), dim3(advect_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+    hipLaunchKernelGGL((advect_staggered_kernel<T, DIM, 2, MODE>), dim3((unsigned)sample_blocks(v.cn[2]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
                        (const T*)(fwd ? fwd[2] : nullptr), (T*)out[2], (T)dt, (T)ch);
 }
 
@@ -178,7 +195,7 @@ template <typename T, int DIM, int MODE>
 static void launch_advect_centered(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
                                    const void* fwd, void* out, double dt, double ch, hipStream_t s) {
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    hipLaunchKernelGGL((advect_centered_kernel<T, DIM, MODE>), dim3(advect_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb,
+    hipLaunchKernelGGL((advect_centered_kernel<T, DIM, MODE>), dim3((unsigned)sample_blocks(v.n), v.batch), dim3(kBlock), 0, s, g, sb,
                        (const T*)sfield, vv, (const T*)fwd, (T*)out, (T)dt, (T)ch);
 }
 
