@@ -221,3 +221,36 @@ def test_bad_arguments_are_reported(emu_ctx, emu_library):
     bad = pc.C.make_grid(2, 0, 1, (8, 8), (0, 0), (8, 8), ((PER, CLO), (PER, PER)))
     with pytest.raises(pc.C.PhiHipError):
         emu_ctx.component_shape(bad, 0)
+
+
+def test_bad_arguments_of_the_widened_entry_points(emu_ctx):
+    """ error behaviour of the f2-f5 entry points: negative status + message, never a crash """
+    C = pc.C
+    dom, grid = pc.make_case((8, 8, 8), ((PER, PER),) * 3, np.float32)
+    v = [np.zeros((1, 8, 8, 8), np.float32) for _ in range(3)]
+    P = lambda arrs: [a.ctypes.data for a in arrs]
+    with pytest.raises(C.PhiHipError) as e:                       # output aliases the input
+        emu_ctx.mac_cormack_staggered(grid, P(v), P(v), P(v), 0.1, 1.0)
+    assert e.value.status == -1 and "alias" in str(e.value)
+    s = np.zeros((1, 8, 8, 8), np.float32)
+    with pytest.raises(C.PhiHipError) as e:                       # scalar periodicity must match the grid
+        emu_ctx.mac_cormack_centered(grid, s.ctypes.data, ((CLO, CLO),) * 3, None, P(v), np.zeros_like(s).ctypes.data, 0.1, 1.0)
+    assert "periodicity" in str(e.value)
+    bad = C.make_obstacles([dict(kind=7, center=(1, 1, 1), half_size=(1, 1, 1))])
+    with pytest.raises(C.PhiHipError) as e:
+        emu_ctx.apply_obstacles(grid, bad, 1, P(v))
+    assert "unknown kind" in str(e.value)
+    with pytest.raises(C.PhiHipError) as e:                       # halo announced but no plane given
+        emu_ctx.slab_residual(grid, (True, False), 0, s.ctypes.data, (0, 0), s.ctypes.data, np.zeros_like(s).ctypes.data,
+                              np.zeros(2).ctypes.data)
+    assert "halo plane missing" in str(e.value)
+    g2, grid2 = pc.make_case((8, 8), ((PER, PER),) * 2, np.float32)
+    with pytest.raises(C.PhiHipError) as e:                       # slabs are 3-D only
+        emu_ctx.slab_residual(grid2, (False, False), 0, s.ctypes.data, (0, 0), s.ctypes.data, s.ctypes.data, np.zeros(2).ctypes.data)
+    assert "3-D" in str(e.value)
+    with pytest.raises(C.PhiHipError):                            # gradient buffers are mandatory for the MacCormack adjoint
+        emu_ctx.mac_cormack_centered_backward(grid, s.ctypes.data, ((PER, PER),) * 3, None, P(v), s.ctypes.data, 0.1, 1.0, 0, None)
+    plan = emu_ctx.query_plan(grid, False, 1)
+    assert plan["rows"] in (1, 2, 4) and plan["nblk"] >= 1 and plan["occupancy"] >= 1
+    with pytest.raises(C.PhiHipError):
+        emu_ctx.set_tuning_kernel(5, 1, 16, 8)
