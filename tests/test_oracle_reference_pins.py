@@ -168,3 +168,78 @@ def test_mixed_boundary_corner_padding_order():
     assert val[0, 0] == 3.0
     padded = O.pad_component(a, 0, [(0, 2), (0, 2)], dom)
     assert padded[0, -1, -1] == 3.0 and padded[0, -1, 0] == 7.0
+
+
+# ---- pins of the widened rows --------------------------------------------------------------------------
+def test_reference_explicit_centered_diffusion_known_answer():
+    """ tests/commit/physics/test_diffuse.py:68-72 exactly: a unit impulse on a 3 x 3 CenteredGrid with ZERO extrapolation,
+    `diffuse.explicit(grid, 1, 1).values == [[0,1,0],[1,-3,1],[0,1,0]]` (dx = 1) """
+    dom = O.Domain((3, 3), (0, 0), (3, 3), ((CLO, CLO), (CLO, CLO)))
+    s = np.zeros((1, 3, 3), np.float32)
+    s[0, 1, 1] = 1
+    out = O.diffuse_explicit_centered(s, 1.0, 1.0, dom, ((CLO, CLO), (CLO, CLO)), [(0.0, 0.0)] * 2)
+    np.testing.assert_allclose(out[0], [[0, 1, 0], [1, -3, 1], [0, 1, 0]], atol=1e-6)
+
+
+@pytest.mark.parametrize("bc", [((CLO, CLO), (CLO, CLO)), ((OPN, OPN), (OPN, OPN)), ((PER, PER), (PER, PER))])
+def test_reference_mac_cormack_identity(bc):
+    """ tests/commit/physics/test_advect.py:29-30 (`_test_advection(advect.mac_cormack)`): adv(f, v, 0) == adv(f, v*0, 1) == f
+    for centred and staggered fields """
+    rng = np.random.default_rng(0)
+    dom = O.Domain((4, 3), (0, 0), (4, 3), bc)
+    v = [rng.standard_normal((1,) + dom.comp_shape(d)).astype(np.float32) for d in range(2)]
+    zero = [np.zeros_like(a) for a in v]
+    s = rng.standard_normal((1, 4, 3)).astype(np.float32)
+    for a, b in zip(O.mac_cormack_staggered(v, v, 0.0, dom), v):
+        np.testing.assert_allclose(a, b, atol=1e-5)
+    for a, b in zip(O.mac_cormack_staggered(v, zero, 1.0, dom), v):
+        np.testing.assert_allclose(a, b, atol=1e-5)
+    np.testing.assert_allclose(O.mac_cormack_centered(s, v, 0.0, dom, bc), s, atol=1e-5)
+    np.testing.assert_allclose(O.mac_cormack_centered(s, zero, 1.0, dom, bc), s, atol=1e-5)
+
+
+def test_mac_cormack_is_second_order_and_bounded():
+    """ properties the scheme is built for (advect.py:188-190): on a smooth periodic field advected by a constant velocity the
+    error is well below semi-Lagrangian's, and the result never leaves the range of the field (limiter) """
+    n = 64
+    dom = O.Domain((n, n), (0, 0), (1, 1), ((PER, PER), (PER, PER)))
+    x = (np.arange(n) + 0.5) / n
+    s = (np.sin(2 * np.pi * x)[:, None] * np.cos(2 * np.pi * x)[None, :]).astype(np.float64)[None]
+    u, w, dt = 0.37, -0.21, 0.4 / n * 3
+    v = [np.full((1,) + dom.comp_shape(0), u), np.full((1,) + dom.comp_shape(1), w)]
+    exact = (np.sin(2 * np.pi * (x - u * dt))[:, None] * np.cos(2 * np.pi * (x - w * dt))[None, :])[None]
+    err_sl = np.abs(O.semi_lagrangian_centered(s, v, dt, dom, dom.bc) - exact).mean()
+    mc = O.mac_cormack_centered(s, v, dt, dom, dom.bc)
+    assert np.abs(mc - exact).mean() < 0.25 * err_sl          # (at the extrema the limiter falls back to first order)
+    assert mc.max() <= s.max() + 1e-12 and mc.min() >= s.min() - 1e-12
+
+
+def test_centered_to_staggered_resample_values():
+    """ `smoke * (0, 0.1) @ velocity` (tests/commit/physics/test_fluid.py:26): face values are means of the adjacent cells, wall
+    faces of a closed domain are not stored, open domains store N + 1 faces with the edge value copied outside """
+    s = np.arange(12, dtype=np.float32).reshape(1, 4, 3)
+    closed = O.Domain((4, 3), (0, 0), (4, 3), ((CLO, CLO), (CLO, CLO)))
+    out = O.centered_to_staggered(s, closed, ((OPN, OPN), (OPN, OPN)), None, (0.0, 0.1))
+    assert out[0].shape == (1, 3, 3) and out[1].shape == (1, 4, 2) and np.all(out[0] == 0)
+    np.testing.assert_allclose(out[1][0], 0.1 * 0.5 * (s[0, :, 1:] + s[0, :, :-1]), rtol=1e-6)
+    opened = O.Domain((4, 3), (0, 0), (4, 3), ((OPN, OPN), (OPN, OPN)))
+    out = O.centered_to_staggered(s, opened, ((OPN, OPN), (OPN, OPN)), None, (1.0, 1.0))
+    assert out[0].shape == (1, 5, 3)
+    np.testing.assert_allclose(out[0][0, 0], s[0, 0])            # zero-gradient ghost cell: mean of a value with itself
+    np.testing.assert_allclose(out[0][0, 2], 0.5 * (s[0, 1] + s[0, 2]))
+
+
+def test_obstacle_boundary_conditions_known_values():
+    """ fluid.apply_boundary_conditions (fluid.py:212-240): deep inside a moving obstacle the fluid takes the obstacle's
+    velocity (linear + angular x r), far away it is untouched, the transition is one cell wide """
+    dom = O.Domain((32, 32), (0, 0), (32, 32), ((CLO, CLO), (CLO, CLO)))
+    ob = O.BoxObstacle((10, 10), (22, 22), velocity=(1.5, -0.5), angular_velocity=0.25)
+    v = [np.full((1,) + dom.comp_shape(d), 7.0) for d in range(2)]
+    out = O.apply_boundary_conditions(v, [ob], dom)
+    fx = O.face_positions(0, dom, np.float64)
+    inside = (np.abs(fx[0] - 16) < 4) & (np.abs(fx[1] - 16) < 4)
+    np.testing.assert_allclose(out[0][0][inside], (1.5 - 0.25 * (fx[1] - 16))[inside])          # u_x = U_x - w (y - c_y)
+    far = (np.abs(fx[0] - 16) > 8) | (np.abs(fx[1] - 16) > 8)
+    assert np.all(out[0][0][far] == 7.0)
+    active, hard, soft = O.obstacle_masks([ob], dom)
+    assert active[0].sum() == 32 * 32 - 12 * 12
