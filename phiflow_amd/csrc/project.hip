@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
         if (flags) {
             const unsigned f = flags[(flags_per_batch ? (long long)b * cells : 0) + cell];
             act = (f & 64u) ? T(1) : T(0);
-            sum *= act;
+            sum = (f & 64u) ? sum : T(0);   // div * active, and non-finite values of inactive cells do not leak (fluid.py:139-144)
         }
         div[(long long)b * cells + cell] = sum;
         acc_val += sum;
