@@ -364,3 +364,38 @@ def test_full_size_cavity_fp64_with_obstacle(ctx, mem):
     mem.sync()
     for a, b in zip(before, v):
         assert float((a - b).abs().max()) <= 1e-7 * 0.05
+
+
+def test_full_size_taylor_green_run_is_stable(ctx, mem):
+    """ BASELINE configs[1] at full size, the benchmark's own loop: 12 steps of {semi-Lagrangian self-advection, projection with
+    exactly 100 CG iterations from the previous pressure}. Size-independent sanity properties: all fields stay finite, the
+    kinetic energy never grows (semi-Lagrangian advection and the projection are both dissipative), the relative residual of
+    every solve stays small, and the z-component of the extruded 2-D vortex stays zero. """
+    import torch
+    n = 256
+    L = 2 * math.pi
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(L,) * 3)
+    h = L / n
+    idx = torch.arange(n, dtype=torch.float64)
+    face, cent = idx * h, (idx + 0.5) * h
+    u = (torch.cos(face)[:, None] * torch.sin(cent)[None, :])[:, :, None].expand(n, n, n)
+    w = (-torch.sin(cent)[:, None] * torch.cos(face)[None, :])[:, :, None].expand(n, n, n)
+    v = [t.to(torch.float32).unsqueeze(0).contiguous().to(mem.device) for t in (u, w, torch.zeros(n, n, n, dtype=torch.float64))]
+    v2 = [torch.empty_like(t) for t in v]
+    p = torch.zeros(1, n, n, n, device=mem.device)
+    res = torch.zeros(1, 2, dtype=torch.float64, device=mem.device)
+    solve = pc.C.Solve(0.0, 0.0, 100, 50, 0, 0)
+    P = lambda ts: [t.data_ptr() for t in ts]
+    energy = [float(sum((t.double() ** 2).sum() for t in v))]
+    for _ in range(12):
+        ctx.advect_staggered(grid, P(v), P(v), P(v2), 0.5 * h)
+        ctx.make_incompressible(grid, P(v2), None, 0, 1, True, p.data_ptr(), 0, solve, want_info=False)
+        ctx.solve_residuals(1, res.data_ptr())
+        v, v2 = v2, v
+        mem.sync()
+        energy.append(float(sum((t.double() ** 2).sum() for t in v)))
+        assert all(bool(torch.isfinite(t).all()) for t in v) and bool(torch.isfinite(p).all())
+        assert float(torch.sqrt(res[0, 0] / res[0, 1])) < 5e-2
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(energy, energy[1:])), energy
+    assert energy[-1] > 0.9 * energy[0]                        # ... and the vortex is still there
+    assert float(v[2].abs().max()) < 1e-3
