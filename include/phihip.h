@@ -259,6 +259,10 @@ int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row,
 /* the same for one kernel family only: 0 = operator apply / residual, 1 = MATVEC (d = r + beta d; d.Ad), 2 = UPDATE (x, r) */
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes);
 
+/* Grids of at most 8192 cells per batch entry are solved by ONE kernel (one workgroup per batch entry, the
+ * search direction in LDS, no kernel boundary or host polling inside the loop; cg_small.hip). enable = 0 forces the marching
+ * kernels for every size (A/B measurements, tests of the marching path on small grids). Default: enabled. */
+int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
 /* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
  * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);

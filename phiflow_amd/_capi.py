@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
-    "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state",
+    "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
 )
 
 
@@ -196,6 +196,7 @@ class Library:
         d.phihip_profile_read.argtypes = [c_void_p, POINTER(c_int32 * K_COUNT), POINTER(c_double * K_COUNT), c_int]
         d.phihip_set_tuning.argtypes = [c_void_p, c_int, c_int, c_int]
         d.phihip_set_tuning_kernel.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+        d.phihip_set_small_grid_solver.argtypes = [c_void_p, c_int]
         d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
         for name in EXPORTED_SYMBOLS:
             if name not in ("phihip_version", "phihip_last_error"):
@@ -403,6 +404,9 @@ class Context:
         """ family: 0 = apply / residual, 1 = MATVEC, 2 = UPDATE """
         self.lib.check(self.lib.dll.phihip_set_tuning_kernel(self.handle, int(family), int(rows_per_thread), int(threads_per_row),
                                                              int(chunk_planes)))
+
+    def set_small_grid_solver(self, enable: bool):
+        self.lib.check(self.lib.dll.phihip_set_small_grid_solver(self.handle, int(bool(enable))))
 
     def query_plan(self, grid, has_flags=False, family=1) -> dict:
         out = (c_int32 * 6)()

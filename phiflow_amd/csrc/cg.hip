@@ -200,9 +200,45 @@ int run_laplace_apply(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
                                  : laplace_apply_t<float>(ctx, v, flags, mask_batch, p, out, s);
 }
 
+long long small_cg_limit(int dtype);
+int run_cg_small(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, void* st_out,
+                 hipStream_t);
+
+// small grids: the whole solve in ONE kernel, one workgroup per batch entry (cg_small.hip)
+static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+                         const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)3 * v.batch * sizeof(CgState)));
+    CgState* st = (CgState*)ctx->ws_state.ptr;
+    PHIHIP_TRY(run_cg_small(ctx, v, flags, mask_batch, rhs, x, solve, st, s));
+    ctx->last_state = st;
+    ctx->last_state_batch = v.batch;
+    if (info) {
+        if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
+            if (ctx->host_state) (void)hipHostFree(ctx->host_state);
+            ctx->host_state = nullptr;
+            ctx->host_state_bytes = 0;
+            PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));
+            ctx->host_state_bytes = (size_t)v.batch * sizeof(CgState);
+        }
+        CgState* hst = (CgState*)ctx->host_state;
+        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+        PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < v.batch; ++b) {
+            info[b].residual_sq = hst[b].rsq;
+            info[b].rhs_sq = hst[b].rhs_sq;
+            info[b].iterations = hst[b].iterations;
+            info[b].converged = hst[b].converged;
+            info[b].diverged = hst[b].diverged;
+            info[b].reserved = 0;
+        }
+    }
+    return PHIHIP_OK;
+}
+
 template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
                 const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    if (ctx->small_cg && v.cells <= small_cg_limit(v.dtype)) return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     MarchConfig c, c_mv, c_up;   // residual / MATVEC / UPDATE may run different tile shapes
     MarchGrid g, g_mv, g_up;
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));

@@ -1,0 +1,251 @@
+// cg_small.hip -- the whole CG solve of a SMALL grid in one kernel: one 512-thread workgroup per batch entry, the search
+// direction d and q = A d live in LDS (128 KB of the CU's 160 KB), x / r / d of the thread's own cells in registers, alpha / beta / the
+// convergence logic in the workgroup -- no kernel boundary and no host polling inside the loop.
+//
+// Why: the marching kernels need two dependent launches per iteration, i.e. >= 9.5 us per iteration however small the grid
+// (tools/host_bound_check.py); PhiFlow's typical learning workloads are large batches of small simulations (64^2 ... 128^2),
+// and BASELINE configs[0] is a 128^2 plume. Here a 128^2 entry costs the arithmetic of one CU per iteration and every batch
+// entry gets its own CU. Same algorithm and control flow as cg.hip / stencil_march.hpp (PhiML cg).
+#include "common.hpp"
+#include "march_dispatch.hpp"
+
+namespace phihip {
+
+// The per-cell loops are fully unrolled (register arrays need constant indices); without a scheduling fence the compiler hoists
+// all 6 * CPT LDS reads of a loop to its top and spills. The fence keeps one cell's stencil in flight at a time.
+#ifdef __HIP_DEVICE_COMPILE__
+#define PHIHIP_KEEP_ORDER() __builtin_amdgcn_sched_barrier(0)
+#define PHIHIP_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define PHIHIP_KEEP_ORDER() do { } while (0)
+#define PHIHIP_OPAQUE(v) do { } while (0)
+#endif
+
+constexpr int kSmallThreads = 512;
+constexpr int kSmallWaves = kSmallThreads / kWave;
+constexpr int kSmallLdsBytes = 64 * 1024;   // 8192 cells per batch entry (fp64)
+
+template <typename T>
+struct SmallArgs {
+    const T* rhs;
+    T* x;
+    const uint8_t* flags;
+    CgState* st_out;
+    CgParams prm;
+    int refresh_every;
+    T w0, w1, w2;
+};
+
+__device__ __forceinline__ double small_block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallWaves; ++w) s += red[w];   // every thread adds the same values in the same order
+    return s;
+}
+
+// 2-bit neighbour rule per axis side, packed per cell: 0 interior, 1 wrap, 2 clamp (self), 3 zero ghost
+__device__ __forceinline__ unsigned side_code(int i, int n, int rule, bool lower) {
+    if (lower ? i > 0 : i < n - 1) return 0u;
+    return rule == NB_WRAP ? 1u : (rule == NB_CLAMP ? 2u : 3u);
+}
+
+template <typename T>
+__device__ __forceinline__ T small_nb(const T* L, int c, T self, unsigned code, int stride, int wrap_shift, bool lower) {
+    if (code == 0u) return L[lower ? c - stride : c + stride];
+    if (code == 1u) return L[lower ? c - stride + wrap_shift : c + stride - wrap_shift];
+    return code == 2u ? self : T(0);
+}
+
+template <typename T, int CPT, bool FLAGS>
+__global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, SmallArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) T L[kSmallLdsBytes / sizeof(T)];   // the vector whose Laplacian is taken (x, then d)
+    __shared__ __attribute__((aligned(16))) T Q[kSmallLdsBytes / sizeof(T)];   // q = A d of the thread's own cells (spares CPT registers)
+    __shared__ double red[kSmallWaves];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int cells = (int)g.cells;
+    const int n1 = g.n1, n2 = g.n2;
+    const int s0 = n1 * n2, s1 = n2;
+    const long long base = (long long)b * cells;
+    const bool dim3_ = g.n0 > 1;
+
+    T x[CPT], r[CPT], d[CPT];
+    unsigned code[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = k * kSmallThreads + tid;
+        x[k] = r[k] = d[k] = T(0);
+        code[k] = 0u;
+        if (c < cells) {
+            const int i2 = c % n2, t = c / n2, i1 = t % n1, i0 = t / n1;
+            unsigned cd = side_code(i2, n2, g.nb[2][0], true) | (side_code(i2, n2, g.nb[2][1], false) << 2) |
+                          (side_code(i1, n1, g.nb[1][0], true) << 4) | (side_code(i1, n1, g.nb[1][1], false) << 6);
+            if (dim3_) cd |= (side_code(i0, g.n0, g.nb[0][0], true) << 8) | (side_code(i0, g.n0, g.nb[0][1], false) << 10);
+            if (FLAGS) cd |= (unsigned)p.flags[(g.flags_per_batch ? base : 0) + c] << 16;
+            code[k] = cd;
+            x[k] = p.x[base + c];
+        }
+    }
+
+    // A applied to the vector in L at the thread's k-th cell (same operation order as march_kernel)
+    auto apply = [&](int k, T self) -> T {
+        const int c = k * kSmallThreads + tid;
+        unsigned cd = code[k];
+        PHIHIP_OPAQUE(cd);   // keeps the neighbour-offset decode inside the loop (hoisted it costs 6 registers per cell)
+        const T lo2 = small_nb<T>(L, c, self, cd & 3u, 1, n2, true), hi2 = small_nb<T>(L, c, self, (cd >> 2) & 3u, 1, n2, false);
+        const T up = small_nb<T>(L, c, self, (cd >> 4) & 3u, s1, n1 * s1, true), dn = small_nb<T>(L, c, self, (cd >> 6) & 3u, s1, n1 * s1, false);
+        T lo0 = T(0), hi0 = T(0);
+        if (dim3_) {
+            lo0 = small_nb<T>(L, c, self, (cd >> 8) & 3u, s0, g.n0 * s0, true);
+            hi0 = small_nb<T>(L, c, self, (cd >> 10) & 3u, s0, g.n0 * s0, false);
+        }
+        if (FLAGS) {
+            const unsigned f = cd >> 16;
+            T q = T(0);
+            if (dim3_) {
+                if (f & 1u) q += (lo0 - self) * p.w0;
+                if (f & 2u) q += (hi0 - self) * p.w0;
+            }
+            if (f & 4u) q += (up - self) * p.w1;
+            if (f & 8u) q += (dn - self) * p.w1;
+            if (f & 16u) q += (lo2 - self) * p.w2;
+            if (f & 32u) q += (hi2 - self) * p.w2;
+            if (!(f & 64u)) q = self;   // inactive cell: identity row (fluid.py:202)
+            return q;
+        }
+        const T t2 = ((hi2 - self) - (self - lo2)) * p.w2;
+        const T t1 = ((dn - self) - (self - up)) * p.w1;
+        return dim3_ ? ((hi0 - self) - (self - lo0)) * p.w0 + t1 + t2 : t1 + t2;
+    };
+    auto publish = [&](const T (&v)[CPT]) {   // own cells of a register vector -> L (callers sync around it)
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = k * kSmallThreads + tid;
+            if (c < cells) L[c] = v[k];
+        }
+    };
+    // r = y - A x from the current x; returns (sum r^2, sum y^2)
+    auto residual = [&](double& rr, double& yy) {
+        __syncthreads();
+        publish(x);
+        __syncthreads();
+        T a1 = T(0), a2 = T(0);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = k * kSmallThreads + tid;
+            if (c < cells) {
+                const T y = p.rhs[base + c];
+                r[k] = y - apply(k, x[k]);
+                a1 += r[k] * r[k];
+                a2 += y * y;
+            }
+            PHIHIP_KEEP_ORDER();
+        }
+        rr = small_block_sum((double)a1, red);
+        yy = small_block_sum((double)a2, red);
+    };
+
+    double rr, yy;
+    residual(rr, yy);
+    CgState S = cg_advance(PRO_FIRST, CgState(), rr, yy, p.prm);
+    for (int it = 1; it <= p.prm.max_iter && S.cont; ++it) {
+        // ---- MATVEC: d = r + beta d ; dq = d . A d ----
+        const T beta = (T)S.beta;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) d[k] = fma(beta, d[k], r[k]);
+        __syncthreads();
+        publish(d);
+        __syncthreads();
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = k * kSmallThreads + tid;
+            if (c < cells) {
+                const T q = apply(k, d[k]);
+                Q[c] = q;
+                acc += d[k] * q;
+            }
+            PHIHIP_KEEP_ORDER();
+        }
+        const double dq = small_block_sum((double)acc, red);
+        S = cg_advance(PRO_ALPHA, S, dq, 0.0, p.prm);
+        const T alpha = (T)S.alpha;
+        // ---- UPDATE: x += alpha d ; r -= alpha A d (or the true residual every refresh_every-th iteration) ----
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) x[k] = x[k] + alpha * d[k];
+        if (p.refresh_every > 0 && it % p.refresh_every == 0) {
+            double dummy;
+            residual(rr, dummy);
+        } else {
+            T a1 = T(0);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = k * kSmallThreads + tid;
+                if (c < cells) {
+                    r[k] = r[k] - alpha * Q[c];
+                    a1 += r[k] * r[k];
+                }
+            }
+            rr = small_block_sum((double)a1, red);
+        }
+        S = cg_advance(PRO_BETA, S, rr, 0.0, p.prm);
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = k * kSmallThreads + tid;
+        if (c < cells) p.x[base + c] = x[k];
+    }
+    if (tid == 0) p.st_out[b] = S;
+}
+
+template <typename T, int CPT>
+static void launch_small(const MarchGrid& g, const SmallArgs<T>& a, int batch, bool flags, hipStream_t s) {
+    if (flags)
+        hipLaunchKernelGGL((cg_small_kernel<T, CPT, true>), dim3(batch), dim3(kSmallThreads), 0, s, g, a);
+    else
+        hipLaunchKernelGGL((cg_small_kernel<T, CPT, false>), dim3(batch), dim3(kSmallThreads), 0, s, g, a);
+}
+
+// cells per batch entry up to which the single-workgroup solver is used (register + LDS budget of one CU)
+// Measured on MI355X (tools/sweep_cg2d.py): 64^2 x 256 entries 4.2 us / iteration against 14.7 us with the marching kernels,
+// 90^2 x 8 6.5 against 9.8 us; at 128^2 (32 cells per thread: register spills, 11.4 us) the marching kernels win (9.2 us),
+// so the limit is 16 cells per thread.
+long long small_cg_limit(int dtype) { (void)dtype; return 16LL * kSmallThreads; }
+
+template <typename T>
+static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+                      const phihip_solve* solve, CgState* st_out, hipStream_t s) {
+    MarchConfig c;
+    MarchGrid g;
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));   // only the grid description is used
+    SmallArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.rhs = (const T*)rhs;
+    a.x = (T*)x;
+    a.flags = flags;
+    a.st_out = st_out;
+    a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; a.prm.pad = 0;
+    a.refresh_every = solve->refresh_every;
+    a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    const int need = ceil_div(v.cells, kSmallThreads);
+    LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
+    if (need <= 2) launch_small<T, 2>(g, a, v.batch, flags != nullptr, s);
+    else if (need <= 8) launch_small<T, 8>(g, a, v.batch, flags != nullptr, s);
+    else launch_small<T, 16>(g, a, v.batch, flags != nullptr, s);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_cg_small(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
+                 const phihip_solve* solve, void* st_out, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? cg_small_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, (CgState*)st_out, s)
+                                 : cg_small_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, (CgState*)st_out, s);
+}
+
+}  // namespace phihip

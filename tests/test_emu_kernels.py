@@ -109,7 +109,12 @@ def test_advection_with_wall_velocity(emu_ctx):
 def test_cg_matches_oracle(emu_ctx, res, bc, dtype):
     rng = np.random.default_rng(4)
     dom, grid = pc.make_case(res, bc, dtype, batch=2)
-    pc.check_cg(emu_ctx, MEM, dom, grid, dtype, rng)
+    try:
+        for small in (True, False):     # single-kernel solver for small grids (cg_small.hip) and the marching kernels
+            emu_ctx.set_small_grid_solver(small)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(4))
+    finally:
+        emu_ctx.set_small_grid_solver(True)
 
 
 def test_cg_fixed_iterations_and_refresh(emu_ctx):

@@ -170,7 +170,12 @@ def test_advection_with_wall_velocity(ctx, mem):
 def test_cg_matches_oracle(ctx, mem, res, bc, dtype):
     rng = np.random.default_rng(4)
     dom, grid = pc.make_case(res, bc, dtype, batch=2)
-    pc.check_cg(ctx, mem, dom, grid, dtype, rng)
+    try:
+        for small in (True, False):     # single-kernel solver for small grids (cg_small.hip) and the marching kernels
+            ctx.set_small_grid_solver(small)
+            pc.check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(4))
+    finally:
+        ctx.set_small_grid_solver(True)
 
 
 def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):

@@ -28,8 +28,10 @@ def main():
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, args.iters, 0, 0, 0)
-    for rows, tpr in [(0, 0), (1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
-        ctx.set_tuning(rows, tpr, 0)
+    ap_small = n * n <= 16384
+    for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0), (1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
+        ctx.set_small_grid_solver(rows < 0)          # rows = -1: the single-kernel solver (cg_small.hip)
+        ctx.set_tuning(max(rows, 0), max(tpr, 0), 0)
         x.zero_()
         ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, 0), want_info=False)
         torch.cuda.synchronize()
