@@ -251,14 +251,19 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * part_n * sizeof(double)));
-    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)3 * v.batch * sizeof(CgState)));
-    if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
+    if (ctx->host_state_bytes < (size_t)2 * v.batch * sizeof(CgState)) {
         if (ctx->host_state) (void)hipHostFree(ctx->host_state);
         ctx->host_state = nullptr;
         ctx->host_state_bytes = 0;
-        PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));
-        ctx->host_state_bytes = (size_t)v.batch * sizeof(CgState);
+        PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)2 * v.batch * sizeof(CgState), hipHostMallocDefault));
+        ctx->host_state_bytes = (size_t)2 * v.batch * sizeof(CgState);
     }
+    if (!ctx->poll_ev[0]) {
+        PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[0]));
+        PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[1]));
+    }
+    int checks = 0;
     T* r = (T*)ctx->ws_r.ptr;
     T* d[2] = {(T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr};
     double* part_rr = (double*)ctx->ws_part.ptr;
@@ -330,17 +335,26 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             nblk_rr = g_up.nblk;
         }
         if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
-            // peek at the decision the next MATVEC prologue will take, without advancing the chain
+            // Peek at the decision the next MATVEC prologue will take, without advancing the chain -- and WITHOUT draining the
+            // stream: the peek of this check point is copied to a pinned slot behind an event, the host then inspects the
+            // PREVIOUS check point (long finished) and keeps enqueueing. The continue flags only ever go 1 -> 0 and frozen
+            // entries make every kernel return at once, so running one check interval ahead is harmless.
+            const int slot = checks & 1;
             {
                 LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur], st_peek,
-                                   (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
+                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur],
+                                   st_peek + (size_t)slot * v.batch, (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
             }
-            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st_peek, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
-            PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
-            bool any = false;
-            for (int b = 0; b < v.batch; ++b) any = any || hst[b].cont;
-            if (!any) break;
+            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst + (size_t)slot * v.batch, st_peek + (size_t)slot * v.batch, (size_t)v.batch * sizeof(CgState),
+                                            hipMemcpyDeviceToHost, s));
+            PHIHIP_CHECK_HIP(hipEventRecord(ctx->poll_ev[slot], s));
+            if (checks > 0) {
+                PHIHIP_CHECK_HIP(hipEventSynchronize(ctx->poll_ev[slot ^ 1]));
+                bool any = false;
+                for (int b = 0; b < v.batch; ++b) any = any || hst[(size_t)(slot ^ 1) * v.batch + b].cont;
+                if (!any) break;
+            }
+            ++checks;
         }
     }
     {   // fold the last reduction into the control block (or build it when no iteration ran)

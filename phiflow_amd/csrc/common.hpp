@@ -101,6 +101,7 @@ struct phihip_ctx {
     int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
     size_t host_state_bytes = 0;
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};   // lagged convergence polling (cg.hip)
     // profiling
     bool profiling = false;
     struct EventPair {
