@@ -14,16 +14,14 @@ namespace phihip {
 // The per-cell loops are fully unrolled (register arrays need constant indices); without a scheduling fence the compiler hoists
 // all 6 * CPT LDS reads of a loop to its top and spills. The fence keeps one cell's stencil in flight at a time.
 #ifdef __HIP_DEVICE_COMPILE__
-#define PHIHIP_KEEP_ORDER() __builtin_amdgcn_sched_barrier(0)
+#define PHIHIP_KEEP_ORDER() do { } while (0)
 #define PHIHIP_OPAQUE(v) asm volatile("" : "+v"(v))
 #else
 #define PHIHIP_KEEP_ORDER() do { } while (0)
 #define PHIHIP_OPAQUE(v) do { } while (0)
 #endif
 
-constexpr int kSmallThreads = 512;
-constexpr int kSmallWaves = kSmallThreads / kWave;
-constexpr int kSmallLdsBytes = 64 * 1024;   // 8192 cells per batch entry (fp64)
+constexpr int kSmallMaxThreads = 1024;
 
 template <typename T>
 struct SmallArgs {
@@ -36,6 +34,7 @@ struct SmallArgs {
     T w0, w1, w2;
 };
 
+template <int NT>
 __device__ __forceinline__ double small_block_sum(double v, double* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -44,7 +43,7 @@ __device__ __forceinline__ double small_block_sum(double v, double* red) {
     __syncthreads();
     double s = 0;
 #pragma unroll
-    for (int w = 0; w < kSmallWaves; ++w) s += red[w];   // every thread adds the same values in the same order
+    for (int w = 0; w < NT / kWave; ++w) s += red[w];   // every thread adds the same values in the same order
     return s;
 }
 
@@ -61,11 +60,12 @@ __device__ __forceinline__ T small_nb(const T* L, int c, T self, unsigned code, 
     return code == 2u ? self : T(0);
 }
 
-template <typename T, int CPT, bool FLAGS>
-__global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, SmallArgs<T> p) {
-    __shared__ __attribute__((aligned(16))) T L[kSmallLdsBytes / sizeof(T)];   // the vector whose Laplacian is taken (x, then d)
-    __shared__ __attribute__((aligned(16))) T Q[kSmallLdsBytes / sizeof(T)];   // q = A d of the thread's own cells (spares CPT registers)
-    __shared__ double red[kSmallWaves];
+template <typename T, int NT, int CPT, bool FLAGS>
+__global__ __launch_bounds__(NT) void cg_small_kernel(MarchGrid g, SmallArgs<T> p) {
+    constexpr int kSmallThreads = NT;
+    __shared__ __attribute__((aligned(16))) T L[NT * CPT];   // the vector whose Laplacian is taken (x, then d)
+    __shared__ __attribute__((aligned(16))) T Q[NT * CPT];   // q = A d of the thread's own cells (spares CPT registers)
+    __shared__ double red[NT / kWave];
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, Sm
             }
             PHIHIP_KEEP_ORDER();
         }
-        rr = small_block_sum((double)a1, red);
-        yy = small_block_sum((double)a2, red);
+        rr = small_block_sum<NT>((double)a1, red);
+        yy = small_block_sum<NT>((double)a2, red);
     };
 
     double rr, yy;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, Sm
             }
             PHIHIP_KEEP_ORDER();
         }
-        const double dq = small_block_sum((double)acc, red);
+        const double dq = small_block_sum<NT>((double)acc, red);
         S = cg_advance(PRO_ALPHA, S, dq, 0.0, p.prm);
         const T alpha = (T)S.alpha;
         // ---- UPDATE: x += alpha d ; r -= alpha A d (or the true residual every refresh_every-th iteration) ----
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, Sm
                     a1 += r[k] * r[k];
                 }
             }
-            rr = small_block_sum((double)a1, red);
+            rr = small_block_sum<NT>((double)a1, red);
         }
         S = cg_advance(PRO_BETA, S, rr, 0.0, p.prm);
     }
@@ -204,19 +204,19 @@ __global__ __launch_bounds__(kSmallThreads) void cg_small_kernel(MarchGrid g, Sm
     if (tid == 0) p.st_out[b] = S;
 }
 
-template <typename T, int CPT>
+template <typename T, int NT, int CPT>
 static void launch_small(const MarchGrid& g, const SmallArgs<T>& a, int batch, bool flags, hipStream_t s) {
     if (flags)
-        hipLaunchKernelGGL((cg_small_kernel<T, CPT, true>), dim3(batch), dim3(kSmallThreads), 0, s, g, a);
+        hipLaunchKernelGGL((cg_small_kernel<T, NT, CPT, true>), dim3(batch), dim3(NT), 0, s, g, a);
     else
-        hipLaunchKernelGGL((cg_small_kernel<T, CPT, false>), dim3(batch), dim3(kSmallThreads), 0, s, g, a);
+        hipLaunchKernelGGL((cg_small_kernel<T, NT, CPT, false>), dim3(batch), dim3(NT), 0, s, g, a);
 }
 
 // cells per batch entry up to which the single-workgroup solver is used (register + LDS budget of one CU)
 // Measured on MI355X (tools/sweep_cg2d.py): 64^2 x 256 entries 4.2 us / iteration against 14.7 us with the marching kernels,
-// 90^2 x 8 6.5 against 9.8 us; at 128^2 (32 cells per thread: register spills, 11.4 us) the marching kernels win (9.2 us),
-// so the limit is 16 cells per thread.
-long long small_cg_limit(int dtype) { (void)dtype; return 16LL * kSmallThreads; }
+// 90^2 x 128 5.3 against 31.6 us; at 128^2 (16384 cells on one CU: 11.4 us) the marching kernels win (9.2 us), so the
+// limit is 8192 cells.
+long long small_cg_limit(int dtype) { (void)dtype; return 8192; }
 
 template <typename T>
 static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
@@ -233,11 +233,16 @@ static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
     a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; a.prm.pad = 0;
     a.refresh_every = solve->refresh_every;
     a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
-    const int need = ceil_div(v.cells, kSmallThreads);
     LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-    if (need <= 2) launch_small<T, 2>(g, a, v.batch, flags != nullptr, s);
-    else if (need <= 8) launch_small<T, 8>(g, a, v.batch, flags != nullptr, s);
-    else launch_small<T, 16>(g, a, v.batch, flags != nullptr, s);
+    const bool fl = flags != nullptr;
+    // (threads, cells per thread) variants; LDS = 2 * threads * cells per thread * sizeof(T), so small grids leave room for
+    // several workgroups (batch entries) per CU. Measured (tools/sweep_cg2d.py, us per iteration, 512- vs 1024-thread form):
+    // 32^2 x 512: 3.96 / 5.6, 45^2 x 256: 2.91 / 3.19, 64^2 x 256: 4.16 / 4.03, 90^2 x 128: 6.6 / 5.3.
+    if (v.cells <= 1024) launch_small<T, 512, 2>(g, a, v.batch, fl, s);
+    else if (v.cells <= 2048) launch_small<T, 512, 4>(g, a, v.batch, fl, s);
+    else if (v.cells <= 4096) launch_small<T, 512, 8>(g, a, v.batch, fl, s);
+    else if (sizeof(T) == 8) launch_small<T, 512, 16>(g, a, v.batch, fl, s);   // fp64: 1024 x 8 would exceed 128 VGPRs by far
+    else launch_small<T, 1024, 8>(g, a, v.batch, fl, s);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }

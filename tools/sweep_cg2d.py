@@ -18,17 +18,18 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--lib", default="")
     args = ap.parse_args()
     n, B = args.size, args.batch
     dev = torch.device("cuda:0")
-    ctx = C.Context(C.load_default_library(), 0)
+    ctx = C.Context(C.Library(args.lib, strict=False) if args.lib else C.load_default_library(), 0)
     grid = C.make_grid(2, C.PHIHIP_F32, B, (n, n), (0, 0), (100.0, 100.0), ((1, 1), (1, 1)))
     rhs = torch.randn(B, n, n, generator=torch.Generator().manual_seed(0))
     rhs -= rhs.mean(dim=(1, 2), keepdim=True)
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, args.iters, 0, 0, 0)
-    ap_small = n * n <= 16384
+    ap_small = n * n <= 8192
     for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0), (1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
         ctx.set_small_grid_solver(rows < 0)          # rows = -1: the single-kernel solver (cg_small.hip)
         ctx.set_tuning(max(rows, 0), max(tpr, 0), 0)
