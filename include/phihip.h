@@ -62,6 +62,11 @@ typedef struct phihip_grid {
     double bc_val[3][2][3];   /* [axis][side][component] constant velocity on CLOSED sides (ZERO -> 0) */
 } phihip_grid;
 
+typedef enum phihip_method {
+    PHIHIP_METHOD_CG = 0,           /* Solve('CG', ...): alpha = r.r / d.Ad, beta = r'.r' / r.r */
+    PHIHIP_METHOD_CG_ADAPTIVE = 1   /* Solve('CG-adaptive', ...) (examples/grids/Fluid_Logo.ipynb): alpha = d.r / d.Ad, d' = r' - (r'.Ad / d.Ad) d */
+} phihip_method;
+
 /* phiml.math.Solve subset used by fluid.make_incompressible (phi/physics/fluid.py:96,145-156) */
 typedef struct phihip_solve {
     double rel_tol;           /* stop when ||r||^2 <= max(rel_tol^2 ||rhs||^2, abs_tol^2) (per batch entry) */
@@ -69,7 +74,7 @@ typedef struct phihip_solve {
     int32_t max_iterations;
     int32_t refresh_every;    /* recompute r = y - A x every n-th iteration (PhiML: 50); 0 = never */
     int32_t check_every;      /* host polls the device-side continue flags every n iterations; 0 = only at the end */
-    int32_t reserved;
+    int32_t method;           /* phihip_method: 0 = 'CG' (also what 'auto' maps to), 1 = 'CG-adaptive' */
 } phihip_solve;
 
 /* per batch entry result of the linear solve (phiml SolveInfo: iterations, residual, converged, diverged) */

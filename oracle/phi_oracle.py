@@ -577,6 +577,48 @@ def cg(apply_A, y: np.ndarray, x0: np.ndarray, rtol: float, atol: float, max_ite
     return x, SolveInfo(iterations, rsq, rhs_sq, converged, diverged)
 
 
+def cg_adaptive(apply_A, y: np.ndarray, x0: np.ndarray, rtol: float, atol: float, max_iter: int, refresh: int = 20):
+    """ PhiML's 'CG-adaptive' (`Solve('CG-adaptive', ...)`, /root/reference examples/grids/Fluid_Logo.ipynb):
+        the same loop as `cg` with   alpha = sum(d r) / sum(d q)   and   d = r - (sum(r q) / sum(d q)) d,
+        true-residual refresh every `refresh` iterations (0 = never). Parity unpinned: phiml is not available here. """
+    dtype = y.dtype.type
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        x = x0.astype(y.dtype).copy()
+        r = y - apply_A(x)
+        d = r.copy()
+        q = apply_A(d)
+        B = y.shape[0]
+        rhs_sq = _bsum(y * y)
+        tol_sq = np.maximum(dtype(rtol) ** 2 * rhs_sq, dtype(atol) ** 2)
+        rsq = _bsum(r * r)
+        rsq0 = rsq.copy()
+        iterations = np.zeros(B, dtype=np.int32)
+        diverged = ~np.all(np.isfinite(x.reshape(B, -1)), axis=1)
+        converged = rsq <= tol_sq
+        cont = ~converged & ~diverged & (iterations < max_iter)
+        it_counter = 0
+        while np.any(cont):
+            it_counter += 1
+            iterations += cont.astype(np.int32)
+            dq = _bsum(d * q)
+            dq_safe = np.where(dq != 0, dq, 1)
+            alpha = np.where(dq != 0, _bsum(d * r) / dq_safe, 0).astype(y.dtype)
+            alpha = alpha * cont.astype(y.dtype)
+            x = x + _bshape(alpha, x) * d
+            if refresh and it_counter % refresh == 0:
+                r = y - apply_A(x)
+            else:
+                r = r - _bshape(alpha, r) * q
+            rsq = _bsum(r * r)
+            beta = np.where(dq != 0, -_bsum(r * q) / dq_safe, 0).astype(y.dtype)
+            d = r + _bshape(beta, d) * d
+            q = apply_A(d)
+            diverged = (rsq / rsq0 > 100) & (iterations >= 8)
+            converged = rsq <= tol_sq
+            cont = cont & ~converged & ~diverged & (iterations < max_iter)
+    return x, SolveInfo(iterations, rsq, rhs_sq, converged, diverged)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # a7: obstacle masks (phi/physics/fluid.py:130-137,212-240,277-288; phi/geom/_box.py:174-185,217-236;
 #     phi/geom/_geom.py:278-308)
@@ -728,9 +770,9 @@ def balance_divergence(div: np.ndarray, active: Optional[np.ndarray]):
 
 
 def make_incompressible(v: List[np.ndarray], dom: Domain, obstacles=(), x0: Optional[np.ndarray] = None,
-                        rtol: float = 1e-5, atol: float = 0.0, max_iter: int = 1000, refresh: int = 50,
-                        balance: Optional[bool] = None):
-    """ returns (velocity, pressure, SolveInfo, div_rhs). """
+                        rtol: float = 1e-5, atol: float = 0.0, max_iter: int = 1000, refresh: Optional[int] = None,
+                        balance: Optional[bool] = None, method: str = 'CG'):
+    """ returns (velocity, pressure, SolveInfo, div_rhs). `method`: 'CG' (refresh 50) or 'CG-adaptive' (refresh 20). """
     dtype = v[0].dtype
     hard = active = None
     if obstacles:
@@ -745,7 +787,10 @@ def make_incompressible(v: List[np.ndarray], dom: Domain, obstacles=(), x0: Opti
     if x0 is None:
         x0 = np.zeros_like(div)
     A = lambda p: masked_laplace(p, dom, hard, active)
-    p, info = cg(A, rhs, x0, rtol, atol, max_iter, refresh)
+    if method == 'CG-adaptive':
+        p, info = cg_adaptive(A, rhs, x0, rtol, atol, max_iter, 20 if refresh is None else refresh)
+    else:
+        p, info = cg(A, rhs, x0, rtol, atol, max_iter, 50 if refresh is None else refresh)
     v_new = gradient_subtract(v, p, dom, hard)
     return v_new, p, info, rhs
 

@@ -85,7 +85,7 @@ def make_obstacles(items) -> "ctypes.Array":
 class Solve(ctypes.Structure):
     """ mirrors ``phihip_solve`` """
     _fields_ = [("rel_tol", c_double), ("abs_tol", c_double), ("max_iterations", c_int32), ("refresh_every", c_int32),
-                ("check_every", c_int32), ("reserved", c_int32)]
+                ("check_every", c_int32), ("method", c_int32)]
 
 
 class SolveInfo(ctypes.Structure):

@@ -371,6 +371,17 @@ static int check_solve(const phihip_solve* solve) {
     PHIHIP_REQUIRE(solve->max_iterations >= 0, "solve.max_iterations must be >= 0");
     PHIHIP_REQUIRE(solve->rel_tol >= 0 && solve->abs_tol >= 0, "solve tolerances must be >= 0");
     PHIHIP_REQUIRE(solve->refresh_every >= 0 && solve->check_every >= 0, "solve.refresh_every / check_every must be >= 0");
+    PHIHIP_REQUIRE(solve->method == PHIHIP_METHOD_CG || solve->method == PHIHIP_METHOD_CG_ADAPTIVE, "solve.method must be a phihip_method");
+    return PHIHIP_OK;
+}
+
+// the slab phases implement 'CG' only
+static int check_slab_solve(const phihip_solve* solve) {
+    PHIHIP_TRY(check_solve(solve));
+    if (solve->method != PHIHIP_METHOD_CG) {
+        set_error("slab-decomposed solve: only PHIHIP_METHOD_CG is available");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
     return PHIHIP_OK;
 }
 
@@ -412,7 +423,7 @@ int phihip_slab_matvec(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, in
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIHIP_REQUIRE(sums_in && r && d_old && d_new && sum_out && d_old != d_new, "slab_matvec: NULL or aliased argument");
     PHIHIP_REQUIRE((!halo_lo || (r_lo && d_lo)) && (!halo_hi || (r_hi && d_hi)), "slab_matvec: halo plane missing");
-    PHIHIP_TRY(check_solve(solve));
+    PHIHIP_TRY(check_slab_solve(solve));
     return run_slab_matvec(ctx, v, flags, 1, first, sums_in, r, r_lo, r_hi, d_old, d_lo, d_hi, d_new, sum_out, solve, (hipStream_t)stream);
 }
 
@@ -425,7 +436,7 @@ int phihip_slab_update(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, in
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIHIP_REQUIRE(sum_in && d && x && (x_only || (r && sum_out)), "slab_update: NULL argument");
     PHIHIP_REQUIRE(x_only || ((!halo_lo || d_lo) && (!halo_hi || d_hi)), "slab_update: halo plane missing");
-    PHIHIP_TRY(check_solve(solve));
+    PHIHIP_TRY(check_slab_solve(solve));
     return run_slab_update(ctx, v, flags, 1, sum_in, d, d_lo, d_hi, x, r, sum_out, x_only, solve, (hipStream_t)stream);
 }
 
@@ -436,7 +447,7 @@ int phihip_slab_state(phihip_ctx* ctx, const phihip_grid* grid, int first, const
     PHIHIP_TRY(make_view(grid, &v));
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIHIP_REQUIRE(sums_in != nullptr, "slab_state: sums_in is NULL");
-    PHIHIP_TRY(check_solve(solve));
+    PHIHIP_TRY(check_slab_solve(solve));
     return run_slab_finish(ctx, v, first, sums_in, solve, info, peek, (hipStream_t)stream);
 }
 

@@ -141,17 +141,28 @@ __global__ __launch_bounds__(kBlock) void cg_state_kernel(int kind, const CgStat
 
 // x += alpha * d for the true-residual refresh iterations (PhiML recomputes r = y - A x every 50th iteration)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const CgState* st_in, CgState* st_out, const double* part_dq, int nblk,
-                                                    CgParams prm, long long cells) {
+__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, int kind, const CgState* st_in, CgState* st_out, const double* part_dq,
+                                                    const double* part_dr, int nblk, CgParams prm, long long cells) {
     __shared__ double red[kBlock / kWave];
     __shared__ CgState sh;
     const int b = blockIdx.y;
-    const CgState S = cg_prologue(PRO_ALPHA, st_in, st_out, part_dq, nullptr, nblk, prm, b, blockIdx.x == 0, red, &sh);
+    const CgState S = cg_prologue(kind, st_in, st_out, part_dq, part_dr, nblk, prm, b, blockIdx.x == 0, red, &sh);
     if (S.cont == 0) return;
     const T alpha = (T)S.alpha;
     const long long base = (long long)b * cells;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock)
         x[base + i] = fma(alpha, d[base + i], x[base + i]);
+}
+
+// per-workgroup partial sums of a . b ('CG-adaptive' refresh iterations: r_new . A d with both vectors stored)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void dot_partials_kernel(const T* a, const T* b, long long cells, double* part) {
+    __shared__ double red[kBlock / kWave];
+    const long long base = (long long)blockIdx.y * cells;
+    T acc = T(0);
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock) acc += a[base + i] * b[base + i];
+    const double s = block_sum((double)acc, red);
+    if (threadIdx.x == 0) part[(long long)blockIdx.y * gridDim.x + blockIdx.x] = s;
 }
 
 __global__ void cg_export_residuals(const CgState* st, int batch, double* out) {
@@ -250,7 +261,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
-    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 3 * part_n * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * part_n * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
     if (ctx->host_state_bytes < (size_t)2 * v.batch * sizeof(CgState)) {
         if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -269,6 +280,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     double* part_rr = (double*)ctx->ws_part.ptr;
     double* part_dq = part_rr + part_n;
     double* part_yy = part_dq + part_n;
+    double* part_rq = part_yy + part_n;   // 'CG-adaptive' only: sum r_new . A d (UPDATE) and sum d . r (MATVEC)
+    double* part_dr = part_rq + part_n;
+    const bool ad = solve->method == PHIHIP_METHOD_CG_ADAPTIVE;
+    const int mode_mv = ad ? MODE_MATVEC_AD : MODE_MATVEC, mode_up = ad ? MODE_UPDATE_AD : MODE_UPDATE;
+    const int pro_alpha = ad ? PRO_ALPHA_AD : PRO_ALPHA, pro_beta = ad ? PRO_BETA_AD : PRO_BETA;
     CgState* st[2] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch};
     CgState* st_peek = (CgState*)ctx->ws_state.ptr + 2 * v.batch;
     int cur = 0;   // slot holding the most recent control block
@@ -301,20 +317,27 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         T* d_new = d[k & 1];
         {
             MarchArgs<T> a = base;
-            a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq;
-            a.prologue = first ? PRO_FIRST : PRO_BETA;
-            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = part_yy; a.nblk_in = nblk_rr;
+            a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq; a.part2 = part_dr;
+            a.prologue = first ? PRO_FIRST : pro_beta;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = (first || !ad) ? part_yy : part_rq; a.nblk_in = nblk_rr;
             LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c_mv, MODE_MATVEC, has_flags, g_mv, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, c_mv, mode_mv, has_flags, g_mv, a, s));
             cur ^= 1;
             first = false;
         }
         if (solve->refresh_every > 0 && k % solve->refresh_every == 0) {
             {
                 LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-                hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new,
-                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, g_mv.nblk, prm, v.cells);
+                hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new, pro_alpha,
+                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, (const double*)part_dr, g_mv.nblk, prm, v.cells);
                 cur ^= 1;
+            }
+            if (ad) {   // q = A d is not kept by the fused kernels: store it once (into the free d buffer) for sum r_new . q below
+                MarchArgs<T> a = base;
+                a.a = d_new; a.o1 = d_old;
+                a.prologue = PRO_NONE;
+                LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+                PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY, has_flags, g, a, s));
             }
             MarchArgs<T> a = base;
             a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = r;
@@ -324,13 +347,17 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
             PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
             nblk_rr = g.nblk;
+            if (ad) {
+                LaunchScope ls2(ctx, PHIHIP_K_OTHER, s);
+                hipLaunchKernelGGL(dot_partials_kernel<T>, dim3(g.nblk, v.batch), dim3(kBlock), 0, s, (const T*)r, (const T*)d_old, v.cells, part_rq);
+            }
         } else {
             MarchArgs<T> a = base;
-            a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr;
-            a.prologue = PRO_ALPHA;
-            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq; a.nblk_in = g_mv.nblk;
+            a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr; a.part2 = part_rq;
+            a.prologue = pro_alpha;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq; a.pin2 = part_dr; a.nblk_in = g_mv.nblk;
             LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c_up, MODE_UPDATE, has_flags, g_up, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, c_up, mode_up, has_flags, g_up, a, s));
             cur ^= 1;
             nblk_rr = g_up.nblk;
         }
@@ -342,8 +369,8 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             const int slot = checks & 1;
             {
                 LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur],
-                                   st_peek + (size_t)slot * v.batch, (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
+                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, pro_beta, (const CgState*)st[cur],
+                                   st_peek + (size_t)slot * v.batch, (const double*)part_rr, (const double*)(ad ? part_rq : part_yy), nblk_rr, prm);
             }
             PHIHIP_CHECK_HIP(hipMemcpyAsync(hst + (size_t)slot * v.batch, st_peek + (size_t)slot * v.batch, (size_t)v.batch * sizeof(CgState),
                                             hipMemcpyDeviceToHost, s));
@@ -359,8 +386,8 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     }
     {   // fold the last reduction into the control block (or build it when no iteration ran)
         LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-        hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : PRO_BETA), (const CgState*)st[cur],
-                           st[cur ^ 1], (const double*)part_rr, (const double*)part_yy, nblk_rr, prm);
+        hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : pro_beta), (const CgState*)st[cur],
+                           st[cur ^ 1], (const double*)part_rr, (const double*)((first || !ad) ? part_yy : part_rq), nblk_rr, prm);
         cur ^= 1;
     }
     ctx->last_state = st[cur];
@@ -487,8 +514,8 @@ static int slab_update_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
     if (x_only) {
         const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
         LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-        hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d, (const CgState*)su.st[ctx->slab_cur],
-                           su.st[ctx->slab_cur ^ 1], sum_in, 1, prm, v.cells);
+        hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d, (int)PRO_ALPHA,
+                           (const CgState*)su.st[ctx->slab_cur], su.st[ctx->slab_cur ^ 1], sum_in, (const double*)nullptr, 1, prm, v.cells);
         ctx->slab_cur ^= 1;
         PHIHIP_CHECK_HIP(hipGetLastError());
         return PHIHIP_OK;

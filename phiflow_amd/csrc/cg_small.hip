@@ -1,6 +1,7 @@
-// cg_small.hip -- the whole CG solve of a SMALL grid in one kernel: one 512-thread workgroup per batch entry, the search
-// direction d and q = A d live in LDS (128 KB of the CU's 160 KB), x / r / d of the thread's own cells in registers, alpha / beta / the
-// convergence logic in the workgroup -- no kernel boundary and no host polling inside the loop.
+// cg_small.hip -- the whole CG solve of a SMALL grid in one kernel: one 512- or 1024-thread workgroup per batch entry, the
+// search direction d and q = A d live in LDS (sized by the variant: 2 * threads * cells-per-thread words, <= 64 KB), x / r / d
+// of the thread's own cells in registers, alpha / beta / the convergence logic in the workgroup -- no kernel boundary and no
+// host polling inside the loop.
 //
 // Why: the marching kernels need two dependent launches per iteration, i.e. >= 9.5 us per iteration however small the grid
 // (tools/host_bound_check.py); PhiFlow's typical learning workloads are large batches of small simulations (64^2 ... 128^2),
@@ -11,13 +12,11 @@
 
 namespace phihip {
 
-// The per-cell loops are fully unrolled (register arrays need constant indices); without a scheduling fence the compiler hoists
-// all 6 * CPT LDS reads of a loop to its top and spills. The fence keeps one cell's stencil in flight at a time.
+// The per-cell loops are fully unrolled (register arrays need constant indices). Making the packed neighbour code opaque to the
+// optimiser keeps its decode inside the loop; hoisted, the decoded offsets cost 6 registers per cell and the kernel spills.
 #ifdef __HIP_DEVICE_COMPILE__
-#define PHIHIP_KEEP_ORDER() do { } while (0)
 #define PHIHIP_OPAQUE(v) asm volatile("" : "+v"(v))
 #else
-#define PHIHIP_KEEP_ORDER() do { } while (0)
 #define PHIHIP_OPAQUE(v) do { } while (0)
 #endif
 
@@ -31,6 +30,7 @@ struct SmallArgs {
     CgState* st_out;
     CgParams prm;
     int refresh_every;
+    int adaptive;          // 1: PhiML 'CG-adaptive' (alpha = d.r / d.q, beta = -(r'.q) / d.q)
     T w0, w1, w2;
 };
 
@@ -145,7 +145,6 @@ __global__ __launch_bounds__(NT) void cg_small_kernel(MarchGrid g, SmallArgs<T> 
                 a1 += r[k] * r[k];
                 a2 += y * y;
             }
-            PHIHIP_KEEP_ORDER();
         }
         rr = small_block_sum<NT>((double)a1, red);
         yy = small_block_sum<NT>((double)a2, red);
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(NT) void cg_small_kernel(MarchGrid g, SmallArgs<T> 
         __syncthreads();
         publish(d);
         __syncthreads();
-        T acc = T(0);
+        T acc = T(0), acc_dr = T(0);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int c = k * kSmallThreads + tid;
@@ -170,31 +169,41 @@ __global__ __launch_bounds__(NT) void cg_small_kernel(MarchGrid g, SmallArgs<T> 
                 const T q = apply(k, d[k]);
                 Q[c] = q;
                 acc += d[k] * q;
+                acc_dr += d[k] * r[k];
             }
-            PHIHIP_KEEP_ORDER();
         }
         const double dq = small_block_sum<NT>((double)acc, red);
-        S = cg_advance(PRO_ALPHA, S, dq, 0.0, p.prm);
+        if (p.adaptive) S = cg_advance(PRO_ALPHA_AD, S, dq, small_block_sum<NT>((double)acc_dr, red), p.prm);
+        else S = cg_advance(PRO_ALPHA, S, dq, 0.0, p.prm);
         const T alpha = (T)S.alpha;
         // ---- UPDATE: x += alpha d ; r -= alpha A d (or the true residual every refresh_every-th iteration) ----
 #pragma unroll
         for (int k = 0; k < CPT; ++k) x[k] = x[k] + alpha * d[k];
+        T a2 = T(0);   // sum r_new . q ('CG-adaptive')
         if (p.refresh_every > 0 && it % p.refresh_every == 0) {
             double dummy;
             residual(rr, dummy);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = k * kSmallThreads + tid;
+                if (c < cells) a2 += r[k] * Q[c];
+            }
         } else {
             T a1 = T(0);
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const int c = k * kSmallThreads + tid;
                 if (c < cells) {
-                    r[k] = r[k] - alpha * Q[c];
+                    const T q = Q[c];
+                    r[k] = r[k] - alpha * q;
                     a1 += r[k] * r[k];
+                    a2 += r[k] * q;
                 }
             }
             rr = small_block_sum<NT>((double)a1, red);
         }
-        S = cg_advance(PRO_BETA, S, rr, 0.0, p.prm);
+        if (p.adaptive) S = cg_advance(PRO_BETA_AD, S, rr, small_block_sum<NT>((double)a2, red), p.prm);
+        else S = cg_advance(PRO_BETA, S, rr, 0.0, p.prm);
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
@@ -232,6 +241,7 @@ static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
     a.st_out = st_out;
     a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; a.prm.pad = 0;
     a.refresh_every = solve->refresh_every;
+    a.adaptive = solve->method == PHIHIP_METHOD_CG_ADAPTIVE ? 1 : 0;
     a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
     LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
     const bool fl = flags != nullptr;

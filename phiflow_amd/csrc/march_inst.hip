@@ -1,5 +1,5 @@
 // march_inst.hip -- explicit instantiation + dispatch of march_kernel for one (element type, dimensionality) pair.
-// Compiled four times (-DPHIHIP_INST_F64=0|1 -DPHIHIP_INST_DIM3=0|1) so the ~50 kernels per pair build in parallel.
+// Compiled four times (-DPHIHIP_INST_F64=0|1 -DPHIHIP_INST_DIM3=0|1) so the ~80 kernels per pair build in parallel.
 #include "common.hpp"
 #include "march_dispatch.hpp"
 
@@ -16,8 +16,9 @@ constexpr int kVmax = 16 / sizeof(InstT);
 template <int V, int R, int TPR, int MODE, bool FLAGS>
 static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
     // the bidirectional variant exists for 3-D MATVEC only (the phase whose traffic is dominated by the stencil source)
-    if (MODE == MODE_MATVEC && kInstDim3 && g.bidir)
-        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (MODE == MODE_MATVEC && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
+    constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD;
+    if (mv && kInstDim3 && g.bidir)
+        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (mv && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
     else
         hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false>), grid, dim3(kBlock), 0, s, g, a);
 }
@@ -34,6 +35,8 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
         PHIHIP_MODE_CASE(MODE_RESID)
         PHIHIP_MODE_CASE(MODE_MATVEC)
         PHIHIP_MODE_CASE(MODE_UPDATE)
+        PHIHIP_MODE_CASE(MODE_MATVEC_AD)
+        PHIHIP_MODE_CASE(MODE_UPDATE_AD)
         default:
             set_error("march: bad mode %d", mode);
             return PHIHIP_ERR_BAD_ARG;

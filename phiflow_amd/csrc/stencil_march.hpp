@@ -13,6 +13,8 @@
 //   MATVEC  S = r + beta * d_old   d_new = S                       sum S * (A S)        (q = A d is never stored)
 //   UPDATE  S = d                  x += alpha S ; r -= alpha A S   sum r_new^2          (q recomputed from d)
 // so one CG iteration moves 3 + 5 = 8 words per cell through HBM instead of the textbook 10-11.
+// MATVEC_AD / UPDATE_AD are the same passes for PhiML's 'CG-adaptive' (SURVEY Appendix B.2): they additionally reduce
+// sum d * r resp. sum r_new * (A d), from which alpha = (d.r)/(d.q) and d = r - ((r.q)/(d.q)) d are formed.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,7 +26,7 @@ constexpr int kWave = 64;
 
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
                                                                             // neighbour slab's halo buffer (MarchArgs::a_lo ...)
-enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3 };
+enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5 };
 
 // Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
 // iteration: every workgroup of the NEXT kernel re-reduces the previous kernel's per-workgroup partial sums in a fixed order
@@ -46,7 +48,9 @@ enum CgPrologue {
     PRO_CONT = 1,       // read the continue flag only (true-residual refresh)
     PRO_FIRST = 2,      // build the control block from the initial residual's sums (rr, yy); beta = 0
     PRO_BETA = 3,       // rsq_new from the UPDATE / refresh partials: beta, convergence flags
-    PRO_ALPHA = 4       // dq from the MATVEC partials: alpha, iteration count
+    PRO_ALPHA = 4,      // dq from the MATVEC partials: alpha, iteration count
+    PRO_BETA_AD = 5,    // 'CG-adaptive': (rsq_new, r_new.q) -> beta = -(r.q)/(d.q), convergence flags
+    PRO_ALPHA_AD = 6    // 'CG-adaptive': (d.q, d.r) -> alpha = (d.r)/(d.q), iteration count
 };
 
 __device__ __forceinline__ bool cg_finite(double v) { return (v == v) && v <= 1.7e308 && v >= -1.7e308; }
@@ -62,19 +66,20 @@ __device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, 
         s.diverged = cg_finite(sum1) ? 0 : 1;
         s.converged = sum1 <= s.tol_sq ? 1 : 0;
         s.cont = (!s.converged && !s.diverged && prm.max_iter > 0) ? 1 : 0;
-    } else if (kind == PRO_BETA) {
+    } else if (kind == PRO_BETA || kind == PRO_BETA_AD) {
         if (s.cont) {
-            s.beta = s.rsq != 0 ? sum1 / s.rsq : 0;   // divide_no_nan
+            if (kind == PRO_BETA) s.beta = s.rsq != 0 ? sum1 / s.rsq : 0;   // divide_no_nan
+            else s.beta = s.dq != 0 ? -sum2 / s.dq : 0;
             s.rsq = sum1;
             s.diverged = (!cg_finite(sum1) || (s.rsq0 > 0 && sum1 / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
             s.converged = sum1 <= s.tol_sq ? 1 : 0;
             s.cont = (!s.converged && !s.diverged && s.iterations < prm.max_iter) ? 1 : 0;
         }
-    } else if (kind == PRO_ALPHA) {
+    } else if (kind == PRO_ALPHA || kind == PRO_ALPHA_AD) {
         if (s.cont) {
             s.iterations += 1;
             s.dq = sum1;
-            s.alpha = sum1 != 0 ? s.rsq / sum1 : 0;
+            s.alpha = sum1 != 0 ? (kind == PRO_ALPHA ? s.rsq : sum2) / sum1 : 0;
         }
     }
     return s;
@@ -99,9 +104,9 @@ struct MarchArgs {
     const CgState* st_in;  // [batch] control block written by the previous kernel
     CgState* st_out;       // [batch] slot for the next kernel (written by workgroup 0)
     const double* pin1;    // [batch][nblk] partial sums to reduce in the prologue
-    const double* pin2;    //               (PRO_FIRST: sum y^2)
+    const double* pin2;    //               (PRO_FIRST: sum y^2, PRO_ALPHA_AD: sum d r, PRO_BETA_AD: sum r q)
     double* part1;         // [batch][nblk] partial sums produced by this kernel
-    double* part2;         // [batch][nblk]
+    double* part2;         // [batch][nblk]   (RESID: sum y^2, MATVEC_AD: sum d r, UPDATE_AD: sum r q)
     CgParams prm;
     int prologue;          // CgPrologue
     int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
@@ -186,7 +191,7 @@ __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, C
     if (threadIdx.x == 0 && kind != PRO_FIRST) s = st_in[b];
     double s1 = 0, s2 = 0;
     if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
-    if (kind == PRO_FIRST) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
+    if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
     if (threadIdx.x == 0) {
         s = cg_advance(kind, s, s1, s2, prm);
         *sh = s;
@@ -206,6 +211,9 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     static_assert(2 * TPR + 2 * T1 <= kBlock, "halo items must fit one per thread");
     using VT = Vec<T, V>;
     using VF = Vec<uint8_t, V>;
+    constexpr bool IS_MV = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD;
+    constexpr bool IS_UP = MODE == MODE_UPDATE || MODE == MODE_UPDATE_AD;
+    constexpr bool AD = MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_AD;
 
     __shared__ __attribute__((aligned(16))) T lds[2][LROWS * LS];
     __shared__ double red[kBlock / kWave];
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     T alpha = T(0), beta = T(0);
+    T acc1 = T(0), acc2 = T(0);
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
@@ -246,15 +255,15 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R]) {
         bool zero = false;
         const T* pa = p.a + base;
-        const T* pb = MODE == MODE_MATVEC ? p.b + base : nullptr;
+        const T* pb = IS_MV ? p.b + base : nullptr;
         int ii = 0;
         if (DIM3) {
             if (i < 0 && g.nb[0][0] == NB_HALO) {
                 pa = p.a_lo + (long long)b * n1 * n2;
-                if (MODE == MODE_MATVEC) pb = p.b_lo + (long long)b * n1 * n2;
+                if (IS_MV) pb = p.b_lo + (long long)b * n1 * n2;
             } else if (i >= g.n0 && g.nb[0][1] == NB_HALO) {
                 pa = p.a_hi + (long long)b * n1 * n2;
-                if (MODE == MODE_MATVEC) pb = p.b_hi + (long long)b * n1 * n2;
+                if (IS_MV) pb = p.b_hi + (long long)b * n1 * n2;
             } else {
                 ii = nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero);
             }
@@ -264,10 +273,10 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             if (ok[rr] && !zero) {
                 const long long off = ((long long)ii * n1 + (j1b + rr)) * n2 + j2;
                 A[rr] = vec_load<T, V>(pa + off);
-                if (MODE == MODE_MATVEC) B[rr] = vec_load<T, V>(pb + off);
+                if (IS_MV) B[rr] = vec_load<T, V>(pb + off);
             } else {
                 A[rr] = vec_zero<T, V>();
-                if (MODE == MODE_MATVEC) B[rr] = vec_zero<T, V>();
+                if (IS_MV) B[rr] = vec_zero<T, V>();
             }
         }
     };
@@ -283,13 +292,18 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         alpha = (T)S.alpha;
         beta = (T)S.beta;
     }
-    auto combine = [&](const VT (&A)[R], const VT (&B)[R], VT (&S)[R]) {
+    // `own`: the plane belongs to this workgroup's chunk (MATVEC_AD sums d_new * r over exactly those)
+    auto combine = [&](const VT (&A)[R], const VT (&B)[R], VT (&S)[R], bool own) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             S[rr] = A[rr];
-            if (MODE == MODE_MATVEC) {
+            if (IS_MV) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) S[rr].v[v] = fma(beta, B[rr].v[v], A[rr].v[v]);
+                if (AD && own) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc2 += S[rr].v[v] * A[rr].v[v];
+                }
             }
         }
     };
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     // ---- source loaders ---------------------------------------------------------------------------------------------
     auto src_vec = [&](long long off) -> VT {
         VT s = vec_load<T, V>(p.a + base + off);
-        if (MODE == MODE_MATVEC) {
+        if (IS_MV) {
             VT d = vec_load<T, V>(p.b + base + off);
 #pragma unroll
             for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
@@ -306,13 +320,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     };
     auto src_one = [&](long long off) -> T {
         T s = p.a[base + off];
-        if (MODE == MODE_MATVEC) s = fma(beta, p.b[base + off], s);
+        if (IS_MV) s = fma(beta, p.b[base + off], s);
         return s;
     };
-    auto load_plane = [&](int i, VT (&S)[R]) {
+    auto load_plane = [&](int i, VT (&S)[R], bool own) {
         VT A[R], B[R];
         load_raw(i, A, B);
-        combine(A, B, S);
+        combine(A, B, S, own);
     };
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             if (!ok[rr]) continue;
             const long long off = ((long long)i * n1 + (j1b + rr)) * n2 + j2;
             if (MODE == MODE_RESID) E.e1[rr] = vec_load<T, V>(p.b + base + off);
-            if (MODE == MODE_UPDATE) {
+            if (IS_UP) {
                 E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
                 E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
             }
@@ -381,13 +395,12 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         Sp[rr] = vec_zero<T, V>();
         Sn[rr] = vec_zero<T, V>();
     }
-    if (DIM3) combine(Ra_p, Rb_p, Sp);
-    combine(Ra_c, Rb_c, Sc);
+    if (DIM3) combine(Ra_p, Rb_p, Sp, false);
+    combine(Ra_c, Rb_c, Sc, true);
     load_halo(i_first, hv_c, hs_c);
     load_extra(i_first, Ec);
     hv_n = hv_c; hs_n = hs_c; En = Ec;
 
-    T acc1 = T(0), acc2 = T(0);
     int buf = 0;
     const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
     const int lcol = V + tx * V;             // LDS column of this thread's vector
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     // Sp = the plane behind, Sn = the plane ahead in marching direction (the a0 stencil is symmetric in them)
     const unsigned bit_behind = step > 0 ? 1u : 2u, bit_ahead = step > 0 ? 2u : 1u;
     for (int k = 0, i = i_first; k < count; ++k, i += step) {
-        if (DIM3) load_plane(i + step, Sn);
+        if (DIM3) load_plane(i + step, Sn, k + 1 < count);
         if (k + 1 < count) {
             load_halo(i + step, hv_n, hs_n);
             load_extra(i + step, En);
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     acc2 += y * y;
                 }
                 vec_store<T, V>(p.o1 + off, r);
-            } else if (MODE == MODE_MATVEC) {
+            } else if (IS_MV) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc1 += Sc[rr].v[v] * q.v[v];
                 vec_store<T, V>(p.o1 + off, Sc[rr]);
@@ -473,6 +486,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
                     rn.v[v] = Ec.e2[rr].v[v] - alpha * q.v[v];
                     acc1 += rn.v[v] * rn.v[v];
+                    if (AD) acc2 += rn.v[v] * q.v[v];
                 }
                 vec_store<T, V>(p.o1 + off, xn);
                 vec_store<T, V>(p.o2 + off, rn);
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     if (MODE != MODE_APPLY) {
         const double s1 = block_sum((double)acc1, red);
         if (tid == 0) p.part1[(long long)b * g.nblk + blockIdx.x] = s1;
-        if (MODE == MODE_RESID) {
+        if (MODE == MODE_RESID || AD) {
             const double s2 = block_sum((double)acc2, red);
             if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
         }

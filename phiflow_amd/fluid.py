@@ -169,8 +169,8 @@ def make_incompressible(velocity: Field,
         raise NotImplementedError("HIP backend: make_incompressible implements order=2 only")
     if not velocity.is_staggered or wide_stencil:
         raise NotImplementedError("HIP backend: make_incompressible implements the StaggeredGrid path (wide_stencil=False) only")
-    if solve.method not in ('auto', 'CG'):
-        raise NotImplementedError(f"HIP backend: Solve(method={solve.method!r}) is not available, use 'CG' or 'auto'")
+    if solve.method not in Solve.METHODS:
+        raise NotImplementedError(f"HIP backend: Solve(method={solve.method!r}) is not available, use one of {tuple(Solve.METHODS)}")
     obstacles = _get_obstacles_for(obstacles, velocity)
     be = velocity.backend
     all_active = active is None
@@ -191,7 +191,7 @@ def make_incompressible(velocity: Field,
         _check_pressure_padding(x0.boundary, velocity.boundary, velocity.dims)
         pressure = x0.values.to(velocity.dtype)
         pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()
-    csolve = _capi.Solve(solve.rel_tol, solve.abs_tol, int(solve.max_iterations), int(solve.refresh_every), int(solve.check_every), 0)
+    csolve = solve.to_c(fp64)
     if autodiff.needs_grad(*velocity.values):
         # differentiable path: the same kernels behind torch.autograd.Function nodes (adjoint kernels in csrc/adjoint.hip)
         vin = [t.contiguous() for t in velocity.values]
@@ -199,7 +199,7 @@ def make_incompressible(velocity: Field,
         if obstacles:
             vin = list(_apply_obstacles_autograd(velocity, obstacles, vin))
         gsolve = solve.gradient_solve if getattr(solve, 'gradient_solve', None) is not None else solve
-        csolve_bwd = _capi.Solve(gsolve.rel_tol, gsolve.abs_tol, int(gsolve.max_iterations), int(gsolve.refresh_every), int(gsolve.check_every), 0)
+        csolve_bwd = gsolve.to_c(fp64)
         meta = dict(be=be, grid=velocity.grid_struct(), flags_ptr=flags.data_ptr() if flags is not None else 0, flags=flags, balance=balance,
                     csolve=csolve, csolve_bwd=csolve_bwd, shapes=shapes, dtype=velocity.dtype)
         *new_v, pressure = autodiff.MakeIncompressible.apply(meta, pressure.detach(), *vin)

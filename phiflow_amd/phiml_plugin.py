@@ -109,7 +109,7 @@ def make_incompressible(velocity, obstacles=(), solve=None, active=None, order: 
     from phi.physics import fluid as ref
     from phiml.math import Solve
     solve = Solve() if solve is None else solve
-    if active is not None or not _supported(velocity, order, wide_stencil=wide_stencil, correct_skew=correct_skew) or solve.method not in ('auto', 'CG'):
+    if active is not None or not _supported(velocity, order, wide_stencil=wide_stencil, correct_skew=correct_skew) or solve.method not in _hip.Solve.METHODS:
         return _ORIGINALS.get('make_incompressible', ref.make_incompressible)(velocity, obstacles, solve, active, order, correct_skew, wide_stencil)
     hv, batch = to_hip(velocity)
     obs = [_to_hip_obstacle(o) for o in ref._get_obstacles_for(obstacles, velocity)]

@@ -485,28 +485,28 @@ def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
         assert err <= tol(dtype)['stencil'] * 4, f"diffuse[{d}] rel err {err}"
 
 
-def solve_params(dtype, max_iter=1000, rtol=None, atol=0.0, refresh=50, check=10):
+def solve_params(dtype, max_iter=1000, rtol=None, atol=0.0, refresh=50, check=10, method=0):
     rtol = rtol if rtol is not None else (1e-5 if np.dtype(dtype) == np.float32 else 1e-10)
-    return C.Solve(rtol, atol, max_iter, refresh, check, 0)
+    return C.Solve(rtol, atol, max_iter, refresh, check, method)
 
 
 def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=50, flags_np=None, hard=None, active=None,
-             fixed_iterations=False):
+             fixed_iterations=False, adaptive=False):
     """ CG on a consistent rhs (balanced divergence of a random velocity) from x0 = 0; compares the pressure with the
-    oracle's CG modulo its mean and checks the iteration counts. """
+    oracle's CG modulo its mean and checks the iteration counts. `adaptive`: PhiML's 'CG-adaptive' (phihip_method 1). """
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)
     div = O.divergence(v, dom)
     if active is not None:
         div = div * active
     rhs = div if dom.flexible() else O.balance_divergence(div, active)
-    s = solve_params(dtype, max_iter, 0.0 if fixed_iterations else rtol, 0.0, refresh, 0 if fixed_iterations else 10)
+    s = solve_params(dtype, max_iter, 0.0 if fixed_iterations else rtol, 0.0, refresh, 0 if fixed_iterations else 10, 1 if adaptive else 0)
     drhs, dx = mem.to_dev(rhs.astype(dtype)), mem.to_dev(np.zeros_like(rhs))
     dflags = mem.to_dev(flags_np) if flags_np is not None else None
     info = ctx.cg_solve(grid, mem.ptr(dflags) if dflags is not None else 0, 1, mem.ptr(drhs), mem.ptr(dx), s)
     mem.sync()
     A = lambda q: O.masked_laplace(q, dom, hard, active)
-    xo, io = O.cg(A, rhs.astype(dtype), np.zeros_like(rhs), s.rel_tol, 0.0, max_iter, refresh)
+    xo, io = (O.cg_adaptive if adaptive else O.cg)(A, rhs.astype(dtype), np.zeros_like(rhs), s.rel_tol, 0.0, max_iter, refresh)
     x = mem.to_host(dx)
     singular = not dom.flexible()
     a, b = (demean(x), demean(xo)) if singular and active is None else (x, xo)

@@ -124,6 +124,20 @@ def test_cg_fixed_iterations_and_refresh(emu_ctx):
     pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, rng, max_iter=20, refresh=7, fixed_iterations=True)
 
 
+@pytest.mark.parametrize("res,bc", [GRIDS_2D[0], GRIDS_2D[-1], GRIDS_3D[0], GRIDS_3D[1]])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_adaptive_matches_oracle(emu_ctx, res, bc, dtype):
+    """ Solve('CG-adaptive') (Fluid_Logo.ipynb): both solvers, tolerance mode and fixed iterations + refresh """
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    try:
+        for small in (True, False):
+            emu_ctx.set_small_grid_solver(small)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(4), refresh=20, adaptive=True)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(6), max_iter=12, refresh=5, fixed_iterations=True, adaptive=True)
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+
+
 def test_batch_entries_converge_independently(emu_ctx):
     """ per-batch alpha / beta / stop (PhiML batch dims): a zero rhs entry stops at iteration 0, the other runs on """
     dtype = np.float32

@@ -178,6 +178,27 @@ def test_cg_matches_oracle(ctx, mem, res, bc, dtype):
         ctx.set_small_grid_solver(True)
 
 
+@pytest.mark.parametrize("res,bc", GRIDS[:9:2])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_adaptive_matches_oracle(ctx, mem, res, bc, dtype):
+    """ Solve('CG-adaptive') (Fluid_Logo.ipynb) on both solvers: tolerance mode, and fixed iterations with
+    the true-residual refresh (stored-q branch of the marching path) """
+    dom, grid = pc.make_case(res, bc, dtype, batch=2)
+    try:
+        for small in (True, False):
+            ctx.set_small_grid_solver(small)
+            pc.check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(4), refresh=20, adaptive=True)
+            pc.check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(6), max_iter=12, refresh=5, fixed_iterations=True, adaptive=True)
+    finally:
+        ctx.set_small_grid_solver(True)
+
+
+def test_cg_adaptive_64_cubed_fixed_iterations(ctx, mem):
+    rng = np.random.default_rng(5)
+    dom, grid = pc.make_case((64, 64, 64), ((PER, PER),) * 3, np.float32, upper=(2 * math.pi,) * 3)
+    pc.check_cg(ctx, mem, dom, grid, np.float32, rng, max_iter=100, refresh=20, fixed_iterations=True, adaptive=True)
+
+
 def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):
     """ the benchmark mode (tolerances 0, exactly 100 iterations, refresh at 50) at 64^3 periodic fp32:
     pressure within 1e-4 rel-L2 of the NumPy oracle (north-star tolerance) """

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--method", type=int, default=0, help="phihip_method: 0 = CG, 1 = CG-adaptive")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--configs", default="")
     ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
@@ -40,7 +41,7 @@ def main():
     rhs -= rhs.mean()
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
-    solve = C.Solve(0.0, 0.0, args.iters, 0, 0, 0)
+    solve = C.Solve(0.0, 0.0, args.iters, 0, 0, args.method)
     configs = [(r, t, c) for (r, t) in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)] for c in (8, 16, 32, 64, n)]
     if args.configs:
         configs = [tuple(int(v) for v in item.split(",")) for item in args.configs.split(";")]
@@ -53,7 +54,7 @@ def main():
             ctx.set_tuning(0, 0, 0)
             ctx.set_tuning_kernel(args.family, rows, tpr, chunk)
         x.zero_()
-        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, 0), want_info=False)   # warm-up
+        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, args.method), want_info=False)   # warm-up
         torch.cuda.synchronize()
         x.zero_()
         ctx.profile_enable(True)

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--method", type=int, default=0, help="phihip_method: 0 = CG, 1 = CG-adaptive")
     ap.add_argument("--lib", default="")
     args = ap.parse_args()
     n, B = args.size, args.batch
@@ -28,13 +29,13 @@ def main():
     rhs -= rhs.mean(dim=(1, 2), keepdim=True)
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
-    solve = C.Solve(0.0, 0.0, args.iters, 0, 0, 0)
+    solve = C.Solve(0.0, 0.0, args.iters, 0, 0, args.method)
     ap_small = n * n <= 8192
     for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0), (1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
         ctx.set_small_grid_solver(rows < 0)          # rows = -1: the single-kernel solver (cg_small.hip)
         ctx.set_tuning(max(rows, 0), max(tpr, 0), 0)
         x.zero_()
-        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, 0), want_info=False)
+        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, args.method), want_info=False)
         torch.cuda.synchronize()
         x.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
