@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g,
         face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
         T coord[3] = {T(0), T(0), T(0)};
 #pragma unroll
-        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - dt * u[a] / (T)g.dx[a];
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
         AxisPair<T> ax[3];
         T fr[3], dfr[3];
         lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g,
         if (want_gvel) {
             T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * (-dt / (T)g.dx[a]);   // coord_a = idx_a - dt u_a / dx_a
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
             face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du);
         }
     }
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, 
         center_velocity<T, DIM>(g, vel, b, idx, u);
         T coord[3] = {T(0), T(0), T(0)};
 #pragma unroll
-        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - dt * u[a] / (T)g.dx[a];
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
         AxisPair<T> ax[3];
         T fr[3], dfr[3];
         lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, 
         if (want_gvel) {
             T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * (-dt / (T)g.dx[a]);
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);
             center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
         }
     }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
         T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
 #pragma unroll
         for (int a = A0; a < 3; ++a) {
-            const T sft = dt * u[a] / (T)g.dx[a];
+            const T sft = u[a] * (dt * (T)g.rdx[a]);
             cb_[a] = (T)idx[a] - sft;
             cf_[a] = (T)idx[a] + sft;
         }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
             if (want_gvel) {
                 T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt / (T)g.dx[a]);   // cf_a = idx_a + dt u_a / dx_a
+                for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt * (T)g.rdx[a]);   // cf_a = idx_a + dt u_a / dx_a
                 if (STAG) face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du); else center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
             }
         }

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_kernel(VelGrid g, CCo
         T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
 #pragma unroll
         for (int a = A0; a < 3; ++a) {
-            const T sft = dt * u[a] / (T)g.dx[a];
+            const T sft = u[a] * (dt * (T)g.rdx[a]);
             cb_[a] = (T)idx[a] - sft;
             cf_[a] = (T)idx[a] + sft;
         }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void advect_centered_kernel(VelGrid g, Scal
         T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
 #pragma unroll
         for (int a = A0; a < 3; ++a) {
-            const T sft = dt * u[a] / (T)g.dx[a];
+            const T sft = u[a] * (dt * (T)g.rdx[a]);
             cb_[a] = (T)idx[a] - sft;
             cf_[a] = (T)idx[a] + sft;
         }

@@ -18,32 +18,52 @@ struct AxisPair {
     T cv[2];
 };
 
-template <typename T>
-__device__ __forceinline__ void resolve_axis(int i, int n, int stride, int code_lo, int code_hi, T c_lo, T c_hi, int& off, bool& cst, T& cv) {
-    cst = false;
-    cv = T(0);
-    if (i < 0) {
-        if (code_lo == PHIHIP_BC_PERIODIC) { i %= n; if (i < 0) i += n; }
-        else if (code_lo == PHIHIP_BC_CLOSED) { cst = true; cv = c_lo; i = 0; }
-        else i = 0;
-    } else if (i >= n) {
-        if (code_hi == PHIHIP_BC_PERIODIC) i %= n;
-        else if (code_hi == PHIHIP_BC_CLOSED) { cst = true; cv = c_hi; i = n - 1; }
-        else i = n - 1;
-    }
-    off = i * stride;
+// true when the predicate holds for any lane of the wavefront: lets interior wavefronts skip the constant-side selects with a
+// SCALAR branch (a per-lane `if` makes the compiler predicate both sides). The CPU emulation build has no wavefronts; there the
+// per-thread predicate selects the same values.
+__device__ __forceinline__ bool wave_any(bool pred) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+#else
+    return pred;
+#endif
 }
 
+// wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
+// branch that no wavefront takes at sensible CFL numbers
+__device__ __forceinline__ int wrap_index(int i, int n) {
+    i += i < 0 ? n : 0;
+    i -= i >= n ? n : 0;
+    if (__builtin_expect((unsigned)i >= (unsigned)n, 0)) {
+        i %= n;
+        if (i < 0) i += n;
+    }
+    return i;
+}
+
+// taps i_lo and i_lo + 1 of one axis under its boundary rule; every branch is wave-uniform (scalar)
 template <typename T>
 __device__ __forceinline__ AxisPair<T> make_pair(int i_lo, int n, int stride, int code_lo, int code_hi, T c_lo, T c_hi) {
     AxisPair<T> a;
-    if (i_lo >= 0 && i_lo + 1 < n) {   // interior fast path
+    if (!wave_any(i_lo < 0 || i_lo + 1 >= n)) {   // no lane of the wavefront touches the boundary (scalar branch)
         a.off[0] = i_lo * stride; a.off[1] = a.off[0] + stride;
         a.cst[0] = a.cst[1] = false;
         a.cv[0] = a.cv[1] = T(0);
+    } else if (code_lo == PHIHIP_BC_PERIODIC) {   // periodic is always set on both sides
+        const int w0 = wrap_index(i_lo, n);
+        const int w1 = w0 + 1 == n ? 0 : w0 + 1;
+        a.off[0] = w0 * stride; a.off[1] = w1 * stride;
+        a.cst[0] = a.cst[1] = false;
+        a.cv[0] = a.cv[1] = T(0);
     } else {
-        resolve_axis<T>(i_lo, n, stride, code_lo, code_hi, c_lo, c_hi, a.off[0], a.cst[0], a.cv[0]);
-        resolve_axis<T>(i_lo + 1, n, stride, code_lo, code_hi, c_lo, c_hi, a.off[1], a.cst[1], a.cv[1]);
+        const int i_hi = i_lo + 1;
+        const bool lo_c = code_lo == PHIHIP_BC_CLOSED, hi_c = code_hi == PHIHIP_BC_CLOSED;
+        a.off[0] = min(max(i_lo, 0), n - 1) * stride;
+        a.off[1] = min(max(i_hi, 0), n - 1) * stride;
+        a.cst[0] = (i_lo < 0 && lo_c) || (i_lo >= n && hi_c);
+        a.cst[1] = (i_hi < 0 && lo_c) || (i_hi >= n && hi_c);
+        a.cv[0] = i_lo < 0 ? c_lo : c_hi;
+        a.cv[1] = i_hi < 0 ? c_lo : c_hi;
     }
     return a;
 }
@@ -53,7 +73,7 @@ __device__ __forceinline__ AxisPair<T> make_pair(int i_lo, int n, int stride, in
 template <typename T, int DIM>
 __device__ __forceinline__ T gather_multilinear(const T* __restrict__ F, const AxisPair<T> (&ax)[3], const T (&fr)[3]) {
     constexpr int A0 = 3 - DIM;
-    const bool any_const = ax[2].cst[0] | ax[2].cst[1] | ax[1].cst[0] | ax[1].cst[1] | (DIM == 3 ? (ax[0].cst[0] | ax[0].cst[1]) : false);
+    const bool any_const = wave_any(ax[2].cst[0] | ax[2].cst[1] | ax[1].cst[0] | ax[1].cst[1] | (DIM == 3 ? (ax[0].cst[0] | ax[0].cst[1]) : false));
     T out = T(0);
 #pragma unroll
     for (int corner = 0; corner < (1 << DIM); ++corner) {
@@ -65,7 +85,7 @@ __device__ __forceinline__ T gather_multilinear(const T* __restrict__ F, const A
         w *= b1 ? fr[1] : (T(1) - fr[1]);
         w *= b2 ? fr[2] : (T(1) - fr[2]);
         T val;
-        if (!any_const) {
+        if (!any_const) {   // wave-uniform
             val = F[(DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2]];
         } else if (ax[2].cst[b2]) {
             val = ax[2].cv[b2];
@@ -128,12 +148,13 @@ __device__ __forceinline__ void face_velocity(const VelGrid& g, const CComp3a<T>
             // the later axis of (ca, cb) wins when both lie outside a constant side
             const bool a_last = ca > cb;
             T v[2][2];   // [ca offset][cb offset]
+            const bool any_const = wave_any(pa.cst[0] | pa.cst[1] | pb.cst[0] | pb.cst[1]);
 #pragma unroll
             for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
                     const bool ca_c = pa.cst[ia], cb_c = pb.cst[ib];
-                    if (ca_c || cb_c) {
+                    if (any_const && (ca_c || cb_c)) {
                         if (a_last) v[ia][ib] = ca_c ? pa.cv[ia] : pb.cv[ib];
                         else v[ia][ib] = cb_c ? pb.cv[ib] : pa.cv[ia];
                     } else {

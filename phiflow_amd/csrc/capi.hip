@@ -69,6 +69,7 @@ VelGrid make_velgrid(const GridView& v) {
         g.n[a] = v.n[a];
         g.off[a] = v.off[a];
         g.dx[a] = v.dx[a];
+        g.rdx[a] = 1.0 / v.dx[a];
         g.ccells[a] = v.ccells[a];
         for (int s = 0; s < 2; ++s) {
             g.bc[a][s] = v.bc[a][s];

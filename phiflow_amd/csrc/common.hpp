@@ -63,6 +63,7 @@ struct VelGrid {
     int bc[3][2];
     double bcv[3][2][3];
     double dx[3];
+    double rdx[3];     // 1 / dx (the back-trace works in index space: shift = u * (dt / dx))
     int ax0;
     long long cells;
     long long ccells[3];

@@ -39,7 +39,8 @@ def test_reference_style_scenarios(gpu_backend):
         host.test_identity_advection(gpu_backend, ext)
     for name, ext in (("closed", ZERO), ("open", BOUNDARY), ("periodic", PERIODIC), ("mixed", combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY)))):
         host.test_make_incompressible_staggered(gpu_backend, name, ext)
-    host.test_make_incompressible_matches_oracle(gpu_backend)
+    for method in ('CG', 'CG-adaptive', 'auto'):
+        host.test_make_incompressible_matches_oracle(gpu_backend, method)
     host.test_obstacles_and_x0(gpu_backend)
     host.test_moving_and_rotating_obstacles(gpu_backend)
     host.test_convergence_exceptions(gpu_backend)

@@ -22,15 +22,17 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--lib", default="")
+    ap.add_argument("--bc", type=int, default=0, help="boundary code of every side: 0 periodic, 1 closed, 2 open")
     args = ap.parse_args()
     n = args.size
     dev = torch.device("cuda:0")
     ctx = C.Context(C.Library(args.lib, strict=False) if args.lib else C.load_default_library(), 0)
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     L = 2 * math.pi
-    grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
+    grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((args.bc, args.bc),) * 3)
     g = torch.Generator().manual_seed(0)
-    v = [torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev) for _ in range(3)]
+    shapes = [tuple(n + (0, -1, 1)[args.bc] if a == d else n for a in range(3)) for d in range(3)]
+    v = [torch.randn(1, *sh, generator=g, dtype=tdt).to(dev) for sh in shapes]
     out = [torch.empty_like(t) for t in v]
     s = torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev)
     so = torch.empty_like(s)
@@ -46,10 +48,10 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.reps
 
-    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype,
+    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc,
            "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
            "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
-           "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((0, 0),) * 3, None, P(v), so.data_ptr(), dt)), 5)}
+           "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((args.bc and 2, args.bc and 2),) * 3, None, P(v), so.data_ptr(), dt)), 5)}
     res["GBs_semi_lagrangian_staggered"] = round(6 * n ** 3 * (8 if args.dtype == "f64" else 4) / res["ms_semi_lagrangian_staggered"] / 1e6, 1)
     print(json.dumps(res), flush=True)
 
