@@ -54,7 +54,7 @@ typedef enum phihip_bc { PHIHIP_BC_PERIODIC = 0, PHIHIP_BC_CLOSED = 1, PHIHIP_BC
 typedef struct phihip_grid {
     int32_t rank;             /* 2 or 3 */
     int32_t dtype;            /* phihip_dtype */
-    int32_t batch;            /* number of independent simulations (>= 1) */
+    int32_t batch;            /* number of independent simulations (1 ... 65535) */
     int32_t res[3];           /* cells per axis x, y[, z] */
     double lower[3];          /* Box bounds */
     double upper[3];

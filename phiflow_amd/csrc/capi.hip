@@ -20,6 +20,7 @@ int make_view(const phihip_grid* grid, GridView* out) {
     PHIHIP_REQUIRE(grid->rank == 2 || grid->rank == 3, "grid.rank must be 2 or 3 (got %d)", grid->rank);
     PHIHIP_REQUIRE(grid->dtype == PHIHIP_F32 || grid->dtype == PHIHIP_F64, "grid.dtype must be PHIHIP_F32 or PHIHIP_F64");
     PHIHIP_REQUIRE(grid->batch >= 1, "grid.batch must be >= 1");
+    PHIHIP_REQUIRE(grid->batch <= 65535, "grid.batch must be <= 65535 (the batch index is the y dimension of the launch grids; split larger batches)");
     GridView v;
     memset(&v, 0, sizeof(v));
     v.rank = grid->rank;

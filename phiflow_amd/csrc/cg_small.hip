@@ -30,6 +30,7 @@ struct SmallArgs {
     CgState* st_out;
     CgParams prm;
     int refresh_every;
+    int dim3;              // 1: rank-3 grid (a 3-D grid may have ONE plane, and its a0 boundary rule still applies)
     int adaptive;          // 1: PhiML 'CG-adaptive' (alpha = d.r / d.q, beta = -(r'.q) / d.q)
     T w0, w1, w2;
 };
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NT) void cg_small_kernel(MarchGrid g, SmallArgs<T> 
     const int n1 = g.n1, n2 = g.n2;
     const int s0 = n1 * n2, s1 = n2;
     const long long base = (long long)b * cells;
-    const bool dim3_ = g.n0 > 1;
+    const bool dim3_ = p.dim3 != 0;
 
     T x[CPT], r[CPT], d[CPT];
     unsigned code[CPT];
@@ -241,6 +242,7 @@ static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
     a.st_out = st_out;
     a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; a.prm.pad = 0;
     a.refresh_every = solve->refresh_every;
+    a.dim3 = v.rank == 3 ? 1 : 0;
     a.adaptive = solve->method == PHIHIP_METHOD_CG_ADAPTIVE ? 1 : 0;
     a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
     LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);

@@ -559,3 +559,31 @@ def check_make_incompressible(ctx, mem, dom, grid, dtype, rng, obstacles=(), max
         scale = max(np.abs(vo[d]).max(), 1e-30)
         assert np.abs(v_new[d] - vo[d]).max() <= 1e-4 * scale + (1e-5 if np.dtype(dtype) == np.float32 else 1e-9)
     return info
+
+
+# degenerate resolutions (one or two cells along an axis, single-plane 3-D grids) under every boundary kind
+DEGENERATE_GRIDS = [
+    ((1, 1), ((0, 0), (0, 0))), ((2, 2), ((1, 1), (1, 1))), ((1, 5), ((2, 2), (1, 1))), ((5, 1), ((0, 0), (2, 1))), ((2, 3), ((1, 2), (0, 0))),
+    ((1, 1, 1), ((2, 2),) * 3), ((1, 5, 3), ((0, 0), (1, 1), (2, 2))), ((3, 1, 2), ((1, 1), (0, 0), (1, 2))), ((2, 2, 2), ((1, 1),) * 3),
+    ((3, 2, 1), ((2, 1), (1, 2), (0, 0))),
+]
+
+
+def check_degenerate_grid(ctx, mem, res, bc, dtype, projection=True):
+    """ every kernel of the path on a degenerate grid, both CG solvers """
+    rng = np.random.default_rng(1)
+    dom, grid = make_case(res, bc, dtype, batch=2)
+    check_laplace(ctx, mem, dom, grid, dtype, rng)
+    check_divergence(ctx, mem, dom, grid, dtype, rng, balance=not dom.flexible())
+    check_grad_subtract(ctx, mem, dom, grid, dtype, rng)
+    check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7)
+    check_diffuse(ctx, mem, dom, grid, dtype, rng)
+    try:
+        for small in (True, False):
+            ctx.set_small_grid_solver(small)
+            check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(4))
+            check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(4), refresh=20, adaptive=True)
+            if projection:
+                check_make_incompressible(ctx, mem, dom, grid, dtype, np.random.default_rng(5))
+    finally:
+        ctx.set_small_grid_solver(True)

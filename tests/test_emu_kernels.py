@@ -138,6 +138,12 @@ def test_cg_adaptive_matches_oracle(emu_ctx, res, bc, dtype):
         emu_ctx.set_small_grid_solver(True)
 
 
+@pytest.mark.parametrize("res,bc", pc.DEGENERATE_GRIDS[::2] + [pc.DEGENERATE_GRIDS[5]])
+def test_degenerate_grids(emu_ctx, res, bc):
+    """ one / two cells along an axis, 3-D grids with a single plane (whose a0 boundary rule still applies) """
+    pc.check_degenerate_grid(emu_ctx, MEM, res, bc, np.float32, projection=False)
+
+
 def test_batch_entries_converge_independently(emu_ctx):
     """ per-batch alpha / beta / stop (PhiML batch dims): a zero rhs entry stops at iteration 0, the other runs on """
     dtype = np.float32
@@ -240,6 +246,13 @@ def test_bad_arguments_are_reported(emu_ctx, emu_library):
     bad = pc.C.make_grid(2, 0, 1, (8, 8), (0, 0), (8, 8), ((PER, CLO), (PER, PER)))
     with pytest.raises(pc.C.PhiHipError):
         emu_ctx.component_shape(bad, 0)
+    for batch in (0, 65536):                                      # empty and oversized batches are rejected, not launched
+        with pytest.raises(pc.C.PhiHipError) as e:
+            emu_ctx.component_shape(pc.C.make_grid(2, 0, batch, (8, 8), (0, 0), (8, 8), ((PER, PER), (PER, PER))), 0)
+        assert e.value.status == -1 and "batch" in str(e.value)
+    with pytest.raises(pc.C.PhiHipError) as e:                    # unknown solve method
+        emu_ctx.cg_solve(grid, 0, 1, 8, 16, pc.C.Solve(1e-5, 0.0, 10, 50, 10, 7))
+    assert e.value.status == -1 and "method" in str(e.value)
 
 
 def test_bad_arguments_of_the_widened_entry_points(emu_ctx):

@@ -199,6 +199,13 @@ def test_cg_adaptive_64_cubed_fixed_iterations(ctx, mem):
     pc.check_cg(ctx, mem, dom, grid, np.float32, rng, max_iter=100, refresh=20, fixed_iterations=True, adaptive=True)
 
 
+@pytest.mark.parametrize("res,bc", pc.DEGENERATE_GRIDS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_degenerate_grids(ctx, mem, res, bc, dtype):
+    """ one / two cells along an axis, 3-D grids with a single plane (whose a0 boundary rule still applies) """
+    pc.check_degenerate_grid(ctx, mem, res, bc, dtype)
+
+
 def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):
     """ the benchmark mode (tolerances 0, exactly 100 iterations, refresh at 50) at 64^3 periodic fp32:
     pressure within 1e-4 rel-L2 of the NumPy oracle (north-star tolerance) """
