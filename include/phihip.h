@@ -139,7 +139,10 @@ typedef enum phihip_obstacle_kind { PHIHIP_OBSTACLE_BOX = 0, PHIHIP_OBSTACLE_SPH
 /* Obstacle(geometry, velocity, angular_velocity) with geometry = Box / Cuboid (center, half_size) or Sphere (center, radius) */
 typedef struct phihip_obstacle {
     int32_t kind;                 /* phihip_obstacle_kind */
-    int32_t reserved;
+    int32_t group;                /* 0: an obstacle of its own. > 0: CONSECUTIVE entries with the same value form ONE obstacle whose
+                                   * geometry is their union (phi.geom.union, phi/geom/_geom_ops.py:96-102, _box.py:235): inside = any,
+                                   * signed distance = min, i.e. soft mask = max over the members. At most 16 members; they share
+                                   * `velocity`, and `angular_velocity` must be 0. */
     double center[3];             /* x, y[, z] */
     double half_size[3];          /* box: half extents; sphere: half_size[0] = radius */
     double velocity[3];           /* linear velocity of the obstacle */

@@ -675,6 +675,31 @@ class SphereObstacle:
         return np.sqrt(d2) - self.radius
 
 
+@dataclass
+class UnionObstacle:
+    """ Obstacle(union(geometries)) (phi/geom/_geom_ops.py:96-102, 297-319; stacked boxes: phi/geom/_box.py:175,235): inside = any
+    member, signed distance = min over the members; one linear velocity for the whole body, no rotation """
+    members: Tuple[object, ...]
+    velocity: Optional[Tuple[float, ...]] = None
+    angular_velocity: Optional[object] = None
+
+    @property
+    def center(self):
+        return self.members[0].center      # only used with an angular velocity, which unions do not have here
+
+    def lies_inside(self, pts):
+        out = self.members[0].lies_inside(pts)
+        for m in self.members[1:]:
+            out = out | m.lies_inside(pts)
+        return out
+
+    def sdf(self, pts):
+        out = self.members[0].sdf(pts)
+        for m in self.members[1:]:
+            out = np.minimum(out, m.sdf(pts))
+        return out
+
+
 def obstacle_masks(obstacles, dom: Domain, dtype=np.float32):
     """ returns (active[cells] in {0,1}, hard_bcs[d][faces] in {0,1}, soft[d][faces] in [0,1]).
       accessible = ~union(obstacles) sampled hard at cell centres; outside-domain accessibility from

@@ -318,6 +318,14 @@ static int check_obstacles(const GridView& v, const phihip_obstacle* obstacles, 
                        obstacles[k].kind);
         const int nh = obstacles[k].kind == PHIHIP_OBSTACLE_SPHERE ? 1 : v.rank;
         for (int d = 0; d < nh; ++d) PHIHIP_REQUIRE(obstacles[k].half_size[d] >= 0, "obstacle %d: negative size", k);
+        PHIHIP_REQUIRE(obstacles[k].group >= 0, "obstacle %d: group must be >= 0", k);
+        if (obstacles[k].group > 0) {   // member of a union: one rigid body without rotation
+            for (int d = 0; d < 3; ++d)
+                PHIHIP_REQUIRE(obstacles[k].angular_velocity[d] == 0.0, "obstacle %d: members of a union (group > 0) cannot rotate", k);
+            if (k > 0 && obstacles[k - 1].group == obstacles[k].group)
+                for (int d = 0; d < v.rank; ++d)
+                    PHIHIP_REQUIRE(obstacles[k].velocity[d] == obstacles[k - 1].velocity[d], "obstacle %d: members of a union must share their velocity", k);
+        }
     }
     return PHIHIP_OK;
 }

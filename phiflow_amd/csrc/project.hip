@@ -390,6 +390,7 @@ struct ObstacleSet {
     double rot[kObstaclesPerLaunch][3][3];   // box frame -> world, internal axis order
     int moving[kObstaclesPerLaunch];
     int rotated[kObstaclesPerLaunch];
+    int group[kObstaclesPerLaunch];          // > 0: consecutive entries with the same value are ONE obstacle (union of the members)
 };
 
 static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* obs, int first, int count) {
@@ -399,6 +400,7 @@ static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* o
     for (int k = 0; k < count; ++k) {
         const phihip_obstacle& o = obs[first + k];
         s.kind[k] = o.kind;
+        s.group[k] = o.group;
         bool moving = false;
         for (int d = 0; d < v.rank; ++d) {
             s.center[k][d + v.ax0] = o.center[d];
@@ -523,9 +525,16 @@ __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, doub
         double x[3] = {0, 0, 0};
         for (int a = g.ax0; a < 3; ++a) x[a] = a == ca ? lower[a] + (double)(idx[a] + g.off[a]) * g.dx[a] : lower[a] + (idx[a] + 0.5) * g.dx[a];
         T val = V[f];
+        double m_union = 0.0;
         for (int k = 0; k < s.count; ++k) {
             double m = 1.0 - obstacle_sdf(s, k, x, g.ax0) / radius;
             m = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+            if (s.group[k] != 0) {   // union: sdf = min over the members <=> mask = max; applied once, after the last member
+                const bool cont = k > 0 && s.group[k - 1] == s.group[k];
+                m_union = cont && m_union > m ? m_union : m;
+                if (k + 1 < s.count && s.group[k + 1] == s.group[k]) continue;
+                m = m_union;
+            }
             const T mt = (T)m, keep = T(1) - mt;
             val = keep == T(0) ? T(0) : keep * val;   // safe_mul(1 - mask, velocity)
             if (s.moving[k]) {
@@ -548,8 +557,14 @@ __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, doub
 int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, void* const vel[3], hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    for (int first = 0; first < count; first += kObstaclesPerLaunch) {
-        const int n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
+    for (int first = 0, n = 0; first < count; first += n) {
+        n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
+        // a union is applied by ONE launch: do not cut inside a group
+        while (n > 0 && first + n < count && obs[first + n].group != 0 && obs[first + n].group == obs[first + n - 1].group) --n;
+        if (n == 0) {
+            set_error("apply_obstacles: a union (group %d) has more than %d members", obs[first].group, kObstaclesPerLaunch);
+            return PHIHIP_ERR_UNSUPPORTED;
+        }
         const ObstacleSet set = make_obstacle_set(v, obs, first, n);
         for (int ca = v.ax0; ca < 3; ++ca) {
             const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;

@@ -15,6 +15,7 @@ from . import _capi, autodiff
 from .extrapolation import pressure_extrapolation
 from .field import Field, _check_pressure_padding, _ptrs
 from .geom import Box, Geometry, Sphere
+from .geom import Union as Union_
 from .solve import Diverged, NotConverged, Solve, SolveInfo
 
 
@@ -81,24 +82,32 @@ def _get_obstacles_for(obstacles, velocity: Field) -> List[Obstacle]:
 
 
 def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field):
-    """ ctypes array of `phihip_obstacle` in the velocity's dimension order """
+    """ (ctypes array of `phihip_obstacle` in the velocity's dimension order, entry count); a `union` geometry becomes one group of
+    consecutive entries """
     items = []
+    group = 0
     for ob in obstacles:
-        geo = ob.geometry
-        order = [geo.dims.index(d) for d in velocity.dims]
-        if isinstance(geo, Sphere):
-            kind, half = _capi.OBSTACLE_SPHERE, [geo.radius] * len(order)
-        elif isinstance(geo, Box):
-            kind, half = _capi.OBSTACLE_BOX, [geo.half_size[i] for i in order]
-        else:
-            raise NotImplementedError(f"HIP backend: obstacle geometry {type(geo).__name__} is not supported (Box / Cuboid / Sphere)")
-        ang = ob.angular_velocity if len(order) == 2 else [ob.angular_velocity[i] for i in order]
-        rot = None
-        if isinstance(geo, Box) and geo.rot is not None:
-            rot = [[geo.rot[i][j] for j in order] for i in order]
-        items.append(dict(kind=kind, center=[geo.center[i] for i in order], half_size=half, velocity=[ob.velocity[i] for i in order],
-                          angular_velocity=ang, rotation=rot))
-    return _capi.make_obstacles(items)
+        members = ob.geometry.geometries if isinstance(ob.geometry, Union_) else (ob.geometry,)
+        if len(members) > 1:
+            group += 1
+            if ob.is_rotating:
+                raise NotImplementedError("HIP backend: a union obstacle cannot have an angular velocity")
+        for geo in members:
+            order = [geo.dims.index(d) for d in velocity.dims]
+            if isinstance(geo, Sphere):
+                kind, half = _capi.OBSTACLE_SPHERE, [geo.radius] * len(order)
+            elif isinstance(geo, Box):
+                kind, half = _capi.OBSTACLE_BOX, [geo.half_size[i] for i in order]
+            else:
+                raise NotImplementedError(f"HIP backend: obstacle geometry {type(geo).__name__} is not supported (Box / Cuboid / Sphere / union)")
+            vel_order = [ob.geometry.dims.index(d) for d in velocity.dims]
+            ang = ob.angular_velocity if len(order) == 2 else [ob.angular_velocity[i] for i in vel_order]
+            rot = None
+            if isinstance(geo, Box) and geo.rot is not None:
+                rot = [[geo.rot[i][j] for j in order] for i in order]
+            items.append(dict(kind=kind, center=[geo.center[i] for i in order], half_size=half, velocity=[ob.velocity[i] for i in vel_order],
+                              angular_velocity=ang, rotation=rot, group=group if len(members) > 1 else 0))
+    return _capi.make_obstacles(items), len(items)
 
 
 class _MaskCache:
@@ -129,7 +138,7 @@ def _build_flags(velocity: Field, obstacles: Sequence[Obstacle], user_active: Op
     accessible_t = None
     if obstacles:
         accessible_t = be.empty(res, torch.uint8)
-        be.ctx.obstacle_accessible(grid1, _obstacle_array(obstacles, velocity), len(obstacles), accessible_t.data_ptr(), be.stream())
+        be.ctx.obstacle_accessible(grid1, *_obstacle_array(obstacles, velocity), accessible_t.data_ptr(), be.stream())
     active_t = None
     if user_active is not None:
         assert user_active.is_centered and user_active.resolution == velocity.resolution
@@ -208,7 +217,7 @@ def make_incompressible(velocity: Field,
     else:
         new_v = [t.clone() for t in velocity.values]
         if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
-            be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
+            be.ctx.apply_obstacles(velocity.grid_struct(), *_obstacle_array(obstacles, velocity), _ptrs(new_v), be.stream())
         infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
                                            flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
                                            True, be.stream())
@@ -223,8 +232,9 @@ def make_incompressible(velocity: Field,
 
 def _apply_obstacles_autograd(velocity: Field, obstacles, vin):
     still = [Obstacle(ob.geometry) for ob in obstacles]
-    meta = dict(be=velocity.backend, grid=velocity.grid_struct(), obstacles=_obstacle_array(obstacles, velocity),
-                obstacles_still=_obstacle_array(still, velocity), count=len(obstacles), shapes=[tuple(t.shape) for t in vin], dtype=velocity.dtype)
+    arr, count = _obstacle_array(obstacles, velocity)
+    meta = dict(be=velocity.backend, grid=velocity.grid_struct(), obstacles=arr, obstacles_still=_obstacle_array(still, velocity)[0], count=count,
+                shapes=[tuple(t.shape) for t in vin], dtype=velocity.dtype)
     return autodiff.ApplyObstacles.apply(meta, *vin)
 
 
@@ -252,7 +262,7 @@ def apply_boundary_conditions(velocity: Field, obstacles) -> Field:
     if autodiff.needs_grad(*velocity.values):
         return velocity.with_values(list(_apply_obstacles_autograd(velocity, obstacles, [t.contiguous() for t in velocity.values])))
     new_v = [t.clone() for t in velocity.values]
-    be.ctx.apply_obstacles(velocity.grid_struct(), _obstacle_array(obstacles, velocity), len(obstacles), _ptrs(new_v), be.stream())
+    be.ctx.apply_obstacles(velocity.grid_struct(), *_obstacle_array(obstacles, velocity), _ptrs(new_v), be.stream())
     return velocity.with_values(new_v)
 
 

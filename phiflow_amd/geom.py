@@ -46,6 +46,48 @@ class Geometry:
         raise NotImplementedError
 
 
+class Union(Geometry):
+    """ `union(*geometries)` (phi/geom/_geom_ops.py:297-319): a point lies inside if it lies inside any member; the signed distance is
+    the minimum over the members (phi/geom/_geom_ops.py:96-102, phi/geom/_box.py:235) """
+
+    def __init__(self, geometries: Sequence[Geometry]):
+        self.geometries = tuple(geometries)
+        assert self.geometries, "empty union"
+        self.dims = self.geometries[0].dims
+        assert all(set(g.dims) == set(self.dims) for g in self.geometries), "members of a union must share their dimensions"
+
+    def lies_inside(self, points):
+        out = None
+        for g in self.geometries:
+            pts = [points[self.dims.index(d)] for d in g.dims]
+            inside = g.lies_inside(pts)
+            out = inside if out is None else (out | inside)
+        return out
+
+    def approximate_signed_distance(self, points):
+        out = None
+        for g in self.geometries:
+            pts = [points[self.dims.index(d)] for d in g.dims]
+            dist = g.approximate_signed_distance(pts)
+            out = dist if out is None else np.minimum(out, dist)
+        return out
+
+    def shifted(self, delta):
+        return Union([g.shifted(delta) for g in self.geometries])
+
+    def __repr__(self):
+        return "union(" + ", ".join(repr(g) for g in self.geometries) + ")"
+
+
+def union(*geometries) -> Geometry:
+    """ `union(geometries)` / `union(g1, g2, ...)`; nested unions are flattened, a single geometry is returned as it is """
+    geometries = geometries[0] if len(geometries) == 1 and isinstance(geometries[0], (tuple, list)) else geometries
+    flat = []
+    for g in geometries:
+        flat.extend(g.geometries if isinstance(g, Union) else [g])
+    return flat[0] if len(flat) == 1 else Union(flat)
+
+
 class _BoxType(type):
     def __getitem__(cls, item):
         """ `Box['x,y', 0:100, 0:100]` (tests/commit/physics/test_fluid.py:23) """

@@ -236,33 +236,39 @@ def check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_cons
 
 
 def obstacle_items(obstacles, rank):
-    """ oracle obstacles -> dicts for _capi.make_obstacles """
+    """ oracle obstacles -> dicts for _capi.make_obstacles (a UnionObstacle becomes one group of consecutive entries) """
     items = []
+    group = 0
     for ob in obstacles:
         lin = list(ob.velocity) if ob.velocity is not None else [0.0] * rank
         ang = ob.angular_velocity if ob.angular_velocity is not None else 0.0
         ang = list(ang) if isinstance(ang, (tuple, list, np.ndarray)) else [float(ang)]
-        if isinstance(ob, O.SphereObstacle):
-            items.append(dict(kind=C.OBSTACLE_SPHERE, center=ob.center, half_size=[ob.radius] * rank, velocity=lin, angular_velocity=ang))
-        else:
-            half = [(u - l) / 2 for l, u in zip(ob.lower, ob.upper)]
-            items.append(dict(kind=C.OBSTACLE_BOX, center=ob.center, half_size=half, velocity=lin, angular_velocity=ang, rotation=ob.rotation))
+        union = isinstance(ob, O.UnionObstacle)
+        group += 1 if union else 0
+        for m in (ob.members if union else (ob,)):
+            extra = dict(velocity=lin, angular_velocity=ang, group=group if union else 0)
+            if isinstance(m, O.SphereObstacle):
+                items.append(dict(kind=C.OBSTACLE_SPHERE, center=m.center, half_size=[m.radius] * rank, **extra))
+            else:
+                half = [(u - l) / 2 for l, u in zip(m.lower, m.upper)]
+                items.append(dict(kind=C.OBSTACLE_BOX, center=m.center, half_size=half, rotation=m.rotation, **extra))
     return items
 
 
 def check_obstacle_kernels(ctx, mem, dom, grid, dtype, rng, obstacles):
     """ the hard cell mask and apply_boundary_conditions (stationary, moving and rotating obstacles) on the device """
     B = grid.batch
-    arr = C.make_obstacles(obstacle_items(obstacles, dom.rank))
+    items = obstacle_items(obstacles, dom.rank)
+    arr = C.make_obstacles(items)
     g1 = C.make_grid(dom.rank, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
     dacc = mem.empty(dom.res, np.uint8)
-    ctx.obstacle_accessible(g1, arr, len(obstacles), mem.ptr(dacc))
+    ctx.obstacle_accessible(g1, arr, len(items), mem.ptr(dacc))
     mem.sync()
     active, hard, soft = O.obstacle_masks(obstacles, dom, dtype)
     assert np.array_equal(mem.to_host(dacc), (active[0] > 0).astype(np.uint8))
     v = random_velocity(dom, B, dtype, rng)
     dv = [mem.to_dev(a) for a in v]
-    ctx.apply_obstacles(grid, arr, len(obstacles), [mem.ptr(a) for a in dv])
+    ctx.apply_obstacles(grid, arr, len(items), [mem.ptr(a) for a in dv])
     mem.sync()
     ref = O.apply_boundary_conditions(v, obstacles, dom)
     for d in range(dom.rank):

@@ -214,6 +214,34 @@ def test_obstacle_rasterisation_and_moving_obstacles(emu_ctx):
     pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, many)
 
 
+def test_union_obstacles(emu_ctx):
+    """ Obstacle(union(geometries)) (examples/grids/Fluid_Logo.ipynb): inside = any member, soft mask = max over the members --
+    not the product the same members give as separate obstacles; groups next to plain obstacles, across the 16-per-launch split """
+    rng = np.random.default_rng(21)
+    O = pc.O
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((24, 20), ((CLO, CLO), (OPN, OPN)), dtype, batch=2)
+        logo = O.UnionObstacle((O.BoxObstacle((4.0, 3.0), (7.0, 12.0)), O.BoxObstacle((7.0, 9.0), (13.0, 12.0)), O.SphereObstacle((13.5, 10.0), 2.2)))
+        drifting = O.UnionObstacle((O.BoxObstacle((15.0, 2.0), (18.0, 5.0)), O.BoxObstacle((17.5, 4.0), (21.0, 7.5))), velocity=(0.3, -0.2))
+        obstacles = [O.SphereObstacle((9.0, 16.0), 2.0, angular_velocity=0.5), logo, drifting, O.BoxObstacle((1.0, 15.0), (4.0, 18.5))]
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng, obstacles)
+        separate = list(logo.members)
+        a = O.apply_boundary_conditions(pc.random_velocity(dom, 1, dtype, np.random.default_rng(3)), [logo], dom)
+        b = O.apply_boundary_conditions(pc.random_velocity(dom, 1, dtype, np.random.default_rng(3)), separate, dom)
+        assert max(np.abs(x - y).max() for x, y in zip(a, b)) > 1e-3          # the union is a different obstacle than its members
+    dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO), (PER, PER), (CLO, OPN)), np.float32, batch=1)
+    pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng,
+                              [O.UnionObstacle((O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 9.0)), O.SphereObstacle((7.0, 6.0, 10.0), 2.5)))])
+    dom, grid = pc.make_case((32, 32), ((CLO, CLO), (CLO, CLO)), np.float32, batch=1)
+    many = [O.SphereObstacle((2.0 + 1.5 * k, 3.0 + 1.2 * k), 1.0) for k in range(12)]
+    many.append(O.UnionObstacle(tuple(O.SphereObstacle((28.0 - 1.4 * k, 4.0 + 1.3 * k), 1.2) for k in range(9))))   # straddles entry 16
+    pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, many)
+    too_many = [O.UnionObstacle(tuple(O.SphereObstacle((2.0 + k, 3.0 + k), 1.0) for k in range(17)))]
+    with pytest.raises(pc.C.PhiHipError) as e:
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, too_many)
+    assert e.value.status == -3
+
+
 @pytest.mark.parametrize("res,bc", GRIDS_2D[:4] + GRIDS_3D[:2])
 def test_make_incompressible_matches_oracle_and_is_divergence_free(emu_ctx, res, bc):
     rng = np.random.default_rng(9)

@@ -168,6 +168,45 @@ def test_moving_and_rotating_obstacles(emu_backend):
     assert np.abs(vo[1]).max() > 0.5
 
 
+def test_fluid_logo_union_obstacle_and_cg_adaptive(emu_backend):
+    """ examples/grids/Fluid_Logo.ipynb (cells 2-5) at 32^2: obstacle = union(boxes), inflow = CenteredGrid(Box), smoke and velocity
+    advected semi-Lagrangian, buoyancy resampled to the faces, Solve('CG-adaptive', 1e-5, x0=pressure) starting from pressure None """
+    from oracle import phi_oracle as O
+    from phiflow_amd.flow import resample, union
+    n = 32
+    domain = dict(x=n, y=n, bounds=Box(x=100, y=100))
+    geometries = [Box(x=(15 + x * 7, 15 + (x + 1) * 7), y=(41, 83)) for x in range(1, 10, 2)] + [Box['x,y', 43:50, 41:48], Box['x,y', 15:43, 83:90], Box['x,y', 50:85, 83:90]]
+    geometry = union(geometries)
+    assert union(geometry, geometries[0]).geometries[-1] is geometries[0] and union([geometries[0]]) is geometries[0]
+    inflow = CenteredGrid(Box(x=(14, 21), y=(6, 10)), ZERO_GRADIENT, backend=emu_backend, **domain) + \
+        CenteredGrid(Box(x=(81, 88), y=(6, 10)), ZERO_GRADIENT, backend=emu_backend, **domain) * 0.9
+    v = StaggeredGrid(0, 0, backend=emu_backend, **domain)
+    smoke = CenteredGrid(0, ZERO_GRADIENT, backend=emu_backend, **domain)
+    pressure = None
+    dom = O.Domain((n, n), (0, 0), (100, 100), ((O.CLOSED, O.CLOSED),) * 2)
+    o_geo = [O.UnionObstacle(tuple(O.BoxObstacle(g.lower, g.upper) for g in geometries))]
+    s_codes = ((O.OPEN, O.OPEN),) * 2
+    vo = [np.zeros((1,) + dom.comp_shape(d), np.float32) for d in range(2)]
+    so, po = np.zeros((1, n, n), np.float32), None
+    inflow_o = inflow.numpy()[None].astype(np.float32)
+    for _ in range(3):
+        smoke = advect.semi_lagrangian(smoke, v, 1) + inflow
+        buoyancy_force = resample(smoke * (0, 0.1), to=v)
+        v = advect.semi_lagrangian(v, v, 1) + buoyancy_force
+        v, pressure = fluid.make_incompressible(v, geometry, Solve('CG-adaptive', 1e-5, x0=pressure))
+        so = O.semi_lagrangian_centered(so, vo, 1.0, dom, s_codes) + inflow_o
+        bo = O.centered_to_staggered(so, dom, s_codes, vector=(0.0, 0.1))
+        vo = [a + b for a, b in zip(O.semi_lagrangian_staggered(vo, vo, 1.0, dom), bo)]
+        vo, po, info, _ = O.make_incompressible(vo, dom, o_geo, x0=po, rtol=1e-5, atol=1e-5, method='CG-adaptive')   # abs_tol defaults to 1e-5 (fp32)
+        assert abs(pressure.solve_info.iterations[0] - int(info.iterations[0])) <= max(3, 0.1 * int(info.iterations[0]))
+    np.testing.assert_allclose(smoke.numpy(), so[0], atol=1e-5)
+    for a, b in zip(v.numpy(), vo):
+        np.testing.assert_allclose(a, b[0], atol=2e-4 * np.abs(np.concatenate([c.ravel() for c in vo])).max())
+    assert np.abs(vo[1]).max() > 0.02                                                   # the plumes rise
+    inside = geometry.lies_inside(np.meshgrid(*[(np.arange(n) + 0.5) * 100 / n] * 2, indexing='ij'))
+    assert inside.sum() > 50 and np.abs(pressure.numpy()[inside]).max() == 0.0         # inactive cells keep x0 = 0 (fluid.py:202)
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
