@@ -143,6 +143,10 @@ typedef struct phihip_obstacle {
                                    * geometry is their union (phi.geom.union, phi/geom/_geom_ops.py:96-102, _box.py:235): inside = any,
                                    * signed distance = min, i.e. soft mask = max over the members. At most 16 members; they share
                                    * `velocity`, and `angular_velocity` must be 0. */
+    int32_t embed_mask;           /* bit d set: the geometry is infinitely long along axis d (x = bit 0): that coordinate is ignored
+                                   * (phi.geom.embed / infinite_cylinder, phi/geom/_embed.py:62-66,139-158). Such obstacles neither
+                                   * rotate nor carry a rotation matrix. */
+    int32_t reserved;
     double center[3];             /* x, y[, z] */
     double half_size[3];          /* box: half extents; sphere: half_size[0] = radius */
     double velocity[3];           /* linear velocity of the obstacle */

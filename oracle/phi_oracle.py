@@ -676,6 +676,26 @@ class SphereObstacle:
 
 
 @dataclass
+class EmbeddedObstacle:
+    """ Obstacle(embed(geometry, dims)) / geom.infinite_cylinder (phi/geom/_embed.py:38-45,62-66,139-158): the inner geometry is
+    evaluated on the coordinates of `axes` only (indices into the domain's axes); it is infinitely long along the others """
+    inner: object
+    axes: Tuple[int, ...]
+    velocity: Optional[Tuple[float, ...]] = None
+    angular_velocity: Optional[object] = None
+
+    @property
+    def center(self):
+        raise NotImplementedError("embedded geometries do not rotate")
+
+    def lies_inside(self, pts):
+        return self.inner.lies_inside([pts[a] for a in self.axes])
+
+    def sdf(self, pts):
+        return self.inner.sdf([pts[a] for a in self.axes])
+
+
+@dataclass
 class UnionObstacle:
     """ Obstacle(union(geometries)) (phi/geom/_geom_ops.py:96-102, 297-319; stacked boxes: phi/geom/_box.py:175,235): inside = any
     member, signed distance = min over the members; one linear velocity for the whole body, no rotation """
@@ -763,11 +783,14 @@ def apply_boundary_conditions(v: List[np.ndarray], obstacles, dom: Domain):
             ang = ob.angular_velocity if ob.angular_velocity is not None else 0.0
             moving = any(float(c) != 0 for c in lin) or np.any(np.asarray(ang, dtype=float) != 0)
             if moving:
-                r = [fpts[a] - ob.center[a] for a in range(D)]
-                if D == 2:
+                if not np.any(np.asarray(ang, dtype=float) != 0):
+                    u = np.zeros(fpts[0].shape)
+                elif D == 2:
+                    r = [fpts[a] - ob.center[a] for a in range(D)]
                     w = float(np.asarray(ang, dtype=float).reshape(-1)[0])
                     u = (-w * r[1], w * r[0])[d]
                 else:
+                    r = [fpts[a] - ob.center[a] for a in range(D)]
                     w = np.broadcast_to(np.asarray(ang, dtype=float), (3,)) if np.ndim(ang) == 0 else np.asarray(ang, dtype=float)
                     u = (w[1] * r[2] - w[2] * r[1], w[2] * r[0] - w[0] * r[2], w[0] * r[1] - w[1] * r[0])[d]
                 u = (u + float(lin[d])).astype(dtype)[None]

@@ -54,7 +54,7 @@ class Grid(ctypes.Structure):
 
 class ObstacleStruct(ctypes.Structure):
     """ phihip_obstacle """
-    _fields_ = [("kind", c_int32), ("group", c_int32), ("center", c_double * 3), ("half_size", c_double * 3),
+    _fields_ = [("kind", c_int32), ("group", c_int32), ("embed_mask", c_int32), ("reserved", c_int32), ("center", c_double * 3), ("half_size", c_double * 3),
                 ("velocity", c_double * 3), ("angular_velocity", c_double * 3), ("rotation", c_double * 9)]
 
 
@@ -67,6 +67,7 @@ def make_obstacles(items) -> "ctypes.Array":
     for k, it in enumerate(items):
         arr[k].kind = int(it["kind"])
         arr[k].group = int(it.get("group", 0))
+        arr[k].embed_mask = int(it.get("embed_mask", 0))
         for d, val in enumerate(it["center"]):
             arr[k].center[d] = float(val)
         for d, val in enumerate(it["half_size"]):

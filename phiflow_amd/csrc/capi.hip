@@ -319,6 +319,17 @@ static int check_obstacles(const GridView& v, const phihip_obstacle* obstacles, 
         const int nh = obstacles[k].kind == PHIHIP_OBSTACLE_SPHERE ? 1 : v.rank;
         for (int d = 0; d < nh; ++d) PHIHIP_REQUIRE(obstacles[k].half_size[d] >= 0, "obstacle %d: negative size", k);
         PHIHIP_REQUIRE(obstacles[k].group >= 0, "obstacle %d: group must be >= 0", k);
+        PHIHIP_REQUIRE(obstacles[k].embed_mask >= 0 && obstacles[k].embed_mask < (1 << v.rank) - 1, "obstacle %d: embed_mask must leave one axis", k);
+        if (obstacles[k].embed_mask != 0) {   // embedded geometries are not rotated (phi/geom/_embed.py:96-103)
+            bool plain = true;
+            for (int d = 0; d < 3; ++d) plain = plain && obstacles[k].angular_velocity[d] == 0.0;
+            for (int a = 0; a < v.rank; ++a)
+                for (int c = 0; c < v.rank; ++c) {
+                    const double r = obstacles[k].rotation[a * 3 + c];
+                    plain = plain && (r == 0.0 || (a == c && r == 1.0));
+                }
+            PHIHIP_REQUIRE(plain, "obstacle %d: an embedded geometry (embed_mask != 0) cannot rotate", k);
+        }
         if (obstacles[k].group > 0) {   // member of a union: one rigid body without rotation
             for (int d = 0; d < 3; ++d)
                 PHIHIP_REQUIRE(obstacles[k].angular_velocity[d] == 0.0, "obstacle %d: members of a union (group > 0) cannot rotate", k);

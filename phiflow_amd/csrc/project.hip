@@ -391,6 +391,7 @@ struct ObstacleSet {
     int moving[kObstaclesPerLaunch];
     int rotated[kObstaclesPerLaunch];
     int group[kObstaclesPerLaunch];          // > 0: consecutive entries with the same value are ONE obstacle (union of the members)
+    int skip[kObstaclesPerLaunch];           // bit a (internal axis): the geometry is infinite along a (embed): coordinate ignored
 };
 
 static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* obs, int first, int count) {
@@ -401,6 +402,8 @@ static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* o
         const phihip_obstacle& o = obs[first + k];
         s.kind[k] = o.kind;
         s.group[k] = o.group;
+        for (int d = 0; d < v.rank; ++d)
+            if (o.embed_mask & (1 << d)) s.skip[k] |= 1 << (d + v.ax0);
         bool moving = false;
         for (int d = 0; d < v.rank; ++d) {
             s.center[k][d + v.ax0] = o.center[d];
@@ -437,7 +440,7 @@ static ObstacleSet make_obstacle_set(const GridView& v, const phihip_obstacle* o
 // box-frame coordinates of x - center: R^T (x - c)  (Box.global_to_local(scale=False, origin='center'), phi/geom/_box.py:134-152)
 __device__ __forceinline__ void obstacle_local(const ObstacleSet& s, int k, const double (&x)[3], int ax0, double (&loc)[3]) {
     double r[3] = {0, 0, 0};
-    for (int a = ax0; a < 3; ++a) r[a] = x[a] - s.center[k][a];
+    for (int a = ax0; a < 3; ++a) r[a] = (s.skip[k] >> a) & 1 ? 0.0 : x[a] - s.center[k][a];   // embedded axes: always "at the centre"
     if (!s.rotated[k]) {
         for (int a = 0; a < 3; ++a) loc[a] = r[a];
         return;
@@ -452,13 +455,14 @@ __device__ __forceinline__ void obstacle_local(const ObstacleSet& s, int k, cons
 __device__ __forceinline__ bool obstacle_inside(const ObstacleSet& s, int k, const double (&x)[3], int ax0) {
     if (s.kind[k] == PHIHIP_OBSTACLE_SPHERE) {
         double d2 = 0;
-        for (int a = ax0; a < 3; ++a) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
+        for (int a = ax0; a < 3; ++a)
+            if (!((s.skip[k] >> a) & 1)) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
         return d2 <= s.half[k][ax0] * s.half[k][ax0];
     }
     double loc[3];
     obstacle_local(s, k, x, ax0, loc);
     bool in = true;
-    for (int a = ax0; a < 3; ++a) in = in && (fabs(loc[a]) <= s.half[k][a]);
+    for (int a = ax0; a < 3; ++a) in = in && (((s.skip[k] >> a) & 1) || fabs(loc[a]) <= s.half[k][a]);
     return in;
 }
 
@@ -466,13 +470,15 @@ __device__ __forceinline__ bool obstacle_inside(const ObstacleSet& s, int k, con
 __device__ __forceinline__ double obstacle_sdf(const ObstacleSet& s, int k, const double (&x)[3], int ax0) {
     if (s.kind[k] == PHIHIP_OBSTACLE_SPHERE) {
         double d2 = 0;
-        for (int a = ax0; a < 3; ++a) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
+        for (int a = ax0; a < 3; ++a)
+            if (!((s.skip[k] >> a) & 1)) d2 += (x[a] - s.center[k][a]) * (x[a] - s.center[k][a]);
         return sqrt(d2) - s.half[k][ax0];
     }
     double loc[3];
     obstacle_local(s, k, x, ax0, loc);
     double dist = -1e300;
     for (int a = ax0; a < 3; ++a) {
+        if ((s.skip[k] >> a) & 1) continue;
         const double da = fabs(loc[a]) - s.half[k][a];
         dist = da > dist ? da : dist;
     }

@@ -8,7 +8,8 @@ from .autodiff import functional_gradient, gradient, jacobian, l2_loss, stop_gra
 from .backend import HipBackend, default_backend, precision, set_global_default_backend, set_global_precision
 from .extrapolation import BOUNDARY, ONE, PERIODIC, ZERO, ZERO_GRADIENT, ConstantExtrapolation, combine_sides
 from .field import CenteredGrid, Field, StaggeredGrid, assert_close, divergence, mean, resample, spatial_gradient
-from .geom import Box, Cuboid, Sphere, union, vec
+from . import geom
+from .geom import Box, Cuboid, Sphere, embed, infinite_cylinder, union, vec
 from .fluid import Obstacle
 from .solve import ConvergenceException, Diverged, NotConverged, Solve, SolveInfo, copy_with
 
@@ -17,7 +18,7 @@ __all__ = [
     'HipBackend', 'default_backend', 'precision', 'set_global_default_backend', 'set_global_precision',
     'BOUNDARY', 'ONE', 'PERIODIC', 'ZERO', 'ZERO_GRADIENT', 'ConstantExtrapolation', 'combine_sides',
     'CenteredGrid', 'Field', 'StaggeredGrid', 'assert_close', 'divergence', 'mean', 'resample', 'spatial_gradient',
-    'Box', 'Cuboid', 'Sphere', 'union', 'vec', 'Obstacle',
+    'geom', 'Box', 'Cuboid', 'Sphere', 'embed', 'infinite_cylinder', 'union', 'vec', 'Obstacle',
     'functional_gradient', 'gradient', 'jacobian', 'l2_loss', 'stop_gradient',
     'ConvergenceException', 'Diverged', 'NotConverged', 'Solve', 'SolveInfo', 'copy_with',
 ]

@@ -15,7 +15,7 @@ from . import _capi, autodiff
 from .extrapolation import pressure_extrapolation
 from .field import Field, _check_pressure_padding, _ptrs
 from .geom import Box, Geometry, Sphere
-from .geom import Union as Union_
+from .geom import Embedded, Union as Union_
 from .solve import Diverged, NotConverged, Solve, SolveInfo
 
 
@@ -93,6 +93,19 @@ def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field):
             if ob.is_rotating:
                 raise NotImplementedError("HIP backend: a union obstacle cannot have an angular velocity")
         for geo in members:
+            embed_mask = 0
+            if isinstance(geo, Embedded):   # infinitely long along the dims the inner geometry lacks
+                if ob.is_rotating:
+                    raise NotImplementedError("HIP backend: an embedded geometry (embed / infinite_cylinder) cannot have an angular velocity")
+                embed_mask = sum(1 << i for i, d in enumerate(velocity.dims) if d not in geo.geometry.dims)
+                inner = geo.geometry
+                pad = lambda values, fill: [values[inner.dims.index(d)] if d in inner.dims else fill for d in velocity.dims]
+                if isinstance(inner, Sphere):
+                    geo = Sphere(inner.radius, **dict(zip(velocity.dims, pad(inner.center, 0.0))))
+                elif isinstance(inner, Box) and inner.rot is None:
+                    geo = Box(**{d: (l, u) for d, l, u in zip(velocity.dims, pad(inner.lower, 0.0), pad(inner.upper, 0.0))})
+                else:
+                    raise NotImplementedError(f"HIP backend: embed({type(inner).__name__}) is not supported as an obstacle")
             order = [geo.dims.index(d) for d in velocity.dims]
             if isinstance(geo, Sphere):
                 kind, half = _capi.OBSTACLE_SPHERE, [geo.radius] * len(order)
@@ -106,7 +119,7 @@ def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field):
             if isinstance(geo, Box) and geo.rot is not None:
                 rot = [[geo.rot[i][j] for j in order] for i in order]
             items.append(dict(kind=kind, center=[geo.center[i] for i in order], half_size=half, velocity=[ob.velocity[i] for i in vel_order],
-                              angular_velocity=ang, rotation=rot, group=group if len(members) > 1 else 0))
+                              angular_velocity=ang, rotation=rot, group=group if len(members) > 1 else 0, embed_mask=embed_mask))
     return _capi.make_obstacles(items), len(items)
 
 

@@ -88,6 +88,50 @@ def union(*geometries) -> Geometry:
     return flat[0] if len(flat) == 1 else Union(flat)
 
 
+class Embedded(Geometry):
+    """ `embed(geometry, dims)`: the geometry is constant along the added dims, as if it were infinitely long there
+    (phi/geom/_embed.py:15-66,106-136); like the reference's it cannot be shifted or rotated """
+
+    def __init__(self, geometry: Geometry, dims: Sequence[str]):
+        self.geometry = geometry
+        self.dims = tuple(dims)
+        assert set(geometry.dims) < set(self.dims), f"embedding {geometry.dims} in {self.dims} adds no dimension"
+
+    def _down_project(self, points):
+        return [points[self.dims.index(d)] for d in self.geometry.dims]
+
+    def lies_inside(self, points):
+        return self.geometry.lies_inside(self._down_project(points))
+
+    def approximate_signed_distance(self, points):
+        return self.geometry.approximate_signed_distance(self._down_project(points))
+
+    def __repr__(self):
+        return f"embed({self.geometry!r}, {self.dims})"
+
+
+def embed(geometry: Geometry, projected_dims) -> Geometry:
+    """ `embed(geometry, 'z')` / `embed(geometry, ('x', 'y', 'z'))`: dims the geometry already has are ignored; dims of the geometry
+    that are not listed come first (phi/geom/_embed.py:106-136) """
+    if projected_dims is None:
+        return geometry
+    axes = tuple(d.strip() for d in projected_dims.split(',')) if isinstance(projected_dims, str) else tuple(projected_dims)
+    if all(a in geometry.dims for a in axes):
+        return geometry
+    for name in reversed(geometry.dims):
+        if name not in axes:
+            axes = (name,) + axes
+    return Embedded(geometry, axes)
+
+
+def infinite_cylinder(center=None, radius=None, inf_dim=None, **center_) -> Geometry:
+    """ `geom.infinite_cylinder(x=20, y=50, radius=10, inf_dim='z')` (examples/grids/Wake_Flow.ipynb; phi/geom/_embed.py:139-158):
+    an n-dimensional `Sphere` embedded in n + 1 dimensions """
+    if center is not None:
+        center_ = dict(center)
+    return embed(Sphere(radius, **center_), inf_dim)
+
+
 class _BoxType(type):
     def __getitem__(cls, item):
         """ `Box['x,y', 0:100, 0:100]` (tests/commit/physics/test_fluid.py:23) """

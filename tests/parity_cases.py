@@ -247,6 +247,11 @@ def obstacle_items(obstacles, rank):
         group += 1 if union else 0
         for m in (ob.members if union else (ob,)):
             extra = dict(velocity=lin, angular_velocity=ang, group=group if union else 0)
+            if isinstance(m, O.EmbeddedObstacle):   # inner geometry in its own (lower) rank -> padded to the domain's rank
+                extra['embed_mask'] = sum(1 << a for a in range(rank) if a not in m.axes)
+                inner = m.inner
+                pad = lambda values: [values[m.axes.index(a)] if a in m.axes else 0.0 for a in range(rank)]
+                m = O.SphereObstacle(pad(inner.center), inner.radius) if isinstance(inner, O.SphereObstacle) else O.BoxObstacle(pad(inner.lower), pad(inner.upper))
             if isinstance(m, O.SphereObstacle):
                 items.append(dict(kind=C.OBSTACLE_SPHERE, center=m.center, half_size=[m.radius] * rank, **extra))
             else:

@@ -214,6 +214,24 @@ def test_obstacle_rasterisation_and_moving_obstacles(emu_ctx):
     pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, many)
 
 
+def test_embedded_obstacles(emu_ctx):
+    """ geom.infinite_cylinder / embed (examples/grids/Wake_Flow.ipynb): the obstacle ignores the embedding axis; also as a union member """
+    rng = np.random.default_rng(22)
+    O = pc.O
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case((12, 10, 8), ((CLO, OPN), (PER, PER), (PER, PER)), dtype, batch=2)
+        cylinder = O.EmbeddedObstacle(O.SphereObstacle((5.0, 4.5), 2.6), (0, 1))                        # infinite along z
+        slab = O.EmbeddedObstacle(O.BoxObstacle((2.0,), (4.5,)), (2,), velocity=(0.0, 0.3, 0.0))        # infinite along x and y
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng, [cylinder, slab])
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng,
+                                  [O.UnionObstacle((O.EmbeddedObstacle(O.SphereObstacle((8.0, 3.0), 2.0), (0, 2)), O.BoxObstacle((1.0, 1.0, 1.0), (4.0, 3.0, 5.0))))])
+        dom, grid = pc.make_case((16, 12), ((CLO, CLO), (OPN, OPN)), dtype, batch=1)
+        pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, dtype, rng, [O.EmbeddedObstacle(O.BoxObstacle((5.0,), (9.0,)), (0,))])
+    bad = pc.C.make_obstacles([dict(kind=pc.C.OBSTACLE_SPHERE, center=(1, 1), half_size=(1, 1), embed_mask=3)])
+    with pytest.raises(pc.C.PhiHipError):
+        emu_ctx.apply_obstacles(grid, bad, 1, [0, 0])
+
+
 def test_union_obstacles(emu_ctx):
     """ Obstacle(union(geometries)) (examples/grids/Fluid_Logo.ipynb): inside = any member, soft mask = max over the members --
     not the product the same members give as separate obstacles; groups next to plain obstacles, across the 16-per-launch split """

@@ -207,6 +207,33 @@ def test_fluid_logo_union_obstacle_and_cg_adaptive(emu_backend):
     assert inside.sum() > 50 and np.abs(pressure.numpy()[inside]).max() == 0.0         # inactive cells keep x0 = 0 (fluid.py:202)
 
 
+def test_wake_flow_inflow_boundary_and_infinite_cylinder(emu_backend):
+    """ examples/grids/Wake_Flow.ipynb at 32 x 16 x 4: boundary dict with a constant inflow at x-, open x+, periodic y / z; obstacle =
+    geom.infinite_cylinder; step = semi-Lagrangian self-advection + make_incompressible(v, cylinder, Solve(x0=p)) """
+    from oracle import phi_oracle as O
+    from phiflow_amd.flow import geom
+    cylinder = geom.infinite_cylinder(x=20, y=50, radius=10, inf_dim='z')
+    assert cylinder.dims == ('x', 'y', 'z') and geom.embed(Sphere(x=1, y=2, radius=1), 'x,y') .dims == ('x', 'y')
+    boundary = {'x-': vec(x=2, y=0, z=0), 'x+': ZERO_GRADIENT, 'y': PERIODIC, 'z': PERIODIC}
+    v = StaggeredGrid((8., 0, 0), boundary, x=32, y=16, z=4, bounds=Box(x=200, y=100, z=5), backend=emu_backend)
+    dom = O.Domain((32, 16, 4), (0, 0, 0), (200, 100, 5), ((O.CLOSED, O.OPEN), (O.PERIODIC, O.PERIODIC), (O.PERIODIC, O.PERIODIC)),
+                   [[[2.0, 0.0, 0.0], [0.0] * 3], [[0.0] * 3] * 2, [[0.0] * 3] * 2])
+    o_cyl = [O.EmbeddedObstacle(O.SphereObstacle((20.0, 50.0), 10.0), (0, 1))]
+    vo = [np.full((1,) + dom.comp_shape(d), 8.0 if d == 0 else 0.0, np.float32) for d in range(3)]
+    v, p = fluid.make_incompressible(v, cylinder, Solve())
+    vo, po, info, _ = O.make_incompressible(vo, dom, o_cyl, rtol=1e-5, atol=1e-5)
+    for _ in range(2):
+        v = advect.semi_lagrangian(v, v, 1.)
+        v, p = fluid.make_incompressible(v, cylinder, Solve(x0=p))
+        vo = O.semi_lagrangian_staggered(vo, vo, 1.0, dom)
+        vo, po, info, _ = O.make_incompressible(vo, dom, o_cyl, x0=po, rtol=1e-5, atol=1e-5)
+        assert abs(p.solve_info.iterations[0] - int(info.iterations[0])) <= max(3, 0.1 * int(info.iterations[0]))
+    for a, b in zip(v.numpy(), vo):
+        np.testing.assert_allclose(a, b[0], atol=2e-4 * 8.0)
+    assert np.abs(vo[1]).max() > 1.0 and np.abs(vo[2]).max() == 0.0        # the flow goes around the cylinder, nothing along z
+    np.testing.assert_allclose(p.numpy(), po[0], atol=2e-3 * np.abs(po).max())
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
