@@ -30,6 +30,7 @@ def _torch_dtype_code(dtype: torch.dtype) -> int:
 
 class Field:
     """ A sampled scalar (centred) or vector (staggered) grid field with boundary conditions. """
+    __array_ufunc__ = None     # `numpy_array * field` defers to Field.__rmul__ (a batch vector, one number per batch entry)
 
     def __init__(self, resolution: Dict[str, int], bounds: Box, boundary: Extrapolation, values, staggered: bool,
                  backend: HipBackend, batched: bool):
@@ -159,6 +160,13 @@ class Field:
             assert self.is_staggered and len(other) == self.spatial_rank, "vector operand requires a staggered field"
             vals = [fn(a, float(c)) for a, c in zip(self.values, other)]
             batched = self.batched
+        elif isinstance(other, (np.ndarray, torch.Tensor)) and other.ndim == 1:
+            # one number per batch entry, e.g. `inflow_rate * resample(inflow, to=s, soft=True)` (Batched_Smoke.ipynb)
+            assert self.batch_size in (1, len(other)), f"batch vector of length {len(other)} does not match batch size {self.batch_size}"
+            w = torch.as_tensor(np.asarray(other) if isinstance(other, np.ndarray) else other, dtype=self.dtype, device=self.backend.device)
+            w = w.reshape(-1, *([1] * self.spatial_rank))
+            vals = [fn(a, w) for a in self.values] if self.is_staggered else fn(self.values, w)
+            batched = True
         else:
             vals = [fn(a, other) for a in self.values] if self.is_staggered else fn(self.values, other)
             batched = self.batched
@@ -381,11 +389,28 @@ def mean(field: Field):
     return m if field.batched else m[0]
 
 
-def resample(value: Field, to: Field) -> Field:
+def resample(value, to: Field, soft: bool = False, balance: float = 0.5) -> Field:
     """ `resample(value, to=target)` / `value @ target` (phi/field/_resample.py:13-63). Implemented: same sample points (boundary
-    change only) and centred scalar [x constant vector] -> staggered faces on the same grid (sample_grid_at_faces,
+    change only), centred scalar [x constant vector] -> staggered faces on the same grid (sample_grid_at_faces,
     phi/field/_resample.py:272-276: mean of the two adjacent cells, padded with the scalar's extrapolation) as one HIP kernel
-    per component (`phihip_centered_to_staggered`). """
+    per component (`phihip_centered_to_staggered`), and a `Geometry` -> mask on the target's sample points (set-up work, evaluated on
+    the host): hard `lies_inside` or, with `soft=True`, `clip(balance - sdf / cell_radius, 0, 1)`
+    (`resample(Sphere(...), to=smoke, soft=True)`, Smoke_Plume.ipynb cell 3; phi/field/_resample.py:192-210, phi/geom/_geom.py:278-308). """
+    if isinstance(value, Geometry):
+        radius = float(np.sqrt(sum((0.5 * h) ** 2 for h in to.dx)))
+
+        def mask(pts):
+            if soft:
+                return np.clip(balance - value.approximate_signed_distance(pts) / radius, 0, 1)
+            return value.lies_inside(pts).astype(np.float64)
+        if to.is_staggered:
+            comps = [_tensor_from(mask(_sample_points(to.resolution, to.bounds, d, to.boundary)), component_shape(to.resolution, to.boundary, d),
+                                  to.backend, to.dtype) for d in range(to.spatial_rank)]
+            B = max(t.shape[0] for t, _ in comps)
+            return Field(to.resolution, to.bounds, to.boundary, [t if t.shape[0] == B else t.expand(B, *t.shape[1:]).contiguous() for t, _ in comps],
+                         True, to.backend, any(b for _, b in comps))
+        t, batched = _tensor_from(mask(_sample_points(to.resolution, to.bounds, None, to.boundary)), tuple(to.resolution.values()), to.backend, to.dtype)
+        return Field(to.resolution, to.bounds, to.boundary, t, False, to.backend, batched)
     if value.is_staggered == to.is_staggered and value.resolution == to.resolution:
         if value.is_staggered and value.boundary != to.boundary:
             return value.with_boundary(to.boundary)

@@ -81,13 +81,21 @@ def _get_obstacles_for(obstacles, velocity: Field) -> List[Obstacle]:
     return out
 
 
-def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field):
-    """ (ctypes array of `phihip_obstacle` in the velocity's dimension order, entry count); a `union` geometry becomes one group of
-    consecutive entries """
+def _obstacle_batch(obstacles: Sequence[Obstacle]) -> int:
+    """ batch size of the obstacle geometries (1: the same obstacles for every batch entry) """
+    sizes = {ob.geometry.batch_size for ob in obstacles} - {1}
+    assert len(sizes) <= 1, f"obstacle geometries have different batch sizes {sizes}"
+    return sizes.pop() if sizes else 1
+
+
+def _obstacle_array(obstacles: Sequence[Obstacle], velocity: Field, entry: int = 0):
+    """ (ctypes array of `phihip_obstacle` in the velocity's dimension order, entry count) for batch entry `entry` of batched
+    geometries; a `union` geometry becomes one group of consecutive entries """
     items = []
     group = 0
     for ob in obstacles:
-        members = ob.geometry.geometries if isinstance(ob.geometry, Union_) else (ob.geometry,)
+        geometry = ob.geometry.entry(entry)
+        members = geometry.geometries if isinstance(geometry, Union_) else (geometry,)
         if len(members) > 1:
             group += 1
             if ob.is_rotating:
@@ -149,14 +157,21 @@ def _build_flags(velocity: Field, obstacles: Sequence[Obstacle], user_active: Op
     res = tuple(velocity.resolution.values())
     grid1 = velocity.grid_struct(batch=1)
     accessible_t = None
+    OB = _obstacle_batch(obstacles)
     if obstacles:
-        accessible_t = be.empty(res, torch.uint8)
-        be.ctx.obstacle_accessible(grid1, *_obstacle_array(obstacles, velocity), accessible_t.data_ptr(), be.stream())
+        accessible_t = be.empty((OB,) + res, torch.uint8)
+        for b in range(OB):   # batched geometries (Batched_Smoke.ipynb): one mask per batch entry
+            be.ctx.obstacle_accessible(grid1, *_obstacle_array(obstacles, velocity, b), accessible_t[b].data_ptr(), be.stream())
     active_t = None
     if user_active is not None:
         assert user_active.is_centered and user_active.resolution == velocity.resolution
         assert not user_active.batched, "HIP backend: batched `active` masks are not supported yet"
         active_t = (user_active.values[0] != 0).to(torch.uint8).contiguous()
+    if OB > 1:
+        assert active_t is None, "HIP backend: batched obstacle geometries cannot be combined with a user `active` mask yet"
+        flags = be.empty((OB,) + res, torch.uint8)
+        be.ctx.build_cellflags(velocity.grid_struct(batch=OB), accessible_t.data_ptr(), 0, OB, flags.data_ptr(), be.stream())
+        return flags
     flags = be.empty(res, torch.uint8)
     be.ctx.build_cellflags(grid1, accessible_t.data_ptr() if accessible_t is not None else 0,
                            active_t.data_ptr() if active_t is not None else 0, 1, flags.data_ptr(), be.stream())
@@ -195,6 +210,13 @@ def make_incompressible(velocity: Field,
         raise NotImplementedError(f"HIP backend: Solve(method={solve.method!r}) is not available, use one of {tuple(Solve.METHODS)}")
     obstacles = _get_obstacles_for(obstacles, velocity)
     be = velocity.backend
+    OB = _obstacle_batch(obstacles)
+    if OB > 1:
+        assert velocity.batch_size in (1, OB), f"velocity batch {velocity.batch_size} does not match the obstacles' batch {OB}"
+        if velocity.batch_size == 1:   # the same velocity meets a different obstacle in every batch entry
+            velocity = Field(velocity.resolution, velocity.bounds, velocity.boundary,
+                             [t.expand(OB, *t.shape[1:]).contiguous() for t in velocity.values], True, be, True)
+    mask_batch = velocity.batch_size if OB > 1 else 1
     all_active = active is None
     flags = None
     if obstacles or active is not None:
@@ -218,6 +240,8 @@ def make_incompressible(velocity: Field,
         # differentiable path: the same kernels behind torch.autograd.Function nodes (adjoint kernels in csrc/adjoint.hip)
         vin = [t.contiguous() for t in velocity.values]
         shapes = [tuple(t.shape) for t in vin]
+        if OB > 1:
+            raise NotImplementedError("HIP backend: gradients through batched obstacle geometries are not implemented")
         if obstacles:
             vin = list(_apply_obstacles_autograd(velocity, obstacles, vin))
         gsolve = solve.gradient_solve if getattr(solve, 'gradient_solve', None) is not None else solve
@@ -230,9 +254,9 @@ def make_incompressible(velocity: Field,
     else:
         new_v = [t.clone() for t in velocity.values]
         if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
-            be.ctx.apply_obstacles(velocity.grid_struct(), *_obstacle_array(obstacles, velocity), _ptrs(new_v), be.stream())
+            _apply_obstacles_in_place(velocity, obstacles, new_v)
         infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
-                                           flags.data_ptr() if flags is not None else 0, 1, balance, pressure.data_ptr(), 0, csolve,
+                                           flags.data_ptr() if flags is not None else 0, mask_batch, balance, pressure.data_ptr(), 0, csolve,
                                            True, be.stream())
     info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
                      [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
@@ -241,6 +265,17 @@ def make_incompressible(velocity: Field,
     p_out = Field(velocity.resolution, velocity.bounds, p_ext, pressure, False, be, velocity.batched)
     p_out.solve_info = info
     return v_out, p_out
+
+
+def _apply_obstacles_in_place(velocity: Field, obstacles, values: List[torch.Tensor]):
+    """ apply_boundary_conditions on contiguous component tensors; batched geometries: entry b of the batch meets obstacle entry b """
+    be = velocity.backend
+    if _obstacle_batch(obstacles) == 1:
+        be.ctx.apply_obstacles(velocity.grid_struct(), *_obstacle_array(obstacles, velocity), _ptrs(values), be.stream())
+        return
+    grid1 = velocity.grid_struct(batch=1)
+    for b in range(velocity.batch_size):
+        be.ctx.apply_obstacles(grid1, *_obstacle_array(obstacles, velocity, b), [t[b:b + 1].data_ptr() for t in values], be.stream())
 
 
 def _apply_obstacles_autograd(velocity: Field, obstacles, vin):
@@ -272,10 +307,16 @@ def apply_boundary_conditions(velocity: Field, obstacles) -> Field:
     if not obstacles:
         return velocity
     be = velocity.backend
+    OB = _obstacle_batch(obstacles)
     if autodiff.needs_grad(*velocity.values):
+        if OB > 1:
+            raise NotImplementedError("HIP backend: gradients through batched obstacle geometries are not implemented")
         return velocity.with_values(list(_apply_obstacles_autograd(velocity, obstacles, [t.contiguous() for t in velocity.values])))
-    new_v = [t.clone() for t in velocity.values]
-    be.ctx.apply_obstacles(velocity.grid_struct(), *_obstacle_array(obstacles, velocity), _ptrs(new_v), be.stream())
+    if OB > 1 and velocity.batch_size == 1:
+        velocity = Field(velocity.resolution, velocity.bounds, velocity.boundary,
+                         [t.expand(OB, *t.shape[1:]).contiguous() for t in velocity.values], True, be, True)
+    new_v = [t.clone().contiguous() for t in velocity.values]
+    _apply_obstacles_in_place(velocity, obstacles, new_v)
     return velocity.with_values(new_v)
 
 

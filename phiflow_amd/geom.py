@@ -38,12 +38,67 @@ def vec(**components) -> Vector:
 
 class Geometry:
     dims: Tuple[str, ...]
+    batch_size = 1          # > 1: `Batched` (one geometry per batch entry)
 
     def lies_inside(self, points: Sequence[np.ndarray]) -> np.ndarray:
         raise NotImplementedError
 
     def approximate_signed_distance(self, points: Sequence[np.ndarray]) -> np.ndarray:
         raise NotImplementedError
+
+    def entry(self, b: int) -> 'Geometry':
+        """ the geometry of batch entry b """
+        return self
+
+
+def _batch_len(*values) -> int:
+    """ length of the batch dimension among constructor arguments (numbers or 1-D sequences of equal length), 0 if none """
+    n = 0
+    for v in values:
+        if isinstance(v, (list, tuple, np.ndarray)) and np.ndim(v) == 1:
+            assert n in (0, len(v)), "batched geometry arguments must have the same length"
+            n = len(v)
+    return n
+
+
+def _pick(value, b):
+    if isinstance(value, (list, tuple, np.ndarray)) and np.ndim(value) == 1:
+        return float(value[b])
+    if isinstance(value, (list, tuple)):        # (lower, upper) pair of a Box bound, either may be batched
+        return tuple(_pick(v, b) for v in value)
+    return value
+
+
+class Batched(Geometry):
+    """ One geometry per batch entry, e.g. `Sphere(x=[40, 50, 60], y=9.5, radius=5)` or `Cuboid(vec(x=[15, 50, 70], y=60), half_size=...)`
+    (examples/grids/Batched_Smoke.ipynb: `tensor([...], batch('setting'))` coordinates). `lies_inside` / `approximate_signed_distance`
+    return arrays with a leading batch axis, so fields initialised from it are batched. """
+
+    def __init__(self, geometries: Sequence[Geometry]):
+        self.geometries = tuple(geometries)
+        self.dims = self.geometries[0].dims
+        self.batch_size = len(self.geometries)
+
+    def entry(self, b):
+        return self.geometries[b % len(self.geometries)]
+
+    def lies_inside(self, points):
+        return np.stack([g.lies_inside(points) for g in self.geometries])
+
+    def approximate_signed_distance(self, points):
+        return np.stack([g.approximate_signed_distance(points) for g in self.geometries])
+
+    def shifted(self, delta):
+        return Batched([g.shifted(delta) for g in self.geometries])
+
+    def at(self, center):
+        return Batched([g.at(center) for g in self.geometries])
+
+    def rotated(self, angle):
+        return Batched([g.rotated(angle) for g in self.geometries])
+
+    def __repr__(self):
+        return "batched(" + ", ".join(repr(g) for g in self.geometries) + ")"
 
 
 class Union(Geometry):
@@ -55,8 +110,14 @@ class Union(Geometry):
         assert self.geometries, "empty union"
         self.dims = self.geometries[0].dims
         assert all(set(g.dims) == set(self.dims) for g in self.geometries), "members of a union must share their dimensions"
+        self.batch_size = max(g.batch_size for g in self.geometries)
+
+    def entry(self, b):
+        return self if self.batch_size == 1 else Union([g.entry(b) for g in self.geometries])
 
     def lies_inside(self, points):
+        if self.batch_size > 1:
+            return np.stack([self.entry(b).lies_inside(points) for b in range(self.batch_size)])
         out = None
         for g in self.geometries:
             pts = [points[self.dims.index(d)] for d in g.dims]
@@ -65,6 +126,8 @@ class Union(Geometry):
         return out
 
     def approximate_signed_distance(self, points):
+        if self.batch_size > 1:
+            return np.stack([self.entry(b).approximate_signed_distance(points) for b in range(self.batch_size)])
         out = None
         for g in self.geometries:
             pts = [points[self.dims.index(d)] for d in g.dims]
@@ -95,7 +158,11 @@ class Embedded(Geometry):
     def __init__(self, geometry: Geometry, dims: Sequence[str]):
         self.geometry = geometry
         self.dims = tuple(dims)
+        self.batch_size = geometry.batch_size
         assert set(geometry.dims) < set(self.dims), f"embedding {geometry.dims} in {self.dims} adds no dimension"
+
+    def entry(self, b):
+        return self if self.batch_size == 1 else Embedded(self.geometry.entry(b), self.dims)
 
     def _down_project(self, points):
         return [points[self.dims.index(d)] for d in self.geometry.dims]
@@ -147,6 +214,14 @@ class _BoxType(type):
 class Box(Geometry, metaclass=_BoxType):
     """ box; `Box(x=100, y=(10, 20))`: a number means (0, number). `rot`: optional (D, D) matrix box frame -> world
     (set by `rotated`); bounds describe the box in its own frame around `center`. """
+
+    def __new__(cls, _rot=None, **bounds):
+        # a bound is a number (0, upper), a (lower, upper) pair, or -- batched -- a pair holding 1-D sequences / a 1-D ndarray of uppers
+        pairs = {d: (b if isinstance(b, (tuple, list)) and len(b) == 2 else (0.0, b)) for d, b in bounds.items()}
+        n = _batch_len(*[x for pair in pairs.values() for x in pair])
+        if n:
+            return Batched([Box(_rot=_rot, **{d: (_pick(lo, i), _pick(up, i)) for d, (lo, up) in pairs.items()}) for i in range(n)])
+        return super().__new__(cls)
 
     def __init__(self, _rot=None, **bounds):
         self.dims = tuple(bounds.keys())
@@ -213,17 +288,30 @@ class Box(Geometry, metaclass=_BoxType):
         return "Box(" + ", ".join(f"{d}=({l}, {u})" for d, l, u in zip(self.dims, self.lower, self.upper)) + rot + ")"
 
 
-def Cuboid(center=None, **size) -> Box:
-    """ `Cuboid(vec(x=20, y=80), x=20, y=20)`: box given by centre and edge lengths (phi/geom/_box.py:418); without a centre the
-    arguments are bounds like `Box(...)` """
-    if center is None:
+def Cuboid(center=None, half_size=None, **size) -> Box:
+    """ `Cuboid(vec(x=20, y=80), x=20, y=20)`: box given by centre and edge lengths, or `Cuboid(center, half_size=vec(x=15, y=10))`
+    (phi/geom/_box.py:418-440); coordinates may be batched (1-D sequences); without a centre the arguments are bounds like `Box(...)` """
+    if center is None and half_size is None:
         return Box(**size)
-    c = [center[d] for d in size] if isinstance(center, dict) else list(center)
-    return Box(**{d: (ci - float(s) / 2, ci + float(s) / 2) for (d, s), ci in zip(size.items(), c)})
+    if half_size is not None:
+        half = dict(half_size) if isinstance(half_size, dict) else {d: half_size for d in center}
+    else:
+        half = {d: np.asarray(s, dtype=float) / 2 for d, s in size.items()}
+    c = dict(center) if isinstance(center, dict) else dict(zip(half, center))
+    n = _batch_len(*c.values(), *[h for h in half.values() if np.ndim(h) == 1])
+    def one(i):
+        return Box(**{d: (float(_pick(c[d], i)) - float(_pick(half[d], i)), float(_pick(c[d], i)) + float(_pick(half[d], i))) for d in half})
+    return Batched([one(i) for i in range(n)]) if n else one(0)
 
 
 class Sphere(Geometry):
     """ `Sphere(x=50, y=10, radius=5)` """
+
+    def __new__(cls, radius=None, **center):
+        n = _batch_len(radius, *center.values())
+        if n:
+            return Batched([Sphere(_pick(radius, i), **{d: _pick(c, i) for d, c in center.items()}) for i in range(n)])
+        return super().__new__(cls)
 
     def __init__(self, radius: float, **center):
         self.dims = tuple(center.keys())

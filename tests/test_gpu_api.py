@@ -45,6 +45,7 @@ def test_reference_style_scenarios(gpu_backend):
     host.test_moving_and_rotating_obstacles(gpu_backend)
     host.test_fluid_logo_union_obstacle_and_cg_adaptive(gpu_backend)
     host.test_wake_flow_inflow_boundary_and_infinite_cylinder(gpu_backend)
+    host.test_batched_smoke_with_batched_obstacle_and_inflow(gpu_backend)
     host.test_convergence_exceptions(gpu_backend)
     host.test_lid_driven_cavity_boundaries_and_diffusion(gpu_backend)
     host.test_spatial_gradient_at_faces(gpu_backend)
