@@ -109,6 +109,21 @@ int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void
 int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
                            const double s_val[3][2], const void* const velocity[3], void* out, double dt, void* stream);
 
+/* ---- math.grid_sample(grid, coordinates, extrapolation) (call site phi/field/_resample.py:257-259; the gather every advection
+ *      above is built from, exposed for samples at arbitrary points: grids of another resolution, particle positions) ------------
+ * values: [values_batch][res...] with values_batch = 1 (shared) or grid.batch; `grid.res` = shape of `values`, `grid.bc` / `s_val`-style
+ * rule per side taken from grid.bc and grid.bc_val[axis][side][0]: PERIODIC wrap, OPEN = clamp (zero-gradient), CLOSED = constant.
+ * coords[d]: [batch][points] FRACTIONAL INDICES into `values` along axis d (PhiML's convention: coordinate i is sample i).
+ * out / out_min / out_max: [batch][points]; each may be NULL (out_min and out_max only together): the multilinear interpolation
+ * and the min / max over its 2^D taps (Field.closest_values, phi/field/_field.py:409-429). Bounds of `grid` are ignored. */
+int phihip_grid_sample(phihip_ctx* ctx, const phihip_grid* grid, const void* values, int values_batch, const void* const coords[3],
+                       int64_t points, void* out, void* out_min, void* out_max, void* stream);
+/* VJP of phihip_grid_sample's `out`: grad_values [values_batch][res...] and grad_coords[d] [batch][points] are ACCUMULATED (+=);
+ * either may be NULL. */
+int phihip_grid_sample_backward(phihip_ctx* ctx, const phihip_grid* grid, const void* values, int values_batch,
+                                const void* const coords[3], int64_t points, const void* grad_out, void* grad_values,
+                                void* const grad_coords[3], void* stream);
+
 /* ---- f2: advect.mac_cormack (phi/physics/advect.py:182-215) -------------------------------------------------------- */
 /* forward + backward semi-Lagrangian pass, `fwd + correction_strength * 0.5 * (field - bwd)`, clamped to the min / max of
  * the grid values around the backward lookup (Field.closest_values, phi/field/_field.py:409-429). out must not alias. */

@@ -297,6 +297,65 @@ def _index_coords(points: List[np.ndarray], comp: int, dom: Domain, dtype):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# sampling between DIFFERENT grids (phi/field/_resample.py:66-72,145-161,241-259: sample -> grid_sample at explicit points;
+# phi/physics/advect.py:193 "velocity need not be sampled at same locations as field"; Batched_Smoke.ipynb)
+# --------------------------------------------------------------------------------------------------------------------
+def _centered_index_coords(points: List[np.ndarray], dom: Domain, dtype):
+    return [(points[a] - dtype(dom.lower[a])) / dtype(dom.res[a] * dom.dx[a]) * dtype(dom.res[a]) - dtype(0.5) for a in range(dom.rank)]
+
+
+def sample_staggered_at(v: List[np.ndarray], dom: Domain, points: List[np.ndarray]):
+    """ sample(velocity, points): every component interpolated on its own staggered sub-grid with its own padding rule """
+    dtype = v[0].dtype.type
+    out = []
+    for c in range(dom.rank):
+        codes, consts = _comp_codes(dom, c)
+        out.append(grid_sample(v[c], _index_coords(points, c, dom, dtype), codes, consts))
+    return out
+
+
+def sample_centered_at(s: np.ndarray, dom: Domain, s_codes, s_consts, points: List[np.ndarray]):
+    consts = s_consts if s_consts is not None else [(0.0, 0.0)] * dom.rank
+    return grid_sample(s, _centered_index_coords(points, dom, s.dtype.type), s_codes, consts)
+
+
+def semi_lagrangian_centered_general(s: np.ndarray, dom_s: Domain, velocity: List[np.ndarray], dom_v: Domain, dt: float, s_codes, s_consts=None,
+                                     correction_strength: Optional[float] = None):
+    """ advect.semi_lagrangian (correction_strength None) / advect.mac_cormack of a centred scalar by a velocity on another grid """
+    dtype = s.dtype.type
+    B = max(s.shape[0], velocity[0].shape[0])
+    pts = [np.broadcast_to(p[None], (B,) + p.shape) for p in cell_positions(dom_s, dtype)]
+    vel = [np.broadcast_to(c, (B,) + c.shape[1:]) for c in velocity]
+    src = np.broadcast_to(s, (B,) + s.shape[1:])
+    u = sample_staggered_at(vel, dom_v, pts)
+    back = [p + uc * dtype(-dt) for p, uc in zip(pts, u)]
+    consts = s_consts if s_consts is not None else [(0.0, 0.0)] * dom_s.rank
+    fwd = sample_centered_at(src, dom_s, s_codes, consts, back)
+    if correction_strength is None:
+        return fwd
+    ahead = [p + uc * dtype(dt) for p, uc in zip(pts, u)]
+    bwd = sample_centered_at(fwd, dom_s, s_codes, consts, ahead)
+    new = fwd + dtype(correction_strength * 0.5) * (src - bwd)
+    lo, hi = closest_limits(src, _centered_index_coords(back, dom_s, dtype), s_codes, consts)
+    return np.minimum(np.maximum(new, lo), hi)
+
+
+def resample_centered_general(s: np.ndarray, dom_s: Domain, s_codes, s_consts, dom_t: Domain, staggered: bool = False,
+                              vector: Optional[Sequence[float]] = None):
+    """ resample(s [* vector], to=target) with the target on another grid: at its cell centres, or per component at its stored faces """
+    dtype = s.dtype.type
+    if not staggered:
+        pts = [np.broadcast_to(p[None], (s.shape[0],) + p.shape) for p in cell_positions(dom_t, dtype)]
+        return sample_centered_at(s, dom_s, s_codes, s_consts, pts)
+    vector = [1.0] * dom_t.rank if vector is None else vector
+    out = []
+    for d in range(dom_t.rank):
+        pts = [np.broadcast_to(p[None], (s.shape[0],) + p.shape) for p in face_positions(d, dom_t, dtype)]
+        out.append(sample_centered_at(s, dom_s, s_codes, s_consts, pts) * dtype(vector[d]))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # a1: semi-Lagrangian advection (phi/physics/advect.py:156-179 with euler :20-24)
 # --------------------------------------------------------------------------------------------------------------------
 def semi_lagrangian_staggered(field: List[np.ndarray], velocity: List[np.ndarray], dt: float, dom: Domain,

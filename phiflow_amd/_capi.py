@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
+    "phihip_grid_sample", "phihip_grid_sample_backward",
 )
 
 
@@ -154,6 +155,11 @@ class Library:
         d.phihip_advect_staggered.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
         d.phihip_advect_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
                                              POINTER(_Ptr3), c_void_p, c_double, c_void_p]
+        if hasattr(d, "phihip_grid_sample"):
+            d.phihip_grid_sample.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, POINTER(_Ptr3), ctypes.c_int64, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]
+            d.phihip_grid_sample_backward.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, POINTER(_Ptr3), ctypes.c_int64, c_void_p, c_void_p,
+                                                      POINTER(_Ptr3), c_void_p]
         d.phihip_mac_cormack_staggered.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_double,
                                                    c_void_p]
         d.phihip_mac_cormack_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3),
@@ -255,6 +261,17 @@ class Context:
         bc, val = self._scalar_bc(grid, s_bc, s_val)
         self.lib.check(self.lib.dll.phihip_advect_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val),
                                                            ctypes.byref(ptr3(velocity)), out, float(dt), stream or None))
+
+    def grid_sample(self, grid, values, values_batch, coords, points, out, out_min=0, out_max=0, stream=0):
+        """ math.grid_sample: `grid` describes the VALUES array (res = its shape, bc / bc_val[..][0] = its extrapolation) """
+        self.lib.check(self.lib.dll.phihip_grid_sample(self.handle, ctypes.byref(grid), values, int(values_batch), ctypes.byref(ptr3(coords)),
+                                                       int(points), out or None, out_min or None, out_max or None, stream or None))
+
+    def grid_sample_backward(self, grid, values, values_batch, coords, points, grad_out, grad_values, grad_coords, stream=0):
+        gc = ptr3(grad_coords)
+        self.lib.check(self.lib.dll.phihip_grid_sample_backward(self.handle, ctypes.byref(grid), values, int(values_batch), ctypes.byref(ptr3(coords)),
+                                                                int(points), grad_out, grad_values or None, ctypes.byref(gc) if gc is not None else None,
+                                                                stream or None))
 
     def mac_cormack_staggered(self, grid, field, velocity, out, dt, correction_strength=1.0, stream=0):
         self.lib.check(self.lib.dll.phihip_mac_cormack_staggered(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(field)),

@@ -27,7 +27,7 @@ def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callab
 
     Args:
         field: quantity to be advected (`StaggeredGrid` or `CenteredGrid`)
-        velocity: `StaggeredGrid` on the same grid
+        velocity: `StaggeredGrid`; on the same grid the fused kernels run, otherwise the general sampling path (sampling.py)
         dt: time increment
         integrator: only `euler` is available on the HIP backend
 
@@ -50,8 +50,11 @@ def _advect(field: Field, velocity: Field, dt: float, integrator: Callable, corr
         raise NotImplementedError("HIP backend: grid advection supports integrator=euler only")
     if not velocity.is_staggered:
         raise NotImplementedError("HIP backend: the advecting velocity must be a StaggeredGrid")
-    assert field.resolution == velocity.resolution and field.bounds.lower == velocity.bounds.lower and \
-        field.bounds.upper == velocity.bounds.upper, "field and velocity must live on the same grid"
+    from . import sampling
+    if not sampling.same_grid(field, velocity):
+        # "velocity need not be sampled at same locations as field" (advect.py:193): gathers at explicit coordinates instead of the
+        # fused kernels (Batched_Smoke.ipynb: 200^2 smoke advected by a 64^2 velocity)
+        return sampling.advect_general(field, velocity, float(dt), correction_strength)
     be = velocity.backend
     assert field.dtype == velocity.dtype, "field and velocity must have the same precision"
     B = max(field.batch_size, velocity.batch_size)

@@ -560,4 +560,58 @@ int run_project_bwd(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, in
                                  : project_bwd_t<float>(ctx, v, flags, mask_batch, balance, gv, gp, solve, info, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// VJP of math.grid_sample (advect.hip grid_sample_kernel): taps <- g * weight, coordinates <- g * d(out)/d(frac)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void grid_sample_bwd_kernel(ScalarBc sb, int n0, int n1, int n2, const T* __restrict__ values, long long vstride,
+                                                                 CComp3a<T> coords, long long npts, const T* __restrict__ gout, T* __restrict__ gvalues,
+                                                                 Comp3w<T> gcoords) {
+    constexpr int A0 = 3 - DIM;
+    const int b = blockIdx.y;
+    const int n[3] = {n0, n1, n2};
+    int bc[3][2];
+    T cv[3][2];
+    scalar_rule<T>(sb, bc, cv);
+    const T* __restrict__ F = values + (long long)b * vstride;
+    T* __restrict__ GF = gvalues ? gvalues + (long long)b * vstride : nullptr;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npts; i += (long long)gridDim.x * kBlock) {
+        const long long o = (long long)b * npts + i;
+        T c[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int a = A0; a < 3; ++a) c[a] = coords.p[a][o];
+        AxisPair<T> ax[3];
+        T fr[3], dfr[3];
+        lookup_pairs<T, DIM>(c, n, bc, cv, ax, fr);
+        const T g = gout[o];
+        gather_adjoint<T, DIM>(F, GF, ax, fr, g, dfr);
+#pragma unroll
+        for (int a = A0; a < 3; ++a)
+            if (gcoords.p[a]) gcoords.p[a][o] += g * dfr[a];
+    }
+}
+
+int run_grid_sample_bwd(phihip_ctx* ctx, const GridView& v, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch, const void* const coords[3], long long npts,
+                        const void* gout, void* gvalues, void* const gcoords[3], hipStream_t s) {
+    if (v.cells >= (1LL << 31)) {
+        set_error("grid_sample_backward: more than 2^31 values per batch entry are not supported");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    const long long vstride = values_batch > 1 ? v.cells : 0;   // shared values: every batch entry scatters into the same gradient
+    const unsigned nblk = (unsigned)((npts + kBlock - 1) / kBlock < 65536 ? (npts + kBlock - 1) / kBlock : 65536);
+    LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    if (npts > 0) {
+#define PHIHIP_GSB(T, DIM)                                                                                                                           \
+    hipLaunchKernelGGL((grid_sample_bwd_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, sb, v.n[0], v.n[1], v.n[2], (const T*)values, vstride, \
+                       (CComp3a<T>{{(const T*)coords[0], (const T*)coords[1], (const T*)coords[2]}}), npts, (const T*)gout, (T*)gvalues,               \
+                       (Comp3w<T>{{gcoords ? (T*)gcoords[0] : nullptr, gcoords ? (T*)gcoords[1] : nullptr, gcoords ? (T*)gcoords[2] : nullptr}}))
+        if (v.dtype == PHIHIP_F64) { if (v.rank == 3) PHIHIP_GSB(double, 3); else PHIHIP_GSB(double, 2); }
+        else { if (v.rank == 3) PHIHIP_GSB(float, 3); else PHIHIP_GSB(float, 2); }
+#undef PHIHIP_GSB
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 }  // namespace phihip

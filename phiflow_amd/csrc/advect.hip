@@ -236,4 +236,58 @@ int run_mac_cormack_centered(phihip_ctx* ctx, const GridView& v, const void* sfi
     return PHIHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// math.grid_sample: the same tap resolution + gather at coordinates given by the caller
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void grid_sample_kernel(ScalarBc sb, int n0, int n1, int n2, const T* __restrict__ values, long long vstride,
+                                                             CComp3a<T> coords, long long npts, T* __restrict__ out, T* __restrict__ omin,
+                                                             T* __restrict__ omax) {
+    constexpr int A0 = 3 - DIM;
+    const int b = blockIdx.y;
+    const int n[3] = {n0, n1, n2};
+    int bc[3][2];
+    T cv[3][2];
+    scalar_rule<T>(sb, bc, cv);
+    const T* __restrict__ F = values + (long long)b * vstride;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < npts; i += (long long)gridDim.x * kBlock) {
+        const long long o = (long long)b * npts + i;
+        T c[3] = {T(0), T(0), T(0)};
+#pragma unroll
+        for (int a = A0; a < 3; ++a) c[a] = coords.p[a][o];
+        AxisPair<T> ax[3];
+        T fr[3];
+        lookup_pairs<T, DIM>(c, n, bc, cv, ax, fr);
+        if (out) out[o] = gather_multilinear<T, DIM>(F, ax, fr);
+        if (omin) {
+            T lo, hi;
+            gather_minmax<T, DIM>(F, ax, lo, hi);
+            omin[o] = lo;
+            omax[o] = hi;
+        }
+    }
+}
+
+int run_grid_sample(phihip_ctx* ctx, const GridView& v, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch, const void* const coords[3], long long npts,
+                    void* out, void* out_min, void* out_max, hipStream_t s) {
+    if (v.cells >= (1LL << 31)) {
+        set_error("grid_sample: more than 2^31 values per batch entry are not supported");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    const long long vstride = values_batch > 1 ? v.cells : 0;
+    const unsigned nblk = (unsigned)((npts + kBlock - 1) / kBlock < 65536 ? (npts + kBlock - 1) / kBlock : 65536);
+    LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    if (npts > 0) {
+#define PHIHIP_GS(T, DIM)                                                                                                                       \
+    hipLaunchKernelGGL((grid_sample_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, sb, v.n[0], v.n[1], v.n[2], (const T*)values, vstride, \
+                       (CComp3a<T>{{(const T*)coords[0], (const T*)coords[1], (const T*)coords[2]}}), npts, (T*)out, (T*)out_min, (T*)out_max)
+        if (v.dtype == PHIHIP_F64) { if (v.rank == 3) PHIHIP_GS(double, 3); else PHIHIP_GS(double, 2); }
+        else { if (v.rank == 3) PHIHIP_GS(float, 3); else PHIHIP_GS(float, 2); }
+#undef PHIHIP_GS
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 }  // namespace phihip

@@ -257,6 +257,62 @@ int phihip_advect_centered(phihip_ctx* ctx, const phihip_grid* grid, const void*
     return run_advect_centered(ctx, v, sfield, s_bc, s_val, u, out, dt, s);
 }
 
+// The sampler describes `values` with a phihip_grid (shape, extrapolation) but has no staggered layout: build the view from a copy
+// whose non-periodic sides are OPEN (no face bookkeeping, e.g. a one-sample axis with a constant extrapolation is fine) and hand the
+// real rule over separately.
+static int sampler_view(const phihip_grid* grid, phihip_grid* plain, int32_t s_bc[3][2], double s_val[3][2]) {
+    PHIHIP_REQUIRE(grid != nullptr, "grid is NULL");
+    *plain = *grid;
+    for (int d = 0; d < 3; ++d)
+        for (int side = 0; side < 2; ++side) {
+            s_bc[d][side] = grid->bc[d][side];
+            s_val[d][side] = grid->bc_val[d][side][0];
+            if (d < grid->rank) {
+                PHIHIP_REQUIRE(s_bc[d][side] >= PHIHIP_BC_PERIODIC && s_bc[d][side] <= PHIHIP_BC_OPEN, "grid.bc[%d][%d] invalid", d, side);
+                if (s_bc[d][side] != PHIHIP_BC_PERIODIC) plain->bc[d][side] = PHIHIP_BC_OPEN;
+            }
+            plain->lower[d] = 0.0;
+            plain->upper[d] = 1.0;
+        }
+    return PHIHIP_OK;
+}
+
+int phihip_grid_sample(phihip_ctx* ctx, const phihip_grid* grid_in, const void* values, int values_batch, const void* const coords[3],
+                       int64_t points, void* out, void* out_min, void* out_max, void* stream) {
+    phihip_grid plain;
+    int32_t s_bc[3][2];
+    double s_val[3][2];
+    PHIHIP_TRY(sampler_view(grid_in, &plain, s_bc, s_val));
+    const phihip_grid* grid = &plain;
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(values != nullptr && points >= 0, "grid_sample: values is NULL or points < 0");
+    PHIHIP_REQUIRE(values_batch == 1 || values_batch == v.batch, "grid_sample: values_batch must be 1 or grid.batch");
+    PHIHIP_REQUIRE((out || out_min) && ((out_min == nullptr) == (out_max == nullptr)), "grid_sample: pass out and / or (out_min and out_max)");
+    PHIHIP_TRY(check_ptrs(v, coords, "coords"));
+    const void* c[3];
+    remap3(v, coords, c);
+    return run_grid_sample(ctx, v, s_bc, s_val, values, values_batch, c, (long long)points, out, out_min, out_max, s);
+}
+
+int phihip_grid_sample_backward(phihip_ctx* ctx, const phihip_grid* grid_in, const void* values, int values_batch, const void* const coords[3],
+                                int64_t points, const void* grad_out, void* grad_values, void* const grad_coords[3], void* stream) {
+    phihip_grid plain;
+    int32_t s_bc[3][2];
+    double s_val[3][2];
+    PHIHIP_TRY(sampler_view(grid_in, &plain, s_bc, s_val));
+    const phihip_grid* grid = &plain;
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(values && grad_out && points >= 0, "grid_sample_backward: NULL argument or points < 0");
+    PHIHIP_REQUIRE(values_batch == 1 || values_batch == v.batch, "grid_sample_backward: values_batch must be 1 or grid.batch");
+    PHIHIP_TRY(check_ptrs(v, coords, "coords"));
+    if (grad_coords) PHIHIP_TRY(check_ptrs(v, (const void* const*)grad_coords, "grad_coords"));
+    const void* c[3];
+    void* gc[3];
+    remap3(v, coords, c);
+    remap3w(v, grad_coords, gc);
+    return run_grid_sample_bwd(ctx, v, s_bc, s_val, values, values_batch, c, (long long)points, grad_out, grad_values, grad_coords ? gc : nullptr, s);
+}
+
 static int check_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const char* what) {
     for (int d = 0; d < v.rank; ++d) {
         for (int side = 0; side < 2; ++side)

@@ -139,6 +139,10 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- phases implemented in the .hip files ---------------------------------------------------------------------------
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
+int run_grid_sample(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,
+                    const void* const coords[3], long long npts, void* out, void* out_min, void* out_max, hipStream_t);
+int run_grid_sample_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,
+                        const void* const coords[3], long long npts, const void* gout, void* gvalues, void* const gcoords[3], hipStream_t);
 int run_advect_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2],
                         const void* const v[3], void* out, double dt, hipStream_t);
 int run_mac_cormack_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt,

@@ -435,7 +435,8 @@ def resample(value, to: Field, soft: bool = False, balance: float = 0.5) -> Fiel
         else:
             be.ctx.centered_to_staggered(grid, src.data_ptr(), s_codes, s_val, scale, False, _ptrs(comps), be.stream())
         return Field(to.resolution, to.bounds, to.boundary, comps, True, be, value.batched or to.batched)
-    raise NotImplementedError("resample: only centred -> staggered on the same grid is implemented")
+    from . import sampling
+    return sampling.resample_general(value, to)     # different grids: one gather per (component of the) target
 
 
 def vector_scaled(s: Field, vector: Sequence[float]) -> Field:

@@ -572,6 +572,47 @@ def check_make_incompressible(ctx, mem, dom, grid, dtype, rng, obstacles=(), max
     return info
 
 
+def check_grid_sample(ctx, mem, shape, codes, consts, dtype, rng, batch=2, points=301, shared_values=False, spread=2.5):
+    """ phihip_grid_sample (math.grid_sample) at random coordinates reaching `spread` array lengths beyond the array: interpolation and
+    the min / max of its taps against the oracle's grid_sample / closest_limits; backward against finite differences (fp64) """
+    D = len(shape)
+    vb = 1 if shared_values else batch
+    values = rng.standard_normal((vb,) + tuple(shape)).astype(dtype)
+    coords = [((rng.random((batch, points)) * (2 * spread + 1) - spread) * n).astype(dtype) for n in shape]
+    coords[0][:, :4] = np.asarray([0.0, -1.0, shape[0] - 1.0, float(shape[0])], dtype)[None]     # exactly on samples / one step outside
+    bc_val = [[[consts[a][s], 0.0, 0.0] for s in range(2)] for a in range(D)]
+    grid = C.make_grid(D, C.PHIHIP_F64 if np.dtype(dtype) == np.float64 else C.PHIHIP_F32, batch, shape, (0.0,) * D, (1.0,) * D, codes, bc_val)
+    dvals, dc = mem.to_dev(values), [mem.to_dev(c) for c in coords]
+    dout, dmin, dmax = (mem.empty((batch, points), dtype) for _ in range(3))
+    ctx.grid_sample(grid, mem.ptr(dvals), vb, [mem.ptr(c) for c in dc], points, mem.ptr(dout), mem.ptr(dmin), mem.ptr(dmax))
+    mem.sync()
+    vals_b = np.broadcast_to(values, (batch,) + tuple(shape))
+    ref = O.grid_sample(vals_b, coords, codes, consts)
+    lo, hi = O.closest_limits(vals_b, coords, codes, consts)
+    scale = max(np.abs(ref).max(), 1e-30)
+    # a coordinate within rounding distance of an integer may resolve to the neighbouring tap pair: the interpolation is continuous
+    # there, the min / max window is not -> compare the window robustly
+    assert np.abs(mem.to_host(dout) - ref).max() <= tol(dtype)['advect'] * 8 * scale, np.abs(mem.to_host(dout) - ref).max() / scale
+    for got, want in ((mem.to_host(dmin), lo), (mem.to_host(dmax), hi)):
+        assert (np.abs(got - want) > 1e-6 * scale).mean() <= 5e-3
+    if np.dtype(dtype) == np.float64:
+        g = rng.standard_normal((batch, points))
+        g[:, :4] = 0.0      # those samples sit exactly on the kinks of the interpolant
+        gv, gc = mem.to_dev(np.zeros_like(values)), [mem.to_dev(np.zeros_like(c)) for c in coords]
+        dg = mem.to_dev(g)
+        ctx.grid_sample_backward(grid, mem.ptr(dvals), vb, [mem.ptr(c) for c in dc], points, mem.ptr(dg), mem.ptr(gv), [mem.ptr(c) for c in gc])
+        mem.sync()
+        dv = rng.standard_normal(values.shape)
+        lin = float(np.vdot(g, O.grid_sample(np.broadcast_to(dv, vals_b.shape), coords, codes, [(0.0, 0.0)] * D)))   # linear in the values
+        assert abs(lin - float(np.vdot(mem.to_host(gv), dv))) <= 1e-9 * max(abs(lin), 1.0)
+        dcs = [rng.standard_normal(c.shape) for c in coords]
+        eps = 1e-7
+        fd = (float(np.vdot(g, O.grid_sample(vals_b, [c + eps * d for c, d in zip(coords, dcs)], codes, consts))) -
+              float(np.vdot(g, O.grid_sample(vals_b, [c - eps * d for c, d in zip(coords, dcs)], codes, consts)))) / (2 * eps)
+        an = sum(float(np.vdot(mem.to_host(a), d)) for a, d in zip(gc, dcs))
+        assert abs(fd - an) <= 2e-4 * max(abs(fd), abs(an), 1.0), (fd, an)
+
+
 # degenerate resolutions (one or two cells along an axis, single-plane 3-D grids) under every boundary kind
 DEGENERATE_GRIDS = [
     ((1, 1), ((0, 0), (0, 0))), ((2, 2), ((1, 1), (1, 1))), ((1, 5), ((2, 2), (1, 1))), ((5, 1), ((0, 0), (2, 1))), ((2, 3), ((1, 2), (0, 0))),

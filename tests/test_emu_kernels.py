@@ -214,6 +214,17 @@ def test_obstacle_rasterisation_and_moving_obstacles(emu_ctx):
     pc.check_obstacle_kernels(emu_ctx, MEM, dom, grid, np.float32, rng, many)
 
 
+@pytest.mark.parametrize("shape,codes", [((7, 5), ((PER, PER), (CLO, OPN))), ((1, 9), ((CLO, CLO), (OPN, OPN))), ((4, 6, 5), ((OPN, CLO), (PER, PER), (CLO, CLO))),
+                                         ((3, 1, 8), ((PER, PER), (OPN, OPN), (CLO, OPN)))])
+def test_grid_sample_matches_oracle(emu_ctx, shape, codes):
+    """ math.grid_sample (phi/field/_resample.py:257-259) at arbitrary coordinates, far outside the array included """
+    rng = np.random.default_rng(31)
+    consts = [(0.3, -1.2)] * len(shape)
+    for dtype in (np.float32, np.float64):
+        pc.check_grid_sample(emu_ctx, MEM, shape, codes, consts, dtype, rng)
+        pc.check_grid_sample(emu_ctx, MEM, shape, codes, consts, dtype, rng, batch=3, points=70, shared_values=True, spread=0.6)
+
+
 def test_embedded_obstacles(emu_ctx):
     """ geom.infinite_cylinder / embed (examples/grids/Wake_Flow.ipynb): the obstacle ignores the embedding axis; also as a union member """
     rng = np.random.default_rng(22)

@@ -206,6 +206,17 @@ def test_degenerate_grids(ctx, mem, res, bc, dtype):
     pc.check_degenerate_grid(ctx, mem, res, bc, dtype)
 
 
+@pytest.mark.parametrize("shape,codes", [((7, 5), ((PER, PER), (CLO, OPN))), ((1, 9), ((CLO, CLO), (OPN, OPN))), ((4, 6, 5), ((OPN, CLO), (PER, PER), (CLO, CLO))),
+                                         ((3, 1, 8), ((PER, PER), (OPN, OPN), (CLO, OPN)))])
+def test_grid_sample_matches_oracle(ctx, mem, shape, codes):
+    """ math.grid_sample (phi/field/_resample.py:257-259) at arbitrary coordinates, far outside the array included """
+    rng = np.random.default_rng(31)
+    consts = [(0.3, -1.2)] * len(shape)
+    for dtype in (np.float32, np.float64):
+        pc.check_grid_sample(ctx, mem, shape, codes, consts, dtype, rng)
+        pc.check_grid_sample(ctx, mem, shape, codes, consts, dtype, rng, batch=3, points=70, shared_values=True, spread=0.6)
+
+
 def test_embedded_obstacles(ctx, mem):
     """ geom.infinite_cylinder / embed (examples/grids/Wake_Flow.ipynb): the obstacle ignores the embedding axis; also as a union member """
     rng = np.random.default_rng(22)

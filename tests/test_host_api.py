@@ -277,6 +277,59 @@ def test_batched_smoke_with_batched_obstacle_and_inflow(emu_backend):
     assert not np.allclose(v.numpy()[1][0], v.numpy()[1][1])                # the settings do differ
 
 
+@pytest.mark.parametrize("dtype_name", ["float32", "float64"])
+def test_fields_on_different_grids(emu_backend, dtype_name):
+    """ examples/grids/Batched_Smoke.ipynb samples smoke (200^2) and velocity (64^2) on different grids: mac_cormack / semi_lagrangian of
+    the smoke by the coarse velocity and resample(smoke * (0, 0.1), to=velocity) go through math.grid_sample at explicit points
+    (phi/physics/advect.py:193, phi/field/_resample.py:66-72,241-259) -- here 40^2 / 16^2 against the oracle's restatement """
+    from oracle import phi_oracle as O
+    from phiflow_amd.flow import precision, resample
+    dtype = np.dtype(dtype_name).type
+    rng = np.random.default_rng(17)
+    with precision(64 if dtype_name == "float64" else 32):
+        domain = Box(x=100, y=100)
+        ext = combine_sides(x=0, y=(0, BOUNDARY))
+        shapes = StaggeredGrid(0, ext, domain, x=16, y=16, backend=emu_backend).component_shapes
+        v_np = [rng.standard_normal((2,) + sh).astype(dtype) * 4 for sh in shapes]
+        s_np = rng.standard_normal((40, 40)).astype(dtype)
+        v = StaggeredGrid(v_np, ext, domain, x=16, y=16, backend=emu_backend)
+        s = CenteredGrid(s_np, ZERO_GRADIENT, domain, x=40, y=40, backend=emu_backend)
+        dom_v = O.Domain((16, 16), (0, 0), (100, 100), ((O.CLOSED, O.CLOSED), (O.CLOSED, O.OPEN)))
+        dom_s = O.Domain((40, 40), (0, 0), (100, 100), ((O.CLOSED, O.CLOSED),) * 2)
+        s_codes = ((O.OPEN, O.OPEN),) * 2
+        tol = 2e-5 if dtype_name == "float32" else 1e-12
+        sl = advect.semi_lagrangian(s, v, 1.5)
+        ref = O.semi_lagrangian_centered_general(s_np[None], dom_s, v_np, dom_v, 1.5, s_codes)
+        assert sl.batch_size == 2 and sl.resolution == s.resolution
+        np.testing.assert_allclose(sl.numpy(), ref, atol=tol * np.abs(ref).max())
+        mc = advect.mac_cormack(s, v, 1.5, correction_strength=0.8)
+        ref = O.semi_lagrangian_centered_general(s_np[None], dom_s, v_np, dom_v, 1.5, s_codes, correction_strength=0.8)
+        assert (np.abs(mc.numpy() - ref) > tol * 10 * np.abs(ref).max()).mean() < 5e-3       # clamp windows may flip at cell boundaries
+        assert mc.numpy().max() <= s_np.max() + 1e-6 and mc.numpy().min() >= s_np.min() - 1e-6
+        buoyancy = resample(s * (0, 0.1), to=v)
+        ref = O.resample_centered_general(s_np[None], dom_s, s_codes, None, dom_v, staggered=True, vector=(0.0, 0.1))
+        assert [tuple(c.shape) for c in buoyancy.values] == [(1,) + sh for sh in shapes]
+        for a, b in zip(buoyancy.numpy(), ref):
+            np.testing.assert_allclose(a, b[0], atol=tol)
+        fine = resample(CenteredGrid(v_np[0][0, :, :15] if False else rng.standard_normal((16, 16)).astype(dtype), 1.5, domain, x=16, y=16, backend=emu_backend), to=s)
+        assert fine.resolution == s.resolution and fine.boundary == s.boundary
+        # velocity advected by a velocity on a finer grid, component by component
+        shapes2 = StaggeredGrid(0, ext, domain, x=24, y=20, backend=emu_backend).component_shapes
+        w_np = [rng.standard_normal((1,) + sh).astype(dtype) * 3 for sh in shapes2]
+        w = StaggeredGrid(w_np, ext, domain, x=24, y=20, backend=emu_backend)
+        adv = advect.semi_lagrangian(v, w, 0.7)
+        dom_w = O.Domain((24, 20), (0, 0), (100, 100), ((O.CLOSED, O.CLOSED), (O.CLOSED, O.OPEN)))
+        for d in range(2):
+            pts = [np.broadcast_to(p[None], (2,) + p.shape) for p in O.face_positions(d, dom_v, dtype)]
+            u = O.sample_staggered_at([np.broadcast_to(c, (2,) + c.shape[1:]) for c in w_np], dom_w, pts)
+            back = [p + uc * dtype(-0.7) for p, uc in zip(pts, u)]
+            codes, consts = O._comp_codes(dom_v, d)
+            ref = O.grid_sample(v_np[d], O._index_coords(back, d, dom_v, dtype), codes, consts)
+            np.testing.assert_allclose(adv.numpy()[d], ref, atol=tol * 10 * np.abs(ref).max())
+    with pytest.raises(NotImplementedError):
+        advect.mac_cormack(v, w, 0.5)
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
