@@ -290,6 +290,11 @@ int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, i
  * search direction in LDS, no kernel boundary or host polling inside the loop; cg_small.hip). enable = 0 forces the marching
  * kernels for every size (A/B measurements, tests of the marching path on small grids). Default: enabled. */
 int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
+/* 'CG' with the marching kernels updates the solution every OTHER iteration only: x does not enter the recurrence, and the step that
+ * was skipped is recovered in the next update from operands that kernel reads anyway (d_k = (d_{k+1} - r_{k+1}) / beta_{k+1}), so an
+ * iteration moves 7 instead of 8 words per cell. Same iterates r, d, alpha, beta; x equal up to rounding. enable = 0 updates x in
+ * every iteration (A/B measurements, tests). Default: enabled. */
+int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
 /* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
  * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);

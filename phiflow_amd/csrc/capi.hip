@@ -756,6 +756,12 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
     return PHIHIP_OK;
 }
 
+int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->defer_x = enable != 0;
+    return PHIHIP_OK;
+}
+
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     PHIHIP_REQUIRE(family >= 0 && family < 3, "tuning family must be 0 (apply / residual), 1 (matvec) or 2 (update)");

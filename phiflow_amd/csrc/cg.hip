@@ -140,18 +140,40 @@ __global__ __launch_bounds__(kBlock) void cg_state_kernel(int kind, const CgStat
 }
 
 // x += alpha * d for the true-residual refresh iterations (PhiML recomputes r = y - A x every 50th iteration)
+// `r_pending` != nullptr: x also lacks the previous step (UPDATE_R ran last): add both like UPDATE_X2, r = the residual before this step
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, int kind, const CgState* st_in, CgState* st_out, const double* part_dq,
-                                                    const double* part_dr, int nblk, CgParams prm, long long cells) {
+__global__ __launch_bounds__(kBlock) void cg_axpy_x(T* x, const T* d, const T* r_pending, int kind, const CgState* st_in, CgState* st_out,
+                                                    const double* part_dq, const double* part_dr, int nblk, CgParams prm, long long cells) {
     __shared__ double red[kBlock / kWave];
     __shared__ CgState sh;
     const int b = blockIdx.y;
-    const CgState S = cg_prologue(kind, st_in, st_out, part_dq, part_dr, nblk, prm, b, blockIdx.x == 0, red, &sh);
+    const CgState S = cg_prologue(kind, st_in, st_out, part_dq, part_dr, nblk, prm, b, blockIdx.x == 0, red, &sh, 0, 0);
     if (S.cont == 0) return;
     const T alpha = (T)S.alpha;
     const long long base = (long long)b * cells;
+    if (r_pending) {
+        const T c1 = (T)(S.alpha_prev / S.beta);
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock) {
+            const T dv = d[base + i];
+            x[base + i] = x[base + i] + c1 * (dv - r_pending[base + i]) + alpha * dv;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock)
         x[base + i] = fma(alpha, d[base + i], x[base + i]);
+}
+
+// after the loop: batch entries that stopped right after an UPDATE_R step still lack alpha * d of that step
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_flush_x(T* x, const T* d0, const T* d1, const CgState* st, long long cells) {
+    const int b = blockIdx.y;
+    const CgState S = st[b];
+    if (!S.pending) return;
+    const T alpha = (T)S.alpha;
+    const T* d = (S.pend_buf ? d1 : d0) + (long long)b * cells;
+    const long long base = (long long)b * cells;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < cells; i += (long long)gridDim.x * kBlock)
+        x[base + i] = fma(alpha, d[i], x[base + i]);
 }
 
 // per-workgroup partial sums of a . b ('CG-adaptive' refresh iterations: r_new . A d with both vectors stored)
@@ -309,6 +331,9 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
     }
     bool first = true;
+    // x does not enter the recurrence: update it every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
+    const bool defer = ctx->defer_x && !ad;
+    bool pending = false;
     int nblk_rr = g.nblk;   // workgroup count of the kernel that last wrote part_rr (RESID or UPDATE)
     const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
     CgState* hst = (CgState*)ctx->host_state;
@@ -328,9 +353,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         if (solve->refresh_every > 0 && k % solve->refresh_every == 0) {
             {
                 LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-                hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new, pro_alpha,
-                                   (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq, (const double*)part_dr, g_mv.nblk, prm, v.cells);
+                hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d_new,
+                                   (const T*)(pending ? r : nullptr), pro_alpha, (const CgState*)st[cur], st[cur ^ 1], (const double*)part_dq,
+                                   (const double*)part_dr, g_mv.nblk, prm, v.cells);
                 cur ^= 1;
+                pending = false;
             }
             if (ad) {   // q = A d is not kept by the fused kernels: store it once (into the free d buffer) for sum r_new . q below
                 MarchArgs<T> a = base;
@@ -356,8 +383,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             a.a = d_new; a.o1 = (T*)x; a.o2 = r; a.part1 = part_rr; a.part2 = part_rq;
             a.prologue = pro_alpha;
             a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_dq; a.pin2 = part_dr; a.nblk_in = g_mv.nblk;
+            a.pend_buf = k & 1;
+            const int mode = !defer ? mode_up : (pending ? MODE_UPDATE_X2 : MODE_UPDATE_R);
+            if (defer) pending = !pending;
             LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c_up, mode_up, has_flags, g_up, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, c_up, mode, has_flags, g_up, a, s));
             cur ^= 1;
             nblk_rr = g_up.nblk;
         }
@@ -389,6 +419,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)(first ? PRO_FIRST : pro_beta), (const CgState*)st[cur],
                            st[cur ^ 1], (const double*)part_rr, (const double*)((first || !ad) ? part_yy : part_rq), nblk_rr, prm);
         cur ^= 1;
+    }
+    if (defer) {
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        hipLaunchKernelGGL(cg_flush_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d[0], (const T*)d[1],
+                           (const CgState*)st[cur], v.cells);
     }
     ctx->last_state = st[cur];
     ctx->last_state_batch = v.batch;
@@ -514,7 +549,7 @@ static int slab_update_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
     if (x_only) {
         const int axpy_blocks = (int)((v.cells + kBlock - 1) / kBlock < 2048 ? (v.cells + kBlock - 1) / kBlock : 2048);
         LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-        hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d, (int)PRO_ALPHA,
+        hipLaunchKernelGGL(cg_axpy_x<T>, dim3(axpy_blocks, v.batch), dim3(kBlock), 0, s, (T*)x, (const T*)d, (const T*)nullptr, (int)PRO_ALPHA,
                            (const CgState*)su.st[ctx->slab_cur], su.st[ctx->slab_cur ^ 1], sum_in, (const double*)nullptr, 1, prm, v.cells);
         ctx->slab_cur ^= 1;
         PHIHIP_CHECK_HIP(hipGetLastError());

@@ -1,5 +1,5 @@
 // march_inst.hip -- explicit instantiation + dispatch of march_kernel for one (element type, dimensionality) pair.
-// Compiled four times (-DPHIHIP_INST_F64=0|1 -DPHIHIP_INST_DIM3=0|1) so the ~80 kernels per pair build in parallel.
+// Compiled four times (-DPHIHIP_INST_F64=0|1 -DPHIHIP_INST_DIM3=0|1) so the ~100 kernels per pair build in parallel.
 #include "common.hpp"
 #include "march_dispatch.hpp"
 
@@ -37,6 +37,8 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
         PHIHIP_MODE_CASE(MODE_UPDATE)
         PHIHIP_MODE_CASE(MODE_MATVEC_AD)
         PHIHIP_MODE_CASE(MODE_UPDATE_AD)
+        PHIHIP_MODE_CASE(MODE_UPDATE_R)
+        PHIHIP_MODE_CASE(MODE_UPDATE_X2)
         default:
             set_error("march: bad mode %d", mode);
             return PHIHIP_ERR_BAD_ARG;

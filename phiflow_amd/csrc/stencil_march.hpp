@@ -13,6 +13,10 @@
 //   MATVEC  S = r + beta * d_old   d_new = S                       sum S * (A S)        (q = A d is never stored)
 //   UPDATE  S = d                  x += alpha S ; r -= alpha A S   sum r_new^2          (q recomputed from d)
 // so one CG iteration moves 3 + 5 = 8 words per cell through HBM instead of the textbook 10-11.
+// UPDATE_R / UPDATE_X2 halve the traffic of `x`: the solution does not enter the recurrence, so every other iteration skips it
+// (UPDATE_R: r -= alpha A S only, 3 words) and the next one adds both steps at once -- the previous search direction is recovered
+// from operands the kernel reads anyway, d_k = (d_{k+1} - r_{k+1}) / beta_{k+1}:
+//   UPDATE_X2   x += (alpha_k / beta_{k+1}) (S - r) + alpha_{k+1} S ; r -= alpha_{k+1} A S        => 7 words per iteration on average.
 // MATVEC_AD / UPDATE_AD are the same passes for PhiML's 'CG-adaptive' (SURVEY Appendix B.2): they additionally reduce
 // sum d * r resp. sum r_new * (A d), from which alpha = (d.r)/(d.q) and d = r - ((r.q)/(d.q)) d are formed.
 #pragma once
@@ -26,7 +30,7 @@ constexpr int kWave = 64;
 
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
                                                                             // neighbour slab's halo buffer (MarchArgs::a_lo ...)
-enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5 };
+enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5, MODE_UPDATE_R = 6, MODE_UPDATE_X2 = 7 };
 
 // Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
 // iteration: every workgroup of the NEXT kernel re-reduces the previous kernel's per-workgroup partial sums in a fixed order
@@ -35,7 +39,10 @@ enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 
 struct CgState {
     double alpha, beta;
     double rsq, rsq0, rhs_sq, tol_sq, dq;
+    double alpha_prev;       // alpha of the previous iteration (UPDATE_X2 applies it together with the current one)
     int32_t cont, iterations, converged, diverged;
+    int32_t pending;         // 1: x still lacks alpha * d of the last iteration (UPDATE_R ran); flushed by the paired update or at the end
+    int32_t pend_buf;        // which of the two d buffers holds that direction
 };
 
 struct CgParams {
@@ -58,7 +65,8 @@ __device__ __forceinline__ bool cg_finite(double v) { return (v == v) && v <= 1.
 // PhiML's cg loop body bookkeeping, split at its two reductions
 __device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, double sum2, const CgParams& prm) {
     if (kind == PRO_FIRST) {
-        s.alpha = 0; s.beta = 0; s.dq = 0;
+        s.alpha = 0; s.beta = 0; s.dq = 0; s.alpha_prev = 0;
+        s.pending = 0; s.pend_buf = 0;
         s.rsq = sum1; s.rsq0 = sum1; s.rhs_sq = sum2;
         const double t1 = prm.rtol * prm.rtol * sum2, t2 = prm.atol * prm.atol;
         s.tol_sq = t1 > t2 ? t1 : t2;
@@ -79,6 +87,7 @@ __device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, 
         if (s.cont) {
             s.iterations += 1;
             s.dq = sum1;
+            s.alpha_prev = s.alpha;
             s.alpha = sum1 != 0 ? (kind == PRO_ALPHA ? s.rsq : sum2) / sum1 : 0;
         }
     }
@@ -110,6 +119,7 @@ struct MarchArgs {
     CgParams prm;
     int prologue;          // CgPrologue
     int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
+    int pend_buf;          // UPDATE_R: index of the d buffer this launch reads (recorded with the pending flag)
     T w0, w1, w2;          // 1 / dx^2 per internal axis
     // slab decomposition along a0: one plane [batch][n1][n2] of the source array(s) below plane 0 / above plane
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
@@ -185,7 +195,8 @@ __device__ __forceinline__ double reduce_partials(const double* part, int n, dou
 
 // Prologue shared by every kernel of the CG loop: returns the advanced control block to all threads of the workgroup.
 __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, CgState* st_out, const double* pin1, const double* pin2,
-                                              int nblk, const CgParams& prm, int b, bool writer, double* red, CgState* sh) {
+                                              int nblk, const CgParams& prm, int b, bool writer, double* red, CgState* sh, int pending = -1,
+                                              int pend_buf = 0) {
     // the control block is fetched BEFORE the reductions so that its memory round trip overlaps theirs
     CgState s = CgState();
     if (threadIdx.x == 0 && kind != PRO_FIRST) s = st_in[b];
@@ -194,6 +205,10 @@ __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, C
     if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
     if (threadIdx.x == 0) {
         s = cg_advance(kind, s, s1, s2, prm);
+        if (pending >= 0 && s.cont) {   // an UPDATE phase of a running entry: does x lag one step behind afterwards?
+            s.pending = pending;
+            s.pend_buf = pend_buf;
+        }
         *sh = s;
         if (writer && kind >= PRO_FIRST) st_out[b] = s;
     }
@@ -212,7 +227,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     using VT = Vec<T, V>;
     using VF = Vec<uint8_t, V>;
     constexpr bool IS_MV = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD;
-    constexpr bool IS_UP = MODE == MODE_UPDATE || MODE == MODE_UPDATE_AD;
+    constexpr bool IS_UP = MODE == MODE_UPDATE || MODE == MODE_UPDATE_AD || MODE == MODE_UPDATE_R || MODE == MODE_UPDATE_X2;
+    constexpr bool HAS_X = IS_UP && MODE != MODE_UPDATE_R;   // UPDATE_R leaves x alone
     constexpr bool AD = MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_AD;
 
     __shared__ __attribute__((aligned(16))) T lds[2][LROWS * LS];
@@ -287,10 +303,12 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     load_raw(i_first, Ra_c, Rb_c);
 
     if (p.prologue != PRO_NONE) {
-        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state);
+        const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state,
+                                      IS_UP ? (MODE == MODE_UPDATE_R ? 1 : 0) : -1, p.pend_buf);
         if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
         alpha = (T)S.alpha;
         beta = (T)S.beta;
+        if (MODE == MODE_UPDATE_X2) beta = (T)(S.alpha_prev / S.beta);   // coefficient of (S - r) = beta_{k+1} d_k; beta > 0 while running
     }
     // `own`: the plane belongs to this workgroup's chunk (MATVEC_AD sums d_new * r over exactly those)
     auto combine = [&](const VT (&A)[R], const VT (&B)[R], VT (&S)[R], bool own) {
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             const long long off = ((long long)i * n1 + (j1b + rr)) * n2 + j2;
             if (MODE == MODE_RESID) E.e1[rr] = vec_load<T, V>(p.b + base + off);
             if (IS_UP) {
-                E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
+                if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
                 E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
             }
             if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + fbase + off);
@@ -483,12 +501,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                 VT xn, rn;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
+                    if (MODE == MODE_UPDATE_X2) xn.v[v] = Ec.e1[rr].v[v] + beta * (Sc[rr].v[v] - Ec.e2[rr].v[v]) + alpha * Sc[rr].v[v];
+                    else if (HAS_X) xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
                     rn.v[v] = Ec.e2[rr].v[v] - alpha * q.v[v];
                     acc1 += rn.v[v] * rn.v[v];
                     if (AD) acc2 += rn.v[v] * q.v[v];
                 }
-                vec_store<T, V>(p.o1 + off, xn);
+                if (HAS_X) vec_store<T, V>(p.o1 + off, xn);
                 vec_store<T, V>(p.o2 + off, rn);
             }
         }

@@ -117,6 +117,28 @@ def test_cg_matches_oracle(emu_ctx, res, bc, dtype):
         emu_ctx.set_small_grid_solver(True)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_deferred_x_update(emu_ctx, dtype):
+    """ the marching 'CG' updates x every other iteration (UPDATE_R / UPDATE_X2, phihip_set_deferred_x_update): same solution as the
+    plain update for odd and even iteration counts, an odd refresh period, early exits of single batch entries (flush of the pending
+    step) -- each against the oracle and against the plain path """
+    dom, grid = pc.make_case((8, 12, 16), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=3)
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        for kwargs in (dict(max_iter=7, fixed_iterations=True), dict(max_iter=10, refresh=3, fixed_iterations=True),
+                       dict(max_iter=9, refresh=4, fixed_iterations=True), dict(rtol=1e-3), dict()):
+            xs = []
+            for defer in (True, False):
+                emu_ctx.set_deferred_x_update(defer)
+                x, info = pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(8), **kwargs)
+                xs.append((x, [i.iterations for i in info]))
+            assert xs[0][1] == xs[1][1]                                  # the recurrence does not see x
+            assert pc.rel_l2(xs[0][0], xs[1][0]) <= (5e-6 if dtype == np.float32 else 1e-11)    # recovering d_k costs a few digits of x
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+        emu_ctx.set_deferred_x_update(True)
+
+
 def test_cg_fixed_iterations_and_refresh(emu_ctx):
     """ benchmark mode: tolerances 0, exactly max_iterations; refresh every 7 exercises the true-residual branch """
     rng = np.random.default_rng(5)

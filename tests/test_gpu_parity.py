@@ -263,6 +263,28 @@ def test_union_obstacles(ctx, mem):
     assert e.value.status == -3
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cg_deferred_x_update(ctx, mem, dtype):
+    """ the marching 'CG' updates x every other iteration (UPDATE_R / UPDATE_X2, phihip_set_deferred_x_update): same solution as the
+    plain update for odd and even iteration counts, an odd refresh period, early exits of single batch entries (flush of the pending
+    step) -- each against the oracle and against the plain path """
+    dom, grid = pc.make_case((32, 24, 64), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=3)
+    try:
+        ctx.set_small_grid_solver(False)
+        for kwargs in (dict(max_iter=7, fixed_iterations=True), dict(max_iter=10, refresh=3, fixed_iterations=True),
+                       dict(max_iter=9, refresh=4, fixed_iterations=True), dict(rtol=1e-3), dict()):
+            xs = []
+            for defer in (True, False):
+                ctx.set_deferred_x_update(defer)
+                x, info = pc.check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(8), **kwargs)
+                xs.append((x, [i.iterations for i in info]))
+            assert xs[0][1] == xs[1][1]                                  # the recurrence does not see x
+            assert pc.rel_l2(xs[0][0], xs[1][0]) <= (5e-6 if dtype == np.float32 else 1e-11)    # recovering d_k costs a few digits of x
+    finally:
+        ctx.set_small_grid_solver(True)
+        ctx.set_deferred_x_update(True)
+
+
 def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):
     """ the benchmark mode (tolerances 0, exactly 100 iterations, refresh at 50) at 64^3 periodic fp32:
     pressure within 1e-4 rel-L2 of the NumPy oracle (north-star tolerance) """

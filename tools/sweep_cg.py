@@ -25,12 +25,14 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--configs", default="")
     ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
+    ap.add_argument("--defer", type=int, default=1, help="0: update x in every iteration (phihip_set_deferred_x_update)")
     ap.add_argument("--family", type=int, default=-1, help="-1: all kernels share the configuration; 1 = MATVEC only, 2 = UPDATE only")
     args = ap.parse_args()
     n = args.size
     dev = torch.device("cuda:0")
     lib = C.Library(args.lib, strict=False) if args.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
+    ctx.set_deferred_x_update(bool(args.defer))
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
     L = 2 * math.pi
@@ -76,7 +78,7 @@ def main():
         sc = prof["cg_scalar"][1] / max(1, prof["cg_scalar"][0])
         words = esize
         plans = {f: ctx.query_plan(grid, False, f) for f in (1, 2)}
-        out = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "family": args.family, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
+        out = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "family": args.family, "defer": args.defer, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
                "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_scalar": round(sc, 5),
                "ms_iter_events": round(mv + up + 2 * sc, 5), "ms_iter_wall": round(wall_ms / args.iters, 5),
                "alg_GBs_iter_wall": round(10 * words * cells / (wall_ms / args.iters * 1e-3) / 1e9, 1),
