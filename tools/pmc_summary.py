@@ -20,7 +20,8 @@ from collections import defaultdict
 def classify(name):
     if "march_kernel" in name:
         m = re.search(r"march_kernel<\s*(\w+),\s*(\d+),\s*(\d+),\s*(\d+),\s*(\d+)", name)
-        mode = {0: "laplace_apply", 1: "cg_residual", 2: "cg_matvec_dot", 3: "cg_update"}.get(int(m.group(5)), "march") if m else "march"
+        mode = {0: "laplace_apply", 1: "cg_residual", 2: "cg_matvec_dot", 3: "cg_update", 4: "cg_matvec_dot_adaptive", 5: "cg_update_adaptive",
+                6: "cg_update_r", 7: "cg_update_x2"}.get(int(m.group(5)), "march") if m else "march"
         return f"{mode}<{m.group(1)},V{m.group(2)},R{m.group(3)},TPR{m.group(4)}>" if m else mode
     if "elementwise" in name.lower() or "copy" in name.lower():
         return "calib_copy"
