@@ -702,7 +702,7 @@ int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void
 
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]) {
     PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "query_plan: NULL argument");
-    PHIHIP_REQUIRE(family >= 0 && family < 3, "tuning family must be 0 (apply / residual), 1 (matvec) or 2 (update)");
+    PHIHIP_REQUIRE(family >= 0 && family < 4, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update) or 3 (r-only update)");
     GridView v;
     PHIHIP_TRY(make_view(grid, &v));
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -742,7 +742,7 @@ int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], doubl
 int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < 4; ++f) {
         ctx->tuning[f].rows = rows_per_thread;
         ctx->tuning[f].tpr = threads_per_row;
         ctx->tuning[f].chunk = chunk_planes;
@@ -764,7 +764,7 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable) {
 
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
-    PHIHIP_REQUIRE(family >= 0 && family < 3, "tuning family must be 0 (apply / residual), 1 (matvec) or 2 (update)");
+    PHIHIP_REQUIRE(family >= 0 && family < 4, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update) or 3 (r-only update)");
     PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
     ctx->tuning[family].rows = rows_per_thread;
     ctx->tuning[family].tpr = threads_per_row;

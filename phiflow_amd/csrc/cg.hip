@@ -39,7 +39,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     c->vec = (v.n[2] % vmax == 0) ? vmax : 1;
     const Tuning& t = ctx->tuning[family];
     const int mode = family_mode(family);
-    const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : 1.0 / 3.0);
+    const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : 1.0 / 3.0);   // UPDATE_R: d is 1 of 3 words
+    // the r-only update (2 loads + 1 store per cell) prefers the tiles of MATVEC (family sweep: 256^3 (1,64) x 16, 512^3 (2,32) x 64)
+    const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R;
 
     auto tile_of = [&](int id, int* t1, int* t2) {
         const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
@@ -57,7 +59,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         const double tiles = (double)tiles_of(cand) * v.batch;
         if (v.rank != 3) {
             const double rounds = tiles / slots;
-            const double per_cu = family == FAM_MATVEC ? 4.0 : 2.0;
+            const double per_cu = mv_like ? 4.0 : 2.0;
             const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
             *score_out = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
             return 1;
@@ -65,7 +67,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         static const int kChunks[7] = {64, 48, 32, 24, 16, 12, 8};
         int best = 0;
         double best_score = -1.0;
-        const double per_cu = family == FAM_MATVEC ? 4.0 : 2.0;
+        const double per_cu = mv_like ? 4.0 : 2.0;
         const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
         for (int k = 0; k < 7; ++k) {
             const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
@@ -98,8 +100,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         // at equal chunk length, MATVEC medium tiles and the full-row tile (1, 64)
         static const int pref_mv[6] = {2, 5, 1, 0, 3, 4}, pref_up[6] = {4, 3, 2, 1, 0, 5};
         static const double bonus_mv[6] = {1.0, 1.0, 0.98, 0.97, 0.93, 0.93}, bonus_up[6] = {1.0, 1.0, 0.98, 0.98, 0.97, 0.97};
-        const int* pref = family == FAM_MATVEC ? pref_mv : pref_up;
-        const double* bonus = family == FAM_MATVEC ? bonus_mv : bonus_up;
+        const int* pref = mv_like ? pref_mv : pref_up;
+        const double* bonus = mv_like ? bonus_mv : bonus_up;
         double best_score = -1.0;
         for (int k = 0; k < 6; ++k) {
             const int cand = pref[k];
@@ -272,13 +274,15 @@ template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
                 const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
     if (ctx->small_cg && v.cells <= small_cg_limit(v.dtype)) return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
-    MarchConfig c, c_mv, c_up;   // residual / MATVEC / UPDATE may run different tile shapes
-    MarchGrid g, g_mv, g_up;
+    MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
+    MarchGrid g, g_mv, g_up, g_ur;
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_MATVEC, &c_mv, &g_mv));
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE, &c_up, &g_up));
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE_R, &c_ur, &g_ur));
     const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
-    const int nblk_max = g.nblk > g_mv.nblk ? (g.nblk > g_up.nblk ? g.nblk : g_up.nblk) : (g_mv.nblk > g_up.nblk ? g_mv.nblk : g_up.nblk);
+    int nblk_max = g.nblk > g_mv.nblk ? (g.nblk > g_up.nblk ? g.nblk : g_up.nblk) : (g_mv.nblk > g_up.nblk ? g_mv.nblk : g_up.nblk);
+    nblk_max = nblk_max > g_ur.nblk ? nblk_max : g_ur.nblk;
     const size_t part_n = (size_t)v.batch * nblk_max;
     PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
@@ -386,10 +390,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             a.pend_buf = k & 1;
             const int mode = !defer ? mode_up : (pending ? MODE_UPDATE_X2 : MODE_UPDATE_R);
             if (defer) pending = !pending;
+            const bool r_only = mode == MODE_UPDATE_R;
             LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
-            PHIHIP_TRY(launch_march_any<T>(v, c_up, mode, has_flags, g_up, a, s));
+            PHIHIP_TRY(launch_march_any<T>(v, r_only ? c_ur : c_up, mode, has_flags, r_only ? g_ur : g_up, a, s));
             cur ^= 1;
-            nblk_rr = g_up.nblk;
+            nblk_rr = r_only ? g_ur.nblk : g_up.nblk;
         }
         if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
             // Peek at the decision the next MATVEC prologue will take, without advancing the chain -- and WITHOUT draining the

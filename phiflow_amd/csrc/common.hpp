@@ -93,7 +93,7 @@ struct DeviceBuffer {
 struct phihip_ctx {
     int device = 0;
     int num_cu = 256;
-    phihip::Tuning tuning[3];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE
+    phihip::Tuning tuning[4];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE, 3 = UPDATE_R
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adj_q, ws_adj_l;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
