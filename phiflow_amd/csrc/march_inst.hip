@@ -67,6 +67,10 @@ static int occupancy_cfg(int mode, bool flags) {
         PHIHIP_OCC_CASE(MODE_RESID)
         PHIHIP_OCC_CASE(MODE_MATVEC)
         PHIHIP_OCC_CASE(MODE_UPDATE)
+        PHIHIP_OCC_CASE(MODE_MATVEC_AD)
+        PHIHIP_OCC_CASE(MODE_UPDATE_AD)
+        PHIHIP_OCC_CASE(MODE_UPDATE_R)
+        PHIHIP_OCC_CASE(MODE_UPDATE_X2)
         default: return 1;
     }
 #undef PHIHIP_OCC_CASE
