@@ -130,6 +130,13 @@ class Library:
     def __init__(self, path: str, strict: bool = True):
         """ strict=False (benchmark A/B of an older build only): symbols missing from the library are skipped """
         self.path = os.path.abspath(path)
+        # PyTorch-ROCm ships its own libamdhip64: whichever HIP runtime is loaded first owns the devices, a second copy sees "No HIP
+        # GPUs". When torch is installed (it provides the device tensors for the Python layer), let it load its runtime first so that
+        # libphihip binds to the same one. C / C++ callers of the ABI are not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             self.dll = ctypes.CDLL(self.path)
         except OSError as exc:
