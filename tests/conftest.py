@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
-EMU_LIB = os.path.join(EMU_DIR, "libphihip_emu.so")
+EMU_LIB = os.environ.get("PHIHIP_EMU_LIB", os.path.join(EMU_DIR, "libphihip_emu.so"))   # tools/asan_emu.sh points it at the ASan build
 
 
 def pytest_configure(config):

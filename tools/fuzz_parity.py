@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--max-res", type=int, default=0, help="largest resolution per axis (default: 22 in 2-D, 11 in 3-D; GPU: 48 / 20)")
     args = ap.parse_args()
     if args.emu:
-        ctx = C.Context(C.Library(os.path.join(ROOT, "tests", "hipemu", "libphihip_emu.so")), 0)
+        ctx = C.Context(C.Library(os.environ.get("PHIHIP_EMU_LIB", os.path.join(ROOT, "tests", "hipemu", "libphihip_emu.so"))), 0)
         mem = pc.NumpyMem()
     else:
         ctx = C.Context(C.load_default_library(), 0)
