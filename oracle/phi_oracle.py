@@ -319,25 +319,55 @@ def sample_centered_at(s: np.ndarray, dom: Domain, s_codes, s_consts, points: Li
     return grid_sample(s, _centered_index_coords(points, dom, s.dtype.type), s_codes, consts)
 
 
+def integrate_points(pts: List[np.ndarray], vel: List[np.ndarray], dom_v: Domain, dt: float, integrator: str = 'euler'):
+    """ advect.euler / advect.rk4 (phi/physics/advect.py:20-36): end points of `pts` moved by the velocity for the time dt (negative
+    for the back-trace); every velocity evaluation is sample(velocity, points) on the staggered sub-grids """
+    dtype = pts[0].dtype.type
+    v0 = sample_staggered_at(vel, dom_v, pts)
+    if integrator == 'euler':
+        return [p + u * dtype(dt) for p, u in zip(pts, v0)]
+    assert integrator == 'rk4', integrator
+    v_half = sample_staggered_at(vel, dom_v, [p + dtype(0.5 * dt) * u for p, u in zip(pts, v0)])
+    v_half2 = sample_staggered_at(vel, dom_v, [p + dtype(0.5 * dt) * u for p, u in zip(pts, v_half)])
+    v_full = sample_staggered_at(vel, dom_v, [p + dtype(dt) * u for p, u in zip(pts, v_half2)])
+    v_rk4 = [dtype(1 / 6.) * (a + dtype(2) * (b + c) + d) for a, b, c, d in zip(v0, v_half, v_half2, v_full)]
+    return [p + dtype(dt) * u for p, u in zip(pts, v_rk4)]
+
+
 def semi_lagrangian_centered_general(s: np.ndarray, dom_s: Domain, velocity: List[np.ndarray], dom_v: Domain, dt: float, s_codes, s_consts=None,
-                                     correction_strength: Optional[float] = None):
+                                     correction_strength: Optional[float] = None, integrator: str = 'euler'):
     """ advect.semi_lagrangian (correction_strength None) / advect.mac_cormack of a centred scalar by a velocity on another grid """
     dtype = s.dtype.type
     B = max(s.shape[0], velocity[0].shape[0])
     pts = [np.broadcast_to(p[None], (B,) + p.shape) for p in cell_positions(dom_s, dtype)]
     vel = [np.broadcast_to(c, (B,) + c.shape[1:]) for c in velocity]
     src = np.broadcast_to(s, (B,) + s.shape[1:])
-    u = sample_staggered_at(vel, dom_v, pts)
-    back = [p + uc * dtype(-dt) for p, uc in zip(pts, u)]
+    back = integrate_points(pts, vel, dom_v, -dt, integrator)
     consts = s_consts if s_consts is not None else [(0.0, 0.0)] * dom_s.rank
     fwd = sample_centered_at(src, dom_s, s_codes, consts, back)
     if correction_strength is None:
         return fwd
-    ahead = [p + uc * dtype(dt) for p, uc in zip(pts, u)]
+    ahead = integrate_points(pts, vel, dom_v, dt, integrator)
     bwd = sample_centered_at(fwd, dom_s, s_codes, consts, ahead)
     new = fwd + dtype(correction_strength * 0.5) * (src - bwd)
     lo, hi = closest_limits(src, _centered_index_coords(back, dom_s, dtype), s_codes, consts)
     return np.minimum(np.maximum(new, lo), hi)
+
+
+def semi_lagrangian_staggered_general(field: List[np.ndarray], dom_f: Domain, velocity: List[np.ndarray], dom_v: Domain, dt: float,
+                                      integrator: str = 'euler'):
+    """ advect.semi_lagrangian of a staggered field by a velocity on another grid and / or with the rk4 integrator: per component,
+    the stored faces are traced back and the component is interpolated on its own sub-grid """
+    dtype = field[0].dtype.type
+    B = max(field[0].shape[0], velocity[0].shape[0])
+    vel = [np.broadcast_to(c, (B,) + c.shape[1:]) for c in velocity]
+    out = []
+    for d in range(dom_f.rank):
+        pts = [np.broadcast_to(p[None], (B,) + p.shape) for p in face_positions(d, dom_f, dtype)]
+        back = integrate_points(pts, vel, dom_v, -dt, integrator)
+        codes, consts = _comp_codes(dom_f, d)
+        out.append(grid_sample(np.broadcast_to(field[d], (B,) + field[d].shape[1:]), _index_coords(back, d, dom_f, dtype), codes, consts))
+    return out
 
 
 def resample_centered_general(s: np.ndarray, dom_s: Domain, s_codes, s_consts, dom_t: Domain, staggered: bool = False,

@@ -1,6 +1,6 @@
 """
 Advection schemes backed by libphihip (reference: phi/physics/advect.py).
-Implemented on the HIP backend: `semi_lagrangian` / `advect` / `mac_cormack` with the `euler` integrator for StaggeredGrid
+Implemented on the HIP backend: `semi_lagrangian` / `advect` / `mac_cormack` with the `euler` (fused kernels) and `rk4` / `finite_rk4` integrators for StaggeredGrid
 and CenteredGrid fields advected by a StaggeredGrid velocity. Anything else raises `NotImplementedError`.
 """
 from typing import Callable
@@ -18,8 +18,15 @@ def euler(data: Field, velocity: Field, dt: float, v0=None):
     raise NotImplementedError("euler() is fused into the HIP semi-Lagrangian kernel; pass it as `integrator=euler`")
 
 
-def rk4(data, velocity, dt, v0=None):
-    raise NotImplementedError("rk4 back-tracing is not implemented on the HIP backend")
+def rk4(data: Field, velocity: Field, dt: float, v0=None):
+    """ Runge-Kutta-4 integrator marker (phi/physics/advect.py:27-36): `semi_lagrangian(..., integrator=rk4)` traces the sample points
+    back with four velocity evaluations (sampling.integrate_points) instead of one. """
+    raise NotImplementedError("pass rk4 as `integrator=rk4`")
+
+
+def finite_rk4(data: Field, velocity: Field, dt: float, v0=None):
+    """ rk4 with Euler fallback where the velocity is not finite (phi/physics/advect.py:38-47); marker like `rk4` """
+    raise NotImplementedError("pass finite_rk4 as `integrator=finite_rk4`")
 
 
 def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callable = euler) -> Field:
@@ -29,7 +36,7 @@ def semi_lagrangian(field: Field, velocity: Field, dt: float, integrator: Callab
         field: quantity to be advected (`StaggeredGrid` or `CenteredGrid`)
         velocity: `StaggeredGrid`; on the same grid the fused kernels run, otherwise the general sampling path (sampling.py)
         dt: time increment
-        integrator: only `euler` is available on the HIP backend
+        integrator: `euler` (fused kernels), `rk4` or `finite_rk4` (general sampling path)
 
     Returns:
         Field with the same sample points and boundary as `field`
@@ -46,11 +53,13 @@ def _scalar_boundary(field: Field):
 
 def _advect(field: Field, velocity: Field, dt: float, integrator: Callable, correction_strength) -> Field:
     """ shared argument handling of semi_lagrangian (correction_strength None) and mac_cormack """
-    if integrator is not euler:
-        raise NotImplementedError("HIP backend: grid advection supports integrator=euler only")
+    if integrator not in (euler, rk4, finite_rk4):
+        raise NotImplementedError("HIP backend: grid advection supports the integrators euler, rk4 and finite_rk4")
     if not velocity.is_staggered:
         raise NotImplementedError("HIP backend: the advecting velocity must be a StaggeredGrid")
     from . import sampling
+    if integrator is not euler:   # Runge-Kutta back-trace: explicit velocity evaluations at the intermediate points
+        return sampling.advect_general(field, velocity, float(dt), correction_strength, integrator.__name__)
     if not sampling.same_grid(field, velocity):
         # "velocity need not be sampled at same locations as field" (advect.py:193): gathers at explicit coordinates instead of the
         # fused kernels (Batched_Smoke.ipynb: 200^2 smoke advected by a 64^2 velocity)
@@ -105,7 +114,7 @@ def mac_cormack(field: Field, velocity: Field, dt: float, correction_strength=1.
         velocity: `StaggeredGrid` on the same grid
         dt: time increment
         correction_strength: factor on the error estimate (0 = semi-Lagrangian)
-        integrator: only `euler` is available on the HIP backend
+        integrator: `euler` (fused kernels), `rk4` or `finite_rk4` (general sampling path; centred fields only)
     """
     return _advect(field, velocity, dt, integrator, float(correction_strength))
 

@@ -133,26 +133,39 @@ def resample_general(value: Field, to: Field) -> Field:
     return Field(to.resolution, to.bounds, to.boundary, comps, True, be, batched)
 
 
-def advect_general(field: Field, velocity: Field, dt: float, correction_strength: Optional[float]) -> Field:
-    """ semi-Lagrangian / MacCormack advection of `field` by a velocity sampled on another grid (phi/physics/advect.py:156-215 with
-    euler :20-24): `lookup = x - dt * velocity(x)`, `new = field(lookup)`; MacCormack adds the backward pass and clamps to the min / max
-    of the field's values around the lookup. """
+def integrate_points(points: Sequence[torch.Tensor], velocity: Field, dt: float, integrator: str) -> List[torch.Tensor]:
+    """ `advect.euler` / `advect.rk4` / `advect.finite_rk4` (phi/physics/advect.py:20-47): where the points end up after dt """
+    v0 = sample_field(velocity, points)
+    if integrator == 'euler':
+        return [p + dt * u for p, u in zip(points, v0)]
+    v_half = sample_field(velocity, [p + (0.5 * dt) * u for p, u in zip(points, v0)])
+    v_half2 = sample_field(velocity, [p + (0.5 * dt) * u for p, u in zip(points, v_half)])
+    v_full = sample_field(velocity, [p + dt * u for p, u in zip(points, v_half2)])
+    v_rk4 = [(1 / 6.) * (a + 2 * (b + c) + d) for a, b, c, d in zip(v0, v_half, v_half2, v_full)]
+    if integrator == 'finite_rk4':      # Euler fallback where the RK4 velocity is not finite
+        v_rk4 = [torch.where(torch.isfinite(u), u, u0) for u, u0 in zip(v_rk4, v0)]
+    return [p + dt * u for p, u in zip(points, v_rk4)]
+
+
+def advect_general(field: Field, velocity: Field, dt: float, correction_strength: Optional[float], integrator: str = 'euler') -> Field:
+    """ semi-Lagrangian / MacCormack advection of `field` by a velocity sampled on another grid and / or with a Runge-Kutta back-trace
+    (phi/physics/advect.py:156-215): `lookup = integrator(x, velocity, -dt)`, `new = field(lookup)`; MacCormack adds the backward pass
+    and clamps to the min / max of the field's values around the lookup. """
     assert field.dims == velocity.dims and field.dtype == velocity.dtype
     if correction_strength is not None and field.is_staggered:
-        raise NotImplementedError("HIP backend: MacCormack advection of a StaggeredGrid needs the velocity on the same grid")
+        raise NotImplementedError("HIP backend: MacCormack advection of a StaggeredGrid needs the euler integrator and the velocity on the same grid")
     comps = [None] if field.is_centered else list(range(field.spatial_rank))
     B = max(field.batch_size, velocity.batch_size)
     outs = []
     for c in comps:
         pts = [p.expand(B, -1) for p in sample_points(field, c)]
-        u = sample_field(velocity, pts)                                   # euler(): v0 = sample(velocity, field.geometry)
-        back = [p - dt * uc for p, uc in zip(pts, u)]
+        back = integrate_points(pts, velocity, -dt, integrator)
         if correction_strength is None:
             new = sample_array(field, c, index_coords(field, c, back))
         else:
             fwd_vals, lo, hi = sample_array(field, c, index_coords(field, c, back), limits=True)
             fwd = Field(field.resolution, field.bounds, field.boundary, fwd_vals.reshape(B, *field.resolution.values()), False, field.backend, True)
-            ahead = [p + dt * uc for p, uc in zip(pts, u)]
+            ahead = integrate_points(pts, velocity, dt, integrator)
             bwd = sample_array(fwd, None, index_coords(fwd, None, ahead))
             own = (field.values if field.values.shape[0] == B else field.values.expand(B, *field.values.shape[1:])).reshape(B, -1)
             new = fwd_vals + (0.5 * correction_strength) * (own - bwd)

@@ -330,6 +330,42 @@ def test_fields_on_different_grids(emu_backend, dtype_name):
         advect.mac_cormack(v, w, 0.5)
 
 
+@pytest.mark.parametrize("dtype_name", ["float32", "float64"])
+def test_rk4_integrator(emu_backend, dtype_name):
+    """ `advect.semi_lagrangian(..., integrator=advect.rk4)` / `mac_cormack(..., integrator=advect.rk4)` (phi/physics/advect.py:27-36):
+    four velocity evaluations per back-trace; staggered self-advection and a centred scalar, same grid and a coarser velocity grid """
+    from oracle import phi_oracle as O
+    from phiflow_amd.flow import precision
+    dtype = np.dtype(dtype_name).type
+    rng = np.random.default_rng(23)
+    tol = 3e-5 if dtype_name == "float32" else 1e-12
+    with precision(64 if dtype_name == "float64" else 32):
+        domain = Box(x=100, y=80)
+        ext = combine_sides(x=PERIODIC, y=(0, BOUNDARY))
+        shapes = StaggeredGrid(0, ext, domain, x=20, y=16, backend=emu_backend).component_shapes
+        v_np = [rng.standard_normal((1,) + sh).astype(dtype) * 5 for sh in shapes]
+        v = StaggeredGrid(v_np, ext, domain, x=20, y=16, backend=emu_backend)
+        dom_v = O.Domain((20, 16), (0, 0), (100, 80), ((O.PERIODIC, O.PERIODIC), (O.CLOSED, O.OPEN)))
+        adv = advect.semi_lagrangian(v, v, 1.2, integrator=advect.rk4)
+        ref = O.semi_lagrangian_staggered_general(v_np, dom_v, v_np, dom_v, 1.2, integrator='rk4')
+        for a, b in zip(adv.numpy(), ref):
+            np.testing.assert_allclose(a, b, atol=tol * np.abs(b).max())
+        euler_ref = O.semi_lagrangian_staggered(v_np, v_np, 1.2, dom_v)
+        assert max(np.abs(a - b).max() for a, b in zip(adv.numpy(), euler_ref)) > 1e-2             # it is not the Euler back-trace
+        same = advect.semi_lagrangian(v, v, 1.2, integrator=advect.finite_rk4)
+        for a, b in zip(same.numpy(), adv.numpy()):
+            np.testing.assert_allclose(a, b, atol=0)
+        s_np = rng.standard_normal((2, 50, 40)).astype(dtype)
+        s = CenteredGrid(s_np, combine_sides(x=PERIODIC, y=ZERO_GRADIENT), domain, x=50, y=40, backend=emu_backend)
+        dom_s = O.Domain((50, 40), (0, 0), (100, 80), ((O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED)))
+        s_codes = ((O.PERIODIC, O.PERIODIC), (O.OPEN, O.OPEN))
+        mc = advect.mac_cormack(s, v, 0.9, integrator=advect.rk4)
+        ref = O.semi_lagrangian_centered_general(s_np, dom_s, v_np, dom_v, 0.9, s_codes, correction_strength=1.0, integrator='rk4')
+        assert (np.abs(mc.numpy() - ref) > tol * 10 * np.abs(ref).max()).mean() < 5e-3
+    with pytest.raises(NotImplementedError):
+        advect.semi_lagrangian(v, v, 1.0, integrator=lambda *a: None)
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
