@@ -366,6 +366,9 @@ int phihip_centered_to_staggered(phihip_ctx* ctx, const phihip_grid* grid, const
     return run_centered_to_staggered(ctx, v, sfield, s_bc, s_val, vec, accumulate, o, s);
 }
 
+static_assert(sizeof(phihip_obstacle) == 4 * 4 + 8 * 21, "phihip_obstacle layout is part of the ABI (phiflow_amd/_capi.py mirrors it)");
+static_assert(sizeof(phihip_solve) == 32 && sizeof(phihip_solve_info) == 32, "ABI structs");
+
 static int check_obstacles(const GridView& v, const phihip_obstacle* obstacles, int count) {
     PHIHIP_REQUIRE(count >= 0, "obstacle count must be >= 0");
     PHIHIP_REQUIRE(count == 0 || obstacles != nullptr, "obstacles is NULL");

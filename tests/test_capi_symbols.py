@@ -51,3 +51,4 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.Grid) == 4 * 3 + 4 * 3 + 8 * 3 + 8 * 3 + 4 * 6 + 8 * 18
     assert ctypes.sizeof(_capi.Solve) == 32
     assert ctypes.sizeof(_capi.SolveInfo) == 32
+    assert ctypes.sizeof(_capi.ObstacleStruct) == 4 * 4 + 8 * (3 + 3 + 3 + 3 + 9)      # kind, group, embed_mask, reserved + 21 doubles
