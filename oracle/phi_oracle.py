@@ -18,6 +18,8 @@ PARITY PIN STATUS
   * the reference stores NO golden output for make_incompressible / CG and cannot be executed here, so absolute
     pressure values are "parity unpinned" by the reference itself; they are guarded instead by independent
     cross-checks (discrete-FFT Poisson solve, SciPy sparse direct solve of the assembled operator).
+  * restated from the reference's call sites WITHOUT any reference test to pin them ("parity unpinned"): `cg_adaptive`, union /
+    embedded obstacles, sampling between different grids, the rk4 back-trace, moving / rotating obstacles, MacCormack's limiter.
 
 Conventions (reference citations are relative to /root/reference):
   * arrays are (batch, *spatial) C-contiguous, spatial order x,y,(z) => last spatial axis is the fast one
