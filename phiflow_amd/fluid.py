@@ -163,14 +163,21 @@ def _build_flags(velocity: Field, obstacles: Sequence[Obstacle], user_active: Op
         for b in range(OB):   # batched geometries (Batched_Smoke.ipynb): one mask per batch entry
             be.ctx.obstacle_accessible(grid1, *_obstacle_array(obstacles, velocity, b), accessible_t[b].data_ptr(), be.stream())
     active_t = None
+    AB = 1
     if user_active is not None:
         assert user_active.is_centered and user_active.resolution == velocity.resolution
-        assert not user_active.batched, "HIP backend: batched `active` masks are not supported yet"
-        active_t = (user_active.values[0] != 0).to(torch.uint8).contiguous()
-    if OB > 1:
-        assert active_t is None, "HIP backend: batched obstacle geometries cannot be combined with a user `active` mask yet"
-        flags = be.empty((OB,) + res, torch.uint8)
-        be.ctx.build_cellflags(velocity.grid_struct(batch=OB), accessible_t.data_ptr(), 0, OB, flags.data_ptr(), be.stream())
+        active_t = (user_active.values != 0).to(torch.uint8).contiguous()       # (batch | 1, *res)
+        AB = active_t.shape[0]
+    FB = max(OB, AB)      # per-batch masks (batched geometries, Batched_Smoke.ipynb, or a batched `active` field)
+    if FB > 1:
+        assert OB in (1, FB) and AB in (1, FB), f"obstacle batch {OB} and `active` batch {AB} do not match"
+        if accessible_t is not None and OB == 1:
+            accessible_t = accessible_t.expand(FB, *res).contiguous()
+        if active_t is not None and AB == 1:
+            active_t = active_t.expand(FB, *res).contiguous()
+        flags = be.empty((FB,) + res, torch.uint8)
+        be.ctx.build_cellflags(velocity.grid_struct(batch=FB), accessible_t.data_ptr() if accessible_t is not None else 0,
+                               active_t.data_ptr() if active_t is not None else 0, FB, flags.data_ptr(), be.stream())
         return flags
     flags = be.empty(res, torch.uint8)
     be.ctx.build_cellflags(grid1, accessible_t.data_ptr() if accessible_t is not None else 0,
@@ -211,12 +218,13 @@ def make_incompressible(velocity: Field,
     obstacles = _get_obstacles_for(obstacles, velocity)
     be = velocity.backend
     OB = _obstacle_batch(obstacles)
-    if OB > 1:
-        assert velocity.batch_size in (1, OB), f"velocity batch {velocity.batch_size} does not match the obstacles' batch {OB}"
-        if velocity.batch_size == 1:   # the same velocity meets a different obstacle in every batch entry
+    MB = max(OB, active.batch_size if active is not None else 1)     # batch size of the masks
+    if MB > 1:
+        assert velocity.batch_size in (1, MB), f"velocity batch {velocity.batch_size} does not match the batch {MB} of the obstacles / `active`"
+        if velocity.batch_size == 1:   # the same velocity meets a different obstacle / mask in every batch entry
             velocity = Field(velocity.resolution, velocity.bounds, velocity.boundary,
-                             [t.expand(OB, *t.shape[1:]).contiguous() for t in velocity.values], True, be, True)
-    mask_batch = velocity.batch_size if OB > 1 else 1
+                             [t.expand(MB, *t.shape[1:]).contiguous() for t in velocity.values], True, be, True)
+    mask_batch = velocity.batch_size if MB > 1 else 1
     all_active = active is None
     flags = None
     if obstacles or active is not None:
@@ -240,8 +248,8 @@ def make_incompressible(velocity: Field,
         # differentiable path: the same kernels behind torch.autograd.Function nodes (adjoint kernels in csrc/adjoint.hip)
         vin = [t.contiguous() for t in velocity.values]
         shapes = [tuple(t.shape) for t in vin]
-        if OB > 1:
-            raise NotImplementedError("HIP backend: gradients through batched obstacle geometries are not implemented")
+        if MB > 1:
+            raise NotImplementedError("HIP backend: gradients through batched obstacle geometries / `active` masks are not implemented")
         if obstacles:
             vin = list(_apply_obstacles_autograd(velocity, obstacles, vin))
         gsolve = solve.gradient_solve if getattr(solve, 'gradient_solve', None) is not None else solve

@@ -366,6 +366,38 @@ def test_rk4_integrator(emu_backend, dtype_name):
         advect.semi_lagrangian(v, v, 1.0, integrator=lambda *a: None)
 
 
+def test_user_active_mask_plain_and_batched(emu_backend):
+    """ make_incompressible(..., active=CenteredGrid) (phi/physics/fluid.py:97,139-148,200-202): the pressure is only solved where
+    active != 0 (identity rows elsewhere), the divergence is never balanced; one mask for all entries, and one mask per batch entry """
+    from oracle import phi_oracle as O
+    rng = np.random.default_rng(29)
+    n = 16
+    bounds = Box(x=1, y=1)
+    shapes = StaggeredGrid(0, 0, bounds, x=n, y=n, backend=emu_backend).component_shapes
+    v_np = [rng.standard_normal((2,) + sh).astype(np.float32) for sh in shapes]
+    v = StaggeredGrid(v_np, 0, bounds, x=n, y=n, backend=emu_backend)
+    masks = np.ones((2, n, n), np.float32)
+    masks[0, 3:6, 4:9] = 0
+    masks[1, 10:14, 2:5] = 0
+    dom = O.Domain((n, n), (0, 0), (1, 1), ((O.CLOSED, O.CLOSED),) * 2)
+
+    def oracle(vel, act):
+        div = O.divergence(vel, dom) * act
+        A = lambda q: O.masked_laplace(q, dom, None, act)
+        p, info = O.cg(A, div, np.zeros_like(div), 1e-5, 1e-5, 1000, 50)
+        return O.gradient_subtract(vel, p, dom, None), p, info
+    for act_np in (masks[:1], masks):                          # shared mask, per-entry masks
+        active = CenteredGrid(act_np if act_np.shape[0] > 1 else act_np[0], 0, bounds, x=n, y=n, backend=emu_backend)
+        v_new, p = fluid.make_incompressible(v, (), Solve('CG'), active=active)
+        vo, po, info = oracle(v_np, np.broadcast_to(act_np, masks.shape))
+        assert [abs(a - int(b)) <= 2 for a, b in zip(p.solve_info.iterations, info.iterations)] == [True, True]
+        np.testing.assert_allclose(p.numpy(), po, atol=3e-4 * np.abs(po).max())
+        for a, b in zip(v_new.numpy(), vo):
+            np.testing.assert_allclose(a, b, atol=3e-4 * np.abs(b).max())
+        inactive = np.broadcast_to(act_np, masks.shape) == 0
+        assert np.abs(p.numpy()[inactive]).max() == 0.0
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
