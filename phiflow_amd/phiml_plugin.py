@@ -118,19 +118,30 @@ def make_incompressible(velocity, obstacles=(), solve=None, active=None, order: 
     return from_hip(v, velocity, batch), from_hip(p, velocity, batch, ref._pressure_extrapolation(velocity.extrapolation))
 
 
-def _to_hip_obstacle(obstacle):
+def _to_hip_geometry(geo):
+    """ phi.geom Box / Sphere, their unions (`union(boxes)` = one Box stacked along an instance dim, phi/geom/_geom_ops.py:316-317) and
+    embedded geometries (`geom.infinite_cylinder`, phi/geom/_embed.py) -> phiflow_amd geometry """
     from phi.geom import Box, Sphere
-    geo = obstacle.geometry
+    from phiml import math
+    inst = math.instance(geo)
+    if inst:
+        return _hip.union([_to_hip_geometry(g) for g in math.unstack(geo, inst)])
+    if type(geo).__name__ == '_EmbeddedGeometry':
+        return _hip.embed(_to_hip_geometry(geo.geometry), tuple(geo.axes))
     dims = geo.vector.item_names
     if isinstance(geo, Sphere):
-        hgeo = _hip.Sphere(float(geo.radius), **{d: float(geo.center.vector[d]) for d in dims})
-    elif isinstance(geo, Box):
-        hgeo = _hip.Box(**{d: (float(geo.lower.vector[d]), float(geo.upper.vector[d])) for d in dims})
-    else:
-        raise NotImplementedError(f"obstacle geometry {type(geo).__name__}")
+        return _hip.Sphere(float(geo.radius), **{d: float(geo.center.vector[d]) for d in dims})
+    if isinstance(geo, Box):
+        return _hip.Box(**{d: (float(geo.lower.vector[d]), float(geo.upper.vector[d])) for d in dims})
+    raise NotImplementedError(f"obstacle geometry {type(geo).__name__}")
+
+
+def _to_hip_obstacle(obstacle):
+    geo = obstacle.geometry
+    dims = geo.vector.item_names
     vel = obstacle.velocity
     vel = [float(vel.vector[d]) for d in dims] if hasattr(vel, 'vector') else float(vel)
-    return _hip.Obstacle(hgeo, vel, float(obstacle.angular_velocity) if len(dims) == 2 else 0)
+    return _hip.Obstacle(_to_hip_geometry(geo), vel, float(obstacle.angular_velocity) if len(dims) == 2 else 0)
 
 
 def _advect(name):
