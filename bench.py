@@ -106,6 +106,32 @@ def cpu_baseline(n, cg_iters):
                       f"(oracle/phi_oracle.py, single-threaded NumPy), {dt:.1f} s"}
 
 
+def cpu_cg_variants(n, iters, dtype=np.float32):
+    """ part of the cpu_baseline leg: the two host forms of the CG -- the matrix-free NumPy restatement and the assembled
+    SciPy-CSR operator, which is what PhiML's NumPy backend iterates on after tracing `masked_laplace` (phi/physics/fluid.py:165) """
+    from oracle import phi_oracle as O
+    L = 2 * np.pi
+    dom = O.Domain((n, n, n), (0, 0, 0), (L, L, L), ((O.PERIODIC, O.PERIODIC),) * 3)
+    rng = np.random.default_rng(0)
+    rhs = rng.standard_normal((1, n, n, n)).astype(dtype)
+    rhs -= rhs.mean()
+    t0 = time.perf_counter()
+    x_mf, _ = O.cg(lambda p: O.masked_laplace(p, dom, None, None), rhs, np.zeros_like(rhs), 0.0, 0.0, iters, 50)
+    t_mf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    A = O.laplace_csr(dom, dtype)
+    t_asm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    x_sp, _ = O.cg(lambda p: (A @ p.reshape(-1)).reshape(p.shape), rhs, np.zeros_like(rhs), 0.0, 0.0, iters, 50)
+    t_sp = time.perf_counter() - t0
+    rel = float(np.linalg.norm(x_mf - x_sp) / np.linalg.norm(x_mf))
+    cells = n ** 3
+    return {"size": n, "iterations": iters, "matrix_free_numpy_Mcell_it_per_s": round(cells * iters / t_mf / 1e6, 1),
+            "scipy_csr_Mcell_it_per_s": round(cells * iters / t_sp / 1e6, 1), "csr_assembly_s": round(t_asm, 2),
+            "solutions_rel_l2": rel, "cores": 1}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +226,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_size > 0:
         cpu = cpu_baseline(args.cpu_size, args.cg_iters)
+        extra["cpu_cg_variants"] = cpu_cg_variants(96, 20)
 
     if rank == 0:
         out = {

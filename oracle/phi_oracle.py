@@ -710,6 +710,40 @@ def cg_adaptive(apply_A, y: np.ndarray, x0: np.ndarray, rtol: float, atol: float
     return x, SolveInfo(iterations, rsq, rhs_sq, converged, diverged)
 
 
+def laplace_csr(dom: Domain, dtype=np.float32):
+    """ the obstacle-free pressure operator of `masked_laplace` ASSEMBLED as a SciPy CSR matrix (N x N, 5 / 7 entries per row) -- what
+    `math.solve_linear` actually iterates on in the reference: PhiML traces `masked_laplace` into a sparse matrix per call
+    (`jit_compile_linear`, phi/physics/fluid.py:165) and its NumPy backend multiplies with scipy.sparse (SURVEY §8 a4/a5
+    [PHIML-RECALL]). Used for the CPU timing of the sparse-matrix CG variant and as an independent check of the stencil. """
+    import scipy.sparse as sp
+    res = dom.res
+    N = int(np.prod(res))
+    idx = np.arange(N).reshape(res)
+    rows, cols, vals = [], [], []
+    diag = np.zeros(res, dtype=np.float64)
+    pbc = pressure_bc(dom)
+    for a in range(dom.rank):
+        w = 1.0 / (dom.dx[a] * dom.dx[a])
+        for side, shift in ((0, -1), (1, 1)):
+            nb = np.roll(idx, -shift, axis=a)                    # index of the neighbour in direction `shift`
+            inside = np.ones(res, dtype=bool)
+            edge = [slice(None)] * dom.rank
+            edge[a] = 0 if shift < 0 else res[a] - 1
+            code = pbc[a][side]
+            if code != PERIODIC:
+                inside[tuple(edge)] = False
+                if code == OPEN:                                 # open velocity boundary = pressure ZERO ghost: the diagonal keeps -w
+                    d = np.zeros(res)
+                    d[tuple(edge)] = -w
+                    diag += d
+            rows.append(idx[inside]); cols.append(nb[inside]); vals.append(np.full(int(inside.sum()), w))
+            diag[inside] -= w
+    rows.append(idx.ravel()); cols.append(idx.ravel()); vals.append(diag.ravel())
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+    A.sum_duplicates()
+    return A.astype(dtype)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # a7: obstacle masks (phi/physics/fluid.py:130-137,212-240,277-288; phi/geom/_box.py:174-185,217-236;
 #     phi/geom/_geom.py:278-308)

@@ -2,7 +2,7 @@
 """
 Randomised parity run: random resolutions (degenerate ones included), boundary mixes, wall velocities, batch sizes and dtypes through
 every check of tests/parity_cases.py (kernels vs the NumPy oracle), on the GPU library or on the CPU emulation build.
-  python tools/fuzz_parity.py --first 0 --count 100 [--emu]
+  python tests/fuzz_parity.py --first 0 --count 100 [--emu]
 Prints one line per case; exit code 1 if any case failed. Known limitation that is reported as "skip": an axis with ONE cell between
 two closed sides has no stored faces.
 """
@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # this file lives there: test infrastructure (it drives the oracle)
 import parity_cases as pc            # noqa: E402
 from phiflow_amd import _capi as C   # noqa: E402
 

@@ -243,3 +243,25 @@ def test_obstacle_boundary_conditions_known_values():
     assert np.all(out[0][0][far] == 7.0)
     active, hard, soft = O.obstacle_masks([ob], dom)
     assert active[0].sum() == 32 * 32 - 12 * 12
+
+
+def test_assembled_csr_operator_equals_the_matrix_free_stencil():
+    """ oracle.laplace_csr (the sparse matrix PhiML would trace from masked_laplace, fluid.py:165) == oracle.masked_laplace for every
+    boundary kind, incl. one-cell axes; and CG on either form gives the same pressure """
+    rng = np.random.default_rng(41)
+    cases = [((6, 5), ((O.PERIODIC, O.PERIODIC), (O.CLOSED, O.OPEN))), ((4, 5, 3), ((O.OPEN, O.CLOSED), (O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED))),
+             ((1, 4), ((O.OPEN, O.OPEN), (O.PERIODIC, O.PERIODIC))), ((3, 3, 3), ((O.OPEN, O.OPEN),) * 3)]
+    for res, bc in cases:
+        dom = O.Domain(res, (0.0,) * len(res), tuple(0.7 * r for r in res), bc)
+        A = O.laplace_csr(dom, np.float64)
+        p = rng.standard_normal((2,) + res)
+        ref = O.masked_laplace(p, dom, None, None)
+        got = np.stack([(A @ q.ravel()).reshape(res) for q in p])
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+        assert A.nnz <= (2 * len(res) + 1) * int(np.prod(res)) and abs(A - A.T).max() < 1e-15          # symmetric 5/7-point matrix
+    dom = O.Domain((8, 6, 5), (0, 0, 0), (1, 1, 1), ((O.OPEN, O.OPEN), (O.CLOSED, O.OPEN), (O.PERIODIC, O.PERIODIC)))
+    A = O.laplace_csr(dom, np.float64)
+    y = rng.standard_normal((1, 8, 6, 5))
+    x1, i1 = O.cg(lambda q: O.masked_laplace(q, dom, None, None), y, np.zeros_like(y), 1e-10, 0, 500)
+    x2, i2 = O.cg(lambda q: (A @ q.ravel()).reshape(q.shape), y, np.zeros_like(y), 1e-10, 0, 500)
+    assert int(i1.iterations[0]) == int(i2.iterations[0]) and np.abs(x1 - x2).max() <= 1e-9 * np.abs(x1).max()

@@ -7,5 +7,5 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$REPO"
 SANITIZE=1 bash tests/hipemu/build_emu.sh
 export ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so)" PHIHIP_EMU_LIB="$REPO/tests/hipemu/libphihip_emu_asan.so"
-python tools/fuzz_parity.py --emu --first 0 --count "${1:-60}" 2>&1 | grep -E "ERROR|FAIL|fails|SUMMARY" || true
+python tests/fuzz_parity.py --emu --first 0 --count "${1:-60}" 2>&1 | grep -E "ERROR|FAIL|fails|SUMMARY" || true
 python -m pytest tests/test_emu_kernels.py -x -q -p no:cacheprovider 2>&1 | tail -3
