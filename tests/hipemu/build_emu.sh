@@ -3,10 +3,13 @@
 #   build_emu.sh            -> libphihip_emu.so
 #   SANITIZE=1 build_emu.sh -> libphihip_emu_asan.so (AddressSanitizer: out-of-bounds accesses of the kernels on "device" buffers,
 #                              LDS arrays and workspaces; run with LD_PRELOAD=$(gcc -print-file-name=libasan.so), see tools/asan_emu.sh)
+#   SANITIZE=undefined build_emu.sh -> libphihip_emu_ubsan.so (LD_PRELOAD=$(gcc -print-file-name=libubsan.so))
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 src="$here/../../phiflow_amd/csrc"
-if [ "${SANITIZE:-0}" = "1" ]; then
+if [ "${SANITIZE:-0}" = "undefined" ]; then
+  out="$here/libphihip_emu_ubsan.so"; build="$here/build/ubsan"; extra="-fsanitize=undefined -fno-sanitize-recover=undefined"
+elif [ "${SANITIZE:-0}" = "1" ]; then
   out="$here/libphihip_emu_asan.so"; build="$here/build/asan"; extra="-fsanitize=address -fno-omit-frame-pointer"
 else
   out="$here/libphihip_emu.so"; build="$here/build"; extra=""
