@@ -20,7 +20,7 @@ namespace phihip {
 // VGPRs) wants >= 3 medium workgroups per CU, UPDATE (3 loads, 2 stores, up to 224 VGPRs) the largest tile. So every (tile,
 // chunk) candidate gets   score = slot efficiency / relative traffic
 //     slot efficiency = rounds / ceil(rounds)            (rounds = workgroups * batch / (occupancy(kernel) * CUs) > 1)
-//                     = min(1, workgroups / min(slots, 4 [MATVEC] or 2 [UPDATE, residual] per CU))      (one round)
+//                     = min(1, workgroups / min(slots, 4 [MATVEC, UPDATE_R] or 2 [UPDATE, residual; 1.5 in fp64] per CU))   (one round)
 //     relative traffic = 1 + (2 / chunk) * (source words / all words)
 // and the best score (x a small per-family tile preference) wins.
 int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
@@ -59,7 +59,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         const double tiles = (double)tiles_of(cand) * v.batch;
         if (v.rank != 3) {
             const double rounds = tiles / slots;
-            const double per_cu = mv_like ? 4.0 : 2.0;
+            const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
             const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
             *score_out = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
             return 1;
@@ -67,7 +67,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         static const int kChunks[7] = {64, 48, 32, 24, 16, 12, 8};
         int best = 0;
         double best_score = -1.0;
-        const double per_cu = mv_like ? 4.0 : 2.0;
+        // one round of workgroups: how many per CU keep the memory system busy. fp64 tiles carry twice the bytes: 384^3 fp64 UPDATE runs
+        // 7-14 % faster with 432 large (4,64) workgroups than with 864 (2,32) ones (tools/sweep_cg.py --family 2 --dtype f64)
+        const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
         const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
         for (int k = 0; k < 7; ++k) {
             const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--configs", default="")
     ap.add_argument("--lib", default="", help="alternative libphihip build to load (A/B comparisons)")
+    ap.add_argument("--obstacle", type=int, default=0, help="1: closed box with a solid box obstacle in the middle (cell flags, BASELINE config 5)")
     ap.add_argument("--defer", type=int, default=1, help="0: update x in every iteration (phihip_set_deferred_x_update)")
     ap.add_argument("--family", type=int, default=-1, help="-1: all kernels share the configuration; 1 = MATVEC only, 2 = UPDATE only")
     args = ap.parse_args()
@@ -37,7 +38,16 @@ def main():
     esize = 8 if args.dtype == "f64" else 4
     L = 2 * math.pi
     grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L),
-                       ((0, 0),) * 3)
+                       ((1, 1),) * 3 if args.obstacle else ((0, 0),) * 3)
+    flags_ptr = 0
+    if args.obstacle:
+        import numpy as np
+        inside = (np.arange(n) >= 3 * n // 8) & (np.arange(n) < 5 * n // 8)
+        acc = ~(inside[:, None, None] & inside[None, :, None] & inside[None, None, :])
+        acc_t = torch.from_numpy(acc.astype(np.uint8)).to(dev)
+        flags_t = torch.empty(n, n, n, dtype=torch.uint8, device=dev)
+        ctx.build_cellflags(grid, acc_t.data_ptr(), 0, 1, flags_t.data_ptr())
+        flags_ptr = flags_t.data_ptr()
     g = torch.Generator(device="cpu").manual_seed(0)
     rhs = torch.randn(1, n, n, n, generator=g, dtype=tdt)
     rhs -= rhs.mean()
@@ -56,12 +66,12 @@ def main():
             ctx.set_tuning(0, 0, 0)
             ctx.set_tuning_kernel(args.family, rows, tpr, chunk)
         x.zero_()
-        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, args.method), want_info=False)   # warm-up
+        ctx.cg_solve(grid, flags_ptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, args.method), want_info=False)   # warm-up
         torch.cuda.synchronize()
         x.zero_()
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
-        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=False)
+        ctx.cg_solve(grid, flags_ptr, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=False)
         torch.cuda.synchronize()
         prof = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
@@ -69,7 +79,7 @@ def main():
         x.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=False)
+        ctx.cg_solve(grid, flags_ptr, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=False)
         e1.record()
         torch.cuda.synchronize()
         wall_ms = e0.elapsed_time(e1)
@@ -77,7 +87,7 @@ def main():
         up = prof["cg_update"][1] / max(1, prof["cg_update"][0])
         sc = prof["cg_scalar"][1] / max(1, prof["cg_scalar"][0])
         words = esize
-        plans = {f: ctx.query_plan(grid, False, f) for f in (1, 2, 3)}
+        plans = {f: ctx.query_plan(grid, bool(args.obstacle), f) for f in (1, 2, 3)}
         out = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "family": args.family, "defer": args.defer, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "plan_ur": list(plans[3].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
                "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_scalar": round(sc, 5),
                "ms_iter_events": round(mv + up + 2 * sc, 5), "ms_iter_wall": round(wall_ms / args.iters, 5),
