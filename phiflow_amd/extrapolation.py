@@ -179,7 +179,16 @@ def combine_sides(boundary_dict: Optional[dict] = None, **extrapolations) -> Ext
 
 
 def resolve(ext: Extrapolation, dims: Sequence[str]):
-    """ -> (codes[D][2], values[D][2][D]) for the C ABI `phihip_grid.bc / bc_val` """
+    """ -> (codes[D][2], values[D][2][D]) for the C ABI `phihip_grid.bc / bc_val`. Extrapolations are immutable: the result is cached on
+    the object (a field is constructed ~10 times per simulation step; callers must not modify the returned lists). """
+    cache = ext.__dict__.setdefault('_resolved', {})
+    key = tuple(dims)
+    if key not in cache:
+        cache[key] = _resolve(ext, key)
+    return cache[key]
+
+
+def _resolve(ext: Extrapolation, dims: Sequence[str]):
     D = len(dims)
     codes = [[0, 0] for _ in range(D)]
     vals = [[[0.0] * D for _ in range(2)] for _ in range(D)]
