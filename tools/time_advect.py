@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--lib", default="")
+    ap.add_argument("--field", default="random", help="random | tg (the smooth Taylor-Green velocity of the benchmark, CFL 0.5)")
     ap.add_argument("--bc", type=int, default=0, help="boundary code of every side: 0 periodic, 1 closed, 2 open")
     args = ap.parse_args()
     n = args.size
@@ -33,6 +34,14 @@ def main():
     g = torch.Generator().manual_seed(0)
     shapes = [tuple(n + (0, -1, 1)[args.bc] if a == d else n for a in range(3)) for d in range(3)]
     v = [torch.randn(1, *sh, generator=g, dtype=tdt).to(dev) for sh in shapes]
+    if args.field == "tg":
+        h = L / n
+        face = (torch.arange(n, dtype=tdt) * h)
+        cent = ((torch.arange(n, dtype=tdt) + 0.5) * h)
+        u = (torch.cos(face)[:, None, None] * torch.sin(cent)[None, :, None]).expand(n, n, n)
+        w = (-torch.sin(cent)[:, None, None] * torch.cos(face)[None, :, None]).expand(n, n, n)
+        full = [u, w, torch.zeros(n, n, n, dtype=tdt)]
+        v = [full[d][tuple(slice(0, sh[a]) for a in range(3))].contiguous()[None].to(dev) for d, sh in enumerate(shapes)]
     out = [torch.empty_like(t) for t in v]
     s = torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev)
     so = torch.empty_like(s)
@@ -48,7 +57,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.reps
 
-    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc,
+    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "field": args.field,
            "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
            "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
            "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((args.bc and 2, args.bc and 2),) * 3, None, P(v), so.data_ptr(), dt)), 5)}
