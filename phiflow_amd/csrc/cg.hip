@@ -22,7 +22,8 @@ namespace phihip {
 //     slot efficiency = rounds / ceil(rounds)            (rounds = workgroups * batch / (occupancy(kernel) * CUs) > 1)
 //                     = min(1, workgroups / min(slots, 4 [MATVEC, UPDATE_R] or 2 [UPDATE, residual; 1.5 in fp64] per CU))   (one round)
 //     relative traffic = 1 + (2 / chunk) * (source words / all words)
-// and the best score (x a small per-family tile preference) wins.
+// and the best score (x a small per-family tile preference) wins; for small grids the serial march of a chunk (latency) replaces the
+// traffic term (see best_chunk).
 int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
     const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const int vmax = 16 / esize;
@@ -64,20 +65,26 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             *score_out = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
             return 1;
         }
-        static const int kChunks[7] = {64, 48, 32, 24, 16, 12, 8};
+        // time model of one launch (us): the workgroups of a round march `chunk` planes one after the other (~0.75 us per plane after
+        // ~3 us of prologue + first loads: 64^3 (1,16) 7.9 / 8.5 / 10.1 / 13.2 us at chunk 1 / 2 / 4 / 8 incl. the launch gap), and the
+        // launch cannot beat its HBM traffic at ~5.5 TB/s. Large grids are traffic-bound (long chunks: fewer re-read halo planes), small
+        // ones latency-bound (short chunks, many workgroups: 64^3 iteration 20.7 -> 11.1 us, 128^3 24.2 -> 18.1 us).
+        static const int kChunks[10] = {64, 48, 32, 24, 16, 12, 8, 4, 2, 1};
         int best = 0;
         double best_score = -1.0;
-        // one round of workgroups: how many per CU keep the memory system busy. fp64 tiles carry twice the bytes: 384^3 fp64 UPDATE runs
-        // 7-14 % faster with 432 large (4,64) workgroups than with 864 (2,32) ones (tools/sweep_cg.py --family 2 --dtype f64)
         const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
         const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
-        for (int k = 0; k < 7; ++k) {
+        const double words = family == FAM_UPDATE ? 5.0 : 3.0;
+        const double us_traffic = (double)v.cells * v.batch * words * esize / 5.5e6;
+        for (int k = 0; k < 10; ++k) {
             const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
             const double blocks = tiles * ceil_div(v.n[0], ch);
             const double rounds = blocks / slots;
             const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < wanted ? blocks / wanted : 1.0);
             const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
-            const double score = eff / (1.0 + planes * src_share);
+            const double us_bw = us_traffic * (1.0 + planes * src_share) / eff;
+            const double us_lat = ceil(rounds - 1e-9) * (3.0 + 0.75 * (ch + 1));
+            const double score = us_traffic / (us_bw > us_lat ? us_bw : us_lat);   // = eff / relative traffic when traffic-bound
             if (score > best_score * 1.0001) { best_score = score; best = ch; }
         }
         *score_out = best_score;
