@@ -80,7 +80,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
             const double blocks = tiles * ceil_div(v.n[0], ch);
             const double rounds = blocks / slots;
-            const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < wanted ? blocks / wanted : 1.0);
+            // (a round filled to >= 90 % counts as full: 320^3 runs 8 % faster with 1000 workgroups of 32 planes than with 1400 of 24)
+            const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < 0.9 * wanted ? blocks / (0.9 * wanted) : 1.0);
             const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
             const double us_bw = us_traffic * (1.0 + planes * src_share) / eff;
             const double us_lat = ceil(rounds - 1e-9) * (3.0 + 0.75 * (ch + 1));
