@@ -58,11 +58,17 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     auto best_chunk = [&](int cand, double* score_out) -> int {
         const double slots = (double)march_occupancy_any(v, cand, c->vec, mode, flags) * ctx->num_cu;
         const double tiles = (double)tiles_of(cand) * v.batch;
+        const double words = family == FAM_UPDATE ? 5.0 : 3.0;
+        // every workgroup of the NEXT kernel re-reads all partial sums of its batch entry: nblk^2 doubles per entry, served by L2 (~3x
+        // HBM speed). Negligible in 3-D (<= 0.5 % at 512^3), decisive for large 2-D grids, which have one workgroup per tile:
+        // 2048^2 with 4096 small tiles 43.9 us per iteration, with 1024 (4,64) tiles 26.1 us (tools/sweep_cg2d.py)
+        auto partials_share = [&](double nblk_entry) { return nblk_entry * nblk_entry * 8.0 / 3.0 / ((double)v.cells * words * esize); };
         if (v.rank != 3) {
             const double rounds = tiles / slots;
             const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
             const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
-            *score_out = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
+            const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (tiles < wanted ? tiles / wanted : 1.0);
+            *score_out = eff / (1.0 + partials_share((double)tiles_of(cand)));
             return 1;
         }
         // time model of one launch (us): the workgroups of a round march `chunk` planes one after the other (~0.75 us per plane after
@@ -74,7 +80,6 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         double best_score = -1.0;
         const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
         const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
-        const double words = family == FAM_UPDATE ? 5.0 : 3.0;
         const double us_traffic = (double)v.cells * v.batch * words * esize / 5.5e6;
         for (int k = 0; k < 10; ++k) {
             const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
@@ -83,7 +88,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             // (a round filled to >= 90 % counts as full: 320^3 runs 8 % faster with 1000 workgroups of 32 planes than with 1400 of 24)
             const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < 0.9 * wanted ? blocks / (0.9 * wanted) : 1.0);
             const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
-            const double us_bw = us_traffic * (1.0 + planes * src_share) / eff;
+            const double us_bw = us_traffic * (1.0 + planes * src_share + partials_share(blocks / v.batch)) / eff;
             const double us_lat = ceil(rounds - 1e-9) * (3.0 + 0.75 * (ch + 1));
             const double score = us_traffic / (us_bw > us_lat ? us_bw : us_lat);   // = eff / relative traffic when traffic-bound
             if (score > best_score * 1.0001) { best_score = score; best = ch; }
