@@ -193,6 +193,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
+    if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     for (int i = 0; i < 2; ++i)
         if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     for (auto& p : ctx->ev_pool) {

@@ -315,6 +315,16 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[0]));
         PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[1]));
     }
+    if (ctx->host_flags_count < (size_t)v.batch) {
+        if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+        ctx->host_flags = nullptr;
+        ctx->host_flags_count = 0;
+        PHIHIP_CHECK_HIP(hipHostMalloc((void**)&ctx->host_flags, (size_t)v.batch * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(ctx->host_flags, 0, (size_t)v.batch * sizeof(unsigned long long));
+        PHIHIP_CHECK_HIP(hipHostGetDevicePointer((void**)&ctx->host_flags_dev, ctx->host_flags, 0));
+        ctx->host_flags_count = (size_t)v.batch;
+    }
+    const unsigned int seq = ++ctx->solve_seq;   // 0 never matches: flags of earlier solves read as "still running"
     int checks = 0;
     T* r = (T*)ctx->ws_r.ptr;
     T* d[2] = {(T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr};
@@ -327,7 +337,6 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     const int mode_mv = ad ? MODE_MATVEC_AD : MODE_MATVEC, mode_up = ad ? MODE_UPDATE_AD : MODE_UPDATE;
     const int pro_alpha = ad ? PRO_ALPHA_AD : PRO_ALPHA, pro_beta = ad ? PRO_BETA_AD : PRO_BETA;
     CgState* st[2] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch};
-    CgState* st_peek = (CgState*)ctx->ws_state.ptr + 2 * v.batch;
     int cur = 0;   // slot holding the most recent control block
     const bool has_flags = flags != nullptr;
     CgParams prm;
@@ -362,6 +371,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         {
             MarchArgs<T> a = base;
             a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq; a.part2 = part_dr;
+            if (solve->check_every > 0) { a.host_flags = ctx->host_flags_dev; a.seq = seq; }
             a.prologue = first ? PRO_FIRST : pro_beta;
             a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = (first || !ad) ? part_yy : part_rq; a.nblk_in = nblk_rr;
             LaunchScope ls(ctx, PHIHIP_K_CG_MATVEC_DOT, s);
@@ -411,27 +421,23 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             cur ^= 1;
             nblk_rr = r_only ? g_ur.nblk : g_up.nblk;
         }
-        if (solve->check_every > 0 && k % solve->check_every == 0 && k < solve->max_iterations) {
-            // Peek at the decision the next MATVEC prologue will take, without advancing the chain -- and WITHOUT draining the
-            // stream: the peek of this check point is copied to a pinned slot behind an event, the host then inspects the
-            // PREVIOUS check point (long finished) and keeps enqueueing. The continue flags only ever go 1 -> 0 and frozen
-            // entries make every kernel return at once, so running one check interval ahead is harmless.
-            const int slot = checks & 1;
-            {
-                LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
-                hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, pro_beta, (const CgState*)st[cur],
-                                   st_peek + (size_t)slot * v.batch, (const double*)part_rr, (const double*)(ad ? part_rq : part_yy), nblk_rr, prm);
+        if (solve->check_every > 0 && k < solve->max_iterations) {
+            // Tolerance mode. Every MATVEC prologue publishes its continue decision into host-mapped memory (publish_flag), so the host
+            // looks before each enqueue -- no peek kernel, no copy -- and stops as soon as every entry reports "done" for THIS solve
+            // (sequence number). Flags only go 1 -> 0 and frozen entries make every kernel return at once, so the launches that
+            // were enqueued ahead are harmless; an event every `check_every` iterations bounds that run-ahead to two intervals.
+            bool any = false;
+            for (int b = 0; b < v.batch && !any; ++b) {
+                const unsigned long long f = *(volatile unsigned long long*)(ctx->host_flags + b);
+                any = (unsigned int)(f >> 32) != seq || (f & 1ull);
             }
-            PHIHIP_CHECK_HIP(hipMemcpyAsync(hst + (size_t)slot * v.batch, st_peek + (size_t)slot * v.batch, (size_t)v.batch * sizeof(CgState),
-                                            hipMemcpyDeviceToHost, s));
-            PHIHIP_CHECK_HIP(hipEventRecord(ctx->poll_ev[slot], s));
-            if (checks > 0) {
-                PHIHIP_CHECK_HIP(hipEventSynchronize(ctx->poll_ev[slot ^ 1]));
-                bool any = false;
-                for (int b = 0; b < v.batch; ++b) any = any || hst[(size_t)(slot ^ 1) * v.batch + b].cont;
-                if (!any) break;
+            if (!any) break;
+            if (k % solve->check_every == 0) {
+                const int slot = checks & 1;
+                PHIHIP_CHECK_HIP(hipEventRecord(ctx->poll_ev[slot], s));
+                if (checks > 0) PHIHIP_CHECK_HIP(hipEventSynchronize(ctx->poll_ev[slot ^ 1]));
+                ++checks;
             }
-            ++checks;
         }
     }
     {   // fold the last reduction into the control block (or build it when no iteration ran)

@@ -103,7 +103,13 @@ struct phihip_ctx {
     int last_state_batch = 0;
     void* host_state = nullptr;   // pinned readback buffer
     size_t host_state_bytes = 0;
-    hipEvent_t poll_ev[2] = {nullptr, nullptr};   // lagged convergence polling (cg.hip)
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};   // throttle of the host's run-ahead in tolerance mode (cg.hip)
+    // tolerance mode: the MATVEC prologue publishes (solve sequence number << 32 | continue flag) per batch entry straight into this
+    // pinned, device-mapped array; the host reads it before every enqueue -- no peek kernel, no copy, no stream drain
+    unsigned long long* host_flags = nullptr;
+    unsigned long long* host_flags_dev = nullptr;
+    size_t host_flags_count = 0;
+    unsigned int solve_seq = 0;
     // profiling
     bool profiling = false;
     struct EventPair {

@@ -60,6 +60,15 @@ enum CgPrologue {
     PRO_ALPHA_AD = 6    // 'CG-adaptive': (d.q, d.r) -> alpha = (d.r)/(d.q), iteration count
 };
 
+// one 64-bit store that the HOST may read at any time (pinned, device-mapped memory)
+__device__ __forceinline__ void publish_flag(unsigned long long* p, unsigned long long v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *reinterpret_cast<volatile unsigned long long*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ bool cg_finite(double v) { return (v == v) && v <= 1.7e308 && v >= -1.7e308; }
 
 // PhiML's cg loop body bookkeeping, split at its two reductions
@@ -120,6 +129,8 @@ struct MarchArgs {
     int prologue;          // CgPrologue
     int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
     int pend_buf;          // UPDATE_R: index of the d buffer this launch reads (recorded with the pending flag)
+    unsigned long long* host_flags;   // MATVEC: host-mapped [batch] array that receives (seq << 32 | continue flag), or nullptr
+    unsigned int seq;
     T w0, w1, w2;          // 1 / dx^2 per internal axis
     // slab decomposition along a0: one plane [batch][n1][n2] of the source array(s) below plane 0 / above plane
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
@@ -305,6 +316,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     if (p.prologue != PRO_NONE) {
         const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state,
                                       IS_UP ? (MODE == MODE_UPDATE_R ? 1 : 0) : -1, p.pend_buf);
+        if (IS_MV && p.host_flags && blockIdx.x == 0 && tid == 0)   // the host stops enqueueing once every entry reports 0
+            publish_flag(p.host_flags + b, ((unsigned long long)p.seq << 32) | (unsigned long long)(S.cont != 0));
         if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
         alpha = (T)S.alpha;
         beta = (T)S.beta;

@@ -33,6 +33,7 @@ typedef struct hipemu_event* hipEvent_t;
 enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorLaunchFailure = 719 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipHostMallocDefault 0
+#define hipHostMallocMapped 2
 struct hipDeviceProp_t {
     int multiProcessorCount;
     char name[64];
@@ -93,6 +94,7 @@ hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);
+inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }   // one address space
 hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
