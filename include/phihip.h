@@ -73,7 +73,8 @@ typedef struct phihip_solve {
     double abs_tol;
     int32_t max_iterations;
     int32_t refresh_every;    /* recompute r = y - A x every n-th iteration (PhiML: 50); 0 = never */
-    int32_t check_every;      /* host polls the device-side continue flags every n iterations; 0 = only at the end */
+    int32_t check_every;      /* > 0: tolerance mode -- the host watches the continue flags the kernels publish into mapped host memory
+                               * and throttles its run-ahead with an event every n iterations; 0 = run max_iterations launches */
     int32_t method;           /* phihip_method: 0 = 'CG' (also what 'auto' maps to), 1 = 'CG-adaptive' */
 } phihip_solve;
 
