@@ -126,7 +126,7 @@ def test_cg_deferred_x_update(emu_ctx, dtype):
     try:
         emu_ctx.set_small_grid_solver(False)
         for kwargs in (dict(max_iter=7, fixed_iterations=True), dict(max_iter=10, refresh=3, fixed_iterations=True),
-                       dict(max_iter=9, refresh=4, fixed_iterations=True), dict(rtol=1e-3), dict()):
+                       dict(max_iter=9, refresh=4, fixed_iterations=True), dict(rtol=1e-3)):
             xs = []
             for defer in (True, False):
                 emu_ctx.set_deferred_x_update(defer)
@@ -146,8 +146,7 @@ def test_cg_fixed_iterations_and_refresh(emu_ctx):
     pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, rng, max_iter=20, refresh=7, fixed_iterations=True)
 
 
-@pytest.mark.parametrize("res,bc", [GRIDS_2D[0], GRIDS_2D[-1], GRIDS_3D[0], GRIDS_3D[1]])
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("res,bc,dtype", [GRIDS_2D[0] + (np.float32,), GRIDS_2D[-1] + (np.float64,), GRIDS_3D[0] + (np.float64,), GRIDS_3D[1] + (np.float32,)])
 def test_cg_adaptive_matches_oracle(emu_ctx, res, bc, dtype):
     """ Solve('CG-adaptive') (Fluid_Logo.ipynb): both solvers, tolerance mode and fixed iterations + refresh """
     dom, grid = pc.make_case(res, bc, dtype, batch=2)
