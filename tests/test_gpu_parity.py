@@ -332,6 +332,28 @@ def test_make_incompressible_matches_oracle_and_is_divergence_free(ctx, mem, res
     pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, rng)
 
 
+def test_launch_plan_regimes(ctx, mem):
+    """ the launch plan switches regime with the grid: single-plane chunks for small 3-D grids (latency-bound), large tiles for large 2-D
+    grids (cost of re-reading the partial sums), long chunks for large 3-D grids -- every regime against the oracle """
+    cases = [((48, 40, 64), ((CLO, OPN), (PER, PER), (CLO, CLO)), 12),          # small 3-D: chunks of 1-2 planes
+             ((1024, 1536), ((CLO, CLO), (OPN, CLO)), 6),                       # large 2-D: >= 1024 tiles per entry with small tiles
+             ((160, 96, 128), ((PER, PER), (CLO, CLO), (OPN, OPN)), 6)]         # mid 3-D
+    for res, bc, iters in cases:
+        dom, grid = pc.make_case(res, bc, np.float32, batch=1)
+        plans = [ctx.query_plan(grid, False, f) for f in (1, 2, 3)]
+        assert all(p["nblk"] >= 1 and p["chunk"] >= 1 for p in plans)
+        if res == (48, 40, 64):
+            assert plans[0]["chunk"] <= 4
+        if len(res) == 2:
+            assert plans[0]["nblk"] <= 2048
+        try:
+            ctx.set_small_grid_solver(False)
+            pc.check_laplace(ctx, mem, dom, grid, np.float32, np.random.default_rng(2))
+            pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(3), max_iter=iters, fixed_iterations=True)
+        finally:
+            ctx.set_small_grid_solver(True)
+
+
 def test_tile_configurations_agree(ctx, mem):
     rng = np.random.default_rng(10)
     dtype = np.float32
