@@ -287,9 +287,10 @@ int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row,
 /* the same for one kernel family only: 0 = operator apply / residual, 1 = MATVEC (d = r + beta d; d.Ad), 2 = UPDATE (x, r) */
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes);
 
-/* Grids of at most 8192 cells per batch entry are solved by ONE kernel (one workgroup per batch entry, the
+/* Grids of at most 8192 cells per batch entry (16384 for fp32 batches of >= 8 entries) are solved by ONE kernel (one workgroup per batch entry, the
  * search direction in LDS, no kernel boundary or host polling inside the loop; cg_small.hip). enable = 0 forces the marching
- * kernels for every size (A/B measurements, tests of the marching path on small grids). Default: enabled. */
+ * kernels for every size (A/B measurements, tests of the marching path on small grids); enable > 1 sets the cell limit explicitly
+ * (capped at 16384 fp32 / 8192 fp64). Default: enabled. */
 int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
 /* 'CG' with the marching kernels updates the solution every OTHER iteration only: x does not enter the recurrence, and the step that
  * was skipped is recovered in the next update from operands that kernel reads anyway (d_k = (d_{k+1} - r_{k+1}) / beta_{k+1}), so an

@@ -433,8 +433,9 @@ class Context:
         self.lib.check(self.lib.dll.phihip_set_tuning_kernel(self.handle, int(family), int(rows_per_thread), int(threads_per_row),
                                                              int(chunk_planes)))
 
-    def set_small_grid_solver(self, enable: bool):
-        self.lib.check(self.lib.dll.phihip_set_small_grid_solver(self.handle, int(bool(enable))))
+    def set_small_grid_solver(self, enable):
+        """ False / True, or an int > 1 = explicit cell limit of the single-kernel solver """
+        self.lib.check(self.lib.dll.phihip_set_small_grid_solver(self.handle, int(enable)))
 
     def set_deferred_x_update(self, enable: bool):
         if hasattr(self.lib.dll, "phihip_set_deferred_x_update"):

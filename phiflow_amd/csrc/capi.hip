@@ -757,6 +757,7 @@ int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row,
 int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->small_cg = enable != 0;
+    ctx->small_cg_cells = enable > 1 ? enable : 0;   // > 1: use the single-kernel solver up to that many cells (<= 16384 fp32, 8192 fp64)
     return PHIHIP_OK;
 }
 

@@ -250,7 +250,7 @@ int run_laplace_apply(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
                                  : laplace_apply_t<float>(ctx, v, flags, mask_batch, p, out, s);
 }
 
-long long small_cg_limit(int dtype);
+long long small_cg_limit(const phihip_ctx* ctx, const GridView& v);
 int run_cg_small(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, void* st_out,
                  hipStream_t);
 
@@ -288,7 +288,7 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
 template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
                 const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
-    if (ctx->small_cg && v.cells <= small_cg_limit(v.dtype)) return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+    if (ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
     MarchGrid g, g_mv, g_up, g_ur;
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));

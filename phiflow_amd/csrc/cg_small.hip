@@ -226,7 +226,13 @@ static void launch_small(const MarchGrid& g, const SmallArgs<T>& a, int batch, b
 // Measured on MI355X (tools/sweep_cg2d.py): 64^2 x 256 entries 4.2 us / iteration against 14.7 us with the marching kernels,
 // 90^2 x 128 5.3 against 31.6 us; at 128^2 (16384 cells on one CU: 11.4 us) the marching kernels win (9.2 us), so the
 // limit is 8192 cells.
-long long small_cg_limit(int dtype) { (void)dtype; return 8192; }
+long long small_cg_limit(const phihip_ctx* ctx, const GridView& v) {
+    const long long cap = v.dtype == PHIHIP_F64 ? 8192 : 16384;   // LDS: 2 * cells * sizeof(T) <= 128 KB
+    if (ctx->small_cg_cells > 0) return ctx->small_cg_cells < cap ? ctx->small_cg_cells : cap;
+    // 8193 ... 16384 cells (fp32, 1024 threads x 16 cells): one CU per entry needs ~11-12 us per iteration, the marching kernels 9.2 us
+    // for ONE 128^2 entry but they grow with the batch: 25^3 x 64 entries 12.9 against 35.8 us, 100^2 x 32 8.8 / 12.1, 128^2 x 32 11.0 / 11.6
+    return v.batch >= 8 ? cap : 8192;
+}
 
 template <typename T>
 static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
@@ -254,7 +260,8 @@ static int cg_small_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, 
     else if (v.cells <= 2048) launch_small<T, 512, 4>(g, a, v.batch, fl, s);
     else if (v.cells <= 4096) launch_small<T, 512, 8>(g, a, v.batch, fl, s);
     else if (sizeof(T) == 8) launch_small<T, 512, 16>(g, a, v.batch, fl, s);   // fp64: 1024 x 8 would exceed 128 VGPRs by far
-    else launch_small<T, 1024, 8>(g, a, v.batch, fl, s);
+    else if (v.cells <= 8192) launch_small<T, 1024, 8>(g, a, v.batch, fl, s);
+    else if constexpr (sizeof(T) == 4) launch_small<T, 1024, 16>(g, a, v.batch, fl, s);   // 128 KB of LDS: fp32 only (small_cg_limit)
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }

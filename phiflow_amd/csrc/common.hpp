@@ -97,6 +97,7 @@ struct phihip_ctx {
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adj_q, ws_adj_l;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
+    long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule
     bool small_cg = true;         // grids that fit one CU's LDS are solved by the single-kernel CG (cg_small.hip)
     int slab_cur = 0;             // control-block slot of the running slab-decomposed solve
     void* last_state = nullptr;   // device control blocks of the most recent solve

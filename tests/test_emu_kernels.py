@@ -139,6 +139,18 @@ def test_cg_deferred_x_update(emu_ctx, dtype):
         emu_ctx.set_deferred_x_update(True)
 
 
+def test_single_kernel_solver_16384_cells(emu_ctx):
+    """ the 1024-thread x 16-cell form of cg_small (8193 ... 16384 cells, fp32): chosen for batches of >= 8 entries, here forced """
+    try:
+        emu_ctx.set_small_grid_solver(16384)
+        for res, bc in (((96, 100), ((CLO, OPN), (PER, PER))), ((24, 20, 25), ((CLO, CLO), (OPN, OPN), (PER, PER)))):
+            dom, grid = pc.make_case(res, bc, np.float32, batch=2)
+            pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(4), rtol=1e-4)
+            pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(5), max_iter=9, refresh=4, fixed_iterations=True, adaptive=True)
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+
+
 def test_cg_fixed_iterations_and_refresh(emu_ctx):
     """ benchmark mode: tolerances 0, exactly max_iterations; refresh every 7 exercises the true-residual branch """
     rng = np.random.default_rng(5)

@@ -285,6 +285,18 @@ def test_cg_deferred_x_update(ctx, mem, dtype):
         ctx.set_deferred_x_update(True)
 
 
+def test_single_kernel_solver_16384_cells(ctx, mem):
+    """ the 1024-thread x 16-cell form of cg_small (8193 ... 16384 cells, fp32): chosen for batches of >= 8 entries, here forced """
+    try:
+        ctx.set_small_grid_solver(16384)
+        for res, bc in (((96, 100), ((CLO, OPN), (PER, PER))), ((24, 20, 25), ((CLO, CLO), (OPN, OPN), (PER, PER)))):
+            dom, grid = pc.make_case(res, bc, np.float32, batch=2)
+            pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(4), rtol=1e-4)
+            pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(5), max_iter=9, refresh=4, fixed_iterations=True, adaptive=True)
+    finally:
+        ctx.set_small_grid_solver(True)
+
+
 def test_cg_fixed_100_iterations_matches_oracle(ctx, mem):
     """ the benchmark mode (tolerances 0, exactly 100 iterations, refresh at 50) at 64^3 periodic fp32:
     pressure within 1e-4 rel-L2 of the NumPy oracle (north-star tolerance) """

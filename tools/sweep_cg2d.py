@@ -20,19 +20,22 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--method", type=int, default=0, help="phihip_method: 0 = CG, 1 = CG-adaptive")
     ap.add_argument("--lib", default="")
+    ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--small-limit", type=int, default=1, help="cell limit of the single-kernel solver (1 = built-in rule)")
     args = ap.parse_args()
     n, B = args.size, args.batch
     dev = torch.device("cuda:0")
     ctx = C.Context(C.Library(args.lib, strict=False) if args.lib else C.load_default_library(), 0)
-    grid = C.make_grid(2, C.PHIHIP_F32, B, (n, n), (0, 0), (100.0, 100.0), ((1, 1), (1, 1)))
-    rhs = torch.randn(B, n, n, generator=torch.Generator().manual_seed(0))
-    rhs -= rhs.mean(dim=(1, 2), keepdim=True)
+    D = args.dim
+    grid = C.make_grid(D, C.PHIHIP_F32, B, (n,) * D, (0,) * D, (100.0,) * D, ((1, 1),) * D)
+    rhs = torch.randn((B,) + (n,) * D, generator=torch.Generator().manual_seed(0))
+    rhs -= rhs.mean(dim=tuple(range(1, D + 1)), keepdim=True)
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, args.iters, 0, 0, args.method)
-    ap_small = n * n <= 8192
-    for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0), (1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)]:
-        ctx.set_small_grid_solver(rows < 0)          # rows = -1: the single-kernel solver (cg_small.hip)
+    ap_small = n ** D <= max(8192, args.small_limit)
+    for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0)] + ([(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64)] if D == 2 else []):
+        ctx.lib.check(ctx.lib.dll.phihip_set_small_grid_solver(ctx.handle, args.small_limit if rows < 0 else 0))   # rows = -1: cg_small.hip
         ctx.set_tuning(max(rows, 0), max(tpr, 0), 0)
         x.zero_()
         ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 3, 0, 0, args.method), want_info=False)
@@ -46,7 +49,7 @@ def main():
         us = e0.elapsed_time(e1) / args.iters * 1e3
         plans = {f: list(ctx.query_plan(grid, False, f).values()) for f in (1, 2)}
         print(json.dumps({"size": n, "batch": B, "rows": rows, "tpr": tpr, "us_per_iteration": round(us, 2),
-                          "alg_GBs": round(40 * B * n * n / us / 1e3, 1), "plan_mv": plans[1], "plan_up": plans[2]}), flush=True)
+                          "alg_GBs": round(40 * B * n ** D / us / 1e3, 1), "plan_mv": plans[1], "plan_up": plans[2]}), flush=True)
 
 
 if __name__ == "__main__":
