@@ -163,7 +163,12 @@ def advect_general(field: Field, velocity: Field, dt: float, correction_strength
         if correction_strength is None:
             new = sample_array(field, c, index_coords(field, c, back))
         else:
-            fwd_vals, lo, hi = sample_array(field, c, index_coords(field, c, back), limits=True)
+            coords_back = index_coords(field, c, back)
+            needs_grad = field.values.requires_grad or any(t.requires_grad for t in coords_back)
+            with torch.no_grad():
+                fwd_vals, lo, hi = sample_array(field, c, [t.detach() for t in coords_back], limits=True)
+            if needs_grad:   # differentiable gather; the clamp window stays constant (a clamped sample gets no gradient here)
+                fwd_vals = sample_array(field, c, coords_back)
             fwd = Field(field.resolution, field.bounds, field.boundary, fwd_vals.reshape(B, *field.resolution.values()), False, field.backend, True)
             ahead = integrate_points(pts, velocity, dt, integrator)
             bwd = sample_array(fwd, None, index_coords(fwd, None, ahead))

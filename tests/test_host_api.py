@@ -522,6 +522,29 @@ def test_functional_gradient_through_a_fluid_step(emu_backend):
         _fd_gradient_check(loss_np, v_vals + [s_vals], g_v.numpy() + [g_s.numpy()], rng, eps=1e-6, tol=1e-4)
 
 
+def test_gradient_through_sampling_between_grids(emu_backend):
+    """ gradients through the general sampling path (phihip_grid_sample_backward behind torch.autograd): smoke on a finer grid than the
+    velocity (Batched_Smoke.ipynb), semi-Lagrangian with the euler and the rk4 back-trace, resample of the buoyancy to the coarse faces """
+    from phiflow_amd.flow import functional_gradient, l2_loss, precision, resample
+    rng = np.random.default_rng(33)
+    with precision(64):
+        bounds = Box(x=32, y=40)
+
+        def simulate(velocity, smoke):
+            smoke = advect.semi_lagrangian(smoke, velocity, 1.3)
+            smoke = advect.semi_lagrangian(smoke, velocity, 0.7, integrator=advect.rk4)
+            velocity = velocity + resample(smoke * (0.2, 0.5), to=velocity)
+            return l2_loss(smoke) + l2_loss(velocity), smoke
+
+        shapes = StaggeredGrid(0, 0, bounds, x=8, y=10, backend=emu_backend).component_shapes
+        v_vals = [0.8 * rng.standard_normal(s) for s in shapes]
+        s_vals = rng.random((20, 24))
+        mk = lambda vs, ss: (StaggeredGrid(vs, 0, bounds, x=8, y=10, backend=emu_backend), CenteredGrid(ss, BOUNDARY, bounds, x=20, y=24, backend=emu_backend))
+        g_v, g_s = functional_gradient(simulate, wrt=[0, 1], get_output=False)(*mk(v_vals, s_vals))
+        loss_np = lambda arrs: float(simulate(*mk(arrs[:2], arrs[2]))[0])
+        _fd_gradient_check(loss_np, v_vals + [s_vals], g_v.numpy() + [g_s.numpy()], rng, eps=1e-7, tol=2e-4)
+
+
 def test_colab_tutorial_functional_gradient(emu_backend, full=False):
     """ tests/commit/test_colab_fluids_tutorial.py:11-34 (batch of 4 inflow locations, MacCormack smoke, buoyancy, self-advection,
     projection, loss = l2(diffuse.explicit(smoke - stop_gradient(target)))) with `functional_gradient(simulate, wrt=[0])`; the
