@@ -205,7 +205,10 @@ __device__ __forceinline__ void lookup_pairs(const T (&coord)[3], const int (&n)
     for (int a = A0; a < 3; ++a) {
         const T fl = floor(coord[a]);
         fr[a] = coord[a] - fl;
-        ax[a] = make_pair<T>((int)fl, n[a], stride[a], bc[a][0], bc[a][1], cv[a][0], cv[a][1]);
+        // NaN / infinite / absurd coordinates (finite_rk4 exists because velocities may be NaN) must not become wild indices: the
+        // integer part is clamped to +-2^30 (NaN -> -2^30), the taps then resolve through the boundary rule and the result is NaN
+        const T fc = fmin(fmax(fl, T(-1073741824.0)), T(1073741823.0));
+        ax[a] = make_pair<T>((int)fc, n[a], stride[a], bc[a][0], bc[a][1], cv[a][0], cv[a][1]);
     }
     if (DIM == 2) { ax[0].off[0] = ax[0].off[1] = 0; ax[0].cst[0] = ax[0].cst[1] = false; ax[0].cv[0] = ax[0].cv[1] = T(0); }
 }

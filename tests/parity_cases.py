@@ -613,6 +613,33 @@ def check_grid_sample(ctx, mem, shape, codes, consts, dtype, rng, batch=2, point
         assert abs(fd - an) <= 2e-4 * max(abs(fd), abs(an), 1.0), (fd, an)
 
 
+def check_grid_sample_wild_coordinates(ctx, mem, dtype):
+    """ NaN, infinite and absurdly large coordinates must not turn into wild memory accesses: those samples come out NaN / boundary
+    values, their neighbours are unaffected """
+    shape, codes, consts = (6, 7), ((PER, PER), (CLO, OPN)), [(0.0, 0.0), (2.5, 0.0)]
+    rng = np.random.default_rng(0)
+    values = rng.standard_normal((1,) + shape).astype(dtype)
+    pts = 16
+    cx = rng.random((1, pts)).astype(dtype) * 5
+    cy = rng.random((1, pts)).astype(dtype) * 6
+    good = [cx.copy(), cy.copy()]
+    cx[0, [1, 5]] = [np.nan, np.inf]
+    cy[0, [7, 9, 11]] = [-np.inf, 1e30, -3e38 if np.dtype(dtype) == np.float32 else -1e300]
+    grid = C.make_grid(2, C.PHIHIP_F64 if np.dtype(dtype) == np.float64 else C.PHIHIP_F32, 1, shape, (0.0, 0.0), (1.0, 1.0), codes,
+                       [[[consts[a][s], 0.0, 0.0] for s in range(2)] for a in range(2)])
+    dv, dc = mem.to_dev(values), [mem.to_dev(cx), mem.to_dev(cy)]
+    dout, dmin, dmax = (mem.empty((1, pts), dtype) for _ in range(3))
+    ctx.grid_sample(grid, mem.ptr(dv), 1, [mem.ptr(c) for c in dc], pts, mem.ptr(dout), mem.ptr(dmin), mem.ptr(dmax))
+    mem.sync()
+    out = mem.to_host(dout)
+    ref = O.grid_sample(values, good, codes, consts)
+    wild = np.zeros(pts, bool)
+    wild[[1, 5, 7, 9, 11]] = True
+    assert np.abs(out[0, ~wild] - ref[0, ~wild]).max() <= tol(dtype)['advect'] * 8 * np.abs(ref).max()
+    assert not np.isfinite(out[0, [1, 5, 7]]).any()                       # NaN / inf coordinates: NaN results, nothing worse
+    assert np.isfinite(mem.to_host(dmin)[0, ~wild]).all() and np.isfinite(mem.to_host(dmax)[0, ~wild]).all()
+
+
 # degenerate resolutions (one or two cells along an axis, single-plane 3-D grids) under every boundary kind
 DEGENERATE_GRIDS = [
     ((1, 1), ((0, 0), (0, 0))), ((2, 2), ((1, 1), (1, 1))), ((1, 5), ((2, 2), (1, 1))), ((5, 1), ((0, 0), (2, 1))), ((2, 3), ((1, 2), (0, 0))),

@@ -258,6 +258,11 @@ def test_grid_sample_matches_oracle(emu_ctx, shape, codes):
         pc.check_grid_sample(emu_ctx, MEM, shape, codes, consts, dtype, rng, batch=3, points=70, shared_values=True, spread=0.6)
 
 
+def test_grid_sample_wild_coordinates(emu_ctx):
+    for dtype in (np.float32, np.float64):
+        pc.check_grid_sample_wild_coordinates(emu_ctx, MEM, dtype)
+
+
 def test_embedded_obstacles(emu_ctx):
     """ geom.infinite_cylinder / embed (examples/grids/Wake_Flow.ipynb): the obstacle ignores the embedding axis; also as a union member """
     rng = np.random.default_rng(22)

@@ -217,6 +217,11 @@ def test_grid_sample_matches_oracle(ctx, mem, shape, codes):
         pc.check_grid_sample(ctx, mem, shape, codes, consts, dtype, rng, batch=3, points=70, shared_values=True, spread=0.6)
 
 
+def test_grid_sample_wild_coordinates(ctx, mem):
+    for dtype in (np.float32, np.float64):
+        pc.check_grid_sample_wild_coordinates(ctx, mem, dtype)
+
+
 def test_embedded_obstacles(ctx, mem):
     """ geom.infinite_cylinder / embed (examples/grids/Wake_Flow.ipynb): the obstacle ignores the embedding axis; also as a union member """
     rng = np.random.default_rng(22)
