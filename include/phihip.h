@@ -15,7 +15,8 @@
  *         PHIHIP_BC_PERIODIC -> (1,0)   N_d   faces (lower face of each cell)
  *         PHIHIP_BC_CLOSED   -> (0,0)   N_d-1 faces (wall faces carry the constant boundary value, not stored)
  *         PHIHIP_BC_OPEN     -> (1,1)   N_d+1 faces
- *     (tests/commit/field/test__grid.py:25-36). Use phihip_component_shape().
+ *     (tests/commit/field/test__grid.py:25-36). Use phihip_component_shape(). A component must keep at least one face: an axis
+ *     with ONE cell between two CLOSED sides is rejected (PHIHIP_ERR_BAD_ARG).
  *   - Pressure / divergence / scalars = CenteredGrid, shape res.
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream) except
  *     phihip_cg_solve / phihip_make_incompressible when `info != NULL`, which synchronise the stream to report.
