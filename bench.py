@@ -33,9 +33,11 @@ ALG_BYTES_PER_CELL = {           # algorithmic words per cell (fp
     "cg_iteration": 10 * 4,
     "step_non_cg": 21 * 4,
 }
+ALG_BYTES_PER_CELL["cg_update_r"] = 6 * 4
 MOVED_BYTES_PER_CELL = {         # words the kernels move by construction: q = A d is recomputed instead of stored, and
     "cg_matvec_dot": 3 * 4,      # x is updated every other iteration: UPDATE alternates r-only (3 words) and x + r (5 words)
-    "cg_update": 4 * 4,
+    "cg_update": 5 * 4,          # UPDATE_X2: read x, r, d; write x, r
+    "cg_update_r": 3 * 4,        # UPDATE_R: read r, d; write r
     "cg_iteration": 7 * 4,
 }
 
@@ -87,7 +89,8 @@ class FluidStep:
 
 
 def cpu_baseline(n, cg_iters):
-    """ the NumPy oracle (restatement of the reference's CPU path) timed on the same step at a bounded size """
+    """ the NumPy oracle (restatement of the reference's CPU path) timed on the same step at a bounded size; the oracle's fields are
+    kept for the parity block (the GPU repeats exactly this step on the same inputs) """
     from oracle import phi_oracle as O
     L = 2 * math.pi
     dom = O.Domain((n, n, n), (0, 0, 0), (L, L, L), ((O.PERIODIC, O.PERIODIC),) * 3)
@@ -99,11 +102,114 @@ def cpu_baseline(n, cg_iters):
     vel = [np.ascontiguousarray(a, dtype=np.float32)[None] for a in (u, v, np.zeros((n, n, n)))]
     t0 = time.perf_counter()
     vel = O.semi_lagrangian_staggered(vel, vel, 0.5 * h, dom)
-    O.make_incompressible(vel, dom, rtol=0.0, atol=0.0, max_iter=cg_iters, refresh=50)
+    vel, p, info, _ = O.make_incompressible(vel, dom, rtol=0.0, atol=0.0, max_iter=cg_iters, refresh=50)
     dt = time.perf_counter() - t0
-    return {"value": n ** 3 / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"1 step of the same workload at {n}^3 fp32 ({cg_iters} CG iterations) with the NumPy oracle "
-                      f"(oracle/phi_oracle.py, single-threaded NumPy), {dt:.1f} s"}
+    cpu = {"value": n ** 3 / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+           "sample": f"1 step of the same workload at {n}^3 fp32 ({cg_iters} CG iterations) with the NumPy oracle "
+                     f"(oracle/phi_oracle.py, single-threaded NumPy), {dt:.1f} s"}
+    return cpu, dict(v=vel, p=p, rel_residual_sq=float(info.residual_sq[0] / info.rhs_sq[0]))
+
+
+def parity_block(ctx, n, cg_iters, device, ref):
+    """ the GPU on the SAME inputs as the CPU leg (one benchmark step at n^3), compared with the oracle's fields: the north-star's
+    'pressure within 1e-4 rel-L2 of NumPy' measured inside the benchmark run """
+    sim = FluidStep(ctx, n, 1, cg_iters, device)
+    pv, pv2 = [t.data_ptr() for t in sim.v], [t.data_ptr() for t in sim.v2]
+    ctx.advect_staggered(sim.grid, pv, pv, pv2, sim.dt, sim.stream)
+    info = ctx.make_incompressible(sim.grid, pv2, None, 0, 1, True, sim.p.data_ptr(), 0, sim.solve, want_info=True, stream=sim.stream)
+    torch.cuda.synchronize(device)
+    pg = sim.p.cpu().numpy().astype(np.float64)
+    po = ref["p"].astype(np.float64)
+    pg -= pg.mean(); po -= po.mean()
+    p_err = float(np.linalg.norm(pg - po) / np.linalg.norm(po))
+    v_err = max(float(np.abs(a.cpu().numpy() - b).max()) for a, b in zip(sim.v2, ref["v"]))
+    return {"size": n, "cg_iterations": int(info[0].iterations), "pressure_rel_l2": p_err, "velocity_max_abs": v_err,
+            "rel_residual_sq": info[0].residual_sq / info[0].rhs_sq, "rel_residual_sq_oracle": ref["rel_residual_sq"],
+            "tolerance": {"pressure_rel_l2": 1e-4, "velocity_max_abs": 2e-5}, "ok": bool(p_err <= 1e-4 and v_err <= 2e-5),
+            "reference": "NumPy oracle (oracle/phi_oracle.py) on identical inputs: the cpu_baseline sample"}
+
+
+def config3_block(ctx, device, n=512, iters=100):
+    """ BASELINE configs[2] (the north-star's roofline target): 512^3 fp32 periodic pressure solve, `iters` fixed CG iterations on a
+    seeded mean-free random rhs; wall time per iteration + per-kernel hipEvent times, bytes MOVED by construction vs 8 TB/s """
+    L = 2 * math.pi
+    per = ((C.BC_PERIODIC, C.BC_PERIODIC),) * 3
+    grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), per)
+    g = torch.Generator(device=device).manual_seed(0)
+    rhs = torch.randn(1, n, n, n, generator=g, device=device)
+    rhs -= rhs.mean()
+    x = torch.zeros_like(rhs)
+    solve = C.Solve(0.0, 0.0, iters, 50, 0, 0)
+    stream = int(torch.cuda.current_stream(device).cuda_stream)
+    ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 4, 0, 0, 0), want_info=False, stream=stream)   # warm-up (workspace, plans)
+    x.zero_()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=False, stream=stream)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    x.zero_()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), solve, want_info=True, stream=stream)
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    assert info[0].iterations == iters and not info[0].diverged, (info[0].iterations, info[0].diverged)
+    cells = n ** 3
+    per_k = {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()}
+    ms_it = wall / iters * 1e3
+    moved = MOVED_BYTES_PER_CELL["cg_iteration"] * cells
+    out = {"workload": f"{n}^3 fp32 periodic pressure solve, {iters} CG iterations, seeded random rhs (BASELINE.json configs[2])",
+           "ms_per_solve": round(wall * 1e3, 3), "ms_per_iteration": round(ms_it, 5),
+           "moved_bytes_per_iteration": moved, "moved_GBs": round(moved / (ms_it * 1e-3) / 1e9, 1),
+           "moved_frac": round(moved / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "algorithmic_equiv_frac": round(ALG_BYTES_PER_CELL["cg_iteration"] * cells / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "kernel_ms_per_launch": {k: (round(v, 5) if v else None) for k, v in per_k.items() if v},
+           "plan": {name: ctx.query_plan(grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))},
+           "final_relative_residual": math.sqrt(info[0].residual_sq / info[0].rhs_sq),
+           "note": "wall time of the whole solve (initial residual, 100 x (MATVEC + UPDATE), refresh at 50, final state) / iterations; "
+                   "moved = 7 words per cell and iteration by construction (3 MATVEC + mean of 3 / 5 UPDATE_R / UPDATE_X2)"}
+    del rhs, x
+    return out
+
+
+def live_pmc_traffic(n, kernel_key):
+    """ HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes run NOW (separate FETCH_SIZE / WRITE_SIZE passes of
+    tools/pmc_workload.py at this size, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2048 B -- gfx950 counts half of a
+    wide streaming read --, WRITE_SIZE x 1024 B). Returns (bytes or None, source string). """
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or any(k.startswith("ROCPROF") for k in os.environ) or os.environ.get("PHIHIP_BENCH_PMC", "1") == "0":
+        return None, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        base = tempfile.mkdtemp(prefix="phihip_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(base, ctr), "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n)]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                return None, None
+            if proc.returncode != 0:
+                return None, None
+        res = pmc_summary.summarise(base)
+        for key, e in res["kernels"].items():
+            if key.startswith(kernel_key + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e:
+                src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run inside this bench invocation on tools/pmc_workload.py {n} "
+                       f"({key}; calibration copy: fetch unit {res['units']['fetch_bytes_per_unit_calibrated']}, "
+                       f"write unit {res['units']['write_bytes_per_unit_calibrated']} B)")
+                return int(round(e["read_bytes_prescribed"] + e["write_bytes_prescribed"])), src
+    except Exception:
+        pass
+    return None, None
 
 
 def cpu_cg_variants(n, iters, dtype=np.float32):
@@ -141,6 +247,8 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=100)
     ap.add_argument("--cpu-size", type=int, default=192, help="grid size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
+    ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block (pressure solve only; 0 = skip)")
+    ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
     args = ap.parse_args()
 
@@ -189,6 +297,17 @@ def main():
     cells = n ** 3 * B
     value = cells * world * args.steps / elapsed
 
+    # ---- the timed steps must have run the iterations they claim (an entry that freezes -- diverged / residual 0 -- makes the remaining
+    # launches return at once and would overstate the throughput): one more step that reports ----
+    info = None
+    if rank == 0:
+        pv2 = [t.data_ptr() for t in sim.v2]
+        ctx.advect_staggered(sim.grid, [t.data_ptr() for t in sim.v], [t.data_ptr() for t in sim.v], pv2, sim.dt, sim.stream)
+        info = ctx.make_incompressible(sim.grid, pv2, None, 0, 1, True, sim.p.data_ptr(), sim.div.data_ptr(), sim.solve, want_info=True,
+                                       stream=sim.stream)
+        sim.v, sim.v2 = sim.v2, sim.v
+        assert all(i.iterations == args.cg_iters and not i.diverged for i in info), [(i.iterations, i.diverged, i.residual_sq) for i in info]
+
     # ---- roofline of the dominant kernel: hipEvent pairs around every launch on the solve stream, extra profiled steps ----
     roofline = None
     extra = {}
@@ -200,33 +319,58 @@ def main():
         torch.cuda.synchronize(device)
         prof = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
-        per = {k: (v[1] / v[0] if v[0] else None, v[0]) for k, v in prof.items()}
-        t_upd, t_mv = per["cg_update"][0], per["cg_matvec_dot"][0]
-        if t_upd:
-            achieved = ALG_BYTES_PER_CELL["cg_update"] * cells / (t_upd * 1e-3) / 1e9
-            # the UPDATE phase alternates two forms (x is updated every other iteration): 3 and 5 words per cell actually moved, while
-            # SURVEY §8d's algorithmic count of this pass stays 6 words -- `achieved` follows the contract (algorithmic bytes), the
-            # bytes the kernels move by construction and the PMC-measured HBM bytes are reported next to it
-            moved = MOVED_BYTES_PER_CELL["cg_update"] * cells
-            roofline = {"bound": "hbm", "kernel": "march_kernel<MODE_UPDATE_R | MODE_UPDATE_X2> (cg_update, mean of the alternating forms)",
-                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": _pmc_traffic(n), "avg_launch_ms": round(t_upd, 5), "launches": per["cg_update"][1],
-                        "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL["cg_update"] * cells,
-                        "moved_bytes_per_launch": moved, "moved_GBs": round(moved / (t_upd * 1e-3) / 1e9, 1),
-                        "moved_frac": round(moved / (t_upd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        if t_upd and t_mv:
-            it = ALG_BYTES_PER_CELL["cg_iteration"] * cells / ((t_upd + t_mv) * 1e-3) / 1e9
+        per = {k: (v[1] / v[0] if v[0] else None, v[0], v[1]) for k, v in prof.items()}
+        # dominant kernel = largest share of the step's GPU time among the distinct kernels (MATVEC / UPDATE_X2 / UPDATE_R are three
+        # template instantiations; at 256^3 MATVEC leads with ~40 %)
+        cg_kernels = {"cg_matvec_dot": "march_kernel<MODE_MATVEC> (d = r + beta d, sum d.Ad; 100 launches per step)",
+                      "cg_update": "march_kernel<MODE_UPDATE_X2> (x += two steps, r -= alpha A d, sum r^2)",
+                      "cg_update_r": "march_kernel<MODE_UPDATE_R> (r -= alpha A d, sum r^2)"}
+        dom_key = max(cg_kernels, key=lambda k: per[k][2])
+        t_dom = per[dom_key][0]
+        total_ms = sum(v[2] for v in per.values())
+        if t_dom:
+            moved = MOVED_BYTES_PER_CELL[dom_key] * cells
+            alg = ALG_BYTES_PER_CELL[dom_key] * cells
+            gbs = moved / (t_dom * 1e-3) / 1e9
+            traffic, source = None, None
+            if world == 1 and args.pmc:
+                traffic, source = live_pmc_traffic(n, dom_key)
+            if traffic is None:
+                traffic, source = _pmc_traffic(n, dom_key)
+            roofline = {"bound": "hbm", "kernel": cg_kernels[dom_key], "share_of_step_gpu_time": round(per[dom_key][2] / total_ms, 3),
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "traffic_source": source,
+                        "traffic_frac": round(traffic / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "avg_launch_ms": round(t_dom, 5), "launches": per[dom_key][1],
+                        "bytes_per_launch": moved, "bytes_basis": "bytes the kernel moves by construction (DESIGN.md 3.1): "
+                        f"{MOVED_BYTES_PER_CELL[dom_key] // 4} words x 4 B x {cells} cells; the PMC figure (`traffic`) cross-checks it",
+                        "algorithmic_bytes_per_launch": alg,
+                        "algorithmic_equiv_frac": round(alg / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "achievable_copy_GBs": 6290.0}
+        t_mv, t_x2, t_ur = per["cg_matvec_dot"][0], per["cg_update"][0], per["cg_update_r"][0]
+        if t_mv and (t_x2 or t_ur):
+            t_up = 0.5 * ((t_x2 or t_ur) + (t_ur or t_x2))          # the two update forms alternate
             moved_it = MOVED_BYTES_PER_CELL["cg_iteration"] * cells
-            extra["roofline_cg_iteration"] = {"achieved": round(it, 1), "unit": "GB/s", "frac": round(it / HBM_PEAK_GBS, 4),
-                                              "ms_matvec_dot": round(t_mv, 5), "ms_update": round(t_upd, 5),
+            extra["roofline_cg_iteration"] = {"ms_matvec_dot": round(t_mv, 5), "ms_update_x2": round(t_x2, 5) if t_x2 else None,
+                                              "ms_update_r": round(t_ur, 5) if t_ur else None, "ms_iteration": round(t_mv + t_up, 5),
+                                              "moved_bytes": moved_it, "moved_GBs": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9, 1),
+                                              "moved_frac": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                               "algorithmic_bytes": ALG_BYTES_PER_CELL["cg_iteration"] * cells,
-                                              "moved_bytes": moved_it, "moved_frac": round(moved_it / ((t_upd + t_mv) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                              "algorithmic_equiv_frac": round(ALG_BYTES_PER_CELL["cg_iteration"] * cells / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         extra["kernel_ms_per_launch"] = {k: (round(v[0], 5) if v[0] else None) for k, v in per.items()}
+        extra["kernel_ms_per_step"] = {k: round(v[2] / args.profile_steps, 5) for k, v in per.items()}
+        extra["plan"] = {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_size > 0:
-        cpu = cpu_baseline(args.cpu_size, args.cg_iters)
+        cpu, ref = cpu_baseline(args.cpu_size, args.cg_iters)
+        extra["parity"] = parity_block(ctx, args.cpu_size, args.cg_iters, device, ref)
+        del ref
         extra["cpu_cg_variants"] = cpu_cg_variants(96, 20)
+    if rank == 0 and world == 1 and args.config3_size > 0:
+        del sim
+        torch.cuda.empty_cache()
+        extra["config3"] = config3_block(ctx, device, args.config3_size, args.cg_iters)
 
     if rank == 0:
         out = {
@@ -237,6 +381,7 @@ def main():
                                    f"iterations/step (BASELINE.json configs[1])", "cells_per_gpu": cells, "batch_per_gpu": B,
                        "cg_iterations": args.cg_iters, "parallelism": f"batch-parallel replicas x{world}, 1 all-reduce(max residual)/step"},
             "final_relative_residual": float(rel.item()) if rel is not None else None,
+            "iterations_verified": [int(i.iterations) for i in info] if info else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out.update(extra)
@@ -245,16 +390,18 @@ def main():
         dist.destroy_process_group()
 
 
-def _pmc_traffic(n):
-    """ HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
-    tools/pmc_summary.py from separate --pmc runs; corrected as MI355X_MICROARCH.md prescribes). None if not collected. """
+def _pmc_traffic(n, kernel_key):
+    """ fallback when the PMC passes cannot run inside this invocation (no rocprofv3, nested profiler, N > 1): HBM bytes per launch
+    of the kernel from the committed passes (profiles/pmc_traffic.json, tools/pmc_summary.py). (None, None) if not collected. """
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = {"cg_update": "cg_update_x2"}.get(kernel_key, kernel_key)
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get(f"cg_update_{n}", None)
+        val = data.get(f"{key}_{n}", None)
+        return val, ("profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of an earlier run, not this invocation)" if val else None)
     except Exception:
-        return None
+        return None, None
 
 
 if __name__ == "__main__":

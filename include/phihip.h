@@ -7,7 +7,9 @@
  *
  * Conventions
  *   - All field buffers are DEVICE pointers owned by the caller (e.g. torch-ROCm tensor.data_ptr()); the library owns
- *     only its context / workspace. Nothing is allocated inside the CG loop.
+ *     only its context / workspace. Nothing is allocated inside the CG loop. Buffers must be aligned to their element size;
+ *     16-byte alignment (what hipMalloc / torch allocations have) enables the 16-byte vector paths of the stencil kernels --
+ *     pointers that are not 16-byte aligned (offset views) are accepted and take the scalar path.
  *   - Arrays are dense C-contiguous (batch, x, y[, z]); the LAST spatial axis is the fast one
  *     (phi/field/_field.py:160-180). `batch` independent simulations share one grid description (PhiML batch dims).
  *   - Velocity = StaggeredGrid (phi/field/_grid.py:89-176): one array per component d with
@@ -35,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PHIHIP_VERSION 100 /* 0.1.0 */
+#define PHIHIP_VERSION 101 /* 0.1.1 */
 
 typedef enum phihip_status {
     PHIHIP_OK = 0,
@@ -278,7 +280,9 @@ int phihip_slab_state(phihip_ctx* ctx, const phihip_grid* grid, int first, const
 /* Kernel families timed with hipEvent pairs on the solve stream while profiling is enabled. */
 typedef enum phihip_kernel_id {
     PHIHIP_K_ADVECT = 0, PHIHIP_K_DIVERGENCE = 1, PHIHIP_K_CG_RESIDUAL = 2, PHIHIP_K_CG_MATVEC_DOT = 3,
-    PHIHIP_K_CG_UPDATE = 4, PHIHIP_K_CG_SCALAR = 5, PHIHIP_K_GRAD_SUBTRACT = 6, PHIHIP_K_OTHER = 7, PHIHIP_K_COUNT = 8
+    PHIHIP_K_CG_UPDATE = 4, PHIHIP_K_CG_SCALAR = 5, PHIHIP_K_GRAD_SUBTRACT = 6, PHIHIP_K_OTHER = 7,
+    PHIHIP_K_CG_UPDATE_R = 8,   /* the r-only form of the update (odd iterations of the deferred x update): a kernel of its own */
+    PHIHIP_K_COUNT = 9
 } phihip_kernel_id;
 int phihip_profile_enable(phihip_ctx* ctx, int enable);
 /* synchronises, then returns launches and summed milliseconds per family since the last reset */

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 PHIHIP_F32, PHIHIP_F64 = 0, 1
 BC_PERIODIC, BC_CLOSED, BC_OPEN = 0, 1, 2
 
-K_NAMES = ("advect", "divergence", "cg_residual", "cg_matvec_dot", "cg_update", "cg_scalar", "grad_subtract", "other")
+K_NAMES = ("advect", "divergence", "cg_residual", "cg_matvec_dot", "cg_update", "cg_scalar", "grad_subtract", "other", "cg_update_r")
 K_COUNT = len(K_NAMES)
 
 STATUS_NAMES = {0: "PHIHIP_OK", -1: "PHIHIP_ERR_BAD_ARG", -2: "PHIHIP_ERR_HIP", -3: "PHIHIP_ERR_UNSUPPORTED",

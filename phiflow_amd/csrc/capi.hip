@@ -151,6 +151,11 @@ static void remap3w(const GridView& v, void* const in[3], void* out[3]) {
     for (int d = 0; d < v.rank; ++d) out[d + v.ax0] = in ? in[d] : nullptr;
 }
 
+// the 16-byte vector paths of the marching kernels need 16-byte aligned fields (and 4-byte aligned flags): anything else -> scalar path
+static void note_align(GridView& v, const void* p, unsigned mask = 15u) {
+    if (p && ((uintptr_t)p & mask)) v.unaligned = true;
+}
+
 static int check_ptrs(const GridView& v, const void* const p[3], const char* what) {
     PHIHIP_REQUIRE(p != nullptr, "%s is NULL", what);
     for (int d = 0; d < v.rank; ++d) PHIHIP_REQUIRE(p[d] != nullptr, "%s[%d] is NULL", what, d);
@@ -444,6 +449,7 @@ int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t
     PHIHIP_ENTER(ctx, grid);
     PHIHIP_REQUIRE(p && out && p != out, "laplace_apply: p / out NULL or aliased");
     PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
+    note_align(v, p); note_align(v, out); note_align(v, flags, 3u);
     return run_laplace_apply(ctx, v, flags, mask_batch, p, out, s);
 }
 
@@ -472,6 +478,7 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
     PHIHIP_REQUIRE(rhs && x && rhs != x, "cg_solve: rhs / x NULL or aliased");
     PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
     PHIHIP_TRY(check_solve(solve));
+    note_align(v, rhs); note_align(v, x); note_align(v, flags, 3u);
     return run_cg(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
 }
 
@@ -492,6 +499,7 @@ int phihip_slab_residual(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, 
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
     PHIHIP_REQUIRE(x && rhs && r && sums, "slab_residual: NULL argument");
     PHIHIP_REQUIRE((!halo_lo || x_lo) && (!halo_hi || x_hi), "slab_residual: halo plane missing");
+    note_align(v, x); note_align(v, x_lo); note_align(v, x_hi); note_align(v, rhs); note_align(v, r); note_align(v, flags, 3u);
     return run_slab_residual(ctx, v, flags, 1, x, x_lo, x_hi, rhs, r, sums, keep_going, (hipStream_t)stream);
 }
 
@@ -505,6 +513,8 @@ int phihip_slab_matvec(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, in
     PHIHIP_REQUIRE(sums_in && r && d_old && d_new && sum_out && d_old != d_new, "slab_matvec: NULL or aliased argument");
     PHIHIP_REQUIRE((!halo_lo || (r_lo && d_lo)) && (!halo_hi || (r_hi && d_hi)), "slab_matvec: halo plane missing");
     PHIHIP_TRY(check_slab_solve(solve));
+    note_align(v, r); note_align(v, r_lo); note_align(v, r_hi); note_align(v, d_old); note_align(v, d_lo); note_align(v, d_hi);
+    note_align(v, d_new); note_align(v, flags, 3u);
     return run_slab_matvec(ctx, v, flags, 1, first, sums_in, r, r_lo, r_hi, d_old, d_lo, d_hi, d_new, sum_out, solve, (hipStream_t)stream);
 }
 
@@ -518,6 +528,7 @@ int phihip_slab_update(phihip_ctx* ctx, const phihip_grid* grid, int halo_lo, in
     PHIHIP_REQUIRE(sum_in && d && x && (x_only || (r && sum_out)), "slab_update: NULL argument");
     PHIHIP_REQUIRE(x_only || ((!halo_lo || d_lo) && (!halo_hi || d_hi)), "slab_update: halo plane missing");
     PHIHIP_TRY(check_slab_solve(solve));
+    note_align(v, d); note_align(v, d_lo); note_align(v, d_hi); note_align(v, x); note_align(v, r); note_align(v, flags, 3u);
     return run_slab_update(ctx, v, flags, 1, sum_in, d, d_lo, d_hi, x, r, sum_out, x_only, solve, (hipStream_t)stream);
 }
 
@@ -565,6 +576,7 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
         remap3(v, soft_mask, m);
         PHIHIP_TRY(run_scale_faces(ctx, v, u, m, s));
     }
+    note_align(v, pressure); note_align(v, div_out); note_align(v, flags, 3u);
     void* div = div_out;
     if (!div) {
         const size_t bytes = (size_t)v.batch * v.cells * (v.dtype == PHIHIP_F64 ? 8 : 4);
@@ -688,6 +700,7 @@ int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid
     PHIHIP_TRY(check_solve(solve));
     void* gu[3];
     remap3w(v, grad_velocity, gu);
+    note_align(v, grad_pressure); note_align(v, flags, 3u);
     return run_project_bwd(ctx, v, flags, mask_batch, balance, gu, grad_pressure, solve, info, s);
 }
 

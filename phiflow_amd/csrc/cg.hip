@@ -37,7 +37,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         }
     g->flags_per_batch = mask_batch > 1 ? 1 : 0;
     c->batch = v.batch;
-    c->vec = (v.n[2] % vmax == 0) ? vmax : 1;
+    c->vec = (v.n[2] % vmax == 0 && !v.unaligned) ? vmax : 1;
     const Tuning& t = ctx->tuning[family];
     const int mode = family_mode(family);
     const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : 1.0 / 3.0);   // UPDATE_R: d is 1 of 3 words
@@ -416,7 +416,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
             const int mode = !defer ? mode_up : (pending ? MODE_UPDATE_X2 : MODE_UPDATE_R);
             if (defer) pending = !pending;
             const bool r_only = mode == MODE_UPDATE_R;
-            LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
+            LaunchScope ls(ctx, r_only ? PHIHIP_K_CG_UPDATE_R : PHIHIP_K_CG_UPDATE, s);
             PHIHIP_TRY(launch_march_any<T>(v, r_only ? c_ur : c_up, mode, has_flags, r_only ? g_ur : g_up, a, s));
             cur ^= 1;
             nblk_rr = r_only ? g_ur.nblk : g_up.nblk;

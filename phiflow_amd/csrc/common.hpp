@@ -51,6 +51,7 @@ struct GridView {
     long long cells;           // n0*n1*n2
     long long ccells[3];       // cells per stored component
     int halo[2];               // slab decomposition: planes beyond the lower / upper a0 side come from a neighbour rank
+    bool unaligned;            // some caller buffer of this call is not 16-byte aligned: the marching kernels take the scalar path
 };
 
 int make_view(const phihip_grid* grid, GridView* out);

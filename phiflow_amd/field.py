@@ -33,7 +33,11 @@ class Field:
     __array_ufunc__ = None     # `numpy_array * field` defers to Field.__rmul__ (a batch vector, one number per batch entry)
 
     def __init__(self, resolution: Dict[str, int], bounds: Box, boundary: Extrapolation, values, staggered: bool,
-                 backend: HipBackend, batched: bool):
+                 backend: HipBackend, batched: bool, vector_scale: Optional[Sequence[float]] = None):
+        # vector_scale: `scalar * (0, 0.1)` -- a centred scalar times a constant vector, kept lazily (values stay the scalar's) until
+        # it is resampled to a staggered grid with `@` / `resample`; every operator below either carries it along or refuses
+        assert vector_scale is None or (not staggered and len(vector_scale) == len(resolution))
+        self.vector_scale = [float(c) for c in vector_scale] if vector_scale is not None else None
         self.resolution = dict(resolution)
         self.bounds = bounds
         self.boundary = boundary
@@ -112,7 +116,7 @@ class Field:
         return Field(res, Box(**kw), comp_boundary, self.values[d], False, self.backend, self.batched)
 
     def with_values(self, values) -> 'Field':
-        return Field(self.resolution, self.bounds, self.boundary, values, self.is_staggered, self.backend, self.batched)
+        return Field(self.resolution, self.bounds, self.boundary, values, self.is_staggered, self.backend, self.batched, self.vector_scale)
 
     def with_boundary(self, boundary) -> 'Field':
         """ change the extrapolation; staggered fields re-store their boundary faces accordingly: faces that become
@@ -120,7 +124,7 @@ class Field:
         (phi/field/_field.py:451-472; tests/commit/field/test__grid.py:85-94). """
         boundary = as_extrapolation(boundary)
         if not self.is_staggered:
-            return Field(self.resolution, self.bounds, boundary, self.values, False, self.backend, self.batched)
+            return Field(self.resolution, self.bounds, boundary, self.values, False, self.backend, self.batched, self.vector_scale)
         new_vals = []
         for d, dim in enumerate(self.dims):
             t = self.values[d]
@@ -146,9 +150,17 @@ class Field:
     with_extrapolation = with_boundary
 
     # --- arithmetic (elementwise glue on device tensors; not part of the kernel hot path) --------------------------
-    def _op(self, other, fn) -> 'Field':
+    def _op(self, other, fn, additive: bool = False) -> 'Field':
+        """ elementwise `fn(self, other)`. additive: + / - (a lazy `scalar * vector` field only combines with one of the same vector) """
+        scale = self.vector_scale
         if isinstance(other, Field):
-            assert other.is_staggered == self.is_staggered and other.resolution == self.resolution, "incompatible fields"
+            assert other.is_staggered == self.is_staggered and same_grid(self, other), \
+                f"incompatible fields (sample points differ): {self!r} vs {other!r}; resample one with `@` first"
+            if additive and scale != other.vector_scale:
+                raise NotImplementedError("adding a lazy `scalar * vector` field to a field with a different (or no) vector factor; "
+                                          "resample it to the staggered grid first (`field @ velocity`)")
+            if not additive and other.vector_scale is not None:
+                scale = other.vector_scale if scale is None else [a * b for a, b in zip(scale, other.vector_scale)]
             if self.is_staggered:
                 assert [tuple(a.shape[1:]) for a in self.values] == [tuple(b.shape[1:]) for b in other.values], \
                     "staggered fields with different face layouts (boundaries) cannot be combined"
@@ -160,6 +172,8 @@ class Field:
             assert self.is_staggered and len(other) == self.spatial_rank, "vector operand requires a staggered field"
             vals = [fn(a, float(c)) for a, c in zip(self.values, other)]
             batched = self.batched
+        elif additive and scale is not None:
+            raise NotImplementedError("adding a number to a lazy `scalar * vector` field; resample it to the staggered grid first")
         elif isinstance(other, (np.ndarray, torch.Tensor)) and other.ndim == 1:
             # one number per batch entry, e.g. `inflow_rate * resample(inflow, to=s, soft=True)` (Batched_Smoke.ipynb)
             assert self.batch_size in (1, len(other)), f"batch vector of length {len(other)} does not match batch size {self.batch_size}"
@@ -170,19 +184,22 @@ class Field:
         else:
             vals = [fn(a, other) for a in self.values] if self.is_staggered else fn(self.values, other)
             batched = self.batched
-        return Field(self.resolution, self.bounds, self.boundary, vals, self.is_staggered, self.backend, batched)
+        return Field(self.resolution, self.bounds, self.boundary, vals, self.is_staggered, self.backend, batched, scale)
 
-    def __add__(self, other): return self._op(other, lambda a, b: a + b)
-    def __radd__(self, other): return self._op(other, lambda a, b: b + a)
-    def __sub__(self, other): return self._op(other, lambda a, b: a - b)
-    def __rsub__(self, other): return self._op(other, lambda a, b: b - a)
+    def __add__(self, other): return self._op(other, lambda a, b: a + b, additive=True)
+    def __radd__(self, other): return self._op(other, lambda a, b: b + a, additive=True)
+    def __sub__(self, other): return self._op(other, lambda a, b: a - b, additive=True)
+    def __rsub__(self, other): return self._op(other, lambda a, b: b - a, additive=True)
     def __mul__(self, other):
         if isinstance(other, (tuple, list)) and self.is_centered:
             return vector_scaled(self, other)   # `smoke * (0, 0.1)`; becomes a vector field when resampled with `@`
         return self._op(other, lambda a, b: a * b)
 
     def __rmul__(self, other): return self.__mul__(other)
-    def __truediv__(self, other): return self._op(other, lambda a, b: a / b)
+    def __truediv__(self, other):
+        if isinstance(other, Field) and other.vector_scale is not None:
+            raise NotImplementedError("division by a lazy `scalar * vector` field")
+        return self._op(other, lambda a, b: a / b)
     def __neg__(self): return self._op(-1.0, lambda a, b: a * b)
 
     def __matmul__(self, other: 'Field') -> 'Field':
@@ -193,6 +210,13 @@ class Field:
     def __repr__(self):
         kind = "StaggeredGrid" if self.is_staggered else "CenteredGrid"
         return f"{kind}[{self.resolution}, batch={self.batch_size if self.batched else None}, {self.boundary}, {self.dtype}, {self.backend}]"
+
+
+def same_grid(a: 'Field', b: 'Field') -> bool:
+    """ same sample points up to staggering: resolution, bounds and dims (the reference short-circuits `resample` only when
+    `value.geometry == to.geometry`, phi/field/_resample.py:42-48) """
+    return a.resolution == b.resolution and a.dims == b.dims and tuple(a.bounds.lower) == tuple(b.bounds.lower) \
+        and tuple(a.bounds.upper) == tuple(b.bounds.upper)
 
 
 def _boundary_slab(t: torch.Tensor, ax: int, code: int, const: float, lower: bool, periodic_src) -> torch.Tensor:
@@ -411,13 +435,16 @@ def resample(value, to: Field, soft: bool = False, balance: float = 0.5) -> Fiel
                          True, to.backend, any(b for _, b in comps))
         t, batched = _tensor_from(mask(_sample_points(to.resolution, to.bounds, None, to.boundary)), tuple(to.resolution.values()), to.backend, to.dtype)
         return Field(to.resolution, to.bounds, to.boundary, t, False, to.backend, batched)
-    if value.is_staggered == to.is_staggered and value.resolution == to.resolution:
+    if value.is_staggered == to.is_staggered and same_grid(value, to) and value.vector_scale is None:
         if value.is_staggered and value.boundary != to.boundary:
             return value.with_boundary(to.boundary)
         return Field(value.resolution, value.bounds, to.boundary, value.values, value.is_staggered, value.backend, value.batched)
-    if value.is_centered and to.is_staggered and value.resolution == to.resolution:
+    if value.vector_scale is not None and to.is_centered:
+        raise NotImplementedError("HIP backend: a `scalar * vector` field can only be resampled to a StaggeredGrid (centred vector fields "
+                                  "are not implemented)")
+    if value.is_centered and to.is_staggered and same_grid(value, to):
         be = value.backend
-        scale = getattr(value, '_vector_scale', None) or [1.0] * value.spatial_rank
+        scale = value.vector_scale or [1.0] * value.spatial_rank
         B = max(value.batch_size, to.batch_size)
         src = value.values if value.batch_size == B else value.values.expand(B, *value.values.shape[1:])
         src = src.contiguous()
@@ -442,9 +469,10 @@ def resample(value, to: Field, soft: bool = False, balance: float = 0.5) -> Fiel
 def vector_scaled(s: Field, vector: Sequence[float]) -> Field:
     """ `smoke * (0, 0.1)`: a centred scalar times a constant vector, kept lazily until it is resampled with `@`. """
     assert s.is_centered and len(vector) == s.spatial_rank
-    out = Field(s.resolution, s.bounds, s.boundary, s.values, False, s.backend, s.batched)
-    out._vector_scale = [float(v) for v in vector]
-    return out
+    vec = [float(c) for c in vector]
+    if s.vector_scale is not None:             # (s * (0, 1)) * (2, 3): component-wise product of the vectors
+        vec = [a * b for a, b in zip(s.vector_scale, vec)]
+    return Field(s.resolution, s.bounds, s.boundary, s.values, False, s.backend, s.batched, vec)
 
 
 def assert_close(*fields, rel_tolerance: float = 1e-5, abs_tolerance: float = 0, msg: str = ""):

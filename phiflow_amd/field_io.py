@@ -8,6 +8,8 @@ A StaggeredGrid is stored as its padded `staggered_tensor()`: all components pad
 dim and stacked along a trailing `vector` dim (phi/field/_field.py:586-604); reading slices the valid faces back out
 (`unstack_staggered_tensor`, phi/field/_grid.py:179-187).
 """
+import pickle
+import zipfile
 from typing import Optional
 
 import numpy as np
@@ -47,6 +49,39 @@ def extrapolation_from_dict(d: dict, dims) -> Extrapolation:
     if t == 'mixed':
         return _Mixed({dim: (extrapolation_from_dict(lo, dims), extrapolation_from_dict(up, dims)) for dim, (lo, up) in d['dims'].items()})
     raise NotImplementedError(f"extrapolation type {t!r} is not supported by the HIP backend")
+
+
+class _MetadataUnpickler(pickle.Unpickler):
+    """ The format stores three small metadata entries (`extrapolation`, `dim_item_names`, `bounds_item_names`) as pickled object
+    arrays. `np.load(allow_pickle=True)` would run ANY pickle a shared scene file carries; this unpickler only rebuilds numpy arrays /
+    scalars / dtypes and plain containers and refuses every other global. """
+    _ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "list"),
+                ("builtins", "str"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "complex"),
+                ("builtins", "slice"), ("builtins", "NoneType")}
+    _ALLOWED_NAMES = {"_reconstruct", "scalar", "_frombuffer"}      # numpy.core.multiarray / numpy._core.multiarray helpers
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED or (module.startswith("numpy") and "multiarray" in module and name in self._ALLOWED_NAMES) \
+                or (module.startswith("numpy") and module.endswith("numeric") and name == "_frombuffer"):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"field file metadata may only contain numpy arrays and plain containers, found {module}.{name}")
+
+
+def _load_npz(file: str) -> dict:
+    """ every entry of the .npz: numeric / string arrays through numpy (allow_pickle=False), object arrays through `_MetadataUnpickler` """
+    out = {}
+    with zipfile.ZipFile(file) as zf:
+        for member in zf.namelist():
+            key = member[:-4] if member.endswith(".npy") else member
+            with zf.open(member) as fp:
+                version = np.lib.format.read_magic(fp)
+                shape, fortran, dtype = np.lib.format.read_array_header_1_0(fp) if version == (1, 0) else np.lib.format.read_array_header_2_0(fp)
+                if dtype.hasobject:
+                    out[key] = _MetadataUnpickler(fp).load()
+                    continue
+            with zf.open(member) as fp:
+                out[key] = np.lib.format.read_array(fp, allow_pickle=False)
+    return out
 
 
 def write(field: Field, file: str):
@@ -105,11 +140,16 @@ def _pad_component_for_storage(field: Field, i: int, c: np.ndarray) -> np.ndarra
 def read(file: str, backend: Optional[HipBackend] = None) -> Field:
     """ Loads a CenteredGrid / StaggeredGrid written by `write()` or by PhiFlow's `field.write` (incl. the legacy files
     tests/commit/field/dens_001000.npz / velo_001000.npz of the reference). Spatial dims keep the file's order. """
-    stored = np.load(file, allow_pickle=True)
+    stored = _load_npz(file)
+    for key in ('field_type', 'data', 'dim_names', 'dim_types', 'lower', 'upper', 'extrapolation'):
+        if key not in stored:
+            raise ValueError(f"{file}: not a PhiFlow field file (missing '{key}')")
     ftype = str(stored['field_type'])
     if ftype not in ('CenteredGrid', 'StaggeredGrid'):
         raise NotImplementedError(f"{ftype} not implemented")
     data = stored['data']
+    if not (isinstance(data, np.ndarray) and data.dtype.kind == 'f' and len(stored['dim_names']) == len(stored['dim_types']) == data.ndim):
+        raise ValueError(f"{file}: 'data' must be a float array with one axis per entry of dim_names / dim_types")
     names = [str(n) for n in stored['dim_names']]
     types = [str(t) for t in stored['dim_types']]
     spatial = [n for n, t in zip(names, types) if t == 'spatial']
@@ -117,7 +157,7 @@ def read(file: str, backend: Optional[HipBackend] = None) -> Field:
     assert len(batch) <= 1, "only one batch dimension is supported"
     order = [names.index(b) for b in batch] + [names.index(s) for s in spatial] + [i for i, t in enumerate(types) if t == 'channel']
     data = np.transpose(data, order)
-    bounds_names = stored['bounds_item_names'] if 'bounds_item_names' in stored.files else None
+    bounds_names = stored.get('bounds_item_names')
     if bounds_names is None or getattr(bounds_names, 'shape', None) == () or bounds_names is None:
         bounds_names = spatial
     bounds_names = [str(b) for b in np.atleast_1d(bounds_names)] if not isinstance(bounds_names, list) else bounds_names

@@ -13,7 +13,7 @@ import torch
 
 from . import _capi, autodiff
 from .extrapolation import pressure_extrapolation
-from .field import Field, _check_pressure_padding, _ptrs
+from .field import Field, _check_pressure_padding, _ptrs, same_grid
 from .geom import Box, Geometry, Sphere
 from .geom import Embedded, Union as Union_
 from .solve import Diverged, NotConverged, Solve, SolveInfo
@@ -239,7 +239,7 @@ def make_incompressible(velocity: Field,
         pressure = be.zeros((B,) + res_shape, velocity.dtype)
     else:
         x0 = solve.x0
-        assert isinstance(x0, Field) and x0.is_centered and x0.resolution == velocity.resolution, "x0 must be a CenteredGrid on the same grid"
+        assert isinstance(x0, Field) and x0.is_centered and same_grid(x0, velocity), "x0 must be a CenteredGrid on the velocity's grid"
         _check_pressure_padding(x0.boundary, velocity.boundary, velocity.dims)
         pressure = x0.values.to(velocity.dtype)
         pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()

@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .extrapolation import ConstantExtrapolation, resolve
-from .field import Field, _ptrs, _sample_points, _torch_dtype_code, component_shape
+from .field import Field, _ptrs, _sample_points, _torch_dtype_code, component_shape, same_grid   # noqa: F401
 
 
 class GridSample(torch.autograd.Function):
@@ -102,9 +102,6 @@ def sample_field(field: Field, points: Sequence[torch.Tensor]) -> List[torch.Ten
     return [sample_array(field, c, index_coords(field, c, pts)) for c in comps]
 
 
-def same_grid(a: Field, b: Field) -> bool:
-    return a.resolution == b.resolution and tuple(a.bounds.lower) == tuple(b.bounds.lower) and tuple(a.bounds.upper) == tuple(b.bounds.upper) \
-        and a.dims == b.dims
 
 
 def resample_general(value: Field, to: Field) -> Field:
@@ -118,7 +115,7 @@ def resample_general(value: Field, to: Field) -> Field:
     if to.is_centered:
         out = sample_field(value, sample_points(to))[0]
         return Field(to.resolution, to.bounds, to.boundary, out.reshape(out.shape[0], *to.resolution.values()), False, be, batched)
-    scale = getattr(value, '_vector_scale', None) or [1.0] * value.spatial_rank
+    scale = value.vector_scale or [1.0] * value.spatial_rank
     comps = []
     for d in range(to.spatial_rank):
         pts = sample_points(to, d)

@@ -1,0 +1,173 @@
+"""
+Oracle parity on the BASELINE.json configurations themselves: every function runs the workload a number
+is quoted for through the C ABI and compares it with the NumPy oracle on the same inputs -- pressure rel-L2 modulo the mean
+(north-star: 1e-4 fp32; 1e-9 fp64), velocities, and the solver's own residual after an EXACT number of iterations (tolerances 0).
+
+The size is a parameter: tests/test_gpu_baseline_sizes.py runs the full sizes on the MI355X (the launch plans only large grids
+select: chunks of 16-64 planes, (4,64) tiles, bidirectional MATVEC, the deferred x update over 100 iterations),
+tests/test_emu_kernels.py the same code at toy sizes under emulation (guards the test logic itself).
+"""
+import math
+
+import numpy as np
+
+import parity_cases as pc
+from parity_cases import C, O, CLO, PER
+
+
+def _check_residual(r_gpu, r_ref, rtol, floor):
+    """ squared relative residual after the same number of iterations; below the rounding floor of the dtype only its level counts """
+    if r_ref > floor:
+        assert abs(r_gpu - r_ref) <= rtol * r_ref, (r_gpu, r_ref)
+    else:
+        assert r_gpu <= 100 * floor, (r_gpu, r_ref)
+
+
+def _p_err(p_gpu, p_ref):
+    a, b = pc.demean(np.asarray(p_gpu, np.float64)), pc.demean(np.asarray(p_ref, np.float64))
+    return pc.rel_l2(a, b)
+
+
+def taylor_green_velocity(n, dtype=np.float32):
+    """ u = cos x sin y, v = -sin x cos y at the face centres, extruded along z, w = 0 on [0, 2 pi]^3 """
+    h = 2 * math.pi / n
+    idx = np.arange(n)
+    face, cent = idx * h, (idx + 0.5) * h
+    u = np.broadcast_to((np.cos(face)[:, None] * np.sin(cent)[None, :])[:, :, None], (n, n, n))
+    v = np.broadcast_to((-np.sin(cent)[:, None] * np.cos(face)[None, :])[:, :, None], (n, n, n))
+    return [np.ascontiguousarray(a, dtype=dtype)[None] for a in (u, v, np.zeros((n, n, n)))]
+
+
+def config2_step(ctx, mem, n=256, iters=100, report=None):
+    """ BASELINE configs[1]: one benchmark step (semi-Lagrangian self-advection + projection with exactly `iters` CG iterations,
+    refresh at 50) of the 3-D periodic Taylor-Green case in fp32 vs the oracle. """
+    L = 2 * math.pi
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(L,) * 3)
+    vel = taylor_green_velocity(n)
+    dt = 0.5 * L / n
+    dv = [mem.to_dev(a) for a in vel]
+    dv2 = [mem.empty(a.shape, np.float32) for a in vel]
+    dp = mem.to_dev(np.zeros((1, n, n, n), np.float32))
+    solve = C.Solve(0.0, 0.0, iters, 50, 0, 0)
+    P = lambda ts: [mem.ptr(t) for t in ts]
+    ctx.advect_staggered(grid, P(dv), P(dv), P(dv2), dt)
+    info = ctx.make_incompressible(grid, P(dv2), None, 0, 1, True, mem.ptr(dp), 0, solve)
+    mem.sync()
+    vo = O.semi_lagrangian_staggered(vel, vel, dt, dom)
+    vo, po, io, _ = O.make_incompressible(vo, dom, rtol=0.0, atol=0.0, max_iter=iters, refresh=50)
+    assert info[0].iterations == iters == int(io.iterations[0]) and not info[0].diverged
+    p_err = _p_err(mem.to_host(dp), po)
+    v_err = max(float(np.abs(mem.to_host(a) - b).max()) for a, b in zip(dv2, vo))
+    r_gpu, r_ref = info[0].residual_sq / info[0].rhs_sq, float(io.residual_sq[0] / io.rhs_sq[0])
+    if report is not None:
+        report.update(size=n, iterations=iters, pressure_rel_l2=p_err, velocity_max_abs=v_err, rel_residual_sq=r_gpu, rel_residual_sq_oracle=r_ref)
+    assert p_err <= 1e-4, f"pressure rel-L2 {p_err:.3e} vs oracle at {n}^3 / {iters} iterations"
+    assert v_err <= 2e-5, f"velocity max abs error {v_err:.3e}"
+    _check_residual(r_gpu, r_ref, 2e-2, 1e-10)
+    return p_err, v_err
+
+
+def config3_solve(ctx, mem, n=512, iters=20, report=None):
+    """ BASELINE configs[2]: pressure solve only, periodic fp32, mean-free pseudo-random rhs (numpy default_rng(0)), x0 = 0,
+    exactly `iters` iterations vs the oracle's CG on the same rhs. """
+    L = 2 * math.pi
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(L,) * 3)
+    rhs = np.random.default_rng(0).standard_normal((1, n, n, n), dtype=np.float32)
+    rhs -= rhs.mean(dtype=np.float64).astype(np.float32)
+    drhs, dx = mem.to_dev(rhs), mem.to_dev(np.zeros_like(rhs))
+    info = ctx.cg_solve(grid, 0, 1, mem.ptr(drhs), mem.ptr(dx), C.Solve(0.0, 0.0, iters, 50, 0, 0))
+    mem.sync()
+    xo, io = O.cg(lambda q: O.masked_laplace(q, dom, None, None), rhs, np.zeros_like(rhs), 0.0, 0.0, iters, 50)
+    assert info[0].iterations == iters == int(io.iterations[0]) and not info[0].diverged
+    p_err = _p_err(mem.to_host(dx), xo)
+    r_gpu, r_ref = info[0].residual_sq / info[0].rhs_sq, float(io.residual_sq[0] / io.rhs_sq[0])
+    if report is not None:
+        report.update(size=n, iterations=iters, pressure_rel_l2=p_err, rel_residual_sq=r_gpu, rel_residual_sq_oracle=r_ref)
+    assert p_err <= 1e-4, f"pressure rel-L2 {p_err:.3e} vs oracle at {n}^3 / {iters} iterations"
+    _check_residual(r_gpu, r_ref, 1e-2, 1e-10)
+    return p_err
+
+
+def config5_cavity(ctx, mem, n=256, iters=20, report=None):
+    """ BASELINE configs[4] (size class): fp64 lid-driven cavity, closed box with the lid velocity (1,0,0) on z+, one solid box in
+    the centre -> active / hard_bcs flags; advect + apply_boundary_conditions + projection with exactly `iters` iterations. """
+    bcv = np.zeros((3, 2, 3)); bcv[2, 1, 0] = 1.0
+    dom, grid = pc.make_case((n, n, n), ((CLO, CLO),) * 3, np.float64, bc_val=bcv, upper=(1.0, 1.0, 1.0))
+    rng = np.random.default_rng(5)
+    vel = [0.05 * rng.standard_normal((1,) + dom.comp_shape(d)) for d in range(3)]
+    obstacles = [O.BoxObstacle((0.375, 0.375, 0.375), (0.625, 0.625, 0.625))]
+    items = pc.obstacle_items(obstacles, 3)
+    cobs = C.make_obstacles(items)
+    dt = 0.5 / n / 0.15                                   # CFL ~ 0.5 for |u| ~ 3 sigma
+    g1 = C.make_grid(3, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    dacc, dflags = mem.empty(dom.res, np.uint8), mem.empty(dom.res, np.uint8)
+    ctx.obstacle_accessible(g1, cobs, len(items), mem.ptr(dacc))
+    ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    dv = [mem.to_dev(a) for a in vel]
+    dv2 = [mem.empty(a.shape, np.float64) for a in vel]
+    dp = mem.to_dev(np.zeros((1, n, n, n), np.float64))
+    P = lambda ts: [mem.ptr(t) for t in ts]
+    ctx.advect_staggered(grid, P(dv), P(dv), P(dv2), dt)
+    ctx.apply_obstacles(grid, cobs, len(items), P(dv2))
+    info = ctx.make_incompressible(grid, P(dv2), None, mem.ptr(dflags), 1, True, mem.ptr(dp), 0, C.Solve(0.0, 0.0, iters, 50, 0, 0))
+    mem.sync()
+    vo = O.semi_lagrangian_staggered(vel, vel, dt, dom)
+    vo, po, io, _ = O.make_incompressible(vo, dom, obstacles, rtol=0.0, atol=0.0, max_iter=iters, refresh=50)
+    assert info[0].iterations == iters == int(io.iterations[0]) and not info[0].diverged
+    pg = mem.to_host(dp)
+    p_err = pc.rel_l2(pg, po)                              # with obstacles the oracle balances on the active cells: no free mean
+    v_err = max(float(np.abs(mem.to_host(a) - b).max()) for a, b in zip(dv2, vo))
+    r_gpu, r_ref = info[0].residual_sq / info[0].rhs_sq, float(io.residual_sq[0] / io.rhs_sq[0])
+    if report is not None:
+        report.update(size=n, iterations=iters, pressure_rel_l2=p_err, velocity_max_abs=v_err, rel_residual_sq=r_gpu, rel_residual_sq_oracle=r_ref)
+    assert p_err <= 1e-9, f"fp64 pressure rel-L2 {p_err:.3e}"
+    assert v_err <= 1e-10, f"fp64 velocity max abs error {v_err:.3e}"
+    _check_residual(r_gpu, r_ref, 1e-8, 1e-26)
+    return p_err, v_err
+
+
+def config4_batched_smoke(ctx, mem, n=512, B=8, steps=3, iters=60, report=None):
+    """ BASELINE configs[3]: B x n^2 batched smoke plumes (closed box, per-entry inflow position x in linspace(30, 70, B)), `steps`
+    steps of Smoke_Plume.ipynb cell 5 (mac_cormack smoke + inflow, semi-Lagrangian velocity + buoyancy resample, projection from
+    the previous pressure) with exactly `iters` CG iterations per projection, every field of every step vs the oracle. """
+    dom, grid = pc.make_case((n, n), ((CLO, CLO),) * 2, np.float32, batch=B, upper=(100.0, 100.0))
+    cp = O.cell_positions(dom, np.float64)
+    xs = np.linspace(30, 70, B)
+    inflow = np.stack([(((cp[0] - x0) ** 2 + (cp[1] - 9.5) ** 2) <= 25).astype(np.float32) for x0 in xs]) * np.float32(0.2)
+    s_codes = ((O.OPEN, O.OPEN),) * 2                      # ZERO_GRADIENT smoke
+    P = lambda ts: [mem.ptr(t) for t in ts]
+    smoke = np.zeros((B, n, n), np.float32)
+    v = [np.zeros((B,) + dom.comp_shape(d), np.float32) for d in range(2)]
+    p = np.zeros((B, n, n), np.float32)
+    d_smoke, d_smoke2 = mem.to_dev(smoke), mem.empty(smoke.shape, np.float32)
+    d_inflow = mem.to_dev(inflow)
+    dv, dv2 = [mem.to_dev(a) for a in v], [mem.empty(a.shape, np.float32) for a in v]
+    dp = mem.to_dev(p)
+    solve = C.Solve(0.0, 0.0, iters, 50, 0, 0)
+    worst = dict(smoke=0.0, v=0.0, p=0.0, res=0.0)
+    for step in range(steps):
+        ctx.mac_cormack_centered(grid, mem.ptr(d_smoke), s_codes, None, P(dv), mem.ptr(d_smoke2), 1.0, 1.0)
+        mem.sync()
+        d_smoke2 += d_inflow                               # `+ inflow` (elementwise glue on the device tensors / host arrays)
+        ctx.advect_staggered(grid, P(dv), P(dv), P(dv2), 1.0)
+        ctx.centered_to_staggered(grid, mem.ptr(d_smoke2), s_codes, None, (0.0, 0.1), True, P(dv2))
+        info = ctx.make_incompressible(grid, P(dv2), None, 0, 1, True, mem.ptr(dp), 0, solve)
+        mem.sync()
+        d_smoke, d_smoke2 = d_smoke2, d_smoke
+        dv, dv2 = dv2, dv
+        smoke = O.mac_cormack_centered(smoke, v, 1.0, dom, s_codes) + inflow
+        buoy = O.centered_to_staggered(smoke, dom, s_codes, None, (0.0, 0.1))
+        v = O.semi_lagrangian_staggered(v, v, 1.0, dom)
+        v = [a + b for a, b in zip(v, buoy)]
+        v, p, io, _ = O.make_incompressible(v, dom, x0=p, rtol=0.0, atol=0.0, max_iter=iters, refresh=50)
+        assert [i.iterations for i in info] == [iters] * B == [int(k) for k in io.iterations]
+        worst['smoke'] = max(worst['smoke'], pc.rel_l2(mem.to_host(d_smoke), smoke))
+        worst['p'] = max(worst['p'], max(_p_err(mem.to_host(dp)[b:b + 1], p[b:b + 1]) for b in range(B)))
+        scale = max(float(np.abs(a).max()) for a in v)
+        worst['v'] = max(worst['v'], max(float(np.abs(mem.to_host(a) - b).max()) for a, b in zip(dv, v)) / scale)
+        worst['res'] = max(worst['res'], max([0.0] + [abs(i.residual_sq / i.rhs_sq - float(ro / yo)) / float(ro / yo)
+                                             for i, ro, yo in zip(info, io.residual_sq, io.rhs_sq) if float(ro / yo) > 1e-10]))
+    if report is not None:
+        report.update(size=n, batch=B, steps=steps, iterations=iters, **{f"worst_{k}": v_ for k, v_ in worst.items()})
+    assert worst['smoke'] <= 2e-5 and worst['p'] <= 1e-4 and worst['v'] <= 1e-4 and worst['res'] <= 2e-2, worst
+    return worst

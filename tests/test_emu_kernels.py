@@ -381,3 +381,48 @@ def test_bad_arguments_of_the_widened_entry_points(emu_ctx):
     assert plan["rows"] in (1, 2, 4) and plan["nblk"] >= 1 and plan["occupancy"] >= 1
     with pytest.raises(C.PhiHipError):
         emu_ctx.set_tuning_kernel(5, 1, 16, 8)
+
+
+def test_baseline_config_cases_at_toy_sizes(emu_ctx):
+    """ tests/baseline_cases.py (the oracle comparisons the GPU suite runs at the BASELINE sizes) at sizes the emulation finishes """
+    import baseline_cases as bc
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        bc.config2_step(emu_ctx, MEM, 16, 12)
+        bc.config3_solve(emu_ctx, MEM, 16, 8)
+        bc.config5_cavity(emu_ctx, MEM, 16, 8)
+        bc.config4_batched_smoke(emu_ctx, MEM, 32, 3, 2, 10)
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+
+
+def test_unaligned_buffers_take_the_scalar_path(emu_ctx):
+    """ field pointers that are not 16-byte aligned (offset views) must not reach the 16-byte vector loads: the plan falls
+    back to the scalar instantiation and the results stay those of the oracle """
+    dtype = np.float32
+    dom, grid = pc.make_case((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
+    rng = np.random.default_rng(3)
+    p = rng.standard_normal((1,) + dom.res).astype(dtype)
+    ref = pc.O.masked_laplace(p, dom, None, None)
+    cells = p.size
+    raw_in, raw_out = np.zeros(cells + 8, dtype), np.zeros(cells + 8, dtype)
+    for shift in (0, 1, 3):                                       # 0: aligned (numpy allocations are 16-byte aligned here), 1 / 3: +4 / +12 bytes
+        a, o = raw_in[shift:shift + cells], raw_out[shift:shift + cells]
+        a[:] = p.ravel()
+        o[:] = np.nan
+        assert (a.ctypes.data % 16 != 0) == (shift != 0) or raw_in.ctypes.data % 16 != 0
+        emu_ctx.laplace_apply(grid, 0, 1, a.ctypes.data, o.ctypes.data)
+        assert pc.rel_err(o.reshape(p.shape), ref) <= pc.tol(dtype)['stencil']
+    rhs = pc.O.balance_divergence(rng.standard_normal((1,) + dom.res).astype(dtype), None) if not dom.flexible() else rng.standard_normal((1,) + dom.res).astype(dtype)
+    xs = []
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        for shift in (0, 1):
+            a, o = raw_in[shift:shift + cells], raw_out[shift:shift + cells]
+            a[:] = rhs.ravel()
+            o[:] = 0
+            emu_ctx.cg_solve(grid, 0, 1, a.ctypes.data, o.ctypes.data, pc.solve_params(dtype, max_iter=6, rtol=0.0, check=0))
+            xs.append(o.copy())
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+    assert pc.rel_l2(xs[1], xs[0]) <= 1e-5

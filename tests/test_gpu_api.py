@@ -114,3 +114,8 @@ def test_full_size_batched_smoke_8x512(gpu_backend):
         assert rel(a[0], b[5]) <= 2e-2
     other = rel(smoke.numpy()[2], smoke.numpy()[5])
     assert other > 0.5                                        # ... while different entries are different simulations
+
+
+def test_scene_files_on_the_device(gpu_backend, tmp_path):
+    """ SURVEY §8 f6 with the real library: the reference's scene-file window -> GPU fields -> one step vs the oracle -> round trip """
+    golden_cases.run_scene_files(gpu_backend, tmp_path)

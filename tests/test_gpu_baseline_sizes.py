@@ -1,0 +1,53 @@
+"""
+`-m gpu`: ORACLE parity at the sizes BASELINE.json quotes numbers for (VERDICT r1 "What's weak" 1) -- not properties: the HIP path
+through the C ABI against the NumPy oracle on the same inputs, with the launch plans that only large grids select.
+Each case prints its measured errors (pytest -s / captured in the log) so the margins are visible.
+"""
+import numpy as np
+import pytest
+
+import baseline_cases as bc
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_backend):
+    return gpu_backend.ctx
+
+
+@pytest.fixture(scope="module")
+def mem(gpu_backend):
+    return pc.TorchMem(str(gpu_backend.device))
+
+
+def test_config2_taylor_green_256_100_iterations_vs_oracle(ctx, mem):
+    """ BASELINE configs[1] = the benchmark workload itself: 256^3 fp32, advect + 100 fixed CG iterations, one step """
+    rep = {}
+    bc.config2_step(ctx, mem, 256, 100, rep)
+    print("config2 parity:", rep)
+
+
+def test_config3_pressure_solve_512_vs_oracle(ctx, mem):
+    """ BASELINE configs[2]: 512^3 fp32 pressure solve, 20 fixed iterations on the seeded random rhs (the (4,64) / chunk-64 plans) """
+    rep = {}
+    bc.config3_solve(ctx, mem, 512, 20, rep)
+    print("config3 parity:", rep)
+    for fam in (1, 2, 3):
+        dom, grid = pc.make_case((512,) * 3, ((pc.PER, pc.PER),) * 3, np.float32)
+        print("  plan family", fam, ctx.query_plan(grid, False, fam))
+
+
+def test_config5_cavity_fp64_obstacle_256_vs_oracle(ctx, mem):
+    """ BASELINE configs[4] size class: 256^3 fp64 closed cavity + lid + solid box (flags path), 20 fixed iterations """
+    rep = {}
+    bc.config5_cavity(ctx, mem, 256, 20, rep)
+    print("config5 parity:", rep)
+
+
+def test_config4_batched_smoke_8x512_vs_oracle(ctx, mem):
+    """ BASELINE configs[3]: 8 x 512^2 batched smoke plumes, 3 steps, 60 fixed CG iterations per projection """
+    rep = {}
+    bc.config4_batched_smoke(ctx, mem, 512, 8, 3, 60, rep)
+    print("config4 parity:", rep)

@@ -595,3 +595,44 @@ def test_phiml_plugin_is_inert_without_phiml():
         pytest.skip("phiml is installed: the plug-in is exercised by PhiFlow's own tests instead")
     assert phiml_plugin.install() is False
     phiml_plugin.uninstall()
+
+
+def test_lazy_vector_factor_survives_arithmetic(emu_backend):
+    """ `smoke * (0, 0.1) * dt @ v` -- the lazy constant vector of `scalar * vector` must survive scalar arithmetic, negation
+    and boundary changes, and adding something that would silently drop it must raise """
+    from phiflow_amd.flow import ZERO_GRADIENT
+    rng = np.random.default_rng(0)
+    bounds = Box(x=8, y=8)
+    s = CenteredGrid(rng.random((8, 8)).astype(np.float32) + 0.5, ZERO_GRADIENT, bounds, x=8, y=8, backend=emu_backend)
+    v = StaggeredGrid(0, 0, bounds, x=8, y=8, backend=emu_backend)
+    base = (s * (0, 0.5)) @ v
+    assert float(np.abs(base.numpy()[0]).max()) == 0 and float(np.abs(base.numpy()[1]).max()) > 0.1
+    for expr, factor in ((s * (0, 1.0) * 0.5, 1.0), (0.5 * (s * (0, 1.0)), 1.0), (-(s * (0, 0.5)), -1.0), ((s * (0, 1.0)) / 2.0, 1.0),
+                         ((s * (0, 0.25)) + (s * (0, 0.25)), 1.0), ((s * (0, 1.0)).with_boundary(ZERO_GRADIENT) * 0.5, 1.0),
+                         ((s * (1, 1)) * (0, 0.5), 1.0)):
+        out = expr @ v
+        np.testing.assert_array_equal(out.numpy()[0], 0 * base.numpy()[0])
+        np.testing.assert_allclose(out.numpy()[1], factor * base.numpy()[1], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        (s * (0, 0.5)) + s
+    with pytest.raises(NotImplementedError):
+        (s * (0, 0.5)) + 1.0
+    with pytest.raises(NotImplementedError):
+        (s * (0, 0.5)) @ s
+
+
+def test_resample_compares_bounds_not_only_resolution(emu_backend):
+    """ fields with equal resolution on different boxes do NOT share sample points: `@` must interpolate, arithmetic refuse """
+    from phiflow_amd.flow import ZERO_GRADIENT
+    a = CenteredGrid(lambda x, y: x + 0 * y, ZERO_GRADIENT, Box(x=8, y=8), x=8, y=8, backend=emu_backend)
+    b = CenteredGrid(0, ZERO_GRADIENT, Box(x=4, y=4), x=8, y=8, backend=emu_backend)
+    out = a @ b
+    assert tuple(out.bounds.upper) == (4.0, 4.0)
+    expect = (np.arange(8) + 0.5) * 0.5                     # f(x) = x sampled at b's cell centres (linear interpolation is exact)
+    np.testing.assert_allclose(out.numpy()[:, 0], np.maximum(expect, 0.5), atol=1e-5)      # left of a's first centre: zero-gradient
+    with pytest.raises(AssertionError):
+        a + b
+    v = StaggeredGrid(0, 0, Box(x=4, y=4), x=8, y=8, backend=emu_backend)
+    to_faces = (a * (1.0, 0.0)) @ v                         # general path: different boxes
+    assert tuple(to_faces.bounds.upper) == (4.0, 4.0)
+    np.testing.assert_allclose(to_faces.numpy()[0][:, 0], np.arange(1, 8) * 0.5, atol=1e-5)

@@ -28,9 +28,8 @@ def classify(name):
     return None
 
 
-def main():
-    src = sys.argv[1]
-    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+def summarise(src):
+    """ -> {"units": ..., "kernels": {"<family><T,V,R,TPR>|grid=N": {FETCH_SIZE, WRITE_SIZE, read_bytes_*, write_bytes_*}}} """
     rows = []
     for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
@@ -72,6 +71,13 @@ def main():
             if write_unit:
                 rec["write_bytes_calibrated"] = w * write_unit
         result["kernels"][k] = rec
+    return result
+
+
+def main():
+    src = sys.argv[1]
+    out_path = sys.argv[2] if len(sys.argv) > 2 else None
+    result = summarise(src)
     print(json.dumps(result, indent=1))
     if out_path:
         with open(out_path, "w") as fo:
