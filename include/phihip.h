@@ -302,6 +302,11 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
  * iteration moves 7 instead of 8 words per cell. Same iterates r, d, alpha, beta; x equal up to rounding. enable = 0 updates x in
  * every iteration (A/B measurements, tests). Default: enabled. */
 int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
+/* Self-advection of the staggered velocity (field == velocity pointers) runs as ONE launch whose taps come from LDS tiles staged with a
+ * halo of `halo` samples (1 or 2: lookups displaced by less than that many cells never leave LDS; larger displacements fall back to a
+ * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
+ * measurements, tests). Default: 1. */
+int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
 /* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
  * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);

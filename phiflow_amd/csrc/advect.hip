@@ -163,6 +163,9 @@ static int check_advect_sizes(const GridView& v) {
 int run_advect_staggered(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3], void* const out[3],
                          double dt, hipStream_t s) {
     PHIHIP_TRY(check_advect_sizes(v));
+    bool self = ctx->adv_halo > 0;
+    for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
+    if (self) return run_advect_self_tiled(ctx, v, vel, out, dt, ctx->adv_halo, s);   // one launch, taps from LDS (advect_tile.hip)
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     dispatch_advect_staggered<0>(v, g, f, vel, nullptr, out, dt, 0.0, s);

@@ -774,6 +774,13 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
     return PHIHIP_OK;
 }
 
+int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    PHIHIP_REQUIRE(halo >= 0 && halo <= 2, "advect halo must be 0 (gather kernels), 1 or 2");
+    ctx->adv_halo = halo;
+    return PHIHIP_OK;
+}
+
 int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->defer_x = enable != 0;

@@ -97,6 +97,7 @@ struct phihip_ctx {
     phihip::Tuning tuning[4];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE, 3 = UPDATE_R
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adj_q, ws_adj_l;
+    int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule
     bool small_cg = true;         // grids that fit one CU's LDS are solved by the single-kernel CG (cg_small.hip)
@@ -148,6 +149,7 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- phases implemented in the .hip files ---------------------------------------------------------------------------
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
+int run_advect_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double dt, int halo, hipStream_t);
 int run_grid_sample(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,
                     const void* const coords[3], long long npts, void* out, void* out_min, void* out_max, hipStream_t);
 int run_grid_sample_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,

@@ -18,7 +18,7 @@ mkdir -p "$build"
 CXX="g++ -O1 -g -std=c++17 -fPIC -I$here/include -w $extra"
 pids=()
 $CXX -c "$here/hipemu.cpp" -o "$build/hipemu.o" & pids+=($!)
-for f in capi cg project advect adjoint cg_small; do
+for f in capi cg project advect advect_tile adjoint cg_small; do
   $CXX -x c++ -c "$src/$f.hip" -o "$build/$f.o" & pids+=($!)
 done
 for t in 0 1; do for d in 0 1; do

@@ -150,16 +150,39 @@ def check_grad_subtract(ctx, mem, dom, grid, dtype, rng):
 
 
 def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
+    """ self-advection through the LDS-tiled kernel (halo 1 and 2) and the gather kernels (halo 0) -- each against the oracle and
+    against each other (same arithmetic: at most rounding apart) --, then a field that is NOT the velocity (always the gather kernels) """
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng, scale)
     dv = [mem.to_dev(a) for a in v]
-    dout = [mem.empty(a.shape, dtype) for a in v]
-    ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
-    mem.sync()
     ref = O.semi_lagrangian_staggered(v, v, dt, dom)
+    results = []
+    try:
+        for halo in (1, 2, 0):
+            ctx.set_advect_halo(halo)
+            dout = [mem.empty(a.shape, dtype) for a in v]
+            ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
+            mem.sync()
+            out = [mem.to_host(a) for a in dout]
+            for d in range(dom.rank):
+                err = rel_err(out[d], ref[d])
+                assert err <= tol(dtype)['advect'], f"advect[{d}] halo {halo}: rel err {err}"
+            results.append(out)
+    finally:
+        ctx.set_advect_halo(1)
+    eps = 4 * np.finfo(dtype).eps
+    for out in results[:2]:
+        for d in range(dom.rank):
+            assert np.abs(out[d] - results[2][d]).max() <= eps * max(np.abs(ref[d]).max(), 1e-30) * 4, f"tiled vs gather kernels differ in component {d}"
+    f = random_velocity(dom, B, dtype, rng, scale)
+    df = [mem.to_dev(a) for a in f]
+    dout = [mem.empty(a.shape, dtype) for a in v]
+    ctx.advect_staggered(grid, [mem.ptr(a) for a in df], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
+    mem.sync()
+    ref = O.semi_lagrangian_staggered(f, v, dt, dom)
     for d in range(dom.rank):
         err = rel_err(mem.to_host(dout[d]), ref[d])
-        assert err <= tol(dtype)['advect'], f"advect[{d}] rel err {err}"
+        assert err <= tol(dtype)['advect'], f"advect field != velocity [{d}] rel err {err}"
 
 
 def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=0.9):

@@ -426,3 +426,15 @@ def test_unaligned_buffers_take_the_scalar_path(emu_ctx):
     finally:
         emu_ctx.set_small_grid_solver(True)
     assert pc.rel_l2(xs[1], xs[0]) <= 1e-5
+
+
+@pytest.mark.parametrize("res,bc", [((20, 24, 72), ((OPN, CLO), (CLO, CLO), (PER, PER))), ((19, 35, 70), ((PER, PER), (OPN, OPN), (CLO, OPN))),
+                                    ((40, 136), ((CLO, OPN), (PER, PER)))])
+def test_tiled_advection_across_tiles_and_chunks(emu_ctx, res, bc):
+    """ advect_tile.hip: several tiles along both fast axes and several chunks of planes (ring refill, chunk prologue), every boundary
+    kind on the tile edges, displacements below and beyond the halo (LDS taps / global fallback) """
+    rng = np.random.default_rng(31)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        for dt in (0.45, 1.4, 3.3):
+            pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=dt)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--lib", default="")
     ap.add_argument("--field", default="random", help="random | tg (the smooth Taylor-Green velocity of the benchmark, CFL 0.5)")
+    ap.add_argument("--cfl", type=float, default=0.5, help="dt = cfl * dx (random field: |u| ~ N(0,1))")
     ap.add_argument("--bc", type=int, default=0, help="boundary code of every side: 0 periodic, 1 closed, 2 open")
     args = ap.parse_args()
     n = args.size
@@ -46,7 +47,7 @@ def main():
     s = torch.randn(1, n, n, n, generator=g, dtype=tdt).to(dev)
     so = torch.empty_like(s)
     P = lambda ts: [t.data_ptr() for t in ts]
-    dt = 0.5 * L / n
+    dt = args.cfl * L / n
 
     def timed(fn):
         fn(); torch.cuda.synchronize()
@@ -57,10 +58,16 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / args.reps
 
-    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "field": args.field,
+    res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "field": args.field, "cfl": args.cfl}
+    if hasattr(ctx.lib.dll, "phihip_set_advect_halo") and not args.lib:
+        for halo in (0, 1, 2):      # 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles (advect_tile.hip)
+            ctx.set_advect_halo(halo)
+            res[f"ms_semi_lagrangian_staggered_halo{halo}"] = round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5)
+        ctx.set_advect_halo(1)
+    res.update({
            "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
            "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
-           "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((args.bc and 2, args.bc and 2),) * 3, None, P(v), so.data_ptr(), dt)), 5)}
+           "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((args.bc and 2, args.bc and 2),) * 3, None, P(v), so.data_ptr(), dt)), 5)})
     res["GBs_semi_lagrangian_staggered"] = round(6 * n ** 3 * (8 if args.dtype == "f64" else 4) / res["ms_semi_lagrangian_staggered"] / 1e6, 1)
     print(json.dumps(res), flush=True)
 
