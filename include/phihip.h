@@ -307,6 +307,9 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
  * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
  * measurements, tests). Default: 1. */
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
+/* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
+ * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
+int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
 /* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
  * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);

@@ -8,9 +8,13 @@
 //     (the gather kernels of advect.hip issue 17 scattered loads per SAMPLE: they are bound by the address unit, not by HBM);
 //   * the 4-point means of the other components at a face (phi/field/_resample.py:279-287,341-364) and the 2^D taps of the
 //     multilinear lookup (phi/field/_resample.py:257-259) are LDS reads at uniform / compile-time offsets from one address;
-//   * a lookup that leaves the staged window (|displacement| >= H cells, NaN) takes the global gather of advect_common.hpp behind a
-//     wave-uniform branch -- same arithmetic, so the result does not depend on the path;
-//   * planes p+H+1 are requested before plane p is computed and written to the ring after it: one barrier per plane.
+//   * a lookup that leaves the staged window (|displacement| >= H cells) cannot be served from LDS: the workgroup raises a flag and
+//     `advect_self_fixup_kernel` (same grid, launched right behind; workgroups whose flag is clear exit at once) recomputes the samples
+//     of exactly those workgroups with the boundary-resolved global gather of advect_common.hpp -- same arithmetic, so the result does
+//     not depend on the path, and the LDS kernel carries no gather code (it was two thirds of its instructions and most of its
+//     scalar-register pressure);
+//   * plane p+H+2 is requested before plane p is computed and enters the ring after plane p+1 (HBM latency exceeds one plane of
+//     arithmetic; two register sets alternate); one barrier per plane.
 // Algorithmic traffic 2 D words per cell; the kernel reads each velocity sample once per workgroup (+ halo) and writes each once.
 #include "advect_common.hpp"
 
@@ -75,15 +79,32 @@ __device__ __forceinline__ int pad_index(int i, int n, int code_lo, int code_hi)
     return i;
 }
 
-__device__ __forceinline__ int clamp_int(int x, int lo, int hi) { return min(max(x, lo), hi); }
+// keeps the instruction scheduler from hoisting every sample's LDS reads to the top of the plane (that costs > 200 registers)
+__device__ __forceinline__ void sched_fence() {
+#ifdef __HIP_DEVICE_COMPILE__
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// min(max(x, lo), hi) as ONE v_med3 (NaN -> lo, which the callers treat as "outside")
+__device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return x >= lo ? (x <= hi ? x : hi) : lo;
+#endif
+}
+__device__ __forceinline__ double clamp_real(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
 
 template <typename T, int DIM, int H, int T1>
-__global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
-                                                                  T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0) {
+__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
+                                                                  T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
+                                                                  int* __restrict__ flags) {
     using C = AdvTile<T, DIM, H, T1>;
     constexpr int A0 = 3 - DIM;
     constexpr int T2 = C::T2, TY = C::TY, S = C::S, P1 = C::P1, P2 = C::P2, PLANE = C::PLANE, NC = C::NC, NP = C::NP, KP = C::KP;
     __shared__ T lds[NC * NP * PLANE];
+    __shared__ int slow_sh;
 
     const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2;
     const int b = blockIdx.y;
@@ -96,6 +117,20 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
     const int pb = DIM == 3 ? c0 * chunk : 0;
     const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
     T* const outp[3] = {o0, o1, o2};
+    if (tid == 0) slow_sh = 0;
+    bool slow_any = false;
+    // per-thread output bookkeeping: element offset of position s = 0 in plane 0 per component, plane strides, and one bit per
+    // (position, component): the sample exists in that component's array
+    long long obase[3] = {0, 0, 0}, pstride[3] = {0, 0, 0};
+    unsigned vbits = 0;
+#pragma unroll
+    for (int c = A0; c < 3; ++c) {
+        obase[c] = (long long)b * g.ccells[c] + (long long)(lo1 + ty) * g.cn[c][2] + lo2 + tx;
+        pstride[c] = (long long)g.cn[c][1] * g.cn[c][2];
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+            if (lo1 + ty + k * TY < g.cn[c][1] && lo2 + tx < g.cn[c][2]) vbits |= 1u << (k * 3 + c);
+    }
 
     // Does this workgroup's window reach beyond a CLOSED side (constant padding)? Uniform, so interior tiles (and periodic / open
     // domains altogether) run the fill without a single select.
@@ -109,9 +144,8 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
 
     // ---- per-thread fill descriptors (plane-invariant) -------------------------------------------------------------------------
     // element kp of component c: row ty + kp TY, column tx of the window. eoff = in-plane element offset after wrap / clamp;
-    // rcode / ccode: 0 = stored sample, 1 / 2 = the lower / upper CONSTANT side of a1 resp. a2 supplies the value
+    // ccode: 0 = stored sample, 1 / 2 = the lower / upper CONSTANT side of a2 supplies the value (rows: recomputed in the cold path)
     int eoff[3][KP];
-    int rcode[3][KP];
     int ccode[3];
     const bool last_ok = ty + (KP - 1) * TY < P1;        // only the last pass can run past the window's rows
 #pragma unroll
@@ -121,7 +155,6 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
-            rcode[c][kp] = j < 0 ? -j : 0;
             eoff[c][kp] = (j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k);
         }
     }
@@ -170,9 +203,10 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
 #pragma unroll
                 for (int kp = 0; kp < KP; ++kp) {
                     T v = R[c][kp];
-                    const T rv = rcode[c][kp] == 1 ? k10 : k11;
+                    const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
+                    const T rv = j == -1 ? k10 : k11;
                     v = k < 0 ? pv : v;
-                    v = rcode[c][kp] ? rv : v;
+                    v = j < 0 ? rv : v;
                     v = ccode[c] ? cv : v;
                     R[c][kp] = v;
                 }
@@ -202,50 +236,32 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
         return m < 0 ? m + NP : m;
     };
 
-    // ---- prologue: planes pb-H .. pb+H ------------------------------------------------------------------------------------------
-    T R[3][KP];
-    T tailv = T(0);
-    if (DIM == 3) {
-        for (int i0 = pb - H; i0 <= pb + H; ++i0) {
-            load_plane(i0, R, tailv);
-            store_plane(slot_of(i0), R, tailv);
-        }
-    } else {
-        load_plane(0, R, tailv);
-        store_plane(0, R, tailv);
-    }
-    __syncthreads();
 
-    int bc[3][2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { bc[a][0] = g.bc[a][0]; bc[a][1] = g.bc[a][1]; }
-
-    for (int p = pb; p < pe; ++p) {
-        const bool more = DIM == 3 && p + 1 < pe;
-        if (more) load_plane(p + H + 1, R, tailv);
-        const int sl_m = slot_of(p - 1), sl_0 = slot_of(p), sl_p = slot_of(p + 1);
-
+    // one plane of samples
+    // one plane of samples. Per sample: displacement from the own component and the 4-point sums of the others (x 1/4 folded into the
+    // scale), coordinate = index - displacement rounded like the reference rounds it (absolute index space), taps relative to the
+    // sample's own LDS position, blend as nested lerps along a2, a1, a0.
+    auto compute_plane = [&](int p) {
+        const int so_m = slot_of(p - 1) * PLANE, so_0 = slot_of(p) * PLANE, so_p = slot_of(p + 1) * PLANE;   // uniform element offsets
+        const T idxf0 = (T)p;
 #pragma unroll 1
-        for (int s = 0; s < S; ++s) {   // (not unrolled: the components of one position already give D independent samples)
-            const int j1 = lo1 + ty + s * TY, j2 = lo2 + tx;
+        for (int s = 0; s < S; ++s) {
             const int center = (ty + s * TY + H) * P2 + tx + H;
+            const T idxf[3] = {idxf0, (T)(lo1 + ty + s * TY), (T)(lo2 + tx)};
 #pragma unroll
             for (int ca = A0; ca < 3; ++ca) {
-                const bool valid = p < g.cn[ca][0] && j1 < g.cn[ca][1] && j2 < g.cn[ca][2];   // every LDS read below is in bounds regardless
-                const int idx[3] = {p, j1, j2};
-                // LDS element of component x at (plane offset d0 in {-1,0,1}, row offset d1, column offset d2) from this sample
-                auto at = [&](int x, int d0, int d1, int d2) -> T {
-                    const int sl = d0 < 0 ? sl_m : (d0 > 0 ? sl_p : sl_0);
-                    return lds[((x - A0) * NP + sl) * PLANE + center + d1 * P2 + d2];
+                // uniform LDS offset of component x at (plane offset d0 in {-1,0,1}, row offset d1, column offset d2) from the sample
+                auto uoff = [&](int x, int d0, int d1, int d2) -> int {
+                    return (x - A0) * NP * PLANE + (d0 < 0 ? so_m : (d0 > 0 ? so_p : so_0)) + d1 * P2 + d2;
                 };
-                T u[3] = {T(0), T(0), T(0)};
-                u[ca] = at(ca, 0, 0, 0);
+                T coord[3] = {T(0), T(0), T(0)};
+                coord[ca] = fma(lds[center + uoff(ca, 0, 0, 0)], -g.shift[ca], idxf[ca]);
 #pragma unroll
                 for (int cb = A0; cb < 3; ++cb) {
                     if (cb == ca) continue;
                     // component cb at this ca-face: cells (m-1, m) along ca, faces (s, s+1) along cb, in cb's stored indices:
                     // offsets (off[ca] - 1 + ia) along ca and (-off[cb] + ib) along cb (advect_common.hpp face_velocity)
-                    T v[2][2];
+                    T sum = T(0);
 #pragma unroll
                     for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -253,75 +269,124 @@ __global__ __launch_bounds__(kBlock) void advect_self_tile_kernel(TileGrid<T> g,
                             int d[3] = {0, 0, 0};
                             d[ca] = g.off[ca] - 1 + ia;
                             d[cb] = -g.off[cb] + ib;
-                            v[ia][ib] = at(cb, d[0], d[1], d[2]);
+                            sum += lds[center + uoff(cb, d[0], d[1], d[2])];
                         }
-                    if (ca < cb) {
-                        const T a0 = v[1][0] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[0][1] * T(0.5);
-                        u[cb] = a1 * T(0.5) + a0 * T(0.5);
-                    } else {
-                        const T a0 = v[0][1] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[1][0] * T(0.5);
-                        u[cb] = a1 * T(0.5) + a0 * T(0.5);
-                    }
+                    coord[cb] = fma(sum, T(-0.25) * g.shift[cb], idxf[cb]);
                 }
-                // back-trace in the index space of component ca's own array
-                T coord[3] = {T(0), T(0), T(0)}, fl[3] = {T(0), T(0), T(0)}, fr[3] = {T(0), T(0), T(0)};
+                // taps relative to the sample: rel = floor(coord) - index in [-H, H-1] or the lookup leaves the window
+                T fr[3] = {T(0), T(0), T(0)};
+                int di[3] = {0, 0, 0};
+                bool slow = false;
 #pragma unroll
                 for (int a = A0; a < 3; ++a) {
-                    coord[a] = (T)idx[a] - u[a] * g.shift[a];
-                    fl[a] = floor(coord[a]);
-                    fr[a] = coord[a] - fl[a];
+                    const T fl = floor(coord[a]);
+                    fr[a] = coord[a] - fl;
+                    const T rel = fl - idxf[a];
+                    const T relc = clamp_real(rel, T(-H), T(H - 1));
+                    slow = slow || !(rel == relc);                 // also true for NaN
+                    di[a] = (int)relc;
                 }
-                // the 2^D taps i_lo, i_lo + 1 must lie in the staged window (NaN compares false -> global path)
-                bool inwin = fl[1] >= (T)(lo1 - H) && fl[1] <= (T)(lo1 + T1 + H - 2) && fl[2] >= (T)(lo2 - H) && fl[2] <= (T)(lo2 + T2 + H - 2);
-                if (DIM == 3) inwin = inwin && fl[0] >= (T)(p - H) && fl[0] <= (T)(p + H - 1);
-                // LDS lookup for every lane (addresses clamped into the window; lanes outside it are overwritten below)
-                const int i1 = clamp_int((int)fl[1] - (lo1 - H), 0, P1 - 2), i2 = clamp_int((int)fl[2] - (lo2 - H), 0, P2 - 2);
-                int base0 = (ca - A0) * NP * PLANE + i1 * P2 + i2, base1 = base0;
+                const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0];
+                slow_any = slow_any || (valid && slow);          // -> the whole workgroup is redone by advect_self_fixup_kernel
+                int base0 = (ca - A0) * NP * PLANE + center + di[1] * P2 + di[2], base1 = base0;
                 if (DIM == 3) {
-                    const int dz = clamp_int((int)fl[0] - p, -H, H - 1);
-                    int s0, s1;
-                    if ((NP & (NP - 1)) == 0) { s0 = (p + dz) & (NP - 1); s1 = (p + dz + 1) & (NP - 1); }
-                    else {
-                        s0 = sl_0 + dz; s0 += s0 < 0 ? NP : 0; s0 -= s0 >= NP ? NP : 0;
-                        s1 = s0 + 1; s1 -= s1 >= NP ? NP : 0;
+                    if (H == 1) {                                  // lower tap plane p-1 or p, upper p or p+1
+                        base1 += di[0] < 0 ? so_0 : so_p;
+                        base0 += di[0] < 0 ? so_m : so_0;
+                    } else {
+                        int s0 = slot_of(p) + di[0];
+                        s0 += s0 < 0 ? NP : 0; s0 -= s0 >= NP ? NP : 0;
+                        int s1 = s0 + 1; s1 -= s1 >= NP ? NP : 0;
+                        base1 += s1 * PLANE;
+                        base0 += s0 * PLANE;
                     }
-                    base1 = base0 + s1 * PLANE;
-                    base0 += s0 * PLANE;
                 }
-                T val = T(0);
-                // same corner order and weight products as gather_multilinear (a0 = lowest bit)
+                T y[2];
 #pragma unroll
-                for (int corner = 0; corner < (1 << DIM); ++corner) {
-                    const int b0 = DIM == 3 ? (corner & 1) : 0;
-                    const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
-                    const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
-                    T w = T(1);
-                    if (DIM == 3) w *= b0 ? fr[0] : (T(1) - fr[0]);
-                    w *= b1 ? fr[1] : (T(1) - fr[1]);
-                    w *= b2 ? fr[2] : (T(1) - fr[2]);
-                    val += lds[(b0 ? base1 : base0) + b1 * P2 + b2] * w;
+                for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+                    const int bk = k ? base1 : base0;
+                    const T a00 = lds[bk], a01 = lds[bk + 1], a10 = lds[bk + P2], a11 = lds[bk + P2 + 1];
+                    const T x0 = fma(fr[2], a01 - a00, a00), x1 = fma(fr[2], a11 - a10, a10);
+                    y[k] = fma(fr[1], x1 - x0, x0);
                 }
-                const bool slow = valid && !inwin;
-                if (wave_any(slow)) {
-                    if (slow) {
-                        const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
-                        const T cv[3][2] = {{g.bcv[0][0][ca], g.bcv[0][1][ca]}, {g.bcv[1][0][ca], g.bcv[1][1][ca]}, {g.bcv[2][0][ca], g.bcv[2][1][ca]}};
-                        AxisPair<T> ax[3];
-                        T fr2[3];
-                        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr2);
-                        val = gather_multilinear<T, DIM>(vel.p[ca] + (long long)b * g.ccells[ca], ax, fr2);
-                    }
-                }
-                if (valid) outp[ca][(long long)b * g.ccells[ca] + ((long long)p * g.cn[ca][1] + j1) * g.cn[ca][2] + j2] = val;
+                const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
+                if (valid) outp[ca][obase[ca] + (long long)p * pstride[ca] + s * TY * g.cn[ca][2]] = val;
+                sched_fence();     // one sample's LDS reads in flight at a time: 4 waves per SIMD hide the latency, registers stay <= 128
             }
         }
-        if (more) store_plane(slot_of(p + H + 1), R, tailv);
+    };
+
+    // Pipeline, two planes per trip so that the two register sets keep static names. In half-step p: plane p+H+2 is requested, plane p
+    // is computed (once the ring holds p-H .. p+H), plane p+H+1 -- requested one half-step earlier -- enters the ring; one barrier.
+    // The trips before pb only fill the ring (their loads are back to back, so the warm-up costs about one memory round trip).
+    T RA[3][KP], RB[3][KP];
+    T tailA = T(0), tailB = T(0);
+    const int k_lo = DIM == 3 ? pb - H : 0, k_hi = DIM == 3 ? pe - 1 + H : 0;     // planes this workgroup stages
+    auto half_step = [&](int p, T (&Rld)[3][KP], T& tail_ld, const T (&Rst)[3][KP], const T& tail_st) {
+        const int kl = p + H + 2, ks = p + H + 1;
+        if (kl >= k_lo && kl <= k_hi) load_plane(kl, Rld, tail_ld);
+        if (p >= pb && p < pe) compute_plane(p);
+        if (ks >= k_lo && ks <= k_hi) store_plane(slot_of(ks), Rst, tail_st);
         __syncthreads();
+    };
+    const int p_first = k_lo - H - 2;     // the half-step that requests the first staged plane
+    for (int p = p_first; p < pe; p += 2) {
+        half_step(p, RA, tailA, RB, tailB);
+        half_step(p + 1, RB, tailB, RA, tailA);
     }
+    if (slow_any) slow_sh = 1;
+    __syncthreads();
+    if (tid == 0) flags[(long long)b * nblk + blockIdx.x] = slow_sh;
+}
+
+// Redo of the workgroups that met lookups outside their LDS window (flag set by advect_self_tile_kernel): every sample of the same
+// (tile, chunk) with the gather code of the per-component kernels (advect.hip), reading the untouched input velocity.
+template <typename T, int DIM, int T1>
+__global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
+                                                                   T dt, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
+                                                                   const int* __restrict__ flags) {
+    using C = AdvTile<T, DIM, 1, T1>;
+    constexpr int A0 = 3 - DIM;
+    const int b = blockIdx.y;
+    if (flags[(long long)b * nblk + blockIdx.x] == 0) return;
+    const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int t2 = bid % tiles2;
+    const int t1 = (bid / tiles2) % tiles1;
+    const int c0 = bid / (tiles2 * tiles1);
+    const int pb = DIM == 3 ? c0 * chunk : 0;
+    const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
+    T* const outp[3] = {o0, o1, o2};
+    for (int p = pb; p < pe; ++p)
+        for (int s = 0; s < C::S; ++s) {
+            const int j1 = t1 * T1 + ty + s * C::TY, j2 = t2 * C::T2 + tx;
+#pragma unroll
+            for (int ca = A0; ca < 3; ++ca) {
+                if (p >= g.cn[ca][0] || j1 >= g.cn[ca][1] || j2 >= g.cn[ca][2]) continue;
+                const int idx[3] = {p, j1, j2};
+                const int f = (p * g.cn[ca][1] + j1) * g.cn[ca][2] + j2;
+                T u[3];
+                if (ca == 0) face_velocity<T, DIM, 0>(g, vel, b, idx, f, u);
+                else if (ca == 1) face_velocity<T, DIM, 1>(g, vel, b, idx, f, u);
+                else face_velocity<T, DIM, 2>(g, vel, b, idx, f, u);
+                T coord[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+                const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
+                int bc[3][2];
+                T cv[3][2];
+                comp_rule<T>(g, ca, bc, cv);
+                AxisPair<T> ax[3];
+                T fr[3];
+                lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+                outp[ca][(long long)b * g.ccells[ca] + f] = gather_multilinear<T, DIM>(vel.p[ca] + (long long)b * g.ccells[ca], ax, fr);
+            }
+        }
 }
 
 template <typename T, int DIM, int H, int T1>
-static int launch_tile(const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
     const TileGrid<T> g = make_tilegrid<T>(vg, dt);
     using C = AdvTile<T, DIM, H, T1>;
     int nmax[3] = {1, 1, 1};
@@ -339,9 +404,14 @@ static int launch_tile(const GridView& v, const VelGrid& vg, const void* const v
         chunks0 = ceil_div(nmax[0], chunk);
     }
     const int nblk = tiles1 * tiles2 * chunks0;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, (size_t)nblk * v.batch * sizeof(int)));
+    int* flags = (int*)ctx->ws_adv_flags.ptr;
+    ctx->adv_last_nblk = nblk * v.batch;
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2],
-                       chunk, tiles1, tiles2, nblk, nmax[0]);
+                       chunk, tiles1, tiles2, nblk, nmax[0], flags);
+    hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
+                       (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;
 }
 
@@ -350,12 +420,14 @@ int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const 
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     const bool f64 = v.dtype == PHIHIP_F64;
-    if (v.rank == 3) {
-        if (halo >= 2) { if (f64) launch_tile<double, 3, 2, 8>(v, g, vel, out, dt, s); else launch_tile<float, 3, 2, 8>(v, g, vel, out, dt, s); }
-        else { if (f64) launch_tile<double, 3, 1, 16>(v, g, vel, out, dt, s); else launch_tile<float, 3, 1, 16>(v, g, vel, out, dt, s); }
+    if (v.rank == 3 && halo == 3) {   // experiment: halo 1 with the 16-row tile (2 workgroups per CU)
+        if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 16>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 16>(ctx, v, g, vel, out, dt, s)));
+    } else if (v.rank == 3) {
+        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); }
+        else { if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 8>(ctx, v, g, vel, out, dt, s))); }
     } else {
-        if (halo >= 2) { if (f64) launch_tile<double, 2, 2, 8>(v, g, vel, out, dt, s); else launch_tile<float, 2, 2, 8>(v, g, vel, out, dt, s); }
-        else { if (f64) launch_tile<double, 2, 1, 8>(v, g, vel, out, dt, s); else launch_tile<float, 2, 1, 8>(v, g, vel, out, dt, s); }
+        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); }
+        else { if (f64) PHIHIP_TRY((launch_tile<double, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); }
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

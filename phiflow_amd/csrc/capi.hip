@@ -194,7 +194,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adj_q, &ctx->ws_adj_l};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -212,7 +212,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes;
     return PHIHIP_OK;
 }
 
@@ -776,8 +776,21 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
 
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
-    PHIHIP_REQUIRE(halo >= 0 && halo <= 2, "advect halo must be 0 (gather kernels), 1 or 2");
+    PHIHIP_REQUIRE(halo >= 0 && halo <= 3, "advect halo must be 0 (gather kernels), 1 or 2");
     ctx->adv_halo = halo;
+    return PHIHIP_OK;
+}
+
+int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "ctx / out is NULL");
+    out[0] = out[1] = 0;
+    if (ctx->adv_last_nblk <= 0 || !ctx->ws_adv_flags.ptr) return PHIHIP_OK;
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<int> host((size_t)ctx->adv_last_nblk);
+    PHIHIP_CHECK_HIP(hipMemcpyAsync(host.data(), ctx->ws_adv_flags.ptr, host.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PHIHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int f : host) out[0] += f != 0;
+    out[1] = ctx->adv_last_nblk;
     return PHIHIP_OK;
 }
 

@@ -60,7 +60,7 @@ def main():
 
     res = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "field": args.field, "cfl": args.cfl}
     if hasattr(ctx.lib.dll, "phihip_set_advect_halo") and not args.lib:
-        for halo in (0, 1, 2):      # 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles (advect_tile.hip)
+        for halo in (0, 1, 2, 3):      # 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles (advect_tile.hip)
             ctx.set_advect_halo(halo)
             res[f"ms_semi_lagrangian_staggered_halo{halo}"] = round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5)
         ctx.set_advect_halo(1)
