@@ -307,6 +307,8 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
  * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
  * measurements, tests). Default: 1. */
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
+/* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
+int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
  * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk",
 )
 
 
@@ -215,6 +215,7 @@ class Library:
         if hasattr(d, "phihip_set_deferred_x_update"):
             d.phihip_set_deferred_x_update.argtypes = [c_void_p, c_int]
         d.phihip_set_advect_halo.argtypes = [c_void_p, c_int]
+        d.phihip_set_advect_chunk.argtypes = [c_void_p, c_int]
         d.phihip_advect_fallback_stats.argtypes = [c_void_p, POINTER(c_int32 * 2), c_void_p]
         d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
         for name in EXPORTED_SYMBOLS:
@@ -446,6 +447,9 @@ class Context:
     def set_advect_halo(self, halo: int):
         """ 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles with that halo for self-advection (default 1) """
         self.lib.check(self.lib.dll.phihip_set_advect_halo(self.handle, int(halo)))
+
+    def set_advect_chunk(self, planes: int):
+        self.lib.check(self.lib.dll.phihip_set_advect_chunk(self.handle, int(planes)))
 
     def advect_fallback_stats(self, stream=0):
         """ (workgroups redone by the gather path, workgroups launched) of the most recent tiled self-advection; synchronises """

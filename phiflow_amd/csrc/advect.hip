@@ -165,7 +165,11 @@ int run_advect_staggered(phihip_ctx* ctx, const GridView& v, const void* const f
     PHIHIP_TRY(check_advect_sizes(v));
     bool self = ctx->adv_halo > 0;
     for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
-    if (self) return run_advect_self_tiled(ctx, v, vel, out, dt, ctx->adv_halo, s);   // one launch, taps from LDS (advect_tile.hip)
+    if (self) {   // one launch, taps from LDS (advect_tile.hip); axes with fewer than 4 samples keep the gather kernels
+        const int st = run_advect_self_tiled(ctx, v, vel, out, dt, ctx->adv_halo, s);
+        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        ctx->adv_last_nblk = 0;
+    }
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     dispatch_advect_staggered<0>(v, g, f, vel, nullptr, out, dt, 0.0, s);

@@ -16,6 +16,8 @@
 //   * plane p+H+2 is requested before plane p is computed and enters the ring after plane p+1 (HBM latency exceeds one plane of
 //     arithmetic; two register sets alternate); one barrier per plane.
 // Algorithmic traffic 2 D words per cell; the kernel reads each velocity sample once per workgroup (+ halo) and writes each once.
+#include <math.h>
+
 #include "advect_common.hpp"
 
 namespace phihip {
@@ -96,13 +98,16 @@ __device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
 }
 __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
 
-template <typename T, int DIM, int H, int T1>
+template <typename T, int DIM, int H, int T1, int OFFM>
 __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
                                                                   int* __restrict__ flags) {
     using C = AdvTile<T, DIM, H, T1>;
     constexpr int A0 = 3 - DIM;
     constexpr int T2 = C::T2, TY = C::TY, S = C::S, P1 = C::P1, P2 = C::P2, PLANE = C::PLANE, NC = C::NC, NP = C::NP, KP = C::KP;
+    // physical face number of stored index 0 per axis (1 below a CLOSED side): compile-time, so that every tap of the 4-point means is
+    // an immediate LDS offset from three per-position addresses (27 scalar offsets per plane otherwise -- they spilled)
+    constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
     __shared__ T lds[NC * NP * PLANE];
     __shared__ int slow_sh;
 
@@ -121,11 +126,12 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
     bool slow_any = false;
     // per-thread output bookkeeping: element offset of position s = 0 in plane 0 per component, plane strides, and one bit per
     // (position, component): the sample exists in that component's array
-    long long obase[3] = {0, 0, 0}, pstride[3] = {0, 0, 0};
+    unsigned obase[3] = {0, 0, 0};      // in-plane element offset (unsigned 32-bit + uniform 64-bit base: address arithmetic stays scalar)
+    long long pstride[3] = {0, 0, 0};
     unsigned vbits = 0;
 #pragma unroll
     for (int c = A0; c < 3; ++c) {
-        obase[c] = (long long)b * g.ccells[c] + (long long)(lo1 + ty) * g.cn[c][2] + lo2 + tx;
+        obase[c] = (unsigned)((lo1 + ty) * g.cn[c][2] + lo2 + tx);
         pstride[c] = (long long)g.cn[c][1] * g.cn[c][2];
 #pragma unroll
         for (int k = 0; k < S; ++k)
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
     // ---- per-thread fill descriptors (plane-invariant) -------------------------------------------------------------------------
     // element kp of component c: row ty + kp TY, column tx of the window. eoff = in-plane element offset after wrap / clamp;
     // ccode: 0 = stored sample, 1 / 2 = the lower / upper CONSTANT side of a2 supplies the value (rows: recomputed in the cold path)
-    int eoff[3][KP];
+    unsigned eoff[3][KP];
     int ccode[3];
     const bool last_ok = ty + (KP - 1) * TY < P1;        // only the last pass can run past the window's rows
 #pragma unroll
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
-            eoff[c][kp] = (j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k);
+            eoff[c][kp] = (unsigned)((j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k));
         }
     }
     // tail element (halo columns T2 .. T2+2H-1 of every row): component, row and column of THIS thread
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
     const int tail_c = A0 + tail_ci;
     const int tail_r = has_tail ? (tid % (P1 * 2 * H)) / (2 * H) : 0;
     const int tail_q = T2 + tid % (2 * H);
-    int tail_off = 0, tail_rcode = 0, tail_ccode = 0, tail_n0 = 1, tail_n1 = 1, tail_n2 = 1;
+    unsigned tail_off = 0;
+    int tail_rcode = 0, tail_ccode = 0, tail_n0 = 1, tail_n1 = 1, tail_n2 = 1;
     const T* tail_base = vel.p[2];
 #pragma unroll
     for (int c = A0; c < 3; ++c)     // (selects over the static component index: dynamic indexing of kernel arguments goes through scratch)
@@ -174,24 +181,32 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
         const int j = pad_index(lo1 - H + tail_r, tail_n1, g.bc[1][0], g.bc[1][1]);
         tail_ccode = kk < 0 ? -kk : 0;
         tail_rcode = j < 0 ? -j : 0;
-        tail_off = (j < 0 ? 0 : j * tail_n2) + (kk < 0 ? 0 : kk);
+        tail_off = (unsigned)((j < 0 ? 0 : j * tail_n2) + (kk < 0 ? 0 : kk));
     }
-    const long long tail_pstride = (long long)tail_n1 * tail_n2;
+    (void)tail_n0;
 
     // request plane i0 of every component into registers: plain loads; the constant sides are patched in afterwards (cold, uniform)
+    // plane of component c that supplies staged plane i0: wrapped (every axis has >= 4 samples here, so one +-n suffices) or clamped;
+    // beyond a CONSTANT side any valid plane is read and patched below. Branch-free scalar code: it runs every half-step.
+    auto plane_src = [&](int c, int i0) -> long long {
+        if (DIM == 2) return 0;
+        const int n = g.cn[c][0];
+        int w = i0;
+        if (g.bc[0][0] == PHIHIP_BC_PERIODIC) { w += w < 0 ? n : 0; w -= w >= n ? n : 0; }
+        w = min(max(w, 0), n - 1);
+        return (long long)w * pstride[c];
+    };
     auto load_plane = [&](int i0, T (&R)[3][KP], T& tailv) {
+        long long psrc[3] = {0, 0, 0};
 #pragma unroll
         for (int c = A0; c < 3; ++c) {
-            const int k = DIM == 3 ? pad_index(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;
-            const T* __restrict__ base = vel.p[c] + (long long)b * g.ccells[c] + (k < 0 ? 0 : (long long)k * g.cn[c][1] * g.cn[c][2]);
+            psrc[c] = plane_src(c, i0);
+            const T* __restrict__ base = vel.p[c] + (long long)b * g.ccells[c] + psrc[c];
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp)
                 if (kp < KP - 1 || last_ok) R[c][kp] = base[eoff[c][kp]];
         }
-        if (has_tail) {
-            const int k = DIM == 3 ? pad_index(i0, tail_n0, g.bc[0][0], g.bc[0][1]) : 0;
-            tailv = tail_base[(k < 0 ? 0 : (long long)k * tail_pstride) + tail_off];
-        }
+        if (has_tail) tailv = (tail_base + (tail_c == 0 ? psrc[0] : (tail_c == 1 ? psrc[1] : psrc[2])))[tail_off];
         if (has_const) {   // PhiML pads axis after axis: the LAST axis outside a constant side decides (a2 over a1 over a0)
 #pragma unroll
             for (int c = A0; c < 3; ++c) {
@@ -247,31 +262,30 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
 #pragma unroll 1
         for (int s = 0; s < S; ++s) {
             const int center = (ty + s * TY + H) * P2 + tx + H;
+            const int cen[3] = {center + so_m, center + so_0, center + so_p};     // this position in the planes p-1, p, p+1
             const T idxf[3] = {idxf0, (T)(lo1 + ty + s * TY), (T)(lo2 + tx)};
 #pragma unroll
             for (int ca = A0; ca < 3; ++ca) {
-                // uniform LDS offset of component x at (plane offset d0 in {-1,0,1}, row offset d1, column offset d2) from the sample
-                auto uoff = [&](int x, int d0, int d1, int d2) -> int {
-                    return (x - A0) * NP * PLANE + (d0 < 0 ? so_m : (d0 > 0 ? so_p : so_0)) + d1 * P2 + d2;
-                };
+                // component x at (plane offset d0 in {-1,0,1}, row offset d1, column offset d2) from the sample: immediate offsets
+                auto at = [&](int x, int d0, int d1, int d2) -> T { return lds[cen[d0 + 1] + ((x - A0) * NP * PLANE + d1 * P2 + d2)]; };
                 T coord[3] = {T(0), T(0), T(0)};
-                coord[ca] = fma(lds[center + uoff(ca, 0, 0, 0)], -g.shift[ca], idxf[ca]);
+                coord[ca] = fma(at(ca, 0, 0, 0), -g.shift[ca], idxf[ca]);
 #pragma unroll
                 for (int cb = A0; cb < 3; ++cb) {
                     if (cb == ca) continue;
                     // component cb at this ca-face: cells (m-1, m) along ca, faces (s, s+1) along cb, in cb's stored indices:
                     // offsets (off[ca] - 1 + ia) along ca and (-off[cb] + ib) along cb (advect_common.hpp face_velocity)
-                    T sum = T(0);
+                    T v4[2][2];
 #pragma unroll
                     for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) {
                             int d[3] = {0, 0, 0};
-                            d[ca] = g.off[ca] - 1 + ia;
-                            d[cb] = -g.off[cb] + ib;
-                            sum += lds[center + uoff(cb, d[0], d[1], d[2])];
+                            d[ca] = OFF[ca] - 1 + ia;
+                            d[cb] = -OFF[cb] + ib;
+                            v4[ia][ib] = at(cb, d[0], d[1], d[2]);
                         }
-                    coord[cb] = fma(sum, T(-0.25) * g.shift[cb], idxf[cb]);
+                    coord[cb] = fma((v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]), T(-0.25) * g.shift[cb], idxf[cb]);
                 }
                 // taps relative to the sample: rel = floor(coord) - index in [-H, H-1] or the lookup leaves the window
                 T fr[3] = {T(0), T(0), T(0)};
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
                 }
                 const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0];
                 slow_any = slow_any || (valid && slow);          // -> the whole workgroup is redone by advect_self_fixup_kernel
-                int base0 = (ca - A0) * NP * PLANE + center + di[1] * P2 + di[2], base1 = base0;
+                int base0 = (ca - A0) * NP * PLANE + center + __mul24(di[1], P2) + di[2], base1 = base0;
                 if (DIM == 3) {
                     if (H == 1) {                                  // lower tap plane p-1 or p, upper p or p+1
                         base1 += di[0] < 0 ? so_0 : so_p;
@@ -305,12 +319,12 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
 #pragma unroll
                 for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
                     const int bk = k ? base1 : base0;
-                    const T a00 = lds[bk], a01 = lds[bk + 1], a10 = lds[bk + P2], a11 = lds[bk + P2 + 1];
+                    const T a00 = lds[bk], a10 = lds[bk + P2], a01 = lds[bk + 1], a11 = lds[bk + P2 + 1];   // (row pairs: packed lerp along a2)
                     const T x0 = fma(fr[2], a01 - a00, a00), x1 = fma(fr[2], a11 - a10, a10);
                     y[k] = fma(fr[1], x1 - x0, x0);
                 }
                 const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
-                if (valid) outp[ca][obase[ca] + (long long)p * pstride[ca] + s * TY * g.cn[ca][2]] = val;
+                if (valid) (outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca])[obase[ca] + (unsigned)(s * TY * g.cn[ca][2])] = val;
                 sched_fence();     // one sample's LDS reads in flight at a time: 4 waves per SIMD hide the latency, registers stay <= 128
             }
         }
@@ -385,8 +399,8 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
         }
 }
 
-template <typename T, int DIM, int H, int T1>
-static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+template <typename T, int DIM, int H, int T1, int OFFM>
+static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
     const TileGrid<T> g = make_tilegrid<T>(vg, dt);
     using C = AdvTile<T, DIM, H, T1>;
     int nmax[3] = {1, 1, 1};
@@ -395,12 +409,28 @@ static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, co
     const int tiles1 = ceil_div(nmax[1], T1), tiles2 = ceil_div(nmax[2], C::T2);
     int chunk = 1, chunks0 = 1;
     if (DIM == 3) {
-        // ~1536 workgroups (3 rounds of 2 per CU) unless that makes the chunks shorter than 8 planes (2H+1 prologue planes per chunk)
+        // Chunks of planes per workgroup: every chunk stages 2H+1 extra planes, and a launch that needs 1 < rounds < 2 of resident
+        // workgroups costs two rounds (at 256^3 1536 workgroups on 1024 slots ran at 55 % VALU utilisation). Score every chunk count by
+        // (slot efficiency of the last round) x (useful planes / staged planes) and prefer >= 2 rounds at equal score.
+        static int occ = 0;
+        if (occ == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, advect_self_tile_kernel<T, DIM, H, T1, OFFM>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+            occ = n;
+        }
+        const double slots = (double)occ * ctx->num_cu;
         const long long tiles = (long long)tiles1 * tiles2 * v.batch;
-        const int want = (int)((1536 + tiles - 1) / tiles);
-        chunk = ceil_div(nmax[0], want < 1 ? 1 : want);
-        chunk = chunk < 8 ? 8 : chunk;
-        chunk = chunk > nmax[0] ? nmax[0] : chunk;
+        double best = -1.0;
+        for (int c = 1; c <= nmax[0]; ++c) {
+            const int ch = ceil_div(nmax[0], c);
+            if (c > 1 && ch < 4) break;
+            if (ceil_div(nmax[0], ch) != c) continue;            // same decomposition as a smaller c
+            const double rounds = (double)tiles * c / slots;
+            const double eff = rounds / ceil(rounds - 1e-9);
+            const double score = eff * ch / (ch + 2 * H + 1) * (rounds >= 2.0 ? 1.0 : (rounds >= 1.0 ? 0.97 : 0.9));
+            if (score > best * 1.0001) { best = score; chunk = ch; }
+        }
+        if (ctx->adv_chunk > 0) chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
         chunks0 = ceil_div(nmax[0], chunk);
     }
     const int nblk = tiles1 * tiles2 * chunks0;
@@ -408,16 +438,40 @@ static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, co
     int* flags = (int*)ctx->ws_adv_flags.ptr;
     ctx->adv_last_nblk = nblk * v.batch;
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2],
+    hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        chunk, tiles1, tiles2, nblk, nmax[0], flags);
     hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;
 }
 
+template <typename T, int DIM, int H, int T1>
+static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+    const int m = (vg.off[0] & 1) | ((vg.off[1] & 1) << 1) | ((vg.off[2] & 1) << 2);     // (2-D: off[0] = 0)
+    switch (m) {
+        case 0: return launch_tile_off<T, DIM, H, T1, 0>(ctx, v, vg, vel, out, dt, s);
+        case 2: return launch_tile_off<T, DIM, H, T1, 2>(ctx, v, vg, vel, out, dt, s);
+        case 4: return launch_tile_off<T, DIM, H, T1, 4>(ctx, v, vg, vel, out, dt, s);
+        case 6: return launch_tile_off<T, DIM, H, T1, 6>(ctx, v, vg, vel, out, dt, s);
+        default: break;
+    }
+    if (DIM == 3) switch (m) {
+        case 1: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 1 : 0)>(ctx, v, vg, vel, out, dt, s);
+        case 3: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 3 : 0)>(ctx, v, vg, vel, out, dt, s);
+        case 5: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 5 : 0)>(ctx, v, vg, vel, out, dt, s);
+        case 7: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 7 : 0)>(ctx, v, vg, vel, out, dt, s);
+        default: break;
+    }
+    set_error("advect: unexpected face-offset pattern %d", m);
+    return PHIHIP_ERR_BAD_ARG;
+}
+
 // halo: 1 or 2 samples (taps reach |displacement| < halo cells without leaving LDS)
 int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], void* const out[3], double dt, int halo, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
+    for (int c = v.ax0; c < 3; ++c)
+        for (int a = v.ax0; a < 3; ++a)
+            if (v.cn[c][a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a ring / window wider than the axis: not worth tiling (caller: gather kernels)
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     const bool f64 = v.dtype == PHIHIP_F64;
     if (v.rank == 3 && halo == 3) {   // experiment: halo 1 with the 16-row tile (2 workgroups per CU)

@@ -781,6 +781,12 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     return PHIHIP_OK;
 }
 
+int phihip_set_advect_chunk(phihip_ctx* ctx, int planes) {
+    PHIHIP_REQUIRE(ctx != nullptr && planes >= 0, "ctx is NULL or planes < 0");
+    ctx->adv_chunk = planes;
+    return PHIHIP_OK;
+}
+
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) {
     PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "ctx / out is NULL");
     out[0] = out[1] = 0;

@@ -98,6 +98,7 @@ struct phihip_ctx {
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l;
     int adv_last_nblk = 0;        // workgroup flags of the most recent tiled advection (ws_adv_flags): count
+    int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule

@@ -60,6 +60,7 @@ int cur_lane();
     hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { hipemu::sync_block(); }
+inline int __mul24(int a, int b) { return a * b; }
 
 // fibers of the emulation run one at a time: a plain read-modify-write is atomic
 template <typename T>

@@ -175,10 +175,11 @@ def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
                 for d in range(dom.rank):
                     err = rel_err(mem.to_host(dout[d]), ref[d])
                     assert err <= tol(dtype)['advect'], f"advect[{d}] {name} field, halo {halo}: rel err {err}"
+                tiled = all(n >= 4 for d in range(dom.rank) for n in dom.comp_shape(d))     # thinner axes keep the gather kernels
                 if halo and name == "gentle":
                     redone, total = ctx.advect_fallback_stats()
-                    assert total > 0 and redone == 0, f"{redone} of {total} workgroups fell back although every displacement is < 0.9 cells"
-                if halo == 2 and name == "spots" and dt != 0:
+                    assert (total > 0) == tiled and redone == 0, f"{redone} of {total} workgroups fell back although every displacement is < 0.9 cells"
+                if halo == 2 and name == "spots" and dt != 0 and tiled:
                     redone, total = ctx.advect_fallback_stats()
                     assert total > 0 and (redone < total or total <= 4), "displacements up to 2.4 cells at a few spots flagged every workgroup"
         finally:

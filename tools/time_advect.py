@@ -64,6 +64,10 @@ def main():
             ctx.set_advect_halo(halo)
             res[f"ms_semi_lagrangian_staggered_halo{halo}"] = round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5)
         ctx.set_advect_halo(1)
+        for chunk in (8, 16, 32, 64):
+            ctx.set_advect_chunk(chunk)
+            res[f"ms_halo1_chunk{chunk}"] = round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5)
+        ctx.set_advect_chunk(0)
     res.update({
            "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
            "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
