@@ -18,17 +18,6 @@ struct AxisPair {
     T cv[2];
 };
 
-// true when the predicate holds for any lane of the wavefront: lets interior wavefronts skip the constant-side selects with a
-// SCALAR branch (a per-lane `if` makes the compiler predicate both sides). The CPU emulation build has no wavefronts; there the
-// per-thread predicate selects the same values.
-__device__ __forceinline__ bool wave_any(bool pred) {
-#ifdef __HIP_DEVICE_COMPILE__
-    return __builtin_amdgcn_ballot_w64(pred) != 0ull;
-#else
-    return pred;
-#endif
-}
-
 // wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
 // branch that no wavefront takes at sensible CFL numbers
 __device__ __forceinline__ int wrap_index(int i, int n) {

@@ -584,8 +584,14 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
         div = ctx->ws_rhs.ptr;
     }
     const void* cu[3] = {u[0], u[1], u[2]};
-    PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, balance, div, s));
-    PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, div, pressure, solve, info, s));
+    if (balance && cg_uses_marching(ctx, v) && !v.unaligned) {
+        // divergence + partial sums in one pass; the mean is subtracted inside the solver's initial residual (no extra pass over div)
+        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, 2, div, s));
+        PHIHIP_TRY(run_cg_balancing(ctx, v, flags, mask_batch, div, pressure, solve, info, (const double*)ctx->ws_scalars.ptr, s));
+    } else {
+        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, balance, div, s));
+        PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, div, pressure, solve, info, s));
+    }
     PHIHIP_TRY(run_grad_subtract(ctx, v, flags, mask_batch, pressure, u, s));
     return PHIHIP_OK;
 }

@@ -285,10 +285,15 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
     return PHIHIP_OK;
 }
 
+// shift != nullptr: rhs is the UNBALANCED divergence and shift[b] its mean over the active cells (device doubles): the initial residual
+// kernel subtracts it on the fly and writes the balanced right-hand side back into `rhs` (marching path only)
 template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
-                const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
-    if (ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+                const phihip_solve* solve, phihip_solve_info* info, const double* shift, hipStream_t s) {
+    if (ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) {
+        if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
+        return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+    }
     MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
     MarchGrid g, g_mv, g_up, g_ur;
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));
@@ -348,13 +353,14 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     base.prm = prm;
     base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
 
-    // ---- r0 = y - A x0 ; d0 = r0 (beta = 0 on a zeroed d buffer) ----
-    PHIHIP_CHECK_HIP(hipMemsetAsync(d[0], 0, vec_bytes, s));
+    // ---- r0 = y - A x0 ; d0 = r0 (the first MATVEC runs with beta = 0 and reads r in place of d_old: no zeroed buffer needed) ----
     {
         MarchArgs<T> a = base;
         a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = r;
         a.part1 = part_rr; a.part2 = part_yy;
         a.prologue = PRO_NONE;
+        a.shift = shift;
+        a.yout = shift ? (T*)const_cast<void*>(rhs) : nullptr;
         LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
         PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
     }
@@ -370,7 +376,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         T* d_new = d[k & 1];
         {
             MarchArgs<T> a = base;
-            a.a = r; a.b = d_old; a.o1 = d_new; a.part1 = part_dq; a.part2 = part_dr;
+            a.a = r; a.b = first ? r : d_old; a.o1 = d_new; a.part1 = part_dq; a.part2 = part_dr;
             if (solve->check_every > 0) { a.host_flags = ctx->host_flags_dev; a.seq = seq; }
             a.prologue = first ? PRO_FIRST : pro_beta;
             a.st_in = st[cur]; a.st_out = st[cur ^ 1]; a.pin1 = part_rr; a.pin2 = (first || !ad) ? part_yy : part_rq; a.nblk_in = nblk_rr;
@@ -658,8 +664,16 @@ int run_slab_finish(phihip_ctx* ctx, const GridView& v, int first, const double*
 
 int run_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
            const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
-    return v.dtype == PHIHIP_F64 ? cg_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, info, s)
-                                 : cg_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+    return v.dtype == PHIHIP_F64 ? cg_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, info, nullptr, s)
+                                 : cg_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, info, nullptr, s);
+}
+
+bool cg_uses_marching(const phihip_ctx* ctx, const GridView& v) { return !(ctx->small_cg && v.cells <= small_cg_limit(ctx, v)); }
+
+int run_cg_balancing(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, void* rhs, void* x, const phihip_solve* solve,
+                     phihip_solve_info* info, const double* shift, hipStream_t s) {
+    return v.dtype == PHIHIP_F64 ? cg_t<double>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s)
+                                 : cg_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
 }
 
 }  // namespace phihip

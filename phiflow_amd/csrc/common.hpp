@@ -80,6 +80,20 @@ struct ScalarBc {
 
 ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const double s_val[3][2]);
 
+}  // namespace phihip
+
+namespace phihip {
+// true when the predicate holds for any lane of the wavefront: lets interior wavefronts skip the constant-side selects with a
+// SCALAR branch (a per-lane `if` makes the compiler predicate both sides). The CPU emulation build has no wavefronts; there the
+// per-thread predicate selects the same values.
+__device__ __forceinline__ bool wave_any(bool pred) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+#else
+    return pred;
+#endif
+}
+
 struct Tuning {
     int rows = 0, tpr = 0, chunk = 0;   // 0 = auto
 };
@@ -198,5 +212,9 @@ int run_diffuse(phihip_ctx*, const GridView&, const void* const v[3], void* cons
 int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
 int run_export_residuals(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_cg(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, phihip_solve_info*, hipStream_t);
+// projection: rhs = unbalanced divergence, shift[b] = its mean over the active cells (run_divergence with balance = 2); balanced in place
+bool cg_uses_marching(const phihip_ctx*, const GridView&);
+int run_cg_balancing(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, void* rhs, void* x, const phihip_solve*, phihip_solve_info*,
+                     const double* shift, hipStream_t);
 
 }  // namespace phihip

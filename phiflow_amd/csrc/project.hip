@@ -44,23 +44,40 @@ __device__ __forceinline__ T fetch_comp(const T* C, const VelGrid& g, int ca, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // divergence (phi/field/_field_math.py:617-626 with bake_extrapolation :20-39)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kMaxPartialBlocks = 2048;   // grid-stride kernels: bounded number of per-block partial sums
+constexpr int kMaxPartialBlocks = 4096;   // patch-stride kernels: bounded number of per-block partial sums
+constexpr int kPatchCols = 64, kPatchRows = kBlock / kPatchCols;   // a workgroup visits (4 rows x 64 columns) patches of one a0 plane
+
+// uniform decode of a patch number into (plane, first row, first column): the per-thread div / mod of a linear cell index used to be
+// a third of this kernel's instructions
+__device__ __forceinline__ void decode_patch(int patch, int patches1, int patches2, int& i0, int& r0, int& c0) {
+    const int t = patch / patches2;
+    c0 = (patch - t * patches2) * kPatchCols;
+    i0 = t / patches1;
+    r0 = (t - i0 * patches1) * kPatchRows;
+}
 
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
-                                                            T* __restrict__ div, double* part_sum, double* part_act, int nblk) {
+                                                            T* __restrict__ div, double* part_sum, double* part_act, int nblk, int patches1,
+                                                            int patches2) {
     constexpr int A0 = 3 - DIM;
     __shared__ double red[kBlock / kWave];
     const int b = blockIdx.y;
     const int cells = (int)g.cells;
     const int n1 = g.n[1], n2 = g.n[2];
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = g.n[0] * patches1 * patches2;
+    T dxs[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) dxs[ax] = (T)g.dx[ax];
     T acc_val = T(0), acc_act = T(0);
-    for (int cell = blockIdx.x * kBlock + threadIdx.x; cell < cells; cell += gridDim.x * kBlock) {
-        int idx[3];
-        idx[2] = cell % n2;
-        const int t = cell / n2;
-        idx[1] = t % n1;
-        idx[0] = t / n1;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3], r0, c0;
+        decode_patch(patch, patches1, patches2, idx[0], r0, c0);
+        idx[1] = r0 + ty;
+        idx[2] = c0 + tx;
+        if (idx[1] >= n1 || idx[2] >= n2) continue;
+        const int cell = (idx[0] * n1 + idx[1]) * n2 + idx[2];
         T sum = T(0);
 #pragma unroll
         for (int ax = A0; ax < 3; ++ax) {
@@ -69,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
             const int lo = idx[ax] - g.off[ax], hi = lo + 1;
             const T* __restrict__ C = v.p[ax] + (long long)b * g.ccells[ax];
             T vl, vh;
-            if (lo >= 0 && hi < g.cn[ax][ax]) {   // interior: both faces stored
+            if (!wave_any(lo < 0 || hi >= g.cn[ax][ax])) {   // interior wavefront: both faces stored (scalar branch)
                 const int base = (idx[0] * c1 + idx[1]) * c2 + idx[2] - idx[ax] * stride;
                 vl = C[base + lo * stride];
                 vh = C[base + hi * stride];
@@ -79,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
                 vl = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], l[0], l[1], l[2]);
                 vh = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], h[0], h[1], h[2]);
             }
-            sum += (vh - vl) / (T)g.dx[ax];
+            sum += (vh - vl) / dxs[ax];
         }
         T act = T(1);
         if (flags) {
@@ -171,7 +188,8 @@ template <typename T, int DIM>
 static void launch_divergence(const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
                               double* part_sum, double* part_act, int nblk, hipStream_t s) {
     CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk);
+    hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
+                       ceil_div(v.n[1], kPatchRows), ceil_div(v.n[2], kPatchCols));
 }
 
 int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const uint8_t* flags, int mask_batch, int balance,
@@ -181,8 +199,9 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
         return PHIHIP_ERR_UNSUPPORTED;
     }
     const VelGrid g = make_velgrid(v);
-    const int nblk = ceil_div(v.cells, kBlock) < kMaxPartialBlocks ? ceil_div(v.cells, kBlock) : kMaxPartialBlocks;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
+    const long long npatch = (long long)v.n[0] * ceil_div(v.n[1], kPatchRows) * ceil_div(v.n[2], kPatchCols);
+    const int nblk = npatch < kMaxPartialBlocks ? (int)npatch : kMaxPartialBlocks;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * kMaxPartialBlocks * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
     double* part_sum = (double*)ctx->ws_div.ptr;
     double* part_act = part_sum + (size_t)v.batch * nblk;
@@ -202,6 +221,10 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         hipLaunchKernelGGL(balance_scalar_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)part_sum, (const double*)part_act,
                            nblk, shift);
+        if (balance == 2) {   // the caller folds the shift (ctx->ws_scalars) into the solver's initial residual
+            PHIHIP_CHECK_HIP(hipGetLastError());
+            return PHIHIP_OK;
+        }
         const int nb2 = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
         if (v.dtype == PHIHIP_F64)
             hipLaunchKernelGGL(balance_apply_kernel<double>, dim3(nb2, v.batch), dim3(kBlock), 0, s, (double*)div, flags, fpb,
@@ -217,53 +240,62 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
 // ---------------------------------------------------------------------------------------------------------------------
 // v_d[f] -= h_f (p_R - p_L) / dx_d   (phi/physics/fluid.py:158-161; stagger :535-581)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int DIM, int CA>
-__global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, T* __restrict__ vc, const T* __restrict__ p, const uint8_t* flags,
-                                                               int flags_per_batch) {
-    constexpr int ca = CA;
+// ONE launch for all components: a thread owns the stored index (i0, i1, i2) in every component's array (they differ by at most one
+// sample per axis), so the pressure cell it shares between the D faces is fetched once and the D neighbours come from lines the
+// neighbouring lanes / rows touch anyway; the per-component launches read p three times.
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
+                                                               int nmax0, int patches1, int patches2) {
+    constexpr int A0 = 3 - DIM;
     const int b = blockIdx.y;
-    const int total = (int)g.ccells[ca];
-    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
-    const int n = g.n[ca];
-    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
     const T* __restrict__ P = p + (long long)b * g.cells;
     const uint8_t* F = flags ? flags + (flags_per_batch ? (long long)b * g.cells : 0) : nullptr;
-    T* __restrict__ V = vc + (long long)b * total;
-    const T dx = (T)g.dx[ca];
-    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
-        int idx[3];
-        idx[2] = f % c2;
-        const int t = f / c2;
-        idx[1] = t % c1;
-        idx[0] = t / c1;
-        const int phys = idx[ca] + g.off[ca];
-        int l = phys - 1, r = phys;
-        bool zl = false, zr = false;
-        const bool l_in = l >= 0, r_in = r < n;
-        if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
-        if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
-        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;   // other axes coincide with cell indices
-        const int offL = rest + l * pstride, offR = rest + r * pstride;
-        const T pl = zl ? T(0) : P[offL];
-        const T pr = zr ? T(0) : P[offR];
-        T h = T(1);
-        if (F) {
-            // the face is the lower face of cell R (if R exists in the domain or by wrap) else the upper face of cell L
-            if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) h = (F[offR] >> (2 * ca)) & 1u ? T(1) : T(0);
-            else if (l_in) h = (F[offL] >> (2 * ca + 1)) & 1u ? T(1) : T(0);
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = nmax0 * patches1 * patches2;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3], r0, c0;
+        decode_patch(patch, patches1, patches2, idx[0], r0, c0);
+        idx[1] = r0 + ty;
+        idx[2] = c0 + tx;
+#pragma unroll
+        for (int ca = A0; ca < 3; ++ca) {
+            if (idx[0] >= g.cn[ca][0] || idx[1] >= g.cn[ca][1] || idx[2] >= g.cn[ca][2]) continue;
+            const int n = g.n[ca];
+            const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
+            const int phys = idx[ca] + g.off[ca];
+            int l = phys - 1, r = phys;
+            bool zl = false, zr = false;
+            const bool l_in = l >= 0, r_in = r < n;
+            if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
+            if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
+            const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;   // other axes coincide with cell indices
+            const int offL = rest + l * pstride, offR = rest + r * pstride;
+            const T pl = zl ? T(0) : P[offL];
+            const T pr = zr ? T(0) : P[offR];
+            T h = T(1);
+            if (F) {
+                // the face is the lower face of cell R (if R exists in the domain or by wrap) else the upper face of cell L
+                if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) h = (F[offR] >> (2 * ca)) & 1u ? T(1) : T(0);
+                else if (l_in) h = (F[offL] >> (2 * ca + 1)) & 1u ? T(1) : T(0);
+            }
+            T* __restrict__ V = vc.p[ca] + (long long)b * g.ccells[ca];
+            const int f = (idx[0] * g.cn[ca][1] + idx[1]) * g.cn[ca][2] + idx[2];
+            V[f] = V[f] - h * ((pr - pl) / (T)g.dx[ca]);
         }
-        V[f] = V[f] - h * ((pr - pl) / dx);
     }
 }
 
 template <typename T, int DIM>
 static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint8_t* flags, int fpb, const void* p, void* const vel[3],
                                  hipStream_t s) {
-    auto nb = [&](int ca) { return ceil_div(v.ccells[ca], kBlock) < 16384 ? ceil_div(v.ccells[ca], kBlock) : 16384; };
-    if (DIM == 3)
-        hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 0>), dim3(nb(0), v.batch), dim3(kBlock), 0, s, g, (T*)vel[0], (const T*)p, flags, fpb);
-    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 1>), dim3(nb(1), v.batch), dim3(kBlock), 0, s, g, (T*)vel[1], (const T*)p, flags, fpb);
-    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM, 2>), dim3(nb(2), v.batch), dim3(kBlock), 0, s, g, (T*)vel[2], (const T*)p, flags, fpb);
+    int nmax[3] = {1, 1, 1};
+    for (int a = 0; a < 3; ++a)
+        for (int c = v.ax0; c < 3; ++c) nmax[a] = v.cn[c][a] > nmax[a] ? v.cn[c][a] : nmax[a];
+    const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(nmax[2], kPatchCols);
+    const long long npatch = (long long)nmax[0] * patches1 * patches2;
+    const int nblk = npatch < 16384 ? (int)npatch : 16384;
+    Comp3<T> c{{(T*)vel[0], (T*)vel[1], (T*)vel[2]}};
+    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1, patches2);
 }
 
 int run_grad_subtract(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* const vel[3],

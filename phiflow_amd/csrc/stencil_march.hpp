@@ -136,6 +136,10 @@ struct MarchArgs {
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
     const T* a_lo; const T* a_hi;
     const T* b_lo; const T* b_hi;
+    // RESID only: fluid._balance_divergence folded into the initial residual -- y is read as y - shift[b] * active and, when `yout` is
+    // set, written back balanced (the refreshes and the caller see the balanced right-hand side); saves the separate read + write pass
+    const double* shift;
+    T* yout;
 };
 
 template <typename T, int V>
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
+    const T yshift = (MODE == MODE_RESID && p.shift) ? (T)p.shift[b] : T(0);
     T alpha = T(0), beta = T(0);
     T acc1 = T(0), acc2 = T(0);
 
@@ -497,14 +502,18 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             if (MODE == MODE_APPLY) {
                 vec_store<T, V>(p.o1 + off, q);
             } else if (MODE == MODE_RESID) {
-                VT r;
+                VT r, yb;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const T y = Ec.e1[rr].v[v];
+                    T y = Ec.e1[rr].v[v];
+                    if (FLAGS) y -= (Ec.fl[rr].v[v] & 64u) ? yshift : T(0);   // div -= active * mean(div) / mean(active)  (fluid.py:205-209)
+                    else y -= yshift;
+                    yb.v[v] = y;
                     r.v[v] = y - q.v[v];
                     acc1 += r.v[v] * r.v[v];
                     acc2 += y * y;
                 }
+                if (p.yout) vec_store<T, V>(p.yout + off, yb);
                 vec_store<T, V>(p.o1 + off, r);
             } else if (IS_MV) {
 #pragma unroll
