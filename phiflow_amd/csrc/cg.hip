@@ -362,7 +362,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         a.shift = shift;
         a.yout = shift ? (T*)const_cast<void*>(rhs) : nullptr;
         LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
-        PHIHIP_TRY(launch_march_any<T>(v, c, MODE_RESID, has_flags, g, a, s));
+        PHIHIP_TRY(launch_march_any<T>(v, c, shift ? MODE_RESID_BAL : MODE_RESID, has_flags, g, a, s));
     }
     bool first = true;
     // x does not enter the recurrence: update it every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)

@@ -39,6 +39,7 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
         PHIHIP_MODE_CASE(MODE_UPDATE_AD)
         PHIHIP_MODE_CASE(MODE_UPDATE_R)
         PHIHIP_MODE_CASE(MODE_UPDATE_X2)
+        PHIHIP_MODE_CASE(MODE_RESID_BAL)
         default:
             set_error("march: bad mode %d", mode);
             return PHIHIP_ERR_BAD_ARG;
@@ -71,6 +72,7 @@ static int occupancy_cfg(int mode, bool flags) {
         PHIHIP_OCC_CASE(MODE_UPDATE_AD)
         PHIHIP_OCC_CASE(MODE_UPDATE_R)
         PHIHIP_OCC_CASE(MODE_UPDATE_X2)
+        PHIHIP_OCC_CASE(MODE_RESID_BAL)
         default: return 1;
     }
 #undef PHIHIP_OCC_CASE

@@ -56,57 +56,81 @@ __device__ __forceinline__ void decode_patch(int patch, int patches1, int patche
     r0 = (t - i0 * patches1) * kPatchRows;
 }
 
+// one face index of component `ax` along its own axis under the velocity extrapolation: stored index to read, or -1 / -2 when the
+// lower / upper CONSTANT side supplies the value (bake_extrapolation, phi/field/_field_math.py:20-39)
+__device__ __forceinline__ int face_index(int i, int n, int code_lo, int code_hi) {
+    if (i < 0) return code_lo == PHIHIP_BC_PERIODIC ? i + n : (code_lo == PHIHIP_BC_CLOSED ? -1 : 0);
+    if (i >= n) return code_hi == PHIHIP_BC_PERIODIC ? i - n : (code_hi == PHIHIP_BC_CLOSED ? -2 : n - 1);
+    return i;
+}
+
+// A workgroup owns a (4 rows x 64 columns) column of cells and marches over a chunk of a0 planes: the in-plane face offsets (and the
+// boundary rule of the a1 / a2 faces) are resolved once per thread, the upper a0 face of one plane is the lower face of the next
+// (5 loads + 1 store per cell, no integer division anywhere), and the per-workgroup partial sums of div and of the active cells
+// feed fluid._balance_divergence.
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
-                                                            T* __restrict__ div, double* part_sum, double* part_act, int nblk, int patches1,
-                                                            int patches2) {
-    constexpr int A0 = 3 - DIM;
+                                                            T* __restrict__ div, double* part_sum, double* part_act, int nblk, int tiles1,
+                                                            int tiles2, int chunk) {
     __shared__ double red[kBlock / kWave];
     const int b = blockIdx.y;
-    const int cells = (int)g.cells;
-    const int n1 = g.n[1], n2 = g.n[2];
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
-    const int npatch = g.n[0] * patches1 * patches2;
-    T dxs[3];
+    const int t2 = blockIdx.x % tiles2;
+    const int t1 = (blockIdx.x / tiles2) % tiles1;
+    const int c0 = blockIdx.x / (tiles2 * tiles1);
+    const int i1 = t1 * kPatchRows + ty, i2 = t2 * kPatchCols + tx;
+    const bool inside = i1 < n1 && i2 < n2;
+    const int p0 = DIM == 3 ? c0 * chunk : 0, p1 = DIM == 3 ? min(p0 + chunk, n0) : 1;
+    const T d0 = (T)g.dx[0], d1 = (T)g.dx[1], d2 = (T)g.dx[2];
+    // in-plane taps: component 1 at rows (i1 - off1, +1), component 2 at columns (i2 - off2, +1)
+    int o1[2] = {0, 0}, o2[2] = {0, 0};
+    T k1[2] = {T(0), T(0)}, k2[2] = {T(0), T(0)};
+    bool c1f[2] = {false, false}, c2f[2] = {false, false};
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) dxs[ax] = (T)g.dx[ax];
+    for (int k = 0; k < 2; ++k) {
+        const int f1 = face_index(i1 - g.off[1] + k, g.cn[1][1], g.bc[1][0], g.bc[1][1]);
+        const int f2 = face_index(i2 - g.off[2] + k, g.cn[2][2], g.bc[2][0], g.bc[2][1]);
+        c1f[k] = f1 < 0; k1[k] = (T)(f1 == -1 ? g.bcv[1][0][1] : g.bcv[1][1][1]); o1[k] = (f1 < 0 ? 0 : f1) * g.cn[1][2] + i2;
+        c2f[k] = f2 < 0; k2[k] = (T)(f2 == -1 ? g.bcv[2][0][2] : g.bcv[2][1][2]); o2[k] = i1 * g.cn[2][2] + (f2 < 0 ? 0 : f2);
+    }
+    const int o0 = i1 * g.cn[0][2] + i2;                                   // component 0: same (i1, i2) in every plane
+    const long long ps0 = (long long)g.cn[0][1] * g.cn[0][2], ps1 = (long long)g.cn[1][1] * g.cn[1][2], ps2 = (long long)g.cn[2][1] * g.cn[2][2];
+    const T* __restrict__ C0 = DIM == 3 ? v.p[0] + (long long)b * g.ccells[0] : nullptr;
+    const T* __restrict__ C1 = v.p[1] + (long long)b * g.ccells[1];
+    const T* __restrict__ C2 = v.p[2] + (long long)b * g.ccells[2];
+    const uint8_t* F = flags ? flags + (flags_per_batch ? (long long)b * g.cells : 0) : nullptr;
+    T* __restrict__ D = div + (long long)b * g.cells;
+    auto face0 = [&](int phys) -> T {      // component 0 at physical face `phys` of this thread's column (uniform boundary decision)
+        const int f = face_index(phys - g.off[0], g.cn[0][0], g.bc[0][0], g.bc[0][1]);
+        if (f < 0) return (T)(f == -1 ? g.bcv[0][0][0] : g.bcv[0][1][0]);
+        return C0[(long long)f * ps0 + o0];
+    };
     T acc_val = T(0), acc_act = T(0);
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-        int idx[3], r0, c0;
-        decode_patch(patch, patches1, patches2, idx[0], r0, c0);
-        idx[1] = r0 + ty;
-        idx[2] = c0 + tx;
-        if (idx[1] >= n1 || idx[2] >= n2) continue;
-        const int cell = (idx[0] * n1 + idx[1]) * n2 + idx[2];
-        T sum = T(0);
-#pragma unroll
-        for (int ax = A0; ax < 3; ++ax) {
-            const int c1 = g.cn[ax][1], c2 = g.cn[ax][2];
-            const int stride = ax == 0 ? c1 * c2 : (ax == 1 ? c2 : 1);
-            const int lo = idx[ax] - g.off[ax], hi = lo + 1;
-            const T* __restrict__ C = v.p[ax] + (long long)b * g.ccells[ax];
-            T vl, vh;
-            if (!wave_any(lo < 0 || hi >= g.cn[ax][ax])) {   // interior wavefront: both faces stored (scalar branch)
-                const int base = (idx[0] * c1 + idx[1]) * c2 + idx[2] - idx[ax] * stride;
-                vl = C[base + lo * stride];
-                vh = C[base + hi * stride];
-            } else {
-                int l[3] = {idx[0], idx[1], idx[2]}, h[3] = {idx[0], idx[1], idx[2]};
-                l[ax] = lo; h[ax] = hi;
-                vl = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], l[0], l[1], l[2]);
-                vh = fetch_comp<T>(v.p[ax], g, ax, (long long)b * g.ccells[ax], h[0], h[1], h[2]);
+    if (inside && p0 < p1) {
+        T lo0 = DIM == 3 ? face0(p0) : T(0);
+        for (int p = p0; p < p1; ++p) {
+            T sum = T(0);
+            if (DIM == 3) {
+                const T hi0 = face0(p + 1);
+                sum += (hi0 - lo0) / d0;
+                lo0 = hi0;
             }
-            sum += (vh - vl) / dxs[ax];
+            const T a = c1f[0] ? k1[0] : C1[(long long)p * ps1 + o1[0]], bb = c1f[1] ? k1[1] : C1[(long long)p * ps1 + o1[1]];
+            sum += (bb - a) / d1;
+            const T c = c2f[0] ? k2[0] : C2[(long long)p * ps2 + o2[0]], d = c2f[1] ? k2[1] : C2[(long long)p * ps2 + o2[1]];
+            sum += (d - c) / d2;
+            const long long cell = ((long long)p * n1 + i1) * n2 + i2;
+            T act = T(1);
+            if (F) {
+                const unsigned f = F[cell];
+                act = (f & 64u) ? T(1) : T(0);
+                sum = (f & 64u) ? sum : T(0);   // div * active, and non-finite values of inactive cells do not leak (fluid.py:139-144)
+            }
+            D[cell] = sum;
+            acc_val += sum;
+            acc_act += act;
         }
-        T act = T(1);
-        if (flags) {
-            const unsigned f = flags[(flags_per_batch ? (long long)b * cells : 0) + cell];
-            act = (f & 64u) ? T(1) : T(0);
-            sum = (f & 64u) ? sum : T(0);   // div * active, and non-finite values of inactive cells do not leak (fluid.py:139-144)
-        }
-        div[(long long)b * cells + cell] = sum;
-        acc_val += sum;
-        acc_act += act;
     }
     const double s1 = block_sum((double)acc_val, red);
     const double s2 = block_sum((double)acc_act, red);
@@ -186,10 +210,11 @@ int run_balance(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
 
 template <typename T, int DIM>
 static void launch_divergence(const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
-                              double* part_sum, double* part_act, int nblk, hipStream_t s) {
+                              double* part_sum, double* part_act, int nblk, int chunk_planes, hipStream_t s) {
     CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    const int tiles1 = ceil_div(v.n[1], kPatchRows), tiles2 = ceil_div(v.n[2], kPatchCols);
     hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
-                       ceil_div(v.n[1], kPatchRows), ceil_div(v.n[2], kPatchCols));
+                       tiles1, tiles2, chunk_planes);
 }
 
 int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const uint8_t* flags, int mask_batch, int balance,
@@ -199,9 +224,15 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
         return PHIHIP_ERR_UNSUPPORTED;
     }
     const VelGrid g = make_velgrid(v);
-    const long long npatch = (long long)v.n[0] * ceil_div(v.n[1], kPatchRows) * ceil_div(v.n[2], kPatchCols);
-    const int nblk = npatch < kMaxPartialBlocks ? (int)npatch : kMaxPartialBlocks;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * kMaxPartialBlocks * sizeof(double)));
+    // (4 x 64)-cell columns x chunks of planes: ~4096 workgroups per batch entry when the grid allows (2 rounds of 8 per CU)
+    const long long tiles = (long long)ceil_div(v.n[1], kPatchRows) * ceil_div(v.n[2], kPatchCols);
+    PHIHIP_REQUIRE(tiles <= (1 << 24), "divergence: grid too large");
+    int chunks = v.rank == 3 ? (int)((4096 + tiles - 1) / tiles) : 1;
+    chunks = chunks > v.n[0] ? v.n[0] : (chunks < 1 ? 1 : chunks);
+    const int chunk_planes = ceil_div(v.n[0], chunks);
+    chunks = ceil_div(v.n[0], chunk_planes);
+    const int nblk = (int)tiles * chunks;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
     double* part_sum = (double*)ctx->ws_div.ptr;
     double* part_act = part_sum + (size_t)v.batch * nblk;
@@ -210,11 +241,11 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
     {
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         if (v.dtype == PHIHIP_F64) {
-            if (v.rank == 3) launch_divergence<double, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
-            else launch_divergence<double, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
+            if (v.rank == 3) launch_divergence<double, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
+            else launch_divergence<double, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
         } else {
-            if (v.rank == 3) launch_divergence<float, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
-            else launch_divergence<float, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, s);
+            if (v.rank == 3) launch_divergence<float, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
+            else launch_divergence<float, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
         }
     }
     if (balance) {

@@ -30,7 +30,8 @@ constexpr int kWave = 64;
 
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
                                                                             // neighbour slab's halo buffer (MarchArgs::a_lo ...)
-enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5, MODE_UPDATE_R = 6, MODE_UPDATE_X2 = 7 };
+enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5, MODE_UPDATE_R = 6, MODE_UPDATE_X2 = 7,
+                 MODE_RESID_BAL = 8 };   // RESID that also balances y: y -= shift * active, written back (once per projection)
 
 // Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
 // iteration: every workgroup of the NEXT kernel re-reduces the previous kernel's per-workgroup partial sums in a fixed order
@@ -136,8 +137,8 @@ struct MarchArgs {
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
     const T* a_lo; const T* a_hi;
     const T* b_lo; const T* b_hi;
-    // RESID only: fluid._balance_divergence folded into the initial residual -- y is read as y - shift[b] * active and, when `yout` is
-    // set, written back balanced (the refreshes and the caller see the balanced right-hand side); saves the separate read + write pass
+    // RESID_BAL only: fluid._balance_divergence folded into the initial residual -- y is read as y - shift[b] * active and written
+    // back balanced to `yout` (the refreshes and the caller see the balanced right-hand side); saves the separate read + write pass
     const double* shift;
     T* yout;
 };
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const T yshift = (MODE == MODE_RESID && p.shift) ? (T)p.shift[b] : T(0);
+    constexpr bool IS_RES = MODE == MODE_RESID || MODE == MODE_RESID_BAL;
+    const T yshift = MODE == MODE_RESID_BAL ? (T)p.shift[b] : T(0);
     T alpha = T(0), beta = T(0);
     T acc1 = T(0), acc2 = T(0);
 
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         for (int rr = 0; rr < R; ++rr) {
             if (!ok[rr]) continue;
             const long long off = ((long long)i * n1 + (j1b + rr)) * n2 + j2;
-            if (MODE == MODE_RESID) E.e1[rr] = vec_load<T, V>(p.b + base + off);
+            if (IS_RES) E.e1[rr] = vec_load<T, V>(p.b + base + off);
             if (IS_UP) {
                 if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
                 E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
@@ -501,19 +503,21 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             const long long off = base + ((long long)i * n1 + (j1b + rr)) * n2 + j2;
             if (MODE == MODE_APPLY) {
                 vec_store<T, V>(p.o1 + off, q);
-            } else if (MODE == MODE_RESID) {
+            } else if (IS_RES) {
                 VT r, yb;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     T y = Ec.e1[rr].v[v];
-                    if (FLAGS) y -= (Ec.fl[rr].v[v] & 64u) ? yshift : T(0);   // div -= active * mean(div) / mean(active)  (fluid.py:205-209)
-                    else y -= yshift;
-                    yb.v[v] = y;
+                    if (MODE == MODE_RESID_BAL) {   // div -= active * mean(div) / mean(active)  (fluid.py:205-209)
+                        if (FLAGS) y -= (Ec.fl[rr].v[v] & 64u) ? yshift : T(0);
+                        else y -= yshift;
+                        yb.v[v] = y;
+                    }
                     r.v[v] = y - q.v[v];
                     acc1 += r.v[v] * r.v[v];
                     acc2 += y * y;
                 }
-                if (p.yout) vec_store<T, V>(p.yout + off, yb);
+                if (MODE == MODE_RESID_BAL) vec_store<T, V>(p.yout + off, yb);
                 vec_store<T, V>(p.o1 + off, r);
             } else if (IS_MV) {
 #pragma unroll
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     if (MODE != MODE_APPLY) {
         const double s1 = block_sum((double)acc1, red);
         if (tid == 0) p.part1[(long long)b * g.nblk + blockIdx.x] = s1;
-        if (MODE == MODE_RESID || AD) {
+        if (IS_RES || AD) {
             const double s2 = block_sum((double)acc2, red);
             if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
         }
