@@ -312,6 +312,11 @@ int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
  * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
+/* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
+ * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or
+ * PHIHIP_AUTOTUNE=0 in the environment when the context is created) keeps the analytic launch plan: same launch geometry, hence the same
+ * summation order of the dot products, in every process. Explicit phihip_set_tuning[_kernel] settings always win. Default: enabled. */
+int phihip_set_autotune(phihip_ctx* ctx, int enable);
 /* launch plan the library would use for this grid and kernel family: out = {rows per thread, threads per row, planes per
  * workgroup, workgroups per batch entry, resident workgroups per CU of that kernel, vector width} */
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]);

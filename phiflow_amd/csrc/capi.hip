@@ -1,5 +1,6 @@
 // capi.hip -- extern "C" surface of libphihip.so (declared in include/phihip.h) + context / workspace / profiling plumbing.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 #include "march_dispatch.hpp"
@@ -185,6 +186,8 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
     PHIHIP_CHECK_HIP(hipSetDevice(device));
     phihip_ctx* ctx = new phihip_ctx();
     ctx->device = device;
+    const char* at = getenv("PHIHIP_AUTOTUNE");
+    if (at && at[0] == '0') ctx->autotune = false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cu = prop.multiProcessorCount;
     *out = ctx;
@@ -803,6 +806,13 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) 
     PHIHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     for (int f : host) out[0] += f != 0;
     out[1] = ctx->adv_last_nblk;
+    return PHIHIP_OK;
+}
+
+int phihip_set_autotune(phihip_ctx* ctx, int enable) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->autotune = enable != 0;
+    if (!enable) ctx->tuned.clear();
     return PHIHIP_OK;
 }
 

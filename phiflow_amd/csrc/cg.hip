@@ -24,6 +24,10 @@ namespace phihip {
 //     relative traffic = 1 + (2 / chunk) * (source words / all words)
 // and the best score (x a small per-family tile preference) wins; for small grids the serial march of a chunk (latency) replaces the
 // traffic term (see best_chunk).
+static PlanKey plan_key(const GridView& v, int mask_batch, bool flags, int family) {
+    return PlanKey{v.dtype, v.rank, v.n[0], v.n[1], v.n[2], v.batch, flags ? 1 : 0, mask_batch > 1 ? 1 : 0, family, v.unaligned ? 0 : 1};
+}
+
 int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
     const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const int vmax = 16 / esize;
@@ -99,7 +103,11 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
 
     int id = -1, chunk = 1;
     double score = 0;
-    if (c->vec == 1) {
+    const auto tuned = (t.rows > 0 || t.chunk > 0 || v.halo[0] || v.halo[1]) ? ctx->tuned.end() : ctx->tuned.find(plan_key(v, mask_batch, flags, family));
+    if (tuned != ctx->tuned.end()) {   // measured on this device (autotune_cg)
+        id = tuned->second.id;
+        chunk = tuned->second.chunk;
+    } else if (c->vec == 1) {
         id = 5;   // (1, 64): the only scalar instantiation
         chunk = best_chunk(id, &score);
     } else if (t.rows > 0 && t.tpr > 0) {
@@ -132,7 +140,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     if (v.rank == 3 && t.chunk > 0) chunk = t.chunk < v.n[0] ? t.chunk : v.n[0];
     tile_of(id, &c->t1, &c->t2);
     // every workgroup of the next kernel re-reduces all partial sums of its batch entry: keep that list short
-    while (v.rank == 3 && t.chunk == 0 && chunk < v.n[0] && tiles_of(id) * ceil_div(v.n[0], chunk) > 8192) chunk = chunk * 2 < v.n[0] ? chunk * 2 : v.n[0];
+    while (v.rank == 3 && t.chunk == 0 && tuned == ctx->tuned.end() && chunk < v.n[0] && tiles_of(id) * ceil_div(v.n[0], chunk) > 8192) chunk = chunk * 2 < v.n[0] ? chunk * 2 : v.n[0];
     c->id = id;
     c->chunk = chunk;
     g->tiles1 = ceil_div(v.n[1], c->t1);
@@ -285,6 +293,114 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
     return PHIHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// first-call autotune: time the (tile, chunk) candidates of MATVEC / UPDATE_X2 / UPDATE_R for this grid on the context's workspace
+// (r, d0, d1 -- the solve that follows initialises them) and cache the fastest. The analytic plan of plan_march misses by up to
+// 25 % between its fitted sizes (320^3 ... 448^3: profiles/r01_size_scan.jsonl); a measurement does not.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, T* r, T* d0, T* d1, double* part, hipStream_t s) {
+    const bool has_flags = flags != nullptr;
+    const int esize = (int)sizeof(T);
+    const int vec = (v.n[2] % (16 / esize) == 0 && !v.unaligned) ? 16 / esize : 1;
+    static const int kChunks[11] = {96, 64, 48, 32, 24, 16, 12, 8, 4, 2, 1};
+    struct Cand { int id, chunk; float us; };
+    const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
+    PHIHIP_CHECK_HIP(hipMemsetAsync(r, 0, vec_bytes, s));
+    PHIHIP_CHECK_HIP(hipMemsetAsync(d0, 0, vec_bytes, s));
+    PHIHIP_CHECK_HIP(hipMemsetAsync(d1, 0, vec_bytes, s));
+    hipEvent_t e0, e1;
+    PHIHIP_CHECK_HIP(hipEventCreate(&e0));
+    PHIHIP_CHECK_HIP(hipEventCreate(&e1));
+    int status = PHIHIP_OK;
+    for (int family = FAM_MATVEC; family <= FAM_UPDATE_R && status == PHIHIP_OK; ++family) {
+        const PlanKey key = plan_key(v, mask_batch, has_flags, family);
+        if (ctx->tuned.count(key)) continue;
+        const int mode = family == FAM_MATVEC ? MODE_MATVEC : (family == FAM_UPDATE ? MODE_UPDATE_X2 : MODE_UPDATE_R);
+        MarchConfig c_model;
+        MarchGrid g_model;
+        status = plan_march(ctx, v, mask_batch, has_flags, family, &c_model, &g_model);
+        if (status != PHIHIP_OK) break;
+        const long long maxblk = g_model.nblk > 8192 ? g_model.nblk : 8192;
+        if (ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * maxblk * sizeof(double)) != PHIHIP_OK) { status = PHIHIP_ERR_ALLOC; break; }
+        part = (double*)ctx->ws_part.ptr;
+        std::vector<Cand> cands;
+        cands.push_back({c_model.id, c_model.chunk, 0.f});                      // the model's choice goes first (ties keep it)
+        for (int id = 0; id < kNumTileConfigs; ++id) {
+            if (vec == 1 && id != 5) continue;
+            if (v.rank != 3) {
+                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
+                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec);
+                if (id != c_model.id && blocks <= maxblk) cands.push_back({id, 1, 0.f});
+                continue;
+            }
+            for (int k = 0; k < 11; ++k) {
+                const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
+                if (id == c_model.id && ch == c_model.chunk) continue;
+                bool dup = false;
+                for (const Cand& o : cands) dup = dup || (o.id == id && o.chunk == ch);
+                if (dup) continue;
+                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
+                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * ceil_div(v.n[0], ch);
+                if (blocks * v.batch < ctx->num_cu || blocks > 8192) continue;   // starved chip / partial-sum lists too long
+                cands.push_back({id, ch, 0.f});
+            }
+        }
+        const Tuning saved = ctx->tuning[family];
+        auto run = [&](Cand& cd, int reps) -> int {
+            ctx->tuning[family].rows = vec == 1 ? 1 : kTileShapes[cd.id].rows;
+            ctx->tuning[family].tpr = vec == 1 ? 64 : kTileShapes[cd.id].tpr;
+            ctx->tuning[family].chunk = v.rank == 3 ? cd.chunk : 0;
+            MarchConfig c;
+            MarchGrid g;
+            PHIHIP_TRY(plan_march(ctx, v, mask_batch, has_flags, family, &c, &g));
+            MarchArgs<T> a;
+            memset(&a, 0, sizeof(a));
+            a.flags = flags;
+            a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+            a.prologue = PRO_NONE;                       // alpha = beta = 0: every vector stays zero
+            a.part1 = part; a.part2 = part + (size_t)v.batch * maxblk;
+            if (family == FAM_MATVEC) { a.a = r; a.b = d0; a.o1 = d1; }
+            else { a.a = d1; a.o1 = d0; a.o2 = r; }
+            float best = 1e30f;
+            for (int k = 0; k < reps; ++k) {
+                PHIHIP_CHECK_HIP(hipEventRecord(e0, s));
+                PHIHIP_TRY(launch_march_any<T>(v, c, mode, has_flags, g, a, s));
+                PHIHIP_CHECK_HIP(hipEventRecord(e1, s));
+                PHIHIP_CHECK_HIP(hipEventSynchronize(e1));
+                float ms = 0;
+                PHIHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            cd.us = best * 1e3f;
+            return PHIHIP_OK;
+        };
+        Cand warm = cands[0];
+        status = run(warm, 2);                                                   // clocks up, code loaded
+        for (size_t k = 0; k < cands.size() && status == PHIHIP_OK; ++k) status = run(cands[k], 2);
+        // confirm the leaders with more repetitions (single launches of ~30 us carry a few % of timer noise)
+        std::vector<size_t> order(cands.size());
+        for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+        for (size_t a_ = 0; a_ + 1 < order.size(); ++a_)
+            for (size_t b_ = a_ + 1; b_ < order.size(); ++b_)
+                if (cands[order[b_]].us < cands[order[a_]].us) { const size_t t_ = order[a_]; order[a_] = order[b_]; order[b_] = t_; }
+        const float us_model_first = cands[0].us;
+        for (size_t k = 0; k < order.size() && k < 3 && status == PHIHIP_OK; ++k) status = run(cands[order[k]], 5);
+        if (status == PHIHIP_OK) status = run(cands[0], 5);
+        ctx->tuning[family] = saved;
+        if (status != PHIHIP_OK) break;
+        size_t win = 0;
+        for (size_t k = 1; k < cands.size(); ++k)
+            if (cands[k].us < cands[win].us * 0.98f) win = k;                   // the model's plan stays unless something is > 2 % faster
+        TunedPlan tp;
+        tp.id = cands[win].id; tp.chunk = cands[win].chunk; tp.us = cands[win].us; tp.us_model = cands[0].us < us_model_first ? cands[0].us : us_model_first;
+        ctx->tuned[key] = tp;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return status;
+}
+
 // shift != nullptr: rhs is the UNBALANCED divergence and shift[b] its mean over the active cells (device doubles): the initial residual
 // kernel subtracts it on the fly and writes the balanced right-hand side back into `rhs` (marching path only)
 template <typename T>
@@ -293,6 +409,15 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     if (ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) {
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
+    }
+    if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
+        !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R))) {
+        const size_t vb = (size_t)v.batch * v.cells * sizeof(T);
+        PHIHIP_TRY(ensure_buffer(ctx->ws_r, vb));
+        PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vb));
+        PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vb));
+        PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * 8192 * sizeof(double)));
+        PHIHIP_TRY(autotune_cg<T>(ctx, v, flags, mask_batch, (T*)ctx->ws_r.ptr, (T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr, (double*)ctx->ws_part.ptr, s));
     }
     MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
     MarchGrid g, g_mv, g_up, g_ur;

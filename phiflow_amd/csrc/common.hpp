@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <array>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -98,6 +100,14 @@ struct Tuning {
     int rows = 0, tpr = 0, chunk = 0;   // 0 = auto
 };
 
+// launch plan measured on this device for one (grid, kernel family): tile configuration + planes per workgroup (cg.hip autotune)
+struct TunedPlan {
+    int id, chunk;
+    float us;            // measured launch time of the winner
+    float us_model;      // measured launch time of the plan the analytic model would have chosen
+};
+typedef std::array<int, 10> PlanKey;   // dtype, rank, n0, n1, n2, batch, flags, flags per batch, family, vector path
+
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -114,6 +124,11 @@ struct phihip_ctx {
     int adv_last_nblk = 0;        // workgroup flags of the most recent tiled advection (ws_adv_flags): count
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
+    // first-call autotune of the CG marching kernels: the candidates of the plan model are timed once per (grid, family) on the
+    // context's own workspace and the fastest is cached here. PHIHIP_AUTOTUNE=0 in the environment / phihip_set_autotune(ctx, 0)
+    // keep the analytic plan (bit-reproducible launch geometry across processes).
+    bool autotune = true;
+    std::map<phihip::PlanKey, phihip::TunedPlan> tuned;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule
     bool small_cg = true;         // grids that fit one CU's LDS are solved by the single-kernel CG (cg_small.hip)

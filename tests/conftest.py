@@ -30,6 +30,9 @@ def _emu_is_stale():
 def emu_library():
     """ TEST INFRASTRUCTURE: the kernel sources compiled with g++ against the fiber emulation (tests/hipemu). """
     from phiflow_amd import _capi
+    # contexts on the emulation keep the analytic launch plan: timing candidates there is meaningless (and the bit-for-bit tests of
+    # tests/test_parallel_gloo.py need the same launch geometry in every process)
+    os.environ["PHIHIP_AUTOTUNE"] = "0"
     if _emu_is_stale():
         subprocess.run(["bash", os.path.join(EMU_DIR, "build_emu.sh")], check=True, stdout=subprocess.DEVNULL)
     return _capi.Library(EMU_LIB)

@@ -438,3 +438,28 @@ def test_tiled_advection_across_tiles_and_chunks(emu_ctx, res, bc):
         dom, grid = pc.make_case(res, bc, dtype, batch=2)
         for dt in (0.45, 1.4, 3.3):
             pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=dt)
+
+
+def test_autotuned_launch_plans_stay_correct(emu_library):
+    """ first-call autotune of the CG marching kernels (cg.hip autotune_cg): whatever (tile, chunk) the timings pick -- noise under the
+    emulation -- the solve must equal the oracle's, explicit tunings still win, and disabling it restores the analytic plan """
+    ctx = pc.C.Context(emu_library, 0)
+    try:
+        ctx.set_small_grid_solver(False)
+        ctx.set_autotune(True)
+        for res, bc in (((8, 12, 16), ((PER, PER), (CLO, OPN), (PER, PER))), ((20, 24), ((CLO, CLO), (PER, PER)))):
+            dom, grid = pc.make_case(res, bc, np.float32, batch=2)
+            pc.check_cg(ctx, MEM, dom, grid, np.float32, np.random.default_rng(7), max_iter=9, refresh=4, fixed_iterations=True)
+            tuned = [ctx.query_plan(grid, False, f) for f in (1, 2, 3)]
+            assert all(p["nblk"] >= 1 and p["chunk"] >= 1 for p in tuned)
+            pc.check_cg(ctx, MEM, dom, grid, np.float32, np.random.default_rng(8))          # cached plans, tolerance mode
+        dom, grid = pc.make_case((8, 12, 16), ((PER, PER),) * 3, np.float32, batch=1)
+        ctx.set_tuning(2, 16, 3)
+        assert ctx.query_plan(grid, False, 1)["chunk"] == 3 and ctx.query_plan(grid, False, 1)["rows"] == 2
+        ctx.set_tuning(0, 0, 0)
+        ctx.set_autotune(False)
+        model = [ctx.query_plan(grid, False, f) for f in (1, 2, 3)]
+        ctx2 = pc.C.Context(emu_library, 0)                                                  # PHIHIP_AUTOTUNE=0 (conftest): analytic plan
+        assert model == [ctx2.query_plan(grid, False, f) for f in (1, 2, 3)]
+    finally:
+        ctx.close()
