@@ -202,6 +202,14 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
  * batch-sharded multi-GPU run performs. */
 int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void* stream);
 
+/* The ONE collective of a batch-sharded multi-GPU step, for C / C++ callers that hold an RCCL communicator themselves (the
+ * Python layer goes through torch.distributed, whose `nccl` backend IS RCCL): all-reduces `count` device doubles in place over `comm`
+ * (an `ncclComm_t` passed as void*), op: 0 = sum, 2 = max (RCCL's ncclRedOp_t values) -- e.g. the 2 * batch values written by
+ * phihip_solve_residuals, or max over ranks of ||r|| / ||rhs||. Enqueued on `stream`; no host synchronisation. librccl is NOT a link
+ * dependency of libphihip: `ncclAllReduce` is resolved at the first call from the RCCL already loaded into the process (the one that
+ * created `comm`), else from librccl.so.1; PHIHIP_ERR_UNSUPPORTED if neither exists. */
+int phihip_allreduce_residual(phihip_ctx* ctx, void* comm, double* values_device, int count, int op, void* stream);
+
 /* ---- a6: v -= hard_bcs * spatial_gradient(p, at=face) (phi/physics/fluid.py:158-161) ---------------------------- */
 /* in-place on velocity */
 int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,

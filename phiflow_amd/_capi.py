@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_autotune",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual",
 )
 
 
@@ -217,6 +217,7 @@ class Library:
         d.phihip_set_advect_halo.argtypes = [c_void_p, c_int]
         d.phihip_set_advect_chunk.argtypes = [c_void_p, c_int]
         d.phihip_set_autotune.argtypes = [c_void_p, c_int]
+        d.phihip_allreduce_residual.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
         d.phihip_advect_fallback_stats.argtypes = [c_void_p, POINTER(c_int32 * 2), c_void_p]
         d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
         for name in EXPORTED_SYMBOLS:
@@ -448,6 +449,10 @@ class Context:
     def set_advect_halo(self, halo: int):
         """ 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles with that halo for self-advection (default 1) """
         self.lib.check(self.lib.dll.phihip_set_advect_halo(self.handle, int(halo)))
+
+    def allreduce_residual(self, comm, values_device, count, op=2, stream=0):
+        """ in-place RCCL all-reduce of `count` device doubles over the caller's ncclComm_t (op 0 = sum, 2 = max); asynchronous """
+        self.lib.check(self.lib.dll.phihip_allreduce_residual(self.handle, comm, values_device, int(count), int(op), stream or None))
 
     def set_autotune(self, enable: bool):
         """ first-call timing of the CG launch-plan candidates (default on; off = the analytic plan, reproducible launch geometry) """

@@ -1,4 +1,5 @@
 // capi.hip -- extern "C" surface of libphihip.so (declared in include/phihip.h) + context / workspace / profiling plumbing.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -550,6 +551,43 @@ int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void*
     PHIHIP_REQUIRE(ctx != nullptr && out_device != nullptr && batch >= 1, "solve_residuals: bad argument");
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
     return run_export_residuals(ctx, batch, out_device, (hipStream_t)stream);
+}
+
+// RCCL's ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream); ncclDouble = 8 (rccl.h). Resolved lazily: the library
+// that created the caller's communicator is already in the process (dlsym over the global scope finds it, e.g. torch's bundled
+// librccl); only a process without one gets a fresh librccl.so.1.
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static nccl_allreduce_fn resolve_nccl_allreduce() {
+    static nccl_allreduce_fn fn = nullptr;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        fn = (nccl_allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!fn) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) fn = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+        }
+    }
+    return fn;
+}
+
+int phihip_allreduce_residual(phihip_ctx* ctx, void* comm, double* values_device, int count, int op, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr && comm != nullptr && values_device != nullptr, "allreduce_residual: NULL argument");
+    PHIHIP_REQUIRE(count > 0, "allreduce_residual: count must be > 0");
+    PHIHIP_REQUIRE(op == 0 || op == 2, "allreduce_residual: op must be 0 (sum) or 2 (max)");
+    nccl_allreduce_fn fn = resolve_nccl_allreduce();
+    if (!fn) {
+        set_error("allreduce_residual: no RCCL in this process and librccl.so.1 cannot be loaded (%s)", dlerror() ? dlerror() : "not found");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    const int rc = fn(values_device, values_device, (size_t)count, /*ncclDouble*/ 8, op, comm, (hipStream_t)stream);
+    if (rc != 0) {
+        set_error("ncclAllReduce failed with ncclResult_t %d", rc);
+        return PHIHIP_ERR_HIP;
+    }
+    return PHIHIP_OK;
 }
 
 int phihip_grad_subtract(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p,

@@ -12,6 +12,7 @@ from . import geom
 from .geom import Box, Cuboid, Sphere, embed, infinite_cylinder, union, vec
 from .fluid import Obstacle
 from .solve import ConvergenceException, Diverged, NotConverged, Solve, SolveInfo, copy_with
+from .linear import solve_linear
 
 __all__ = [
     'advect', 'diffuse', 'fluid', 'extrapolation',
@@ -20,5 +21,5 @@ __all__ = [
     'CenteredGrid', 'Field', 'StaggeredGrid', 'assert_close', 'divergence', 'mean', 'resample', 'spatial_gradient',
     'geom', 'Box', 'Cuboid', 'Sphere', 'embed', 'infinite_cylinder', 'union', 'vec', 'Obstacle',
     'functional_gradient', 'gradient', 'jacobian', 'l2_loss', 'stop_gradient',
-    'ConvergenceException', 'Diverged', 'NotConverged', 'Solve', 'SolveInfo', 'copy_with',
+    'ConvergenceException', 'Diverged', 'NotConverged', 'Solve', 'SolveInfo', 'copy_with', 'solve_linear',
 ]

@@ -345,3 +345,6 @@ def masked_laplace(pressure: Field, v_boundary, hard_bcs=None, active=None, flag
     be.ctx.laplace_apply(grid, flags.data_ptr() if flags is not None else 0, 1, pressure.values.contiguous().data_ptr(), out.data_ptr(),
                          be.stream())
     return pressure.with_values(out)
+
+
+from .linear import _balance_divergence   # noqa: E402,F401  (fluid._balance_divergence, phi/physics/fluid.py:205-209)

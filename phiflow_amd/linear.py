@@ -1,0 +1,375 @@
+"""
+`solve_linear` and the sparse-matrix side of the drop-in boundary (reference: phi/field/__init__.py:31 re-exports
+`phiml.math.solve_linear`, call site phi/physics/fluid.py:156 `math.solve_linear(masked_laplace, div, solve, v_boundary, hard_bcs, active,
+...)`; backend selection phi/__init__.py:41-63, phi/torch/flow.py:15-35).
+
+Two entry levels:
+
+* `solve_linear(f, y, solve, *f_args)` -- the phi-level call. The linear operators this backend implements matrix-free are dispatched to
+  `phihip_cg_solve` (fluid.masked_laplace); anything else raises `NotImplementedError`, exactly like every other off-path request.
+
+* `recognise_laplace_stencil(...)` + `HipLinearSolveMixin` -- PhiML hands its backend an ASSEMBLED sparse matrix (`jit_compile_linear`,
+  fluid.py:165). A backend that wants the matrix-free kernels has to recognise the constant-coefficient 5 / 7-point pattern of
+  `masked_laplace` in that matrix: grid spacing from the off-diagonal values, periodic / Neumann / Dirichlet sides from the wrap-around
+  entries and the diagonal deficit, obstacle masks (`hard_bcs`, `active`) from missing couplings and identity rows. The recogniser
+  rebuilds the matrix from what it extracted and compares: it never guesses. `make_phiml_backend()` wraps it into a PhiML `Backend`
+  subclass when PhiML is importable.
+"""
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from .extrapolation import as_extrapolation, pressure_extrapolation
+from .field import Field, _check_pressure_padding, _torch_dtype_code, mean
+from .solve import Diverged, NotConverged, Solve, SolveInfo
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# phi level
+# ---------------------------------------------------------------------------------------------------------------------
+def _balance_divergence(div: Field, active: Optional[Field]) -> Field:
+    """ fluid._balance_divergence (phi/physics/fluid.py:205-209): the `preprocess_y` of singular pressure solves """
+    if active is not None:
+        m, ma = mean(div), mean(active)
+        shift = (m / ma).reshape(-1, *([1] * div.spatial_rank)) if div.batched or active.batched else m / ma
+        return div - active * shift
+    m = mean(div)
+    return div - (m.reshape(-1, *([1] * div.spatial_rank)) if div.batched else m)
+
+
+def solve_linear(f: Callable, y: Field, solve: Solve, *f_args, grad_for_f: bool = False, f_kwargs: Optional[dict] = None, **f_kwargs_) -> Field:
+    """ `field.solve_linear(f, y, solve, *f_args)`: solves `f(x, *f_args) = y` for x (phi/field/__init__.py:31 -> phiml.math.solve_linear).
+
+    Implemented operators (matrix-free HIP kernels, `phihip_cg_solve`):
+        `fluid.masked_laplace(pressure, v_boundary, hard_bcs, active)` with `hard_bcs` None and `active` None or a CenteredGrid mask, or
+        the packed obstacle `flags=` this backend uses in place of the two mask fields (`fluid.masked_laplace(..., flags=...)`).
+    `solve.preprocess_y(y, *solve.preprocess_y_args)` is applied first like PhiML does (fluid.py:145-148 uses it to balance the
+    divergence); `solve.x0` must be a CenteredGrid on y's grid (or None = zeros). Raises `NotConverged` / `Diverged` unless suppressed. """
+    from . import fluid
+    kwargs = dict(f_kwargs or {}, **f_kwargs_)
+    if f is not fluid.masked_laplace:
+        raise NotImplementedError(f"HIP backend: solve_linear implements fluid.masked_laplace only, got {getattr(f, '__name__', f)!r}")
+    if grad_for_f:
+        raise NotImplementedError("HIP backend: solve_linear(grad_for_f=True)")
+    if not isinstance(y, Field) or y.is_staggered:
+        raise NotImplementedError("HIP backend: solve_linear needs a CenteredGrid right-hand side")
+    if len(f_args) < 1:
+        raise TypeError("masked_laplace needs the velocity boundary: solve_linear(masked_laplace, y, solve, v_boundary, hard_bcs, active)")
+    v_boundary = as_extrapolation(f_args[0])
+    hard_bcs = f_args[1] if len(f_args) > 1 else kwargs.pop('hard_bcs', None)
+    active = f_args[2] if len(f_args) > 2 else kwargs.pop('active', None)
+    flags = kwargs.pop('flags', None)
+    for name, ok in (('wide_stencil', (False, None)), ('order', (2,)), ('implicit', (None,)), ('upwind', (None,)), ('correct_skew', (False,))):
+        if kwargs.pop(name, ok[0]) not in ok:
+            raise NotImplementedError(f"HIP backend: masked_laplace({name}=...) is not implemented")
+    if kwargs:
+        raise TypeError(f"unexpected arguments for masked_laplace: {sorted(kwargs)}")
+    if hard_bcs is not None:
+        raise NotImplementedError("HIP backend: pass the packed obstacle `flags=` (fluid._MASKS / phihip_build_cellflags) instead of a hard_bcs field")
+    be = y.backend
+    if solve.method not in Solve.METHODS:
+        raise NotImplementedError(f"HIP backend: Solve(method={solve.method!r}) is not available, use one of {tuple(Solve.METHODS)}")
+    if solve.preprocess_y is not None:
+        y = solve.preprocess_y(y, *solve.preprocess_y_args)
+    fp64 = y.dtype == torch.float64
+    proto = Field(y.resolution, y.bounds, v_boundary, None, True, be, y.batched)
+    B = y.batch_size
+    res_shape = tuple(y.resolution.values())
+    mask_batch = 1
+    if flags is None and active is not None:
+        assert isinstance(active, Field) and active.is_centered and active.resolution == y.resolution, "active must be a CenteredGrid on y's grid"
+        act = (active.values != 0).to(torch.uint8).contiguous()
+        mask_batch = act.shape[0] if act.shape[0] > 1 else 1
+        if mask_batch > 1:
+            assert mask_batch in (B, 1) or B == 1, "batch of `active` does not match the right-hand side"
+            B = max(B, mask_batch)
+        flags = be.empty((mask_batch,) + res_shape if mask_batch > 1 else res_shape, torch.uint8)
+        gmask = _capi.make_grid(y.spatial_rank, _torch_dtype_code(y.dtype), mask_batch, list(res_shape), y.bounds.lower, y.bounds.upper,
+                                proto._codes, proto._bc_val)
+        be.ctx.build_cellflags(gmask, 0, act.data_ptr(), mask_batch, flags.data_ptr(), be.stream())
+    elif flags is not None:
+        flags = flags.contiguous()
+        mask_batch = flags.shape[0] if flags.dim() == y.spatial_rank + 1 and flags.shape[0] > 1 else 1
+    rhs = y.values if y.values.shape[0] == B else y.values.expand(B, *res_shape)
+    rhs = rhs.contiguous()
+    p_ext = pressure_extrapolation(v_boundary, y.dims)
+    if solve.x0 is None:
+        x = be.zeros((B,) + res_shape, y.dtype)
+    else:
+        x0 = solve.x0
+        assert isinstance(x0, Field) and x0.is_centered and x0.resolution == y.resolution, "x0 must be a CenteredGrid on y's grid"
+        _check_pressure_padding(x0.boundary, v_boundary, y.dims)
+        x = x0.values.to(y.dtype)
+        x = (x.expand(B, *res_shape) if x.shape[0] != B else x).clone().contiguous()
+    grid = _capi.make_grid(y.spatial_rank, _torch_dtype_code(y.dtype), B, list(res_shape), y.bounds.lower, y.bounds.upper, proto._codes, proto._bc_val)
+    s = solve.with_defaults(fp64)
+    infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, mask_batch, rhs.data_ptr(), x.data_ptr(), s.to_c(fp64), True, be.stream())
+    info = SolveInfo(s, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+    from .fluid import _raise_if_failed
+    _raise_if_failed(info)
+    out = Field(y.resolution, y.bounds, p_ext, x, False, be, y.batched or B > 1)
+    out.solve_info = info
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sparse-matrix level: recognise masked_laplace in an assembled matrix
+# ---------------------------------------------------------------------------------------------------------------------
+class NotALaplaceStencil(ValueError):
+    """ the matrix is not the 5 / 7-point `masked_laplace` of a uniform grid (the caller falls back to its generic solver) """
+
+
+def _neighbour_index(res: Sequence[int], axis: int, shift: int, wrap: bool):
+    """ flat index of the neighbour of every cell along `axis` (-1 where it lies outside and `wrap` is False) """
+    idx = np.arange(int(np.prod(res))).reshape(res)
+    nb = np.roll(idx, -shift, axis=axis)
+    if not wrap:
+        edge = [slice(None)] * len(res)
+        edge[axis] = (0 if shift < 0 else res[axis] - 1)
+        nb = nb.copy()
+        nb[tuple(edge)] = -1
+    return nb.ravel()
+
+
+def assemble_laplace(res: Sequence[int], weights: Sequence[float], bc: Sequence[Tuple[int, int]], flags: Optional[np.ndarray] = None):
+    """ CSR matrix of the operator the HIP kernels apply for this description (stencil_march.hpp `march_kernel`):
+        row c = sum over faces f of c [open for flux] * w_axis * (x[neighbour] - x[c]), ghost 0 beyond an OPEN side, no flux through a
+        CLOSED side; inactive cells (flags bit 6 clear) are identity rows. Flag bits as phihip_build_cellflags packs them: bit
+        2 * internal axis + side with internal axis = axis + 3 - rank (2-D grids use the bits of a1, a2), bit 6 = active. bc codes: _capi.BC_PERIODIC / BC_CLOSED / BC_OPEN per (axis,
+        side) of the VELOCITY (pressure: periodic / Neumann / Dirichlet). """
+    import scipy.sparse as sp
+    res = tuple(int(r) for r in res)
+    N = int(np.prod(res))
+    rows, cols, vals = [], [], []
+    diag = np.zeros(N)
+    fl = None if flags is None else np.asarray(flags, np.uint8).ravel()
+    active = np.ones(N, bool) if fl is None else (fl & 64) != 0
+    for a in range(len(res)):
+        for side, shift in ((0, -1), (1, 1)):
+            periodic = bc[a][side] == _capi.BC_PERIODIC
+            nb = _neighbour_index(res, a, shift, periodic)
+            open_face = np.ones(N, bool) if fl is None else ((fl >> (2 * (a + 3 - len(res)) + side)) & 1) != 0      # bits of the INTERNAL axis
+            if fl is None:
+                open_face = (nb >= 0) | (bc[a][side] == _capi.BC_OPEN)
+            couple = open_face & (nb >= 0) & active
+            rows.append(np.nonzero(couple)[0]); cols.append(nb[couple]); vals.append(np.full(int(couple.sum()), float(weights[a])))
+            diag -= np.where(open_face & active, float(weights[a]), 0.0)
+    diag = np.where(active, diag, 1.0)
+    rows.append(np.arange(N)); cols.append(np.arange(N)); vals.append(diag)
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N))
+    A.sum_duplicates()
+    return A
+
+
+def recognise_laplace_stencil(matrix, resolution: Sequence[int], rtol: float = 1e-5) -> Dict:
+    """ -> dict(weights=[1/dx_a^2], bc=[(lower, upper) codes], flags=uint8 array of shape `resolution` or None)
+    for a SciPy sparse `matrix` (N x N, N = prod(resolution), cells in C order) that is `masked_laplace` on that grid; raises
+    `NotALaplaceStencil` otherwise. `flags` is None when the matrix is the obstacle-free operator. """
+    import scipy.sparse as sp
+    res = tuple(int(r) for r in resolution)
+    N = int(np.prod(res))
+    A = sp.csr_matrix(matrix).astype(np.float64)
+    A.sum_duplicates()
+    if A.shape != (N, N):
+        raise NotALaplaceStencil(f"matrix shape {A.shape} does not match the grid {res}")
+    D = len(res)
+    if D not in (2, 3) or A.nnz > (2 * D + 1) * N:
+        raise NotALaplaceStencil("more than 2 D + 1 entries per row")
+    coo = A.tocoo()
+    row, col, val = coo.row, coo.col, coo.data
+    off = row != col
+    diag = np.zeros(N)
+    np.add.at(diag, row[~off], val[~off])
+    weights, bc = [], []
+    face_bits = np.zeros(N, np.uint8)
+    claimed = np.zeros(int(off.sum()), bool)
+    r_off, c_off, v_off = row[off], col[off], val[off]
+    for a in range(D):
+        sides, w_axis = [], None
+        per_axis = []
+        for side, shift in ((0, -1), (1, 1)):
+            nb_in = _neighbour_index(res, a, shift, False)         # inside neighbours only
+            nb_wrap = _neighbour_index(res, a, shift, True)
+            hit_in = (nb_in[r_off] == c_off)
+            wraps = (nb_in[r_off] < 0) & (nb_wrap[r_off] == c_off) & (res[a] > 2)
+            per_axis.append((hit_in, wraps))
+            vals_here = v_off[hit_in | wraps]
+            if vals_here.size:
+                w = float(np.median(vals_here))
+                w_axis = w if w_axis is None else w_axis
+        if w_axis is None or w_axis <= 0:
+            raise NotALaplaceStencil(f"no coupling along axis {a}")
+        for side, (hit_in, wraps) in enumerate(per_axis):
+            sel = hit_in | wraps
+            if np.any(np.abs(v_off[sel] - w_axis) > rtol * w_axis):
+                raise NotALaplaceStencil(f"couplings along axis {a} are not one constant 1/dx^2")
+            claimed |= sel
+            face_bits[r_off[sel]] |= np.uint8(1 << (2 * (a + 3 - D) + side))
+            sides.append(bool(np.any(wraps)))
+        weights.append(w_axis)
+        bc.append(tuple(sides))
+    if not np.all(claimed):
+        raise NotALaplaceStencil("couplings between cells that are not face neighbours")
+    # identity rows = inactive cells; every other row: diagonal = -(sum of couplings) - w * (number of Dirichlet faces)
+    row_sum = np.zeros(N)
+    np.add.at(row_sum, r_off, v_off)
+    inactive = (row_sum == 0) & (np.abs(diag - 1.0) <= rtol) & (face_bits == 0)
+    bc_codes = []
+    for a in range(D):
+        codes = []
+        for side, shift in ((0, -1), (1, 1)):
+            if bc[a][side]:
+                codes.append(_capi.BC_PERIODIC)
+                continue
+            edge = _neighbour_index(res, a, shift, False) < 0
+            cand = edge & ~inactive
+            deficit = -(diag + row_sum)                              # = w * (Dirichlet faces of the row) for an active row
+            # a boundary row of this side is Dirichlet iff its deficit contains this axis' weight; rows touching several boundaries
+            # are ambiguous on their own, rows touching only this one decide
+            only = cand.copy()
+            for a2 in range(D):
+                for side2, shift2 in ((0, -1), (1, 1)):
+                    if (a2, side2) != (a, side):
+                        only &= ~(_neighbour_index(res, a2, shift2, False) < 0) | bool(bc[a2][side2])
+            pick = only if np.any(only) else cand
+            if not np.any(pick):
+                codes.append(_capi.BC_CLOSED)
+                continue
+            frac = np.median(deficit[pick]) / weights[a]
+            codes.append(_capi.BC_OPEN if frac > 0.5 else _capi.BC_CLOSED)
+        if (codes[0] == _capi.BC_PERIODIC) != (codes[1] == _capi.BC_PERIODIC):
+            raise NotALaplaceStencil(f"axis {a} wraps on one side only")
+        bc_codes.append(tuple(codes))
+    # flags: coupling bits + the faces towards an OPEN side (flux into the zero ghost) + active
+    flags = face_bits.copy()
+    for a in range(D):
+        for side, shift in ((0, -1), (1, 1)):
+            if bc_codes[a][side] == _capi.BC_OPEN:
+                edge = _neighbour_index(res, a, shift, False) < 0
+                flags[edge & ~inactive] |= np.uint8(1 << (2 * (a + 3 - D) + side))
+    flags[~inactive] |= np.uint8(64)
+    plain = assemble_laplace(res, weights, bc_codes, None)
+    masked = assemble_laplace(res, weights, bc_codes, flags.reshape(res))
+    def same(X):
+        d = (X - A).tocoo()
+        return d.nnz == 0 or float(np.abs(d.data).max()) <= rtol * max(weights)
+    if same(plain):
+        return dict(weights=weights, bc=bc_codes, flags=None)
+    if same(masked):
+        return dict(weights=weights, bc=bc_codes, flags=flags.reshape(res))
+    raise NotALaplaceStencil("the matrix is not reproduced by the recognised (spacing, boundary, mask) description")
+
+
+class HipLinearSolveMixin:
+    """ `linear_solve` / `conjugate_gradient` override for a PhiML `Backend` ([PHIML-RECALL] signatures of phiml.backend.Backend:
+    `linear_solve(self, method, lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)`). `lin` = the sparse matrix PhiML assembled;
+    when it is recognised as `masked_laplace` on the grid whose resolution the caller registered (`set_grid_resolution`, or the cube /
+    square root of N), the solve runs on `phihip_cg_solve`; otherwise `super()` handles it. """
+
+    hip_resolution: Optional[Tuple[int, ...]] = None
+
+    def set_grid_resolution(self, resolution: Optional[Sequence[int]]):
+        self.hip_resolution = tuple(int(r) for r in resolution) if resolution is not None else None
+
+    def _hip_backend(self):
+        from .backend import default_backend
+        return default_backend()
+
+    def _as_scipy(self, lin):
+        import scipy.sparse as sp
+        if sp.issparse(lin):
+            return lin
+        if isinstance(lin, torch.Tensor) and lin.layout in (torch.sparse_csr, torch.sparse_coo):
+            t = lin.to_sparse_coo().coalesce().cpu()
+            i = t.indices().numpy()
+            return sp.csr_matrix((t.values().numpy(), (i[0], i[1])), shape=tuple(t.shape))
+        raise NotALaplaceStencil(f"unsupported matrix type {type(lin).__name__}")
+
+    def hip_linear_solve(self, method: str, lin, y, x0, rtol, atol, max_iter):
+        """ returns (x, iterations, residual_sq, converged, diverged) as torch tensors / lists, or raises NotALaplaceStencil """
+        if method not in ('CG', 'auto', 'CG-adaptive'):
+            raise NotALaplaceStencil(f"method {method}")
+        A = self._as_scipy(lin)
+        N = A.shape[0]
+        res = self.hip_resolution
+        if res is None or int(np.prod(res)) != N:
+            for D in (3, 2):
+                n = round(N ** (1.0 / D))
+                if n ** D == N:
+                    res = (n,) * D
+                    break
+            else:
+                raise NotALaplaceStencil("grid resolution unknown")
+        d = recognise_laplace_stencil(A, res)
+        be = self._hip_backend()
+        yt = torch.as_tensor(y).to(be.device)
+        fp64 = yt.dtype == torch.float64
+        yt = yt.reshape(-1, *res).contiguous()
+        B = yt.shape[0]
+        xt = torch.as_tensor(x0).to(device=be.device, dtype=yt.dtype).reshape(-1, *res).expand(B, *res).clone().contiguous()
+        dx = [1.0 / float(np.sqrt(w)) for w in d['weights']]
+        grid = _capi.make_grid(len(res), _capi.PHIHIP_F64 if fp64 else _capi.PHIHIP_F32, B, list(res), [0.0] * len(res),
+                               [n * h for n, h in zip(res, dx)], d['bc'])
+        flags = None if d['flags'] is None else torch.as_tensor(d['flags']).to(be.device).contiguous()
+        scalar = lambda v, default: float(np.max(np.asarray(v if v is not None else default, dtype=np.float64)))
+        csolve = _capi.Solve(scalar(rtol, 1e-5), scalar(atol, 0.0), int(np.max(np.asarray(max_iter))), 20 if method == 'CG-adaptive' else 50, 10,
+                             1 if method == 'CG-adaptive' else 0)
+        infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, 1, yt.data_ptr(), xt.data_ptr(), csolve, True, be.stream())
+        return (xt.reshape(B, N), [i.iterations for i in infos], [i.residual_sq for i in infos], [bool(i.converged) for i in infos],
+                [bool(i.diverged) for i in infos])
+
+
+def make_phiml_backend():
+    """ A PhiML `Backend` named 'hip' (reference: phi/__init__.py:41-63 `detect_backends`, phi/torch/flow.py:31-32): PhiML's torch backend
+    (tensors stay torch-ROCm) with `grid_sample` and `linear_solve` routed to libphihip, registered in `phiml.backend.BACKENDS`.
+    Raises ImportError without PhiML. """
+    from phiml import backend as pb                                  # noqa: F401
+    try:
+        from phiml.backend.torch import TORCH                        # [PHIML-RECALL] singleton of the torch backend
+        base = type(TORCH)
+    except Exception:
+        base = pb.Backend
+
+    class HipPhimlBackend(HipLinearSolveMixin, base):
+        def __init__(self, *args, **kwargs):
+            try:
+                super().__init__(*args, **kwargs)
+            except TypeError:
+                super().__init__('hip', [], None)
+            self._name = 'hip'
+
+        @property
+        def name(self):
+            return 'hip'
+
+        def grid_sample(self, grid, coordinates, extrapolation: str):
+            """ `math.grid_sample` hot loop of advection (phi/field/_resample.py:259): natives (batch, x, y[, z], channels), coordinates
+            (batch, points..., D) as fractional indices; extrapolation 'periodic' | 'boundary' | 'zeros' | 'constant' """
+            from .sampling import backend_grid_sample
+            out = backend_grid_sample(self._hip_backend(), grid, coordinates, extrapolation)
+            return out if out is not None else super().grid_sample(grid, coordinates, extrapolation)
+
+        def linear_solve(self, method, lin, y, x0, rtol, atol, max_iter, pre=None, matrix_offset=None):
+            try:
+                if pre is not None or matrix_offset is not None:
+                    raise NotALaplaceStencil("preconditioner / rank-deficiency offset")
+                x, iterations, residual_sq, converged, diverged = self.hip_linear_solve(method, lin, y, x0, rtol, atol, max_iter)
+            except NotALaplaceStencil:
+                return super().linear_solve(method, lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)
+            result_type = getattr(pb, 'SolveResult', None)
+            if result_type is None:
+                return x
+            it = torch.as_tensor(iterations)
+            return result_type(f"HIP {method}", x, torch.as_tensor(residual_sq).sqrt().reshape(-1, 1).expand_as(x), it, it,
+                               torch.as_tensor(converged), torch.as_tensor(diverged), [""] * len(iterations))
+
+        def conjugate_gradient(self, lin, y, x0, rtol, atol, max_iter, pre=None, matrix_offset=None):
+            return self.linear_solve('CG', lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)
+
+    hip = HipPhimlBackend()
+    if all(getattr(b, 'name', None) != 'hip' for b in pb.BACKENDS):
+        pb.BACKENDS.append(hip)
+    return hip

@@ -176,3 +176,31 @@ def advect_general(field: Field, velocity: Field, dt: float, correction_strength
         outs.append(new.reshape(B, *shape))
     batched = field.batched or velocity.batched
     return Field(field.resolution, field.bounds, field.boundary, outs[0] if field.is_centered else outs, field.is_staggered, field.backend, batched)
+
+
+def backend_grid_sample(be, grid: torch.Tensor, coordinates: torch.Tensor, extrapolation: str):
+    """ PhiML's `Backend.grid_sample(grid, coordinates, extrapolation)` on natives (reference call site phi/field/_resample.py:259
+    `math.grid_sample`): `grid` (batch, x, y[, z], channels), `coordinates` (batch, *points, D) as fractional
+    indices, extrapolation 'periodic' | 'boundary' | 'zeros'. One `phihip_grid_sample` launch per channel. Returns None for anything
+    else (the caller falls back to its generic gather). """
+    rule = {'periodic': (_capi.BC_PERIODIC, 0.0), 'boundary': (_capi.BC_OPEN, 0.0), 'zeros': (_capi.BC_CLOSED, 0.0)}.get(extrapolation)
+    D = coordinates.shape[-1]
+    if rule is None or D not in (2, 3) or grid.dim() != D + 2 or grid.dtype not in (torch.float32, torch.float64):
+        return None
+    code, const = rule
+    B = max(grid.shape[0], coordinates.shape[0])
+    pts_shape = tuple(coordinates.shape[1:-1])
+    npts = int(np.prod(pts_shape)) if pts_shape else 1
+    coords = coordinates.to(device=be.device, dtype=grid.dtype).reshape(coordinates.shape[0], npts, D)
+    coords = coords.expand(B, npts, D)
+    cs = [coords[..., d].contiguous() for d in range(D)]
+    res = list(grid.shape[1:-1])
+    g = _capi.make_grid(D, _torch_dtype_code(grid.dtype), B, res, (0.0,) * D, (1.0,) * D, ((code, code),) * D,
+                        [[[const, 0.0, 0.0] for _ in range(2)] for _ in range(D)])
+    out = torch.empty((B, npts, grid.shape[-1]), dtype=grid.dtype, device=be.device)
+    for c in range(grid.shape[-1]):
+        values = grid[..., c].to(be.device).contiguous()
+        oc = torch.empty((B, npts), dtype=grid.dtype, device=be.device)
+        be.ctx.grid_sample(g, values.data_ptr(), values.shape[0], _ptrs(cs), npts, oc.data_ptr(), 0, 0, be.stream())
+        out[..., c] = oc
+    return out.reshape((B,) + pts_shape + (grid.shape[-1],))

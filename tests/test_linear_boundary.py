@@ -1,0 +1,169 @@
+"""
+SURVEY §8b, the solve_linear side of the drop-in boundary (`-m "not gpu"`, kernel sources under emulation):
+  * `flow.solve_linear(fluid.masked_laplace, div, solve, v_boundary, hard_bcs, active)` -- signature of phi/field/__init__.py:31 /
+    call site phi/physics/fluid.py:156 -- against the oracle's CG and against `make_incompressible`;
+  * the sparse-matrix recogniser a PhiML `Backend.linear_solve` override needs (PhiML hands the backend an ASSEMBLED matrix): pinned to
+    `oracle.laplace_csr` (what the reference's NumPy backend iterates on) for every boundary mix, and to dense probes of
+    `oracle.masked_laplace` with obstacle masks;
+  * `HipLinearSolveMixin.hip_linear_solve`: matrix in -> phihip_cg_solve -> same solution as the oracle.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import phi_oracle as O
+from phiflow_amd import _capi as C
+from phiflow_amd import linear
+from phiflow_amd.flow import (BOUNDARY, PERIODIC, ZERO, Box, CenteredGrid, NotConverged, Solve, StaggeredGrid, combine_sides, divergence, fluid,
+                              solve_linear)
+
+CODES = {O.PERIODIC: C.BC_PERIODIC, O.CLOSED: C.BC_CLOSED, O.OPEN: C.BC_OPEN}
+
+
+def _dense_operator(dom, hard, active):
+    N = int(np.prod(dom.res))
+    cols = []
+    for k in range(N):
+        e = np.zeros((1,) + dom.res)
+        e.reshape(-1)[k] = 1.0
+        cols.append(O.masked_laplace(e, dom, hard, active).reshape(-1))
+    return np.stack(cols, axis=1)
+
+
+@pytest.mark.parametrize("res", [(6, 5), (4, 5, 6)])
+def test_recogniser_pinned_to_the_assembled_reference_operator(res):
+    sides = [(O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED), (O.OPEN, O.OPEN), (O.CLOSED, O.OPEN), (O.OPEN, O.CLOSED)]
+    upper = tuple(float(n) * (0.5 + 0.25 * a) for a, n in enumerate(res))          # different dx per axis
+    for bc in itertools.product(sides, repeat=len(res)):
+        dom = O.Domain(res, (0.0,) * len(res), upper, bc)
+        A = O.laplace_csr(dom, np.float64)
+        d = linear.recognise_laplace_stencil(A, res)
+        assert d['flags'] is None
+        assert d['bc'] == [tuple(CODES[c] for c in pair) for pair in bc], (bc, d['bc'])
+        np.testing.assert_allclose(d['weights'], [1.0 / h ** 2 for h in dom.dx], rtol=1e-12)
+        rebuilt = linear.assemble_laplace(res, d['weights'], d['bc'], None)
+        assert abs(rebuilt - A).max() <= 1e-12 * max(d['weights'])
+
+
+def test_recogniser_with_obstacle_masks_and_rejections():
+    dom = O.Domain((7, 6), (0, 0), (7, 6), ((O.CLOSED, O.OPEN), (O.PERIODIC, O.PERIODIC)))
+    obstacles = [O.BoxObstacle((2.0, 1.0), (4.0, 3.0))]
+    active, hard, _ = O.obstacle_masks(obstacles, dom, np.float64)
+    dense = _dense_operator(dom, hard, active)
+    d = linear.recognise_laplace_stencil(sp.csr_matrix(dense), dom.res)
+    assert d['bc'] == [(C.BC_CLOSED, C.BC_OPEN), (C.BC_PERIODIC, C.BC_PERIODIC)] and d['flags'] is not None
+    assert np.array_equal((d['flags'] >> 6) & 1, (active[0] > 0).astype(np.uint8))
+    np.testing.assert_allclose(linear.assemble_laplace(dom.res, d['weights'], d['bc'], d['flags']).toarray(), dense, atol=1e-12)
+    # the same description drives the HIP kernels: flags from the recogniser == flags from phihip_build_cellflags (checked in the solve below)
+    bad = sp.csr_matrix(dense).tolil()
+    bad[3, 20] = 0.5                                        # a coupling between cells that are not neighbours
+    with pytest.raises(linear.NotALaplaceStencil):
+        linear.recognise_laplace_stencil(bad.tocsr(), dom.res)
+    var = sp.csr_matrix(dense).tolil()
+    var[8, 9] *= 1.5                                        # a variable coefficient
+    with pytest.raises(linear.NotALaplaceStencil):
+        linear.recognise_laplace_stencil(var.tocsr(), dom.res)
+    with pytest.raises(linear.NotALaplaceStencil):
+        linear.recognise_laplace_stencil(sp.identity(41, format='csr'), dom.res)
+
+
+def test_solve_linear_matches_make_incompressible_and_the_oracle(emu_backend):
+    rng = np.random.default_rng(3)
+    for ext, bc in ((ZERO, ((O.CLOSED, O.CLOSED),) * 2), (PERIODIC, ((O.PERIODIC, O.PERIODIC),) * 2),
+                    (combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY)), ((O.OPEN, O.OPEN), (O.CLOSED, O.OPEN)))):
+        bounds = Box(x=100, y=100)
+        shapes = StaggeredGrid(0, ext, bounds, x=16, y=20, backend=emu_backend).component_shapes
+        v = StaggeredGrid([0.1 * rng.standard_normal((2,) + s).astype(np.float32) for s in shapes], ext, bounds, x=16, y=20, backend=emu_backend)
+        div = divergence(v)
+        solve = Solve('CG', 1e-5, 0)
+        if not ext.is_flexible:
+            solve = solve.with_preprocessing(fluid._balance_divergence, None)          # fluid.py:145-148
+        p = solve_linear(fluid.masked_laplace, div, solve, v.boundary, None, None)
+        v2, p_ref = fluid.make_incompressible(v, (), Solve('CG', 1e-5, 0))
+        assert p.solve_info.iterations == p_ref.solve_info.iterations and all(p.solve_info.converged)
+        np.testing.assert_allclose(p.numpy(), p_ref.numpy(), rtol=0, atol=2e-6 * np.abs(p_ref.numpy()).max())
+        dom = O.Domain((16, 20), (0, 0), (100, 100), bc)
+        _, po, _, _ = O.make_incompressible([a.copy() for a in v.numpy()], dom, rtol=1e-5, atol=0.0)
+        a, b = p.numpy(), po
+        if not dom.flexible():
+            a, b = a - a.mean(axis=(1, 2), keepdims=True), b - b.mean(axis=(1, 2), keepdims=True)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-3
+    # x0, suppress and the error behaviour of math.solve_linear
+    p2 = solve_linear(fluid.masked_laplace, div, Solve('CG', 1e-5, 0, x0=p), v.boundary, None, None)
+    assert max(p2.solve_info.iterations) <= 2
+    with pytest.raises(NotConverged):
+        solve_linear(fluid.masked_laplace, div, Solve('CG', 1e-7, 0, max_iterations=3), v.boundary, None, None)
+    p3 = solve_linear(fluid.masked_laplace, div, Solve('CG', 1e-7, 0, max_iterations=3, suppress=[NotConverged]), v.boundary, None, None)
+    assert p3.solve_info.iterations == [3, 3]
+    with pytest.raises(NotImplementedError):
+        solve_linear(lambda x: x, div, Solve())
+    with pytest.raises(NotImplementedError):
+        solve_linear(fluid.masked_laplace, div, Solve(), v.boundary, None, None, order=4)
+
+
+def test_solve_linear_with_an_active_mask(emu_backend):
+    """ `active` as a CenteredGrid mask (phi/physics/fluid.py:113-114,139-144): identity rows for inactive cells """
+    rng = np.random.default_rng(4)
+    bounds = Box(x=12, y=10)
+    mask = np.ones((12, 10), np.float32)
+    mask[4:7, 3:6] = 0
+    active = CenteredGrid(mask, 0, bounds, x=12, y=10, backend=emu_backend)
+    y = CenteredGrid(rng.standard_normal((12, 10)).astype(np.float32) * mask, 0, bounds, x=12, y=10, backend=emu_backend)
+    p = solve_linear(fluid.masked_laplace, y, Solve('CG', 1e-6, 0), ZERO, None, active)
+    dom = O.Domain((12, 10), (0, 0), (12, 10), ((O.CLOSED, O.CLOSED),) * 2)
+    A = lambda q: O.masked_laplace(q, dom, None, mask[None])
+    xo, info = O.cg(A, y.numpy()[None], np.zeros((1, 12, 10), np.float32), 1e-6, 0.0, 1000)
+    assert np.linalg.norm(p.numpy() - xo[0]) / np.linalg.norm(xo[0]) <= 1e-3
+    np.testing.assert_allclose(p.numpy()[4:7, 3:6], y.numpy()[4:7, 3:6], atol=1e-6)      # identity rows: p = y there
+
+
+def test_backend_linear_solve_from_an_assembled_matrix(emu_backend):
+    """ what a PhiML `Backend.linear_solve` override does: matrix (as PhiML traces it) -> recognise -> phihip_cg_solve """
+    class Probe(linear.HipLinearSolveMixin):
+        def _hip_backend(self):
+            return emu_backend
+    be = Probe()
+    rng = np.random.default_rng(5)
+    for res, bc, obstacles in (((10, 12), ((O.CLOSED, O.CLOSED), (O.PERIODIC, O.PERIODIC)), ()),
+                               ((6, 5, 8), ((O.OPEN, O.OPEN), (O.CLOSED, O.CLOSED), (O.PERIODIC, O.PERIODIC)), ()),
+                               ((9, 8), ((O.CLOSED, O.OPEN), (O.CLOSED, O.CLOSED)), [O.BoxObstacle((3.0, 2.0), (5.0, 5.0))])):
+        dom = O.Domain(res, (0.0,) * len(res), tuple(float(n) for n in res), bc)
+        hard = active = None
+        if obstacles:
+            active, hard, _ = O.obstacle_masks(obstacles, dom, np.float64)
+            A = sp.csr_matrix(_dense_operator(dom, hard, active))
+        else:
+            A = O.laplace_csr(dom, np.float64)
+        be.set_grid_resolution(res)
+        y = rng.standard_normal((2,) + res).astype(np.float32)
+        if active is not None:
+            y *= active.astype(np.float32)
+        if not dom.flexible() and active is None:
+            y -= y.mean(axis=tuple(range(1, y.ndim)), keepdims=True)
+        x, its, rsq, conv, div = be.hip_linear_solve('CG', A, y.reshape(2, -1), np.zeros((2, A.shape[0]), np.float32), 1e-5, 0.0, 1000)
+        assert all(conv) and not any(div)
+        xo, info = O.cg(lambda q: O.masked_laplace(q, dom, hard, active), y, np.zeros_like(y), 1e-5, 0.0, 1000)
+        a, b = x.numpy().reshape(y.shape), xo
+        if not dom.flexible() and active is None:
+            a, b = a - a.mean(axis=tuple(range(1, a.ndim)), keepdims=True), b - b.mean(axis=tuple(range(1, b.ndim)), keepdims=True)
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-3, (res, bc)
+    with pytest.raises(linear.NotALaplaceStencil):
+        be.hip_linear_solve('biCG', A, y.reshape(2, -1), np.zeros((2, A.shape[0]), np.float32), 1e-5, 0.0, 10)
+
+
+def test_backend_grid_sample_matches_the_oracle(emu_backend):
+    """ PhiML `Backend.grid_sample(grid, coordinates, extrapolation)` on natives -> phihip_grid_sample (math.grid_sample, B.4) """
+    import torch
+    from phiflow_amd.sampling import backend_grid_sample
+    rng = np.random.default_rng(6)
+    grid = rng.standard_normal((2, 7, 9, 3)).astype(np.float32)
+    coords = (rng.random((2, 11, 5, 2)) * np.array([9.0, 12.0]) - 1.5).astype(np.float32)
+    for name, code in (('periodic', O.PERIODIC), ('boundary', O.OPEN), ('zeros', O.CLOSED)):
+        out = backend_grid_sample(emu_backend, torch.as_tensor(grid), torch.as_tensor(coords), name)
+        assert tuple(out.shape) == (2, 11, 5, 3)
+        for c in range(3):
+            ref = O.grid_sample(grid[..., c], [coords[..., 0].reshape(2, -1), coords[..., 1].reshape(2, -1)], ((code, code),) * 2, ((0.0, 0.0),) * 2)
+            np.testing.assert_allclose(out.numpy()[..., c].reshape(2, -1), ref, atol=2e-5)
+    assert backend_grid_sample(emu_backend, torch.as_tensor(grid), torch.as_tensor(coords), 'symmetric') is None
