@@ -88,6 +88,91 @@ class FluidStep:
         return None
 
 
+class SmokeBatchStep:
+    """ BASELINE.json configs[3] (`--workload config4`): `total` independent 2-D smoke plumes of n^2 cells (closed box 100 x 100, inflow
+    sphere at x in linspace(30, 70, total), buoyancy (0, 0.1), dt = 1 -- Batched_Smoke / Smoke_Plume.ipynb cell 5), block-distributed over
+    the ranks (phiflow_amd.parallel.local_batch_range): this rank owns entries [b0, b1). One step = mac_cormack(smoke) + inflow,
+    semi_lagrangian(v) + buoyancy resample, projection from the previous pressure with exactly `cg_iters` CG iterations. """
+
+    def __init__(self, ctx, n, total, rank, world, cg_iters, device):
+        from phiflow_amd.parallel import local_batch_range
+        self.ctx, self.n, self.device = ctx, n, device
+        self.b0, self.b1 = local_batch_range(total, rank, world)
+        B = self.batch = self.b1 - self.b0
+        clo = ((C.BC_CLOSED, C.BC_CLOSED),) * 2
+        self.grid = C.make_grid(2, C.PHIHIP_F32, max(B, 1), (n, n), (0, 0), (100.0, 100.0), clo)
+        h = 100.0 / n
+        c = (torch.arange(n, device=device, dtype=torch.float64) + 0.5) * h
+        xs = torch.linspace(30.0, 70.0, total, dtype=torch.float64, device=device)[self.b0:self.b1]
+        inside = ((c[None, :, None] - xs[:, None, None]) ** 2 + (c[None, None, :] - 9.5) ** 2) <= 25.0
+        self.inflow = (0.2 * inside).to(torch.float32).contiguous()
+        z = lambda *shape: torch.zeros(max(B, 1), *shape, device=device, dtype=torch.float32)
+        self.smoke, self.smoke2 = z(n, n), z(n, n)
+        self.v, self.v2 = [z(n - 1, n), z(n, n - 1)], [z(n - 1, n), z(n, n - 1)]
+        self.p = z(n, n)
+        self.res = torch.zeros(max(B, 1), 2, device=device, dtype=torch.float64)
+        self.solve = C.Solve(0.0, 0.0, cg_iters, 50, 0, 0)
+        self.s_bc = ((C.BC_OPEN, C.BC_OPEN),) * 2            # ZERO_GRADIENT smoke
+        self.stream = int(torch.cuda.current_stream(device).cuda_stream)
+
+    def step(self, allreduce=None):
+        ctx, s, g = self.ctx, self.stream, self.grid
+        rel = torch.zeros(1, device=self.device, dtype=torch.float64)
+        if self.batch > 0:
+            P = lambda ts: [t.data_ptr() for t in ts]
+            ctx.mac_cormack_centered(g, self.smoke.data_ptr(), self.s_bc, None, P(self.v), self.smoke2.data_ptr(), 1.0, 1.0, s)
+            self.smoke2 += self.inflow
+            ctx.advect_staggered(g, P(self.v), P(self.v), P(self.v2), 1.0, s)
+            ctx.centered_to_staggered(g, self.smoke2.data_ptr(), self.s_bc, None, (0.0, 0.1), True, P(self.v2), s)
+            ctx.make_incompressible(g, P(self.v2), None, 0, 1, True, self.p.data_ptr(), 0, self.solve, want_info=False, stream=s)
+            ctx.solve_residuals(self.batch, self.res.data_ptr(), s)
+            self.smoke, self.smoke2 = self.smoke2, self.smoke
+            self.v, self.v2 = self.v2, self.v
+            rel = torch.sqrt(self.res[:, 0] / torch.clamp(self.res[:, 1], min=1e-300)).max().reshape(1)
+        if allreduce is not None:
+            allreduce(rel)
+        return rel
+
+
+def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
+    """ strong scaling of the batched smoke workload: the SAME 8 simulations on 1 / 2 / 4 / 8 GPUs """
+    total, n = args.batch_total, args.size if args.size != 256 else 512
+    sim = SmokeBatchStep(ctx, n, total, rank, world, args.cg_iters, device)
+    for _ in range(args.warmup):
+        sim.step(allreduce)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rel = sim.step(allreduce)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        sim.step(None)
+        torch.cuda.synchronize(device)
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        cells = total * n * n
+        it_us = (prof["cg_matvec_dot"][1] + prof["cg_update"][1] + prof["cg_update_r"][1]) / max(1, prof["cg_matvec_dot"][0]) * 1e3
+        print(json.dumps({
+            "metric": f"cell-updates/sec (mac_cormack + advect + {args.cg_iters} CG iters), {total} x {n}^2 fp32 batched smoke", "value": cells * args.steps / elapsed,
+            "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batched 2D smoke {total} x {n}^2 (BASELINE.json configs[3]), batch block-distributed over {world} GPU(s), "
+                                   f"{args.cg_iters} CG iterations per projection", "sims_total": total, "sims_rank0": sim.batch, "cg_iterations": args.cg_iters,
+                       "parallelism": f"batch-parallel x{world}, no data-path collective, 1 all-reduce(max residual)/step"},
+            "final_relative_residual": float(rel.item()), "us_per_cg_iteration_rank0": round(it_us, 3),
+            "kernel_ms_per_step_rank0": {k: round(v[1], 5) for k, v in prof.items()},
+            "plan": {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def cpu_baseline(n, cg_iters):
     """ the NumPy oracle (restatement of the reference's CPU path) timed on the same step at a bounded size; the oracle's fields are
     kept for the parity block (the GPU repeats exactly this step on the same inputs) """
@@ -247,6 +332,10 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=100)
     ap.add_argument("--cpu-size", type=int, default=192, help="grid size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
+                    help="config2 (default, the BASELINE metric): 256^3 Taylor-Green replicas, weak scaling. config4: 8 x 512^2 batched smoke, the batch "
+                         "sharded over the GPUs, strong scaling")
+    ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
@@ -271,7 +360,6 @@ def main():
     if args.tuning:
         ctx.set_tuning(*[int(x) for x in args.tuning.split(",")])
     n, B = args.size, 1
-    sim = FluidStep(ctx, n, B, args.cg_iters, device)
 
     def allreduce(t):
         if dist is not None:
@@ -281,6 +369,10 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
+
+    if args.workload == "config4":
+        return bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce)
+    sim = FluidStep(ctx, n, B, args.cg_iters, device)
 
     for _ in range(args.warmup):
         sim.step(allreduce)

@@ -8,6 +8,12 @@ Every rank owns `n_x / world` planes of x, rhs, r, d. Per CG iteration the ranks
   * two scalars per batch entry (d.Ad and |r|^2) by all-reduce,
 and run the same marching kernels as the single-GPU solver on their slab (`phihip_slab_*`, NB_HALO planes). The control
 block (alpha, beta, convergence flags) stays on the device; the host only polls every `check_every` iterations.
+
+Communication is enqueue-only: the boundary planes are packed by a device copy into send buffers that live as long as the solver (no
+allocation inside the loop; for batch 1 the plane is contiguous and sent in place), the point-to-point exchange of a phase and that
+phase's scalar all-reduce are issued TOGETHER (`async_op`) and waited for together -- two communication latencies per iteration instead
+of four -- and with the "nccl" (= RCCL) backend a `wait()` is a stream dependency, not a host block. Not done: splitting the marching
+kernels into interior / boundary planes so that the exchange hides behind the interior.
 """
 from typing import List, Optional, Tuple
 
@@ -53,25 +59,36 @@ class SlabSolver:
         z = lambda s: backend.zeros(s, dtype)
         self.r, self.d = z(shape), [z(shape), z(shape)]
         self.halos = {name: [z(plane), z(plane)] for name in ("x", "r", "d0", "d1")}
+        self.send = [z(plane), z(plane)]      # packed boundary planes (batch > 1: the plane of a slab is strided over the batch)
         self.sums2 = backend.zeros((2 * batch,), torch.float64)
         self.sum1 = backend.zeros((batch,), torch.float64)
 
     # --- communication ---
-    def _exchange(self, t: torch.Tensor, halo: List[torch.Tensor]):
-        """ boundary planes of `t` -> the neighbours' halo buffers; their boundary planes -> `halo` """
+    def _plane(self, t: torch.Tensor, side: int) -> torch.Tensor:
+        """ boundary plane of the slab as a contiguous buffer: in place for batch 1, packed into the persistent send buffer otherwise """
+        view = t[:, 0 if side == 0 else -1]
+        if view.is_contiguous():
+            return view
+        self.send[side].copy_(view)
+        return self.send[side]
+
+    def _exchange(self, t: torch.Tensor, halo: List[torch.Tensor], reduce: Optional[torch.Tensor] = None):
+        """ boundary planes of `t` -> the neighbours' halo buffers, their boundary planes -> `halo`; `reduce`: per-entry sums of the same
+        phase, all-reduced (SUM) concurrently. Everything is issued before anything is waited for. """
         if self.world == 1:
             return
-        ops, keep = [], []
+        ops = []
         if self.lo_rank is not None:
-            send = t[:, 0].contiguous(); keep.append(send)
-            ops += [dist.P2POp(dist.isend, send, self._global(self.lo_rank), self.group), dist.P2POp(dist.irecv, halo[0], self._global(self.lo_rank), self.group)]
+            ops += [dist.P2POp(dist.isend, self._plane(t, 0), self._global(self.lo_rank), self.group), dist.P2POp(dist.irecv, halo[0], self._global(self.lo_rank), self.group)]
         if self.hi_rank is not None:
-            send = t[:, -1].contiguous(); keep.append(send)
-            ops += [dist.P2POp(dist.isend, send, self._global(self.hi_rank), self.group), dist.P2POp(dist.irecv, halo[1], self._global(self.hi_rank), self.group)]
+            ops += [dist.P2POp(dist.isend, self._plane(t, 1), self._global(self.hi_rank), self.group), dist.P2POp(dist.irecv, halo[1], self._global(self.hi_rank), self.group)]
         if self.world == 2 and self.lo_rank == self.hi_rank and self.lo_rank is not None:
             # two ranks on a periodic axis: both messages go to the same peer; order them so that lo matches the peer's hi
             ops = ops if self.rank == 0 else [ops[2], ops[3], ops[0], ops[1]]
-        for req in dist.batch_isend_irecv(ops):
+        pending = list(dist.batch_isend_irecv(ops)) if ops else []
+        if reduce is not None:
+            pending.append(dist.all_reduce(reduce, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for req in pending:
             req.wait()
 
     def _global(self, r):
@@ -103,8 +120,7 @@ class SlabSolver:
             h[0].zero_(); h[1].zero_()
         self._exchange(x, self.halos["x"])
         ctx.slab_residual(g, halo, fl, x.data_ptr(), self._hp("x"), rhs.data_ptr(), self.r.data_ptr(), self.sums2.data_ptr(), False, s)
-        self._allreduce(self.sums2)
-        self._exchange(self.r, self.halos["r"])
+        self._exchange(self.r, self.halos["r"], reduce=self.sums2)
         first, sums_in = True, self.sums2
         for k in range(1, int(max_iterations) + 1):
             d_old, d_new = self.d[(k - 1) & 1], self.d[k & 1]
@@ -112,22 +128,19 @@ class SlabSolver:
             ctx.slab_matvec(g, halo, fl, first, sums_in.data_ptr(), self.r.data_ptr(), self._hp("r"), d_old.data_ptr(), self._hp(ho),
                             d_new.data_ptr(), self.sum1.data_ptr(), csolve, s)
             first = False
-            self._allreduce(self.sum1)
+            self._exchange(d_new, self.halos[hn], reduce=self.sum1)          # planes of d_new + the d.Ad sums: one round of communication
             if refresh_every > 0 and k % refresh_every == 0:
                 ctx.slab_update(g, halo, fl, self.sum1.data_ptr(), d_new.data_ptr(), (0, 0), x.data_ptr(), 0, 0, csolve, True, s)
-                self._exchange(d_new, self.halos[hn])
                 self._exchange(x, self.halos["x"])
                 ctx.slab_residual(g, halo, fl, x.data_ptr(), self._hp("x"), rhs.data_ptr(), self.r.data_ptr(), self.sums2.data_ptr(), True, s)
-                self._allreduce(self.sums2)
-                sums_in = self.sums2           # [0..batch) = global |r|^2
+                self._exchange(self.r, self.halos["r"], reduce=self.sums2)   # [0..batch) = global |r|^2
+                sums_in = self.sums2
             else:
-                self._exchange(d_new, self.halos[hn])
                 rr = self.sums2[: self.batch]
                 ctx.slab_update(g, halo, fl, self.sum1.data_ptr(), d_new.data_ptr(), self._hp(hn), x.data_ptr(), self.r.data_ptr(), rr.data_ptr(),
                                 csolve, False, s)
-                self._allreduce(rr)
+                self._exchange(self.r, self.halos["r"], reduce=rr)           # planes of r + the |r|^2 sums: the second round
                 sums_in = self.sums2
-            self._exchange(self.r, self.halos["r"])
             if check_every > 0 and k % check_every == 0 and k < max_iterations:
                 infos = ctx.slab_state(g, False, sums_in.data_ptr(), csolve, True, s)
                 if not any(i.reserved for i in infos):

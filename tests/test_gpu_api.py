@@ -116,6 +116,15 @@ def test_full_size_batched_smoke_8x512(gpu_backend):
     assert other > 0.5                                        # ... while different entries are different simulations
 
 
+def test_solve_linear_and_the_backend_level_boundary(gpu_backend):
+    """ SURVEY §8b on the real library: flow.solve_linear(masked_laplace, ...), the matrix-level linear_solve and grid_sample """
+    import test_linear_boundary as lb
+    lb.test_solve_linear_matches_make_incompressible_and_the_oracle(gpu_backend)
+    lb.test_solve_linear_with_an_active_mask(gpu_backend)
+    lb.test_backend_linear_solve_from_an_assembled_matrix(gpu_backend)
+    lb.test_backend_grid_sample_matches_the_oracle(gpu_backend)
+
+
 def test_scene_files_on_the_device(gpu_backend, tmp_path):
     """ SURVEY §8 f6 with the real library: the reference's scene-file window -> GPU fields -> one step vs the oracle -> round trip """
     golden_cases.run_scene_files(gpu_backend, tmp_path)

@@ -550,3 +550,39 @@ def test_full_size_taylor_green_run_is_stable(ctx, mem):
     assert all(b <= a * (1 + 1e-6) for a, b in zip(energy, energy[1:])), energy
     assert energy[-1] > 0.9 * energy[0]                        # ... and the vortex is still there
     assert float(v[2].abs().max()) < 1e-3
+
+
+def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
+    """ `phihip_allreduce_residual` over an RCCL communicator a C caller created itself (here: one rank, through ctypes on
+    the librccl torch already loaded) -- the collective is resolved at run time from that library, in place, on the solve stream """
+    import ctypes
+    import os
+    import torch
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        dom, grid = pc.make_case((32, 24, 64), ((PER, PER),) * 3, np.float32, batch=3)
+        ctx.set_small_grid_solver(False)
+        pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(1), max_iter=5, fixed_iterations=True)
+        res = torch.zeros(3, 2, dtype=torch.float64, device=mem.device)
+        ctx.solve_residuals(3, res.data_ptr())
+        before = res.clone()
+        ctx.allreduce_residual(comm, res.data_ptr(), 6, op=2)                 # max over the (single) rank: unchanged
+        ctx.allreduce_residual(comm, res.data_ptr(), 6, op=0)                 # sum over one rank: unchanged
+        mem.sync()
+        assert torch.equal(res, before) and float(before[:, 1].min()) > 0
+        with pytest.raises(pc.C.PhiHipError):
+            ctx.allreduce_residual(comm, res.data_ptr(), 6, op=1)
+        with pytest.raises(pc.C.PhiHipError):
+            ctx.allreduce_residual(None, res.data_ptr(), 6)
+    finally:
+        ctx.set_small_grid_solver(True)
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

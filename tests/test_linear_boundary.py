@@ -145,7 +145,7 @@ def test_backend_linear_solve_from_an_assembled_matrix(emu_backend):
         x, its, rsq, conv, div = be.hip_linear_solve('CG', A, y.reshape(2, -1), np.zeros((2, A.shape[0]), np.float32), 1e-5, 0.0, 1000)
         assert all(conv) and not any(div)
         xo, info = O.cg(lambda q: O.masked_laplace(q, dom, hard, active), y, np.zeros_like(y), 1e-5, 0.0, 1000)
-        a, b = x.numpy().reshape(y.shape), xo
+        a, b = x.cpu().numpy().reshape(y.shape), xo
         if not dom.flexible() and active is None:
             a, b = a - a.mean(axis=tuple(range(1, a.ndim)), keepdims=True), b - b.mean(axis=tuple(range(1, b.ndim)), keepdims=True)
         assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-3, (res, bc)
@@ -165,5 +165,5 @@ def test_backend_grid_sample_matches_the_oracle(emu_backend):
         assert tuple(out.shape) == (2, 11, 5, 3)
         for c in range(3):
             ref = O.grid_sample(grid[..., c], [coords[..., 0].reshape(2, -1), coords[..., 1].reshape(2, -1)], ((code, code),) * 2, ((0.0, 0.0),) * 2)
-            np.testing.assert_allclose(out.numpy()[..., c].reshape(2, -1), ref, atol=2e-5)
+            np.testing.assert_allclose(out.cpu().numpy()[..., c].reshape(2, -1), ref, atol=2e-5)
     assert backend_grid_sample(emu_backend, torch.as_tensor(grid), torch.as_tensor(coords), 'symmetric') is None
