@@ -320,6 +320,12 @@ int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
  * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
+/* Solve('CG') on grids whose iteration is bound by the two kernel boundaries rather than by memory traffic (batched 2-D, small 3-D) runs the
+ * SINGLE-REDUCTION form of CG (Chronopoulos & Gear): one launch per iteration that carries w = A r and s = A p as vectors -- the same
+ * iterates as the two-launch form in exact arithmetic (alpha, beta from gamma = r.r and delta = (A r).r of the previous launch), 10 instead
+ * of 7 words per cell, half the launches. mode 0: never; 1 (default): when cells x batch <= max_cells (0 = built-in threshold); 2: always.
+ * 'CG-adaptive', slab-decomposed solves and grids of the single-workgroup solver are not affected. */
+int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or
  * PHIHIP_AUTOTUNE=0 in the environment when the context is created) keeps the analytic launch plan: same launch geometry, hence the same

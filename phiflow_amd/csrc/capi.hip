@@ -198,7 +198,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -216,7 +216,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes + ctx->ws_cg1.bytes;
     return PHIHIP_OK;
 }
 
@@ -766,7 +766,7 @@ int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void
 
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]) {
     PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "query_plan: NULL argument");
-    PHIHIP_REQUIRE(family >= 0 && family < 4, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update) or 3 (r-only update)");
+    PHIHIP_REQUIRE(family >= 0 && family < 5, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update), 3 (r-only update) or 4 (fused single-reduction iteration)");
     GridView v;
     PHIHIP_TRY(make_view(grid, &v));
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -847,6 +847,13 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) 
     return PHIHIP_OK;
 }
 
+int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cells) {
+    PHIHIP_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 2 && max_cells >= 0, "set_single_reduction_cg: mode must be 0, 1 or 2, max_cells >= 0");
+    ctx->cg1_mode = mode;
+    ctx->cg1_cells = max_cells;
+    return PHIHIP_OK;
+}
+
 int phihip_set_autotune(phihip_ctx* ctx, int enable) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->autotune = enable != 0;
@@ -862,7 +869,7 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable) {
 
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
-    PHIHIP_REQUIRE(family >= 0 && family < 4, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update) or 3 (r-only update)");
+    PHIHIP_REQUIRE(family >= 0 && family < 5, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update), 3 (r-only update) or 4 (fused single-reduction iteration)");
     PHIHIP_REQUIRE(rows_per_thread >= 0 && threads_per_row >= 0 && chunk_planes >= 0, "tuning values must be >= 0");
     ctx->tuning[family].rows = rows_per_thread;
     ctx->tuning[family].tpr = threads_per_row;

@@ -44,7 +44,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     c->vec = (v.n[2] % vmax == 0 && !v.unaligned) ? vmax : 1;
     const Tuning& t = ctx->tuning[family];
     const int mode = family_mode(family);
-    const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : 1.0 / 3.0);   // UPDATE_R: d is 1 of 3 words
+    const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : (family == FAM_CG1 ? 0.3 : 1.0 / 3.0));   // UPDATE_R: d is 1 of 3 words
     // the r-only update (2 loads + 1 store per cell) prefers the tiles of MATVEC (family sweep: 256^3 (1,64) x 16, 512^3 (2,32) x 64)
     const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R;
 
@@ -62,7 +62,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     auto best_chunk = [&](int cand, double* score_out) -> int {
         const double slots = (double)march_occupancy_any(v, cand, c->vec, mode, flags) * ctx->num_cu;
         const double tiles = (double)tiles_of(cand) * v.batch;
-        const double words = family == FAM_UPDATE ? 5.0 : 3.0;
+        const double words = family == FAM_UPDATE ? 5.0 : (family == FAM_CG1 ? 10.0 : 3.0);
         // every workgroup of the NEXT kernel re-reads all partial sums of its batch entry: nblk^2 doubles per entry, served by L2 (~3x
         // HBM speed). Negligible in 3-D (<= 0.5 % at 512^3), decisive for large 2-D grids, which have one workgroup per tile:
         // 2048^2 with 4096 small tiles 43.9 us per iteration, with 1024 (4,64) tiles 26.1 us (tools/sweep_cg2d.py)
@@ -401,6 +401,177 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
     return status;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-reduction CG (Chronopoulos & Gear 1989; stencil_march.hpp MODE_CG1): ONE launch per iteration. Used where the two launches of
+// the form above are bound by their boundaries (dependent launch ~2.7 us + prologue chain, profiles/r02_xcd_barrier_microbench.txt), not
+// by traffic. Vectors: r, w = A r, s = A p in ping-pong pairs (a launch's neighbours still read the inputs), p and x in place.
+//   start:  r = y - A x (RESID[_BAL]) ; state from (|r|^2, |y|^2) ; w = A r with gamma = |r|^2, delta = (A r).r (APPLY_DOT)
+//   k-th launch: prologue (gamma', delta' of the previous launch) -> PhiML's convergence / divergence tests, beta, alpha, count; body above
+//   refresh (every 50th like PhiML): r = y - A x ; w = A r, gamma, delta recomputed -- s = A p continues by its recurrence
+// ---------------------------------------------------------------------------------------------------------------------
+static long long cg1_threshold(const phihip_ctx* ctx, const GridView& v) {
+    if (ctx->cg1_cells > 0) return ctx->cg1_cells;
+    // cells x batch up to which ONE launch with 10 words per cell beats TWO with 7 (tools/sweep_cg1.py, profiles/r02_cg1_sweep.jsonl: 1.2-1.4x
+    // faster at 0.26-1.05 M cells, 0.86-0.91x at 2.1 M)
+    return v.dtype == PHIHIP_F64 ? 750000 : 1500000;
+}
+
+template <typename T>
+static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve* solve,
+                 phihip_solve_info* info, const double* shift, hipStream_t s) {
+    MarchConfig c, c1;
+    MarchGrid g, g1;
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_APPLY, &c, &g));
+    PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_CG1, &c1, &g1));
+    const bool has_flags = flags != nullptr;
+    const size_t vec_bytes = (((size_t)v.batch * v.cells * sizeof(T)) + 255) / 256 * 256;
+    const int nblk_max = g.nblk > g1.nblk ? g.nblk : g1.nblk;
+    const size_t part_n = (size_t)v.batch * nblk_max;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_cg1, 4 * vec_bytes));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 6 * part_n * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
+    if (ctx->host_state_bytes < (size_t)2 * v.batch * sizeof(CgState)) {
+        if (ctx->host_state) (void)hipHostFree(ctx->host_state);
+        ctx->host_state = nullptr;
+        ctx->host_state_bytes = 0;
+        PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)2 * v.batch * sizeof(CgState), hipHostMallocDefault));
+        ctx->host_state_bytes = (size_t)2 * v.batch * sizeof(CgState);
+    }
+    if (!ctx->poll_ev[0]) {
+        PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[0]));
+        PHIHIP_CHECK_HIP(hipEventCreate(&ctx->poll_ev[1]));
+    }
+    if (ctx->host_flags_count < (size_t)v.batch) {
+        if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+        ctx->host_flags = nullptr;
+        ctx->host_flags_count = 0;
+        PHIHIP_CHECK_HIP(hipHostMalloc((void**)&ctx->host_flags, (size_t)v.batch * sizeof(unsigned long long), hipHostMallocMapped));
+        memset(ctx->host_flags, 0, (size_t)v.batch * sizeof(unsigned long long));
+        PHIHIP_CHECK_HIP(hipHostGetDevicePointer((void**)&ctx->host_flags_dev, ctx->host_flags, 0));
+        ctx->host_flags_count = (size_t)v.batch;
+    }
+    const unsigned int seq = ++ctx->solve_seq;
+    char* extra = (char*)ctx->ws_cg1.ptr;
+    T* rv[2] = {(T*)ctx->ws_r.ptr, (T*)extra};
+    T* wv[2] = {(T*)ctx->ws_d0.ptr, (T*)(extra + vec_bytes)};
+    T* sv[2] = {(T*)ctx->ws_d1.ptr, (T*)(extra + 2 * vec_bytes)};
+    T* pv = (T*)(extra + 3 * vec_bytes);
+    double* part = (double*)ctx->ws_part.ptr;
+    double* part_g[2] = {part, part + part_n};            // gamma / delta of the launch before, ping-pong (a launch reads one pair, writes the other)
+    double* part_d[2] = {part + 2 * part_n, part + 3 * part_n};
+    double* part_rr = part + 4 * part_n;
+    double* part_yy = part + 5 * part_n;
+    CgState* st[2] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch};
+    int cur = 0;
+    CgParams prm;
+    prm.rtol = solve->rel_tol; prm.atol = solve->abs_tol; prm.max_iter = solve->max_iterations; prm.pad = 0;
+    MarchArgs<T> base;
+    memset(&base, 0, sizeof(base));
+    base.flags = flags;
+    base.prm = prm;
+    base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+
+    int vc = 0;     // which half of the (r, w, s) pairs holds the current vectors
+    int pc = 0;     // which (gamma, delta) partial pair the next CG1 prologue reads
+    int nblk_in = g.nblk;
+    PHIHIP_CHECK_HIP(hipMemsetAsync(pv, 0, vec_bytes, s));          // p_{-1} = s_{-1} = 0 (beta_0 = 0 alone would keep NaN garbage alive)
+    PHIHIP_CHECK_HIP(hipMemsetAsync(sv[0], 0, vec_bytes, s));
+    auto residual_and_w = [&](int prologue, bool balance_now) -> int {
+        {   // r = y - A x
+            MarchArgs<T> a = base;
+            a.a = (const T*)x; a.b = (const T*)rhs; a.o1 = rv[vc];
+            a.part1 = part_rr; a.part2 = part_yy;
+            a.prologue = prologue;
+            a.st_in = st[cur];
+            a.shift = balance_now ? shift : nullptr;
+            a.yout = balance_now ? (T*)const_cast<void*>(rhs) : nullptr;
+            LaunchScope ls(ctx, PHIHIP_K_CG_RESIDUAL, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c, balance_now ? MODE_RESID_BAL : MODE_RESID, has_flags, g, a, s));
+        }
+        if (prologue == PRO_NONE) {   // the control block of this solve: tolerances, |r0|^2, converged at once?
+            LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+            hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_FIRST, (const CgState*)st[cur], st[cur ^ 1], (const double*)part_rr,
+                               (const double*)part_yy, g.nblk, prm);
+            cur ^= 1;
+        }
+        {   // w = A r ; gamma = |r|^2 ; delta = (A r) . r
+            MarchArgs<T> a = base;
+            a.a = rv[vc]; a.o1 = wv[vc];
+            a.part1 = part_g[pc]; a.part2 = part_d[pc];
+            a.prologue = PRO_CONT;
+            a.st_in = st[cur];
+            LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY_DOT, has_flags, g, a, s));
+        }
+        nblk_in = g.nblk;
+        return PHIHIP_OK;
+    };
+    PHIHIP_TRY(residual_and_w(PRO_NONE, shift != nullptr));
+    int checks = 0;
+    for (int k = 1; k <= solve->max_iterations; ++k) {
+        {
+            MarchArgs<T> a = base;
+            a.a = rv[vc]; a.b = wv[vc]; a.c = sv[vc];
+            a.o1 = rv[vc ^ 1]; a.o2 = wv[vc ^ 1]; a.o3 = sv[vc ^ 1]; a.o4 = pv; a.o5 = (T*)x;
+            a.pin1 = part_g[pc]; a.pin2 = part_d[pc]; a.nblk_in = nblk_in;
+            a.part1 = part_g[pc ^ 1]; a.part2 = part_d[pc ^ 1];
+            a.prologue = PRO_CG1;
+            a.st_in = st[cur]; a.st_out = st[cur ^ 1];
+            if (solve->check_every > 0) { a.host_flags = ctx->host_flags_dev; a.seq = seq; }
+            LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
+            PHIHIP_TRY(launch_march_any<T>(v, c1, MODE_CG1, has_flags, g1, a, s));
+            cur ^= 1; vc ^= 1; pc ^= 1;
+            nblk_in = g1.nblk;
+        }
+        if (solve->refresh_every > 0 && k % solve->refresh_every == 0) {
+            // true residual like PhiML every 50th iteration: r = y - A x and w, gamma, delta from it REPLACE the sums of launch k in the
+            // pair the next prologue reads -- beta = gamma_true / gamma_k exactly as PhiML forms it (rsq / rsq_old); entries that were
+            // frozen before launch k skip both passes (PRO_CONT)
+            PHIHIP_TRY(residual_and_w(PRO_CONT, false));
+        }
+        if (solve->check_every > 0 && k < solve->max_iterations) {
+            bool any = false;
+            for (int b = 0; b < v.batch && !any; ++b) {
+                const unsigned long long f = *(volatile unsigned long long*)(ctx->host_flags + b);
+                any = (unsigned int)(f >> 32) != seq || (f & 1ull);
+            }
+            if (!any) break;
+            if (k % solve->check_every == 0) {
+                const int slot = checks & 1;
+                PHIHIP_CHECK_HIP(hipEventRecord(ctx->poll_ev[slot], s));
+                if (checks > 0) PHIHIP_CHECK_HIP(hipEventSynchronize(ctx->poll_ev[slot ^ 1]));
+                ++checks;
+            }
+        }
+    }
+    {   // fold the last (gamma, delta) into the control block: converged / diverged / residual of the final iterate
+        LaunchScope ls(ctx, PHIHIP_K_CG_SCALAR, s);
+        hipLaunchKernelGGL(cg_state_kernel, dim3(v.batch), dim3(kBlock), 0, s, (int)PRO_BETA, (const CgState*)st[cur], st[cur ^ 1], (const double*)part_g[pc],
+                           (const double*)part_d[pc], nblk_in, prm);
+        cur ^= 1;
+    }
+    ctx->last_state = st[cur];
+    ctx->last_state_batch = v.batch;
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    if (info) {
+        CgState* hst = (CgState*)ctx->host_state;
+        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st[cur], (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+        PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < v.batch; ++b) {
+            info[b].residual_sq = hst[b].rsq;
+            info[b].rhs_sq = hst[b].rhs_sq;
+            info[b].iterations = hst[b].iterations;
+            info[b].converged = hst[b].converged;
+            info[b].diverged = hst[b].diverged;
+            info[b].reserved = 0;
+        }
+    }
+    return PHIHIP_OK;
+}
+
 // shift != nullptr: rhs is the UNBALANCED divergence and shift[b] its mean over the active cells (device doubles): the initial residual
 // kernel subtracts it on the fly and writes the balanced right-hand side back into `rhs` (marching path only)
 template <typename T>
@@ -410,6 +581,9 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     }
+    if (solve->method == PHIHIP_METHOD_CG && !v.halo[0] && !v.halo[1] &&
+        (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))
+        return cg1_t<T>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
     if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
         !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R))) {
         const size_t vb = (size_t)v.batch * v.cells * sizeof(T);

@@ -19,10 +19,10 @@ struct MarchConfig {
     int batch;
 };
 
-inline int family_mode(int family) { return family == 1 ? MODE_MATVEC : (family == 2 ? MODE_UPDATE : (family == 3 ? MODE_UPDATE_R : MODE_RESID)); }
+inline int family_mode(int family) { return family == 1 ? MODE_MATVEC : (family == 2 ? MODE_UPDATE : (family == 3 ? MODE_UPDATE_R : (family == 4 ? MODE_CG1 : MODE_RESID))); }
 
 // kernel families that may use different tile shapes (phihip_set_tuning_kernel)
-enum MarchFamily { FAM_APPLY = 0, FAM_MATVEC = 1, FAM_UPDATE = 2, FAM_UPDATE_R = 3, FAM_COUNT = 4 };   // UPDATE_R: the r-only update (3 words)
+enum MarchFamily { FAM_APPLY = 0, FAM_MATVEC = 1, FAM_UPDATE = 2, FAM_UPDATE_R = 3, FAM_CG1 = 4, FAM_COUNT = 5 };   // UPDATE_R: the r-only update (3 words); CG1: the fused single-reduction iteration
 
 // choose tile + chunk for a grid (honours ctx->tuning[family]) and fill the decomposition fields of MarchGrid
 int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* cfg, MarchGrid* g);

@@ -40,6 +40,8 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
         PHIHIP_MODE_CASE(MODE_UPDATE_R)
         PHIHIP_MODE_CASE(MODE_UPDATE_X2)
         PHIHIP_MODE_CASE(MODE_RESID_BAL)
+        PHIHIP_MODE_CASE(MODE_APPLY_DOT)
+        PHIHIP_MODE_CASE(MODE_CG1)
         default:
             set_error("march: bad mode %d", mode);
             return PHIHIP_ERR_BAD_ARG;
@@ -73,6 +75,8 @@ static int occupancy_cfg(int mode, bool flags) {
         PHIHIP_OCC_CASE(MODE_UPDATE_R)
         PHIHIP_OCC_CASE(MODE_UPDATE_X2)
         PHIHIP_OCC_CASE(MODE_RESID_BAL)
+        PHIHIP_OCC_CASE(MODE_APPLY_DOT)
+        PHIHIP_OCC_CASE(MODE_CG1)
         default: return 1;
     }
 #undef PHIHIP_OCC_CASE

@@ -17,6 +17,11 @@
 // (UPDATE_R: r -= alpha A S only, 3 words) and the next one adds both steps at once -- the previous search direction is recovered
 // from operands the kernel reads anyway, d_k = (d_{k+1} - r_{k+1}) / beta_{k+1}:
 //   UPDATE_X2   x += (alpha_k / beta_{k+1}) (S - r) + alpha_{k+1} S ; r -= alpha_{k+1} A S        => 7 words per iteration on average.
+// CG1 is the whole iteration of the SINGLE-REDUCTION form of CG (Chronopoulos & Gear 1989) in ONE launch, for grids whose iteration is
+// bound by the two kernel boundaries rather than by traffic (batched 2-D, small 3-D): with w = A r and s = A p carried as vectors,
+//   S = r - alpha (w + beta s)   [= r_new, also on the halo]      p = r + beta p ; s = w + beta s ; x += alpha p ; r = S ; w = A S
+//   sum S^2 (= gamma), sum (A S) S (= delta)   ->   beta' = gamma' / gamma ,  alpha' = gamma' / (delta' - beta' gamma' / alpha)
+// Same iterates as PhiML's cg in exact arithmetic, one global reduction point per iteration, 10 words per cell instead of 7.
 // MATVEC_AD / UPDATE_AD are the same passes for PhiML's 'CG-adaptive' (SURVEY Appendix B.2): they additionally reduce
 // sum d * r resp. sum r_new * (A d), from which alpha = (d.r)/(d.q) and d = r - ((r.q)/(d.q)) d are formed.
 #pragma once
@@ -31,7 +36,9 @@ constexpr int kWave = 64;
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
                                                                             // neighbour slab's halo buffer (MarchArgs::a_lo ...)
 enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5, MODE_UPDATE_R = 6, MODE_UPDATE_X2 = 7,
-                 MODE_RESID_BAL = 8 };   // RESID that also balances y: y -= shift * active, written back (once per projection)
+                 MODE_RESID_BAL = 8,     // RESID that also balances y: y -= shift * active, written back (once per projection)
+                 MODE_APPLY_DOT = 9,     // w = A r with sum r^2 and sum (A r) r: start / refresh of the single-reduction CG
+                 MODE_CG1 = 10 };        // one WHOLE iteration of the single-reduction (Chronopoulos-Gear) CG, see below
 
 // Per batch entry CG control block (device memory). There is no separate "scalar" kernel between the phases of an
 // iteration: every workgroup of the NEXT kernel re-reduces the previous kernel's per-workgroup partial sums in a fixed order
@@ -58,7 +65,8 @@ enum CgPrologue {
     PRO_BETA = 3,       // rsq_new from the UPDATE / refresh partials: beta, convergence flags
     PRO_ALPHA = 4,      // dq from the MATVEC partials: alpha, iteration count
     PRO_BETA_AD = 5,    // 'CG-adaptive': (rsq_new, r_new.q) -> beta = -(r.q)/(d.q), convergence flags
-    PRO_ALPHA_AD = 6    // 'CG-adaptive': (d.q, d.r) -> alpha = (d.r)/(d.q), iteration count
+    PRO_ALPHA_AD = 6,   // 'CG-adaptive': (d.q, d.r) -> alpha = (d.r)/(d.q), iteration count
+    PRO_CG1 = 7         // single-reduction CG: (gamma', delta') of the previous launch -> convergence flags, then beta, alpha, count
 };
 
 // one 64-bit store that the HOST may read at any time (pinned, device-mapped memory)
@@ -92,6 +100,26 @@ __device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, 
             s.diverged = (!cg_finite(sum1) || (s.rsq0 > 0 && sum1 / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
             s.converged = sum1 <= s.tol_sq ? 1 : 0;
             s.cont = (!s.converged && !s.diverged && s.iterations < prm.max_iter) ? 1 : 0;
+        }
+    } else if (kind == PRO_CG1) {
+        if (s.cont) {
+            // the residual the previous launch (or the start / refresh) produced: PhiML's checks first ...
+            const double g_old = s.rsq;
+            if (s.iterations > 0 || s.dq != 0) {   // (not the very first launch: PRO_FIRST already judged r0)
+                s.rsq = sum1;
+                s.diverged = (!cg_finite(sum1) || (s.rsq0 > 0 && sum1 / s.rsq0 > 100 && s.iterations >= 8)) ? 1 : 0;
+                s.converged = sum1 <= s.tol_sq ? 1 : 0;
+                s.cont = (!s.converged && !s.diverged && s.iterations < prm.max_iter) ? 1 : 0;
+            }
+            if (s.cont) {   // ... then this launch's step
+                const bool first = s.iterations == 0 && s.dq == 0;
+                s.beta = first ? 0 : (g_old != 0 ? sum1 / g_old : 0);
+                const double denom = first ? sum2 : sum2 - (s.alpha != 0 ? s.beta * sum1 / s.alpha : 0);
+                s.alpha_prev = s.alpha;
+                s.alpha = denom != 0 ? sum1 / denom : 0;
+                s.dq = denom != 0 ? denom : 1;        // d.Ad of this step (kept non-zero: marks "not the first launch")
+                s.iterations += 1;
+            }
         }
     } else if (kind == PRO_ALPHA || kind == PRO_ALPHA_AD) {
         if (s.cont) {
@@ -137,6 +165,11 @@ struct MarchArgs {
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
     const T* a_lo; const T* a_hi;
     const T* b_lo; const T* b_hi;
+    // CG1 only: third stencil source (s = A p of the previous step) and the remaining outputs. a = r, b = w, c = s (inputs of this
+    // launch); o1 = r_new, o2 = w_new, o3 = s_new (the OTHER set of the three ping-pong pairs: neighbours still read the inputs),
+    // o4 = p, o5 = x (own cells only: in place)
+    const T* c;
+    T* o3; T* o4; T* o5;
     // RESID_BAL only: fluid._balance_divergence folded into the initial residual -- y is read as y - shift[b] * active and written
     // back balanced to `yout` (the refreshes and the caller see the balanced right-hand side); saves the separate read + write pass
     const double* shift;
@@ -218,7 +251,7 @@ __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, C
     if (threadIdx.x == 0 && kind != PRO_FIRST) s = st_in[b];
     double s1 = 0, s2 = 0;
     if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
-    if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);
+    if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);   // (incl. PRO_CG1)
     if (threadIdx.x == 0) {
         s = cg_advance(kind, s, s1, s2, prm);
         if (pending >= 0 && s.cont) {   // an UPDATE phase of a running entry: does x lag one step behind afterwards?
@@ -242,7 +275,9 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     static_assert(2 * TPR + 2 * T1 <= kBlock, "halo items must fit one per thread");
     using VT = Vec<T, V>;
     using VF = Vec<uint8_t, V>;
-    constexpr bool IS_MV = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD;
+    constexpr bool IS_CG1 = MODE == MODE_CG1;
+    constexpr bool IS_MV = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD || IS_CG1;   // the stencil source is a combination: A + beta B [+ gam C]
+    constexpr bool IS_AP = MODE == MODE_APPLY || MODE == MODE_APPLY_DOT;
     constexpr bool IS_UP = MODE == MODE_UPDATE || MODE == MODE_UPDATE_AD || MODE == MODE_UPDATE_R || MODE == MODE_UPDATE_X2;
     constexpr bool HAS_X = IS_UP && MODE != MODE_UPDATE_R;   // UPDATE_R leaves x alone
     constexpr bool AD = MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_AD;
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int b = blockIdx.y;
     constexpr bool IS_RES = MODE == MODE_RESID || MODE == MODE_RESID_BAL;
     const T yshift = MODE == MODE_RESID_BAL ? (T)p.shift[b] : T(0);
-    T alpha = T(0), beta = T(0);
+    T alpha = T(0), beta = T(0), gam = T(0), beta_cg = T(0);   // CG1: S = A + beta B + gam C with beta = -alpha, gam = -alpha beta_cg
     T acc1 = T(0), acc2 = T(0);
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
@@ -286,10 +321,11 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     // raw operands of a source plane (own cells): pointer selection incl. the slab halos, loads only. The first two planes are
     // requested BEFORE the prologue's partial-sum reduction so that their HBM latency overlaps it; `combine` applies beta later.
-    auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R]) {
+    auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R], VT (&Cc)[R]) {
         bool zero = false;
         const T* pa = p.a + base;
         const T* pb = IS_MV ? p.b + base : nullptr;
+        const T* pc = IS_CG1 ? p.c + base : nullptr;
         int ii = 0;
         if (DIM3) {
             if (i < 0 && g.nb[0][0] == NB_HALO) {
@@ -308,17 +344,19 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                 const long long off = ((long long)ii * n1 + (j1b + rr)) * n2 + j2;
                 A[rr] = vec_load<T, V>(pa + off);
                 if (IS_MV) B[rr] = vec_load<T, V>(pb + off);
+                if (IS_CG1) Cc[rr] = vec_load<T, V>(pc + off);
             } else {
                 A[rr] = vec_zero<T, V>();
                 if (IS_MV) B[rr] = vec_zero<T, V>();
+                if (IS_CG1) Cc[rr] = vec_zero<T, V>();
             }
         }
     };
-    VT Ra_p[R], Rb_p[R], Ra_c[R], Rb_c[R];
+    VT Ra_p[R], Rb_p[R], Rc_p[R], Ra_c[R], Rb_c[R], Rc_c[R];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = vec_zero<T, V>();
-    if (DIM3) load_raw(i_first - step, Ra_p, Rb_p);   // the plane behind the marching direction
-    load_raw(i_first, Ra_c, Rb_c);
+    for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = Rc_p[rr] = Rc_c[rr] = vec_zero<T, V>();
+    if (DIM3) load_raw(i_first - step, Ra_p, Rb_p, Rc_p);   // the plane behind the marching direction
+    load_raw(i_first, Ra_c, Rb_c, Rc_c);
 
     if (p.prologue != PRO_NONE) {
         const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state,
@@ -329,15 +367,20 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         alpha = (T)S.alpha;
         beta = (T)S.beta;
         if (MODE == MODE_UPDATE_X2) beta = (T)(S.alpha_prev / S.beta);   // coefficient of (S - r) = beta_{k+1} d_k; beta > 0 while running
+        if (IS_CG1) { beta_cg = (T)S.beta; beta = (T)(-S.alpha); gam = (T)(-S.alpha * S.beta); }
     }
     // `own`: the plane belongs to this workgroup's chunk (MATVEC_AD sums d_new * r over exactly those)
-    auto combine = [&](const VT (&A)[R], const VT (&B)[R], VT (&S)[R], bool own) {
+    auto combine = [&](const VT (&A)[R], const VT (&B)[R], const VT (&Cc)[R], VT (&S)[R], bool own) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             S[rr] = A[rr];
             if (IS_MV) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) S[rr].v[v] = fma(beta, B[rr].v[v], A[rr].v[v]);
+                if (IS_CG1) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) S[rr].v[v] = fma(gam, Cc[rr].v[v], S[rr].v[v]);
+                }
                 if (AD && own) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc2 += S[rr].v[v] * A[rr].v[v];
@@ -354,17 +397,23 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 #pragma unroll
             for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
         }
+        if (IS_CG1) {
+            VT d = vec_load<T, V>(p.c + base + off);
+#pragma unroll
+            for (int v = 0; v < V; ++v) s.v[v] = fma(gam, d.v[v], s.v[v]);
+        }
         return s;
     };
     auto src_one = [&](long long off) -> T {
         T s = p.a[base + off];
         if (IS_MV) s = fma(beta, p.b[base + off], s);
+        if (IS_CG1) s = fma(gam, p.c[base + off], s);
         return s;
     };
     auto load_plane = [&](int i, VT (&S)[R], bool own) {
-        VT A[R], B[R];
-        load_raw(i, A, B);
-        combine(A, B, S, own);
+        VT A[R], B[R], Cc[R];
+        load_raw(i, A, B, Cc);
+        combine(A, B, Cc, S, own);
     };
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
@@ -405,8 +454,9 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     // ---- per-plane extra operands (own cells only) --------------------------------------------------------------------
     struct Extra {
-        VT e1[R];   // RESID: y      UPDATE: x
-        VT e2[R];   //               UPDATE: r
+        VT e1[R];   // RESID: y      UPDATE: x      CG1: p
+        VT e2[R];   //               UPDATE: r      CG1: x
+        VT e3[R], e4[R], e5[R];   // CG1: r, w, s of the own cells (the stencil source only keeps their combination)
         VF fl[R];   // stencil flags
     };
     auto load_extra = [&](int i, Extra& E) {
@@ -418,6 +468,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             if (IS_UP) {
                 if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
                 E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
+            }
+            if (IS_CG1) {
+                E.e1[rr] = vec_load<T, V>(p.o4 + base + off);
+                E.e2[rr] = vec_load<T, V>(p.o5 + base + off);
+                E.e3[rr] = vec_load<T, V>(p.a + base + off);
+                E.e4[rr] = vec_load<T, V>(p.b + base + off);
+                E.e5[rr] = vec_load<T, V>(p.c + base + off);
             }
             if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + fbase + off);
         }
@@ -433,8 +490,8 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         Sp[rr] = vec_zero<T, V>();
         Sn[rr] = vec_zero<T, V>();
     }
-    if (DIM3) combine(Ra_p, Rb_p, Sp, false);
-    combine(Ra_c, Rb_c, Sc, true);
+    if (DIM3) combine(Ra_p, Rb_p, Rc_p, Sp, false);
+    combine(Ra_c, Rb_c, Rc_c, Sc, true);
     load_halo(i_first, hv_c, hs_c);
     load_extra(i_first, Ec);
     hv_n = hv_c; hs_n = hs_c; En = Ec;
@@ -501,8 +558,30 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                 q.v[v] = r;
             }
             const long long off = base + ((long long)i * n1 + (j1b + rr)) * n2 + j2;
-            if (MODE == MODE_APPLY) {
+            if (IS_AP) {
                 vec_store<T, V>(p.o1 + off, q);
+                if (MODE == MODE_APPLY_DOT) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        acc1 += Sc[rr].v[v] * Sc[rr].v[v];
+                        acc2 += q.v[v] * Sc[rr].v[v];
+                    }
+                }
+            } else if (IS_CG1) {
+                VT pn, sn, xn;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    pn.v[v] = fma(beta_cg, Ec.e1[rr].v[v], Ec.e3[rr].v[v]);       // p = r + beta p
+                    sn.v[v] = fma(beta_cg, Ec.e5[rr].v[v], Ec.e4[rr].v[v]);       // s = w + beta s  (= A p)
+                    xn.v[v] = fma(-beta, pn.v[v], Ec.e2[rr].v[v]);                // x += alpha p   (beta holds -alpha here)
+                    acc1 += Sc[rr].v[v] * Sc[rr].v[v];                           // gamma' = |r_new|^2
+                    acc2 += q.v[v] * Sc[rr].v[v];                                // delta' = (A r_new) . r_new
+                }
+                vec_store<T, V>(p.o4 + off, pn);
+                vec_store<T, V>(p.o3 + off, sn);
+                vec_store<T, V>(p.o5 + off, xn);
+                vec_store<T, V>(p.o1 + off, Sc[rr]);
+                vec_store<T, V>(p.o2 + off, q);
             } else if (IS_RES) {
                 VT r, yb;
 #pragma unroll
@@ -549,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     if (MODE != MODE_APPLY) {
         const double s1 = block_sum((double)acc1, red);
         if (tid == 0) p.part1[(long long)b * g.nblk + blockIdx.x] = s1;
-        if (IS_RES || AD) {
+        if (IS_RES || AD || IS_CG1 || MODE == MODE_APPLY_DOT) {
             const double s2 = block_sum((double)acc2, red);
             if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
         }

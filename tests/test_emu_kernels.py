@@ -463,3 +463,25 @@ def test_autotuned_launch_plans_stay_correct(emu_library):
         assert model == [ctx2.query_plan(grid, False, f) for f in (1, 2, 3)]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("res,bc", [((20, 24), ((CLO, CLO), (PER, PER))), ((16, 20), ((OPN, OPN), (CLO, OPN))), ((8, 12, 16), ((PER, PER), (CLO, OPN), (PER, PER))),
+                                    ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)))])
+def test_single_reduction_cg_matches_oracle(emu_ctx, res, bc):
+    """ the one-launch-per-iteration (Chronopoulos-Gear) form of 'CG' (stencil_march.hpp MODE_CG1): same iterates as PhiML's cg in exact
+    arithmetic -- fixed iteration counts incl. refreshes, tolerance mode with per-entry freezing, obstacles, both dtypes """
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        emu_ctx.set_single_reduction_cg(2)
+        for dtype in (np.float32, np.float64):
+            dom, grid = pc.make_case(res, bc, dtype, batch=2)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(7), max_iter=7, fixed_iterations=True)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(8), max_iter=11, refresh=4, fixed_iterations=True)
+            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(9))
+            pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(10))
+        if len(res) == 3:
+            dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float32, batch=1)
+            pc.check_make_incompressible(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(11), obstacles=[pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))])
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+        emu_ctx.set_single_reduction_cg(1)
