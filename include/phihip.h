@@ -323,8 +323,11 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
 /* Solve('CG') on grids whose iteration is bound by the two kernel boundaries rather than by memory traffic (batched 2-D, small 3-D) runs the
  * SINGLE-REDUCTION form of CG (Chronopoulos & Gear): one launch per iteration that carries w = A r and s = A p as vectors -- the same
  * iterates as the two-launch form in exact arithmetic (alpha, beta from gamma = r.r and delta = (A r).r of the previous launch), 10 instead
- * of 7 words per cell, half the launches. mode 0: never; 1 (default): when cells x batch <= max_cells (0 = built-in threshold); 2: always.
- * 'CG-adaptive', slab-decomposed solves and grids of the single-workgroup solver are not affected. */
+ * of 7 words per cell, half the launches: 1.2-1.4x faster per iteration up to ~1 M cells x batch (512^2: 10.1 -> 7.4 us). It is OPT-IN: the
+ * recurrences that replace the second reduction cost attainable accuracy in fp32 (closed 512^2 box: relative residual floor 9e-4 against 3e-5
+ * of the two-launch form, tools/cg1_accuracy.py), so a tolerance below ~kappa * 1e-7 may never be met. mode 0 (default): never; 1: when
+ * cells x batch <= max_cells (0 = built-in threshold, 1.5 M fp32 / 0.75 M fp64); 2: always. 'CG-adaptive', slab-decomposed solves and grids
+ * of the single-workgroup solver are not affected. */
 int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or

@@ -129,9 +129,10 @@ struct phihip_ctx {
     // keep the analytic plan (bit-reproducible launch geometry across processes).
     bool autotune = true;
     std::map<phihip::PlanKey, phihip::TunedPlan> tuned;
-    // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never, 1 = for solves whose
-    // iteration is bound by the kernel boundaries (cg1_cells: cells x batch at most this), 2 = always ('CG' only)
-    int cg1_mode = 1;
+    // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never (default: in fp32 its
+    // attainable accuracy is 1-2 digits worse than the two-launch form, tools/cg1_accuracy.py), 1 = for solves whose iteration is bound
+    // by the kernel boundaries (cg1_cells: cells x batch at most this), 2 = always ('CG' only)
+    int cg1_mode = 0;
     long long cg1_cells = 0;      // 0 = built-in threshold
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule

@@ -46,7 +46,7 @@ def main():
             rec["speedup_single_reduction"] = round(rec["two_launch"]["us_per_iteration"] / rec["single_reduction"]["us_per_iteration"], 3)
             print(json.dumps(rec), flush=True)
             del rhs, x
-    ctx.set_single_reduction_cg(1)
+    ctx.set_single_reduction_cg(0)
 
 
 if __name__ == "__main__":
