@@ -586,3 +586,21 @@ def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
         ctx.set_small_grid_solver(True)
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_single_reduction_cg_opt_in(ctx, mem):
+    """ phihip_set_single_reduction_cg: ONE fused launch per iteration (Chronopoulos-Gear recurrences). Same iterates as PhiML's cg while
+    far from the rounding floor (fixed iteration counts, fp32), converged solutions in fp64; off by default (fp32 accuracy floor) """
+    try:
+        ctx.set_small_grid_solver(False)
+        ctx.set_single_reduction_cg(2)
+        dom, grid = pc.make_case((64, 64, 64), ((PER, PER), (CLO, OPN), (CLO, CLO)), np.float32, batch=2)
+        pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(3), max_iter=40, refresh=16, fixed_iterations=True)
+        dom, grid = pc.make_case((512, 512), ((CLO, CLO), (CLO, CLO)), np.float32, batch=2)
+        pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(4), max_iter=60, fixed_iterations=True)
+        dom, grid = pc.make_case((96, 128), ((CLO, OPN), (PER, PER)), np.float64, batch=3)
+        pc.check_cg(ctx, mem, dom, grid, np.float64, np.random.default_rng(5))
+        pc.check_make_incompressible(ctx, mem, dom, grid, np.float64, np.random.default_rng(6), max_div=1e-7)
+    finally:
+        ctx.set_small_grid_solver(True)
+        ctx.set_single_reduction_cg(0)
