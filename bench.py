@@ -286,8 +286,10 @@ def live_pmc_traffic(n, kernel_key):
             if proc.returncode != 0:
                 return None, None
         res = pmc_summary.summarise(base)
-        for key, e in res["kernels"].items():
-            if key.startswith(kernel_key + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e:
+        cands = [(e.get("launches", 0), key, e) for key, e in res["kernels"].items()
+                 if key.startswith(kernel_key + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e]
+        for _, key, e in sorted(cands, key=lambda c: -c[0])[:1]:      # the plan the solve ran: the variant with the most launches
+            if True:
                 src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run inside this bench invocation on tools/pmc_workload.py {n} "
                        f"({key}; calibration copy: fetch unit {res['units']['fetch_bytes_per_unit_calibrated']}, "
                        f"write unit {res['units']['write_bytes_per_unit_calibrated']} B)")
