@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
     const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2;
     const int b = blockIdx.y;
     int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-aware order: neighbouring tiles share an XCD's L2
+    bid = xcd_order(bid, nblk);   // neighbouring tiles share an XCD's L2
     const int t2 = bid % tiles2;
     const int t1 = (bid / tiles2) % tiles1;
     const int c0 = bid / (tiles2 * tiles1);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
     if (flags[(long long)b * nblk + blockIdx.x] == 0) return;
     const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
     int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    bid = xcd_order(bid, nblk);
     const int t2 = bid % tiles2;
     const int t1 = (bid / tiles2) % tiles1;
     const int c0 = bid / (tiles2 * tiles1);

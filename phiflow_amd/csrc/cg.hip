@@ -85,12 +85,25 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         const double per_cu = mv_like ? 4.0 : (esize == 8 ? 1.5 : 2.0);
         const double wanted = slots < per_cu * ctx->num_cu ? slots : per_cu * ctx->num_cu;
         const double us_traffic = (double)v.cells * v.batch * words * esize / 5.5e6;
-        for (int k = 0; k < 10; ++k) {
-            const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
+        // candidates: the fixed list, then the chunk lengths that put m = 1 .. occupancy workgroups on EVERY CU
+        const int occ_i = (int)(slots / ctx->num_cu + 0.5);
+        for (int k = 0; k < 10 + occ_i; ++k) {
+            int ch;
+            if (k < 10) ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
+            else {
+                long long chunks0 = (long long)((double)(k - 9) * ctx->num_cu / tiles);
+                if (chunks0 < 1) continue;
+                if (chunks0 > v.n[0]) chunks0 = v.n[0];
+                ch = ceil_div(v.n[0], (int)chunks0);
+                if (ch > 128) continue;
+            }
             const double blocks = tiles * ceil_div(v.n[0], ch);
             const double rounds = blocks / slots;
             // (a round filled to >= 90 % counts as full: 320^3 runs 8 % faster with 1000 workgroups of 32 planes than with 1400 of 24)
-            const double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < 0.9 * wanted ? blocks / (0.9 * wanted) : 1.0);
+            double eff = rounds > 1.0 ? rounds / ceil(rounds - 1e-9) : (blocks < 0.9 * wanted ? blocks / (0.9 * wanted) : 1.0);
+            // within a round the CUs should carry the same number of workgroups: 384^3 (1,16) 1152 workgroups (4.5 per CU) 146 us,
+            // 1008 (3.9) and 1440 (5.6) 137 us (profiles/r02_midsize_chunks.jsonl)
+            if (rounds <= 1.0 && blocks >= ctx->num_cu) eff *= blocks / (ceil(blocks / ctx->num_cu - 1e-9) * ctx->num_cu);
             const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
             const double us_bw = us_traffic * (1.0 + planes * src_share + partials_share(blocks / v.batch)) / eff;
             const double us_lat = ceil(rounds - 1e-9) * (3.0 + 0.75 * (ch + 1));
@@ -313,6 +326,10 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
     PHIHIP_CHECK_HIP(hipEventCreate(&e0));
     PHIHIP_CHECK_HIP(hipEventCreate(&e1));
     int status = PHIHIP_OK;
+    struct Pick { int id, chunk; float us, us_model; };
+    Pick model_pick[FAM_COUNT], tuned_pick[FAM_COUNT];
+    std::vector<Pick> challengers[FAM_COUNT];
+    int fresh = 0;
     for (int family = FAM_MATVEC; family <= FAM_UPDATE_R && status == PHIHIP_OK; ++family) {
         const PlanKey key = plan_key(v, mask_batch, has_flags, family);
         if (ctx->tuned.count(key)) continue;
@@ -344,6 +361,26 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
                 const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * ceil_div(v.n[0], ch);
                 if (blocks * v.batch < ctx->num_cu || blocks > 8192) continue;   // starved chip / partial-sum lists too long
                 cands.push_back({id, ch, 0.f});
+            }
+            // chunk lengths that fill the chip EVENLY: m workgroups on every CU (m = 1 .. resident workgroups, and two such rounds).
+            // 384^3 MATVEC (1,16): 1152 workgroups of 48 planes (4.5 per CU) 146 us, 1008 of 55 planes (3.9) or 1440 of 39 (5.6) 137 us
+            // (profiles/r02_midsize_chunks.jsonl) -- the fixed list above has no such member for most sizes
+            {
+                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
+                const long long tiles = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * v.batch;
+                const int occ = march_occupancy_any(v, id, vec, mode, has_flags);
+                for (int m = 1; m <= occ + 1; ++m) {
+                    const long long target = (long long)(m <= occ ? m : 2 * occ) * ctx->num_cu;
+                    long long chunks0 = target / tiles;
+                    if (chunks0 < 1) continue;
+                    if (chunks0 > v.n[0]) chunks0 = v.n[0];
+                    const int ch = ceil_div(v.n[0], (int)chunks0);
+                    const long long blocks = tiles / v.batch * ceil_div(v.n[0], ch);
+                    if (blocks * v.batch < ctx->num_cu || blocks > 8192) continue;
+                    bool dup = false;
+                    for (const Cand& o : cands) dup = dup || (o.id == id && o.chunk == ch);
+                    if (!dup) cands.push_back({id, ch, 0.f});
+                }
             }
         }
         const Tuning saved = ctx->tuning[family];
@@ -392,9 +429,91 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         size_t win = 0;
         for (size_t k = 1; k < cands.size(); ++k)
             if (cands[k].us < cands[win].us * 0.98f) win = k;                   // the model's plan stays unless something is > 2 % faster
-        TunedPlan tp;
-        tp.id = cands[win].id; tp.chunk = cands[win].chunk; tp.us = cands[win].us; tp.us_model = cands[0].us < us_model_first ? cands[0].us : us_model_first;
-        ctx->tuned[key] = tp;
+        const float us_model = cands[0].us < us_model_first ? cands[0].us : us_model_first;
+        model_pick[family] = Pick{cands[0].id, cands[0].chunk, us_model, us_model};
+        tuned_pick[family] = Pick{cands[win].id, cands[win].chunk, cands[win].us, us_model};
+        for (size_t k = 0; k < order.size() && challengers[family].size() < 3; ++k)      // the three fastest in isolation (after the re-timing)
+            if (order[k] != 0 && cands[order[k]].us < us_model * 1.02f) challengers[family].push_back(Pick{cands[order[k]].id, cands[order[k]].chunk, cands[order[k]].us, us_model});
+        ++fresh;
+    }
+    // A candidate timed on its own re-reads operands its previous launch left in the Infinity Cache; inside the iteration the other phase
+    // has replaced them (192^3: a plan that won in isolation lost 15 % in the loop). So every challenger is confirmed in the loop it will
+    // run in -- MATVEC, UPDATE_R, MATVEC, UPDATE_X2 on the (zeroed) workspace -- against the model's plans, one family at a time.
+    if (status == PHIHIP_OK && fresh == 3) {
+        Tuning saved[FAM_COUNT];
+        for (int f = 0; f < FAM_COUNT; ++f) saved[f] = ctx->tuning[f];
+        auto loop_us = [&](const Pick (&pk)[FAM_COUNT], float* us) -> int {
+            MarchConfig c[FAM_COUNT];
+            MarchGrid g[FAM_COUNT];
+            for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) {
+                ctx->tuning[f].rows = vec == 1 ? 1 : kTileShapes[pk[f].id].rows;
+                ctx->tuning[f].tpr = vec == 1 ? 64 : kTileShapes[pk[f].id].tpr;
+                ctx->tuning[f].chunk = v.rank == 3 ? pk[f].chunk : 0;
+                PHIHIP_TRY(plan_march(ctx, v, mask_batch, has_flags, f, &c[f], &g[f]));
+            }
+            long long maxblk = 8192;
+            for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) maxblk = g[f].nblk > maxblk ? g[f].nblk : maxblk;
+            if (ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * maxblk * sizeof(double)) != PHIHIP_OK) return PHIHIP_ERR_ALLOC;
+            double* pp = (double*)ctx->ws_part.ptr;
+            MarchArgs<T> a;
+            memset(&a, 0, sizeof(a));
+            a.flags = flags;
+            a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+            a.prologue = PRO_NONE;
+            a.part1 = pp; a.part2 = pp + (size_t)v.batch * maxblk;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                PHIHIP_CHECK_HIP(hipEventRecord(e0, s));
+                for (int it = 0; it < 2; ++it) {
+                    T* dn = it ? d0 : d1;
+                    T* dold = it ? d1 : d0;
+                    a.a = r; a.b = dold; a.o1 = dn; a.o2 = nullptr;
+                    PHIHIP_TRY(launch_march_any<T>(v, c[FAM_MATVEC], MODE_MATVEC, has_flags, g[FAM_MATVEC], a, s));
+                    a.a = dn; a.b = nullptr; a.o1 = dold; a.o2 = r;     // (UPDATE_X2: the idle direction buffer stands in for x)
+                    if (it == 0) PHIHIP_TRY(launch_march_any<T>(v, c[FAM_UPDATE_R], MODE_UPDATE_R, has_flags, g[FAM_UPDATE_R], a, s));
+                    else PHIHIP_TRY(launch_march_any<T>(v, c[FAM_UPDATE], MODE_UPDATE_X2, has_flags, g[FAM_UPDATE], a, s));
+                }
+                PHIHIP_CHECK_HIP(hipEventRecord(e1, s));
+                PHIHIP_CHECK_HIP(hipEventSynchronize(e1));
+                float ms = 0;
+                PHIHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                best = ms < best ? ms : best;
+            }
+            *us = best * 1e3f;
+            return PHIHIP_OK;
+        };
+        float us_base = 0;
+        status = loop_us(model_pick, &us_base);
+        if (status == PHIHIP_OK) status = loop_us(model_pick, &us_base);           // (first pass warms the clocks)
+        Pick final_pick[FAM_COUNT];
+        for (int f = 0; f < FAM_COUNT; ++f) final_pick[f] = model_pick[f];
+        for (int f = FAM_MATVEC; f <= FAM_UPDATE_R && status == PHIHIP_OK; ++f) {
+            float us_best = us_base * 0.995f;
+            for (const Pick& ch : challengers[f]) {
+                Pick trial[FAM_COUNT];
+                for (int k = 0; k < FAM_COUNT; ++k) trial[k] = model_pick[k];
+                trial[f] = ch;
+                float us_trial = 0;
+                status = loop_us(trial, &us_trial);
+                if (status != PHIHIP_OK) break;
+                if (us_trial < us_best) { us_best = us_trial; final_pick[f] = ch; }
+            }
+        }
+        for (int f = 0; f < FAM_COUNT; ++f) ctx->tuning[f] = saved[f];
+        if (status == PHIHIP_OK)
+            for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) {
+                TunedPlan tp;
+                tp.id = final_pick[f].id; tp.chunk = final_pick[f].chunk; tp.us = final_pick[f].us; tp.us_model = final_pick[f].us_model;
+                ctx->tuned[plan_key(v, mask_batch, has_flags, f)] = tp;
+            }
+    } else if (status == PHIHIP_OK) {
+        for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) {
+            const PlanKey key = plan_key(v, mask_batch, has_flags, f);
+            if (ctx->tuned.count(key)) continue;
+            TunedPlan tp;
+            tp.id = tuned_pick[f].id; tp.chunk = tuned_pick[f].chunk; tp.us = tuned_pick[f].us; tp.us_model = tuned_pick[f].us_model;
+            ctx->tuned[key] = tp;
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -33,6 +33,15 @@ namespace phihip {
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
+// XCD-aware workgroup order: the dispatcher deals workgroups round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own
+// L2. Map the hardware index to a logical one so that every XCD works on ONE contiguous range of logical indices -- neighbouring tiles
+// (which share halo rows / planes) then share an L2. Bijection for any count: XCD x owns n/8 (+1 if x < n % 8) consecutive indices.
+__device__ __forceinline__ int xcd_order(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
+
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
                                                                             // neighbour slab's halo buffer (MarchArgs::a_lo ...)
 enum MarchMode { MODE_APPLY = 0, MODE_RESID = 1, MODE_MATVEC = 2, MODE_UPDATE = 3, MODE_MATVEC_AD = 4, MODE_UPDATE_AD = 5, MODE_UPDATE_R = 6, MODE_UPDATE_X2 = 7,
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
-    if ((g.nblk & 7) == 0) bid = (bid & 7) * (g.nblk >> 3) + (bid >> 3);
+    bid = xcd_order(bid, g.nblk);
     const int t2 = bid % g.tiles2;
     const int t1 = (bid / g.tiles2) % g.tiles1;
     const int c0 = bid / (g.tiles2 * g.tiles1);

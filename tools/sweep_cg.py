@@ -86,10 +86,12 @@ def main():
         mv = prof["cg_matvec_dot"][1] / max(1, prof["cg_matvec_dot"][0])
         up = prof["cg_update"][1] / max(1, prof["cg_update"][0])
         sc = prof["cg_scalar"][1] / max(1, prof["cg_scalar"][0])
+        ur = prof.get("cg_update_r", (0, 0.0))
+        ur = ur[1] / max(1, ur[0])
         words = esize
         plans = {f: ctx.query_plan(grid, bool(args.obstacle), f) for f in (1, 2, 3)}
         out = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "family": args.family, "defer": args.defer, "plan_mv": list(plans[1].values()), "plan_up": list(plans[2].values()), "plan_ur": list(plans[3].values()), "rows": rows, "tpr": tpr, "chunk": chunk,
-               "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_scalar": round(sc, 5),
+               "ms_matvec": round(mv, 5), "ms_update": round(up, 5), "ms_update_r": round(ur, 5), "ms_scalar": round(sc, 5),
                "ms_iter_events": round(mv + up + 2 * sc, 5), "ms_iter_wall": round(wall_ms / args.iters, 5),
                "alg_GBs_iter_wall": round(10 * words * cells / (wall_ms / args.iters * 1e-3) / 1e9, 1),
                "alg_GBs_update": round(6 * words * cells / (up * 1e-3) / 1e9, 1),
