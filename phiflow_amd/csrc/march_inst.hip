@@ -96,9 +96,22 @@ int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
     }
 }
 
+// the slot that lanes outside the grid store into (march_kernel issues every store unconditionally); one per process and instantiation unit
+static InstT* march_dump_slot() {
+    static void* slot = nullptr;
+    if (!slot && hipMalloc(&slot, 256) != hipSuccess) slot = nullptr;
+    return (InstT*)slot;
+}
+
 template <>
 int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, const MarchGrid& g,
-                                   const MarchArgs<InstT>& a, hipStream_t s) {
+                                   const MarchArgs<InstT>& a_in, hipStream_t s) {
+    MarchArgs<InstT> a = a_in;
+    a.dump = march_dump_slot();
+    if (!a.dump) {
+        set_error("march: cannot allocate the dump slot");
+        return PHIHIP_ERR_ALLOC;
+    }
     dim3 grid(g.nblk, c.batch);
     if (c.vec == 1) return launch_cfg<1, 1, 64>(mode, flags, g, a, grid, s);
     switch (c.id) {

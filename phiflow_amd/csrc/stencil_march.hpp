@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace phihip {
 
 constexpr int kBlock = 256;
@@ -183,6 +185,8 @@ struct MarchArgs {
     // back balanced to `yout` (the refreshes and the caller see the balanced right-hand side); saves the separate read + write pass
     const double* shift;
     T* yout;
+    // 16 bytes that lanes outside the grid store into (every store of the plane loop is unconditional, see march_kernel); set by launch_march
+    T* dump;
 };
 
 template <typename T, int V>
@@ -274,8 +278,16 @@ __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, C
     return *sh;
 }
 
+// waves per SIMD the register allocator has to leave room for: the one-row tiles of the 3-word phases sit at 78-82 VGPRs -- 80 is the
+// step between 5 and 6 resident waves
+// (fp32 without cell flags: 78-82 registers, no spill at 80; the flag / fp64 variants would spill 2-26 dwords and keep their allocation)
+template <typename T, int R, int MODE, bool FLAGS>
+constexpr int march_min_waves() {
+    return (sizeof(T) == 4 && !FLAGS && R == 1 && (MODE == MODE_APPLY || MODE == MODE_RESID || MODE == MODE_MATVEC || MODE == MODE_UPDATE_R)) ? 6 : 1;
+}
+
 template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false>
-__global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T> p) {
+__global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
     constexpr int TR = kBlock / TPR;   // thread rows
     constexpr int T1 = TR * R;         // tile rows (axis a1)
     constexpr int T2 = TPR * V;        // tile columns (axis a2)
@@ -324,48 +336,55 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const long long fbase = g.flags_per_batch ? base : 0;
     const int n1 = g.n1, n2 = g.n2;
 
+    // Every global load / store of the plane loop is UNCONDITIONAL (lanes outside the grid read element 0 of the plane and store into a
+    // dump slot; lanes without a halo role read element 0 as well): hipcc can then count the outstanding operations and waits with
+    // s_waitcnt vmcnt(N > 0) for exactly the plane it needs, while the requests for later planes stay in flight across the barrier. With
+    // loads under `if (ok)` / `if (halo role)` the compiler has to assume the branch was skipped and drains the queue (vmcnt(0)) -- the
+    // round-1 loop paid two to three serialised memory round trips per plane that way (halo rows, halo columns, own cells).
     bool ok[R];
+    int own_off[R];        // in-plane element offset of the thread's vector in its row rr
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) ok[rr] = (j2 < n2) && (j1b + rr < n1);
+    for (int rr = 0; rr < R; ++rr) {
+        ok[rr] = (j2 < n2) && (j1b + rr < n1);
+        own_off[rr] = ok[rr] ? (j1b + rr) * n2 + j2 : 0;
+    }
+    const long long plane = (long long)n1 * n2;
 
-    // raw operands of a source plane (own cells): pointer selection incl. the slab halos, loads only. The first two planes are
-    // requested BEFORE the prologue's partial-sum reduction so that their HBM latency overlaps it; `combine` applies beta later.
-    auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R], VT (&Cc)[R]) {
-        bool zero = false;
+    // raw operands of a source plane (own cells): the plane selection incl. the slab halos and the ghost-plane rule is uniform; `zero` =
+    // the plane is a zero ghost (NB_ZERO): the loads still run (plane 0), `combine` discards them
+    auto load_raw = [&](int i, VT (&A)[R], VT (&B)[R], VT (&Cc)[R], bool& zero) {
+        zero = false;
         const T* pa = p.a + base;
         const T* pb = IS_MV ? p.b + base : nullptr;
         const T* pc = IS_CG1 ? p.c + base : nullptr;
-        int ii = 0;
         if (DIM3) {
             if (i < 0 && g.nb[0][0] == NB_HALO) {
-                pa = p.a_lo + (long long)b * n1 * n2;
-                if (IS_MV) pb = p.b_lo + (long long)b * n1 * n2;
+                pa = p.a_lo + (long long)b * plane;
+                if (IS_MV) pb = p.b_lo + (long long)b * plane;
             } else if (i >= g.n0 && g.nb[0][1] == NB_HALO) {
-                pa = p.a_hi + (long long)b * n1 * n2;
-                if (IS_MV) pb = p.b_hi + (long long)b * n1 * n2;
+                pa = p.a_hi + (long long)b * plane;
+                if (IS_MV) pb = p.b_hi + (long long)b * plane;
             } else {
-                ii = nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero);
+                const long long po = (long long)nb_index(i, g.n0, g.nb[0][0], g.nb[0][1], zero) * plane;
+                pa += po;
+                if (IS_MV) pb += po;
+                if (IS_CG1) pc += po;
             }
         }
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (ok[rr] && !zero) {
-                const long long off = ((long long)ii * n1 + (j1b + rr)) * n2 + j2;
-                A[rr] = vec_load<T, V>(pa + off);
-                if (IS_MV) B[rr] = vec_load<T, V>(pb + off);
-                if (IS_CG1) Cc[rr] = vec_load<T, V>(pc + off);
-            } else {
-                A[rr] = vec_zero<T, V>();
-                if (IS_MV) B[rr] = vec_zero<T, V>();
-                if (IS_CG1) Cc[rr] = vec_zero<T, V>();
-            }
+            A[rr] = vec_load<T, V>(pa + own_off[rr]);
+            if (IS_MV) B[rr] = vec_load<T, V>(pb + own_off[rr]);
+            if (IS_CG1) Cc[rr] = vec_load<T, V>(pc + own_off[rr]);
         }
     };
     VT Ra_p[R], Rb_p[R], Rc_p[R], Ra_c[R], Rb_c[R], Rc_c[R];
+    bool zero_p = false, zero_c = false;
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = Rc_p[rr] = Rc_c[rr] = vec_zero<T, V>();
-    if (DIM3) load_raw(i_first - step, Ra_p, Rb_p, Rc_p);   // the plane behind the marching direction
-    load_raw(i_first, Ra_c, Rb_c, Rc_c);
+    for (int rr = 0; rr < R; ++rr) Ra_p[rr] = Rb_p[rr] = Rc_p[rr] = Rb_c[rr] = Rc_c[rr] = vec_zero<T, V>();
+    // The first two planes are requested BEFORE the prologue's partial-sum reduction so that their HBM latency overlaps it.
+    if (DIM3) load_raw(i_first - step, Ra_p, Rb_p, Rc_p, zero_p);   // the plane behind the marching direction
+    load_raw(i_first, Ra_c, Rb_c, Rc_c, zero_c);
 
     if (p.prologue != PRO_NONE) {
         const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state,
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         if (IS_CG1) { beta_cg = (T)S.beta; beta = (T)(-S.alpha); gam = (T)(-S.alpha * S.beta); }
     }
     // `own`: the plane belongs to this workgroup's chunk (MATVEC_AD sums d_new * r over exactly those)
-    auto combine = [&](const VT (&A)[R], const VT (&B)[R], const VT (&Cc)[R], VT (&S)[R], bool own) {
+    auto combine = [&](const VT (&A)[R], const VT (&B)[R], const VT (&Cc)[R], VT (&S)[R], bool own, bool zero) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             S[rr] = A[rr];
@@ -390,39 +409,13 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 #pragma unroll
                     for (int v = 0; v < V; ++v) S[rr].v[v] = fma(gam, Cc[rr].v[v], S[rr].v[v]);
                 }
-                if (AD && own) {
+                if (AD && own && ok[rr]) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc2 += S[rr].v[v] * A[rr].v[v];
                 }
             }
+            if (zero) S[rr] = vec_zero<T, V>();
         }
-    };
-
-    // ---- source loaders ---------------------------------------------------------------------------------------------
-    auto src_vec = [&](long long off) -> VT {
-        VT s = vec_load<T, V>(p.a + base + off);
-        if (IS_MV) {
-            VT d = vec_load<T, V>(p.b + base + off);
-#pragma unroll
-            for (int v = 0; v < V; ++v) s.v[v] = fma(beta, d.v[v], s.v[v]);
-        }
-        if (IS_CG1) {
-            VT d = vec_load<T, V>(p.c + base + off);
-#pragma unroll
-            for (int v = 0; v < V; ++v) s.v[v] = fma(gam, d.v[v], s.v[v]);
-        }
-        return s;
-    };
-    auto src_one = [&](long long off) -> T {
-        T s = p.a[base + off];
-        if (IS_MV) s = fma(beta, p.b[base + off], s);
-        if (IS_CG1) s = fma(gam, p.c[base + off], s);
-        return s;
-    };
-    auto load_plane = [&](int i, VT (&S)[R], bool own) {
-        VT A[R], B[R], Cc[R];
-        load_raw(i, A, B, Cc);
-        combine(A, B, Cc, S, own);
     };
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
@@ -436,14 +429,15 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
     const int cols_here = min(T2, n2 - t2 * T2);   // valid columns of this tile
     bool hv_ok = false, hv_zero = false, hs_ok = false, hs_zero = false;
     int hv_lrow = 0, hs_lcol = 0;
-    long long hv_off = 0, hs_off = 0;   // offsets within a plane
+    int h_o = 0, hs_e = 0;    // ONE vector load per thread and source plane serves both kinds of item: offset of the 16-byte vector within a
+                              // plane (0 = a harmless address for lanes that have nothing to fetch); scalar items pick element hs_e of it
     if (hv_role) {
         const int jh2 = t2 * T2 + hv_col * V;
         const int jh1 = hv_side == 0 ? t1 * T1 - 1 : t1 * T1 + rows_here;
         hv_lrow = hv_side == 0 ? 0 : rows_here + 1;
         const int jt1 = nb_index(jh1, n1, g.nb[1][0], g.nb[1][1], hv_zero);
         hv_ok = jh2 < n2;
-        hv_off = (long long)jt1 * n2 + jh2;
+        if (hv_ok && !hv_zero) h_o = jt1 * n2 + jh2;
     }
     if (hs_role) {
         const int jh1 = t1 * T1 + hs_row;
@@ -451,14 +445,35 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         hs_lcol = hs_side == 0 ? V - 1 : V + cols_here;
         const int jt2 = nb_index(jh2, n2, g.nb[2][0], g.nb[2][1], hs_zero);
         hs_ok = jh1 < n1;
-        hs_off = (long long)jh1 * n2 + jt2;
+        if (hs_ok && !hs_zero) {
+            h_o = jh1 * n2 + (jt2 / V) * V;      // rows start on vector boundaries (n2 % V == 0 on the vector path)
+            hs_e = jt2 % V;
+        }
     }
-    auto load_halo = [&](int i, VT& hv, T& hs) {
-        const long long poff = (long long)i * n1 * n2;
-        hv = vec_zero<T, V>();
-        hs = T(0);
-        if (hv_ok && !hv_zero) hv = src_vec(poff + hv_off);
-        if (hs_ok && !hs_zero) hs = src_one(poff + hs_off);
+    struct HaloRaw {
+        VT va, vb, vc;
+    };
+    auto load_halo = [&](int i, HaloRaw& H) {
+        const long long poff = base + (long long)i * plane;
+        H.va = vec_load<T, V>(p.a + poff + h_o);
+        if (IS_MV) H.vb = vec_load<T, V>(p.b + poff + h_o);
+        if (IS_CG1) H.vc = vec_load<T, V>(p.c + poff + h_o);
+    };
+    auto combine_halo = [&](const HaloRaw& H, VT& hv, T& hs) {
+        hv = H.va;
+        if (IS_MV) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) hv.v[v] = fma(beta, H.vb.v[v], H.va.v[v]);
+        }
+        if (IS_CG1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) hv.v[v] = fma(gam, H.vc.v[v], hv.v[v]);
+        }
+        hs = hv.v[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) hs = hs_e == v ? hv.v[v] : hs;
+        if (hv_zero) hv = vec_zero<T, V>();
+        if (hs_zero) hs = T(0);
     };
 
     // ---- per-plane extra operands (own cells only) --------------------------------------------------------------------
@@ -469,41 +484,45 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         VF fl[R];   // stencil flags
     };
     auto load_extra = [&](int i, Extra& E) {
+        const long long poff = base + (long long)i * plane;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (!ok[rr]) continue;
-            const long long off = ((long long)i * n1 + (j1b + rr)) * n2 + j2;
-            if (IS_RES) E.e1[rr] = vec_load<T, V>(p.b + base + off);
+            const long long off = poff + own_off[rr];
+            if (IS_RES) E.e1[rr] = vec_load<T, V>(p.b + off);
             if (IS_UP) {
-                if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + base + off);
-                E.e2[rr] = vec_load<T, V>(p.o2 + base + off);
+                if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + off);
+                E.e2[rr] = vec_load<T, V>(p.o2 + off);
             }
             if (IS_CG1) {
-                E.e1[rr] = vec_load<T, V>(p.o4 + base + off);
-                E.e2[rr] = vec_load<T, V>(p.o5 + base + off);
-                E.e3[rr] = vec_load<T, V>(p.a + base + off);
-                E.e4[rr] = vec_load<T, V>(p.b + base + off);
-                E.e5[rr] = vec_load<T, V>(p.c + base + off);
+                E.e1[rr] = vec_load<T, V>(p.o4 + off);
+                E.e2[rr] = vec_load<T, V>(p.o5 + off);
+                E.e3[rr] = vec_load<T, V>(p.a + off);
+                E.e4[rr] = vec_load<T, V>(p.b + off);
+                E.e5[rr] = vec_load<T, V>(p.c + off);
             }
-            if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + fbase + off);
+            if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + (fbase - base) + off);
         }
     };
+    // destination of a store: the cell's slot, or the dump slot for lanes outside the grid
+    auto dst = [&](T* arr, long long off, int rr) -> T* { return ok[rr] ? arr + off : p.dump; };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------
     VT Sp[R], Sc[R], Sn[R];
-    VT hv_c, hv_n;
-    T hs_c, hs_n;
-    Extra Ec, En;
+    VT Rn_a[R], Rn_b[R], Rn_c[R];
+    bool zero_n = false;
+    HaloRaw Hn;
+    Extra En;
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
         Sp[rr] = vec_zero<T, V>();
         Sn[rr] = vec_zero<T, V>();
+        Rn_a[rr] = Rn_b[rr] = Rn_c[rr] = vec_zero<T, V>();
     }
-    if (DIM3) combine(Ra_p, Rb_p, Rc_p, Sp, false);
-    combine(Ra_c, Rb_c, Rc_c, Sc, true);
-    load_halo(i_first, hv_c, hs_c);
-    load_extra(i_first, Ec);
-    hv_n = hv_c; hs_n = hs_c; En = Ec;
+    if (DIM3) combine(Ra_p, Rb_p, Rc_p, Sp, false, zero_p);
+    combine(Ra_c, Rb_c, Rc_c, Sc, true, zero_c);
+    if (DIM3) load_raw(i_first + step, Rn_a, Rn_b, Rn_c, zero_n);
+    load_halo(i_first, Hn);
+    load_extra(i_first, En);
 
     int buf = 0;
     const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
@@ -511,10 +530,19 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
 
     // Sp = the plane behind, Sn = the plane ahead in marching direction (the a0 stencil is symmetric in them)
     const unsigned bit_behind = step > 0 ? 1u : 2u, bit_ahead = step > 0 ? 2u : 1u;
-    for (int k = 0, i = i_first; k < count; ++k, i += step) {
-        if (DIM3) load_plane(i + step, Sn, k + 1 < count);
-        if (k + 1 < count) {
-            load_halo(i + step, hv_n, hs_n);
+    int i = i_first;
+    // One plane. What the previous trip requested is consumed at the top (it has had a whole trip to arrive), then the requests for the
+    // trips to come are issued -- source plane i + 2, halo and own-cell operands of plane i + 1 -- and stay in flight across the barrier.
+    auto one_plane = [&](auto has_next_tag) {
+        constexpr bool has_next = decltype(has_next_tag)::value;
+        if (DIM3) combine(Rn_a, Rn_b, Rn_c, Sn, has_next, zero_n);
+        VT hv_c;
+        T hs_c;
+        combine_halo(Hn, hv_c, hs_c);
+        const Extra Ec = En;
+        if (has_next) {
+            if (DIM3) load_raw(i + 2 * step, Rn_a, Rn_b, Rn_c, zero_n);
+            load_halo(i + step, Hn);
             load_extra(i + step, En);
         }
         T* L = lds[buf];
@@ -525,9 +553,9 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
         if (hs_ok) L[(hs_row + 1) * LS + hs_lcol] = hs_c;
         __syncthreads();
 
+        const long long poff = base + (long long)i * plane;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            if (!ok[rr]) continue;
             const int lr = lrow0 + rr;
             VT up, dn;
             if (rr > 0) up = Sc[rr - 1]; else up = vec_load<T, V>(L + (lr - 1) * LS + lcol);
@@ -566,14 +594,15 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                 }
                 q.v[v] = r;
             }
-            const long long off = base + ((long long)i * n1 + (j1b + rr)) * n2 + j2;
+            const long long off = poff + own_off[rr];
+            T s1 = T(0), s2 = T(0);   // this row's contributions to the two dot products
             if (IS_AP) {
-                vec_store<T, V>(p.o1 + off, q);
+                vec_store<T, V>(dst(p.o1, off, rr), q);
                 if (MODE == MODE_APPLY_DOT) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        acc1 += Sc[rr].v[v] * Sc[rr].v[v];
-                        acc2 += q.v[v] * Sc[rr].v[v];
+                        s1 += Sc[rr].v[v] * Sc[rr].v[v];
+                        s2 += q.v[v] * Sc[rr].v[v];
                     }
                 }
             } else if (IS_CG1) {
@@ -583,14 +612,14 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     pn.v[v] = fma(beta_cg, Ec.e1[rr].v[v], Ec.e3[rr].v[v]);       // p = r + beta p
                     sn.v[v] = fma(beta_cg, Ec.e5[rr].v[v], Ec.e4[rr].v[v]);       // s = w + beta s  (= A p)
                     xn.v[v] = fma(-beta, pn.v[v], Ec.e2[rr].v[v]);                // x += alpha p   (beta holds -alpha here)
-                    acc1 += Sc[rr].v[v] * Sc[rr].v[v];                           // gamma' = |r_new|^2
-                    acc2 += q.v[v] * Sc[rr].v[v];                                // delta' = (A r_new) . r_new
+                    s1 += Sc[rr].v[v] * Sc[rr].v[v];                  // gamma' = |r_new|^2
+                    s2 += q.v[v] * Sc[rr].v[v];                       // delta' = (A r_new) . r_new
                 }
-                vec_store<T, V>(p.o4 + off, pn);
-                vec_store<T, V>(p.o3 + off, sn);
-                vec_store<T, V>(p.o5 + off, xn);
-                vec_store<T, V>(p.o1 + off, Sc[rr]);
-                vec_store<T, V>(p.o2 + off, q);
+                vec_store<T, V>(dst(p.o4, off, rr), pn);
+                vec_store<T, V>(dst(p.o3, off, rr), sn);
+                vec_store<T, V>(dst(p.o5, off, rr), xn);
+                vec_store<T, V>(dst(p.o1, off, rr), Sc[rr]);
+                vec_store<T, V>(dst(p.o2, off, rr), q);
             } else if (IS_RES) {
                 VT r, yb;
 #pragma unroll
@@ -602,15 +631,15 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                         yb.v[v] = y;
                     }
                     r.v[v] = y - q.v[v];
-                    acc1 += r.v[v] * r.v[v];
-                    acc2 += y * y;
+                    s1 += r.v[v] * r.v[v];
+                    s2 += y * y;
                 }
-                if (MODE == MODE_RESID_BAL) vec_store<T, V>(p.yout + off, yb);
-                vec_store<T, V>(p.o1 + off, r);
+                if (MODE == MODE_RESID_BAL) vec_store<T, V>(dst(p.yout, off, rr), yb);
+                vec_store<T, V>(dst(p.o1, off, rr), r);
             } else if (IS_MV) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc1 += Sc[rr].v[v] * q.v[v];
-                vec_store<T, V>(p.o1 + off, Sc[rr]);
+                for (int v = 0; v < V; ++v) s1 += Sc[rr].v[v] * q.v[v];
+                vec_store<T, V>(dst(p.o1, off, rr), Sc[rr]);
             } else {
                 VT xn, rn;
 #pragma unroll
@@ -618,11 +647,15 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
                     if (MODE == MODE_UPDATE_X2) xn.v[v] = Ec.e1[rr].v[v] + beta * (Sc[rr].v[v] - Ec.e2[rr].v[v]) + alpha * Sc[rr].v[v];
                     else if (HAS_X) xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
                     rn.v[v] = Ec.e2[rr].v[v] - alpha * q.v[v];
-                    acc1 += rn.v[v] * rn.v[v];
-                    if (AD) acc2 += rn.v[v] * q.v[v];
+                    s1 += rn.v[v] * rn.v[v];
+                    if (AD) s2 += rn.v[v] * q.v[v];
                 }
-                if (HAS_X) vec_store<T, V>(p.o1 + off, xn);
-                vec_store<T, V>(p.o2 + off, rn);
+                if (HAS_X) vec_store<T, V>(dst(p.o1, off, rr), xn);
+                vec_store<T, V>(dst(p.o2, off, rr), rn);
+            }
+            if (ok[rr]) {   // lanes outside the grid computed on garbage (possibly NaN): keep them out of the sums
+                acc1 += s1;
+                acc2 += s2;
             }
         }
 #pragma unroll
@@ -630,9 +663,11 @@ __global__ __launch_bounds__(kBlock) void march_kernel(MarchGrid g, MarchArgs<T>
             Sp[rr] = Sc[rr];
             Sc[rr] = Sn[rr];
         }
-        hv_c = hv_n; hs_c = hs_n; Ec = En;
         buf ^= 1;
-    }
+        i += step;
+    };
+    for (int k = 0; k + 1 < count; ++k) one_plane(std::true_type{});
+    if (count > 0) one_plane(std::false_type{});
 
     if (MODE != MODE_APPLY) {
         const double s1 = block_sum((double)acc1, red);
