@@ -18,7 +18,16 @@
 // Algorithmic traffic 2 D words per cell; the kernel reads each velocity sample once per workgroup (+ halo) and writes each once.
 #include <math.h>
 
+#include <type_traits>
+
 #include "advect_common.hpp"
+
+#ifndef PHIHIP_ADV_WAVES
+#define PHIHIP_ADV_WAVES 3
+#endif
+#ifndef PHIHIP_ADV_WAVES_F64
+#define PHIHIP_ADV_WAVES_F64 2
+#endif
 
 namespace phihip {
 
@@ -88,6 +97,13 @@ __device__ __forceinline__ void sched_fence() {
 #endif
 }
 
+// hides a value from the optimiser (no instruction): what is computed from it cannot be hoisted out of the loop and kept in a register
+__device__ __forceinline__ void opaque_int(int& v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" : "+v"(v));
+#endif
+}
+
 // min(max(x, lo), hi) as ONE v_med3 (NaN -> lo, which the callers treat as "outside")
 __device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -99,9 +115,9 @@ __device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
 __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
 
 template <typename T, int DIM, int H, int T1, int OFFM>
-__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
+__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? PHIHIP_ADV_WAVES : PHIHIP_ADV_WAVES_F64) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
-                                                                  int* __restrict__ flags) {
+                                                                  int* __restrict__ flags, T* __restrict__ dump) {
     using C = AdvTile<T, DIM, H, T1>;
     constexpr int A0 = 3 - DIM;
     constexpr int T2 = C::T2, TY = C::TY, S = C::S, P1 = C::P1, P2 = C::P2, PLANE = C::PLANE, NC = C::NC, NP = C::NP, KP = C::KP;
@@ -163,6 +179,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
             const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
             eoff[c][kp] = (unsigned)((j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k));
         }
+        if (!last_ok) eoff[c][KP - 1] = eoff[c][0];   // (row past the window: the load still runs -- see load_plane -- on a valid address)
     }
     // tail element (halo columns T2 .. T2+2H-1 of every row): component, row and column of THIS thread
     const bool has_tail = tid < C::NTAIL;
@@ -196,6 +213,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
         w = min(max(w, 0), n - 1);
         return (long long)w * pstride[c];
     };
+    // Every global load (and, in compute_plane, store) of the plane loop is unconditional: hipcc can then count the outstanding operations
+    // and waits with s_waitcnt vmcnt(N > 0) for the register set that is due, while the younger requests stay in flight (with loads
+    // under `if` it drains the queue, i.e. it also waits for the output stores it has just issued -- stencil_march.hpp has the story).
     auto load_plane = [&](int i0, T (&R)[3][KP], T& tailv) {
         long long psrc[3] = {0, 0, 0};
 #pragma unroll
@@ -203,34 +223,35 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
             psrc[c] = plane_src(c, i0);
             const T* __restrict__ base = vel.p[c] + (long long)b * g.ccells[c] + psrc[c];
 #pragma unroll
-            for (int kp = 0; kp < KP; ++kp)
-                if (kp < KP - 1 || last_ok) R[c][kp] = base[eoff[c][kp]];
+            for (int kp = 0; kp < KP; ++kp) R[c][kp] = base[eoff[c][kp]];
         }
-        if (has_tail) tailv = (tail_base + (tail_c == 0 ? psrc[0] : (tail_c == 1 ? psrc[1] : psrc[2])))[tail_off];
-        if (has_const) {   // PhiML pads axis after axis: the LAST axis outside a constant side decides (a2 over a1 over a0)
+        tailv = (tail_base + (tail_c == 0 ? psrc[0] : (tail_c == 1 ? psrc[1] : psrc[2])))[tail_off];
+    };
+    // constant sides are patched in when the plane enters the ring (cold, uniform: only workgroups whose window crosses a CLOSED side)
+    auto patch_plane = [&](int i0, T (&R)[3][KP], T& tailv) {
+        // PhiML pads axis after axis: the LAST axis outside a constant side decides (a2 over a1 over a0)
 #pragma unroll
-            for (int c = A0; c < 3; ++c) {
-                const int k = DIM == 3 ? pad_index(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;
-                // (values first, selects after: a select between two kernel-argument LOADS becomes a per-lane address + flat load)
-                const T k00 = g.bcv[0][0][c], k01 = g.bcv[0][1][c], k10 = g.bcv[1][0][c], k11 = g.bcv[1][1][c], k20 = g.bcv[2][0][c], k21 = g.bcv[2][1][c];
-                const T pv = k == -1 ? k00 : k01;
-                const T cv = ccode[c] == 1 ? k20 : k21;
+        for (int c = A0; c < 3; ++c) {
+            const int k = DIM == 3 ? pad_index(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;
+            // (values first, selects after: a select between two kernel-argument LOADS becomes a per-lane address + flat load)
+            const T k00 = g.bcv[0][0][c], k01 = g.bcv[0][1][c], k10 = g.bcv[1][0][c], k11 = g.bcv[1][1][c], k20 = g.bcv[2][0][c], k21 = g.bcv[2][1][c];
+            const T pv = k == -1 ? k00 : k01;
+            const T cv = ccode[c] == 1 ? k20 : k21;
 #pragma unroll
-                for (int kp = 0; kp < KP; ++kp) {
-                    T v = R[c][kp];
-                    const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
-                    const T rv = j == -1 ? k10 : k11;
-                    v = k < 0 ? pv : v;
-                    v = j < 0 ? rv : v;
-                    v = ccode[c] ? cv : v;
-                    R[c][kp] = v;
-                }
-                if (has_tail && c == tail_c) {
-                    const T rv = tail_rcode == 1 ? k10 : k11, cv2 = tail_ccode == 1 ? k20 : k21;
-                    tailv = k < 0 ? pv : tailv;
-                    tailv = tail_rcode ? rv : tailv;
-                    tailv = tail_ccode ? cv2 : tailv;
-                }
+            for (int kp = 0; kp < KP; ++kp) {
+                T v = R[c][kp];
+                const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
+                const T rv = j == -1 ? k10 : k11;
+                v = k < 0 ? pv : v;
+                v = j < 0 ? rv : v;
+                v = ccode[c] ? cv : v;
+                R[c][kp] = v;
+            }
+            if (has_tail && c == tail_c) {
+                const T rv = tail_rcode == 1 ? k10 : k11, cv2 = tail_ccode == 1 ? k20 : k21;
+                tailv = k < 0 ? pv : tailv;
+                tailv = tail_rcode ? rv : tailv;
+                tailv = tail_ccode ? cv2 : tailv;
             }
         }
     };
@@ -242,7 +263,11 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
             for (int kp = 0; kp < KP; ++kp)
                 if (kp < KP - 1 || last_ok) L[(ty + kp * TY) * P2 + tx] = R[c][kp];
         }
-        if (has_tail) lds[(tail_ci * NP + slot) * PLANE + tail_r * P2 + tail_q] = tailv;
+        // The tail element's ring position is recomputed from the thread index every time: kept live it was spilled to scratch, and a scratch
+        // reload counts as a VMEM load -- the s_waitcnt vmcnt(0) behind it drained every request in flight, once per plane.
+        int t = tid;
+        opaque_int(t);
+        if (t < C::NTAIL) lds[((t / (P1 * 2 * H)) * NP + slot) * PLANE + ((t % (P1 * 2 * H)) / (2 * H)) * P2 + T2 + t % (2 * H)] = tailv;
     };
     auto slot_of = [&](int i0) -> int {   // uniform
         if (DIM == 2) return 0;
@@ -324,7 +349,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
                     y[k] = fma(fr[1], x1 - x0, x0);
                 }
                 const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
-                if (valid) (outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca])[obase[ca] + (unsigned)(s * TY * g.cn[ca][2])] = val;
+                T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
+                *(valid ? slot : dump) = val;     // unconditional store (see load_plane)
                 sched_fence();     // one sample's LDS reads in flight at a time: 4 waves per SIMD hide the latency, registers stay <= 128
             }
         }
@@ -336,17 +362,40 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? 4 : 2) vo
     T RA[3][KP], RB[3][KP];
     T tailA = T(0), tailB = T(0);
     const int k_lo = DIM == 3 ? pb - H : 0, k_hi = DIM == 3 ? pe - 1 + H : 0;     // planes this workgroup stages
-    auto half_step = [&](int p, T (&Rld)[3][KP], T& tail_ld, const T (&Rst)[3][KP], const T& tail_st) {
+    auto half_step = [&](int p, auto mode_tag, T (&Rld)[3][KP], T& tail_ld, T (&Rst)[3][KP], T& tail_st) {
+        constexpr int MODE_ = decltype(mode_tag)::value;   // 0: the general half-step (2-D), 1: ring warm-up (no samples yet), 2: steady state
         const int kl = p + H + 2, ks = p + H + 1;
-        if (kl >= k_lo && kl <= k_hi) load_plane(kl, Rld, tail_ld);
-        if (p >= pb && p < pe) compute_plane(p);
-        if (ks >= k_lo && ks <= k_hi) store_plane(slot_of(ks), Rst, tail_st);
+        if (MODE_ == 0) {
+            if (kl >= k_lo && kl <= k_hi) load_plane(kl, Rld, tail_ld);
+            if (p >= pb && p < pe) compute_plane(p);
+        } else {
+            load_plane(min(max(kl, k_lo), k_hi), Rld, tail_ld);   // (past the last staged plane: that plane again, nobody stores it)
+            if (MODE_ == 2) compute_plane(p);
+        }
+        if (ks >= k_lo && ks <= k_hi) {
+            if (has_const) patch_plane(ks, Rst, tail_st);
+            store_plane(slot_of(ks), Rst, tail_st);
+        }
         __syncthreads();
     };
     const int p_first = k_lo - H - 2;     // the half-step that requests the first staged plane
-    for (int p = p_first; p < pe; p += 2) {
-        half_step(p, RA, tailA, RB, tailB);
-        half_step(p + 1, RB, tailB, RA, tailA);
+    if (DIM == 3) {
+        // pb - p_first = 2H + 2 half-steps fill the ring, then every half-step computes a plane: both loops are straight-line code
+        int p = p_first;
+        for (; p < pb; p += 2) {
+            half_step(p, std::integral_constant<int, 1>{}, RA, tailA, RB, tailB);
+            half_step(p + 1, std::integral_constant<int, 1>{}, RB, tailB, RA, tailA);
+        }
+        for (; p + 1 < pe; p += 2) {
+            half_step(p, std::integral_constant<int, 2>{}, RA, tailA, RB, tailB);
+            half_step(p + 1, std::integral_constant<int, 2>{}, RB, tailB, RA, tailA);
+        }
+        if (p < pe) half_step(p, std::integral_constant<int, 2>{}, RA, tailA, RB, tailB);
+    } else {
+        for (int p = p_first; p < pe; p += 2) {
+            half_step(p, std::integral_constant<int, 0>{}, RA, tailA, RB, tailB);
+            half_step(p + 1, std::integral_constant<int, 0>{}, RB, tailB, RA, tailA);
+        }
     }
     if (slow_any) slow_sh = 1;
     __syncthreads();
@@ -434,12 +483,14 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
         chunks0 = ceil_div(nmax[0], chunk);
     }
     const int nblk = tiles1 * tiles2 * chunks0;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, (size_t)nblk * v.batch * sizeof(int)));
+    const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
     int* flags = (int*)ctx->ws_adv_flags.ptr;
+    T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
     ctx->adv_last_nblk = nblk * v.batch;
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2],
-                       chunk, tiles1, tiles2, nblk, nmax[0], flags);
+                       chunk, tiles1, tiles2, nblk, nmax[0], flags, dump);
     hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;
