@@ -25,6 +25,9 @@
 #ifndef PHIHIP_ADV_WAVES
 #define PHIHIP_ADV_WAVES 3
 #endif
+#ifndef PHIHIP_ADV_FENCE
+#define PHIHIP_ADV_FENCE 1
+#endif
 #ifndef PHIHIP_ADV_WAVES_F64
 #define PHIHIP_ADV_WAVES_F64 2
 #endif
@@ -351,8 +354,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                 const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
                 T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
                 *(valid ? slot : dump) = val;     // unconditional store (see load_plane)
-                sched_fence();     // one sample's LDS reads in flight at a time: 4 waves per SIMD hide the latency, registers stay <= 128
+                if (PHIHIP_ADV_FENCE == 1) sched_fence();     // one sample's LDS reads in flight at a time
             }
+            if (PHIHIP_ADV_FENCE == 2) sched_fence();         // one position (all components) at a time
         }
     };
 
