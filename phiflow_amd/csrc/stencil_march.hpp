@@ -312,7 +312,9 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     constexpr bool IS_RES = MODE == MODE_RESID || MODE == MODE_RESID_BAL;
     const T yshift = MODE == MODE_RESID_BAL ? (T)p.shift[b] : T(0);
     T alpha = T(0), beta = T(0), gam = T(0), beta_cg = T(0);   // CG1: S = A + beta B + gam C with beta = -alpha, gam = -alpha beta_cg
-    T acc1 = T(0), acc2 = T(0);
+    // per-thread partial sums of the dot products: one row of a plane is summed in T, rows and planes are added up in double (a thread of
+    // a 512^3 launch adds ~1000 rows; in fp32 that alone cost the eigenfunction test five extra iterations)
+    double acc1 = 0.0, acc2 = 0.0;
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
@@ -410,8 +412,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     for (int v = 0; v < V; ++v) S[rr].v[v] = fma(gam, Cc[rr].v[v], S[rr].v[v]);
                 }
                 if (AD && own && ok[rr]) {
+                    T sa = T(0);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) acc2 += S[rr].v[v] * A[rr].v[v];
+                    for (int v = 0; v < V; ++v) sa += S[rr].v[v] * A[rr].v[v];
+                    acc2 += (double)sa;
                 }
             }
             if (zero) S[rr] = vec_zero<T, V>();
@@ -654,8 +658,8 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                 vec_store<T, V>(dst(p.o2, off, rr), rn);
             }
             if (ok[rr]) {   // lanes outside the grid computed on garbage (possibly NaN): keep them out of the sums
-                acc1 += s1;
-                acc2 += s2;
+                acc1 += (double)s1;
+                acc2 += (double)s2;
             }
         }
 #pragma unroll
@@ -670,10 +674,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     if (count > 0) one_plane(std::false_type{});
 
     if (MODE != MODE_APPLY) {
-        const double s1 = block_sum((double)acc1, red);
+        const double s1 = block_sum(acc1, red);
         if (tid == 0) p.part1[(long long)b * g.nblk + blockIdx.x] = s1;
         if (IS_RES || AD || IS_CG1 || MODE == MODE_APPLY_DOT) {
-            const double s2 = block_sum((double)acc2, red);
+            const double s2 = block_sum(acc2, red);
             if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
         }
     }
