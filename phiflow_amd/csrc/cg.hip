@@ -414,7 +414,23 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         };
         Cand warm = cands[0];
         status = run(warm, 2);                                                   // clocks up, code loaded
-        for (size_t k = 0; k < cands.size() && status == PHIHIP_OK; ++k) status = run(cands[k], 2);
+        // Time budget of the first pass: max(60 ms, 40 launches of the model's plan) per family -- everything at <= 512^3, the model's tile
+        // with its other chunk lengths first and then whatever fits at 1024^3 (2.5 ms per launch), where trying all ~100 would cost seconds.
+        // Untimed candidates keep us = 1e30 and cannot win.
+        {
+            std::vector<Cand> ordered;
+            ordered.push_back(cands[0]);
+            for (size_t k = 1; k < cands.size(); ++k) if (cands[k].id == cands[0].id) ordered.push_back(cands[k]);
+            for (size_t k = 1; k < cands.size(); ++k) if (cands[k].id != cands[0].id) ordered.push_back(cands[k]);
+            cands.swap(ordered);
+        }
+        double spent_us = 0, budget_us = 6e4;
+        for (size_t k = 0; k < cands.size() && status == PHIHIP_OK; ++k) {
+            if (k > 0 && spent_us > budget_us) { cands[k].us = 1e30f; continue; }
+            status = run(cands[k], 2);
+            if (k == 0 && 40.0 * cands[0].us > budget_us) budget_us = 40.0 * cands[0].us;
+            spent_us += 2.0 * cands[k].us;
+        }
         // confirm the leaders with more repetitions (single launches of ~30 us carry a few % of timer noise)
         std::vector<size_t> order(cands.size());
         for (size_t k = 0; k < order.size(); ++k) order[k] = k;

@@ -96,11 +96,13 @@ int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
     }
 }
 
-// the slot that lanes outside the grid store into (march_kernel issues every store unconditionally); one per process and instantiation unit
+// the slot that lanes outside the grid store into (march_kernel issues every store unconditionally); one per device and instantiation unit
 static InstT* march_dump_slot() {
-    static void* slot = nullptr;
-    if (!slot && hipMalloc(&slot, 256) != hipSuccess) slot = nullptr;
-    return (InstT*)slot;
+    static void* slot[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!slot[dev] && hipMalloc(&slot[dev], 256) != hipSuccess) slot[dev] = nullptr;
+    return (InstT*)slot[dev];
 }
 
 template <>

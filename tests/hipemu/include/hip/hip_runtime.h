@@ -104,6 +104,7 @@ hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int d);
 // emulation: pretend 4 resident workgroups per CU for every kernel
 template <typename F>
