@@ -146,3 +146,150 @@ class SlabSolver:
                 if not any(i.reserved for i in infos):
                     break
         return ctx.slab_state(g, first, sums_in.data_ptr(), csolve, False, s)
+
+
+class SlabFluid:
+    """ The whole fluid step -- advect.semi_lagrangian(v, v, dt), divergence, pressure solve, gradient subtraction (phi/physics/advect.py:
+    156-179, phi/physics/fluid.py:94-162) -- for ONE 3-D simulation decomposed into x-slabs (no reference counterpart).
+
+    Every rank stores the samples it OWNS: the cells [begin, end) of centred fields and of the y / z velocity components, and the x faces
+    [face_begin, face_end) (face f = lower face of cell f; the last rank also owns the outer face of an OPEN upper side). Advection,
+    divergence and gradient run the ordinary single-GPU kernels on the slab EXTENDED by `ghost` planes of the neighbours' samples on each cut
+    side (one packed message per neighbour and operation); the cut sides of the extended grid are declared OPEN, which only shapes results
+    inside the ghost zone -- those are discarded. The reach of the operators bounds what is exact: divergence and gradient need one plane,
+    the advection |u| dt / dx <= ghost - 1 cells along x (back-trace + multilinear taps + the 4-point means of the other components).
+    The pressure solve is `SlabSolver` on the owned cells. """
+
+    def __init__(self, backend, res, lower, upper, bc, dtype=torch.float32, batch: int = 1, bc_val=None, ghost: int = 2, group=None):
+        assert len(res) == 3 and ghost >= 1
+        self.be, self.group, self.dtype, self.batch, self.ghost = backend, group, dtype, int(batch), int(ghost)
+        self.res, self.bc = tuple(int(r) for r in res), [tuple(int(c) for c in p) for p in bc]
+        self.solver = SlabSolver(backend, res, lower, upper, bc, dtype, batch, group)
+        s = self.solver
+        self.world, self.rank, self.begin, self.end = s.world, s.rank, s.begin, s.end
+        self.lo_rank, self.hi_rank = s.lo_rank, s.hi_rank
+        n0 = self.res[0]
+        assert self.world == 1 or min(slab_range(n0, r, self.world)[1] - slab_range(n0, r, self.world)[0] for r in range(self.world)) >= ghost + 1, \
+            "every slab needs at least ghost + 1 planes"
+        self.gl = ghost if self.lo_rank is not None else 0
+        self.gr = ghost if self.hi_rank is not None else 0
+        # owned x faces (global face numbers): face 0 is stored unless the lower side is CLOSED, face n0 only on an OPEN upper side
+        self.face_begin = self.begin if (self.begin > 0 or self.bc[0][0] != _capi.BC_CLOSED) else 1
+        self.face_end = self.end + (1 if (self.end == n0 and self.bc[0][1] == _capi.BC_OPEN) else 0)
+        dx = (upper[0] - lower[0]) / n0
+        local_bc = [list(p) for p in self.bc]
+        if self.lo_rank is not None:
+            local_bc[0][0] = _capi.BC_OPEN
+        if self.hi_rank is not None:
+            local_bc[0][1] = _capi.BC_OPEN
+        if self.world > 1 and self.bc[0][0] == _capi.BC_PERIODIC:
+            local_bc[0] = [_capi.BC_OPEN, _capi.BC_OPEN]
+        code = _capi.PHIHIP_F64 if dtype == torch.float64 else _capi.PHIHIP_F32
+        self.ext_cells = (self.end + self.gr) - (self.begin - self.gl)
+        self.grid = _capi.make_grid(3, code, batch, (self.ext_cells, self.res[1], self.res[2]),
+                                    (lower[0] + (self.begin - self.gl) * dx, lower[1], lower[2]),
+                                    (lower[0] + (self.end + self.gr) * dx, upper[1], upper[2]), local_bc, bc_val)
+        self.ext_shape = [(batch,) + tuple(backend.ctx.component_shape(self.grid, c)) for c in range(3)]
+        off_lo = 1 if local_bc[0][0] == _capi.BC_CLOSED else 0
+        # extended array of component c: planes [own0[c], own0[c] + own_n[c]) are this rank's own samples, lo_n / hi_n ghost planes around them
+        g0 = self.begin - self.gl + off_lo                    # global number of the first stored x face of the extended grid
+        self.own0 = [self.face_begin - g0, self.gl, self.gl]
+        self.own_n = [self.face_end - self.face_begin, self.end - self.begin, self.end - self.begin]
+        self.lo_n = list(self.own0)
+        self.hi_n = [self.ext_shape[c][1] - self.own0[c] - self.own_n[c] for c in range(3)]
+        assert self.lo_n[0] == self.gl and self.hi_n[1] == self.gr and self.hi_n[2] == self.gr
+        assert self.hi_n[0] == (self.gr + 1 if self.hi_rank is not None else 0), (self.hi_n, self.gr)
+        self.own_shape = [(batch, self.own_n[c]) + self.ext_shape[c][2:] for c in range(3)]
+        self.cell_shape = (batch, self.end - self.begin, self.res[1], self.res[2])
+
+    # --- ghost exchange: one packed message per neighbour ---
+    def _pack(self, parts: List[torch.Tensor]) -> torch.Tensor:
+        return torch.cat([p.reshape(-1) for p in parts]) if parts else self.be.zeros((0,), self.dtype)
+
+    def _extend(self, own: List[torch.Tensor], lo_n: List[int], hi_n: List[int], shapes) -> List[torch.Tensor]:
+        """ own[k]: (batch, planes_k, ...) -> arrays with lo_n[k] / hi_n[k] planes of the neighbours' adjacent samples around them. The
+        neighbour sends its top lo_n[k] planes to the rank above and its bottom hi_n[k] planes to the rank below (the counts are the same
+        on every rank with a neighbour on that side). """
+        ext = [self.be.empty(shapes[k], self.dtype) for k in range(len(own))]
+        for k, t in enumerate(own):
+            ext[k][:, lo_n[k]: lo_n[k] + t.shape[1]] = t
+        if self.world == 1:
+            return ext
+        # what goes UP is what the rank above lacks below its own samples (ghost planes of every field), what goes DOWN what the rank below
+        # lacks above them (ghost cell planes, ghost + 1 x faces: the upper face of its last ghost cell included)
+        up_counts = [self.ghost] * len(own)
+        down_counts = [self.ghost + 1, self.ghost, self.ghost] if len(own) == 3 else [self.ghost] * len(own)
+        send_up = self._pack([t[:, t.shape[1] - up_counts[k]:] for k, t in enumerate(own)]) if self.hi_rank is not None else None
+        send_down = self._pack([t[:, : down_counts[k]] for k, t in enumerate(own)]) if self.lo_rank is not None else None
+        plane = [self.batch * int(shapes[k][2]) * int(shapes[k][3]) for k in range(len(own))]
+        recv_lo = self.be.empty((sum(lo_n[k] * plane[k] for k in range(len(own))),), self.dtype) if self.lo_rank is not None else None
+        recv_hi = self.be.empty((sum(hi_n[k] * plane[k] for k in range(len(own))),), self.dtype) if self.hi_rank is not None else None
+        ops = []
+        gr = self.solver._global
+        if self.lo_rank is not None:
+            ops += [dist.P2POp(dist.isend, send_down, gr(self.lo_rank), self.group), dist.P2POp(dist.irecv, recv_lo, gr(self.lo_rank), self.group)]
+        if self.hi_rank is not None:
+            ops += [dist.P2POp(dist.isend, send_up, gr(self.hi_rank), self.group), dist.P2POp(dist.irecv, recv_hi, gr(self.hi_rank), self.group)]
+        if self.world == 2 and self.lo_rank == self.hi_rank and self.lo_rank is not None and self.rank == 1:
+            ops = [ops[2], ops[3], ops[0], ops[1]]        # two ranks on a periodic axis: match my "up" with the peer's "down"
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for side, buf, counts in ((0, recv_lo, lo_n), (1, recv_hi, hi_n)):
+            if buf is None:
+                continue
+            pos = 0
+            for k in range(len(own)):
+                n = counts[k] * plane[k]
+                if n:
+                    block = buf[pos: pos + n].reshape((self.batch, counts[k]) + tuple(shapes[k][2:]))
+                    if side == 0:
+                        ext[k][:, : counts[k]] = block
+                    else:
+                        ext[k][:, shapes[k][1] - counts[k]:] = block
+                pos += n
+        return ext
+
+    def _extend_velocity(self, v: List[torch.Tensor]) -> List[torch.Tensor]:
+        return self._extend(v, self.lo_n, self.hi_n, self.ext_shape)
+
+    def _extend_cells(self, p: torch.Tensor) -> torch.Tensor:
+        shape = (self.batch, self.ext_cells, self.res[1], self.res[2])
+        return self._extend([p], [self.gl], [self.gr], [shape])[0]
+
+    def _own_velocity(self, ext: List[torch.Tensor]) -> List[torch.Tensor]:
+        return [ext[c][:, self.own0[c]: self.own0[c] + self.own_n[c]].contiguous() for c in range(3)]
+
+    # --- the operators ---
+    def advect(self, v: List[torch.Tensor], dt: float) -> List[torch.Tensor]:
+        """ semi-Lagrangian self-advection of the owned velocity samples; exact while |u_x| dt / dx <= ghost - 1 """
+        ext = self._extend_velocity(v)
+        out = [torch.empty_like(t) for t in ext]
+        P = lambda ts: [t.data_ptr() for t in ts]
+        self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
+        return self._own_velocity(out)
+
+    def divergence(self, v: List[torch.Tensor], balance: bool = False) -> torch.Tensor:
+        ext = self._extend_velocity(v)
+        div = self.be.empty((self.batch, self.ext_cells, self.res[1], self.res[2]), self.dtype)
+        self.be.ctx.divergence(self.grid, [t.data_ptr() for t in ext], 0, 1, False, div.data_ptr(), self.be.stream())
+        own = div[:, self.gl: self.gl + (self.end - self.begin)].contiguous()
+        if balance:    # fluid._balance_divergence (fluid.py:205-209) over the WHOLE domain
+            total = own.sum(dim=(1, 2, 3), dtype=torch.float64)
+            if self.world > 1:
+                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+            own -= (total / (self.res[0] * self.res[1] * self.res[2])).to(self.dtype)[:, None, None, None]
+        return own
+
+    def grad_subtract(self, v: List[torch.Tensor], p: torch.Tensor) -> List[torch.Tensor]:
+        ext_v, ext_p = self._extend_velocity(v), self._extend_cells(p)
+        self.be.ctx.grad_subtract(self.grid, 0, 1, ext_p.data_ptr(), [t.data_ptr() for t in ext_v], self.be.stream())
+        return self._own_velocity(ext_v)
+
+    def step(self, v: List[torch.Tensor], p: torch.Tensor, dt: float, rel_tol=1e-5, abs_tol=0.0, max_iterations=1000, refresh_every=50,
+             check_every=10):
+        """ one operator-split time step; `p` holds the pressure guess on entry and the pressure on exit. Returns (v, infos). """
+        v = self.advect(v, dt)
+        singular = all(c != _capi.BC_OPEN for pair in self.bc for c in pair)
+        div = self.divergence(v, balance=singular)
+        infos = self.solver.solve(div, p, rel_tol, abs_tol, max_iterations, refresh_every, check_every)
+        return self.grad_subtract(v, p), infos

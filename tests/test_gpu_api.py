@@ -128,3 +128,33 @@ def test_solve_linear_and_the_backend_level_boundary(gpu_backend):
 def test_scene_files_on_the_device(gpu_backend, tmp_path):
     """ SURVEY §8 f6 with the real library: the reference's scene-file window -> GPU fields -> one step vs the oracle -> round trip """
     golden_cases.run_scene_files(gpu_backend, tmp_path)
+
+
+def test_slab_fluid_single_rank_on_the_device(gpu_backend):
+    """ SURVEY §8 f4 on the GPU with ONE rank (no process group): the slab step is the ordinary step -- exercises SlabFluid / SlabSolver
+    with device tensors; the two-rank form runs under gloo in tests/test_parallel_gloo.py (the boxes have one GPU) """
+    import torch
+    from phiflow_amd import _capi as C
+    from phiflow_amd.slab import SlabFluid
+    res, bc, batch = (48, 32, 64), ((1, 2), (1, 1), (0, 0)), 2
+    ctx = gpu_backend.ctx
+    grid = C.make_grid(3, C.PHIHIP_F32, batch, res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    gen = torch.Generator().manual_seed(5)
+    v = [(0.4 * torch.randn((batch,) + tuple(ctx.component_shape(grid, c)), generator=gen)).to(gpu_backend.device) for c in range(3)]
+    fluid = SlabFluid(gpu_backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=batch)
+    assert fluid.world == 1 and [tuple(s) for s in fluid.own_shape] == [tuple(t.shape) for t in v]
+    p = torch.zeros(fluid.cell_shape, device=gpu_backend.device)
+    out, infos = fluid.step([t.clone() for t in v], p, 0.5, rel_tol=1e-5, max_iterations=500)
+    P = lambda ts: [t.data_ptr() for t in ts]
+    adv = [torch.empty_like(t) for t in v]
+    ctx.advect_staggered(grid, P(v), P(v), P(adv), 0.5)
+    div = torch.empty((batch,) + res, device=gpu_backend.device)
+    ctx.divergence(grid, P(adv), 0, 1, False, div.data_ptr())
+    p_ref = torch.zeros_like(div)
+    info = ctx.cg_solve(grid, 0, 1, div.data_ptr(), p_ref.data_ptr(), C.Solve(1e-5, 0.0, 500, 50, 10, 0))
+    ctx.grad_subtract(grid, 0, 1, p_ref.data_ptr(), P(adv))
+    torch.cuda.synchronize()
+    assert all(i.converged for i in infos) and all(abs(a.iterations - b.iterations) <= 2 for a, b in zip(infos, info))
+    assert float((p - p_ref).abs().max()) <= 2e-4 * float(p_ref.abs().max())
+    for c in range(3):
+        assert float((out[c] - adv[c]).abs().max()) <= 1e-4

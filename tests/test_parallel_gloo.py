@@ -149,3 +149,93 @@ def test_slab_solver_single_rank_equals_cg(emu_backend, emu_ctx):
     info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x_ref.ctypes.data, C.Solve(1e-5, 0.0, 200, 50, 10, 0))
     assert [i.iterations for i in infos] == [i.iterations for i in info] and all(i.converged for i in infos)
     assert np.abs(x.numpy() - x_ref).max() <= 1e-6 * np.abs(x_ref).max()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY §8 f4, the whole step on slabs: advection, divergence and gradient run on the slab extended by ghost planes of the neighbours
+# ---------------------------------------------------------------------------------------------------------------------
+def _fluid_problem(case, dtype=np.float32, batch=2):
+    from phiflow_amd import _capi as C
+    res, bc = SLAB_CASES[case]["res"], SLAB_CASES[case]["bc"]
+    grid = C.make_grid(3, C.PHIHIP_F32, batch, res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    rng = np.random.default_rng(11)
+    return res, bc, grid, rng
+
+
+def _smooth_velocity(ctx, grid, rng, batch):
+    """ a smooth velocity with |u| <= 0.6 cells per unit time on the staggered layout of `grid` """
+    comps = []
+    for c in range(3):
+        shape = ctx.component_shape(grid, c)
+        idx = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in shape], indexing="ij")
+        ph = rng.uniform(0, 2 * np.pi, size=(batch, 3))
+        field = np.stack([0.2 * (np.sin(2 * np.pi * idx[0] / shape[0] + ph[b, 0]) + np.cos(2 * np.pi * idx[1] / shape[1] + ph[b, 1])
+                                 + np.sin(4 * np.pi * idx[2] / shape[2] + ph[b, 2])) for b in range(batch)])
+        comps.append(np.ascontiguousarray(field.astype(np.float32)))
+    return comps
+
+
+def _reference_step(ctx, grid, v, dt, singular):
+    from phiflow_amd import _capi as C
+    P = lambda ts: [t.ctypes.data for t in ts]
+    adv = [np.empty_like(t) for t in v]
+    ctx.advect_staggered(grid, P(v), P(v), P(adv), dt)
+    div = np.empty((grid.batch,) + tuple(grid.res[d] for d in range(3)), np.float32)
+    ctx.divergence(grid, P(adv), 0, 1, singular, div.ctypes.data)
+    p = np.zeros_like(div)
+    info = ctx.cg_solve(grid, 0, 1, div.ctypes.data, p.ctypes.data, C.Solve(1e-5, 0.0, 200, 50, 10, 0))
+    out = [t.copy() for t in adv]
+    ctx.grad_subtract(grid, 0, 1, p.ctypes.data, P(out))
+    return adv, div, p, out, info
+
+
+def _fluid_worker(rank, world, port, emu_path, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PHIHIP_AUTOTUNE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phiflow_amd import _capi
+    from phiflow_amd.backend import HipBackend
+    from phiflow_amd.slab import SlabFluid
+    backend = HipBackend(library=_capi.Library(emu_path), device="cpu")
+    res, bc, grid, rng = _fluid_problem(case)
+    v = _smooth_velocity(backend.ctx, grid, rng, grid.batch)
+    fluid = SlabFluid(backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=grid.batch)
+    off = 0 if bc[0][0] != _capi.BC_CLOSED else 1          # global x face number of stored index 0
+    own = [torch.from_numpy(np.ascontiguousarray(v[0][:, fluid.face_begin - off: fluid.face_end - off])),
+           torch.from_numpy(np.ascontiguousarray(v[1][:, fluid.begin: fluid.end])), torch.from_numpy(np.ascontiguousarray(v[2][:, fluid.begin: fluid.end]))]
+    adv = fluid.advect(own, 0.9)
+    div = fluid.divergence(adv, balance=all(c != 2 for pair in bc for c in pair))
+    p = torch.zeros(fluid.cell_shape, dtype=torch.float32)
+    out, infos = fluid.step(own, p, 0.9, rel_tol=1e-5, max_iterations=200)
+    np.savez(os.path.join(out_dir, f"fluid{rank}.npz"), f0=fluid.face_begin - off, f1=fluid.face_end - off, b0=fluid.begin, b1=fluid.end,
+             adv0=adv[0].numpy(), adv1=adv[1].numpy(), adv2=adv[2].numpy(), div=div.numpy(), p=p.numpy(),
+             out0=out[0].numpy(), out1=out[1].numpy(), out2=out[2].numpy(), it=[i.iterations for i in infos])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", list(SLAB_CASES))
+def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, case):
+    """ two ranks, each owning half of the x planes, reproduce advection, divergence, pressure and the projected velocity of the
+    single-process step (ghost-plane exchange; sample coordinates are rounded at local instead of global index magnitudes) """
+    world = 2
+    mp.spawn(_fluid_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
+    res, bc, grid, rng = _fluid_problem(case)
+    v = _smooth_velocity(emu_ctx, grid, rng, grid.batch)
+    singular = all(c != 2 for pair in bc for c in pair)
+    adv, div, p, out, info = _reference_step(emu_ctx, grid, v, 0.9, singular)
+    parts = [np.load(tmp_path / f"fluid{r}.npz") for r in range(world)]
+    assert int(parts[0]["f0"]) == 0 and int(parts[1]["f1"]) == v[0].shape[1] and int(parts[0]["f1"]) == int(parts[1]["f0"])
+    cat = lambda key: np.concatenate([q[key] for q in parts], axis=1)
+    for c in range(3):
+        assert cat(f"adv{c}").shape == adv[c].shape
+        assert np.abs(cat(f"adv{c}") - adv[c]).max() <= 2e-5, (c, np.abs(cat(f"adv{c}") - adv[c]).max())
+    assert np.abs(cat("div") - div).max() <= 2e-5 * max(1.0, np.abs(div).max())
+    assert all(abs(int(a) - i.iterations) <= 1 for a, i in zip(parts[0]["it"], info))
+    pr, pm = cat("p"), p
+    if singular:
+        pr, pm = pr - pr.mean(axis=(1, 2, 3), keepdims=True), pm - pm.mean(axis=(1, 2, 3), keepdims=True)
+    assert np.abs(pr - pm).max() <= 5e-4 * np.abs(pm).max(), np.abs(pr - pm).max() / np.abs(pm).max()
+    for c in range(3):
+        assert np.abs(cat(f"out{c}") - out[c]).max() <= 2e-4, (c, np.abs(cat(f"out{c}") - out[c]).max())
