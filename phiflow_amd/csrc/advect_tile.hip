@@ -22,15 +22,6 @@
 
 #include "advect_common.hpp"
 
-#ifndef PHIHIP_ADV_WAVES
-#define PHIHIP_ADV_WAVES 3
-#endif
-#ifndef PHIHIP_ADV_FENCE
-#define PHIHIP_ADV_FENCE 1
-#endif
-#ifndef PHIHIP_ADV_WAVES_F64
-#define PHIHIP_ADV_WAVES_F64 2
-#endif
 
 namespace phihip {
 
@@ -118,7 +109,7 @@ __device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
 __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
 
 template <typename T, int DIM, int H, int T1, int OFFM>
-__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? PHIHIP_ADV_WAVES : PHIHIP_ADV_WAVES_F64) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
+__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? 3 : 2) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
                                                                   int* __restrict__ flags, T* __restrict__ dump) {
     using C = AdvTile<T, DIM, H, T1>;
@@ -354,9 +345,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                 const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
                 T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
                 *(valid ? slot : dump) = val;     // unconditional store (see load_plane)
-                if (PHIHIP_ADV_FENCE == 1) sched_fence();     // one sample's LDS reads in flight at a time
+                sched_fence();     // one sample's LDS reads in flight at a time (fence per position or none: +10 % time, profiles/r02_ab_advect*.jsonl)
             }
-            if (PHIHIP_ADV_FENCE == 2) sched_fence();         // one position (all components) at a time
         }
     };
 
