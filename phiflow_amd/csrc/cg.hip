@@ -46,7 +46,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     const int mode = family_mode(family);
     const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : (family == FAM_CG1 ? 0.3 : 1.0 / 3.0));   // UPDATE_R: d is 1 of 3 words
     // the r-only update (2 loads + 1 store per cell) prefers the tiles of MATVEC (family sweep: 256^3 (1,64) x 16, 512^3 (2,32) x 64)
-    const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R;
+    // APPLY / RESID (never autotuned) take MATVEC's tiles while a vector fits the Infinity Cache regime (<= 72 MB: 256^3 fp32), the large
+    // tiles beyond: same-box A/B 256^3 APPLY 27.5 -> 22 us, RESID 46 -> 40 us, but 512^3 APPLY 195 -> 224 us with MATVEC's (1,64) tile
+    const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R || (family == FAM_APPLY && (double)v.cells * v.batch * esize <= 72e6);
 
     auto tile_of = [&](int id, int* t1, int* t2) {
         const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
