@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
     const int i1 = t1 * kPatchRows + ty, i2 = t2 * kPatchCols + tx;
     const bool inside = i1 < n1 && i2 < n2;
     const int p0 = DIM == 3 ? c0 * chunk : 0, p1 = DIM == 3 ? min(p0 + chunk, n0) : 1;
-    const T d0 = (T)g.dx[0], d1 = (T)g.dx[1], d2 = (T)g.dx[2];
+    const T r0 = (T)g.rdx[0], r1 = (T)g.rdx[1], r2 = (T)g.rdx[2];   // (a true division is ~10 instructions; 3 per cell made the kernel VALU-heavy)
     // in-plane taps: component 1 at rows (i1 - off1, +1), component 2 at columns (i2 - off2, +1)
     int o1[2] = {0, 0}, o2[2] = {0, 0};
     T k1[2] = {T(0), T(0)}, k2[2] = {T(0), T(0)};
@@ -113,13 +113,13 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
             T sum = T(0);
             if (DIM == 3) {
                 const T hi0 = face0(p + 1);
-                sum += (hi0 - lo0) / d0;
+                sum += (hi0 - lo0) * r0;
                 lo0 = hi0;
             }
             const T a = c1f[0] ? k1[0] : C1[(long long)p * ps1 + o1[0]], bb = c1f[1] ? k1[1] : C1[(long long)p * ps1 + o1[1]];
-            sum += (bb - a) / d1;
+            sum += (bb - a) * r1;
             const T c = c2f[0] ? k2[0] : C2[(long long)p * ps2 + o2[0]], d = c2f[1] ? k2[1] : C2[(long long)p * ps2 + o2[1]];
-            sum += (d - c) / d2;
+            sum += (d - c) * r2;
             const long long cell = ((long long)p * n1 + i1) * n2 + i2;
             T act = T(1);
             if (F) {
@@ -276,7 +276,7 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
 // neighbouring lanes / rows touch anyway; the per-component launches read p three times.
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
-                                                               int nmax0, int patches1, int patches2) {
+                                                               int nmax0, int patches1, int patches2, int comps) {
     constexpr int A0 = 3 - DIM;
     const int b = blockIdx.y;
     const T* __restrict__ P = p + (long long)b * g.cells;
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<
         idx[2] = c0 + tx;
 #pragma unroll
         for (int ca = A0; ca < 3; ++ca) {
+            if (!((comps >> ca) & 1)) continue;     // (the vector kernel above took the others)
             if (idx[0] >= g.cn[ca][0] || idx[1] >= g.cn[ca][1] || idx[2] >= g.cn[ca][2]) continue;
             const int n = g.n[ca];
             const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
@@ -311,7 +312,75 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<
             }
             T* __restrict__ V = vc.p[ca] + (long long)b * g.ccells[ca];
             const int f = (idx[0] * g.cn[ca][1] + idx[1]) * g.cn[ca][2] + idx[2];
-            V[f] = V[f] - h * ((pr - pl) / (T)g.dx[ca]);
+            V[f] = V[f] - h * ((pr - pl) * (T)g.rdx[ca]);
+        }
+    }
+}
+
+// The same update with one 16-byte vector of the fast axis per thread (V = 4 fp32 / 2 fp64 cells of a row): for the components whose rows
+// have the length of the pressure rows -- a0 and a1 always, a2 when that axis is periodic -- every load and store is a dwordx4 (the scalar
+// kernel issues 9 dword loads, 3 of them redundant, and 3 dword stores per cell). `comps` = bit mask of the components this launch updates.
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
+                                                                   int nmax0, int patches1, int patches2, int comps) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
+    using VF = Vec<uint8_t, V>;
+    const int b = blockIdx.y;
+    const T* __restrict__ P = p + (long long)b * g.cells;
+    const uint8_t* F = flags ? flags + (flags_per_batch ? (long long)b * g.cells : 0) : nullptr;
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = nmax0 * patches1 * patches2;
+    const int n2 = g.n[2];
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3], r0, c0;
+        decode_patch(patch, patches1, patches2, idx[0], r0, c0);
+        idx[1] = r0 + ty;
+        idx[2] = (c0 + tx) * V;          // (decode_patch counts columns in threads: kPatchCols threads x V cells)
+        if (idx[2] >= n2) continue;
+#pragma unroll
+        for (int ca = A0; ca < 3; ++ca) {
+            if (!((comps >> ca) & 1)) continue;
+            if (idx[0] >= g.cn[ca][0] || idx[1] >= g.cn[ca][1]) continue;
+            VT pl, pr;
+            VF fl;
+            bool use_f = false;
+            int fshift = 2 * ca;
+            if (ca < 2) {   // the neighbours along a0 / a1 are whole rows: same columns, other plane / row
+                const int n = g.n[ca];
+                const int pstride = ca == 0 ? g.n[1] * n2 : n2;
+                const int phys = idx[ca] + g.off[ca];
+                int l = phys - 1, r = phys;
+                bool zl = false, zr = false;
+                const bool l_in = l >= 0, r_in = r < n;
+                if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
+                if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
+                const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
+                const int offL = rest + l * pstride, offR = rest + r * pstride;
+                pl = zl ? vec_zero<T, V>() : vec_load<T, V>(P + offL);
+                pr = zr ? vec_zero<T, V>() : vec_load<T, V>(P + offR);
+                if (F) {
+                    if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) { fl = *reinterpret_cast<const VF*>(F + offR); use_f = true; }
+                    else if (l_in) { fl = *reinterpret_cast<const VF*>(F + offL); use_f = true; fshift = 2 * ca + 1; }
+                }
+            } else {        // a2, periodic: face j is the lower face of cell j; its left cell is the previous element of the row
+                const int row = (idx[0] * g.n[1] + idx[1]) * n2;
+                pr = vec_load<T, V>(P + row + idx[2]);
+                pl.v[0] = P[row + (idx[2] > 0 ? idx[2] - 1 : n2 - 1)];
+#pragma unroll
+                for (int e = 1; e < V; ++e) pl.v[e] = pr.v[e - 1];
+                if (F) { fl = *reinterpret_cast<const VF*>(F + row + idx[2]); use_f = true; }
+            }
+            T* __restrict__ Vp = vc.p[ca] + (long long)b * g.ccells[ca] + ((long long)(idx[0] * g.cn[ca][1] + idx[1]) * n2 + idx[2]);
+            VT u = vec_load<T, V>(Vp);
+            const T rd = (T)g.rdx[ca];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T h = use_f ? (((fl.v[e] >> fshift) & 1u) ? T(1) : T(0)) : T(1);
+                u.v[e] = u.v[e] - h * ((pr.v[e] - pl.v[e]) * rd);
+            }
+            vec_store<T, V>(Vp, u);
         }
     }
 }
@@ -322,11 +391,29 @@ static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint
     int nmax[3] = {1, 1, 1};
     for (int a = 0; a < 3; ++a)
         for (int c = v.ax0; c < 3; ++c) nmax[a] = v.cn[c][a] > nmax[a] ? v.cn[c][a] : nmax[a];
-    const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(nmax[2], kPatchCols);
-    const long long npatch = (long long)nmax[0] * patches1 * patches2;
-    const int nblk = npatch < 16384 ? (int)npatch : 16384;
     Comp3<T> c{{(T*)vel[0], (T*)vel[1], (T*)vel[2]}};
-    hipLaunchKernelGGL((grad_subtract_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1, patches2);
+    constexpr int V = 16 / (int)sizeof(T);
+    int scalar_comps = 7;
+    // vector path: rows of the pressure and of the components are whole vectors and every buffer is 16-byte aligned (flags: V bytes)
+    bool vec_ok = v.n[2] % V == 0 && ((uintptr_t)p & 15u) == 0 && (!flags || ((uintptr_t)flags & (V - 1)) == 0);
+    for (int ca = v.ax0; ca < 3; ++ca) vec_ok = vec_ok && ((uintptr_t)vel[ca] & 15u) == 0;
+    if (vec_ok) {
+        const int a2_periodic = v.bc[2][0] == PHIHIP_BC_PERIODIC ? 1 : 0;
+        const int vec_comps = 3 | (a2_periodic << 2);
+        const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols * V);
+        const long long npatch = (long long)nmax[0] * patches1 * patches2;
+        const int nblk = npatch < 16384 ? (int)npatch : 16384;
+        hipLaunchKernelGGL((grad_subtract_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1, patches2,
+                           vec_comps);
+        scalar_comps = 7 & ~vec_comps;
+    }
+    if (scalar_comps) {
+        const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(nmax[2], kPatchCols);
+        const long long npatch = (long long)nmax[0] * patches1 * patches2;
+        const int nblk = npatch < 16384 ? (int)npatch : 16384;
+        hipLaunchKernelGGL((grad_subtract_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1, patches2,
+                           scalar_comps);
+    }
 }
 
 int run_grad_subtract(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* const vel[3],
