@@ -106,7 +106,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             // within a round the CUs should carry the same number of workgroups: 384^3 (1,16) 1152 workgroups (4.5 per CU) 146 us,
             // 1008 (3.9) and 1440 (5.6) 137 us (profiles/r02_midsize_chunks.jsonl)
             if (rounds <= 1.0 && blocks >= ctx->num_cu) eff *= blocks / (ceil(blocks / ctx->num_cu - 1e-9) * ctx->num_cu);
-            const double planes = (family == FAM_MATVEC && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
+            const double planes = ((family == FAM_MATVEC || family == FAM_UPDATE_R) && ch <= 16 ? 1.0 : 2.0) / ch;   // bidirectional marching shares one of the two
             const double us_bw = us_traffic * (1.0 + planes * src_share + partials_share(blocks / v.batch)) / eff;
             const double us_lat = ceil(rounds - 1e-9) * (3.0 + 0.75 * (ch + 1));
             const double score = us_traffic / (us_bw > us_lat ? us_bw : us_lat);   // = eff / relative traffic when traffic-bound
@@ -165,7 +165,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     g->nblk = g->tiles1 * g->tiles2 * g->chunks0;
     // short chunks re-read a large share of source planes (2 / chunk): let neighbouring chunks meet at their common boundary
     // (256^3 MATVEC with chunk 8: -7 %; at chunk 64 the shared planes are 3 % of the traffic and the reversal only costs)
-    g->bidir = (family == FAM_MATVEC && v.rank == 3 && chunk <= 16 && g->chunks0 > 1) ? 1 : 0;
+    g->bidir = ((family == FAM_MATVEC || family == FAM_UPDATE_R) && v.rank == 3 && chunk <= 16 && g->chunks0 > 1) ? 1 : 0;
     return PHIHIP_OK;
 }
 

@@ -15,8 +15,8 @@ constexpr int kVmax = 16 / sizeof(InstT);
 
 template <int V, int R, int TPR, int MODE, bool FLAGS>
 static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
-    // the bidirectional variant exists for 3-D MATVEC only (the phase whose traffic is dominated by the stencil source)
-    constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD;
+    // the bidirectional variant exists for 3-D MATVEC and UPDATE_R (the 3-word phases: the stencil source's halo planes weigh most there)
+    constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_R;
     if (mv && kInstDim3 && g.bidir)
         hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (mv && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
     else
