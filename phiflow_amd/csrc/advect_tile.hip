@@ -473,18 +473,61 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
             const double score = eff * ch / (ch + 2 * H + 1) * (rounds >= 2.0 ? 1.0 : (rounds >= 1.0 ? 0.97 : 0.9));
             if (score > best * 1.0001) { best = score; chunk = ch; }
         }
-        if (ctx->adv_chunk > 0) chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
-        chunks0 = ceil_div(nmax[0], chunk);
     }
-    const int nblk = tiles1 * tiles2 * chunks0;
-    const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
-    int* flags = (int*)ctx->ws_adv_flags.ptr;
-    T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
-    ctx->adv_last_nblk = nblk * v.batch;
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2],
-                       chunk, tiles1, tiles2, nblk, nmax[0], flags, dump);
+    int nblk = 0;
+    int* flags = nullptr;
+    auto launch = [&](int ch) -> int {
+        chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
+        nblk = tiles1 * tiles2 * chunks0;
+        const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
+        PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
+        flags = (int*)ctx->ws_adv_flags.ptr;
+        T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
+        hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
+                           (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump);
+        return PHIHIP_OK;
+    };
+    if (DIM == 3 && ctx->adv_chunk > 0) {
+        chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
+    } else if (DIM == 3 && ctx->autotune && (long long)nmax[0] * nmax[1] * nmax[2] * v.batch >= (1 << 21)) {
+        // First call on this grid: the planner's chunk length against a few others, timed on the call's own operands (every length
+        // writes the same values, so the output is simply overwritten; ~2 ms once per grid). The planner ranks slot efficiency x halo
+        // overhead and misses e.g. the ring warm-up per chunk: 384^3 fp64 runs 6 % faster with 16 planes than with its 64.
+        const std::array<long long, 6> key = {(long long)sizeof(T), DIM, H, nmax[0], (long long)tiles1 * tiles2, v.batch};
+        const auto it = ctx->adv_tuned.find(key);
+        if (it != ctx->adv_tuned.end()) {
+            chunk = it->second;
+        } else {
+            hipEvent_t e0, e1;
+            PHIHIP_CHECK_HIP(hipEventCreate(&e0));
+            PHIHIP_CHECK_HIP(hipEventCreate(&e1));
+            const int cand[6] = {chunk, 16, 24, 32, 48, 64};
+            float best_ms = 1e30f;
+            int best = chunk;
+            for (int k = 0; k < 6; ++k) {
+                const int ch = cand[k] < nmax[0] ? cand[k] : nmax[0];
+                if (k > 0 && ch == chunk) continue;
+                float ms_min = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {        // (the first repetition also warms the instruction cache)
+                    PHIHIP_CHECK_HIP(hipEventRecord(e0, s));
+                    PHIHIP_TRY(launch(ch));
+                    PHIHIP_CHECK_HIP(hipEventRecord(e1, s));
+                    PHIHIP_CHECK_HIP(hipEventSynchronize(e1));
+                    float ms = 0;
+                    PHIHIP_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+                    ms_min = ms < ms_min ? ms : ms_min;
+                }
+                if (ms_min < best_ms * (k == 0 ? 1.0f : 0.98f)) { best_ms = ms_min; best = ch; }   // the planner's length stays unless > 2 % slower
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            chunk = best;
+            ctx->adv_tuned[key] = chunk;
+        }
+    }
+    PHIHIP_TRY(launch(chunk));
+    ctx->adv_last_nblk = nblk * v.batch;
     hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;

@@ -129,6 +129,7 @@ struct phihip_ctx {
     // keep the analytic plan (bit-reproducible launch geometry across processes).
     bool autotune = true;
     std::map<phihip::PlanKey, phihip::TunedPlan> tuned;
+    std::map<std::array<long long, 6>, int> adv_tuned;   // tiled advection: (dtype bytes, dim, halo, planes, tiles, batch) -> planes per workgroup
     // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never (default: in fp32 its
     // attainable accuracy is 1-2 digits worse than the two-launch form, tools/cg1_accuracy.py), 1 = for solves whose iteration is bound
     // by the kernel boundaries (cg1_cells: cells x batch at most this), 2 = always ('CG' only)
