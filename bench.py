@@ -134,6 +134,19 @@ class SmokeBatchStep:
         return rel
 
 
+_RECORD_FD = None
+
+
+def emit_record(record: dict):
+    """ the one JSON line of the contract, on the process's ORIGINAL stdout (see main) """
+    line = (json.dumps(record) + "\n").encode()
+    if _RECORD_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RECORD_FD, line)
+
+
 def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
     """ strong scaling of the batched smoke workload: the SAME 8 simulations on 1 / 2 / 4 / 8 GPUs """
     total, n = args.batch_total, args.size if args.size != 256 else 512
@@ -159,7 +172,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         ctx.profile_enable(False)
         cells = total * n * n
         it_us = (prof["cg_matvec_dot"][1] + prof["cg_update"][1] + prof["cg_update_r"][1]) / max(1, prof["cg_matvec_dot"][0]) * 1e3
-        print(json.dumps({
+        emit_record({
             "metric": f"cell-updates/sec (mac_cormack + advect + {args.cg_iters} CG iters), {total} x {n}^2 fp32 batched smoke", "value": cells * args.steps / elapsed,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -168,7 +181,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
                        "parallelism": f"batch-parallel x{world}, no data-path collective, 1 all-reduce(max residual)/step"},
             "final_relative_residual": float(rel.item()), "us_per_cg_iteration_rank0": round(it_us, 3),
             "kernel_ms_per_step_rank0": {k: round(v[1], 5) for k, v in prof.items()},
-            "plan": {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}}))
+            "plan": {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}})
     if dist is not None:
         dist.destroy_process_group()
 
@@ -343,6 +356,13 @@ def main():
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 behind Python's back (RCCL prints a
+    # version banner through C stdio, flushed at exit, i.e. AFTER the record) are sent to stderr instead
+    global _RECORD_FD
+    sys.stdout.flush()
+    _RECORD_FD = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -479,7 +499,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out.update(extra)
-        print(json.dumps(out))
+        emit_record(out)
     if dist is not None:
         dist.destroy_process_group()
 
