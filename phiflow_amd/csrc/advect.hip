@@ -191,8 +191,17 @@ int run_mac_cormack_staggered(phihip_ctx* ctx, const GridView& v, const void* co
     PHIHIP_TRY(ensure_buffer(ctx->ws_adv, total));
     void* tmp[3] = {nullptr, nullptr, nullptr};
     for (int ca = v.ax0; ca < 3; ++ca) tmp[ca] = (char*)ctx->ws_adv.ptr + offs[ca];
+    // the semi-Lagrangian pass of mac_cormack(v, v, dt) is the self-advection: one LDS-tiled launch instead of D gather launches
+    bool first_done = false;
+    bool self = ctx->adv_halo > 0;
+    for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
+    if (self) {
+        const int st = run_advect_self_tiled(ctx, v, vel, tmp, dt, ctx->adv_halo, s);
+        if (st == PHIHIP_OK) first_done = true;
+        else if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
-    dispatch_advect_staggered<0>(v, g, f, vel, nullptr, tmp, dt, 0.0, s);
+    if (!first_done) dispatch_advect_staggered<0>(v, g, f, vel, nullptr, tmp, dt, 0.0, s);
     dispatch_advect_staggered<1>(v, g, f, vel, tmp, out, dt, 0.5 * strength, s);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
