@@ -6,9 +6,9 @@ OTHERS=${1:-phiflow_amd/lib/libphihip_prev.so}; SIZES=${2:-256,384,512}; TAG=${3
 OUT=gpurun_out/r02_${TAG}.jsonl; : > $OUT
 for ROUND in 1 2; do
   for OTHER in ${OTHERS//,/ }; do
-    timeout 300 python tools/size_scan.py --sizes $SIZES --lib $OTHER >> $OUT 2>> gpurun_out/r02_${TAG}.err
+    timeout 300 python tools/size_scan.py --sizes $SIZES ${DTYPE:+--dtype $DTYPE} --lib $OTHER >> $OUT 2>> gpurun_out/r02_${TAG}.err
   done
-  timeout 300 python tools/size_scan.py --sizes $SIZES >> $OUT 2>> gpurun_out/r02_${TAG}.err
+  timeout 300 python tools/size_scan.py --sizes $SIZES ${DTYPE:+--dtype $DTYPE} >> $OUT 2>> gpurun_out/r02_${TAG}.err
 done
 python - $OUT <<'PY'
 import json,sys
