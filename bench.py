@@ -345,7 +345,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=256, help="cells per axis (BASELINE: 256)")
     ap.add_argument("--cg-iters", type=int, default=100)
-    ap.add_argument("--cpu-size", type=int, default=192, help="grid size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-size", type=int, default=224, help="grid size of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
     ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
                     help="config2 (default, the BASELINE metric): 256^3 Taylor-Green replicas, weak scaling. config4: 8 x 512^2 batched smoke, the batch "
