@@ -6,7 +6,8 @@
 //   * a0 neighbours live in registers (previous / current / next plane are rotated, every plane is read from HBM once),
 //   * a1 / a2 neighbours of the current plane come from an LDS copy of the tile (+ a one-cell halo ring that designated
 //     threads fetch with the boundary rule applied: wrap / clamp / zero), double buffered => one barrier per plane,
-//   * loads of plane i+1 are issued before the LDS phase of plane i (software prefetch distance: one plane).
+//   * every request is issued one whole trip ahead (source plane i+2, halo items and own-cell operands of plane i+1 while plane i is
+//     computed) and every load / store of the loop is unconditional, so that the compiler's s_waitcnt counts instead of draining.
 // The "source" S whose Laplacian is taken and the epilogue differ per MODE:
 //   APPLY   S = p                  out = A S
 //   RESID   S = x                  r = y - A S                     sum r^2, sum y^2
