@@ -69,6 +69,7 @@ class FluidStep:
         self.p = torch.zeros(batch, n, n, n, device=device, dtype=dtype)
         self.div = torch.empty_like(self.p)
         self.res = torch.zeros(batch, 2, device=device, dtype=torch.float64)
+        self.rel = torch.zeros(1, device=device, dtype=torch.float64)
         self.solve = C.Solve(0.0, 0.0, cg_iters, refresh, 0, 0)
         self.dt = 0.5 * L / n                         # CFL ~ 0.5
         self.stream = int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0
@@ -79,12 +80,11 @@ class FluidStep:
         ctx.advect_staggered(self.grid, pv, pv, pv2, self.dt, s)
         ctx.make_incompressible(self.grid, pv2, None, 0, 1, True, self.p.data_ptr(), self.div.data_ptr(), self.solve,
                                 want_info=False, stream=s)
-        ctx.solve_residuals(self.batch, self.res.data_ptr(), s)
         self.v, self.v2 = self.v2, self.v
+        ctx.solve_relative_residual(self.batch, self.rel.data_ptr(), s)     # max ||r|| / ||rhs|| over the entries: the all-reduce's operand
         if allreduce is not None:
-            rel = torch.sqrt(self.res[:, 0] / torch.clamp(self.res[:, 1], min=1e-300)).max().reshape(1)
-            allreduce(rel)
-            return rel
+            allreduce(self.rel)
+            return self.rel
         return None
 
 
@@ -111,13 +111,15 @@ class SmokeBatchStep:
         self.v, self.v2 = [z(n - 1, n), z(n, n - 1)], [z(n - 1, n), z(n, n - 1)]
         self.p = z(n, n)
         self.res = torch.zeros(max(B, 1), 2, device=device, dtype=torch.float64)
+        self.rel = torch.zeros(1, device=device, dtype=torch.float64)
         self.solve = C.Solve(0.0, 0.0, cg_iters, 50, 0, 0)
         self.s_bc = ((C.BC_OPEN, C.BC_OPEN),) * 2            # ZERO_GRADIENT smoke
         self.stream = int(torch.cuda.current_stream(device).cuda_stream)
 
     def step(self, allreduce=None):
         ctx, s, g = self.ctx, self.stream, self.grid
-        rel = torch.zeros(1, device=self.device, dtype=torch.float64)
+        rel = self.rel
+        rel.zero_()
         if self.batch > 0:
             P = lambda ts: [t.data_ptr() for t in ts]
             ctx.mac_cormack_centered(g, self.smoke.data_ptr(), self.s_bc, None, P(self.v), self.smoke2.data_ptr(), 1.0, 1.0, s)
@@ -125,10 +127,9 @@ class SmokeBatchStep:
             ctx.advect_staggered(g, P(self.v), P(self.v), P(self.v2), 1.0, s)
             ctx.centered_to_staggered(g, self.smoke2.data_ptr(), self.s_bc, None, (0.0, 0.1), True, P(self.v2), s)
             ctx.make_incompressible(g, P(self.v2), None, 0, 1, True, self.p.data_ptr(), 0, self.solve, want_info=False, stream=s)
-            ctx.solve_residuals(self.batch, self.res.data_ptr(), s)
+            ctx.solve_relative_residual(self.batch, rel.data_ptr(), s)
             self.smoke, self.smoke2 = self.smoke2, self.smoke
             self.v, self.v2 = self.v2, self.v
-            rel = torch.sqrt(self.res[:, 0] / torch.clamp(self.res[:, 1], min=1e-300)).max().reshape(1)
         if allreduce is not None:
             allreduce(rel)
         return rel

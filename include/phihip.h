@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PHIHIP_VERSION 101 /* 0.1.1 */
+#define PHIHIP_VERSION 102 /* 0.1.2 */
 
 typedef enum phihip_status {
     PHIHIP_OK = 0,
@@ -201,6 +201,10 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
  * written asynchronously on `stream` into DEVICE memory (no host sync) -- the operand of the one all-reduce per step that a
  * batch-sharded multi-GPU run performs. */
 int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void* stream);
+
+/* The same result reduced on the device to ONE double: out_device[0] = max over the batch entries of ||r|| / ||rhs|| (0 where rhs = 0) --
+ * directly the operand of the step's all-reduce(MAX), without the four elementwise launches a host library would need for it. */
+int phihip_solve_relative_residual(phihip_ctx* ctx, int batch, double* out_device, void* stream);
 
 /* The ONE collective of a batch-sharded multi-GPU step, for C / C++ callers that hold an RCCL communicator themselves (the
  * Python layer goes through torch.distributed, whose `nccl` backend IS RCCL): all-reduces `count` device doubles in place over `comm`

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "PHIHIP_OK", -1: "PHIHIP_ERR_BAD_ARG", -2: "PHIHIP_ERR_HIP", 
 EXPORTED_SYMBOLS = (
     "phihip_version", "phihip_last_error", "phihip_ctx_create", "phihip_ctx_destroy", "phihip_workspace_bytes",
     "phihip_component_shape", "phihip_advect_staggered", "phihip_advect_centered", "phihip_build_cellflags",
-    "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_grad_subtract",
+    "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_solve_relative_residual", "phihip_grad_subtract",
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
     "phihip_set_tuning", "phihip_mac_cormack_staggered", "phihip_mac_cormack_centered", "phihip_centered_to_staggered",
     "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
@@ -203,6 +203,7 @@ class Library:
         d.phihip_laplace_apply.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
         d.phihip_cg_solve.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_solve_residuals.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
+        d.phihip_solve_relative_residual.argtypes = [c_void_p, c_int, c_void_p, c_void_p]
         d.phihip_grad_subtract.argtypes = [c_void_p, POINTER(Grid), c_void_p, c_int, c_void_p, POINTER(_Ptr3), c_void_p]
         d.phihip_make_incompressible.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p,
                                                  c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
@@ -404,6 +405,10 @@ class Context:
     def solve_residuals(self, batch, out_device, stream=0):
         """ device-side (||r||^2, ||rhs||^2) per batch entry of the last solve, no host sync """
         self.lib.check(self.lib.dll.phihip_solve_residuals(self.handle, int(batch), out_device, stream or None))
+
+    def solve_relative_residual(self, batch, out_device, stream=0):
+        """ device-side max over the batch entries of ||r|| / ||rhs|| of the last solve (one double), no host sync """
+        self.lib.check(self.lib.dll.phihip_solve_relative_residual(self.handle, int(batch), out_device, stream or None))
 
     def grad_subtract(self, grid, flags, mask_batch, p, velocity, stream=0):
         self.lib.check(self.lib.dll.phihip_grad_subtract(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), p,

@@ -553,6 +553,12 @@ int phihip_solve_residuals(phihip_ctx* ctx, int batch, double* out_device, void*
     return run_export_residuals(ctx, batch, out_device, (hipStream_t)stream);
 }
 
+int phihip_solve_relative_residual(phihip_ctx* ctx, int batch, double* out_device, void* stream) {
+    PHIHIP_REQUIRE(ctx != nullptr && out_device != nullptr && batch >= 1, "solve_relative_residual: bad argument");
+    PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    return run_export_relative_residual(ctx, batch, out_device, (hipStream_t)stream);
+}
+
 // RCCL's ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream); ncclDouble = 8 (rccl.h). Resolved lazily: the library
 // that created the caller's communicator is already in the process (dlsym over the global scope finds it, e.g. torch's bundled
 // librccl); only a process without one gets a fresh librccl.so.1.

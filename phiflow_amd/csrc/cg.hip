@@ -235,6 +235,31 @@ __global__ void cg_export_residuals(const CgState* st, int batch, double* out) {
     }
 }
 
+// max over the batch entries of ||r|| / ||rhs||: one wavefront, fixed order
+__global__ void cg_export_relative(const CgState* st, int batch, double* out) {
+    double m = 0.0;
+    for (int b = threadIdx.x; b < batch; b += kWave) {
+        const double rel = st[b].rhs_sq > 0 ? sqrt(st[b].rsq / st[b].rhs_sq) : 0.0;
+        m = rel > m ? rel : m;       // (NaN residuals compare false and are reported by the solve info, not here)
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const double o = __shfl_down(m, off, kWave);
+        m = o > m ? o : m;
+    }
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+int run_export_relative_residual(phihip_ctx* ctx, int batch, double* out, hipStream_t s) {
+    if (!ctx->last_state || ctx->last_state_batch < batch) {
+        set_error("solve_relative_residual: no solve with batch >= %d has run on this context", batch);
+        return PHIHIP_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(cg_export_relative, dim3(1), dim3(kWave), 0, s, (const CgState*)ctx->last_state, batch, out);
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 int run_export_residuals(phihip_ctx* ctx, int batch, double* out, hipStream_t s) {
     if (!ctx->last_state || ctx->last_state_batch < batch) {
         set_error("solve_residuals: no solve with batch >= %d has run on this context", batch);

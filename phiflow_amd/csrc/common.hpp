@@ -232,6 +232,7 @@ int run_grad_subtract(phihip_ctx*, const GridView&, const uint8_t* flags, int ma
 int run_diffuse(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double kdt, hipStream_t);
 int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
 int run_export_residuals(phihip_ctx*, int batch, double* out, hipStream_t);
+int run_export_relative_residual(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_cg(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, phihip_solve_info*, hipStream_t);
 // projection: rhs = unbalanced divergence, shift[b] = its mean over the active cells (run_divergence with balance = 2); balanced in place
 bool cg_uses_marching(const phihip_ctx*, const GridView&);

@@ -31,14 +31,11 @@ def shard_field(field, rank: int, world_size: int):
 
 def global_relative_residual(backend, local_batch: int, group=None) -> torch.Tensor:
     """ max over ALL simulations of ||r|| / ||rhs|| of the most recent pressure solve: device-side residuals of the local
-    shard (`phihip_solve_residuals`, no host sync) followed by the step's single all-reduce (MAX). Returns a 1-element tensor
+    shard (`phihip_solve_relative_residual`, no host sync) followed by the step's single all-reduce (MAX). Returns a 1-element tensor
     on the backend's device. """
-    res = backend.zeros((max(local_batch, 1), 2), torch.float64)
+    rel = backend.zeros((1,), torch.float64)
     if local_batch > 0:
-        backend.ctx.solve_residuals(local_batch, res.data_ptr(), backend.stream())
-        rel = torch.sqrt(res[:, 0] / torch.clamp(res[:, 1], min=1e-300)).max().reshape(1)
-    else:
-        rel = backend.zeros((1,), torch.float64)
+        backend.ctx.solve_relative_residual(local_batch, rel.data_ptr(), backend.stream())
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(rel, op=dist.ReduceOp.MAX, group=group)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(dll, name), f"{name} declared in include/phihip.h but not exported"
     lib = _capi.Library(_capi.DEFAULT_LIBRARY_PATH)
-    assert lib.version() == 101
+    assert lib.version() == 102
 
 
 @pytest.mark.skipif(not os.path.exists(_capi.DEFAULT_LIBRARY_PATH), reason="libphihip.so not built")

@@ -578,6 +578,11 @@ def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
         ctx.allreduce_residual(comm, res.data_ptr(), 6, op=0)                 # sum over one rank: unchanged
         mem.sync()
         assert torch.equal(res, before) and float(before[:, 1].min()) > 0
+        rel = torch.zeros(1, dtype=torch.float64, device=mem.device)          # the same result reduced to the all-reduce's operand
+        ctx.solve_relative_residual(3, rel.data_ptr())
+        ctx.allreduce_residual(comm, rel.data_ptr(), 1, op=2)
+        mem.sync()
+        assert abs(float(rel) - float(torch.sqrt(before[:, 0] / before[:, 1]).max())) <= 1e-12 * float(rel)
         with pytest.raises(pc.C.PhiHipError):
             ctx.allreduce_residual(comm, res.data_ptr(), 6, op=1)
         with pytest.raises(pc.C.PhiHipError):
