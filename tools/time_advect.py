@@ -72,6 +72,8 @@ def main():
            "ms_semi_lagrangian_staggered": round(timed(lambda: ctx.advect_staggered(grid, P(v), P(v), P(out), dt)), 5),
            "ms_mac_cormack_staggered": round(timed(lambda: ctx.mac_cormack_staggered(grid, P(v), P(v), P(out), dt, 1.0)), 5),
            "ms_semi_lagrangian_centered": round(timed(lambda: ctx.advect_centered(grid, s.data_ptr(), ((args.bc and 2, args.bc and 2),) * 3, None, P(v), so.data_ptr(), dt)), 5)})
+    sbc = ((args.bc and 2, args.bc and 2),) * 3
+    res["ms_mac_cormack_centered"] = round(timed(lambda: ctx.mac_cormack_centered(grid, s.data_ptr(), sbc, None, P(v), so.data_ptr(), dt, 1.0)), 5)
     res["GBs_semi_lagrangian_staggered"] = round(6 * n ** 3 * (8 if args.dtype == "f64" else 4) / res["ms_semi_lagrangian_staggered"] / 1e6, 1)
     print(json.dumps(res), flush=True)
 
