@@ -158,3 +158,14 @@ def test_slab_fluid_single_rank_on_the_device(gpu_backend):
     assert float((p - p_ref).abs().max()) <= 2e-4 * float(p_ref.abs().max())
     for c in range(3):
         assert float((out[c] - adv[c]).abs().max()) <= 1e-4
+
+
+def test_example_scripts_run(gpu_backend):
+    """ examples/*.py are the reference notebooks with the import line changed: they have to keep running """
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, args in (("smoke_plume.py", ["--size", "64", "--steps", "3"]), ("taylor_green_3d.py", ["--size", "32", "--steps", "2"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ms per step" in r.stdout, r.stderr[-2000:]
