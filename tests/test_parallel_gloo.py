@@ -215,18 +215,19 @@ def _fluid_worker(rank, world, port, emu_path, out_dir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", list(SLAB_CASES))
-def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, case):
-    """ two ranks, each owning half of the x planes, reproduce advection, divergence, pressure and the projected velocity of the
-    single-process step (ghost-plane exchange; sample coordinates are rounded at local instead of global index magnitudes) """
-    world = 2
+@pytest.mark.parametrize("case,world", [(c, 2) for c in SLAB_CASES] + [("closed_open", 3)])
+def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, case, world):
+    """ two ranks, each owning half of the x planes (and three ranks with 4 + 4 + 3 planes: the middle one has ghost planes on both
+    sides), reproduce advection, divergence, pressure and the projected velocity of the single-process step (ghost-plane exchange;
+    sample coordinates are rounded at local instead of global index magnitudes) """
     mp.spawn(_fluid_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
     res, bc, grid, rng = _fluid_problem(case)
     v = _smooth_velocity(emu_ctx, grid, rng, grid.batch)
     singular = all(c != 2 for pair in bc for c in pair)
     adv, div, p, out, info = _reference_step(emu_ctx, grid, v, 0.9, singular)
     parts = [np.load(tmp_path / f"fluid{r}.npz") for r in range(world)]
-    assert int(parts[0]["f0"]) == 0 and int(parts[1]["f1"]) == v[0].shape[1] and int(parts[0]["f1"]) == int(parts[1]["f0"])
+    assert int(parts[0]["f0"]) == 0 and int(parts[-1]["f1"]) == v[0].shape[1]
+    assert all(int(parts[r]["f1"]) == int(parts[r + 1]["f0"]) for r in range(world - 1))
     cat = lambda key: np.concatenate([q[key] for q in parts], axis=1)
     for c in range(3):
         assert cat(f"adv{c}").shape == adv[c].shape
