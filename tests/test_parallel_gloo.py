@@ -114,21 +114,20 @@ def _slab_worker(rank, world, port, emu_path, out_dir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", list(SLAB_CASES))
-def test_slab_decomposed_cg_world2_gloo(emu_library, emu_ctx, tmp_path, case):
-    """ two ranks, each with half of the x planes, must reproduce the single-process solve (same iteration count; the dot
+@pytest.mark.parametrize("case,world", [(c, 2) for c in SLAB_CASES] + [("closed_open", 3), ("periodic", 3)])
+def test_slab_decomposed_cg_world2_gloo(emu_library, emu_ctx, tmp_path, case, world):
+    """ two (three) ranks, each with a share of the x planes, must reproduce the single-process solve (same iteration count; the dot
     products are summed in a different order, so values agree to rounding) """
     from phiflow_amd import _capi as C
-    world = 2
     mp.spawn(_slab_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
     res, bc, rhs = _slab_problem(case)
     grid = C.make_grid(3, C.PHIHIP_F32, rhs.shape[0], res, (0, 0, 0), tuple(float(r) for r in res), bc)
     x_ref = np.zeros_like(rhs)
     info = emu_ctx.cg_solve(grid, 0, 1, rhs.ctypes.data, x_ref.ctypes.data, C.Solve(1e-5, 0.0, 60, 7, 5, 0))
     parts = [np.load(tmp_path / f"slab{r}.npz") for r in range(world)]
-    assert [int(p["b0"]) for p in parts] == [0, int(parts[0]["b1"])] and int(parts[1]["b1"]) == res[0]
+    assert int(parts[0]["b0"]) == 0 and int(parts[-1]["b1"]) == res[0] and all(int(parts[r]["b1"]) == int(parts[r + 1]["b0"]) for r in range(world - 1))
     x = np.concatenate([p["x"] for p in parts], axis=1)
-    assert list(parts[0]["it"]) == list(parts[1]["it"])                     # both ranks took the same (global) decisions
+    assert all(list(parts[0]["it"]) == list(q["it"]) for q in parts)       # every rank took the same (global) decisions
     # the dot products are summed in a different order: an entry may cross the tolerance one iteration earlier or later
     assert all(abs(int(a) - i.iterations) <= 1 for a, i in zip(parts[0]["it"], info))
     assert list(parts[0]["conv"]) == [i.converged for i in info]
