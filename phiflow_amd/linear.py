@@ -263,16 +263,91 @@ def recognise_laplace_stencil(matrix, resolution: Sequence[int], rtol: float = 1
     raise NotALaplaceStencil("the matrix is not reproduced by the recognised (spacing, boundary, mask) description")
 
 
+def infer_resolution(matrix) -> Tuple[int, ...]:
+    """ Grid resolution of a 5 / 7-point matrix over cells in C order, read off the matrix itself: the couplings of an interior row sit
+    at column offsets +-1, +-n_last, +-n_last * n_mid, and every such offset occurs in more than half of the rows (a wrap-around offset of a
+    periodic axis occurs N / n times at most). Raises `NotALaplaceStencil` when the offsets do not describe a 2-D / 3-D box (an axis with
+    fewer than three cells cannot be told apart this way: register the resolution with `set_grid_resolution` then). """
+    import scipy.sparse as sp
+    A = sp.coo_matrix(matrix)
+    N = A.shape[0]
+    d = (A.col.astype(np.int64) - A.row.astype(np.int64))
+    d = d[d > 0]
+    if d.size == 0:
+        raise NotALaplaceStencil("no off-diagonal couplings")
+    offs, counts = np.unique(d, return_counts=True)
+    strides = [int(o) for o, c in zip(offs, counts) if c > 0.45 * N]
+    if not strides or strides[0] != 1 or len(strides) not in (2, 3):
+        raise NotALaplaceStencil(f"coupling offsets {strides} are not the strides of a 2-D / 3-D grid")
+    res = []
+    for lo, hi in zip(strides, strides[1:] + [N]):
+        if hi % lo:
+            raise NotALaplaceStencil(f"coupling offsets {strides} do not divide the matrix size {N}")
+        res.append(hi // lo)
+    return tuple(reversed(res))
+
+
+def _matrix_parts(lin):
+    """ (kind, index tensors / arrays, values) of a sparse matrix without moving it: SciPy matrices and torch sparse CSR / COO tensors """
+    import scipy.sparse as sp
+    if sp.issparse(lin):
+        A = lin if sp.isspmatrix_csr(lin) else sp.csr_matrix(lin)
+        return 'scipy', (A.indptr, A.indices), A.data, A.shape
+    if isinstance(lin, torch.Tensor) and lin.layout == torch.sparse_csr:
+        return 'torch', (lin.crow_indices(), lin.col_indices()), lin.values(), tuple(lin.shape)
+    if isinstance(lin, torch.Tensor) and lin.layout == torch.sparse_coo:
+        i = lin._indices() if not lin.is_coalesced() else lin.indices()
+        return 'torch', (i[0], i[1]), (lin._values() if not lin.is_coalesced() else lin.values()), tuple(lin.shape)
+    raise NotALaplaceStencil(f"unsupported matrix type {type(lin).__name__}")
+
+
+def matrix_fingerprint(lin) -> Tuple:
+    """ Identity of an assembled operator for the recognition cache, computed WHERE THE MATRIX LIVES (a device-resident torch matrix is
+    reduced on the device; one small host read of five numbers): shape, stored entries, and position-weighted checksums of the index and
+    value arrays. PhiFlow re-traces `masked_laplace` every step (`forget_traces=True`, phi/physics/fluid.py:165), i.e. hands the backend a
+    NEW but identical matrix object per solve -- an `id()`-keyed cache would never hit. """
+    kind, idx, val, shape = _matrix_parts(lin)
+    if kind == 'scipy':
+        w = (np.arange(val.size, dtype=np.int64) % 8191 + 1).astype(np.float64)
+        sums = [float(np.asarray(val, np.float64) @ w), float(np.abs(np.asarray(val, np.float64)).sum())] + [float((np.asarray(i, np.float64) * (np.arange(i.size) % 8191 + 1)).sum()) for i in idx]
+    else:
+        def wsum(t):
+            t = t.reshape(-1).to(torch.float64)
+            return (t * (torch.arange(t.numel(), device=t.device) % 8191 + 1).to(torch.float64)).sum()
+        v = val.reshape(-1)
+        sums = torch.stack([wsum(v), v.to(torch.float64).abs().sum()] + [wsum(i) for i in idx]).tolist()
+    return (kind, tuple(shape), int(val.shape[0]), str(val.dtype)) + tuple(sums)
+
+
 class HipLinearSolveMixin:
     """ `linear_solve` / `conjugate_gradient` override for a PhiML `Backend` ([PHIML-RECALL] signatures of phiml.backend.Backend:
     `linear_solve(self, method, lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)`). `lin` = the sparse matrix PhiML assembled;
-    when it is recognised as `masked_laplace` on the grid whose resolution the caller registered (`set_grid_resolution`, or the cube /
-    square root of N), the solve runs on `phihip_cg_solve`; otherwise `super()` handles it. """
+    when it is recognised as `masked_laplace` on a uniform grid the solve runs on `phihip_cg_solve`; otherwise `super()` handles it.
+
+    * The grid resolution is read off the matrix (`infer_resolution`); `set_grid_resolution` overrides it (needed only for axes of fewer
+      than three cells).
+    * Recognition is cached per operator (`matrix_fingerprint`): PhiFlow re-traces the matrix every time step, so the O(nnz) host pass
+      (device -> host copy + SciPy) happens once per grid and obstacle set; afterwards the matrix is only fingerprinted on its device.
+      `hip_stats` counts hits / misses / HIP solves / fall-backs.
+    * `matrix_offset` -- PhiML's treatment of `Solve(rank_deficiency=1)`, which phi/physics/fluid.py:145-148 sets for every box without a
+      flexible (open) side: the solver iterates on `A + offset * 1 1^T`. For a recognised SINGULAR operator (no OPEN side) with a
+      right-hand side in its range (sum over the active cells = 0, what `_balance_divergence` produces) and a start vector without a
+      null-space component, every residual and search direction sums to zero, the rank-one term never contributes, and CG on `A` alone
+      produces the SAME iterates. So: recognise, drop the offset, remove the null-space component of `x0` (mean over the active cells;
+      inactive cells 0), solve matrix-free. A right-hand side that is not balanced, an operator with an open side, or a
+      preconditioner (`pre`) go to `super()`. """
 
     hip_resolution: Optional[Tuple[int, ...]] = None
+    hip_cache_size = 8
 
     def set_grid_resolution(self, resolution: Optional[Sequence[int]]):
         self.hip_resolution = tuple(int(r) for r in resolution) if resolution is not None else None
+
+    @property
+    def hip_stats(self) -> Dict[str, int]:
+        if not hasattr(self, '_hip_stats'):
+            self._hip_stats = dict(cache_hits=0, cache_misses=0, hip_solves=0, fallbacks=0, offsets_dropped=0)
+        return self._hip_stats
 
     def _hip_backend(self):
         from .backend import default_backend
@@ -280,44 +355,92 @@ class HipLinearSolveMixin:
 
     def _as_scipy(self, lin):
         import scipy.sparse as sp
-        if sp.issparse(lin):
+        kind, idx, val, shape = _matrix_parts(lin)
+        if kind == 'scipy':
             return lin
-        if isinstance(lin, torch.Tensor) and lin.layout in (torch.sparse_csr, torch.sparse_coo):
-            t = lin.to_sparse_coo().coalesce().cpu()
-            i = t.indices().numpy()
-            return sp.csr_matrix((t.values().numpy(), (i[0], i[1])), shape=tuple(t.shape))
-        raise NotALaplaceStencil(f"unsupported matrix type {type(lin).__name__}")
+        host = lambda t: t.detach().cpu().numpy()
+        if lin.layout == torch.sparse_csr:
+            return sp.csr_matrix((host(val), host(idx[1]), host(idx[0])), shape=shape)
+        return sp.csr_matrix((host(val), (host(idx[0]), host(idx[1]))), shape=shape)
 
-    def hip_linear_solve(self, method: str, lin, y, x0, rtol, atol, max_iter):
+    def _recognise_cached(self, lin, be):
+        """ -> dict(res, weights, bc, flags (host uint8 array or None), flags_dev (device tensor or None), singular) """
+        if not hasattr(self, '_hip_cache'):
+            self._hip_cache = {}
+        key = matrix_fingerprint(lin) + (self.hip_resolution,)
+        hit = self._hip_cache.get(key)
+        if hit is not None:
+            self.hip_stats['cache_hits'] += 1
+            if isinstance(hit, NotALaplaceStencil):
+                raise hit
+            return hit
+        self.hip_stats['cache_misses'] += 1
+        try:
+            A = self._as_scipy(lin)
+            N = A.shape[0]
+            res = self.hip_resolution
+            if res is None or int(np.prod(res)) != N:
+                res = infer_resolution(A)
+            d = recognise_laplace_stencil(A, res)
+        except NotALaplaceStencil as err:
+            entry = err
+        else:
+            entry = dict(d, res=tuple(res), flags_dev=None if d['flags'] is None else torch.as_tensor(d['flags']).to(be.device).contiguous(),
+                         singular=all(c != _capi.BC_OPEN for pair in d['bc'] for c in pair))
+        if len(self._hip_cache) >= self.hip_cache_size:
+            self._hip_cache.pop(next(iter(self._hip_cache)))
+        self._hip_cache[key] = entry
+        if isinstance(entry, NotALaplaceStencil):
+            raise entry
+        return entry
+
+    def hip_linear_solve(self, method: str, lin, y, x0, rtol, atol, max_iter, matrix_offset=None):
         """ returns (x, iterations, residual_sq, converged, diverged) as torch tensors / lists, or raises NotALaplaceStencil """
         if method not in ('CG', 'auto', 'CG-adaptive'):
             raise NotALaplaceStencil(f"method {method}")
-        A = self._as_scipy(lin)
-        N = A.shape[0]
-        res = self.hip_resolution
-        if res is None or int(np.prod(res)) != N:
-            for D in (3, 2):
-                n = round(N ** (1.0 / D))
-                if n ** D == N:
-                    res = (n,) * D
-                    break
-            else:
-                raise NotALaplaceStencil("grid resolution unknown")
-        d = recognise_laplace_stencil(A, res)
         be = self._hip_backend()
+        d = self._recognise_cached(lin, be)
+        res, N = d['res'], int(np.prod(d['res']))
         yt = torch.as_tensor(y).to(be.device)
+        if not yt.is_floating_point():
+            yt = yt.to(torch.float32)
         fp64 = yt.dtype == torch.float64
         yt = yt.reshape(-1, *res).contiguous()
         B = yt.shape[0]
         xt = torch.as_tensor(x0).to(device=be.device, dtype=yt.dtype).reshape(-1, *res).expand(B, *res).clone().contiguous()
+        flags = d['flags_dev']
+        if matrix_offset is not None:
+            if not d['singular']:
+                raise NotALaplaceStencil("rank-deficiency offset on a non-singular operator (an OPEN side): the offset changes the system")
+            dims = tuple(range(1, yt.dim()))
+            act = None if flags is None else ((flags & 64) != 0).to(yt.dtype)
+            # component of y in the null space of A (constants over the active cells), as a 2-norm: |sum y| / sqrt(N_active). It has to be
+            # far below the tolerance the caller asks for (then it cannot keep CG from converging) or at the rounding level of a
+            # balanced field; otherwise y is not in the range and the offset is what makes the system solvable -> generic path
+            n_act = float(N) if act is None else float(act.sum())
+            ysum = (yt if act is None else yt * act).sum(dim=dims, keepdim=True)
+            null = ysum.abs().reshape(-1) / max(n_act, 1.0) ** 0.5
+            ynorm = yt.to(torch.float64).pow(2).sum(dim=dims).sqrt()
+            rt = torch.as_tensor(rtol if rtol is not None else 1e-5, dtype=torch.float64).reshape(-1).to(ynorm.device)
+            at = torch.as_tensor(atol if atol is not None else 0.0, dtype=torch.float64).reshape(-1).to(ynorm.device)
+            allowed = torch.maximum(0.1 * torch.maximum(rt * ynorm, at), (1e-9 if fp64 else 1e-4) * ynorm)
+            if bool((null.to(torch.float64) > allowed + 1e-300).any()):
+                raise NotALaplaceStencil("right-hand side is not in the range of the singular operator (not balanced)")
+            yt = (yt - ysum / max(n_act, 1.0)) if act is None else (yt - act * (ysum / max(n_act, 1.0)))
+            yt = yt.contiguous()
+            if act is None:
+                xt -= xt.mean(dim=dims, keepdim=True)
+            else:
+                xt = ((xt - (xt * act).sum(dim=dims, keepdim=True) / act.sum().clamp_min(1)) * act).contiguous()
+            self.hip_stats['offsets_dropped'] += 1
         dx = [1.0 / float(np.sqrt(w)) for w in d['weights']]
         grid = _capi.make_grid(len(res), _capi.PHIHIP_F64 if fp64 else _capi.PHIHIP_F32, B, list(res), [0.0] * len(res),
                                [n * h for n, h in zip(res, dx)], d['bc'])
-        flags = None if d['flags'] is None else torch.as_tensor(d['flags']).to(be.device).contiguous()
-        scalar = lambda v, default: float(np.max(np.asarray(v if v is not None else default, dtype=np.float64)))
-        csolve = _capi.Solve(scalar(rtol, 1e-5), scalar(atol, 0.0), int(np.max(np.asarray(max_iter))), 20 if method == 'CG-adaptive' else 50, 10,
+        scalar = lambda v, default: float(np.max(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else (v if v is not None else default), dtype=np.float64)))
+        csolve = _capi.Solve(scalar(rtol, 1e-5), scalar(atol, 0.0), int(scalar(max_iter, 1000)), 20 if method == 'CG-adaptive' else 50, 10,
                              1 if method == 'CG-adaptive' else 0)
         infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, 1, yt.data_ptr(), xt.data_ptr(), csolve, True, be.stream())
+        self.hip_stats['hip_solves'] += 1
         return (xt.reshape(B, N), [i.iterations for i in infos], [i.residual_sq for i in infos], [bool(i.converged) for i in infos],
                 [bool(i.diverged) for i in infos])
 
@@ -325,7 +448,8 @@ class HipLinearSolveMixin:
 def make_phiml_backend():
     """ A PhiML `Backend` named 'hip' (reference: phi/__init__.py:41-63 `detect_backends`, phi/torch/flow.py:31-32): PhiML's torch backend
     (tensors stay torch-ROCm) with `grid_sample` and `linear_solve` routed to libphihip, registered in `phiml.backend.BACKENDS`.
-    Raises ImportError without PhiML. """
+    Raises ImportError without PhiML. EXPERIMENTAL: the Backend surface is [PHIML-RECALL] -- `tools/check_phiml_surface.py` prints every
+    mismatch against an importable PhiML. """
     from phiml import backend as pb                                  # noqa: F401
     try:
         from phiml.backend.torch import TORCH                        # [PHIML-RECALL] singleton of the torch backend
@@ -354,17 +478,20 @@ def make_phiml_backend():
 
         def linear_solve(self, method, lin, y, x0, rtol, atol, max_iter, pre=None, matrix_offset=None):
             try:
-                if pre is not None or matrix_offset is not None:
-                    raise NotALaplaceStencil("preconditioner / rank-deficiency offset")
-                x, iterations, residual_sq, converged, diverged = self.hip_linear_solve(method, lin, y, x0, rtol, atol, max_iter)
+                if pre is not None:
+                    raise NotALaplaceStencil("preconditioner")
+                x, iterations, residual_sq, converged, diverged = self.hip_linear_solve(method, lin, y, x0, rtol, atol, max_iter, matrix_offset)
             except NotALaplaceStencil:
+                self.hip_stats['fallbacks'] += 1
                 return super().linear_solve(method, lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)
             result_type = getattr(pb, 'SolveResult', None)
             if result_type is None:
                 return x
-            it = torch.as_tensor(iterations)
-            return result_type(f"HIP {method}", x, torch.as_tensor(residual_sq).sqrt().reshape(-1, 1).expand_as(x), it, it,
-                               torch.as_tensor(converged), torch.as_tensor(diverged), [""] * len(iterations))
+            dev = x.device
+            it = torch.as_tensor(iterations, device=dev)
+            residual = torch.as_tensor(residual_sq, device=dev, dtype=x.dtype).sqrt().reshape(-1, 1).expand_as(x)
+            return result_type(f"HIP {method}", x, residual, it, it, torch.as_tensor(converged, device=dev), torch.as_tensor(diverged, device=dev),
+                               [""] * len(iterations))
 
         def conjugate_gradient(self, lin, y, x0, rtol, atol, max_iter, pre=None, matrix_offset=None):
             return self.linear_solve('CG', lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)

@@ -189,6 +189,37 @@ class Solve:
         self.method, self.rel_tol, self.abs_tol, self.x0, self.max_iterations = method, rel_tol, abs_tol, x0, max_iterations
         self.suppress, self.preprocess_y, self.preprocess_y_args, self.rank_deficiency = tuple(suppress), preprocess_y, preprocess_y_args, rank_deficiency
 
+    def with_preprocessing(self, pre_y, *args):
+        """ [PHIML-RECALL] Solve.with_preprocessing (call site phi/physics/fluid.py:146) """
+        return copy_with(self, preprocess_y=pre_y, preprocess_y_args=args)
+
+
+def copy_with(obj, **updates):
+    """ [PHIML-RECALL] phiml.math.copy_with (call sites phi/physics/fluid.py:148,151) """
+    import copy
+    new = copy.copy(obj)
+    for k, v in updates.items():
+        setattr(new, k, v)
+    return new
+
+
+def solve_linear(f, y, solve: Solve, *f_args, **f_kwargs):
+    """ TEST DOUBLE of the MATRIX branch of phiml.math.solve_linear [PHIML-RECALL, SURVEY Appendix B]: `f` is the operator PhiML would
+    have traced into a sparse matrix (here: passed as a SciPy / torch sparse matrix, cells in C order), `y` a native (batch, *resolution).
+    What PhiFlow's call site relies on (phi/physics/fluid.py:145-156): `solve.preprocess_y` is applied to y first, `solve.x0` is the start
+    vector, and `Solve(rank_deficiency=1)` reaches the backend as `matrix_offset` -- a constant added to every matrix entry, i.e. the
+    backend iterates on A + offset * 1 1^T (the value used here is arbitrary but of the sign that keeps the negative semi-definite
+    Laplacian definite; the HIP backend must not depend on it). Returns the backend's SolveResult. """
+    from ..backend import default_backend
+    if solve.preprocess_y is not None:
+        y = solve.preprocess_y(y, *solve.preprocess_y_args)
+    be = default_backend()
+    N = f.shape[0]
+    yn = torch.as_tensor(y).reshape(-1, N)
+    x0 = torch.zeros_like(yn) if solve.x0 is None else torch.as_tensor(solve.x0).reshape(-1, N)
+    offset = None if not solve.rank_deficiency else -1.0 / N
+    return be.linear_solve(solve.method, f, yn, x0, solve.rel_tol, solve.abs_tol, solve.max_iterations, None, offset)
+
 
 class ConvergenceException(RuntimeError): pass
 class NotConverged(ConvergenceException): pass

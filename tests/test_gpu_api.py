@@ -125,6 +125,49 @@ def test_solve_linear_and_the_backend_level_boundary(gpu_backend):
     lb.test_backend_grid_sample_matches_the_oracle(gpu_backend)
 
 
+def test_level_b_rank_deficient_matrix_solve_on_the_device(gpu_backend):
+    """ SURVEY §8b Level B on the GPU: what `with HIP: fluid.make_incompressible(v)` hands a PhiML backend for a periodic / closed box
+    (phi/physics/fluid.py:145-156) -- a device-resident torch sparse matrix of `masked_laplace` + `matrix_offset` (rank_deficiency=1) + a
+    balanced right-hand side -- has to run the marching CG kernels (launch counters), be recognised ONCE although every step brings a new
+    matrix object, and give the same pressure as the phi-level solve. 96^3 = 885 k rows: the marching path, not the single-workgroup solver. """
+    import torch
+    from oracle import phi_oracle as O
+    from phiflow_amd import _capi as C, linear
+
+    class Probe(linear.HipLinearSolveMixin):
+        def _hip_backend(self):
+            return gpu_backend
+    be, dev, ctx = Probe(), gpu_backend.device, gpu_backend.ctx
+    rng = np.random.default_rng(21)
+    for res, bc in (((96, 96, 96), ((O.PERIODIC, O.PERIODIC),) * 3), ((640, 512), ((O.CLOSED, O.CLOSED),) * 2)):
+        dom = O.Domain(res, (0.0,) * len(res), tuple(float(n) for n in res), bc)
+        A = O.laplace_csr(dom, np.float32)
+        N = A.shape[0]
+        y = rng.standard_normal((1, N)).astype(np.float32)
+        y -= y.mean()
+        yt = torch.as_tensor(y).to(dev)
+        stats0 = dict(be.hip_stats)
+        ctx.profile_enable(True); ctx.profile_read(reset=True)
+        for step in range(3):        # a NEW device matrix per "time step" (forget_traces=True, fluid.py:165)
+            lin = torch.sparse_csr_tensor(torch.as_tensor(A.indptr).to(dev), torch.as_tensor(A.indices).to(dev), torch.as_tensor(A.data).to(dev), size=A.shape)
+            x, its, rsq, conv, div = be.hip_linear_solve('CG', lin, yt, torch.zeros_like(yt), 1e-4, 0.0, 2000, matrix_offset=-1.0 / N)
+        prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+        assert all(conv) and not any(div) and x.is_cuda
+        assert prof['cg_matvec_dot'][0] >= 3 * its[0] and prof['cg_update'][0] + prof['cg_update_r'][0] >= 3 * (its[0] - 2), (prof, its)
+        assert be.hip_stats['cache_misses'] == stats0['cache_misses'] + 1 and be.hip_stats['cache_hits'] == stats0['cache_hits'] + 2
+        assert be.hip_stats['offsets_dropped'] == stats0['offsets_dropped'] + 3
+        # same system through the phi-level C ABI call
+        grid = C.make_grid(len(res), C.PHIHIP_F32, 1, res, (0.0,) * len(res), tuple(float(n) for n in res),
+                           [tuple({O.PERIODIC: C.BC_PERIODIC, O.CLOSED: C.BC_CLOSED}[c] for c in pair) for pair in bc])
+        rhs = yt.reshape(1, *res).contiguous()
+        p = torch.zeros_like(rhs)
+        info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), p.data_ptr(), C.Solve(1e-4, 0.0, 2000, 50, 10, 0))
+        assert abs(info[0].iterations - its[0]) <= 1
+        a, b = x.reshape(-1).double(), p.reshape(-1).double()
+        assert float((a - b).norm() / b.norm()) <= 1e-3
+        assert abs(float(a.mean())) <= 1e-4 * float(a.abs().mean())
+
+
 def test_scene_files_on_the_device(gpu_backend, tmp_path):
     """ SURVEY §8 f6 with the real library: the reference's scene-file window -> GPU fields -> one step vs the oracle -> round trip """
     golden_cases.run_scene_files(gpu_backend, tmp_path)

@@ -149,8 +149,12 @@ def test_registered_phiml_backend_solves_and_samples(emu_backend):
         x2 = be.conjugate_gradient(A, torch.as_tensor(y.reshape(2, -1)), torch.zeros(2, 120), 1e-5, 0.0, 1000)
         assert torch.equal(x2.x, result.x)
         import scipy.sparse as sp
-        with pytest.raises(NotImplementedError):                                          # not a Laplacian -> the base backend's solver
-            be.linear_solve('CG', sp.random(120, 120, 0.1, format='csr', random_state=0), torch.as_tensor(y.reshape(2, -1)), torch.zeros(2, 120), 1e-5, 0.0, 10)
+        before = be.hip_stats['fallbacks']                                               # not a Laplacian -> the base backend's solver
+        M = sp.random(120, 120, 0.1, format='csr', random_state=0)
+        generic = be.linear_solve('CG', M @ M.T + sp.identity(120), torch.as_tensor(y.reshape(2, -1)), torch.zeros(2, 120), 1e-5, 0.0, 10)
+        assert be.hip_stats['fallbacks'] == before + 1 and generic.method.startswith('generic')
+        with pytest.raises(NotImplementedError):
+            be.linear_solve('biCG-stab(2)', A, torch.as_tensor(y.reshape(2, -1)), torch.zeros(2, 120), 1e-5, 0.0, 10)
         grid = torch.as_tensor(rng.standard_normal((1, 6, 7, 2)).astype(np.float32))
         coords = torch.as_tensor((rng.random((1, 9, 2)) * 6).astype(np.float32))
         out = be.grid_sample(grid, coords, 'boundary')
@@ -159,3 +163,109 @@ def test_registered_phiml_backend_solves_and_samples(emu_backend):
         with pytest.raises(NotImplementedError):
             be.grid_sample(grid, coords, 'symmetric')
         pb.BACKENDS.remove(be)
+
+
+def _level_b_case(res, bc, obstacles=()):
+    dom = O.Domain(res, (0.0,) * len(res), tuple(float(n) * 0.5 for n in res), bc)
+    hard = active = None
+    if obstacles:
+        import scipy.sparse as sp
+        active, hard, _ = O.obstacle_masks(obstacles, dom, np.float64)
+        N = int(np.prod(res))
+        cols = []
+        for k in range(N):
+            e = np.zeros((1,) + tuple(res)); e.reshape(-1)[k] = 1.0
+            cols.append(O.masked_laplace(e, dom, hard, active).reshape(-1))
+        A = sp.csr_matrix(np.stack(cols, axis=1))
+    else:
+        A = O.laplace_csr(dom, np.float64)
+    return dom, A, hard, active
+
+
+def test_level_b_rank_deficient_solves_reach_the_hip_kernels(emu_backend):
+    """ `with HIP: fluid.make_incompressible(v)` on a periodic / closed box (BASELINE configs[1]-[3]): phi/physics/fluid.py:145-148 adds
+    `preprocess_y=_balance_divergence` and `rank_deficiency=1`, PhiML hands the backend the assembled matrix plus `matrix_offset`. The
+    override must (i) solve on libphihip -- launch counters of the marching CG kernels, no fall-back --, (ii) agree with the generic CG on
+    A + offset 1 1^T, which is what every other PhiML backend iterates on, (iii) recognise the matrix once per grid although PhiFlow
+    re-traces it every step (`forget_traces=True`, fluid.py:165), (iv) leave unbalanced right-hand sides and open boxes to `super()`. """
+    from phiml import backend as pb, math
+    ctx = emu_backend.ctx
+    ctx.set_small_grid_solver(False)                     # the marching kernels also at test sizes
+    try:
+        with emu_backend:
+            be = linear.make_phiml_backend()
+            rng = np.random.default_rng(11)
+            cases = [((12, 16), ((O.PERIODIC, O.PERIODIC),) * 2, ()), ((12, 16), ((O.CLOSED, O.CLOSED),) * 2, ()),
+                     ((6, 8, 12), ((O.CLOSED, O.CLOSED), (O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED)), ()),
+                     ((11, 9), ((O.CLOSED, O.CLOSED),) * 2, [O.BoxObstacle((1.5, 1.0), (3.0, 2.5))])]
+            for res, bc, obstacles in cases:
+                dom, A, hard, active = _level_b_case(res, bc, obstacles)
+                N = A.shape[0]
+                act = np.ones(res) if active is None else active[0]
+                div = rng.standard_normal((2,) + tuple(res)) * act                      # unbalanced, zero inside the obstacle (fluid.py:139-140)
+                balance = lambda d, a: d - a * (d.sum(axis=tuple(range(1, d.ndim)), keepdims=True) / a.sum())     # fluid._balance_divergence
+                solve = math.Solve('CG', 1e-6, 0, max_iterations=2000).with_preprocessing(balance, act)
+                solve = math.copy_with(solve, rank_deficiency=1)
+                stats0 = dict(be.hip_stats)
+                ctx.profile_enable(True); ctx.profile_read(reset=True)
+                with be:
+                    for step in range(3):                                                # three "time steps": a NEW matrix object each, like a re-trace
+                        traced = A.copy()
+                        if step == 0 and not obstacles:                                   # PhiML's torch backend hands over a torch sparse tensor
+                            traced = torch.sparse_csr_tensor(torch.as_tensor(A.indptr), torch.as_tensor(A.indices), torch.as_tensor(A.data), size=A.shape)
+                        result = math.solve_linear(traced, div.astype(np.float32), solve)
+                prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+                assert result.method == 'HIP CG' and bool(torch.as_tensor(result.converged).all())
+                assert prof['cg_matvec_dot'][0] > 0 and prof['cg_update'][0] + prof['cg_update_r'][0] > 0, prof        # march_kernel launches
+                assert be.hip_stats['fallbacks'] == stats0['fallbacks'] and be.hip_stats['hip_solves'] == stats0['hip_solves'] + 3
+                assert be.hip_stats['offsets_dropped'] == stats0['offsets_dropped'] + 3
+                # one recognition per distinct matrix STORAGE (torch CSR, SciPy CSR), hits afterwards
+                assert be.hip_stats['cache_misses'] - stats0['cache_misses'] <= 2 and be.hip_stats['cache_hits'] - stats0['cache_hits'] >= 1
+                y = balance(div, act)
+                generic = pb.Backend.linear_solve(be, 'CG', A, y.reshape(2, N), np.zeros((2, N)), 1e-6, 0.0, 2000, None, -1.0 / N)
+                a, b = result.x.numpy().reshape(2, N).astype(np.float64), generic.x
+                assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 2e-3, (res, bc)
+                assert np.abs((a.reshape(y.shape) * act).sum(axis=tuple(range(1, y.ndim)))).max() <= 1e-3 * np.abs(a).sum()   # no null-space component
+                # a start vector with a mean: the generic solver removes it, so does the override
+                x0 = (rng.standard_normal((2, N)) + 3.0)
+                r2 = be.linear_solve('CG', A, torch.as_tensor(y.reshape(2, N), dtype=torch.float64), torch.as_tensor(x0), 1e-9, 0.0, 4000, None, -1.0 / N)
+                g2 = pb.Backend.linear_solve(be, 'CG', A, y.reshape(2, N), x0, 1e-9, 0.0, 4000, None, -1.0 / N)
+                assert np.linalg.norm(r2.x.numpy() - g2.x) / np.linalg.norm(g2.x) <= 1e-6
+                # an unbalanced right-hand side is NOT in the range: the offset matters -> generic path
+                f0 = be.hip_stats['fallbacks']
+                r3 = be.linear_solve('CG', A, torch.as_tensor(div.reshape(2, N), dtype=torch.float64) + 1.0, torch.zeros(2, N, dtype=torch.float64), 1e-6, 0.0, 50, None, -1.0 / N)
+                assert be.hip_stats['fallbacks'] == f0 + 1 and r3.method.startswith('generic')
+            # an open side makes the operator non-singular: an offset would change the system -> generic path
+            dom, A, _, _ = _level_b_case((10, 12), ((O.CLOSED, O.OPEN), (O.CLOSED, O.CLOSED)))
+            f0 = be.hip_stats['fallbacks']
+            y = rng.standard_normal((1, 120)); y -= y.mean()
+            r4 = be.linear_solve('CG', A, torch.as_tensor(y), torch.zeros(1, 120, dtype=torch.float64), 1e-6, 0.0, 500, None, -1.0 / 120)
+            assert be.hip_stats['fallbacks'] == f0 + 1 and r4.method.startswith('generic')
+            r5 = be.linear_solve('CG', A, torch.as_tensor(y), torch.zeros(1, 120, dtype=torch.float64), 1e-6, 0.0, 500)       # without offset: HIP
+            assert r5.method == 'HIP CG' and be.hip_stats['fallbacks'] == f0 + 1
+            pb.BACKENDS.remove(be)
+    finally:
+        ctx.set_small_grid_solver(True)
+
+
+def test_resolution_is_read_off_the_matrix():
+    for res in ((64, 64), (4096 // 64, 64), (16, 16, 16), (5, 7, 9), (30, 4), (3, 50, 3)):
+        for bc in (((O.PERIODIC, O.PERIODIC),) * len(res), ((O.CLOSED, O.OPEN),) * len(res)):
+            dom = O.Domain(res, (0.0,) * len(res), tuple(float(n) for n in res), bc)
+            assert linear.infer_resolution(O.laplace_csr(dom, np.float64)) == tuple(res), (res, bc)
+    import scipy.sparse as sp
+    with pytest.raises(linear.NotALaplaceStencil):
+        linear.infer_resolution(sp.identity(50, format='csr'))
+    # N = 4096: the old cube / square-root guess said 16^3 for a 64 x 64 grid
+    dom = O.Domain((64, 64), (0, 0), (64, 64), ((O.CLOSED, O.CLOSED),) * 2)
+    d = linear.recognise_laplace_stencil(O.laplace_csr(dom, np.float64), linear.infer_resolution(O.laplace_csr(dom, np.float64)))
+    assert d['bc'] == [(1, 1), (1, 1)]
+
+
+def test_surface_checker_agrees_with_the_test_double():
+    """ tools/check_phiml_surface.py lists the PhiML names / signatures the Level-B code relies on; the double must offer the same surface
+    (so that a mismatch reported against a real PhiML is a statement about PhiML, not about the checker) """
+    import subprocess
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_phiml_surface.py"), "--fake"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
