@@ -95,6 +95,10 @@ typedef struct phihip_ctx phihip_ctx;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------------------- */
 int phihip_version(void);
+/* "<git commit the library was built at>[+dirty] src:<16 hex digits>": the second part is the sha1 over the library's sources (csrc .hip and
+ * .hpp files in name order, then include/phihip.h), which the Python layer recomputes from the tree to detect a stale .so
+ * (phiflow_amd._capi.source_hash); bench.py and smoke() print it so that numbers measured on a GPU box are tied to a source state. */
+const char* phihip_build_id(void);
 const char* phihip_last_error(void);
 /* replaces: backend selection `with backend:` / set_default_device('GPU') (phi/torch/flow.py:31-32, demos/Top_Opt/Top_Opt3D.py:190) */
 int phihip_ctx_create(int device, phihip_ctx** out);
@@ -317,7 +321,7 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
 /* Self-advection of the staggered velocity (field == velocity pointers) runs as ONE launch whose taps come from LDS tiles staged with a
  * halo of `halo` samples (1 or 2: lookups displaced by less than that many cells never leave LDS; larger displacements fall back to a
  * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
- * measurements, tests). Default: 1. */
+ * measurements, tests); halo = 3 is an experimental variant (halo 1 with 16-row tiles, 3-D only; 2-D grids treat it as 2). Default: 1. */
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
 /* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);

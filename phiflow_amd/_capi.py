@@ -20,7 +20,7 @@ STATUS_NAMES = {0: "PHIHIP_OK", -1: "PHIHIP_ERR_BAD_ARG", -2: "PHIHIP_ERR_HIP", 
                 -4: "PHIHIP_ERR_NO_DEVICE", -5: "PHIHIP_ERR_ALLOC"}
 
 EXPORTED_SYMBOLS = (
-    "phihip_version", "phihip_last_error", "phihip_ctx_create", "phihip_ctx_destroy", "phihip_workspace_bytes",
+    "phihip_version", "phihip_build_id", "phihip_last_error", "phihip_ctx_create", "phihip_ctx_destroy", "phihip_workspace_bytes",
     "phihip_component_shape", "phihip_advect_staggered", "phihip_advect_centered", "phihip_build_cellflags",
     "phihip_divergence", "phihip_laplace_apply", "phihip_cg_solve", "phihip_solve_residuals", "phihip_solve_relative_residual", "phihip_grad_subtract",
     "phihip_make_incompressible", "phihip_diffuse_explicit", "phihip_profile_enable", "phihip_profile_read",
@@ -154,6 +154,7 @@ class Library:
             raise PhiHipLibraryError(f"{self.path} lacks symbols declared in include/phihip.h: {missing}")
         d = self.dll
         d.phihip_version.restype = c_int
+        d.phihip_build_id.restype = c_char_p
         d.phihip_last_error.restype = c_char_p
         d.phihip_ctx_create.argtypes = [c_int, POINTER(c_void_p)]
         d.phihip_ctx_destroy.argtypes = [c_void_p]
@@ -223,7 +224,7 @@ class Library:
         d.phihip_advect_fallback_stats.argtypes = [c_void_p, POINTER(c_int32 * 2), c_void_p]
         d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("phihip_version", "phihip_last_error"):
+            if name not in ("phihip_version", "phihip_last_error", "phihip_build_id"):
                 getattr(d, name).restype = c_int
 
     def check(self, status: int):
@@ -232,6 +233,29 @@ class Library:
 
     def version(self) -> int:
         return self.dll.phihip_version()
+
+    def build_id(self) -> str:
+        """ "<git commit>[+dirty] src:<hash of the sources the library was compiled from>" (phihip_build_id) """
+        fn = getattr(self.dll, "phihip_build_id", None)
+        raw = fn() if fn is not None and fn.restype is c_char_p else None
+        return (raw or b"unknown src:unknown").decode(errors="replace")
+
+    def built_from_tree(self) -> bool:
+        """ the library was compiled from the kernel sources that sit next to it now (stale-.so check: the .so is not in git) """
+        return self.build_id().rsplit("src:", 1)[-1] == source_hash()
+
+
+def source_hash() -> str:
+    """ sha1 (16 hex digits) over csrc/*.hip, csrc/*.hpp in name order and include/phihip.h -- the Makefile embeds the same value """
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    h = hashlib.sha1()
+    for f in [os.path.join(csrc, f) for f in files] + [os.path.join(here, "..", "include", "phihip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 class Context:

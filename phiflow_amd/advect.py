@@ -53,6 +53,8 @@ def _scalar_boundary(field: Field):
 
 def _advect(field: Field, velocity: Field, dt: float, integrator: Callable, correction_strength) -> Field:
     """ shared argument handling of semi_lagrangian (correction_strength None) and mac_cormack """
+    from .field import require_plain
+    require_plain(field, 'advect'); require_plain(velocity, 'advect (velocity)')
     if integrator not in (euler, rk4, finite_rk4):
         raise NotImplementedError("HIP backend: grid advection supports the integrators euler, rk4 and finite_rk4")
     if not velocity.is_staggered:

@@ -272,6 +272,8 @@ class NotDifferentiable(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------------
 def l2_loss(field) -> torch.Tensor:
     """ `field.l2_loss`: 0.5 * sum(values ** 2) per batch entry (summed to a scalar when not batched) """
+    from .field import require_plain
+    require_plain(field, 'l2_loss')
     vals = field.values if field.is_staggered else [field.values]
     per = sum((t.reshape(t.shape[0], -1) ** 2).sum(dim=1) for t in vals) * 0.5
     return per if field.batched else per[0]

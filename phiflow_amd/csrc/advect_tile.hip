@@ -455,7 +455,8 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
         // Chunks of planes per workgroup: every chunk stages 2H+1 extra planes, and a launch that needs 1 < rounds < 2 of resident
         // workgroups costs two rounds (at 256^3 1536 workgroups on 1024 slots ran at 55 % VALU utilisation). Score every chunk count by
         // (slot efficiency of the last round) x (useful planes / staged planes) and prefer >= 2 rounds at equal score.
-        static int occ = 0;
+        static int occ_dev[16] = {0};       // per device: a process may drive several (the query runs on the current one = ctx->device)
+        int& occ = occ_dev[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
         if (occ == 0) {
             int n = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, advect_self_tile_kernel<T, DIM, H, T1, OFFM>, kBlock, 0) != hipSuccess || n < 1) n = 1;
@@ -490,7 +491,7 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
     };
     if (DIM == 3 && ctx->adv_chunk > 0) {
         chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
-    } else if (DIM == 3 && ctx->autotune && (long long)nmax[0] * nmax[1] * nmax[2] * v.batch >= (1 << 21)) {
+    } else if (DIM == 3 && ctx->autotune && (long long)nmax[0] * nmax[1] * nmax[2] * v.batch >= (1 << 21) && !stream_is_capturing(s)) {
         // First call on this grid: the planner's chunk length against a few others, timed on the call's own operands (every length
         // writes the same values, so the output is simply overwritten; ~2 ms once per grid). The planner ranks slot efficiency x halo
         // overhead and misses e.g. the ring warm-up per chunk: 384^3 fp64 runs 6 % faster with 16 planes than with its 64.

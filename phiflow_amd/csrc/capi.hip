@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "march_dispatch.hpp"
 
@@ -171,6 +173,11 @@ using namespace phihip;
 extern "C" {
 
 int phihip_version(void) { return PHIHIP_VERSION; }
+
+#ifndef PHIHIP_BUILD_ID
+#define PHIHIP_BUILD_ID "unknown src:unknown"
+#endif
+const char* phihip_build_id(void) { return PHIHIP_BUILD_ID; }
 
 const char* phihip_last_error(void) { return g_err; }
 
@@ -563,18 +570,23 @@ int phihip_solve_relative_residual(phihip_ctx* ctx, int batch, double* out_devic
 // that created the caller's communicator is already in the process (dlsym over the global scope finds it, e.g. torch's bundled
 // librccl); only a process without one gets a fresh librccl.so.1.
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-static nccl_allreduce_fn resolve_nccl_allreduce() {
+static nccl_allreduce_fn resolve_nccl_allreduce(std::string* why) {
     static nccl_allreduce_fn fn = nullptr;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::string reason;
+    static std::once_flag once;
+    std::call_once(once, [] {
         fn = (nccl_allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
         if (!fn) {
             void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
             if (h) fn = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+            if (!fn) {
+                const char* e = dlerror();          // (one call: dlerror() clears the message it returns)
+                reason = e ? e : "not found";
+            }
         }
-    }
+    });
+    if (why) *why = reason;
     return fn;
 }
 
@@ -582,9 +594,10 @@ int phihip_allreduce_residual(phihip_ctx* ctx, void* comm, double* values_device
     PHIHIP_REQUIRE(ctx != nullptr && comm != nullptr && values_device != nullptr, "allreduce_residual: NULL argument");
     PHIHIP_REQUIRE(count > 0, "allreduce_residual: count must be > 0");
     PHIHIP_REQUIRE(op == 0 || op == 2, "allreduce_residual: op must be 0 (sum) or 2 (max)");
-    nccl_allreduce_fn fn = resolve_nccl_allreduce();
+    std::string why;
+    nccl_allreduce_fn fn = resolve_nccl_allreduce(&why);
     if (!fn) {
-        set_error("allreduce_residual: no RCCL in this process and librccl.so.1 cannot be loaded (%s)", dlerror() ? dlerror() : "not found");
+        set_error("allreduce_residual: no RCCL in this process and librccl.so.1 cannot be loaded (%s)", why.c_str());
         return PHIHIP_ERR_UNSUPPORTED;
     }
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -829,7 +842,7 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
 
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
-    PHIHIP_REQUIRE(halo >= 0 && halo <= 3, "advect halo must be 0 (gather kernels), 1 or 2");
+    PHIHIP_REQUIRE(halo >= 0 && halo <= 3, "advect halo must be 0 (gather kernels), 1, 2 or 3 (experimental: halo 1 with 16-row tiles, 3-D only)");
     ctx->adv_halo = halo;
     return PHIHIP_OK;
 }

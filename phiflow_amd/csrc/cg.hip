@@ -755,7 +755,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))
         return cg1_t<T>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
     if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
-        !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R))) {
+        !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R)) && !stream_is_capturing(s)) {
         const size_t vb = (size_t)v.batch * v.cells * sizeof(T);
         PHIHIP_TRY(ensure_buffer(ctx->ws_r, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vb));

@@ -184,6 +184,13 @@ struct LaunchScope {
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// The first-call autotunes time candidate launches with hipEventSynchronize -- illegal while `s` is being captured into a hipGraph (and
+// the timings would be meaningless there): a capturing stream keeps the analytic plan, the next eager call on the grid tunes.
+inline bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 // ---- phases implemented in the .hip files ---------------------------------------------------------------------------
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
 int run_advect_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double dt, int halo, hipStream_t);

@@ -52,6 +52,8 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
 
 template <int V, int R, int TPR, int MODE, bool FLAGS>
 static int occupancy_one() {
+    // cached per process, not per device: occupancy is a property of (code object, architecture), and every device this library can run
+    // on is a gfx950 with the same register file / LDS -- the devices of one node give the same answer
     static int cached = 0;
     if (cached == 0) {
         int n = 0;

@@ -14,6 +14,8 @@ def explicit(u: Field, diffusivity: float, dt: float, substeps: int = 1, order: 
     """ Simulate a finite-time diffusion process of the form dF/dt = α · ΔF with explicit Euler steps (`diffuse.explicit`,
     order 2) on a StaggeredGrid or a CenteredGrid. The field's own extrapolation pads the stencil (tangential wall values of a
     velocity matter). Differentiable (adjoint stencil kernels). """
+    from .field import require_plain
+    require_plain(u, 'diffuse.explicit')
     if order != 2:
         raise NotImplementedError("HIP backend: diffuse.explicit implements order=2 only")
     amount = diffusivity * dt

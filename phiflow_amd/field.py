@@ -35,7 +35,8 @@ class Field:
     def __init__(self, resolution: Dict[str, int], bounds: Box, boundary: Extrapolation, values, staggered: bool,
                  backend: HipBackend, batched: bool, vector_scale: Optional[Sequence[float]] = None):
         # vector_scale: `scalar * (0, 0.1)` -- a centred scalar times a constant vector, kept lazily (values stay the scalar's) until
-        # it is resampled to a staggered grid with `@` / `resample`; every operator below either carries it along or refuses
+        # it is resampled to a staggered grid with `@` / `resample`. Arithmetic and resample carry it along; every other consumer of
+        # `values` (mean, gradients, divergence, advection, diffusion, losses, file output) calls `require_plain` and refuses
         assert vector_scale is None or (not staggered and len(vector_scale) == len(resolution))
         self.vector_scale = [float(c) for c in vector_scale] if vector_scale is not None else None
         self.resolution = dict(resolution)
@@ -212,6 +213,14 @@ class Field:
         return f"{kind}[{self.resolution}, batch={self.batch_size if self.batched else None}, {self.boundary}, {self.dtype}, {self.backend}]"
 
 
+def require_plain(field, what: str):
+    """ refuse a lazily vector-scaled scalar (`smoke * (0, 0.1)`) where its `values` would be taken for the field itself: the result would
+    silently be that of the plain scalar. Resample it to a staggered grid first (`field @ velocity`). """
+    if isinstance(field, Field) and field.vector_scale is not None:
+        raise NotImplementedError(f"{what}: the field is a scalar times the constant vector {tuple(field.vector_scale)} (a centred VECTOR field, not "
+                                  f"stored as such); resample it to a StaggeredGrid with `field @ velocity` / `resample(field, to=velocity)` first")
+
+
 def same_grid(a: 'Field', b: 'Field') -> bool:
     """ same sample points up to staggering: resolution, bounds and dims (the reference short-circuits `resample` only when
     `value.geometry == to.geometry`, phi/field/_resample.py:42-48) """
@@ -368,6 +377,7 @@ def _ptrs(tensors: Sequence[torch.Tensor]) -> List[int]:
 def divergence(field: Field, order: int = 2) -> Field:
     """ `field.divergence` of a StaggeredGrid, order 2 (phi/field/_field_math.py:589,617-626) -> CenteredGrid with
     extrapolation `field.extrapolation.spatial_gradient()`. """
+    require_plain(field, 'divergence')
     if order != 2 or not field.is_staggered:
         raise NotImplementedError("the HIP backend implements divergence for StaggeredGrid, order=2 only")
     be = field.backend
@@ -380,6 +390,7 @@ def divergence(field: Field, order: int = 2) -> Field:
 def spatial_gradient(field: Field, boundary=None, at: str = 'face', order: int = 2) -> Field:
     """ `field.spatial_gradient(p, boundary, at='face')` (phi/field/_field_math.py:148-236): gradient of a centred scalar
     at the faces that a StaggeredGrid with `boundary` stores; `field.boundary` pads p. """
+    require_plain(field, 'spatial_gradient')
     if at != 'face' or order != 2 or field.is_staggered:
         raise NotImplementedError("the HIP backend implements spatial_gradient(at='face', order=2) of a CenteredGrid only")
     vb = as_extrapolation(boundary if boundary is not None else field.boundary.spatial_gradient())
@@ -407,6 +418,7 @@ def _check_pressure_padding(p_ext: Extrapolation, v_ext: Extrapolation, dims):
 
 def mean(field: Field):
     """ `field.mean`: mean over the spatial dims per batch entry (phi/field/_field_math.py:780-796) """
+    require_plain(field, 'mean')
     if field.is_staggered:
         raise NotImplementedError
     m = field.values.reshape(field.batch_size, -1).mean(dim=1)

@@ -86,6 +86,8 @@ def _load_npz(file: str) -> dict:
 
 def write(field: Field, file: str):
     """ Writes a (non-batched or batched) grid field to `file` in PhiFlow's .npz format. """
+    from .field import require_plain
+    require_plain(field, 'write')
     dims = list(field.dims)
     D = len(dims)
     names = (['batch'] if field.batched else []) + dims

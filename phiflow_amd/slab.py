@@ -260,9 +260,19 @@ class SlabFluid:
         return [ext[c][:, self.own0[c]: self.own0[c] + self.own_n[c]].contiguous() for c in range(3)]
 
     # --- the operators ---
-    def advect(self, v: List[torch.Tensor], dt: float) -> List[torch.Tensor]:
-        """ semi-Lagrangian self-advection of the owned velocity samples; exact while |u_x| dt / dx <= ghost - 1 """
+    def advect(self, v: List[torch.Tensor], dt: float, check_cfl: bool = True) -> List[torch.Tensor]:
+        """ semi-Lagrangian self-advection of the owned velocity samples. Exact while |u_x| dt / dx <= ghost - 1: a back-trace that leaves the
+        ghost zone would be clamped by the (fake) OPEN cut side and the result would depend on the number of ranks. `check_cfl` (default)
+        verifies the bound on this rank's extended x component -- its own lookups and the 4-point means they use only see those samples, so
+        the check needs no collective -- and raises `ValueError` instead of returning rank-dependent values; it costs one small reduction
+        and a host read per call (the step's pressure solve synchronises anyway). Construct with a larger `ghost` for faster flows. """
         ext = self._extend_velocity(v)
+        if check_cfl and self.world > 1:
+            dx0 = (self.grid.upper[0] - self.grid.lower[0]) / self.ext_cells
+            cfl = float(ext[0].abs().max()) * abs(float(dt)) / dx0
+            if not cfl <= self.ghost - 1:
+                raise ValueError(f"SlabFluid.advect: |u_x| dt / dx = {cfl:.3f} exceeds ghost - 1 = {self.ghost - 1} on rank {self.rank}: back-traces "
+                                 f"would leave the exchanged ghost planes. Use SlabFluid(..., ghost={int(cfl) + 2}) or a smaller dt.")
         out = [torch.empty_like(t) for t in ext]
         P = lambda ts: [t.data_ptr() for t in ts]
         self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
@@ -286,9 +296,10 @@ class SlabFluid:
         return self._own_velocity(ext_v)
 
     def step(self, v: List[torch.Tensor], p: torch.Tensor, dt: float, rel_tol=1e-5, abs_tol=0.0, max_iterations=1000, refresh_every=50,
-             check_every=10):
-        """ one operator-split time step; `p` holds the pressure guess on entry and the pressure on exit. Returns (v, infos). """
-        v = self.advect(v, dt)
+             check_every=10, check_cfl: bool = True):
+        """ one operator-split time step; `p` holds the pressure guess on entry and the pressure on exit. Returns (v, infos).
+        The advection is exact while |u_x| dt / dx <= ghost - 1 (checked per rank, `ValueError` otherwise; see `advect`). """
+        v = self.advect(v, dt, check_cfl)
         singular = all(c != _capi.BC_OPEN for pair in self.bc for c in pair)
         div = self.divergence(v, balance=singular)
         infos = self.solver.solve(div, p, rel_tol, abs_tol, max_iterations, refresh_every, check_every)

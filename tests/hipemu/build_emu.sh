@@ -18,7 +18,9 @@ mkdir -p "$build"
 CXX="g++ -O1 -g -std=c++17 -fPIC -I$here/include -w $extra"
 pids=()
 $CXX -c "$here/hipemu.cpp" -o "$build/hipemu.o" & pids+=($!)
-for f in capi cg project advect advect_tile adjoint cg_small; do
+src_hash=$(cd "$src" && cat $(ls *.hip *.hpp | LC_ALL=C sort) ../../include/phihip.h | sha1sum | cut -c1-16)
+$CXX -x c++ -DPHIHIP_BUILD_ID="\"emulation src:$src_hash\"" -c "$src/capi.hip" -o "$build/capi.o" & pids+=($!)
+for f in cg project advect advect_tile adjoint cg_small; do
   $CXX -x c++ -c "$src/$f.hip" -o "$build/$f.o" & pids+=($!)
 done
 for t in 0 1; do for d in 0 1; do

@@ -109,6 +109,9 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int d);
 // emulation: pretend 4 resident workgroups per CU for every kernel
 template <typename F>
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 4; return hipSuccess; }
+// emulation: streams never capture (the library asks before it synchronises inside a call, e.g. the first-call autotune)
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);

@@ -33,6 +33,19 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.skipif(not os.path.exists(_capi.DEFAULT_LIBRARY_PATH), reason="libphihip.so not built")
+def test_library_was_built_from_the_sources_in_this_tree():
+    """ the .so is not in git and travels to the GPU box as a file: its embedded source hash must match the sources next to it """
+    import subprocess
+    lib = _capi.Library(_capi.DEFAULT_LIBRARY_PATH)
+    if not lib.built_from_tree() and os.path.exists("/opt/rocm/bin/hipcc"):      # sources edited since the last build: rebuild, like build()
+        subprocess.run(["make", "-C", os.path.join(ROOT, "phiflow_amd", "csrc"), f"-j{os.cpu_count() or 4}"], check=True, stdout=subprocess.DEVNULL)
+        lib = _capi.Library(_capi.DEFAULT_LIBRARY_PATH)
+    bid = lib.build_id()
+    assert re.fullmatch(r"[0-9a-f]{12}(\+dirty)? src:[0-9a-f]{16}|nogit src:[0-9a-f]{16}", bid), bid
+    assert lib.built_from_tree(), f"stale libphihip.so: built from {bid}, tree has src:{_capi.source_hash()} -- run __graft_entry__.build()"
+
+
+@pytest.mark.skipif(not os.path.exists(_capi.DEFAULT_LIBRARY_PATH), reason="libphihip.so not built")
 def test_no_cpu_fallback_without_device():
     import torch
     if torch.cuda.is_available():

@@ -636,3 +636,26 @@ def test_resample_compares_bounds_not_only_resolution(emu_backend):
     to_faces = (a * (1.0, 0.0)) @ v                         # general path: different boxes
     assert tuple(to_faces.bounds.upper) == (4.0, 4.0)
     np.testing.assert_allclose(to_faces.numpy()[0][:, 0], np.arange(1, 8) * 0.5, atol=1e-5)
+
+
+def test_vector_scaled_scalar_is_refused_where_it_would_be_taken_for_the_scalar(emu_backend, tmp_path):
+    """ `smoke * (0, 0.1)` stays a lazily scaled scalar until it is resampled to faces (Smoke_Plume.ipynb cell 5); every consumer that
+    would read its `values` as the field itself has to refuse instead of computing with the plain scalar """
+    from phiflow_amd import field_io
+    from phiflow_amd.autodiff import l2_loss
+    from phiflow_amd.field import mean, spatial_gradient
+    from phiflow_amd.flow import Box, CenteredGrid, StaggeredGrid, ZERO_GRADIENT, advect, diffuse, resample
+    bounds = Box(x=8, y=6)
+    smoke = CenteredGrid(np.random.default_rng(0).random((8, 6)).astype(np.float32), ZERO_GRADIENT, bounds, x=8, y=6, backend=emu_backend)
+    v = StaggeredGrid(0.1, 0, bounds, x=8, y=6, backend=emu_backend)
+    buoyancy = smoke * (0, 0.1)
+    assert buoyancy.vector_scale == [0.0, 0.1]
+    for call in (lambda: mean(buoyancy), lambda: spatial_gradient(buoyancy, v.boundary), lambda: advect.semi_lagrangian(buoyancy, v, 1.0),
+                 lambda: advect.mac_cormack(buoyancy, v, 1.0), lambda: diffuse.explicit(buoyancy, 0.1, 1.0), lambda: l2_loss(buoyancy),
+                 lambda: field_io.write(buoyancy, str(tmp_path / "b.npz"))):
+        with pytest.raises(NotImplementedError, match="constant vector"):
+            call()
+    on_faces = resample(buoyancy, to=v)                      # the supported use
+    assert on_faces.is_staggered and float(on_faces.values[0].abs().max()) == 0.0 and float(on_faces.values[1].max()) > 0
+    scaled = (2.0 * buoyancy) @ v                            # arithmetic carries the vector along
+    assert float(scaled.values[1].max()) == pytest.approx(2.0 * float(on_faces.values[1].max()), rel=1e-6)

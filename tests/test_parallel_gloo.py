@@ -207,7 +207,12 @@ def _fluid_worker(rank, world, port, emu_path, out_dir, case):
     div = fluid.divergence(adv, balance=all(c != 2 for pair in bc for c in pair))
     p = torch.zeros(fluid.cell_shape, dtype=torch.float32)
     out, infos = fluid.step(own, p, 0.9, rel_tol=1e-5, max_iterations=200)
-    np.savez(os.path.join(out_dir, f"fluid{rank}.npz"), f0=fluid.face_begin - off, f1=fluid.face_end - off, b0=fluid.begin, b1=fluid.end,
+    try:                                               # |u_x| dt / dx > ghost - 1: refused instead of rank-dependent values (the exchange itself still completes)
+        fluid.advect(own, 6.0)
+        refused = False
+    except ValueError:
+        refused = True
+    np.savez(os.path.join(out_dir, f"fluid{rank}.npz"), refused=refused, f0=fluid.face_begin - off, f1=fluid.face_end - off, b0=fluid.begin, b1=fluid.end,
              adv0=adv[0].numpy(), adv1=adv[1].numpy(), adv2=adv[2].numpy(), div=div.numpy(), p=p.numpy(),
              out0=out[0].numpy(), out1=out[1].numpy(), out2=out[2].numpy(), it=[i.iterations for i in infos])
     dist.barrier()
@@ -225,6 +230,7 @@ def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, 
     singular = all(c != 2 for pair in bc for c in pair)
     adv, div, p, out, info = _reference_step(emu_ctx, grid, v, 0.9, singular)
     parts = [np.load(tmp_path / f"fluid{r}.npz") for r in range(world)]
+    assert any(bool(q["refused"]) for q in parts), "a back-trace of > ghost - 1 cells along x must be refused"
     assert int(parts[0]["f0"]) == 0 and int(parts[-1]["f1"]) == v[0].shape[1]
     assert all(int(parts[r]["f1"]) == int(parts[r + 1]["f0"]) for r in range(world - 1))
     cat = lambda key: np.concatenate([q[key] for q in parts], axis=1)
