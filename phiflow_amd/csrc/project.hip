@@ -317,15 +317,28 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<
     }
 }
 
-// The same update with one 16-byte vector of the fast axis per thread (V = 4 fp32 / 2 fp64 cells of a row): for the components whose rows
-// have the length of the pressure rows -- a0 and a1 always, a2 when that axis is periodic -- every load and store is a dwordx4 (the scalar
-// kernel issues 9 dword loads, 3 of them redundant, and 3 dword stores per cell). `comps` = bit mask of the components this launch updates.
+// The same update with one 16-byte vector of the fast axis per thread (V = 4 fp32 / 2 fp64 cells of a row); `comps` = bit mask of the
+// components this launch updates. The scalar kernel above issues 9 dword loads (3 of them redundant) and 3 dword stores per cell.
+//   a0 / a1: the two cells of a face are whole rows -- same columns, neighbouring plane / row: two aligned vector loads of p.
+//   a2: the faces j = c .. c + V - 1 of a row lie between the cells of ONE aligned vector pc = p[c .. c + V - 1] and that vector shifted by
+//       one cell; the cell that enters at the open end (p[c - 1] when the lower face of a cell is stored, off = 0; p[c + V] when the wall
+//       face is not, off = 1) is one scalar load with the pressure's boundary rule (wrap / zero ghost). Rows of this component hold
+//       n2 - 1 / n2 / n2 + 1 faces (closed / periodic or mixed / open), so its own vector is addressed with element alignment only
+//       (VecU: the hardware takes dwordx4 at any 4-byte address); the last, partial vector of a row and the extra face of an OPEN upper
+//       side (j = n2) are scalar. r3: closed and open boxes -- and with them every obstacle scenario -- used to send this component
+//       through the scalar kernel in a second launch that read p and the flags again.
+template <typename T, int V>
+struct __attribute__((packed, aligned(sizeof(T)))) VecU {
+    T v[V];
+};
+
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
                                                                    int nmax0, int patches1, int patches2, int comps) {
     constexpr int A0 = 3 - DIM;
     constexpr int V = 16 / (int)sizeof(T);
     using VT = Vec<T, V>;
+    using VU = VecU<T, V>;
     using VF = Vec<uint8_t, V>;
     const int b = blockIdx.y;
     const T* __restrict__ P = p + (long long)b * g.cells;
@@ -333,6 +346,8 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Co
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
     const int npatch = nmax0 * patches1 * patches2;
     const int n2 = g.n[2];
+    const int cn2 = g.cn[2][2], off2 = g.off[2];
+    const bool per2 = g.bc[2][0] == PHIHIP_BC_PERIODIC;
     for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
         int idx[3], r0, c0;
         decode_patch(patch, patches1, patches2, idx[0], r0, c0);
@@ -340,37 +355,29 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Co
         idx[2] = (c0 + tx) * V;          // (decode_patch counts columns in threads: kPatchCols threads x V cells)
         if (idx[2] >= n2) continue;
 #pragma unroll
-        for (int ca = A0; ca < 3; ++ca) {
+        for (int ca = A0; ca < 2; ++ca) {
             if (!((comps >> ca) & 1)) continue;
             if (idx[0] >= g.cn[ca][0] || idx[1] >= g.cn[ca][1]) continue;
             VT pl, pr;
             VF fl;
             bool use_f = false;
             int fshift = 2 * ca;
-            if (ca < 2) {   // the neighbours along a0 / a1 are whole rows: same columns, other plane / row
-                const int n = g.n[ca];
-                const int pstride = ca == 0 ? g.n[1] * n2 : n2;
-                const int phys = idx[ca] + g.off[ca];
-                int l = phys - 1, r = phys;
-                bool zl = false, zr = false;
-                const bool l_in = l >= 0, r_in = r < n;
-                if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
-                if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
-                const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
-                const int offL = rest + l * pstride, offR = rest + r * pstride;
-                pl = zl ? vec_zero<T, V>() : vec_load<T, V>(P + offL);
-                pr = zr ? vec_zero<T, V>() : vec_load<T, V>(P + offR);
-                if (F) {
-                    if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) { fl = *reinterpret_cast<const VF*>(F + offR); use_f = true; }
-                    else if (l_in) { fl = *reinterpret_cast<const VF*>(F + offL); use_f = true; fshift = 2 * ca + 1; }
-                }
-            } else {        // a2, periodic: face j is the lower face of cell j; its left cell is the previous element of the row
-                const int row = (idx[0] * g.n[1] + idx[1]) * n2;
-                pr = vec_load<T, V>(P + row + idx[2]);
-                pl.v[0] = P[row + (idx[2] > 0 ? idx[2] - 1 : n2 - 1)];
-#pragma unroll
-                for (int e = 1; e < V; ++e) pl.v[e] = pr.v[e - 1];
-                if (F) { fl = *reinterpret_cast<const VF*>(F + row + idx[2]); use_f = true; }
+            // the neighbours along a0 / a1 are whole rows: same columns, other plane / row
+            const int n = g.n[ca];
+            const int pstride = ca == 0 ? g.n[1] * n2 : n2;
+            const int phys = idx[ca] + g.off[ca];
+            int l = phys - 1, r = phys;
+            bool zl = false, zr = false;
+            const bool l_in = l >= 0, r_in = r < n;
+            if (!l_in) { if (g.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { zl = true; l = 0; } }
+            if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
+            const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
+            const int offL = rest + l * pstride, offR = rest + r * pstride;
+            pl = zl ? vec_zero<T, V>() : vec_load<T, V>(P + offL);
+            pr = zr ? vec_zero<T, V>() : vec_load<T, V>(P + offR);
+            if (F) {
+                if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) { fl = *reinterpret_cast<const VF*>(F + offR); use_f = true; }
+                else if (l_in) { fl = *reinterpret_cast<const VF*>(F + offL); use_f = true; fshift = 2 * ca + 1; }
             }
             T* __restrict__ Vp = vc.p[ca] + (long long)b * g.ccells[ca] + ((long long)(idx[0] * g.cn[ca][1] + idx[1]) * n2 + idx[2]);
             VT u = vec_load<T, V>(Vp);
@@ -381,6 +388,44 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Co
                 u.v[e] = u.v[e] - h * ((pr.v[e] - pl.v[e]) * rd);
             }
             vec_store<T, V>(Vp, u);
+        }
+        if (((comps >> 2) & 1) && idx[0] < g.cn[2][0] && idx[1] < g.cn[2][1]) {
+            const int c = idx[2];
+            const int row = (idx[0] * g.n[1] + idx[1]) * n2;
+            const VT pc = vec_load<T, V>(P + row + c);
+            VF fc;
+            if (F) fc = *reinterpret_cast<const VF*>(F + row + c);
+            // the cell beyond the open end of the vector, with the pressure's boundary rule (periodic wrap; ghost 0 outside an open / closed side:
+            // a closed side stores no face there, the value is not used)
+            T edge = T(0);
+            if (off2 == 0) { if (c > 0) edge = P[row + c - 1]; else if (per2) edge = P[row + n2 - 1]; }
+            else { if (c + V < n2) edge = P[row + c + V]; else if (per2) edge = P[row]; }
+            VT d;        // p_R - p_L per face, h per face from the cell of the vector that owns the face's flag bit
+            T hh[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T left = off2 == 0 ? (e > 0 ? pc.v[e > 0 ? e - 1 : 0] : edge) : pc.v[e];
+                const T right = off2 == 0 ? pc.v[e] : (e < V - 1 ? pc.v[e < V - 1 ? e + 1 : e] : edge);
+                d.v[e] = right - left;
+                // off = 0: face j is the LOWER face of cell j (bit 4); off = 1: the UPPER face of cell j (bit 5) -- cellflags are symmetric
+                hh[e] = F ? (((fc.v[e] >> (off2 == 0 ? 4 : 5)) & 1u) ? T(1) : T(0)) : T(1);
+            }
+            const T rd = (T)g.rdx[2];
+            T* __restrict__ Vp = vc.p[2] + (long long)b * g.ccells[2] + ((long long)(idx[0] * g.cn[2][1] + idx[1]) * cn2 + c);
+            if (c + V <= cn2) {
+                VU u = *reinterpret_cast<const VU*>(Vp);
+#pragma unroll
+                for (int e = 0; e < V; ++e) u.v[e] = u.v[e] - hh[e] * (d.v[e] * rd);
+                *reinterpret_cast<VU*>(Vp) = u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (c + e < cn2) Vp[e] = Vp[e] - hh[e] * (d.v[e] * rd);
+            }
+            if (cn2 > n2 && c + V == n2) {     // OPEN upper side: the extra face j = n2 between the last cell and the zero ghost
+                const T h = F ? (((fc.v[V - 1] >> 5) & 1u) ? T(1) : T(0)) : T(1);
+                Vp[V] = Vp[V] - h * ((T(0) - pc.v[V - 1]) * rd);
+            }
         }
     }
 }
@@ -394,12 +439,13 @@ static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint
     Comp3<T> c{{(T*)vel[0], (T*)vel[1], (T*)vel[2]}};
     constexpr int V = 16 / (int)sizeof(T);
     int scalar_comps = 7;
-    // vector path: rows of the pressure and of the components are whole vectors and every buffer is 16-byte aligned (flags: V bytes)
+    // vector path: rows of the pressure are whole vectors and the buffers of p, of the flags and of the a0 / a1 components are 16-byte
+    // aligned (flags: V bytes); the a2 component only needs element alignment
     bool vec_ok = v.n[2] % V == 0 && ((uintptr_t)p & 15u) == 0 && (!flags || ((uintptr_t)flags & (V - 1)) == 0);
-    for (int ca = v.ax0; ca < 3; ++ca) vec_ok = vec_ok && ((uintptr_t)vel[ca] & 15u) == 0;
+    for (int ca = v.ax0; ca < 2; ++ca) vec_ok = vec_ok && ((uintptr_t)vel[ca] & 15u) == 0;
+    vec_ok = vec_ok && ((uintptr_t)vel[2] & (sizeof(T) - 1)) == 0;
     if (vec_ok) {
-        const int a2_periodic = v.bc[2][0] == PHIHIP_BC_PERIODIC ? 1 : 0;
-        const int vec_comps = 3 | (a2_periodic << 2);
+        const int vec_comps = 7;
         const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols * V);
         const long long npatch = (long long)nmax[0] * patches1 * patches2;
         const int nblk = npatch < 16384 ? (int)npatch : 16384;

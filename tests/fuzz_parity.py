@@ -63,6 +63,8 @@ def main():
             step = "laplace"; pc.check_laplace(ctx, mem, dom, grid, dtype, rng)
             step = "divergence"; pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=not dom.flexible())
             step = "grad_subtract"; pc.check_grad_subtract(ctx, mem, dom, grid, dtype, rng)
+            if all(n >= 4 for n in res):
+                step = "grad_subtract_flags"; pc.check_grad_subtract_flags(ctx, mem, dom, grid, dtype, rng)
             step = "advect_staggered"; pc.check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=float(r.uniform(0.1, 3.0)))
             step = "advect_centered"; pc.check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
             step = "mac_cormack_centered"

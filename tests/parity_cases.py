@@ -149,6 +149,29 @@ def check_grad_subtract(ctx, mem, dom, grid, dtype, rng):
         assert err <= tol(dtype)['stencil'], f"grad_subtract[{d}] rel err {err}"
 
 
+def check_grad_subtract_flags(ctx, mem, dom, grid, dtype, rng):
+    """ v -= hard_bcs * grad p with the packed cell flags of a box obstacle (phi/physics/fluid.py:158-161): hard_bcs from the oracle's
+    obstacle_masks, flags from phihip_build_cellflags; every boundary mix takes the vector kernel when the rows are whole vectors """
+    B = grid.batch
+    lo = [dom.lower[d] + 0.30 * (dom.upper[d] - dom.lower[d]) for d in range(dom.rank)]
+    hi = [dom.lower[d] + 0.62 * (dom.upper[d] - dom.lower[d]) for d in range(dom.rank)]
+    active, hard, _ = O.obstacle_masks([O.BoxObstacle(tuple(lo), tuple(hi))], dom, dtype)
+    acc = np.ascontiguousarray((active[0] > 0).astype(np.uint8))
+    g1 = C.make_grid(dom.rank, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    dacc, dflags = mem.to_dev(acc), mem.empty(dom.res, np.uint8)
+    ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    v = random_velocity(dom, B, dtype, rng)
+    p = rng.standard_normal((B,) + dom.res).astype(dtype)
+    dv = [mem.to_dev(a) for a in v]
+    dp = mem.to_dev(p)
+    ctx.grad_subtract(grid, mem.ptr(dflags), 1, mem.ptr(dp), [mem.ptr(a) for a in dv])
+    mem.sync()
+    ref = O.gradient_subtract(v, p, dom, hard)
+    for d in range(dom.rank):
+        err = rel_err(mem.to_host(dv[d]), ref[d])
+        assert err <= tol(dtype)['stencil'], f"grad_subtract with flags [{d}] rel err {err}"
+
+
 def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
     """ self-advection through the LDS-tiled kernel (halo 1 and 2) and the gather kernels (halo 0), each against the oracle, for three
     velocity fields: as given (random, large displacements: most workgroups are redone by the gather path), gentle (every displacement

@@ -23,6 +23,8 @@ GRIDS_3D = [
     ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER))),
     ((9, 7, 10), ((CLO, CLO), (OPN, OPN), (CLO, OPN))),
     ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO))),   # more than one tile along a2, partial tiles
+    ((3, 5, 264), ((PER, PER), (CLO, CLO), (OPN, OPN))),   # open fast axis: rows of n2 + 1 faces, two patches of the vector kernels
+    ((4, 5, 24), ((OPN, OPN), (OPN, CLO), (OPN, CLO))),    # lower face stored, upper wall face not: rows of n2 faces without wrap
 ]
 
 
@@ -36,6 +38,7 @@ def test_stencils_match_oracle(emu_ctx, res, bc, dtype):
     pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=False)
     pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=True)
     pc.check_grad_subtract(emu_ctx, MEM, dom, grid, dtype, rng)
+    pc.check_grad_subtract_flags(emu_ctx, MEM, dom, grid, dtype, rng)
     pc.check_diffuse(emu_ctx, MEM, dom, grid, dtype, rng)
 
 

@@ -35,6 +35,9 @@ GRIDS = [
     ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO))),
     ((48, 40, 136), ((PER, PER), (CLO, CLO), (OPN, OPN))),
     ((33, 31, 29), ((CLO, CLO), (CLO, CLO), (CLO, CLO))),
+    ((3, 5, 264), ((PER, PER), (CLO, CLO), (OPN, OPN))),
+    ((4, 5, 24), ((OPN, OPN), (OPN, CLO), (OPN, CLO))),
+    ((40, 36, 384), ((CLO, CLO), (CLO, CLO), (CLO, CLO))),   # config-5 rows: three (1,64) fp64 tiles per row, vector gradient kernel with n2 - 1 faces
 ]
 
 
@@ -48,6 +51,7 @@ def test_stencils_match_oracle(ctx, mem, res, bc, dtype):
     pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=False)
     pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=True)
     pc.check_grad_subtract(ctx, mem, dom, grid, dtype, rng)
+    pc.check_grad_subtract_flags(ctx, mem, dom, grid, dtype, rng)
     pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)
 
 
