@@ -6,7 +6,12 @@ One "step" = semi-Lagrangian self-advection of the staggered velocity + pressure
 (100) CG iterations (tolerances 0, true-residual refresh every 50 like PhiML) + gradient subtraction, fp32, on the 3-D
 periodic Taylor-Green configuration 256^3 (BASELINE.json configs[1]). Inputs are resident in HBM before the timed region.
 N > 1: batch-parallel replicas, one simulation per GPU (weak scaling), one RCCL all-reduce per step of the relative
-residual norm. Prints ONE JSON line on rank 0.
+residual norm; every rank reports its verified iteration count and a bit checksum of its fields (`replicas`: identical
+inputs and launch plans => bit-identical results). Prints ONE JSON line on rank 0.
+
+`roofline` names the dominant kernel of the HBM-RESIDENT configuration (512^3 fp32 pressure solve, BASELINE configs[2], run inside this
+invocation); the benchmark configuration's own dominant kernel is in `roofline_256`, marked `infinity_cache_assisted` (its three 67 MB
+operands fit the 256 MiB Infinity Cache). Fractions count the bytes a kernel MOVES by construction (BASELINE.md "Byte model").
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
@@ -73,6 +78,11 @@ class FluidStep:
         self.solve = C.Solve(0.0, 0.0, cg_iters, refresh, 0, 0)
         self.dt = 0.5 * L / n                         # CFL ~ 0.5
         self.stream = int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0
+
+    def reset(self):
+        """ back to the initial state (N > 1: rank 0 spends one step on the launch-plan autotune before the replicas start together) """
+        self.v = taylor_green_velocity(self.n, self.device, self.p.dtype, self.batch)
+        self.p.zero_()
 
     def step(self, allreduce=None):
         ctx, s = self.ctx, self.stream
@@ -187,6 +197,63 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         dist.destroy_process_group()
 
 
+def bench_slab(args, lib, device, rank, world, dist, barrier):
+    """ `--workload slab` (no reference counterpart): ONE n^3 fp32 periodic Taylor-Green simulation decomposed into x-slabs, one per
+    GPU; step = ghost-plane exchange + advection + divergence + slab CG with exactly --cg-iters iterations (halo planes + 2 scalar
+    all-reduces per iteration) + gradient subtraction. Fixed total size => strong scaling. """
+    from phiflow_amd.backend import HipBackend
+    from phiflow_amd.slab import SlabFluid
+    be = HipBackend(library=lib, device=str(device))
+    n = args.size if args.size != 256 else 512
+    L = 2 * math.pi
+    per = ((C.BC_PERIODIC, C.BC_PERIODIC),) * 3
+    fluid = SlabFluid(be, (n, n, n), (0.0, 0.0, 0.0), (L, L, L), per, torch.float32, batch=1, ghost=2)
+    h = L / n
+    idx = torch.arange(n, device=device, dtype=torch.float64)
+    face, cent = idx * h, (idx + 0.5) * h
+    xs_f, xs_c = face[fluid.face_begin:fluid.face_end], cent[fluid.begin:fluid.end]
+    u = (torch.cos(xs_f)[:, None] * torch.sin(cent)[None, :])[:, :, None].expand(len(xs_f), n, n)
+    v_ = (-torch.sin(xs_c)[:, None] * torch.cos(face)[None, :])[:, :, None].expand(len(xs_c), n, n)
+    vel = [u.to(torch.float32).unsqueeze(0).contiguous(), v_.to(torch.float32).unsqueeze(0).contiguous(),
+           torch.zeros(1, len(xs_c), n, n, device=device)]
+    p = torch.zeros(fluid.cell_shape, device=device)
+    dt = 0.5 * h
+
+    def step(v):
+        return fluid.step(v, p, dt, rel_tol=0.0, abs_tol=0.0, max_iterations=args.cg_iters, refresh_every=50, check_every=0)
+    for _ in range(args.warmup):
+        vel, infos = step(vel)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vel, infos = step(vel)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    its = torch.tensor([infos[0].iterations, int(infos[0].diverged)], device=device, dtype=torch.int64)
+    every = [its.clone() for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(every, its)
+    if rank == 0:
+        cells = n ** 3
+        emit_record({
+            "metric": f"cell-updates/sec (advect + {args.cg_iters} CG iters), ONE {n}^3 fp32 simulation on x-slabs", "value": cells * args.steps / elapsed,
+            "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D periodic Taylor-Green {n}^3 fp32 as ONE simulation on {world} x-slab(s) (SURVEY §8 f4), {args.cg_iters} CG iterations/step",
+                       "planes_rank0": fluid.end - fluid.begin, "ghost_planes": fluid.ghost, "cg_iterations": args.cg_iters,
+                       "parallelism": f"slab decomposition x{world}: per CG iteration 2 boundary-plane exchanges (point-to-point) + 2 all-reduces of 8 B"},
+            "iterations_verified": [[int(x) for x in e.tolist()] for e in every], "final_relative_residual": math.sqrt(infos[0].residual_sq / infos[0].rhs_sq),
+            "build_id": lib.build_id(),
+            "scaling_measured": "one point of a strong-scaling curve; no multi-GPU curve has been measured by the builder (single-GPU boxes only)"})
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline(n, cg_iters):
     """ the NumPy oracle (restatement of the reference's CPU path) timed on the same step at a bounded size; the oracle's fields are
     kept for the parity block (the GPU repeats exactly this step on the same inputs) """
@@ -258,7 +325,8 @@ def config3_block(ctx, device, n=512, iters=100):
     per_k = {k: (v[1] / v[0] if v[0] else None) for k, v in prof.items()}
     ms_it = wall / iters * 1e3
     moved = MOVED_BYTES_PER_CELL["cg_iteration"] * cells
-    out = {"workload": f"{n}^3 fp32 periodic pressure solve, {iters} CG iterations, seeded random rhs (BASELINE.json configs[2])",
+    out = {"size": n, "launches": {k: v[0] for k, v in prof.items() if v[0]},
+           "workload": f"{n}^3 fp32 periodic pressure solve, {iters} CG iterations, seeded random rhs (BASELINE.json configs[2])",
            "ms_per_solve": round(wall * 1e3, 3), "ms_per_iteration": round(ms_it, 5),
            "moved_bytes_per_iteration": moved, "moved_GBs": round(moved / (ms_it * 1e-3) / 1e9, 1),
            "moved_frac": round(moved / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -300,8 +368,9 @@ def live_pmc_traffic(n, kernel_key):
             if proc.returncode != 0:
                 return None, None
         res = pmc_summary.summarise(base)
+        kk = {"cg_update": "cg_update_x2"}.get(kernel_key, kernel_key)      # (pmc_summary names mode 7 cg_update_x2)
         cands = [(e.get("launches", 0), key, e) for key, e in res["kernels"].items()
-                 if key.startswith(kernel_key + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e]
+                 if key.startswith(kk + "<") and "read_bytes_prescribed" in e and "write_bytes_prescribed" in e]
         for _, key, e in sorted(cands, key=lambda c: -c[0])[:1]:      # the plan the solve ran: the variant with the most launches
             if True:
                 src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run inside this bench invocation on tools/pmc_workload.py {n} "
@@ -339,6 +408,81 @@ def cpu_cg_variants(n, iters, dtype=np.float32):
 
 
 
+CG_KERNELS = {"cg_matvec_dot": "march_kernel<MODE_MATVEC> (d = r + beta d, sum d.Ad; one launch per CG iteration)",
+              "cg_update": "march_kernel<MODE_UPDATE_X2> (x += two steps, r -= alpha A d, sum r^2; every other iteration)",
+              "cg_update_r": "march_kernel<MODE_UPDATE_R> (r -= alpha A d, sum r^2; every other iteration)"}
+
+
+def roofline_block(n, per, pmc, world, cache_assisted, where):
+    """ per: {kernel family: (avg ms per launch, launches, total ms)} from hipEvent pairs on the solve stream. Dominant kernel = largest share
+    of the GPU time among the three CG kernels; achieved = bytes it MOVES by construction / its average launch time. """
+    cells = n ** 3
+    dom_key = max(CG_KERNELS, key=lambda k: per[k][2])
+    t_dom = per[dom_key][0]
+    if not t_dom:
+        return None, {}
+    total_ms = sum(v[2] for v in per.values())
+    moved = MOVED_BYTES_PER_CELL[dom_key] * cells
+    alg = ALG_BYTES_PER_CELL[dom_key] * cells
+    gbs = moved / (t_dom * 1e-3) / 1e9
+    traffic, source = (None, None)
+    if pmc and world == 1:
+        traffic, source = live_pmc_traffic(n, dom_key)
+    if traffic is None:
+        traffic, source = _pmc_traffic(n, dom_key)
+    block = {"bound": "hbm", "kernel": CG_KERNELS[dom_key], "size": n, "measured_on": where, "infinity_cache_assisted": bool(cache_assisted),
+             "share_of_gpu_time": round(per[dom_key][2] / total_ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+             "traffic_frac": round(traffic / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+             "traffic_over_moved": round(traffic / moved, 3) if traffic else None,
+             "avg_launch_ms": round(t_dom, 5), "launches": per[dom_key][1], "bytes_per_launch": moved,
+             "bytes_basis": f"bytes the kernel moves by construction (BASELINE.md 'Byte model', DESIGN.md 3.1): {MOVED_BYTES_PER_CELL[dom_key] // 4} words x 4 B x "
+                            f"{cells} cells; `traffic` (rocprofv3 PMC) cross-checks it",
+             "algorithmic_bytes_per_launch": alg, "algorithmic_equiv_frac": round(alg / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "achievable_copy_GBs": 6290.0}
+    it = {}
+    t_mv, t_x2, t_ur = per["cg_matvec_dot"][0], per["cg_update"][0], per["cg_update_r"][0]
+    if t_mv and (t_x2 or t_ur):
+        t_up = 0.5 * ((t_x2 or t_ur) + (t_ur or t_x2))          # the two update forms alternate
+        moved_it = MOVED_BYTES_PER_CELL["cg_iteration"] * cells
+        it = {"size": n, "infinity_cache_assisted": bool(cache_assisted), "ms_matvec_dot": round(t_mv, 5), "ms_update_x2": round(t_x2, 5) if t_x2 else None,
+              "ms_update_r": round(t_ur, 5) if t_ur else None, "ms_iteration": round(t_mv + t_up, 5), "moved_bytes": moved_it,
+              "moved_GBs": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9, 1), "moved_frac": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "algorithmic_bytes": ALG_BYTES_PER_CELL["cg_iteration"] * cells,
+              "algorithmic_equiv_frac": round(ALG_BYTES_PER_CELL["cg_iteration"] * cells / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return block, it
+
+
+def sync_launch_plans(ctx, sim, dist, rank, device):
+    """ N > 1: every replica must run the SAME launch geometry (the summation order of the dot products follows it), or the replicas are
+    equal to rounding only. Rank 0 runs one step with the first-call autotune; its plans are broadcast and pinned on every rank. """
+    fams = (0, 1, 2, 3)
+    plans = torch.zeros(len(fams), 3, dtype=torch.int64, device=device)
+    if rank == 0:
+        sim.step(None)
+        torch.cuda.synchronize(device)
+        for i, f in enumerate(fams):
+            q = ctx.query_plan(sim.grid, False, f)
+            plans[i] = torch.tensor([q["rows"], q["tpr"], q["chunk"]], dtype=torch.int64)
+        sim.reset()
+    dist.broadcast(plans, src=0)
+    ctx.set_autotune(False)
+    for i, f in enumerate(fams):
+        rows, tpr, chunk = (int(x) for x in plans[i].tolist())
+        ctx.set_tuning_kernel(f, rows, tpr, chunk)
+    return {f"family{f}": [int(x) for x in plans[i].tolist()] for i, f in enumerate(fams)}
+
+
+def bit_checksum(tensors):
+    """ order-independent checksum of the BIT patterns (int64 sum of the words + of the words weighted by position mod 65521) """
+    out = []
+    for t in tensors:
+        w = t.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+        pos = (torch.arange(w.numel(), device=w.device) % 65521) + 1
+        out += [int(w.sum().item()), int((w * pos).sum().item())]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,15 +490,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=256, help="cells per axis (BASELINE: 256)")
     ap.add_argument("--cg-iters", type=int, default=100)
-    ap.add_argument("--cpu-size", type=int, default=224, help="grid size of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-size", type=int, default=256, help="grid size of the CPU baseline sample and of the parity block (0 = skip); 256 = the metric's own configuration, ~30 s of NumPy")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "slab"],
                     help="config2 (default, the BASELINE metric): 256^3 Taylor-Green replicas, weak scaling. config4: 8 x 512^2 batched smoke, the batch "
-                         "sharded over the GPUs, strong scaling")
+                         "sharded over the GPUs, strong scaling. slab: ONE --size^3 simulation decomposed into x-slabs over the GPUs (SURVEY §8 f4)")
     ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
-    ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block (pressure solve only; 0 = skip)")
+    ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
+    ap.add_argument("--overlap", type=int, default=1, help="slab: 1 = ghost exchange on a side stream while the interior planes are advected")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 behind Python's back (RCCL prints a
@@ -379,6 +524,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     lib = C.load_default_library()
+    assert lib.built_from_tree(), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
     ctx = C.Context(lib, local_rank)
     if args.tuning:
         ctx.set_tuning(*[int(x) for x in args.tuning.split(",")])
@@ -395,7 +541,10 @@ def main():
 
     if args.workload == "config4":
         return bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce)
+    if args.workload == "slab":
+        return bench_slab(args, lib, device, rank, world, dist, barrier)
     sim = FluidStep(ctx, n, B, args.cg_iters, device)
+    pinned_plans = sync_launch_plans(ctx, sim, dist, rank, device) if dist is not None and world > 1 else None
 
     for _ in range(args.warmup):
         sim.step(allreduce)
@@ -413,19 +562,37 @@ def main():
     value = cells * world * args.steps / elapsed
 
     # ---- the timed steps must have run the iterations they claim (an entry that freezes -- diverged / residual 0 -- makes the remaining
-    # launches return at once and would overstate the throughput): one more step that reports ----
-    info = None
-    if rank == 0:
-        pv2 = [t.data_ptr() for t in sim.v2]
-        ctx.advect_staggered(sim.grid, [t.data_ptr() for t in sim.v], [t.data_ptr() for t in sim.v], pv2, sim.dt, sim.stream)
-        info = ctx.make_incompressible(sim.grid, pv2, None, 0, 1, True, sim.p.data_ptr(), sim.div.data_ptr(), sim.solve, want_info=True,
-                                       stream=sim.stream)
-        sim.v, sim.v2 = sim.v2, sim.v
-        assert all(i.iterations == args.cg_iters and not i.diverged for i in info), [(i.iterations, i.diverged, i.residual_sq) for i in info]
+    # launches return at once and would overstate the throughput): one more step that reports, ON EVERY RANK; with it the bit checksum of
+    # the rank's fields (replicas start from the same state and run the same launch plans: they must agree bit for bit) ----
+    pv2 = [t.data_ptr() for t in sim.v2]
+    ctx.advect_staggered(sim.grid, [t.data_ptr() for t in sim.v], [t.data_ptr() for t in sim.v], pv2, sim.dt, sim.stream)
+    info = ctx.make_incompressible(sim.grid, pv2, None, 0, 1, True, sim.p.data_ptr(), sim.div.data_ptr(), sim.solve, want_info=True, stream=sim.stream)
+    sim.v, sim.v2 = sim.v2, sim.v
+    its_local = [int(i.iterations) for i in info]
+    ok_local = all(i.iterations == args.cg_iters and not i.diverged for i in info)
+    replicas = None
+    iterations_all = [its_local]
+    if dist is not None and world > 1:
+        mine = torch.tensor(its_local + [int(ok_local)] + bit_checksum([sim.p] + sim.v), dtype=torch.int64, device=device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = [g.tolist() for g in gathered]
+        iterations_all = [r[:len(its_local)] for r in rows]
+        sums = [r[len(its_local) + 1:] for r in rows]
+        p_norm = torch.tensor([float(sim.p.double().norm())], dtype=torch.float64, device=device)
+        norms = [torch.zeros_like(p_norm) for _ in range(world)]
+        dist.all_gather(norms, p_norm)
+        replicas = {"bit_identical_to_rank0": [s_ == sums[0] for s_ in sums], "all_bit_identical": all(s_ == sums[0] for s_ in sums),
+                    "pressure_norm_rel_diff_vs_rank0": [abs(float(x) - float(norms[0])) / max(float(norms[0]), 1e-300) for x in norms],
+                    "verified_ok": [bool(r[len(its_local)]) for r in rows], "pinned_launch_plans": pinned_plans,
+                    "note": "every rank advanced the same initial state with the launch plans rank 0 tuned: checksums of the bit patterns of p and v"}
+        assert all(replicas["verified_ok"]), iterations_all
+    else:
+        assert ok_local, [(i.iterations, i.diverged, i.residual_sq) for i in info]
 
-    # ---- roofline of the dominant kernel: hipEvent pairs around every launch on the solve stream, extra profiled steps ----
-    roofline = None
+    # ---- benchmark configuration (256^3): hipEvent pairs around every launch on the solve stream, extra profiled steps ----
     extra = {}
+    roofline_bench = None
     if rank == 0 and args.profile_steps > 0:
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
@@ -435,43 +602,10 @@ def main():
         prof = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
         per = {k: (v[1] / v[0] if v[0] else None, v[0], v[1]) for k, v in prof.items()}
-        # dominant kernel = largest share of the step's GPU time among the distinct kernels (MATVEC / UPDATE_X2 / UPDATE_R are three
-        # template instantiations; at 256^3 MATVEC leads with ~40 %)
-        cg_kernels = {"cg_matvec_dot": "march_kernel<MODE_MATVEC> (d = r + beta d, sum d.Ad; 100 launches per step)",
-                      "cg_update": "march_kernel<MODE_UPDATE_X2> (x += two steps, r -= alpha A d, sum r^2)",
-                      "cg_update_r": "march_kernel<MODE_UPDATE_R> (r -= alpha A d, sum r^2)"}
-        dom_key = max(cg_kernels, key=lambda k: per[k][2])
-        t_dom = per[dom_key][0]
-        total_ms = sum(v[2] for v in per.values())
-        if t_dom:
-            moved = MOVED_BYTES_PER_CELL[dom_key] * cells
-            alg = ALG_BYTES_PER_CELL[dom_key] * cells
-            gbs = moved / (t_dom * 1e-3) / 1e9
-            traffic, source = None, None
-            if world == 1 and args.pmc:
-                traffic, source = live_pmc_traffic(n, dom_key)
-            if traffic is None:
-                traffic, source = _pmc_traffic(n, dom_key)
-            roofline = {"bound": "hbm", "kernel": cg_kernels[dom_key], "share_of_step_gpu_time": round(per[dom_key][2] / total_ms, 3),
-                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "traffic_source": source,
-                        "traffic_frac": round(traffic / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                        "avg_launch_ms": round(t_dom, 5), "launches": per[dom_key][1],
-                        "bytes_per_launch": moved, "bytes_basis": "bytes the kernel moves by construction (DESIGN.md 3.1): "
-                        f"{MOVED_BYTES_PER_CELL[dom_key] // 4} words x 4 B x {cells} cells; the PMC figure (`traffic`) cross-checks it",
-                        "algorithmic_bytes_per_launch": alg,
-                        "algorithmic_equiv_frac": round(alg / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "achievable_copy_GBs": 6290.0}
-        t_mv, t_x2, t_ur = per["cg_matvec_dot"][0], per["cg_update"][0], per["cg_update_r"][0]
-        if t_mv and (t_x2 or t_ur):
-            t_up = 0.5 * ((t_x2 or t_ur) + (t_ur or t_x2))          # the two update forms alternate
-            moved_it = MOVED_BYTES_PER_CELL["cg_iteration"] * cells
-            extra["roofline_cg_iteration"] = {"ms_matvec_dot": round(t_mv, 5), "ms_update_x2": round(t_x2, 5) if t_x2 else None,
-                                              "ms_update_r": round(t_ur, 5) if t_ur else None, "ms_iteration": round(t_mv + t_up, 5),
-                                              "moved_bytes": moved_it, "moved_GBs": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9, 1),
-                                              "moved_frac": round(moved_it / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                              "algorithmic_bytes": ALG_BYTES_PER_CELL["cg_iteration"] * cells,
-                                              "algorithmic_equiv_frac": round(ALG_BYTES_PER_CELL["cg_iteration"] * cells / ((t_mv + t_up) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        roofline_bench, it = roofline_block(n, per, False, world, cache_assisted=4 * 4 * n ** 3 <= 256 * 2 ** 20,
+                                            where="profiled steps of the timed benchmark configuration")
+        if it:
+            extra["roofline_cg_iteration_256" if n == 256 else f"roofline_cg_iteration_{n}"] = it
         extra["kernel_ms_per_launch"] = {k: (round(v[0], 5) if v[0] else None) for k, v in per.items()}
         extra["kernel_ms_per_step"] = {k: round(v[2] / args.profile_steps, 5) for k, v in per.items()}
         extra["plan"] = {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}
@@ -482,10 +616,26 @@ def main():
         extra["parity"] = parity_block(ctx, args.cpu_size, args.cg_iters, device, ref)
         del ref
         extra["cpu_cg_variants"] = cpu_cg_variants(96, 20)
-    if rank == 0 and world == 1 and args.config3_size > 0:
+
+    # ---- the HBM-resident configuration: 512^3 pressure solve (BASELINE configs[2]) -> `roofline` ----
+    roofline = None
+    if rank == 0 and args.config3_size > 0:
         del sim
         torch.cuda.empty_cache()
-        extra["config3"] = config3_block(ctx, device, args.config3_size, args.cg_iters)
+        c3 = config3_block(ctx, device, args.config3_size, args.cg_iters)
+        extra["config3"] = c3
+        per3 = {k: (c3["kernel_ms_per_launch"].get(k), c3["launches"].get(k, 0), (c3["kernel_ms_per_launch"].get(k) or 0.0) * c3["launches"].get(k, 0))
+                for k in C.K_NAMES}
+        roofline, it3 = roofline_block(args.config3_size, per3, bool(args.pmc), world, cache_assisted=False,
+                                       where=f"{args.config3_size}^3 fp32 pressure solve run inside this invocation (`config3`)")
+        if it3:
+            it3["ms_iteration_wall"] = c3["ms_per_iteration"]
+            it3["moved_frac_wall"] = c3["moved_frac"]
+            extra[f"roofline_cg_iteration_{args.config3_size}"] = it3
+    if roofline is None:
+        roofline = roofline_bench
+    elif roofline_bench is not None:
+        extra["roofline_256" if n == 256 else f"roofline_{n}"] = roofline_bench
 
     if rank == 0:
         out = {
@@ -496,12 +646,16 @@ def main():
                                    f"iterations/step (BASELINE.json configs[1])", "cells_per_gpu": cells, "batch_per_gpu": B,
                        "cg_iterations": args.cg_iters, "parallelism": f"batch-parallel replicas x{world}, 1 all-reduce(max residual)/step"},
             "final_relative_residual": float(rel.item()) if rel is not None else None,
-            "iterations_verified": [int(i.iterations) for i in info] if info else None,
+            "iterations_verified": iterations_all[0] if world == 1 else iterations_all,
+            "replicas": replicas, "build_id": lib.build_id(),
+            "scaling_measured": ("this line is ONE point of the curve (n_gpus above); the driver computes efficiency from the per-N lines -- no "
+                                 "multi-GPU curve has been measured by the builder (single-GPU boxes only)"),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         out.update(extra)
         emit_record(out)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
