@@ -521,6 +521,10 @@ def load_default_library() -> Library:
     """ loads phiflow_amd/lib/libphihip.so (built by ``__graft_entry__.build()``); raises `PhiHipLibraryError` if absent. """
     global _default_library
     if _default_library is None:
+        override = os.environ.get("PHIHIP_LIBRARY")          # A/B measurements of another BUILD of libphihip (tools/): never a fallback
+        if override:
+            _default_library = Library(override, strict=False)
+            return _default_library
         if not os.path.exists(DEFAULT_LIBRARY_PATH):
             raise PhiHipLibraryError(f"{DEFAULT_LIBRARY_PATH} does not exist. Build the HIP extension first "
                                      f"(`make -C phiflow_amd/csrc` or `__graft_entry__.build()`); phiflow_amd has no CPU fallback.")

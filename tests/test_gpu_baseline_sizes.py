@@ -46,6 +46,19 @@ def test_config5_cavity_fp64_obstacle_256_vs_oracle(ctx, mem):
     print("config5 parity:", rep)
 
 
+def test_config5_cavity_fp64_obstacle_384_vs_oracle(ctx, mem):
+    """ BASELINE configs[4] AT ITS OWN SIZE: 384^3 fp64 closed cavity + lid + solid box, 20 fixed iterations. Only this size selects its
+    launch plans -- (4,64) fp64 tiles with the 1.5-round rule, three 128-cell tiles per row, the 16-plane advection chunk, the vector
+    gradient kernel on rows of n - 1 faces -- so only this size pins them. The oracle needs ~3.5 min of NumPy and
+    ~18 GB of host memory at this size. """
+    rep = {}
+    bc.config5_cavity(ctx, mem, 384, 20, rep)
+    print("config5 parity at 384^3:", rep)
+    dom, grid = pc.make_case((384,) * 3, ((pc.CLO, pc.CLO),) * 3, np.float64)
+    for fam in (1, 2, 3):
+        print("  plan family", fam, ctx.query_plan(grid, True, fam))
+
+
 def test_config4_batched_smoke_8x512_vs_oracle(ctx, mem):
     """ BASELINE configs[3]: 8 x 512^2 batched smoke plumes, 3 steps, 60 fixed CG iterations per projection """
     rep = {}
