@@ -158,9 +158,13 @@ class SlabFluid:
     side (one packed message per neighbour and operation); the cut sides of the extended grid are declared OPEN, which only shapes results
     inside the ghost zone -- those are discarded. The reach of the operators bounds what is exact: divergence and gradient need one plane,
     the advection |u| dt / dx <= ghost - 1 cells along x (back-trace + multilinear taps + the 4-point means of the other components).
-    The pressure solve is `SlabSolver` on the owned cells. """
+    The pressure solve is `SlabSolver` on the owned cells. Obstacles (r3): `set_obstacles` -- masks rasterised per rank, ghost cells from
+    the owner, flags packed on the extended grid; `apply_boundary_conditions` runs on the extended velocity after the advection. """
 
-    def __init__(self, backend, res, lower, upper, bc, dtype=torch.float32, batch: int = 1, bc_val=None, ghost: int = 2, group=None):
+    def __init__(self, backend, res, lower, upper, bc, dtype=torch.float32, batch: int = 1, bc_val=None, ghost: int = 2, group=None,
+                 obstacles=None):
+        """ obstacles: list of obstacle descriptions as `_capi.make_obstacles` takes them (GLOBAL coordinates; Box / Sphere, linear and angular
+        velocity) -- phi/physics/fluid.py:130-137,212-240 on slabs: see `set_obstacles`. """
         assert len(res) == 3 and ghost >= 1
         self.be, self.group, self.dtype, self.batch, self.ghost = backend, group, dtype, int(batch), int(ghost)
         self.res, self.bc = tuple(int(r) for r in res), [tuple(int(c) for c in p) for p in bc]
@@ -201,6 +205,40 @@ class SlabFluid:
         assert self.hi_n[0] == (self.gr + 1 if self.hi_rank is not None else 0), (self.hi_n, self.gr)
         self.own_shape = [(batch, self.own_n[c]) + self.ext_shape[c][2:] for c in range(3)]
         self.cell_shape = (batch, self.end - self.begin, self.res[1], self.res[2])
+        self._own_lower0 = lower[0] + self.begin * dx
+        self._own_upper0 = lower[0] + self.end * dx
+        self._bounds = (tuple(lower), tuple(upper))
+        self._bc_val = bc_val
+        self.obstacles, self.n_obstacles, self.flags_ext, self.flags_own, self.active_count = None, 0, None, None, None
+        if obstacles:
+            self.set_obstacles(obstacles)
+
+    # --- obstacles (fluid.py:130-137: accessible = ~union(geometries), hard_bcs = stagger(accessible, min), active = accessible) ---
+    def set_obstacles(self, items):
+        """ Rasterises the obstacles on this rank's OWN cells (`phihip_obstacle_accessible` on the slab's box), obtains the neighbours' mask
+        for the ghost cells by the same packed exchange as every other cell field -- a ghost cell of a periodic axis lies outside the
+        domain box, its geometry test would be wrong, its owner's is not --, and packs the stencil flags on the extended grid
+        (`phihip_build_cellflags`): bits of own cells see the true accessibility of cells across the cut. The solver takes the own-cell
+        crop, divergence / gradient the extended array. Call again when obstacles move. """
+        be, ctx = self.be, self.be.ctx
+        self.obstacles, self.n_obstacles = _capi.make_obstacles(items), len(items)
+        lower, upper = self._bounds
+        code = _capi.PHIHIP_F64 if self.dtype == torch.float64 else _capi.PHIHIP_F32
+        own_grid = _capi.make_grid(3, code, 1, (self.end - self.begin, self.res[1], self.res[2]), (self._own_lower0, lower[1], lower[2]),
+                                   (self._own_upper0, upper[1], upper[2]), self.bc, self._bc_val)
+        acc_own = be.empty((self.end - self.begin, self.res[1], self.res[2]), torch.uint8)
+        ctx.obstacle_accessible(own_grid, self.obstacles, self.n_obstacles, acc_own.data_ptr(), be.stream())
+        acc_f = acc_own.to(self.dtype).unsqueeze(0).expand(self.batch, *acc_own.shape).contiguous()
+        acc_ext = (self._extend_cells(acc_f)[0] > 0.5).to(torch.uint8).contiguous()
+        ext_grid1 = _capi.make_grid(3, code, 1, (self.ext_cells, self.res[1], self.res[2]), tuple(self.grid.lower[d] for d in range(3)),
+                                    tuple(self.grid.upper[d] for d in range(3)), [tuple(self.grid.bc[d][s] for s in range(2)) for d in range(3)])
+        self.flags_ext = be.empty((self.ext_cells, self.res[1], self.res[2]), torch.uint8)
+        ctx.build_cellflags(ext_grid1, acc_ext.data_ptr(), 0, 1, self.flags_ext.data_ptr(), be.stream())
+        self.flags_own = self.flags_ext[self.gl: self.gl + (self.end - self.begin)].contiguous()
+        count = acc_own.sum(dtype=torch.float64).reshape(1)
+        if self.world > 1:
+            dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group)
+        self.active_count = count            # active cells of the WHOLE domain (for _balance_divergence)
 
     # --- ghost exchange: one packed message per neighbour ---
     def _pack(self, parts: List[torch.Tensor]) -> torch.Tensor:
@@ -276,23 +314,31 @@ class SlabFluid:
         out = [torch.empty_like(t) for t in ext]
         P = lambda ts: [t.data_ptr() for t in ts]
         self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
+        if self.n_obstacles:     # fluid.apply_boundary_conditions (fluid.py:212-240): pointwise in physical coordinates, own samples are exact
+            self.be.ctx.apply_obstacles(self.grid, self.obstacles, self.n_obstacles, P(out), self.be.stream())
         return self._own_velocity(out)
 
     def divergence(self, v: List[torch.Tensor], balance: bool = False) -> torch.Tensor:
         ext = self._extend_velocity(v)
         div = self.be.empty((self.batch, self.ext_cells, self.res[1], self.res[2]), self.dtype)
-        self.be.ctx.divergence(self.grid, [t.data_ptr() for t in ext], 0, 1, False, div.data_ptr(), self.be.stream())
+        fl = self.flags_ext.data_ptr() if self.flags_ext is not None else 0          # div * active (fluid.py:139-140)
+        self.be.ctx.divergence(self.grid, [t.data_ptr() for t in ext], fl, 1, False, div.data_ptr(), self.be.stream())
         own = div[:, self.gl: self.gl + (self.end - self.begin)].contiguous()
-        if balance:    # fluid._balance_divergence (fluid.py:205-209) over the WHOLE domain
+        if balance:    # fluid._balance_divergence (fluid.py:205-209) over the WHOLE domain: div -= active * sum(div) / sum(active)
             total = own.sum(dim=(1, 2, 3), dtype=torch.float64)
             if self.world > 1:
                 dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
-            own -= (total / (self.res[0] * self.res[1] * self.res[2])).to(self.dtype)[:, None, None, None]
+            if self.flags_own is None:
+                own -= (total / (self.res[0] * self.res[1] * self.res[2])).to(self.dtype)[:, None, None, None]
+            else:
+                active = ((self.flags_own & 64) != 0).to(self.dtype)
+                own -= active[None] * (total / self.active_count).to(self.dtype)[:, None, None, None]
         return own
 
     def grad_subtract(self, v: List[torch.Tensor], p: torch.Tensor) -> List[torch.Tensor]:
         ext_v, ext_p = self._extend_velocity(v), self._extend_cells(p)
-        self.be.ctx.grad_subtract(self.grid, 0, 1, ext_p.data_ptr(), [t.data_ptr() for t in ext_v], self.be.stream())
+        fl = self.flags_ext.data_ptr() if self.flags_ext is not None else 0          # grad p * hard_bcs (fluid.py:158-160)
+        self.be.ctx.grad_subtract(self.grid, fl, 1, ext_p.data_ptr(), [t.data_ptr() for t in ext_v], self.be.stream())
         return self._own_velocity(ext_v)
 
     def step(self, v: List[torch.Tensor], p: torch.Tensor, dt: float, rel_tol=1e-5, abs_tol=0.0, max_iterations=1000, refresh_every=50,
@@ -302,5 +348,5 @@ class SlabFluid:
         v = self.advect(v, dt, check_cfl)
         singular = all(c != _capi.BC_OPEN for pair in self.bc for c in pair)
         div = self.divergence(v, balance=singular)
-        infos = self.solver.solve(div, p, rel_tol, abs_tol, max_iterations, refresh_every, check_every)
+        infos = self.solver.solve(div, p, rel_tol, abs_tol, max_iterations, refresh_every, check_every, flags=self.flags_own)
         return self.grad_subtract(v, p), infos

@@ -245,3 +245,79 @@ def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, 
     assert np.abs(pr - pm).max() <= 5e-4 * np.abs(pm).max(), np.abs(pr - pm).max() / np.abs(pm).max()
     for c in range(3):
         assert np.abs(cat(f"out{c}") - out[c]).max() <= 2e-4, (c, np.abs(cat(f"out{c}") - out[c]).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY §8 f4 with obstacles (fluid.py:130-137,212-240 on slabs): masks rasterised per rank, ghost-cell masks from the owner, flags on the
+# extended grid, apply_boundary_conditions after the advection, balance over the active cells of the WHOLE domain
+# ---------------------------------------------------------------------------------------------------------------------
+def _slab_obstacles(res):
+    from phiflow_amd import _capi as C
+    # a box that straddles every cut of a 2- and 3-rank split and touches neither wall; a moving, rotating sphere near the lower x end
+    return [dict(kind=C.OBSTACLE_BOX, center=(0.5 * res[0] + 0.3, 0.5 * res[1], 0.45 * res[2]), half_size=(2.2, 1.6, 3.1)),
+            dict(kind=C.OBSTACLE_SPHERE, center=(2.4, 0.4 * res[1], 0.7 * res[2]), half_size=(1.3, 0, 0), velocity=(0.2, -0.1, 0.0),
+                 angular_velocity=(0.0, 0.0, 0.3))]
+
+
+def _obstacle_worker(rank, world, port, emu_path, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PHIHIP_AUTOTUNE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phiflow_amd import _capi
+    from phiflow_amd.backend import HipBackend
+    from phiflow_amd.slab import SlabFluid
+    backend = HipBackend(library=_capi.Library(emu_path), device="cpu")
+    res, bc, grid, rng = _fluid_problem(case)
+    v = _smooth_velocity(backend.ctx, grid, rng, grid.batch)
+    fluid = SlabFluid(backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=grid.batch, obstacles=_slab_obstacles(res))
+    off = 0 if bc[0][0] != _capi.BC_CLOSED else 1
+    own = [torch.from_numpy(np.ascontiguousarray(v[0][:, fluid.face_begin - off: fluid.face_end - off])),
+           torch.from_numpy(np.ascontiguousarray(v[1][:, fluid.begin: fluid.end])), torch.from_numpy(np.ascontiguousarray(v[2][:, fluid.begin: fluid.end]))]
+    p = torch.zeros(fluid.cell_shape, dtype=torch.float32)
+    out, infos = fluid.step(own, p, 0.9, rel_tol=1e-5, max_iterations=300)
+    np.savez(os.path.join(out_dir, f"obst{rank}.npz"), b0=fluid.begin, b1=fluid.end, flags=fluid.flags_own.numpy(), p=p.numpy(),
+             out0=out[0].numpy(), out1=out[1].numpy(), out2=out[2].numpy(), it=[i.iterations for i in infos], conv=[i.converged for i in infos])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("closed_open", 2), ("periodic", 2), ("closed_open", 3)])
+def test_slab_decomposed_step_with_obstacles_gloo(emu_library, emu_ctx, tmp_path, case, world):
+    from phiflow_amd import _capi as C
+    mp.spawn(_obstacle_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
+    res, bc, grid, rng = _fluid_problem(case)
+    v = _smooth_velocity(emu_ctx, grid, rng, grid.batch)
+    singular = all(c != 2 for pair in bc for c in pair)
+    # single-process reference: the same C ABI calls on the whole grid
+    items = _slab_obstacles(res)
+    obs = C.make_obstacles(items)
+    g1 = C.make_grid(3, C.PHIHIP_F32, 1, res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    acc, flags = np.empty(res, np.uint8), np.empty(res, np.uint8)
+    emu_ctx.obstacle_accessible(g1, obs, len(items), acc.ctypes.data)
+    emu_ctx.build_cellflags(g1, acc.ctypes.data, 0, 1, flags.ctypes.data)
+    P = lambda ts: [t.ctypes.data for t in ts]
+    adv = [np.empty_like(t) for t in v]
+    emu_ctx.advect_staggered(grid, P(v), P(v), P(adv), 0.9)
+    emu_ctx.apply_obstacles(grid, obs, len(items), P(adv))
+    div = np.empty((grid.batch,) + tuple(res), np.float32)
+    emu_ctx.divergence(grid, P(adv), flags.ctypes.data, 1, singular, div.ctypes.data)
+    p = np.zeros_like(div)
+    info = emu_ctx.cg_solve(grid, flags.ctypes.data, 1, div.ctypes.data, p.ctypes.data, C.Solve(1e-5, 0.0, 300, 50, 10, 0))
+    out = [t.copy() for t in adv]
+    emu_ctx.grad_subtract(grid, flags.ctypes.data, 1, p.ctypes.data, P(out))
+    parts = [np.load(tmp_path / f"obst{r}.npz") for r in range(world)]
+    assert 0 < int((acc == 0).sum()) < acc.size
+    assert np.array_equal(np.concatenate([q["flags"] for q in parts], axis=0), flags)          # bit for bit: ghost masks came from their owners
+    assert all(bool(c) for q in parts for c in q["conv"]) and all(i.converged for i in info)
+    assert all(abs(int(a) - i.iterations) <= 2 for a, i in zip(parts[0]["it"], info))
+    cat = lambda key: np.concatenate([q[key] for q in parts], axis=1)
+    act = (flags & 64) != 0
+    pr, pm = cat("p"), p
+    if singular:                                        # the free constant lives on the active cells
+        pr = pr - (pr * act).sum(axis=(1, 2, 3), keepdims=True) / act.sum() * act
+        pm = pm - (pm * act).sum(axis=(1, 2, 3), keepdims=True) / act.sum() * act
+    assert np.abs(pr - pm).max() <= 1e-3 * np.abs(pm).max(), np.abs(pr - pm).max() / np.abs(pm).max()
+    for c in range(3):
+        assert cat(f"out{c}").shape == out[c].shape
+        assert np.abs(cat(f"out{c}") - out[c]).max() <= 3e-4, (c, np.abs(cat(f"out{c}") - out[c]).max())
