@@ -681,15 +681,49 @@ __device__ __forceinline__ double obstacle_sdf(const ObstacleSet& s, int k, cons
     return dist;
 }
 
+// Can obstacle k reach the axis-aligned box [lo, hi] grown by `margin`? (bounding box of the geometry: half extents, the bounding radius
+// for a rotated box, unbounded along embedded axes.) Uniform per patch: whole workgroups skip obstacles that are nowhere near.
+__device__ __forceinline__ bool obstacle_near(const ObstacleSet& s, int k, const double (&lo)[3], const double (&hi)[3], double margin, int ax0) {
+    double rad = 0;
+    if (s.rotated[k]) {
+        for (int a = ax0; a < 3; ++a) rad += s.half[k][a] * s.half[k][a];
+        rad = sqrt(rad);
+    }
+    for (int a = ax0; a < 3; ++a) {
+        if ((s.skip[k] >> a) & 1) continue;
+        const double h = s.rotated[k] ? rad : (s.kind[k] == PHIHIP_OBSTACLE_SPHERE ? s.half[k][ax0] : s.half[k][a]);
+        if (lo[a] - margin > s.center[k][a] + h || hi[a] + margin < s.center[k][a] - h) return false;
+    }
+    return true;
+}
+
+// r3: (4 x 64)-cell patches decoded without integer division (the 64-bit div / mod per cell and the fp64 geometry of EVERY obstacle for
+// EVERY cell made the obstacle kernels run at 1-8 % of the HBM rate); a patch evaluates only the obstacles whose bounding box it touches.
 __global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s,
-                                                                     int first_launch, uint8_t* accessible) {
+                                                                     int first_launch, uint8_t* accessible, int patches1, int patches2) {
     const double lower[3] = {lower0, lower1, lower2};
-    for (long long cell = (long long)blockIdx.x * kBlock + threadIdx.x; cell < g.cells; cell += (long long)gridDim.x * kBlock) {
-        const int idx[3] = {(int)(cell / ((long long)g.n[2] * g.n[1])), (int)((cell / g.n[2]) % g.n[1]), (int)(cell % g.n[2])};
-        double x[3] = {0, 0, 0};
-        for (int a = g.ax0; a < 3; ++a) x[a] = lower[a] + (idx[a] + 0.5) * g.dx[a];
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = g.n[0] * patches1 * patches2;
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int i0, r0, c0;
+        decode_patch(patch, patches1, patches2, i0, r0, c0);
+        const int first[3] = {i0, r0, c0};
+        const int last[3] = {i0, min(r0 + kPatchRows, g.n[1]) - 1, min(c0 + kPatchCols, g.n[2]) - 1};
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int a = g.ax0; a < 3; ++a) { lo[a] = lower[a] + (first[a] + 0.5) * g.dx[a]; hi[a] = lower[a] + (last[a] + 0.5) * g.dx[a]; }
+        unsigned near = 0;
+        for (int k = 0; k < s.count; ++k) near |= obstacle_near(s, k, lo, hi, 1e-9 * (hi[2] - lo[2] + g.dx[2]), g.ax0) ? (1u << k) : 0u;
+        const int idx[3] = {i0, r0 + ty, c0 + tx};
+        if (idx[1] >= g.n[1] || idx[2] >= g.n[2]) continue;
+        if (!near && !first_launch) continue;            // nothing to change in this patch
+        const long long cell = ((long long)i0 * g.n[1] + idx[1]) * g.n[2] + idx[2];
         bool inside = false;
-        for (int k = 0; k < s.count; ++k) inside = inside || obstacle_inside(s, k, x, g.ax0);
+        if (near) {
+            double x[3] = {0, 0, 0};
+            for (int a = g.ax0; a < 3; ++a) x[a] = lower[a] + (idx[a] + 0.5) * g.dx[a];
+            for (int k = 0; k < s.count; ++k)
+                if ((near >> k) & 1u) inside = inside || obstacle_inside(s, k, x, g.ax0);
+        }
         const uint8_t prev = first_launch ? (uint8_t)1 : accessible[cell];
         accessible[cell] = inside ? (uint8_t)0 : prev;
     }
@@ -697,14 +731,17 @@ __global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, 
 
 int run_obstacle_accessible(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, uint8_t* accessible, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
-    const int nblk = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    const int patches1 = ceil_div(v.n[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols);
+    const long long npatch = (long long)v.n[0] * patches1 * patches2;
+    PHIHIP_REQUIRE(npatch < (1LL << 31), "obstacle_accessible: grid too large");
+    const int nblk = npatch < 16384 ? (int)npatch : 16384;
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     int first = 0;
     do {
         const int n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
         const ObstacleSet set = make_obstacle_set(v, obs, first, n);
         hipLaunchKernelGGL(obstacle_accessible_kernel, dim3(nblk), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set,
-                           first == 0 ? 1 : 0, accessible);
+                           first == 0 ? 1 : 0, accessible, patches1, patches2);
         first += n;
     } while (first < count);
     PHIHIP_CHECK_HIP(hipGetLastError());
@@ -713,24 +750,43 @@ int run_obstacle_accessible(phihip_ctx* ctx, const GridView& v, const phihip_obs
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s, int ca,
-                                                                 T* __restrict__ vc) {
+                                                                 T* __restrict__ vc, int patches1, int patches2) {
     const double lower[3] = {lower0, lower1, lower2};
     const int b = blockIdx.y;
     const long long total = g.ccells[ca];
-    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const int c0n = g.cn[ca][0], c1 = g.cn[ca][1], c2 = g.cn[ca][2];
     double r2 = 0;   // bounding radius of a face cell: |half size of a grid cell|
     for (int a = g.ax0; a < 3; ++a) r2 += 0.25 * g.dx[a] * g.dx[a];
     const double radius = sqrt(r2);
     T* __restrict__ V = vc + (long long)b * total;
-    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
-        const int idx[3] = {(int)(f / ((long long)c2 * c1)), (int)((f / c2) % c1), (int)(f % c2)};
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = c0n * patches1 * patches2;
+    // position of sample i along axis a: faces of the component's own axis, cell centres otherwise
+    auto pos = [&](int a, int i) -> double { return a == ca ? lower[a] + (double)(i + g.off[a]) * g.dx[a] : lower[a] + (i + 0.5) * g.dx[a]; };
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int i0, r0, cc0;
+        decode_patch(patch, patches1, patches2, i0, r0, cc0);
+        const int first[3] = {i0, r0, cc0};
+        const int last[3] = {i0, min(r0 + kPatchRows, c1) - 1, min(cc0 + kPatchCols, c2) - 1};
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int a = g.ax0; a < 3; ++a) { lo[a] = pos(a, first[a]); hi[a] = pos(a, last[a]); }
+        // the soft mask m = clip(1 - sdf / radius, 0, 1) vanishes farther than `radius` from the surface: such patches are left untouched
+        unsigned near = 0;
+        for (int k = 0; k < s.count; ++k) near |= obstacle_near(s, k, lo, hi, radius * 1.000001, g.ax0) ? (1u << k) : 0u;
+        if (!near) continue;
+        const int idx[3] = {i0, r0 + ty, cc0 + tx};
+        if (idx[1] >= c1 || idx[2] >= c2) continue;
+        const long long f = ((long long)i0 * c1 + idx[1]) * c2 + idx[2];
         double x[3] = {0, 0, 0};
-        for (int a = g.ax0; a < 3; ++a) x[a] = a == ca ? lower[a] + (double)(idx[a] + g.off[a]) * g.dx[a] : lower[a] + (idx[a] + 0.5) * g.dx[a];
+        for (int a = g.ax0; a < 3; ++a) x[a] = pos(a, idx[a]);
         T val = V[f];
         double m_union = 0.0;
         for (int k = 0; k < s.count; ++k) {
-            double m = 1.0 - obstacle_sdf(s, k, x, g.ax0) / radius;
-            m = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+            double m = 0.0;
+            if ((near >> k) & 1u) {
+                m = 1.0 - obstacle_sdf(s, k, x, g.ax0) / radius;
+                m = m < 0.0 ? 0.0 : (m > 1.0 ? 1.0 : m);
+            }
             if (s.group[k] != 0) {   // union: sdf = min over the members <=> mask = max; applied once, after the last member
                 const bool cont = k > 0 && s.group[k - 1] == s.group[k];
                 m_union = cont && m_union > m ? m_union : m;
@@ -769,13 +825,16 @@ int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacl
         }
         const ObstacleSet set = make_obstacle_set(v, obs, first, n);
         for (int ca = v.ax0; ca < 3; ++ca) {
-            const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
+            const int patches1 = ceil_div(v.cn[ca][1], kPatchRows), patches2 = ceil_div(v.cn[ca][2], kPatchCols);
+            const long long npatch = (long long)v.cn[ca][0] * patches1 * patches2;
+            PHIHIP_REQUIRE(npatch < (1LL << 31), "apply_obstacles: grid too large");
+            const int nblk = npatch < 16384 ? (int)npatch : 16384;
             if (v.dtype == PHIHIP_F64)
                 hipLaunchKernelGGL(apply_obstacles_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
-                                   v.lower[2], set, ca, (double*)vel[ca]);
+                                   v.lower[2], set, ca, (double*)vel[ca], patches1, patches2);
             else
                 hipLaunchKernelGGL(apply_obstacles_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
-                                   v.lower[2], set, ca, (float*)vel[ca]);
+                                   v.lower[2], set, ca, (float*)vel[ca], patches1, patches2);
         }
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
@@ -786,35 +845,35 @@ int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacl
 // obstacle flags (fluid.py:130-137: accessible, hard_bcs = stagger(accessible, minimum), active)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void cellflags_kernel(VelGrid g, const uint8_t* accessible, const uint8_t* active, int per_batch,
-                                                           uint8_t* flags) {
+                                                           uint8_t* flags, int patches1, int patches2) {
     const int b = blockIdx.y;
     const long long mb = per_batch ? (long long)b * g.cells : 0;
-    for (long long cell = (long long)blockIdx.x * kBlock + threadIdx.x; cell < g.cells; cell += (long long)gridDim.x * kBlock) {
-        const int i2 = (int)(cell % g.n[2]);
-        const int i1 = (int)((cell / g.n[2]) % g.n[1]);
-        const int i0 = (int)(cell / ((long long)g.n[2] * g.n[1]));
-        const int idx[3] = {i0, i1, i2};
-        const unsigned self = accessible ? (accessible[mb + cell] ? 1u : 0u) : 1u;
+    const uint8_t* __restrict__ A = accessible ? accessible + mb : nullptr;
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = g.n[0] * patches1 * patches2;
+    const int stride[3] = {g.n[1] * g.n[2], g.n[2], 1};
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3], r0, c0;
+        decode_patch(patch, patches1, patches2, idx[0], r0, c0);
+        idx[1] = r0 + ty;
+        idx[2] = c0 + tx;
+        if (idx[1] >= g.n[1] || idx[2] >= g.n[2]) continue;
+        const int cell = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2];
+        const unsigned self = A ? (A[cell] ? 1u : 0u) : 1u;
         unsigned f = 0;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             if (ax < g.ax0) continue;
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
-                int nbv[3] = {i0, i1, i2};
-                int j = idx[ax] + (side ? 1 : -1);
+                const int j = idx[ax] + (side ? 1 : -1);
                 unsigned other;
                 if (j < 0 || j >= g.n[ax]) {
                     const int code = g.bc[ax][side];
-                    if (code == PHIHIP_BC_PERIODIC) {
-                        nbv[ax] = j < 0 ? j + g.n[ax] : j - g.n[ax];
-                        other = accessible ? (accessible[mb + ((long long)nbv[0] * g.n[1] + nbv[1]) * g.n[2] + nbv[2]] ? 1u : 0u) : 1u;
-                    } else {
-                        other = code == PHIHIP_BC_OPEN ? 1u : 0u;   // _accessible_extrapolation: BOUNDARY -> ONE, constant -> ZERO
-                    }
+                    if (code == PHIHIP_BC_PERIODIC) other = A ? (A[cell + (j < 0 ? g.n[ax] - 1 : 1 - g.n[ax]) * stride[ax]] ? 1u : 0u) : 1u;
+                    else other = code == PHIHIP_BC_OPEN ? 1u : 0u;   // _accessible_extrapolation: BOUNDARY -> ONE, constant -> ZERO
                 } else {
-                    nbv[ax] = j;
-                    other = accessible ? (accessible[mb + ((long long)nbv[0] * g.n[1] + nbv[1]) * g.n[2] + nbv[2]] ? 1u : 0u) : 1u;
+                    other = A ? (A[cell + (side ? stride[ax] : -stride[ax])] ? 1u : 0u) : 1u;
                 }
                 if (self & other) f |= 1u << (2 * ax + side);
             }
@@ -828,10 +887,13 @@ __global__ __launch_bounds__(kBlock) void cellflags_kernel(VelGrid g, const uint
 int run_build_cellflags(phihip_ctx* ctx, const GridView& v, const uint8_t* accessible, const uint8_t* active, int mask_batch,
                         uint8_t* flags, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
-    const int nblk = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    PHIHIP_REQUIRE(v.cells < (1LL << 31), "build_cellflags: more than 2^31 cells per batch entry are not supported");
+    const int patches1 = ceil_div(v.n[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols);
+    const long long npatch = (long long)v.n[0] * patches1 * patches2;
+    const int nblk = npatch < 16384 ? (int)npatch : 16384;
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     hipLaunchKernelGGL(cellflags_kernel, dim3(nblk, mask_batch > 1 ? mask_batch : 1), dim3(kBlock), 0, s, g, accessible, active,
-                       mask_batch > 1 ? 1 : 0, flags);
+                       mask_batch > 1 ? 1 : 0, flags, patches1, patches2);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
@@ -839,95 +901,79 @@ int run_build_cellflags(phihip_ctx* ctx, const GridView& v, const uint8_t* acces
 // ---------------------------------------------------------------------------------------------------------------------
 // diffuse.explicit, order 2: v_d += k dt * laplace(v_d) with the velocity's own padding (phi/physics/diffuse.py:13-60)
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void diffuse_kernel(VelGrid g, int ca, const T* vin, T* vout, T kdt) {
+// One thread per sample of one component, (4 rows x 64 columns) patches decoded without integer division (r3: the per-thread 64-bit
+// div / mod and the generic boundary walk of every tap made this 2-word streaming kernel run at 10 % of the HBM rate). Interior samples
+// read their six neighbours directly; samples on the boundary resolve each tap with the extrapolation: periodic wrap, OPEN = the edge
+// sample itself (zero gradient), CLOSED = the constant wall value.
+// ADJ: the adjoint (I + k dt L)^T as a GATHER (no atomics): the stencil is symmetric in the interior; a clamped tap returns its weight to
+// the edge sample itself, a constant tap contributes nothing, a wrapped tap is the wrapped neighbour.  gin += (...)^T gout.
+template <typename T, bool ADJ>
+__global__ __launch_bounds__(kBlock) void diffuse_kernel(VelGrid g, int ca, const T* __restrict__ vin, T* __restrict__ vout, T kdt, int patches1, int patches2) {
     const int b = blockIdx.y;
-    const long long total = g.ccells[ca];
-    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
-    const long long bb = (long long)b * total;
-    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
-        const int i2 = (int)(f % c2);
-        const int i1 = (int)((f / c2) % c1);
-        const int i0 = (int)(f / ((long long)c2 * c1));
-        const T c = vin[bb + f];
-        T lap = T(0);
+    const int c0n = g.cn[ca][0], c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+    const long long bb = (long long)b * g.ccells[ca];
+    const T* __restrict__ I = vin + bb;
+    T* __restrict__ O = vout + bb;
+    const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
+    const int npatch = c0n * patches1 * patches2;
+    T w[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) w[ax] = ax < g.ax0 ? T(0) : kdt / (T)(g.dx[ax] * g.dx[ax]);
+    const int stride[3] = {c1 * c2, c2, 1};
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3], r0, cc0;
+        decode_patch(patch, patches1, patches2, idx[0], r0, cc0);
+        idx[1] = r0 + ty;
+        idx[2] = cc0 + tx;
+        if (idx[1] >= c1 || idx[2] >= c2) continue;
+        const int f = (idx[0] * c1 + idx[1]) * c2 + idx[2];
+        const T c = I[f];
+        T acc = T(0);          // forward: sum_ax w (lo + hi - 2 c); adjoint: sum of the weighted neighbour gradients
+        T centre = T(1);       // adjoint: coefficient of gout[f] itself
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             if (ax < g.ax0) continue;
-            int lo[3] = {i0, i1, i2}, hi[3] = {i0, i1, i2};
-            lo[ax] -= 1; hi[ax] += 1;
-            const T vl = fetch_comp<T>(vin, g, ca, bb, lo[0], lo[1], lo[2]);
-            const T vh = fetch_comp<T>(vin, g, ca, bb, hi[0], hi[1], hi[2]);
-            lap += (vl + vh - T(2) * c) / (T)(g.dx[ax] * g.dx[ax]);
+            const int n = g.cn[ca][ax], i = idx[ax];
+            T lo, hi;
+            if (i > 0) lo = I[f - stride[ax]];
+            else {
+                const int code = g.bc[ax][0];
+                if (code == PHIHIP_BC_PERIODIC) lo = I[f + (n - 1) * stride[ax]];
+                else if (code == PHIHIP_BC_OPEN) lo = ADJ ? T(0) : c;
+                else lo = ADJ ? T(0) : (T)g.bcv[ax][0][ca];
+                if (ADJ && code == PHIHIP_BC_OPEN) centre += w[ax];           // the clamped tap of this sample read the sample itself
+            }
+            if (i < n - 1) hi = I[f + stride[ax]];
+            else {
+                const int code = g.bc[ax][1];
+                if (code == PHIHIP_BC_PERIODIC) hi = I[f - (n - 1) * stride[ax]];
+                else if (code == PHIHIP_BC_OPEN) hi = ADJ ? T(0) : c;
+                else hi = ADJ ? T(0) : (T)g.bcv[ax][1][ca];
+                if (ADJ && code == PHIHIP_BC_OPEN) centre += w[ax];
+            }
+            if (ADJ) { acc += w[ax] * (lo + hi); centre -= T(2) * w[ax]; }
+            else acc += w[ax] * ((lo - c) + (hi - c));
         }
-        vout[bb + f] = c + kdt * lap;
+        if (ADJ) O[f] += centre * c + acc;
+        else O[f] = c + acc;
     }
 }
 
-// offset of the sample fetch_comp would read, or -1 when the extrapolation supplies a constant there
-__device__ __forceinline__ long long fetch_comp_offset(const VelGrid& g, int ca, int i0, int i1, int i2) {
-    int idx[3] = {i0, i1, i2};
-#pragma unroll
-    for (int ax = 2; ax >= 0; --ax) {
-        if (ax < g.ax0) { idx[ax] = 0; continue; }
-        const int n = g.cn[ca][ax];
-        int i = idx[ax];
-        if (i < 0) {
-            const int code = g.bc[ax][0];
-            if (code == PHIHIP_BC_PERIODIC) { i %= n; if (i < 0) i += n; }
-            else if (code == PHIHIP_BC_CLOSED) return -1;
-            else i = 0;
-        } else if (i >= n) {
-            const int code = g.bc[ax][1];
-            if (code == PHIHIP_BC_PERIODIC) i %= n;
-            else if (code == PHIHIP_BC_CLOSED) return -1;
-            else i = n - 1;
-        }
-        idx[ax] = i;
-    }
-    return ((long long)idx[0] * g.cn[ca][1] + idx[1]) * g.cn[ca][2] + idx[2];
-}
-
-// adjoint of diffuse_kernel: gin += (I + k dt L)^T gout   (scatter; clamped / wrapped taps add to their source sample)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void diffuse_bwd_kernel(VelGrid g, int ca, const T* __restrict__ gout, T* __restrict__ gin, T kdt) {
-    const int b = blockIdx.y;
-    const long long total = g.ccells[ca];
-    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
-    const long long bb = (long long)b * total;
-    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
-        const int i2 = (int)(f % c2);
-        const int i1 = (int)((f / c2) % c1);
-        const int i0 = (int)(f / ((long long)c2 * c1));
-        const T go = gout[bb + f];
-        T centre = T(1);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            if (ax < g.ax0) continue;
-            const T w = kdt / (T)(g.dx[ax] * g.dx[ax]);
-            centre -= T(2) * w;
-            int lo[3] = {i0, i1, i2}, hi[3] = {i0, i1, i2};
-            lo[ax] -= 1; hi[ax] += 1;
-            const long long ol = fetch_comp_offset(g, ca, lo[0], lo[1], lo[2]);
-            const long long oh = fetch_comp_offset(g, ca, hi[0], hi[1], hi[2]);
-            if (ol >= 0) atomicAdd(gin + bb + ol, go * w);
-            if (oh >= 0) atomicAdd(gin + bb + oh, go * w);
-        }
-        atomicAdd(gin + bb + f, go * centre);
-    }
+template <typename T, bool ADJ>
+static void launch_diffuse(const VelGrid& g, int ca, int batch, const void* in, void* out, double kdt, hipStream_t s) {
+    const int patches1 = ceil_div(g.cn[ca][1], kPatchRows), patches2 = ceil_div(g.cn[ca][2], kPatchCols);
+    const long long npatch = (long long)g.cn[ca][0] * patches1 * patches2;
+    const int nblk = npatch < 16384 ? (int)npatch : 16384;
+    hipLaunchKernelGGL((diffuse_kernel<T, ADJ>), dim3(nblk, batch), dim3(kBlock), 0, s, g, ca, (const T*)in, (T*)out, (T)kdt, patches1, patches2);
 }
 
 int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     for (int ca = v.ax0; ca < 3; ++ca) {
-        const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
-        if (v.dtype == PHIHIP_F64)
-            hipLaunchKernelGGL(diffuse_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const double*)vin[ca],
-                               (double*)vout[ca], kdt);
-        else
-            hipLaunchKernelGGL(diffuse_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const float*)vin[ca],
-                               (float*)vout[ca], (float)kdt);
+        if (v.ccells[ca] >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
+        if (v.dtype == PHIHIP_F64) launch_diffuse<double, false>(g, ca, v.batch, vin[ca], vout[ca], kdt, s);
+        else launch_diffuse<float, false>(g, ca, v.batch, vin[ca], vout[ca], kdt, s);
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
@@ -937,11 +983,9 @@ int run_diffuse_bwd(phihip_ctx* ctx, const GridView& v, const void* const gout[3
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     for (int ca = v.ax0; ca < 3; ++ca) {
-        const int nblk = ceil_div(v.ccells[ca], kBlock) < 8192 ? ceil_div(v.ccells[ca], kBlock) : 8192;
-        if (v.dtype == PHIHIP_F64)
-            hipLaunchKernelGGL(diffuse_bwd_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const double*)gout[ca], (double*)gin[ca], kdt);
-        else
-            hipLaunchKernelGGL(diffuse_bwd_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ca, (const float*)gout[ca], (float*)gin[ca], (float)kdt);
+        if (v.ccells[ca] >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
+        if (v.dtype == PHIHIP_F64) launch_diffuse<double, true>(g, ca, v.batch, gout[ca], gin[ca], kdt, s);
+        else launch_diffuse<float, true>(g, ca, v.batch, gout[ca], gin[ca], kdt, s);
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
@@ -968,13 +1012,13 @@ int run_diffuse_centered(phihip_ctx* ctx, const GridView& v, const void* sfield,
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     const VelGrid g = scalar_as_component(v, sb);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    const int nblk = ceil_div(v.cells, kBlock) < 8192 ? ceil_div(v.cells, kBlock) : 8192;
+    if (v.cells >= (1LL << 31)) { set_error("diffuse: more than 2^31 cells per batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
     if (v.dtype == PHIHIP_F64) {
-        if (adjoint) hipLaunchKernelGGL(diffuse_bwd_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const double*)sfield, (double*)out, kdt);
-        else hipLaunchKernelGGL(diffuse_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const double*)sfield, (double*)out, kdt);
+        if (adjoint) launch_diffuse<double, true>(g, 2, v.batch, sfield, out, kdt, s);
+        else launch_diffuse<double, false>(g, 2, v.batch, sfield, out, kdt, s);
     } else {
-        if (adjoint) hipLaunchKernelGGL(diffuse_bwd_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const float*)sfield, (float*)out, (float)kdt);
-        else hipLaunchKernelGGL(diffuse_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, 2, (const float*)sfield, (float*)out, (float)kdt);
+        if (adjoint) launch_diffuse<float, true>(g, 2, v.batch, sfield, out, kdt, s);
+        else launch_diffuse<float, false>(g, 2, v.batch, sfield, out, kdt, s);
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

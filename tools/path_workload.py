@@ -102,7 +102,7 @@ def group_f32_256(ctx, dev, n, reps):
     note(r"advect_centered_kernel<float, 3, 1>", "f2 MacCormack correction pass, centred scalar", 6 * w * N, 6, "read scalar, forward result, 3 components; write 1")
     note(r"advect_staggered_kernel<float, 3, \d, 1>", "f2 MacCormack correction pass, one staggered component", 6 * w * N, 6, "read field, forward result, 3 components; write 1")
     note(r"centered_to_staggered_kernel<float>", "f2 buoyancy: resample(s * vector, to=v), one component", 3 * w * N, 3, "read scalar, read + write the component")
-    note(r"diffuse_kernel<float>", "f1 diffuse.explicit, one component / centred scalar per launch", 2 * w * N, 2, "read + write one array")
+    note(r"diffuse_kernel<float, false>", "f1 diffuse.explicit, one component / centred scalar per launch", 2 * w * N, 2, "read + write one array")
     note(r"divergence_kernel<float, 3>", "a2 divergence + balance sums", 4 * w * N, 4, "read 3 components, write div")
     note(r"march_kernel<float, 4, \d, \d+, 8, false", "a3+a5 initial residual with the balance shift folded in", 4 * w * N, 4, "read x, y; write y, r")
     note(r"march_kernel<float, 4, \d, \d+, 2, false", "a5 CG MATVEC d = r + beta d, d.Ad", 3 * w * N, 3, "read r, d; write d")
@@ -110,6 +110,7 @@ def group_f32_256(ctx, dev, n, reps):
     note(r"march_kernel<float, 4, \d, \d+, 7, false", "a5 CG UPDATE_X2 x += two steps, r -= alpha A d", 5 * w * N, 5, "read x, r, d; write x, r")
     note(r"march_kernel<float, 4, \d, \d+, 0, false", "a4 masked_laplace apply", 2 * w * N, 2, "read p, write A p")
     note(r"grad_subtract_vec_kernel<float, 3>", "a6 gradient subtraction, all components", 7 * w * N, 7, "read p, read + write 3 components")
+    note(r"mask_faces_kernel<float", "f5 projection adjoint: hard_bcs mask of the face gradients", 2 * w * N, 2, "read + write one component")
 
     # f3: obstacles on the device
     obs = C.make_obstacles([dict(kind=C.OBSTACLE_BOX, center=(L / 2, L / 2, L / 2), half_size=(L / 8, L / 8, L / 8), velocity=(0.1, 0, 0),
@@ -158,10 +159,10 @@ def group_f32_256(ctx, dev, n, reps):
          "read grad_out, field, 3 velocity components; read-modify-write grad_field and (partly) 3 grad_velocity components: >= 9 words, atomics")
     note(r"advect_centered_bwd_kernel<float, 3", "f5 adjoint of the centred advection (atomic scatter)", 10 * w * N, 10,
          "read grad_out, scalar, 3 components; rmw grad_s, 3 grad_velocity components")
-    note(r"mac_cormack_centered_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass, centred", 12 * w * N, 12, "as above + forward / backward lookups")
-    note(r"mac_cormack_staggered_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass, one staggered component", 12 * w * N, 12, "as above")
-    note(r"diffuse_bwd_kernel<float>", "f5 adjoint of explicit diffusion, one component per launch (7 atomics per sample)", 3 * w * N, 3, "read grad_out, rmw grad_in")
-    note(r"centered_to_staggered_bwd_kernel<float", "f5 adjoint of the buoyancy resample", 3 * w * N, 3, "read grad_out component, rmw grad_s")
+    note(r"mac_cormack_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass (centred scalar / one staggered component per launch)", 12 * w * N, 12,
+         "read grad_out, field, forward result, 3 velocity components; rmw grad_field, grad_fwd, 3 grad_velocity components")
+    note(r"diffuse_kernel<float, true>", "f5 adjoint of explicit diffusion as a gather (no atomics), one component per launch", 3 * w * N, 3, "read grad_out, read + write grad_in")
+    note(r"c2s_bwd_kernel<float", "f5 adjoint of the buoyancy resample", 3 * w * N, 3, "read grad_out component, rmw grad_s")
     return grid
 
 
