@@ -601,7 +601,7 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_cg1, 4 * vec_bytes));
-    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 6 * part_n * sizeof(double)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 12 * part_n * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
     if (ctx->host_state_bytes < (size_t)2 * v.batch * sizeof(CgState)) {
         if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -634,6 +634,9 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
     double* part_d[2] = {part + 2 * part_n, part + 3 * part_n};
     double* part_rr = part + 4 * part_n;
     double* part_yy = part + 5 * part_n;
+    double* part_mu[2] = {part + 6 * part_n, part + 7 * part_n};       // r'.s, (A r').p, p.s of the launch before (five-sum closure of alpha)
+    double* part_nu[2] = {part + 8 * part_n, part + 9 * part_n};
+    double* part_sg[2] = {part + 10 * part_n, part + 11 * part_n};
     CgState* st[2] = {(CgState*)ctx->ws_state.ptr, (CgState*)ctx->ws_state.ptr + v.batch};
     int cur = 0;
     CgParams prm;
@@ -667,10 +670,12 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
                                (const double*)part_yy, g.nblk, prm);
             cur ^= 1;
         }
-        {   // w = A r ; gamma = |r|^2 ; delta = (A r) . r
+        {   // w = A r ; gamma = |r|^2 ; delta = (A r) . r ; and against the standing p, s (zero at the start): mu = r.s, nu = (A r).p, sigma = p.s
             MarchArgs<T> a = base;
             a.a = rv[vc]; a.o1 = wv[vc];
+            a.c = sv[vc]; a.o4 = pv;
             a.part1 = part_g[pc]; a.part2 = part_d[pc];
+            a.part3 = part_mu[pc]; a.part4 = part_nu[pc]; a.part5 = part_sg[pc];
             a.prologue = PRO_CONT;
             a.st_in = st[cur];
             LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
@@ -687,7 +692,9 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
             a.a = rv[vc]; a.b = wv[vc]; a.c = sv[vc];
             a.o1 = rv[vc ^ 1]; a.o2 = wv[vc ^ 1]; a.o3 = sv[vc ^ 1]; a.o4 = pv; a.o5 = (T*)x;
             a.pin1 = part_g[pc]; a.pin2 = part_d[pc]; a.nblk_in = nblk_in;
+            a.pin3 = part_mu[pc]; a.pin4 = part_nu[pc]; a.pin5 = part_sg[pc];
             a.part1 = part_g[pc ^ 1]; a.part2 = part_d[pc ^ 1];
+            a.part3 = part_mu[pc ^ 1]; a.part4 = part_nu[pc ^ 1]; a.part5 = part_sg[pc ^ 1];
             a.prologue = PRO_CG1;
             a.st_in = st[cur]; a.st_out = st[cur ^ 1];
             if (solve->check_every > 0) { a.host_flags = ctx->host_flags_dev; a.seq = seq; }

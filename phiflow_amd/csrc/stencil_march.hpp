@@ -21,8 +21,13 @@
 // CG1 is the whole iteration of the SINGLE-REDUCTION form of CG (Chronopoulos & Gear 1989) in ONE launch, for grids whose iteration is
 // bound by the two kernel boundaries rather than by traffic (batched 2-D, small 3-D): with w = A r and s = A p carried as vectors,
 //   S = r - alpha (w + beta s)   [= r_new, also on the halo]      p = r + beta p ; s = w + beta s ; x += alpha p ; r = S ; w = A S
-//   sum S^2 (= gamma), sum (A S) S (= delta)   ->   beta' = gamma' / gamma ,  alpha' = gamma' / (delta' - beta' gamma' / alpha)
-// Same iterates as PhiML's cg in exact arithmetic, one global reduction point per iteration, 10 words per cell instead of 7.
+//   sum S^2 (= gamma'), sum (A S) S (= delta'), sum S s (= mu'), sum (A S) p (= nu'), sum p s (= sigma)
+//   ->   beta' = gamma' / gamma ,  alpha' = gamma' / (p'.A p') with p'.A p' = delta' + beta' (mu' + nu') + beta'^2 sigma
+// (r3) The textbook closure p'.A p' = delta' - beta' gamma' / alpha rests on the orthogonality relations of exact CG; in fp32 they erode and
+// the attainable residual stalled 1-2 digits above the two-launch form (closed 512^2: 9e-4 against 3e-5). The five-sum form is an IDENTITY
+// for the vectors the kernel actually holds -- (r' + beta' p).(w' + beta' s) expanded -- so it is as accurate as computing p'.s' directly, which
+// is what the two-launch form does, at the same single reduction point (tools/cg1_accuracy.py: same iteration counts, same floor).
+// Same iterates as PhiML's cg, one global reduction point per iteration, 10 words per cell instead of 7.
 // MATVEC_AD / UPDATE_AD are the same passes for PhiML's 'CG-adaptive' (SURVEY Appendix B.2): they additionally reduce
 // sum d * r resp. sum r_new * (A d), from which alpha = (d.r)/(d.q) and d = r - ((r.q)/(d.q)) d are formed.
 #pragma once
@@ -60,6 +65,7 @@ struct CgState {
     double alpha, beta;
     double rsq, rsq0, rhs_sq, tol_sq, dq;
     double alpha_prev;       // alpha of the previous iteration (UPDATE_X2 applies it together with the current one)
+    double sigma;            // single-reduction CG: p.Ap of the step just taken (diagnostic; the five-sum closure does not chain it)
     int32_t cont, iterations, converged, diverged;
     int32_t pending;         // 1: x still lacks alpha * d of the last iteration (UPDATE_R ran); flushed by the paired update or at the end
     int32_t pend_buf;        // which of the two d buffers holds that direction
@@ -93,7 +99,8 @@ __device__ __forceinline__ void publish_flag(unsigned long long* p, unsigned lon
 __device__ __forceinline__ bool cg_finite(double v) { return (v == v) && v <= 1.7e308 && v >= -1.7e308; }
 
 // PhiML's cg loop body bookkeeping, split at its two reductions
-__device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, double sum2, const CgParams& prm) {
+__device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, double sum2, const CgParams& prm, double sum3 = 0, double sum4 = 0,
+                                             double sum5 = 0) {
     if (kind == PRO_FIRST) {
         s.alpha = 0; s.beta = 0; s.dq = 0; s.alpha_prev = 0;
         s.pending = 0; s.pend_buf = 0;
@@ -126,7 +133,9 @@ __device__ __forceinline__ CgState cg_advance(int kind, CgState s, double sum1, 
             if (s.cont) {   // ... then this launch's step
                 const bool first = s.iterations == 0 && s.dq == 0;
                 s.beta = first ? 0 : (g_old != 0 ? sum1 / g_old : 0);
-                const double denom = first ? sum2 : sum2 - (s.alpha != 0 ? s.beta * sum1 / s.alpha : 0);
+                // p'.A p' = (r' + beta p).(w' + beta s) = delta' + beta (mu' + nu') + beta^2 sigma: sums over the vectors as they are (see the header)
+                const double denom = first ? sum2 : sum2 + s.beta * (sum3 + sum4) + s.beta * s.beta * sum5;
+                s.sigma = denom;
                 s.alpha_prev = s.alpha;
                 s.alpha = denom != 0 ? sum1 / denom : 0;
                 s.dq = denom != 0 ? denom : 1;        // d.Ad of this step (kept non-zero: marks "not the first launch")
@@ -166,6 +175,9 @@ struct MarchArgs {
     const double* pin2;    //               (PRO_FIRST: sum y^2, PRO_ALPHA_AD: sum d r, PRO_BETA_AD: sum r q)
     double* part1;         // [batch][nblk] partial sums produced by this kernel
     double* part2;         // [batch][nblk]   (RESID: sum y^2, MATVEC_AD: sum d r, UPDATE_AD: sum r q)
+    // single-reduction CG (CG1, APPLY_DOT): three more sums per launch -- mu = r'.s, nu = (A r').p, sigma = p.s -- and the previous launch's
+    const double* pin3; const double* pin4; const double* pin5;
+    double* part3; double* part4; double* part5;
     CgParams prm;
     int prologue;          // CgPrologue
     int nblk_in;           // workgroups per batch entry of the kernel that produced pin1 / pin2
@@ -249,6 +261,29 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return s;
 }
 
+// N sums at once over the 256 threads of a block (one pair of barriers instead of N): results valid in thread 0. `red` = N * kBlock / kWave doubles.
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[k * (kBlock / kWave) + wave] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double s = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) s += red[k * (kBlock / kWave) + w];
+            v[k] = s;
+        }
+    }
+}
+
 // fixed-order sum of n partials by the whole block; valid in thread 0
 __device__ __forceinline__ double reduce_partials(const double* part, int n, double* red) {
     double s = 0;
@@ -259,15 +294,25 @@ __device__ __forceinline__ double reduce_partials(const double* part, int n, dou
 // Prologue shared by every kernel of the CG loop: returns the advanced control block to all threads of the workgroup.
 __device__ __forceinline__ CgState cg_prologue(int kind, const CgState* st_in, CgState* st_out, const double* pin1, const double* pin2,
                                               int nblk, const CgParams& prm, int b, bool writer, double* red, CgState* sh, int pending = -1,
-                                              int pend_buf = 0) {
+                                              int pend_buf = 0, const double* pin3 = nullptr, const double* pin4 = nullptr, const double* pin5 = nullptr) {
     // the control block is fetched BEFORE the reductions so that its memory round trip overlaps theirs
     CgState s = CgState();
     if (threadIdx.x == 0 && kind != PRO_FIRST) s = st_in[b];
-    double s1 = 0, s2 = 0;
-    if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
-    if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);   // (incl. PRO_CG1)
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+    if (kind == PRO_CG1 && pin3) {      // the five sums of the single-reduction CG in ONE pass (that kernel is latency-bound: barriers count)
+        double t[5] = {0, 0, 0, 0, 0};
+        for (int i = threadIdx.x; i < nblk; i += kBlock) {
+            const long long o = (long long)b * nblk + i;
+            t[0] += pin1[o]; t[1] += pin2[o]; t[2] += pin3[o]; t[3] += pin4[o]; t[4] += pin5[o];
+        }
+        block_sum_n<5>(t, red);
+        s1 = t[0]; s2 = t[1]; s3 = t[2]; s4 = t[3]; s5 = t[4];
+    } else {
+        if (kind >= PRO_FIRST) s1 = reduce_partials(pin1 + (long long)b * nblk, nblk, red);
+        if (kind == PRO_FIRST || kind >= PRO_BETA_AD) s2 = reduce_partials(pin2 + (long long)b * nblk, nblk, red);   // (incl. PRO_CG1 without the extra sums)
+    }
     if (threadIdx.x == 0) {
-        s = cg_advance(kind, s, s1, s2, prm);
+        s = cg_advance(kind, s, s1, s2, prm, s3, s4, s5);
         if (pending >= 0 && s.cont) {   // an UPDATE phase of a running entry: does x lag one step behind afterwards?
             s.pending = pending;
             s.pend_buf = pend_buf;
@@ -305,7 +350,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     constexpr bool AD = MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_AD;
 
     __shared__ __attribute__((aligned(16))) T lds[2][LROWS * LS];
-    __shared__ double red[kBlock / kWave];
+    __shared__ double red[5 * (kBlock / kWave)];
     __shared__ CgState sh_state;
 
     const int tid = threadIdx.x;
@@ -316,6 +361,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     // per-thread partial sums of the dot products: one row of a plane is summed in T, rows and planes are added up in double (a thread of
     // a 512^3 launch adds ~1000 rows; in fp32 that alone cost the eigenfunction test five extra iterations)
     double acc1 = 0.0, acc2 = 0.0;
+    double acc3 = 0.0, acc4 = 0.0, acc5 = 0.0;   // single-reduction CG only: r'.s, (A r').p, p.s
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
@@ -391,7 +437,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
 
     if (p.prologue != PRO_NONE) {
         const CgState S = cg_prologue(p.prologue, p.st_in, p.st_out, p.pin1, p.pin2, p.nblk_in, p.prm, b, blockIdx.x == 0, red, &sh_state,
-                                      IS_UP ? (MODE == MODE_UPDATE_R ? 1 : 0) : -1, p.pend_buf);
+                                      IS_UP ? (MODE == MODE_UPDATE_R ? 1 : 0) : -1, p.pend_buf, IS_CG1 ? p.pin3 : nullptr, p.pin4, p.pin5);
         if (IS_MV && p.host_flags && blockIdx.x == 0 && tid == 0)   // the host stops enqueueing once every entry reports 0
             publish_flag(p.host_flags + b, ((unsigned long long)p.seq << 32) | (unsigned long long)(S.cont != 0));
         if (S.cont == 0) return;   // frozen batch entry: x, r, d stay as they are
@@ -497,6 +543,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
             if (IS_UP) {
                 if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + off);
                 E.e2[rr] = vec_load<T, V>(p.o2 + off);
+            }
+            if (MODE == MODE_APPLY_DOT && p.c) {      // refresh of the single-reduction CG: mu, nu, sigma against the standing p and s
+                E.e1[rr] = vec_load<T, V>(p.o4 + off);
+                E.e5[rr] = vec_load<T, V>(p.c + off);
             }
             if (IS_CG1) {
                 E.e1[rr] = vec_load<T, V>(p.o4 + off);
@@ -609,6 +659,16 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                         s1 += Sc[rr].v[v] * Sc[rr].v[v];
                         s2 += q.v[v] * Sc[rr].v[v];
                     }
+                    if (p.c && ok[rr]) {
+                        T t3 = T(0), t4 = T(0), t5 = T(0);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            t3 += Sc[rr].v[v] * Ec.e5[rr].v[v];          // r . s
+                            t4 += q.v[v] * Ec.e1[rr].v[v];               // (A r) . p
+                            t5 += Ec.e1[rr].v[v] * Ec.e5[rr].v[v];       // p . s
+                        }
+                        acc3 += (double)t3; acc4 += (double)t4; acc5 += (double)t5;
+                    }
                 }
             } else if (IS_CG1) {
                 VT pn, sn, xn;
@@ -619,6 +679,16 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     xn.v[v] = fma(-beta, pn.v[v], Ec.e2[rr].v[v]);                // x += alpha p   (beta holds -alpha here)
                     s1 += Sc[rr].v[v] * Sc[rr].v[v];                  // gamma' = |r_new|^2
                     s2 += q.v[v] * Sc[rr].v[v];                       // delta' = (A r_new) . r_new
+                }
+                if (ok[rr]) {
+                    T t3 = T(0), t4 = T(0), t5 = T(0);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        t3 += Sc[rr].v[v] * sn.v[v];                  // mu' = r_new . s
+                        t4 += q.v[v] * pn.v[v];                       // nu' = (A r_new) . p
+                        t5 += pn.v[v] * sn.v[v];                      // sigma = p . s
+                    }
+                    acc3 += (double)t3; acc4 += (double)t4; acc5 += (double)t5;
                 }
                 vec_store<T, V>(dst(p.o4, off, rr), pn);
                 vec_store<T, V>(dst(p.o3, off, rr), sn);
@@ -680,6 +750,15 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
         if (IS_RES || AD || IS_CG1 || MODE == MODE_APPLY_DOT) {
             const double s2 = block_sum(acc2, red);
             if (tid == 0) p.part2[(long long)b * g.nblk + blockIdx.x] = s2;
+        }
+        if ((IS_CG1 || MODE == MODE_APPLY_DOT) && p.part3) {
+            double t[3] = {acc3, acc4, acc5};
+            block_sum_n<3>(t, red);
+            if (tid == 0) {
+                p.part3[(long long)b * g.nblk + blockIdx.x] = t[0];
+                p.part4[(long long)b * g.nblk + blockIdx.x] = t[1];
+                p.part5[(long long)b * g.nblk + blockIdx.x] = t[2];
+            }
         }
     }
 }
