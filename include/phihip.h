@@ -309,8 +309,9 @@ int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row,
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes);
 
 /* Grids of at most 8192 cells per batch entry (16384 for fp32 batches of >= 8 entries) are solved by ONE kernel (one workgroup per batch entry, the
- * search direction in LDS, no kernel boundary or host polling inside the loop; cg_small.hip). enable = 0 forces the marching
- * kernels for every size (A/B measurements, tests of the marching path on small grids); enable > 1 sets the cell limit explicitly
+ * search direction in LDS, no kernel boundary or host polling inside the loop; cg_small.hip). enable = 0 forces the two-launch marching
+ * kernels for every size -- it also switches the automatic choice of the single-reduction form off -- (A/B measurements, tests of the
+ * marching path on small grids); enable > 1 sets the cell limit explicitly
  * (capped at 16384 fp32 / 8192 fp64). Default: enabled. */
 int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
 /* 'CG' with the marching kernels updates the solution every OTHER iteration only: x does not enter the recurrence, and the step that
@@ -330,12 +331,12 @@ int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
 /* Solve('CG') on grids whose iteration is bound by the two kernel boundaries rather than by memory traffic (batched 2-D, small 3-D) runs the
  * SINGLE-REDUCTION form of CG (Chronopoulos & Gear): one launch per iteration that carries w = A r and s = A p as vectors -- the same
- * iterates as the two-launch form in exact arithmetic (alpha, beta from gamma = r.r and delta = (A r).r of the previous launch), 10 instead
- * of 7 words per cell, half the launches: 1.2-1.4x faster per iteration up to ~1 M cells x batch (512^2: 10.1 -> 7.4 us). It is OPT-IN: the
- * recurrences that replace the second reduction cost attainable accuracy in fp32 (closed 512^2 box: relative residual floor 9e-4 against 3e-5
- * of the two-launch form, tools/cg1_accuracy.py), so a tolerance below ~kappa * 1e-7 may never be met. mode 0 (default): never; 1: when
- * cells x batch <= max_cells (0 = built-in threshold, 1.5 M fp32 / 0.75 M fp64); 2: always. 'CG-adaptive', slab-decomposed solves and grids
- * of the single-workgroup solver are not affected. */
+ * iterates as the two-launch form (alpha, beta from five sums of the previous launch: gamma = r.r, delta = (A r).r, mu = r.s, nu = (A r).p,
+ * sigma = p.s; p'.A p' = delta + beta (mu + nu) + beta^2 sigma is an identity of the stored vectors, so the attainable accuracy is that of
+ * the two-launch form -- the textbook closure delta - beta gamma / alpha of rounds 1-2 stalled 1-2 digits early in fp32,
+ * tools/cg1_accuracy.py), 10 instead of 7 words per cell, half the launches: 1.1-1.3x faster per iteration up to ~1 M cells x batch
+ * (512^2: 10.7 -> 8.2 us). mode 0: never; 1 (default): when cells x batch <= max_cells (0 = built-in threshold, 1.2 M fp32 / 0.6 M fp64);
+ * 2: always. 'CG-adaptive', slab-decomposed solves and grids of the single-workgroup solver are not affected. */
 int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or

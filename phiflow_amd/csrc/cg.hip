@@ -581,9 +581,9 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
 // ---------------------------------------------------------------------------------------------------------------------
 static long long cg1_threshold(const phihip_ctx* ctx, const GridView& v) {
     if (ctx->cg1_cells > 0) return ctx->cg1_cells;
-    // cells x batch up to which ONE launch with 10 words per cell beats TWO with 7 (tools/sweep_cg1.py, profiles/r02_cg1_sweep.jsonl: 1.2-1.4x
-    // faster at 0.26-1.05 M cells, 0.86-0.91x at 2.1 M)
-    return v.dtype == PHIHIP_F64 ? 750000 : 1500000;
+    // cells x batch up to which ONE launch with 10 words per cell beats TWO with 7 (tools/sweep_cg1.py, profiles/r03_cg1_sweep.jsonl: 1.10-1.31x
+    // faster at 0.26-1.05 M cells, 0.67-0.81x at 2.1 M)
+    return v.dtype == PHIHIP_F64 ? 600000 : 1200000;
 }
 
 template <typename T>
@@ -758,8 +758,9 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     }
+    // (phihip_set_small_grid_solver(ctx, 0) = "the two-launch marching kernels at every size": it also switches the automatic choice off)
     if (solve->method == PHIHIP_METHOD_CG && !v.halo[0] && !v.halo[1] &&
-        (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))
+        (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && ctx->small_cg && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))
         return cg1_t<T>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
     if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
         !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R)) && !stream_is_capturing(s)) {

@@ -130,10 +130,10 @@ struct phihip_ctx {
     bool autotune = true;
     std::map<phihip::PlanKey, phihip::TunedPlan> tuned;
     std::map<std::array<long long, 6>, int> adv_tuned;   // tiled advection: (dtype bytes, dim, halo, planes, tiles, batch) -> planes per workgroup
-    // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never (default: in fp32 its
-    // attainable accuracy is 1-2 digits worse than the two-launch form, tools/cg1_accuracy.py), 1 = for solves whose iteration is bound
+    // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never, 1 (default since r3: the
+    // five-sum closure of alpha reaches the accuracy of the two-launch form, tools/cg1_accuracy.py) = for solves whose iteration is bound
     // by the kernel boundaries (cg1_cells: cells x batch at most this), 2 = always ('CG' only)
-    int cg1_mode = 0;
+    int cg1_mode = 1;
     long long cg1_cells = 0;      // 0 = built-in threshold
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule

@@ -195,9 +195,12 @@ def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
                 dout = [mem.empty(a.shape, dtype) for a in vel]
                 ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
                 mem.sync()
+                # a lookup coordinate is an absolute index (up to n) in the element type: its rounding (n * eps) times the field's gradient -- of
+                # the order of the amplitude per cell for the white-noise fields here -- bounds the attainable agreement on long axes
+                bound = tol(dtype)['advect'] * max(1.0, max(dom.res) / 160.0)
                 for d in range(dom.rank):
                     err = rel_err(mem.to_host(dout[d]), ref[d])
-                    assert err <= tol(dtype)['advect'], f"advect[{d}] {name} field, halo {halo}: rel err {err}"
+                    assert err <= bound, f"advect[{d}] {name} field, halo {halo}: rel err {err}"
                 tiled = all(n >= 4 for d in range(dom.rank) for n in dom.comp_shape(d))     # thinner axes keep the gather kernels
                 if halo and name == "gentle":
                     redone, total = ctx.advect_fallback_stats()

@@ -487,4 +487,4 @@ def test_single_reduction_cg_matches_oracle(emu_ctx, res, bc):
             pc.check_make_incompressible(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(11), obstacles=[pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))])
     finally:
         emu_ctx.set_small_grid_solver(True)
-        emu_ctx.set_single_reduction_cg(0)
+        emu_ctx.set_single_reduction_cg(1)

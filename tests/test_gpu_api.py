@@ -153,8 +153,9 @@ def test_level_b_rank_deficient_matrix_solve_on_the_device(gpu_backend):
             x, its, rsq, conv, div = be.hip_linear_solve('CG', lin, yt, torch.zeros_like(yt), 1e-4, 0.0, 2000, matrix_offset=-1.0 / N)
         prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
         assert all(conv) and not any(div) and x.is_cuda
-        # one MATVEC launch per iteration; UPDATE launches except on the true-residual refresh iterations (every 50th)
-        assert prof['cg_matvec_dot'][0] >= 3 * its[0] and prof['cg_update'][0] + prof['cg_update_r'][0] >= 3 * (its[0] - its[0] // 50 - 2), (prof, its)
+        # (these sizes take the single-reduction form: ONE fused launch per iteration, counted as cg_update; the refresh iterations add passes)
+        launches = prof['cg_matvec_dot'][0] + prof['cg_update'][0] + prof['cg_update_r'][0]
+        assert launches >= 3 * (its[0] - its[0] // 50 - 2) and prof['cg_residual'][0] >= 3, (prof, its)
         assert be.hip_stats['cache_misses'] == stats0['cache_misses'] + 1 and be.hip_stats['cache_hits'] == stats0['cache_hits'] + 2
         assert be.hip_stats['offsets_dropped'] == stats0['offsets_dropped'] + 3
         # same system through the phi-level C ABI call

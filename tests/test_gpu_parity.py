@@ -634,4 +634,4 @@ def test_single_reduction_cg_opt_in(ctx, mem):
         assert np.linalg.norm(out[2][3] - out[0][3]) <= 2e-3 * np.linalg.norm(out[0][3])
     finally:
         ctx.set_small_grid_solver(True)
-        ctx.set_single_reduction_cg(0)
+        ctx.set_single_reduction_cg(1)
