@@ -136,8 +136,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     } else {
         // candidate order + a small preference factor per family (from the family sweeps): UPDATE / residual favour large tiles
         // at equal chunk length, MATVEC medium tiles and the full-row tile (1, 64)
-        static const int pref_mv[7] = {2, 5, 6, 1, 0, 3, 4}, pref_up[7] = {4, 3, 6, 2, 1, 0, 5};
-        static const double bonus_mv[7] = {1.0, 1.0, 0.99, 0.98, 0.97, 0.93, 0.93}, bonus_up[7] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.97};
+        static const int pref_mv[8] = {2, 5, 6, 7, 1, 0, 3, 4}, pref_up[8] = {4, 3, 6, 2, 7, 1, 0, 5};
+        static const double bonus_mv[8] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.93, 0.93}, bonus_up[8] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.98, 0.97, 0.97};
         const int* pref = mv_like ? pref_mv : pref_up;
         const double* bonus = mv_like ? bonus_mv : bonus_up;
         double best_score = -1.0;

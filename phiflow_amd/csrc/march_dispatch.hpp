@@ -10,8 +10,10 @@ struct TileShape {
 };
 // (2, 64) (r3): full-width rows like (1, 64) -- no left / right halo columns when a row is 256 fp32 / 128 fp64 cells -- with 8 instead of
 // 4 rows per tile: two halo rows per eight own rows (25 % extra L2 requests instead of 50 %) at ~105 instead of ~80 VGPRs
-constexpr int kNumTileConfigs = 7;
-constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}};
+// (1, 32) (r3): 8 rows x 128 fp32 / 64 fp64 cells at the register cost of the one-row tiles -- for rows that are multiples of 128 but not of 256
+// cells (384, 640), between (1, 16) (16 x 64: many halo columns) and (1, 64) (4 x 256: two halo rows per four own rows)
+constexpr int kNumTileConfigs = 8;
+constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}};
 
 struct MarchConfig {
     int id;      // index into kTileShapes (ignored when vec == 1)

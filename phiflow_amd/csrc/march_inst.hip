@@ -95,6 +95,7 @@ int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
         case 4: return occupancy_cfg<kVmax, 4, 64>(mode, flags);
         case 5: return occupancy_cfg<kVmax, 1, 64>(mode, flags);
         case 6: return occupancy_cfg<kVmax, 2, 64>(mode, flags);
+        case 7: return occupancy_cfg<kVmax, 1, 32>(mode, flags);
         default: return 1;
     }
 }
@@ -127,6 +128,7 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
         case 4: return launch_cfg<kVmax, 4, 64>(mode, flags, g, a, grid, s);
         case 5: return launch_cfg<kVmax, 1, 64>(mode, flags, g, a, grid, s);
         case 6: return launch_cfg<kVmax, 2, 64>(mode, flags, g, a, grid, s);
+        case 7: return launch_cfg<kVmax, 1, 32>(mode, flags, g, a, grid, s);
         default:
             set_error("march: bad tile config %d", c.id);
             return PHIHIP_ERR_BAD_ARG;

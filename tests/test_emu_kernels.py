@@ -326,7 +326,7 @@ def test_tile_configurations_agree(emu_ctx):
     dtype = np.float32
     dom, grid = pc.make_case((5, 36, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
     try:
-        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64)]:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)]:
             for chunk in (2, 5):
                 emu_ctx.set_tuning(rows, tpr, chunk)
                 pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(11))

@@ -380,7 +380,7 @@ def test_tile_configurations_agree(ctx, mem):
     dtype = np.float32
     dom, grid = pc.make_case((20, 72, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
     try:
-        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64)]:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)]:
             for chunk in (3, 20):
                 ctx.set_tuning(rows, tpr, chunk)
                 pc.check_laplace(ctx, mem, dom, grid, dtype, np.random.default_rng(11))

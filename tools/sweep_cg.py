@@ -54,7 +54,7 @@ def main():
     rhs = rhs.to(dev)
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, args.iters, 0, 0, args.method)
-    configs = [(r, t, c) for (r, t) in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64)] for c in (8, 16, 32, 64, n)]
+    configs = [(r, t, c) for (r, t) in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)] for c in (8, 16, 32, 64, n)]
     if args.configs:
         configs = [tuple(int(v) for v in item.split(",")) for item in args.configs.split(";")]
     configs = [(0, 0, 0)] + configs

@@ -34,7 +34,7 @@ def main():
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, args.iters, 0, 0, args.method)
     ap_small = n ** D <= max(8192, args.small_limit)
-    for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0)] + ([(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64)] if D == 2 else []):
+    for rows, tpr in ([(-1, -1)] if ap_small else []) + [(0, 0)] + ([(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)] if D == 2 else []):
         ctx.lib.check(ctx.lib.dll.phihip_set_small_grid_solver(ctx.handle, args.small_limit if rows < 0 else 0))   # rows = -1: cg_small.hip
         ctx.set_tuning(max(rows, 0), max(tpr, 0), 0)
         x.zero_()
