@@ -38,7 +38,9 @@ def test_library_was_built_from_the_sources_in_this_tree():
     import subprocess
     lib = _capi.Library(_capi.DEFAULT_LIBRARY_PATH)
     if not lib.built_from_tree() and os.path.exists("/opt/rocm/bin/hipcc"):      # sources edited since the last build: rebuild, like build()
-        subprocess.run(["make", "-C", os.path.join(ROOT, "phiflow_amd", "csrc"), f"-j{os.cpu_count() or 4}"], check=True, stdout=subprocess.DEVNULL)
+        # (flock: a second make on the same build directory -- another test session, a developer's shell -- must not interleave object files)
+        csrc = os.path.join(ROOT, "phiflow_amd", "csrc")
+        subprocess.run(["flock", os.path.join(csrc, ".build.lock"), "make", "-C", csrc, f"-j{os.cpu_count() or 4}"], check=True, stdout=subprocess.DEVNULL)
         lib = _capi.Library(_capi.DEFAULT_LIBRARY_PATH)
     bid = lib.build_id()
     assert re.fullmatch(r"[0-9a-f]{12}(\+dirty)? src:[0-9a-f]{16}|nogit src:[0-9a-f]{16}", bid), bid

@@ -112,7 +112,8 @@ def config5():
     cells = n ** 3
     alg_iter = 81.0 * cells      # 10 fp64 words + 1 B mask per cell and iteration
     it_ms = (prof["cg_matvec_dot"] or 0) + (prof["cg_update"] or 0)
-    print(json.dumps({"config": "5: lid-driven cavity 384^3 fp64, closed box + solid box obstacle, advect + 100 CG iterations", "ms_per_step": t * 1e3,
+    plans = {name: ctx.query_plan(grid, True, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3), ("residual", 0))}
+    print(json.dumps({"config": "5: lid-driven cavity 384^3 fp64, closed box + solid box obstacle, advect + 100 CG iterations", "ms_per_step": t * 1e3, "plan": plans,
                       "cell_updates_per_s": cells / t, "cg_iteration_ms": it_ms, "cg_algorithmic_GBs": alg_iter / (it_ms * 1e-3) / 1e9 if it_ms else None,
                       "kernel_ms": prof}), flush=True)
 

@@ -23,7 +23,8 @@ def main():
         if flt and flt not in d:
             continue
         scratch, occ, lds = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")
-        print(f"vgpr={g('VGPRs'):3d} agpr={g('AGPRs'):3d} scratch={scratch:4d} occ={occ} lds={lds:6d} sgpr={g('SGPRs'):3d}  {d}")
+        print(f"vgpr={g('VGPRs'):3d} agpr={g('AGPRs'):3d} scratch={scratch:4d} occ={occ} lds={lds:6d} sgpr={g('SGPRs'):3d} sgpr_spill={g('SGPRs Spill'):4d} "
+              f"vgpr_spill={g('VGPRs Spill'):3d}  {d}")
 
 
 if __name__ == "__main__":
