@@ -343,7 +343,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
     const bool has_flags = flags != nullptr;
     const int esize = (int)sizeof(T);
     const int vec = (v.n[2] % (16 / esize) == 0 && !v.unaligned) ? 16 / esize : 1;
-    static const int kChunks[11] = {96, 64, 48, 32, 24, 16, 12, 8, 4, 2, 1};
+    static const int kChunks[12] = {128, 96, 64, 48, 32, 24, 16, 12, 8, 4, 2, 1};
     struct Cand { int id, chunk; float us; };
     const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
     PHIHIP_CHECK_HIP(hipMemsetAsync(r, 0, vec_bytes, s));
@@ -378,7 +378,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
                 if (id != c_model.id && blocks <= maxblk) cands.push_back({id, 1, 0.f});
                 continue;
             }
-            for (int k = 0; k < 11; ++k) {
+            for (int k = 0; k < 12; ++k) {
                 const int ch = kChunks[k] < v.n[0] ? kChunks[k] : v.n[0];
                 if (id == c_model.id && ch == c_model.chunk) continue;
                 bool dup = false;
@@ -386,7 +386,9 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
                 if (dup) continue;
                 const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
                 const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * ceil_div(v.n[0], ch);
-                if (blocks * v.batch < ctx->num_cu || blocks > 8192) continue;   // starved chip / partial-sum lists too long
+                // starved chip (but a little under one workgroup per CU is a candidate: 384^3 fp64 UPDATE_X2 runs fastest with 216 (4,64) workgroups of
+                // 128 planes, profiles/r03_sweep_config5.jsonl) / partial-sum lists too long
+                if (blocks * v.batch < ctx->num_cu * 3 / 4 || blocks > 8192) continue;
                 cands.push_back({id, ch, 0.f});
             }
             // chunk lengths that fill the chip EVENLY: m workgroups on every CU (m = 1 .. resident workgroups, and two such rounds).
