@@ -84,6 +84,12 @@ __device__ __forceinline__ int pad_index(int i, int n, int code_lo, int code_hi)
     return i;
 }
 
+// 1 / 2 when index i of an axis with n entries lies beyond the lower / upper CONSTANT (closed) side, else 0 (no wrap arithmetic: the value
+// itself was loaded from a valid address already, this only decides whether the constant replaces it)
+__device__ __forceinline__ int const_side(int i, int n, int code_lo, int code_hi) {
+    return (i < 0 && code_lo == PHIHIP_BC_CLOSED) ? 1 : ((i >= n && code_hi == PHIHIP_BC_CLOSED) ? 2 : 0);
+}
+
 // keeps the instruction scheduler from hoisting every sample's LDS reads to the top of the plane (that costs > 200 registers)
 __device__ __forceinline__ void sched_fence() {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -93,6 +99,12 @@ __device__ __forceinline__ void sched_fence() {
 
 // hides a value from the optimiser (no instruction): what is computed from it cannot be hoisted out of the loop and kept in a register
 __device__ __forceinline__ void opaque_int(int& v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" : "+v"(v));
+#endif
+}
+
+__device__ __forceinline__ void opaque_uint(unsigned& v) {
 #ifdef __HIP_DEVICE_COMPILE__
     asm volatile("" : "+v"(v));
 #endif
@@ -108,8 +120,12 @@ __device__ __forceinline__ float clamp_real(float x, float lo, float hi) {
 }
 __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
 
-template <typename T, int DIM, int H, int T1, int OFFM>
-__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? 3 : 2) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
+// CONSTS: the grid has a CLOSED (constant) side somewhere, i.e. a staged window may need wall values patched in. Without one -- periodic /
+// open boxes, the benchmark configuration -- the whole patch path is compiled out: its plane-invariant per-thread predicates were hoisted
+// out of the plane loop as ~100 lane masks in SGPR pairs, 325 of them spilled to VGPR lanes and reloaded every plane (r3: 7631 -> 3210
+// instructions, 148 -> 88 VGPRs, 3 -> 5 waves per SIMD for the fp32 halo-1 kernel).
+template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
+__global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? 4 : 2) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
                                                                   int* __restrict__ flags, T* __restrict__ dump) {
     using C = AdvTile<T, DIM, H, T1>;
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // domains altogether) run the fill without a single select.
     bool has_const = false;
 #pragma unroll
-    for (int c = A0; c < 3; ++c) {
+    for (int c = A0; CONSTS && c < 3; ++c) {
         has_const = has_const || (g.bc[1][0] == PHIHIP_BC_CLOSED && lo1 - H < 0) || (g.bc[1][1] == PHIHIP_BC_CLOSED && lo1 + T1 + H > g.cn[c][1]) ||
                     (g.bc[2][0] == PHIHIP_BC_CLOSED && lo2 - H < 0) || (g.bc[2][1] == PHIHIP_BC_CLOSED && lo2 + T2 + H > g.cn[c][2]);
         if (DIM == 3) has_const = has_const || (g.bc[0][0] == PHIHIP_BC_CLOSED && pb - H < 0) || (g.bc[0][1] == PHIHIP_BC_CLOSED && pe + H > g.cn[c][0]);
@@ -162,16 +178,14 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // element kp of component c: row ty + kp TY, column tx of the window. eoff = in-plane element offset after wrap / clamp;
     // ccode: 0 = stored sample, 1 / 2 = the lower / upper CONSTANT side of a2 supplies the value (rows: recomputed in the cold path)
     unsigned eoff[3][KP];
-    int ccode[3];
     const bool last_ok = ty + (KP - 1) * TY < P1;        // only the last pass can run past the window's rows
 #pragma unroll
     for (int c = A0; c < 3; ++c) {
         const int k = pad_index(lo2 - H + tx, g.cn[c][2], g.bc[2][0], g.bc[2][1]);
-        ccode[c] = k < 0 ? -k : 0;
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
             const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
-            eoff[c][kp] = (unsigned)((j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k));
+            eoff[c][kp] = (unsigned)((j < 0 ? 0 : j * g.cn[c][2]) + (k < 0 ? 0 : k)) * (unsigned)sizeof(T);   // BYTES (planes are < 4 GiB)
         }
         if (!last_ok) eoff[c][KP - 1] = eoff[c][0];   // (row past the window: the load still runs -- see load_plane -- on a valid address)
     }
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     const int tail_r = has_tail ? (tid % (P1 * 2 * H)) / (2 * H) : 0;
     const int tail_q = T2 + tid % (2 * H);
     unsigned tail_off = 0;
-    int tail_rcode = 0, tail_ccode = 0, tail_n0 = 1, tail_n1 = 1, tail_n2 = 1;
+    int tail_n0 = 1, tail_n1 = 1, tail_n2 = 1;
     const T* tail_base = vel.p[2];
 #pragma unroll
     for (int c = A0; c < 3; ++c)     // (selects over the static component index: dynamic indexing of kernel arguments goes through scratch)
@@ -190,9 +204,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     if (has_tail) {
         const int kk = pad_index(lo2 - H + tail_q, tail_n2, g.bc[2][0], g.bc[2][1]);
         const int j = pad_index(lo1 - H + tail_r, tail_n1, g.bc[1][0], g.bc[1][1]);
-        tail_ccode = kk < 0 ? -kk : 0;
-        tail_rcode = j < 0 ? -j : 0;
-        tail_off = (unsigned)((j < 0 ? 0 : j * tail_n2) + (kk < 0 ? 0 : kk));
+        tail_off = (unsigned)((j < 0 ? 0 : j * tail_n2) + (kk < 0 ? 0 : kk)) * (unsigned)sizeof(T);
     }
     (void)tail_n0;
 
@@ -215,37 +227,54 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
 #pragma unroll
         for (int c = A0; c < 3; ++c) {
             psrc[c] = plane_src(c, i0);
-            const T* __restrict__ base = vel.p[c] + (long long)b * g.ccells[c] + psrc[c];
+            // uniform base + 32-bit byte offset per lane = ONE instruction (global_load ... saddr). The offset is hidden from the optimiser at
+            // each use: hoisted out of the plane loop, zext(offset) becomes a 64-bit register pair and the load a 64-bit vector address add
+            const char* __restrict__ base = (const char*)(vel.p[c] + (long long)b * g.ccells[c] + psrc[c]);
 #pragma unroll
-            for (int kp = 0; kp < KP; ++kp) R[c][kp] = base[eoff[c][kp]];
+            for (int kp = 0; kp < KP; ++kp) {
+                unsigned o = eoff[c][kp];
+                opaque_uint(o);
+                R[c][kp] = *(const T*)(base + o);
+            }
         }
-        tailv = (tail_base + (tail_c == 0 ? psrc[0] : (tail_c == 1 ? psrc[1] : psrc[2])))[tail_off];
+        {
+            unsigned o = tail_off;
+            opaque_uint(o);
+            tailv = *(const T*)((const char*)(tail_base + (tail_c == 0 ? psrc[0] : (tail_c == 1 ? psrc[1] : psrc[2]))) + o);
+        }
     };
-    // constant sides are patched in when the plane enters the ring (cold, uniform: only workgroups whose window crosses a CLOSED side)
+    // constant sides are patched in when the plane enters the ring (cold, uniform: only workgroups whose window crosses a CLOSED side).
+    // Every per-thread predicate is recomputed here from the (optimiser-opaque) thread coordinates: kept across planes they are lane
+    // masks in SGPR pairs -- ~100 of them, spilled and reloaded every plane, also by the workgroups that never take this path.
     auto patch_plane = [&](int i0, T (&R)[3][KP], T& tailv) {
+        int tyo = ty, txo = tx, tido = tid;
+        opaque_int(tyo); opaque_int(txo); opaque_int(tido);
         // PhiML pads axis after axis: the LAST axis outside a constant side decides (a2 over a1 over a0)
 #pragma unroll
         for (int c = A0; c < 3; ++c) {
-            const int k = DIM == 3 ? pad_index(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;
+            const int k = DIM == 3 ? const_side(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;       // uniform
             // (values first, selects after: a select between two kernel-argument LOADS becomes a per-lane address + flat load)
             const T k00 = g.bcv[0][0][c], k01 = g.bcv[0][1][c], k10 = g.bcv[1][0][c], k11 = g.bcv[1][1][c], k20 = g.bcv[2][0][c], k21 = g.bcv[2][1][c];
-            const T pv = k == -1 ? k00 : k01;
-            const T cv = ccode[c] == 1 ? k20 : k21;
+            const T pv = k == 1 ? k00 : k01;
+            const int cside = const_side(lo2 - H + txo, g.cn[c][2], g.bc[2][0], g.bc[2][1]);
+            const T cv = cside == 1 ? k20 : k21;
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp) {
                 T v = R[c][kp];
-                const int j = pad_index(lo1 - H + ty + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
-                const T rv = j == -1 ? k10 : k11;
-                v = k < 0 ? pv : v;
-                v = j < 0 ? rv : v;
-                v = ccode[c] ? cv : v;
+                const int j = const_side(lo1 - H + tyo + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
+                const T rv = j == 1 ? k10 : k11;
+                v = k ? pv : v;
+                v = j ? rv : v;
+                v = cside ? cv : v;
                 R[c][kp] = v;
             }
-            if (has_tail && c == tail_c) {
-                const T rv = tail_rcode == 1 ? k10 : k11, cv2 = tail_ccode == 1 ? k20 : k21;
-                tailv = k < 0 ? pv : tailv;
-                tailv = tail_rcode ? rv : tailv;
-                tailv = tail_ccode ? cv2 : tailv;
+            if (tido < C::NTAIL && tido / (P1 * 2 * H) == c - A0) {
+                const int tr = (tido % (P1 * 2 * H)) / (2 * H), tq = T2 + tido % (2 * H);
+                const int rs = const_side(lo1 - H + tr, g.cn[c][1], g.bc[1][0], g.bc[1][1]), cs = const_side(lo2 - H + tq, g.cn[c][2], g.bc[2][0], g.bc[2][1]);
+                const T rv = rs == 1 ? k10 : k11, cv2 = cs == 1 ? k20 : k21;
+                tailv = k ? pv : tailv;
+                tailv = rs ? rv : tailv;
+                tailv = cs ? cv2 : tailv;
             }
         }
     };
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
             if (MODE_ == 2) compute_plane(p);
         }
         if (ks >= k_lo && ks <= k_hi) {
-            if (has_const) patch_plane(ks, Rst, tail_st);
+            if (CONSTS && has_const) patch_plane(ks, Rst, tail_st);
             store_plane(slot_of(ks), Rst, tail_st);
         }
         __syncthreads();
@@ -442,8 +471,8 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
         }
 }
 
-template <typename T, int DIM, int H, int T1, int OFFM>
-static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
+static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
     const TileGrid<T> g = make_tilegrid<T>(vg, dt);
     using C = AdvTile<T, DIM, H, T1>;
     int nmax[3] = {1, 1, 1};
@@ -459,7 +488,7 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
         int& occ = occ_dev[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
         if (occ == 0) {
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, advect_self_tile_kernel<T, DIM, H, T1, OFFM>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>, kBlock, 0) != hipSuccess || n < 1) n = 1;
             occ = n;
         }
         const double slots = (double)occ * ctx->num_cu;
@@ -485,7 +514,7 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
         PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
         flags = (int*)ctx->ws_adv_flags.ptr;
         T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
-        hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
+        hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
                            (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump);
         return PHIHIP_OK;
     };
@@ -532,6 +561,18 @@ static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg
     hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;
+}
+
+// a stored lower face (OFFM bit clear) on every axis does not exclude a CLOSED upper side (mixed boxes): the periodic / open code without
+// the wall-value patch path is a separate instantiation of OFFM = 0 only
+template <typename T, int DIM, int H, int T1, int OFFM>
+static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+    bool closed = false;
+    for (int a = v.ax0; a < 3; ++a) closed = closed || v.bc[a][0] == PHIHIP_BC_CLOSED || v.bc[a][1] == PHIHIP_BC_CLOSED;
+    if constexpr (OFFM == 0) {
+        if (!closed) return launch_tile_consts<T, DIM, H, T1, OFFM, false>(ctx, v, vg, vel, out, dt, s);
+    }
+    return launch_tile_consts<T, DIM, H, T1, OFFM, true>(ctx, v, vg, vel, out, dt, s);
 }
 
 template <typename T, int DIM, int H, int T1>
