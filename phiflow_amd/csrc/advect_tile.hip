@@ -604,11 +604,14 @@ int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const 
             if (v.cn[c][a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a ring / window wider than the axis: not worth tiling (caller: gather kernels)
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     const bool f64 = v.dtype == PHIHIP_F64;
-    if (v.rank == 3 && halo == 3) {   // experiment: halo 1 with the 16-row tile (2 workgroups per CU)
+    // fp64, 3-D: halo 1 with the 16-row tile (2 workgroups per CU, half the halo rows per sample) -- same-box A/B after the r3 instruction diet:
+    // 384^3 closed 1.14 -> 0.94 ms, 256^3 periodic 0.232 -> 0.227 ms; fp32 keeps the 8-row tile (256^3: 0.119 vs 0.146 ms)
+    // (profiles/r03_time_advect.jsonl). halo == 3 selects the 16-row tile for fp32 as well (A/B measurements).
+    if (v.rank == 3 && (halo == 3 || (halo == 1 && f64))) {
         if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 16>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 16>(ctx, v, g, vel, out, dt, s)));
     } else if (v.rank == 3) {
         if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); }
-        else { if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 8>(ctx, v, g, vel, out, dt, s))); }
+        else PHIHIP_TRY((launch_tile<float, 3, 1, 8>(ctx, v, g, vel, out, dt, s)));      // (fp64 halo 1 took the 16-row tile above)
     } else {
         if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); }
         else { if (f64) PHIHIP_TRY((launch_tile<double, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); }
