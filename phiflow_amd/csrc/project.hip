@@ -681,20 +681,37 @@ __device__ __forceinline__ double obstacle_sdf(const ObstacleSet& s, int k, cons
     return dist;
 }
 
-// Can obstacle k reach the axis-aligned box [lo, hi] grown by `margin`? (bounding box of the geometry: half extents, the bounding radius
-// for a rotated box, unbounded along embedded axes.) Uniform per patch: whole workgroups skip obstacles that are nowhere near.
-__device__ __forceinline__ bool obstacle_near(const ObstacleSet& s, int k, const double (&lo)[3], const double (&hi)[3], double margin, int ax0) {
-    double rad = 0;
-    if (s.rotated[k]) {
-        for (int a = ax0; a < 3; ++a) rad += s.half[k][a] * s.half[k][a];
-        rad = sqrt(rad);
+// Bounding boxes of the obstacles of one launch in LDS (half extents, the bounding radius for a rotated box, unbounded along embedded
+// axes), built once per workgroup: the per-patch "is this obstacle anywhere near" test then reads LDS instead of walking the by-value
+// obstacle table in the kernel arguments (dependent scalar loads, ~0.2 us each, per obstacle and patch made these kernels latency-bound).
+__device__ __forceinline__ void obstacle_boxes(const ObstacleSet& s, int ax0, double (*box)[6]) {
+    const int k = threadIdx.x;
+    if (k < s.count) {
+        double rad = 0;
+        if (s.rotated[k]) {
+            for (int a = ax0; a < 3; ++a) rad += s.half[k][a] * s.half[k][a];
+            rad = sqrt(rad);
+        }
+        for (int a = 0; a < 3; ++a) {
+            const bool skip = a < ax0 || ((s.skip[k] >> a) & 1);
+            const double h = s.rotated[k] ? rad : (s.kind[k] == PHIHIP_OBSTACLE_SPHERE ? s.half[k][ax0] : s.half[k][a]);
+            box[k][2 * a] = skip ? -1e300 : s.center[k][a] - h;
+            box[k][2 * a + 1] = skip ? 1e300 : s.center[k][a] + h;
+        }
     }
-    for (int a = ax0; a < 3; ++a) {
-        if ((s.skip[k] >> a) & 1) continue;
-        const double h = s.rotated[k] ? rad : (s.kind[k] == PHIHIP_OBSTACLE_SPHERE ? s.half[k][ax0] : s.half[k][a]);
-        if (lo[a] - margin > s.center[k][a] + h || hi[a] + margin < s.center[k][a] - h) return false;
+    __syncthreads();
+}
+
+// bit k set: obstacle k can reach the axis-aligned box [lo, hi] grown by `margin` (uniform per patch: whole workgroups skip the others)
+__device__ __forceinline__ unsigned obstacles_near(const double (*box)[6], int count, const double (&lo)[3], const double (&hi)[3], double margin) {
+    unsigned near = 0;
+    for (int k = 0; k < count; ++k) {
+        bool hit = true;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) hit = hit && !(lo[a] - margin > box[k][2 * a + 1] || hi[a] + margin < box[k][2 * a]);
+        near |= hit ? (1u << k) : 0u;
     }
-    return true;
+    return near;
 }
 
 // r3: (4 x 64)-cell patches decoded without integer division (the 64-bit div / mod per cell and the fp64 geometry of EVERY obstacle for
@@ -702,6 +719,8 @@ __device__ __forceinline__ bool obstacle_near(const ObstacleSet& s, int k, const
 __global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s,
                                                                      int first_launch, uint8_t* accessible, int patches1, int patches2) {
     const double lower[3] = {lower0, lower1, lower2};
+    __shared__ double box[kObstaclesPerLaunch][6];
+    obstacle_boxes(s, g.ax0, box);
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
     const int npatch = g.n[0] * patches1 * patches2;
     for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
@@ -711,8 +730,7 @@ __global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, 
         const int last[3] = {i0, min(r0 + kPatchRows, g.n[1]) - 1, min(c0 + kPatchCols, g.n[2]) - 1};
         double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         for (int a = g.ax0; a < 3; ++a) { lo[a] = lower[a] + (first[a] + 0.5) * g.dx[a]; hi[a] = lower[a] + (last[a] + 0.5) * g.dx[a]; }
-        unsigned near = 0;
-        for (int k = 0; k < s.count; ++k) near |= obstacle_near(s, k, lo, hi, 1e-9 * (hi[2] - lo[2] + g.dx[2]), g.ax0) ? (1u << k) : 0u;
+        const unsigned near = obstacles_near(box, s.count, lo, hi, 1e-9 * (hi[2] - lo[2] + g.dx[2]));
         const int idx[3] = {i0, r0 + ty, c0 + tx};
         if (idx[1] >= g.n[1] || idx[2] >= g.n[2]) continue;
         if (!near && !first_launch) continue;            // nothing to change in this patch
@@ -759,6 +777,8 @@ __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, doub
     for (int a = g.ax0; a < 3; ++a) r2 += 0.25 * g.dx[a] * g.dx[a];
     const double radius = sqrt(r2);
     T* __restrict__ V = vc + (long long)b * total;
+    __shared__ double box[kObstaclesPerLaunch][6];
+    obstacle_boxes(s, g.ax0, box);
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
     const int npatch = c0n * patches1 * patches2;
     // position of sample i along axis a: faces of the component's own axis, cell centres otherwise
@@ -771,8 +791,7 @@ __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, doub
         double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         for (int a = g.ax0; a < 3; ++a) { lo[a] = pos(a, first[a]); hi[a] = pos(a, last[a]); }
         // the soft mask m = clip(1 - sdf / radius, 0, 1) vanishes farther than `radius` from the surface: such patches are left untouched
-        unsigned near = 0;
-        for (int k = 0; k < s.count; ++k) near |= obstacle_near(s, k, lo, hi, radius * 1.000001, g.ax0) ? (1u << k) : 0u;
+        const unsigned near = obstacles_near(box, s.count, lo, hi, radius * 1.000001);
         if (!near) continue;
         const int idx[3] = {i0, r0 + ty, cc0 + tx};
         if (idx[1] >= c1 || idx[2] >= c2) continue;
@@ -901,70 +920,109 @@ int run_build_cellflags(phihip_ctx* ctx, const GridView& v, const uint8_t* acces
 // ---------------------------------------------------------------------------------------------------------------------
 // diffuse.explicit, order 2: v_d += k dt * laplace(v_d) with the velocity's own padding (phi/physics/diffuse.py:13-60)
 // ---------------------------------------------------------------------------------------------------------------------
-// One thread per sample of one component, (4 rows x 64 columns) patches decoded without integer division (r3: the per-thread 64-bit
-// div / mod and the generic boundary walk of every tap made this 2-word streaming kernel run at 10 % of the HBM rate). Interior samples
-// read their six neighbours directly; samples on the boundary resolve each tap with the extrapolation: periodic wrap, OPEN = the edge
-// sample itself (zero gradient), CLOSED = the constant wall value.
+// A workgroup owns a (4 rows x 64 columns) column of samples of one component and marches over a chunk of a0 planes (like divergence_kernel):
+// the a0 neighbours of a sample are the values the thread read one plane earlier / reads one plane ahead -- every plane is read from HBM
+// once, where the one-thread-per-sample form of rounds 1-2 pulled each plane into three different L2s (FETCH_SIZE 1.8x the array) and spent
+// a 64-bit div / mod per sample: 2-word kernel at 10 % of the HBM rate. The in-plane taps (row +-1, column +-1) and their boundary rule are
+// resolved once per thread: periodic wrap, OPEN = the edge sample itself (zero gradient), CLOSED = the constant wall value.
 // ADJ: the adjoint (I + k dt L)^T as a GATHER (no atomics): the stencil is symmetric in the interior; a clamped tap returns its weight to
 // the edge sample itself, a constant tap contributes nothing, a wrapped tap is the wrapped neighbour.  gin += (...)^T gout.
 template <typename T, bool ADJ>
-__global__ __launch_bounds__(kBlock) void diffuse_kernel(VelGrid g, int ca, const T* __restrict__ vin, T* __restrict__ vout, T kdt, int patches1, int patches2) {
+__global__ __launch_bounds__(kBlock) void diffuse_kernel(VelGrid g, int ca, const T* __restrict__ vin, T* __restrict__ vout, T kdt, int tiles1, int tiles2, int chunk) {
     const int b = blockIdx.y;
     const int c0n = g.cn[ca][0], c1 = g.cn[ca][1], c2 = g.cn[ca][2];
     const long long bb = (long long)b * g.ccells[ca];
     const T* __restrict__ I = vin + bb;
     T* __restrict__ O = vout + bb;
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
-    const int npatch = c0n * patches1 * patches2;
+    const int bid = xcd_order(blockIdx.x, gridDim.x);       // neighbouring columns share an XCD's L2 (their halo rows / columns)
+    const int t2 = bid % tiles2;
+    const int t1 = (bid / tiles2) % tiles1;
+    const int ch = bid / (tiles2 * tiles1);
+    const int i1 = t1 * kPatchRows + ty, i2 = t2 * kPatchCols + tx;
+    if (i1 >= c1 || i2 >= c2) return;
+    const int p0 = ch * chunk, p1 = min(p0 + chunk, c0n);
+    if (p0 >= p1) return;
     T w[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) w[ax] = ax < g.ax0 ? T(0) : kdt / (T)(g.dx[ax] * g.dx[ax]);
-    const int stride[3] = {c1 * c2, c2, 1};
-    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-        int idx[3], r0, cc0;
-        decode_patch(patch, patches1, patches2, idx[0], r0, cc0);
-        idx[1] = r0 + ty;
-        idx[2] = cc0 + tx;
-        if (idx[1] >= c1 || idx[2] >= c2) continue;
-        const int f = (idx[0] * c1 + idx[1]) * c2 + idx[2];
-        const T c = I[f];
-        T acc = T(0);          // forward: sum_ax w (lo + hi - 2 c); adjoint: sum of the weighted neighbour gradients
-        T centre = T(1);       // adjoint: coefficient of gout[f] itself
+    // in-plane taps: offset within the plane, or the rule that replaces the sample outside the array (1: the centre value / nothing for
+    // the adjoint, 2: the wall constant / nothing); `self` counts the clamped taps of this sample (adjoint: weight returned to the centre)
+    int off[4];
+    int rule[4];
+    T cval[4];
+    T centre = T(1);
+    const int o_c = i1 * c2 + i2;
+    {
+        const int idx[2] = {i1, i2}, n[2] = {c1, c2}, st[2] = {c2, 1};
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            if (ax < g.ax0) continue;
-            const int n = g.cn[ca][ax], i = idx[ax];
-            T lo, hi;
-            if (i > 0) lo = I[f - stride[ax]];
-            else {
-                const int code = g.bc[ax][0];
-                if (code == PHIHIP_BC_PERIODIC) lo = I[f + (n - 1) * stride[ax]];
-                else if (code == PHIHIP_BC_OPEN) lo = ADJ ? T(0) : c;
-                else lo = ADJ ? T(0) : (T)g.bcv[ax][0][ca];
-                if (ADJ && code == PHIHIP_BC_OPEN) centre += w[ax];           // the clamped tap of this sample read the sample itself
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int k = 2 * a + side, ax = a + 1;
+                const int j = idx[a] + (side ? 1 : -1);
+                off[k] = o_c + (side ? st[a] : -st[a]);
+                rule[k] = 0;
+                cval[k] = T(0);
+                if (ax >= g.ax0 && (j < 0 || j >= n[a])) {
+                    const int code = g.bc[ax][side];
+                    if (code == PHIHIP_BC_PERIODIC) off[k] = o_c + (side ? -(n[a] - 1) * st[a] : (n[a] - 1) * st[a]);
+                    else if (code == PHIHIP_BC_OPEN) { rule[k] = 1; off[k] = o_c; if (ADJ) centre += w[ax]; }
+                    else { rule[k] = 2; off[k] = o_c; cval[k] = (T)g.bcv[ax][side][ca]; }
+                }
+                if (ax < g.ax0) { rule[k] = 2; off[k] = o_c; }      // (unused axis of a 2-D grid: weight 0 anyway)
             }
-            if (i < n - 1) hi = I[f + stride[ax]];
-            else {
-                const int code = g.bc[ax][1];
-                if (code == PHIHIP_BC_PERIODIC) hi = I[f - (n - 1) * stride[ax]];
-                else if (code == PHIHIP_BC_OPEN) hi = ADJ ? T(0) : c;
-                else hi = ADJ ? T(0) : (T)g.bcv[ax][1][ca];
-                if (ADJ && code == PHIHIP_BC_OPEN) centre += w[ax];
-            }
-            if (ADJ) { acc += w[ax] * (lo + hi); centre -= T(2) * w[ax]; }
-            else acc += w[ax] * ((lo - c) + (hi - c));
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax)
+        if (ax >= g.ax0) centre -= T(2) * w[ax];
+    const long long ps = (long long)c1 * c2;
+    const bool has0 = g.ax0 == 0;
+    // value of the a0 neighbour plane `p` of this thread's column under the boundary rule (uniform decision); `c_edge` = the edge sample
+    auto plane_val = [&](int p, T c_edge, T& centre_adj) -> T {
+        if (p >= 0 && p < c0n) return I[(long long)p * ps + o_c];
+        const int side = p < 0 ? 0 : 1;
+        const int code = g.bc[0][side];
+        if (code == PHIHIP_BC_PERIODIC) return I[(long long)(p < 0 ? p + c0n : p - c0n) * ps + o_c];
+        if (code == PHIHIP_BC_OPEN) { if (ADJ) centre_adj += w[0]; return ADJ ? T(0) : c_edge; }
+        return ADJ ? T(0) : (T)g.bcv[0][side][ca];
+    };
+    T cur = I[(long long)p0 * ps + o_c];
+    T dummy = T(0);
+    T prev = has0 ? plane_val(p0 - 1, cur, dummy) : T(0);
+    for (int p = p0; p < p1; ++p) {
+        const long long po = (long long)p * ps;
+        T cadj = T(0);
+        T next = T(0);
+        if (has0) {
+            next = plane_val(p + 1, cur, cadj);
+            if (ADJ && p == 0 && g.bc[0][0] == PHIHIP_BC_OPEN) cadj += w[0];      // (the lower clamped tap of plane 0: prev was formed before the loop)
         }
-        if (ADJ) O[f] += centre * c + acc;
-        else O[f] = c + acc;
+        T tap[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T v = I[po + off[k]];
+            tap[k] = rule[k] == 0 ? v : (ADJ ? T(0) : (rule[k] == 1 ? cur : cval[k]));
+        }
+        T acc;
+        if (ADJ) acc = (centre + cadj) * cur + w[0] * (prev + next) + w[1] * (tap[0] + tap[1]) + w[2] * (tap[2] + tap[3]);
+        else acc = cur + (w[0] * ((prev - cur) + (next - cur)) + w[1] * ((tap[0] - cur) + (tap[1] - cur)) + w[2] * ((tap[2] - cur) + (tap[3] - cur)));
+        if (ADJ) O[po + o_c] += acc;
+        else O[po + o_c] = acc;
+        prev = cur;
+        cur = next;
     }
 }
 
 template <typename T, bool ADJ>
 static void launch_diffuse(const VelGrid& g, int ca, int batch, const void* in, void* out, double kdt, hipStream_t s) {
-    const int patches1 = ceil_div(g.cn[ca][1], kPatchRows), patches2 = ceil_div(g.cn[ca][2], kPatchCols);
-    const long long npatch = (long long)g.cn[ca][0] * patches1 * patches2;
-    const int nblk = npatch < 16384 ? (int)npatch : 16384;
-    hipLaunchKernelGGL((diffuse_kernel<T, ADJ>), dim3(nblk, batch), dim3(kBlock), 0, s, g, ca, (const T*)in, (T*)out, (T)kdt, patches1, patches2);
+    const int tiles1 = ceil_div(g.cn[ca][1], kPatchRows), tiles2 = ceil_div(g.cn[ca][2], kPatchCols);
+    const long long tiles = (long long)tiles1 * tiles2;
+    int chunks = (int)((4096 + tiles - 1) / tiles);                     // ~4096 workgroups per batch entry when the grid allows
+    chunks = chunks > g.cn[ca][0] ? g.cn[ca][0] : (chunks < 1 ? 1 : chunks);
+    const int chunk = ceil_div(g.cn[ca][0], chunks);
+    chunks = ceil_div(g.cn[ca][0], chunk);
+    hipLaunchKernelGGL((diffuse_kernel<T, ADJ>), dim3((unsigned)(tiles * chunks), batch), dim3(kBlock), 0, s, g, ca, (const T*)in, (T*)out, (T)kdt, tiles1, tiles2, chunk);
 }
 
 int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, hipStream_t s) {

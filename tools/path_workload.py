@@ -123,9 +123,9 @@ def group_f32_256(ctx, dev, n, reps):
         ctx.build_cellflags(grid, acc.data_ptr(), 0, 1, flags.data_ptr())
         ctx.apply_obstacles(grid, obs, 2, P(tmp))
     sync(dev)
-    note(r"obstacle_accessible_kernel", "f3 obstacle rasterisation (2 obstacles)", 1 * N, 0.25, "write 1 byte per cell")
+    note(r"obstacle_accessible_kernel", "f3 obstacle rasterisation (2 obstacles; 1 byte per cell: not a bandwidth kernel -- fp64 geometry only in patches near an obstacle)", 1 * N, 0.25, "write 1 byte per cell")
     note(r"cellflags_kernel", "a7 packed stencil flags", 2 * N, 0.5, "read + write 1 byte per cell")
-    note(r"apply_obstacles_kernel<float>", "f3 apply_boundary_conditions, one component per launch (2 obstacles, fp64 geometry)", 2 * w * N, 2, "read + write one component")
+    note(r"apply_obstacles_kernel<float>", "f3 apply_boundary_conditions, one component per launch (2 obstacles; samples farther than one cell radius from every obstacle are neither read nor written: the bytes by construction are an upper bound)", 2 * w * N, 2, "read + write one component")
 
     # math.grid_sample + adjoint (fields on different grids, rk4)
     npts = N
