@@ -127,10 +127,7 @@ __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { r
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
 __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? 4 : 2) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
-                                                                  int* __restrict__ flags, T* __restrict__ dump, int part) {
-    // part: 0 = every workgroup; 1 = only workgroups whose staged window stays clear of CLOSED sides (launched as the CONSTS = false code);
-    // 2 = only those that cross one (CONSTS = true). Boxes with walls run BOTH launches: three quarters of their workgroups never need the
-    // wall-value patch path, whose code costs every workgroup of its instantiation registers and spill traffic (see CONSTS).
+                                                                  int* __restrict__ flags, T* __restrict__ dump) {
     using C = AdvTile<T, DIM, H, T1>;
     constexpr int A0 = 3 - DIM;
     constexpr int T2 = C::T2, TY = C::TY, S = C::S, P1 = C::P1, P2 = C::P2, PLANE = C::PLANE, NC = C::NC, NP = C::NP, KP = C::KP;
@@ -171,12 +168,11 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // domains altogether) run the fill without a single select.
     bool has_const = false;
 #pragma unroll
-    for (int c = A0; (CONSTS || part != 0) && c < 3; ++c) {
+    for (int c = A0; CONSTS && c < 3; ++c) {
         has_const = has_const || (g.bc[1][0] == PHIHIP_BC_CLOSED && lo1 - H < 0) || (g.bc[1][1] == PHIHIP_BC_CLOSED && lo1 + T1 + H > g.cn[c][1]) ||
                     (g.bc[2][0] == PHIHIP_BC_CLOSED && lo2 - H < 0) || (g.bc[2][1] == PHIHIP_BC_CLOSED && lo2 + T2 + H > g.cn[c][2]);
         if (DIM == 3) has_const = has_const || (g.bc[0][0] == PHIHIP_BC_CLOSED && pb - H < 0) || (g.bc[0][1] == PHIHIP_BC_CLOSED && pe + H > g.cn[c][0]);
     }
-    if ((part == 1 && has_const) || (part == 2 && !has_const)) return;      // the other launch owns this workgroup (uniform)
 
     // ---- per-thread fill descriptors (plane-invariant) -------------------------------------------------------------------------
     // element kp of component c: row ty + kp TY, column tx of the window. eoff = in-plane element offset after wrap / clamp;
@@ -250,32 +246,35 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // constant sides are patched in when the plane enters the ring (cold, uniform: only workgroups whose window crosses a CLOSED side).
     // Every per-thread predicate is recomputed here from the (optimiser-opaque) thread coordinates: kept across planes they are lane
     // masks in SGPR pairs -- ~100 of them, spilled and reloaded every plane, also by the workgroups that never take this path.
-    auto patch_plane = [&](int i0, int slot) {
-        // after store_plane, by the thread that stored the element: wall values overwrite the staged samples beyond a CLOSED side
+    auto patch_plane = [&](int i0, T (&R)[3][KP], T& tailv) {
         int tyo = ty, txo = tx, tido = tid;
         opaque_int(tyo); opaque_int(txo); opaque_int(tido);
         // PhiML pads axis after axis: the LAST axis outside a constant side decides (a2 over a1 over a0)
 #pragma unroll
         for (int c = A0; c < 3; ++c) {
             const int k = DIM == 3 ? const_side(i0, g.cn[c][0], g.bc[0][0], g.bc[0][1]) : 0;       // uniform
+            // (values first, selects after: a select between two kernel-argument LOADS becomes a per-lane address + flat load)
             const T k00 = g.bcv[0][0][c], k01 = g.bcv[0][1][c], k10 = g.bcv[1][0][c], k11 = g.bcv[1][1][c], k20 = g.bcv[2][0][c], k21 = g.bcv[2][1][c];
             const T pv = k == 1 ? k00 : k01;
-            T* L = lds + ((c - A0) * NP + slot) * PLANE;
             const int cside = const_side(lo2 - H + txo, g.cn[c][2], g.bc[2][0], g.bc[2][1]);
             const T cv = cside == 1 ? k20 : k21;
 #pragma unroll
             for (int kp = 0; kp < KP; ++kp) {
+                T v = R[c][kp];
                 const int j = const_side(lo1 - H + tyo + kp * TY, g.cn[c][1], g.bc[1][0], g.bc[1][1]);
                 const T rv = j == 1 ? k10 : k11;
-                const T v = cside ? cv : (j ? rv : pv);
-                if ((k | j | cside) && (kp < KP - 1 || last_ok)) L[(tyo + kp * TY) * P2 + txo] = v;
+                v = k ? pv : v;
+                v = j ? rv : v;
+                v = cside ? cv : v;
+                R[c][kp] = v;
             }
             if (tido < C::NTAIL && tido / (P1 * 2 * H) == c - A0) {
                 const int tr = (tido % (P1 * 2 * H)) / (2 * H), tq = T2 + tido % (2 * H);
                 const int rs = const_side(lo1 - H + tr, g.cn[c][1], g.bc[1][0], g.bc[1][1]), cs = const_side(lo2 - H + tq, g.cn[c][2], g.bc[2][0], g.bc[2][1]);
                 const T rv = rs == 1 ? k10 : k11, cv2 = cs == 1 ? k20 : k21;
-                const T v = cs ? cv2 : (rs ? rv : pv);
-                if (k | rs | cs) L[tr * P2 + tq] = v;
+                tailv = k ? pv : tailv;
+                tailv = rs ? rv : tailv;
+                tailv = cs ? cv2 : tailv;
             }
         }
     };
@@ -397,8 +396,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
             if (MODE_ == 2) compute_plane(p);
         }
         if (ks >= k_lo && ks <= k_hi) {
+            if (CONSTS && has_const) patch_plane(ks, Rst, tail_st);
             store_plane(slot_of(ks), Rst, tail_st);
-            if (CONSTS && has_const) patch_plane(ks, slot_of(ks));
         }
         __syncthreads();
     };
@@ -515,15 +514,8 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
         PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
         flags = (int*)ctx->ws_adv_flags.ptr;
         T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
-        if (CONSTS) {   // walls: interior workgroups through the lean code, the ones at a wall through the code with the patch path
-            hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, false>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
-                               (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump, 1);
-            hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, true>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
-                               (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump, 2);
-        } else {
-            hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, false>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
-                               (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump, 0);
-        }
+        hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
+                           (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump);
         return PHIHIP_OK;
     };
     if (DIM == 3 && ctx->adv_chunk > 0) {

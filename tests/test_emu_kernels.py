@@ -68,7 +68,7 @@ def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
         pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
-@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:2])
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:3])
 def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
     """ backward kernels vs finite differences / linear responses of the oracle's forward functions (fp64) """
     rng = np.random.default_rng(14)
@@ -76,6 +76,7 @@ def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
     s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
     s_consts = [(0.0, 0.25)] * len(res)
     pc.check_advect_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
+    pc.check_advect_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts, dt=0.2)      # CFL < 1 everywhere: every scatter goes through the LDS windows
     pc.check_project_backward(emu_ctx, MEM, dom, grid, rng)
     pc.check_mac_cormack_and_diffuse_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
 
