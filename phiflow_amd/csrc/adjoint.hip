@@ -7,11 +7,6 @@
 //   * make_incompressible: the implicit-function adjoint of the linear solve (A is symmetric: one more CG solve with the
 //     same matrix-free operator), divergence and gradient swap roles (G^T = -D with homogeneous boundary values).
 // Every kernel recomputes the forward quantities it needs; nothing is taped on the device.
-// (r3) The scatters of the advection adjoints accumulate in LDS: a workgroup owns a BRICK of output samples; at CFL < 1 every tap of the
-// field lookup lies within the brick grown by one cell, the taps of the velocity means within the brick grown by one face, so the
-// contributions are summed with LDS atomics into windows of UNRESOLVED indices and flushed once per window element -- the boundary rule
-// (wrap / clamp / constant side: no gradient) is applied at the flush. 17 global atomics per sample become ~4; a tap outside the window
-// (CFL > 1 locally) still goes to global memory directly.
 #include "advect_common.hpp"
 #include "march_dispatch.hpp"
 
@@ -22,116 +17,10 @@ struct Comp3w {
     T* p[3];
 };
 
-// ---- LDS accumulation windows ----------------------------------------------------------------------------------------------
-constexpr int kBrick1 = 8, kBrick2 = 32;        // one sample row per thread row, 32 lanes along the fast axis
-template <int DIM> constexpr int brick0() { return DIM == 3 ? 4 : 1; }        // planes per brick
-template <int DIM> constexpr int brick_rows() { return DIM == 3 ? 1 : 4; }    // sample rows per thread (2-D bricks are 32 x 32)
-template <int DIM> constexpr int brick_f_elems() { return (brick0<DIM>() + (DIM == 3 ? 2 : 0)) * (kBrick1 * brick_rows<DIM>() + 2) * (kBrick2 + 2); }
-template <int DIM> constexpr int brick_v_elems() { return (brick0<DIM>() + (DIM == 3 ? 1 : 0)) * (kBrick1 * brick_rows<DIM>() + 1) * (kBrick2 + 1); }
-
-// the index a tap of make_pair resolves to, as ONE index: false = outside a constant side (the tap is a constant: no gradient)
-__device__ __forceinline__ bool resolve_index(int i, int n, int code_lo, int code_hi, int& r) {
-    if ((unsigned)i < (unsigned)n) { r = i; return true; }
-    if (code_lo == PHIHIP_BC_PERIODIC) { r = wrap_index(i, n); return true; }
-    if (i < 0) { r = 0; return code_lo != PHIHIP_BC_CLOSED; }
-    r = n - 1;
-    return code_hi != PHIHIP_BC_CLOSED;
-}
-
-// a window of unresolved indices in LDS: origin and extents as plain scalars (the compiler keeps them in SGPRs)
-struct Win {
-    int o0, o1, o2, e0, e1, e2;
-    __device__ __forceinline__ int elems() const { return e0 * e1 * e2; }
-};
-
-// adds v at the unresolved index (i0, i1, i2) if the window holds it
-template <typename T>
-__device__ __forceinline__ bool win_add(T* w, const Win& W, int i0, int i1, int i2, T v) {
-    const int l0 = i0 - W.o0, l1 = i1 - W.o1, l2 = i2 - W.o2;
-    const bool in = (unsigned)l0 < (unsigned)W.e0 && (unsigned)l1 < (unsigned)W.e1 && (unsigned)l2 < (unsigned)W.e2;
-    if (in) {
-#ifdef __HIP_DEVICE_COMPILE__
-        // typed as an LDS pointer: ds_add, and the compiler cannot fold this and the caller's global fallback into one flat atomic
-        typedef __attribute__((address_space(3))) T lds_elem;
-        __hip_atomic_fetch_add((lds_elem*)(w + (l0 * W.e1 + l1) * W.e2 + l2), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        w[(l0 * W.e1 + l1) * W.e2 + l2] += v;
-#endif
-    }
-    return in;
-}
-
-template <typename T>
-__device__ __forceinline__ void win_clear(T* w, int elems) {
-    for (int k = threadIdx.x; k < elems; k += kBlock) w[k] = T(0);
-}
-
-// window -> array G of shape (n0, n1, n2) under the boundary codes bc (after a barrier): one global atomic per touched element
-template <typename T>
-__device__ __forceinline__ void win_flush(const T* w, const Win& W, T* __restrict__ G, int n0, int n1, int n2, const int (&bc)[3][2]) {
-    const int tot = W.elems();
-    for (int k = threadIdx.x; k < tot; k += kBlock) {
-        const T v = w[k];
-        if (v == T(0)) continue;
-        const int l2 = k % W.e2, t = k / W.e2;
-        const int l1 = t % W.e1, l0 = t / W.e1;
-        int r0, r1, r2;
-        const bool ok0 = resolve_index(W.o0 + l0, n0, bc[0][0], bc[0][1], r0);
-        const bool ok1 = resolve_index(W.o1 + l1, n1, bc[1][0], bc[1][1], r1);
-        const bool ok2 = resolve_index(W.o2 + l2, n2, bc[2][0], bc[2][1], r2);
-        if (ok0 && ok1 && ok2) atomicAdd(G + ((long long)r0 * n1 + r1) * n2 + r2, v);
-    }
-}
-
-// The brick of output samples a workgroup owns: origin from the workgroup index (bricks counted along the two fast axes by nb1 x nb2)
-template <int DIM>
-__device__ __forceinline__ void brick_origin(int nb1, int nb2, int& g0, int& g1, int& g2) {
-    const int bid = blockIdx.x;
-    g2 = (bid % nb2) * kBrick2;
-    g1 = ((bid / nb2) % nb1) * (kBrick1 * brick_rows<DIM>());
-    g0 = DIM == 3 ? (bid / (nb2 * nb1)) * brick0<DIM>() : 0;
-}
-
-// F window: taps of the field lookup = the brick grown by one cell along every live axis
-template <int DIM>
-__device__ __forceinline__ Win field_window(int g0, int g1, int g2) {
-    Win W;
-    W.o0 = DIM == 3 ? g0 - 1 : 0; W.e0 = DIM == 3 ? brick0<DIM>() + 2 : 1;
-    W.o1 = g1 - 1; W.e1 = kBrick1 * brick_rows<DIM>() + 2;
-    W.o2 = g2 - 1; W.e2 = kBrick2 + 2;
-    return W;
-}
-
-// V window of velocity component cb: the samples that the means at the brick's samples read -- STAG (samples = faces of component ca):
-// cells (m - 1, m) along ca and faces (s, s + 1) along cb; centred samples: faces (s, s + 1) along cb
-template <int DIM, bool STAG>
-__device__ __forceinline__ Win velocity_window(const VelGrid& g, int g0, int g1, int g2, int ca, int cb) {
-    Win W;
-    W.o0 = DIM == 3 ? g0 : 0; W.e0 = brick0<DIM>();
-    W.o1 = g1; W.e1 = kBrick1 * brick_rows<DIM>();
-    W.o2 = g2; W.e2 = kBrick2;
-    if (cb == 0) { W.o0 -= g.off[0]; W.e0 += 1; }
-    if (cb == 1) { W.o1 -= g.off[1]; W.e1 += 1; }
-    if (cb == 2) { W.o2 -= g.off[2]; W.e2 += 1; }
-    if (STAG) {
-        if (ca == 0) { W.o0 += g.off[0] - 1; W.e0 += 1; }
-        if (ca == 1) { W.o1 += g.off[1] - 1; W.e1 += 1; }
-        if (ca == 2) { W.o2 += g.off[2] - 1; W.e2 += 1; }
-    }
-    return W;
-}
-
-// integer part of a lookup coordinate exactly as lookup_pairs forms it
-template <typename T>
-__device__ __forceinline__ int lookup_floor(T c) {
-    return (int)fmin(fmax(floor(c), T(-1073741824.0)), T(1073741823.0));
-}
-
-// d(out)/d(frac_a) of the multilinear gather and scatter of g * w into the taps of the field gradient; with a window the scatter goes
-// there (il* = unresolved index of tap 0 per axis) and only taps outside of it to global memory
+// d(out)/d(frac_a) of the multilinear gather and scatter of g * w into the taps of the field gradient
 template <typename T, int DIM>
 __device__ __forceinline__ void gather_adjoint(const T* __restrict__ F, T* __restrict__ gF, const AxisPair<T> (&ax)[3], const T (&fr)[3], T g,
-                                               T (&dfr)[3], T* win = nullptr, const Win* W = nullptr, int il0 = 0, int il1 = 0, int il2 = 0) {
+                                               T (&dfr)[3]) {
     dfr[0] = dfr[1] = dfr[2] = T(0);
 #pragma unroll
     for (int corner = 0; corner < (1 << DIM); ++corner) {
@@ -150,10 +39,7 @@ __device__ __forceinline__ void gather_adjoint(const T* __restrict__ F, T* __res
             is_const = false;
             const int off = (DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2];
             val = F[off];
-            if (gF) {
-                const bool in = win && win_add(win, *W, (DIM == 3 ? il0 + b0 : 0), il1 + b1, il2 + b2, g * (w0 * w1 * w2));
-                if (!in) atomicAdd(gF + off, g * (w0 * w1 * w2));
-            }
+            if (gF) atomicAdd(gF + off, g * (w0 * w1 * w2));
         }
         (void)is_const;
         if (DIM == 3) dfr[0] += val * (b0 ? T(1) : T(-1)) * w1 * w2;
@@ -164,8 +50,7 @@ __device__ __forceinline__ void gather_adjoint(const T* __restrict__ F, T* __res
 
 // adjoint of face_velocity: du[cb] (physical units) scattered into the velocity gradient
 template <typename T, int DIM, int CA>
-__device__ __forceinline__ void face_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], int f, const T (&du)[3],
-                                                      T* win = nullptr, int g0 = 0, int g1 = 0, int g2 = 0) {
+__device__ __forceinline__ void face_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], int f, const T (&du)[3]) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
 #pragma unroll
@@ -189,24 +74,13 @@ __device__ __forceinline__ void face_velocity_adjoint(const VelGrid& g, const Co
             for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
-                    if (!pa.cst[ia] && !pb.cst[ib]) {
-                        bool in = false;
-                        if (win) {      // unresolved index in component cb's array
-                            const Win W = velocity_window<DIM, true>(g, g0, g1, g2, ca, cb);
-                            const int u0 = ca == 0 ? m - 1 + ia : (cb == 0 ? s + ib : idx[0]);
-                            const int u1 = ca == 1 ? m - 1 + ia : (cb == 1 ? s + ib : idx[1]);
-                            const int u2 = ca == 2 ? m - 1 + ia : (cb == 2 ? s + ib : idx[2]);
-                            in = win_add(win + cb * brick_v_elems<DIM>(), W, u0, u1, u2, q);
-                        }
-                        if (!in) atomicAdd(C + rest + pa.off[ia] + pb.off[ib], q);
-                    }
+                    if (!pa.cst[ia] && !pb.cst[ib]) atomicAdd(C + rest + pa.off[ia] + pb.off[ib], q);
         }
     }
 }
 
 template <typename T, int DIM>
-__device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], const T (&du)[3],
-                                                        T* win = nullptr, int g0 = 0, int g1 = 0, int g2 = 0) {
+__device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], const T (&du)[3]) {
     constexpr int A0 = 3 - DIM;
 #pragma unroll
     for (int cb = A0; cb < 3; ++cb) {
@@ -218,38 +92,16 @@ __device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const 
 #pragma unroll
         for (int ax = A0; ax < 3; ++ax)
             if (ax != cb) rest += idx[ax] * stride[ax];
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
-            if (!pb.cst[ib]) {
-                bool in = false;
-                if (win) {
-                    const Win W = velocity_window<DIM, false>(g, g0, g1, g2, 0, cb);
-                    const int sft = ib - g.off[cb];
-                    in = win_add(win + cb * brick_v_elems<DIM>(), W, idx[0] + (cb == 0 ? sft : 0), idx[1] + (cb == 1 ? sft : 0), idx[2] + (cb == 2 ? sft : 0),
-                                 du[cb] * T(0.5));
-                }
-                if (!in) atomicAdd(C + rest + pb.off[ib], du[cb] * T(0.5));
-            }
-    }
-}
-
-template <typename T, int DIM, bool STAG>
-__device__ __forceinline__ void flush_velocity_windows(const T* lds_v, const VelGrid& g, const Comp3w<T>& gvel, int b, int g0, int g1, int g2, int ca) {
-#pragma unroll
-    for (int cb = 3 - DIM; cb < 3; ++cb) {
-        if (STAG && cb == ca) continue;
-        const Win W = velocity_window<DIM, STAG>(g, g0, g1, g2, ca, cb);
-        win_flush(lds_v + cb * brick_v_elems<DIM>(), W, gvel.p[cb] + (long long)b * g.ccells[cb], g.cn[cb][0], g.cn[cb][1], g.cn[cb][2], g.bc);
+        if (!pb.cst[0]) atomicAdd(C + rest + pb.off[0], du[cb] * T(0.5));
+        if (!pb.cst[1]) atomicAdd(C + rest + pb.off[1], du[cb] * T(0.5));
     }
 }
 
 template <typename T, int DIM, int CA>
 __global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g, CComp3a<T> field, CComp3a<T> vel, const T* __restrict__ gout,
-                                                                      T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel, T dt, int nb1, int nb2) {
+                                                                      T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel, T dt) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
-    __shared__ T lds_f[brick_f_elems<DIM>()];
-    __shared__ T lds_v[3 * brick_v_elems<DIM>()];
     const int b = blockIdx.y;
     const int total = (int)g.ccells[ca];
     const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
@@ -258,51 +110,33 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g,
     int bc[3][2];
     T cv[3][2];
     comp_rule<T>(g, ca, bc, cv);
-    int g0, g1, g2;
-    brick_origin<DIM>(nb1, nb2, g0, g1, g2);
-    const Win WF = field_window<DIM>(g0, g1, g2);
-    if (GF) win_clear(lds_f, brick_f_elems<DIM>());
-    if (want_gvel) win_clear(lds_v, 3 * brick_v_elems<DIM>());
-    __syncthreads();
-    const int tx = threadIdx.x % kBrick2, ty = threadIdx.x / kBrick2;
-    for (int k0 = 0; k0 < brick0<DIM>(); ++k0)
-        for (int kr = 0; kr < brick_rows<DIM>(); ++kr) {
-            int idx[3] = {g0 + k0, g1 + ty + kr * kBrick1, g2 + tx};
-            if (idx[0] >= n[0] || idx[1] >= n[1] || idx[2] >= n[2]) continue;
-            const int f = (idx[0] * n[1] + idx[1]) * n[2] + idx[2];
-            const T go = gout[(long long)b * total + f];
-            T u[3];
-            face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
-            T coord[3] = {T(0), T(0), T(0)};
-            int ilo[3] = {0, 0, 0};
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
+        T coord[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int a = A0; a < 3; ++a) {
-                coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
-                ilo[a] = lookup_floor(coord[a]);
-            }
-            AxisPair<T> ax[3];
-            T fr[3], dfr[3];
-            lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
-            gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr, lds_f, &WF, ilo[0], ilo[1], ilo[2]);
-            if (want_gvel) {
-                T du[3] = {T(0), T(0), T(0)};
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+        AxisPair<T> ax[3];
+        T fr[3], dfr[3];
+        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
+        if (want_gvel) {
+            T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
-                face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du, lds_v, g0, g1, g2);
-            }
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
+            face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du);
         }
-    __syncthreads();
-    if (GF) win_flush(lds_f, WF, GF, n[0], n[1], n[2], g.bc);
-    if (want_gvel) flush_velocity_windows<T, DIM, true>(lds_v, g, gvel, b, g0, g1, g2, ca);
+    }
 }
 
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ sfield, CComp3a<T> vel,
                                                                      const T* __restrict__ gout, T* __restrict__ gs, Comp3w<T> gvel, int want_gvel,
-                                                                     T dt, int nb1, int nb2) {
+                                                                     T dt) {
     constexpr int A0 = 3 - DIM;
-    __shared__ T lds_f[brick_f_elems<DIM>()];
-    __shared__ T lds_v[3 * brick_v_elems<DIM>()];
     const int b = blockIdx.y;
     const int total = (int)g.cells;
     const int n[3] = {g.n[0], g.n[1], g.n[2]};
@@ -311,42 +145,26 @@ __global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, 
     int bc[3][2];
     T cv[3][2];
     scalar_rule<T>(sb, bc, cv);
-    int g0, g1, g2;
-    brick_origin<DIM>(nb1, nb2, g0, g1, g2);
-    const Win WF = field_window<DIM>(g0, g1, g2);
-    if (GF) win_clear(lds_f, brick_f_elems<DIM>());
-    if (want_gvel) win_clear(lds_v, 3 * brick_v_elems<DIM>());
-    __syncthreads();
-    const int tx = threadIdx.x % kBrick2, ty = threadIdx.x / kBrick2;
-    for (int k0 = 0; k0 < brick0<DIM>(); ++k0)
-        for (int kr = 0; kr < brick_rows<DIM>(); ++kr) {
-            int idx[3] = {g0 + k0, g1 + ty + kr * kBrick1, g2 + tx};
-            if (idx[0] >= n[0] || idx[1] >= n[1] || idx[2] >= n[2]) continue;
-            const int f = (idx[0] * n[1] + idx[1]) * n[2] + idx[2];
-            const T go = gout[(long long)b * total + f];
-            T u[3];
-            center_velocity<T, DIM>(g, vel, b, idx, u);
-            T coord[3] = {T(0), T(0), T(0)};
-            int ilo[3] = {0, 0, 0};
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        center_velocity<T, DIM>(g, vel, b, idx, u);
+        T coord[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int a = A0; a < 3; ++a) {
-                coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
-                ilo[a] = lookup_floor(coord[a]);
-            }
-            AxisPair<T> ax[3];
-            T fr[3], dfr[3];
-            lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
-            gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr, lds_f, &WF, ilo[0], ilo[1], ilo[2]);
-            if (want_gvel) {
-                T du[3] = {T(0), T(0), T(0)};
+        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+        AxisPair<T> ax[3];
+        T fr[3], dfr[3];
+        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
+        if (want_gvel) {
+            T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);
-                center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du, lds_v, g0, g1, g2);
-            }
+            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);
+            center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
         }
-    __syncthreads();
-    if (GF) win_flush(lds_f, WF, GF, n[0], n[1], n[2], sb.bc);
-    if (want_gvel) flush_velocity_windows<T, DIM, false>(lds_v, g, gvel, b, g0, g1, g2, 0);
+    }
 }
 
 // adjoint of centered_to_staggered_kernel: gs[cell] += 0.5 * scale * gout[face] for both cells of every stored face
@@ -403,11 +221,9 @@ template <typename T, int DIM, int CA, bool STAG>
 __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield,
                                                                  CComp3a<T> vel, const T* __restrict__ fwd, const T* __restrict__ gout,
                                                                  T* __restrict__ gfwd, T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel,
-                                                                 T dt, T ch, int nb1, int nb2) {
+                                                                 T dt, T ch) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
-    __shared__ T lds_f[brick_f_elems<DIM>()];          // window of g_fwd: own sample + the taps of the forward lookup
-    __shared__ T lds_v[3 * brick_v_elems<DIM>()];
     const int b = blockIdx.y;
     const int total = STAG ? (int)g.ccells[ca] : (int)g.cells;
     const int n[3] = {STAG ? g.cn[ca][0] : g.n[0], STAG ? g.cn[ca][1] : g.n[1], STAG ? g.cn[ca][2] : g.n[2]};
@@ -418,76 +234,49 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
     int bc[3][2];
     T cv[3][2];
     if (STAG) comp_rule<T>(g, ca, bc, cv); else scalar_rule<T>(sb, bc, cv);
-    int g0, g1, g2;
-    brick_origin<DIM>(nb1, nb2, g0, g1, g2);
-    const Win WF = field_window<DIM>(g0, g1, g2);
-    win_clear(lds_f, brick_f_elems<DIM>());
-    if (want_gvel) win_clear(lds_v, 3 * brick_v_elems<DIM>());
-    __syncthreads();
-    const int tx = threadIdx.x % kBrick2, ty = threadIdx.x / kBrick2;
-    for (int k0 = 0; k0 < brick0<DIM>(); ++k0)
-        for (int kr = 0; kr < brick_rows<DIM>(); ++kr) {
-            int idx[3] = {g0 + k0, g1 + ty + kr * kBrick1, g2 + tx};
-            if (idx[0] >= n[0] || idx[1] >= n[1] || idx[2] >= n[2]) continue;
-            const int f = (idx[0] * n[1] + idx[1]) * n[2] + idx[2];
-            const T go = gout[(long long)b * total + f];
-            T u[3];
-            if (STAG) face_velocity<T, DIM, CA>(g, vel, b, idx, f, u); else center_velocity<T, DIM>(g, vel, b, idx, u);
-            T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
-            int ilo[3] = {0, 0, 0};
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        const T go = gout[(long long)b * total + f];
+        int idx[3];
+        unravel(f, n[1], n[2], idx);
+        T u[3];
+        if (STAG) face_velocity<T, DIM, CA>(g, vel, b, idx, f, u); else center_velocity<T, DIM>(g, vel, b, idx, u);
+        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
 #pragma unroll
-            for (int a = A0; a < 3; ++a) {
-                const T sft = u[a] * (dt * (T)g.rdx[a]);
-                cb_[a] = (T)idx[a] - sft;
-                cf_[a] = (T)idx[a] + sft;
-                ilo[a] = lookup_floor(cf_[a]);
-            }
-            AxisPair<T> ax[3];
-            T fr[3];
-            lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
-            const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-            const T nv = W[f] + ch * (F[f] - bwd);
-            AxisPair<T> axl[3];
-            T frl[3];
-            if (STAG) cb_[ca] += (T)g.off[ca] - T(0.5);
-            lookup_pairs<T, DIM>(cb_, n, bc, cv, axl, frl);
-            T lo, hi;
-            int off_lo, off_hi;
-            gather_minmax_arg<T, DIM>(F, axl, lo, hi, off_lo, off_hi);
-            if (nv < lo) {
-                if (off_lo >= 0) atomicAdd(GF + off_lo, go);
-            } else if (nv > hi) {
-                if (off_hi >= 0) atomicAdd(GF + off_hi, go);
-            } else {
-                win_add(lds_f, WF, idx[0], idx[1], idx[2], go);      // own sample of g_fwd: always inside the window
-                atomicAdd(GF + f, ch * go);
-                const T gb = -ch * go;
-                T dfr[3];
-                gather_adjoint<T, DIM>(W, GW, ax, fr, gb, dfr, lds_f, &WF, ilo[0], ilo[1], ilo[2]);
-                if (want_gvel) {
-                    T du[3] = {T(0), T(0), T(0)};
+        for (int a = A0; a < 3; ++a) {
+            const T sft = u[a] * (dt * (T)g.rdx[a]);
+            cb_[a] = (T)idx[a] - sft;
+            cf_[a] = (T)idx[a] + sft;
+        }
+        AxisPair<T> ax[3];
+        T fr[3];
+        lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+        const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
+        const T nv = W[f] + ch * (F[f] - bwd);
+        AxisPair<T> axl[3];
+        T frl[3];
+        if (STAG) cb_[ca] += (T)g.off[ca] - T(0.5);
+        lookup_pairs<T, DIM>(cb_, n, bc, cv, axl, frl);
+        T lo, hi;
+        int off_lo, off_hi;
+        gather_minmax_arg<T, DIM>(F, axl, lo, hi, off_lo, off_hi);
+        if (nv < lo) {
+            if (off_lo >= 0) atomicAdd(GF + off_lo, go);
+        } else if (nv > hi) {
+            if (off_hi >= 0) atomicAdd(GF + off_hi, go);
+        } else {
+            atomicAdd(GW + f, go);
+            atomicAdd(GF + f, ch * go);
+            const T gb = -ch * go;
+            T dfr[3];
+            gather_adjoint<T, DIM>(W, GW, ax, fr, gb, dfr);
+            if (want_gvel) {
+                T du[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt * (T)g.rdx[a]);   // cf_a = idx_a + dt u_a / dx_a
-                    if (STAG) face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du, lds_v, g0, g1, g2);
-                    else center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du, lds_v, g0, g1, g2);
-                }
+                for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt * (T)g.rdx[a]);   // cf_a = idx_a + dt u_a / dx_a
+                if (STAG) face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du); else center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
             }
         }
-    __syncthreads();
-    win_flush(lds_f, WF, GW, n[0], n[1], n[2], bc);
-    if (want_gvel) {
-        if (STAG) flush_velocity_windows<T, DIM, true>(lds_v, g, gvel, b, g0, g1, g2, ca);
-        else flush_velocity_windows<T, DIM, false>(lds_v, g, gvel, b, g0, g1, g2, 0);
     }
-}
-
-// bricks of a sample array of shape n (DIM live axes): workgroups and the counts along the two fast axes
-template <int DIM>
-static inline unsigned brick_count(const int n[3], int& nb1, int& nb2) {
-    nb2 = (n[2] + kBrick2 - 1) / kBrick2;
-    nb1 = (n[1] + kBrick1 * brick_rows<DIM>() - 1) / (kBrick1 * brick_rows<DIM>());
-    const int nb0 = DIM == 3 ? (n[0] + brick0<DIM>() - 1) / brick0<DIM>() : 1;
-    return (unsigned)nb0 * nb1 * nb2;
 }
 
 static inline int bwd_blocks(long long total) {
@@ -502,19 +291,13 @@ static void launch_advect_staggered_bwd(const GridView& v, const VelGrid& g, con
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
     const int want = gv ? 1 : 0;
-    int nb1, nb2;
-    unsigned nblk;
-    if (DIM == 3) {
-        nblk = brick_count<DIM>(v.cn[0], nb1, nb2);
-        hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 0>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ff, vv, (const T*)gout[0],
-                           gf ? (T*)gf[0] : nullptr, gg, want, (T)dt, nb1, nb2);
-    }
-    nblk = brick_count<DIM>(v.cn[1], nb1, nb2);
-    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ff, vv, (const T*)gout[1],
-                       gf ? (T*)gf[1] : nullptr, gg, want, (T)dt, nb1, nb2);
-    nblk = brick_count<DIM>(v.cn[2], nb1, nb2);
-    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 2>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, ff, vv, (const T*)gout[2],
-                       gf ? (T*)gf[2] : nullptr, gg, want, (T)dt, nb1, nb2);
+    if (DIM == 3)
+        hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 0>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                           (const T*)gout[0], gf ? (T*)gf[0] : nullptr, gg, want, (T)dt);
+    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 1>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                       (const T*)gout[1], gf ? (T*)gf[1] : nullptr, gg, want, (T)dt);
+    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 2>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
+                       (const T*)gout[2], gf ? (T*)gf[2] : nullptr, gg, want, (T)dt);
 }
 
 int run_advect_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3], const void* const gout[3],
@@ -537,10 +320,8 @@ static void launch_advect_centered_bwd(const GridView& v, const VelGrid& g, cons
                                        const void* gout, void* gs, void* const gv[3], double dt, hipStream_t s) {
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
-    int nb1, nb2;
-    const unsigned nblk = brick_count<DIM>(v.n, nb1, nb2);
-    hipLaunchKernelGGL((advect_centered_bwd_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
-                       (const T*)gout, (T*)gs, gg, gv ? 1 : 0, (T)dt, nb1, nb2);
+    hipLaunchKernelGGL((advect_centered_bwd_kernel<T, DIM>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
+                       (const T*)gout, (T*)gs, gg, gv ? 1 : 0, (T)dt);
 }
 
 int run_advect_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
@@ -591,19 +372,13 @@ static void launch_mc_staggered_bwd(const GridView& v, const VelGrid& g, const v
     ScalarBc sb;
     memset(&sb, 0, sizeof(sb));
     const int want = gv ? 1 : 0;
-    int nb1, nb2;
-    unsigned nblk;
-    if (DIM == 3) {
-        nblk = brick_count<DIM>(v.cn[0], nb1, nb2);
-        hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 0, true>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ff, (const T*)nullptr, vv,
-                           (const T*)fwd[0], (const T*)gout[0], (T*)gfwd[0], (T*)gf[0], gg, want, (T)dt, (T)ch, nb1, nb2);
-    }
-    nblk = brick_count<DIM>(v.cn[1], nb1, nb2);
-    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 1, true>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ff, (const T*)nullptr, vv,
-                       (const T*)fwd[1], (const T*)gout[1], (T*)gfwd[1], (T*)gf[1], gg, want, (T)dt, (T)ch, nb1, nb2);
-    nblk = brick_count<DIM>(v.cn[2], nb1, nb2);
-    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, true>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ff, (const T*)nullptr, vv,
-                       (const T*)fwd[2], (const T*)gout[2], (T*)gfwd[2], (T*)gf[2], gg, want, (T)dt, (T)ch, nb1, nb2);
+    if (DIM == 3)
+        hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 0, true>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                           (const T*)nullptr, vv, (const T*)fwd[0], (const T*)gout[0], (T*)gfwd[0], (T*)gf[0], gg, want, (T)dt, (T)ch);
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 1, true>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                       (const T*)nullptr, vv, (const T*)fwd[1], (const T*)gout[1], (T*)gfwd[1], (T*)gf[1], gg, want, (T)dt, (T)ch);
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, true>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
+                       (const T*)nullptr, vv, (const T*)fwd[2], (const T*)gout[2], (T*)gfwd[2], (T*)gf[2], gg, want, (T)dt, (T)ch);
 }
 
 // scratch layout for the MacCormack adjoints: [fwd | g_fwd] per component, 256-byte aligned
@@ -654,10 +429,8 @@ static void launch_mc_centered_bwd(const GridView& v, const VelGrid& g, const Sc
     CComp3a<T> none{{nullptr, nullptr, nullptr}};
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
-    int nb1, nb2;
-    const unsigned nblk = brick_count<DIM>(v.n, nb1, nb2);
-    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, false>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, none, (const T*)sfield, vv,
-                       (const T*)fwd, (const T*)gout, (T*)gfwd, (T*)gs, gg, gv ? 1 : 0, (T)dt, (T)ch, nb1, nb2);
+    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, none,
+                       (const T*)sfield, vv, (const T*)fwd, (const T*)gout, (T*)gfwd, (T*)gs, gg, gv ? 1 : 0, (T)dt, (T)ch);
 }
 
 int run_mac_cormack_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
