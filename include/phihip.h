@@ -235,6 +235,18 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
 int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3],
                             void* const out[3], double diffusivity_dt, void* stream);
 
+/* diffuse.implicit (phi/physics/diffuse.py:63-92; Heat_Flow.ipynb, Burgers.ipynb): out = (I - k dt L)^-1 field by CG from x0 = field
+ * (solve_linear(sharpen, y=field, solve) with sharpen(x) = explicit(x, k, -dt)). The solver is the CG of the pressure path on the field's
+ * own lattice -- every staggered component separately -- with the field's own extrapolation: PERIODIC wraps, OPEN = zero-gradient,
+ * CLOSED = the constant bc_val / s_val, whose contribution is the affine part of `sharpen` and moves to the right-hand side.
+ * solve: method CG or CG-adaptive, tolerances relative to the right-hand side like phihip_cg_solve. info (optional):
+ * [rank][batch] for the staggered form (component-major), [batch] for the centred form. out must not alias the input. */
+int phihip_diffuse_implicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3],
+                            double diffusivity_dt, const phihip_solve* solve, phihip_solve_info* info, void* stream);
+int phihip_diffuse_implicit_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* s, const int32_t s_bc[3][2],
+                                     const double s_val[3][2], void* out, double diffusivity_dt, const phihip_solve* solve,
+                                     phihip_solve_info* info, void* stream);
+
 /* ---- f5: backward passes (vector-Jacobian products) -- PhiFlow is differentiable through its backends' autodiff
  *          (tests/commit/physics/test_fluid.py:55-73, tests/commit/test_colab_fluids_tutorial.py:11-34) ------------------- */
 /* Gradients are ACCUMULATED (+=) into grad_* buffers (zero them first); NULL skips that gradient. */

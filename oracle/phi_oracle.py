@@ -1006,3 +1006,29 @@ def diffuse_explicit(v: List[np.ndarray], diffusivity: float, dt: float, dom: Do
     for _ in range(substeps):
         v = [vd + vd.dtype.type(diffusivity * dt / substeps) * laplace_component(vd, d, dom) for d, vd in enumerate(v)]
     return v
+
+
+def diffuse_implicit_centered(s: np.ndarray, diffusivity: float, dt: float, dom: Domain, s_codes, s_consts=None, rtol: float = 1e-5,
+                              atol: float = 0.0, max_iter: int = 1000):
+    """ diffuse.implicit of a CenteredGrid (phi/physics/diffuse.py:63-92): solve_linear(sharpen, y=s, Solve('CG', x0=s)) with
+    sharpen(x) = explicit(x, diffusivity, -dt). `sharpen` is affine when a constant extrapolation is not zero; solve_linear then solves
+    the linear part against y - sharpen(0) (jit_compile_linear separates matrix and bias). Returns (u, SolveInfo). """
+    sharpen = lambda x: diffuse_explicit_centered(x, diffusivity, -dt, dom, s_codes, s_consts)
+    bias = sharpen(np.zeros_like(s))
+    return cg(lambda x: sharpen(x) - bias, s - bias, s, rtol, atol, max_iter)
+
+
+def diffuse_implicit(v: List[np.ndarray], diffusivity: float, dt: float, dom: Domain, rtol: float = 1e-5, atol: float = 0.0, max_iter: int = 1000):
+    """ diffuse.implicit of a StaggeredGrid: the Laplacian acts on every component separately (laplace_component), so the solve
+    decouples per component -- solved one after the other here with the tolerance relative to the COMPONENT's right-hand side
+    (PhiML reduces over the whole staggered tensor; with a tolerance both stop within the same distance of the same solution).
+    Returns ([u_d], [SolveInfo_d]). """
+    out, infos = [], []
+    for d, vd in enumerate(v):
+        dtype = vd.dtype.type
+        sharpen = lambda x, d=d, dtype=dtype: x - dtype(diffusivity * dt) * laplace_component(x, d, dom)
+        bias = sharpen(np.zeros_like(vd))
+        u, info = cg(lambda x: sharpen(x) - bias, vd - bias, vd, rtol, atol, max_iter)
+        out.append(u)
+        infos.append(info)
+    return out, infos

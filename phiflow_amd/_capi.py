@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
     "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
-    "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered",
+    "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
     "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg",
 )
@@ -209,6 +209,9 @@ class Library:
         d.phihip_make_incompressible.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p,
                                                  c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_diffuse_explicit.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
+        d.phihip_diffuse_implicit.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, POINTER(Solve), POINTER(SolveInfo), c_void_p]
+        d.phihip_diffuse_implicit_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3), c_void_p,
+                                                       c_double, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_profile_enable.argtypes = [c_void_p, c_int]
         d.phihip_profile_read.argtypes = [c_void_p, POINTER(c_int32 * K_COUNT), POINTER(c_double * K_COUNT), c_int]
         d.phihip_set_tuning.argtypes = [c_void_p, c_int, c_int, c_int]
@@ -450,6 +453,20 @@ class Context:
     def diffuse_explicit(self, grid, velocity, out, diffusivity_dt, stream=0):
         self.lib.check(self.lib.dll.phihip_diffuse_explicit(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)),
                                                             ctypes.byref(ptr3(out)), float(diffusivity_dt), stream or None))
+
+    def diffuse_implicit(self, grid, velocity, out, diffusivity_dt, solve: Solve, stream=0):
+        """ diffuse.implicit of a staggered field: (I - k dt L) out = velocity per component, CG from x0 = velocity; returns rank x batch SolveInfo """
+        info = (SolveInfo * (grid.rank * grid.batch))()
+        self.lib.check(self.lib.dll.phihip_diffuse_implicit(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(out)),
+                                                            float(diffusivity_dt), ctypes.byref(solve), info, stream or None))
+        return list(info)
+
+    def diffuse_implicit_centered(self, grid, s, s_bc, s_val, out, diffusivity_dt, solve: Solve, stream=0):
+        bc, val = self._scalar_bc(grid, s_bc, s_val)
+        info = (SolveInfo * grid.batch)()
+        self.lib.check(self.lib.dll.phihip_diffuse_implicit_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), out,
+                                                                     float(diffusivity_dt), ctypes.byref(solve), info, stream or None))
+        return list(info)
 
     def profile_enable(self, enable: bool):
         self.lib.check(self.lib.dll.phihip_profile_enable(self.handle, int(bool(enable))))

@@ -783,6 +783,32 @@ int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void
     return run_diffuse(ctx, v, u, o, diffusivity_dt, s);
 }
 
+int phihip_diffuse_implicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3], double diffusivity_dt,
+                            const phihip_solve* solve, phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));
+    PHIHIP_TRY(check_ptrs(v, (const void* const*)out, "out"));
+    for (int d = 0; d < v.rank; ++d) PHIHIP_REQUIRE(out[d] != velocity[d], "diffuse_implicit: out[%d] must not alias the input", d);
+    PHIHIP_REQUIRE(diffusivity_dt >= 0.0, "diffuse_implicit: diffusivity * dt must be >= 0 (the operator I - k dt L is not positive definite otherwise)");
+    PHIHIP_TRY(check_solve(solve));
+    const void* u[3];
+    void* o[3];
+    remap3(v, velocity, u);
+    remap3w(v, out, o);
+    return run_diffuse_implicit(ctx, v, u, o, diffusivity_dt, solve, info, s);
+}
+
+int phihip_diffuse_implicit_centered(phihip_ctx* ctx, const phihip_grid* grid, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
+                                     void* out, double diffusivity_dt, const phihip_solve* solve, phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(sfield && out && s_bc && sfield != out, "diffuse_implicit_centered: NULL or aliased argument");
+    PHIHIP_REQUIRE(diffusivity_dt >= 0.0, "diffuse_implicit_centered: diffusivity * dt must be >= 0");
+    PHIHIP_TRY(check_scalar_bc(v, s_bc, "diffuse_implicit_centered"));
+    PHIHIP_TRY(check_solve(solve));
+    note_align(v, sfield); note_align(v, out);
+    return run_diffuse_implicit_centered(ctx, v, sfield, s_bc, s_val, out, diffusivity_dt, solve, info, s);
+}
+
 int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, int family, int32_t out[6]) {
     PHIHIP_REQUIRE(ctx != nullptr && out != nullptr, "query_plan: NULL argument");
     PHIHIP_REQUIRE(family >= 0 && family < 5, "tuning family must be 0 (apply / residual), 1 (matvec), 2 (update), 3 (r-only update) or 4 (fused single-reduction iteration)");

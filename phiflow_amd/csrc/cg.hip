@@ -24,6 +24,14 @@ namespace phihip {
 //     relative traffic = 1 + (2 / chunk) * (source words / all words)
 // and the best score (x a small per-family tile preference) wins; for small grids the serial march of a chunk (latency) replaces the
 // traffic term (see best_chunk).
+// coefficients of the operator the marching kernels apply: ident * I + scale * L (GridView::op_*; default 0 * I + 1 * L = the pressure operator)
+template <typename T>
+static inline void set_operator(MarchArgs<T>& a, const GridView& v) {
+    const double sc = v.op_custom ? v.op_scale : 1.0;
+    a.w0 = (T)(sc / (v.dx[0] * v.dx[0])); a.w1 = (T)(sc / (v.dx[1] * v.dx[1])); a.w2 = (T)(sc / (v.dx[2] * v.dx[2]));
+    a.ident = (T)(v.op_custom ? v.op_ident : 0.0);
+}
+
 static PlanKey plan_key(const GridView& v, int mask_batch, bool flags, int family) {
     return PlanKey{v.dtype, v.rank, v.n[0], v.n[1], v.n[2], v.batch, flags ? 1 : 0, mask_batch > 1 ? 1 : 0, family, v.unaligned ? 0 : 1};
 }
@@ -37,7 +45,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     for (int ax = 0; ax < 3; ++ax)
         for (int s = 0; s < 2; ++s) {
             const int code = v.bc[ax][s];
-            g->nb[ax][s] = code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_CLOSED ? NB_CLAMP : NB_ZERO);
+            g->nb[ax][s] = v.op_custom ? v.op_rule[ax][s] : (code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_CLOSED ? NB_CLAMP : NB_ZERO));
         }
     g->flags_per_batch = mask_batch > 1 ? 1 : 0;
     c->batch = v.batch;
@@ -284,7 +292,7 @@ static int laplace_apply_t(phihip_ctx* ctx, const GridView& v, const uint8_t* fl
     a.a = (const T*)p;
     a.o1 = (T*)out;
     a.flags = flags;
-    a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    set_operator(a, v);
     a.prologue = PRO_NONE;
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY, flags != nullptr, g, a, s));
@@ -423,7 +431,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
             MarchArgs<T> a;
             memset(&a, 0, sizeof(a));
             a.flags = flags;
-            a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+            set_operator(a, v);
             a.prologue = PRO_NONE;                       // alpha = beta = 0: every vector stays zero
             a.part1 = part; a.part2 = part + (size_t)v.batch * maxblk;
             if (family == FAM_MATVEC) { a.a = r; a.b = d0; a.o1 = d1; }
@@ -503,7 +511,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
             MarchArgs<T> a;
             memset(&a, 0, sizeof(a));
             a.flags = flags;
-            a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+            set_operator(a, v);
             a.prologue = PRO_NONE;
             a.part1 = pp; a.part2 = pp + (size_t)v.batch * maxblk;
             float best = 1e30f;
@@ -647,7 +655,7 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
     memset(&base, 0, sizeof(base));
     base.flags = flags;
     base.prm = prm;
-    base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    set_operator(base, v);
 
     int vc = 0;     // which half of the (r, w, s) pairs holds the current vectors
     int pc = 0;     // which (gamma, delta) partial pair the next CG1 prologue reads
@@ -756,7 +764,7 @@ static int cg1_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int m
 template <typename T>
 static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x,
                 const phihip_solve* solve, phihip_solve_info* info, const double* shift, hipStream_t s) {
-    if (ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) {
+    if (!v.op_custom && ctx->small_cg && v.cells <= small_cg_limit(ctx, v)) {      // (the single-kernel solver knows the pressure operator only)
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     }
@@ -830,7 +838,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     memset(&base, 0, sizeof(base));
     base.flags = flags;
     base.prm = prm;
-    base.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); base.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); base.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    set_operator(base, v);
 
     // ---- r0 = y - A x0 ; d0 = r0 (the first MATVEC runs with beta = 0 and reads r in place of d_old: no zeroed buffer needed) ----
     {
@@ -995,7 +1003,7 @@ static MarchArgs<T> slab_args(const GridView& v, const uint8_t* flags, const phi
     memset(&a, 0, sizeof(a));
     a.flags = flags;
     if (solve) { a.prm.rtol = solve->rel_tol; a.prm.atol = solve->abs_tol; a.prm.max_iter = solve->max_iterations; }
-    a.w0 = (T)(1.0 / (v.dx[0] * v.dx[0])); a.w1 = (T)(1.0 / (v.dx[1] * v.dx[1])); a.w2 = (T)(1.0 / (v.dx[2] * v.dx[2]));
+    set_operator(a, v);
     return a;
 }
 
@@ -1147,7 +1155,7 @@ int run_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_ba
                                  : cg_t<float>(ctx, v, flags, mask_batch, rhs, x, solve, info, nullptr, s);
 }
 
-bool cg_uses_marching(const phihip_ctx* ctx, const GridView& v) { return !(ctx->small_cg && v.cells <= small_cg_limit(ctx, v)); }
+bool cg_uses_marching(const phihip_ctx* ctx, const GridView& v) { return v.op_custom || !(ctx->small_cg && v.cells <= small_cg_limit(ctx, v)); }
 
 int run_cg_balancing(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, void* rhs, void* x, const phihip_solve* solve,
                      phihip_solve_info* info, const double* shift, hipStream_t s) {

@@ -54,6 +54,12 @@ struct GridView {
     long long ccells[3];       // cells per stored component
     int halo[2];               // slab decomposition: planes beyond the lower / upper a0 side come from a neighbour rank
     bool unaligned;            // some caller buffer of this call is not 16-byte aligned: the marching kernels take the scalar path
+    // Linear operator of the CG kernels. Default (op_custom == 0): the pressure operator L = masked_laplace with the pressure's neighbour
+    // rule derived from bc. Custom: op_ident * I + op_scale * L on a lattice of n cells with an explicit NeighbourRule per side
+    // (implicit diffusion: I - k dt L on the lattice of a centred scalar or of one staggered component, the field's own extrapolation)
+    int op_custom;
+    double op_ident, op_scale;
+    int op_rule[3][2];
 };
 
 int make_view(const phihip_grid* grid, GridView* out);
@@ -237,6 +243,9 @@ int run_divergence(phihip_ctx*, const GridView&, const void* const v[3], const u
 int run_scale_faces(phihip_ctx*, const GridView&, void* const v[3], const void* const m[3], hipStream_t);
 int run_grad_subtract(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* const v[3], hipStream_t);
 int run_diffuse(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double kdt, hipStream_t);
+int run_diffuse_implicit(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double kdt, const phihip_solve*, phihip_solve_info*, hipStream_t);
+int run_diffuse_implicit_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2], void* out, double kdt,
+                                  const phihip_solve*, phihip_solve_info*, hipStream_t);
 int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
 int run_export_residuals(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_export_relative_residual(phihip_ctx*, int batch, double* out, hipStream_t);

@@ -1082,4 +1082,81 @@ int run_diffuse_centered(phihip_ctx* ctx, const GridView& v, const void* sfield,
     return PHIHIP_OK;
 }
 
+// ---- diffuse.implicit (phi/physics/diffuse.py:63-92): solve_linear(sharpen, y = field, x0 = field) with sharpen(x) = explicit(x, k, -dt) ---------
+// The CG of the pressure path runs on the field's own lattice with the operator I - k dt L (GridView::op_*: ident = 1, scale = -k dt) and the
+// field's own extrapolation as the neighbour rule: PERIODIC -> wrap, OPEN (zero-gradient) -> clamp, CLOSED (constant c) -> zero ghost, the
+// constant's contribution being the affine part of `sharpen`, which solve_linear moves to the right-hand side (A x = y - sharpen(0)):
+// rhs = field + k dt c / dx_a^2 in the samples next to such a side.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void implicit_rhs_kernel(VelGrid g, int ca, const T* __restrict__ in, T* __restrict__ rhs, T kdt) {
+    const int b = blockIdx.y;
+    const long long total = g.ccells[ca];
+    const int n1 = g.cn[ca][1], n2 = g.cn[ca][2];
+    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
+        const int i2 = (int)(f % n2);
+        const long long t = f / n2;
+        const int idx[3] = {(int)(t / n1), (int)(t % n1), i2};
+        T add = T(0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (a < g.ax0) continue;
+            const T w = kdt * (T)(g.rdx[a] * g.rdx[a]);
+            if (idx[a] == 0 && g.bc[a][0] == PHIHIP_BC_CLOSED) add += w * (T)g.bcv[a][0][ca];
+            if (idx[a] == g.cn[ca][a] - 1 && g.bc[a][1] == PHIHIP_BC_CLOSED) add += w * (T)g.bcv[a][1][ca];
+        }
+        rhs[(long long)b * total + f] = in[(long long)b * total + f] + add;
+    }
+}
+
+// one lattice (a centred scalar or one staggered component, described as component `ca` of g): out = (I - k dt L)^-1 in, CG from x0 = in
+static int diffuse_implicit_lattice(phihip_ctx* ctx, const GridView& v, const VelGrid& g, int ca, const void* in, void* out, double kdt,
+                                    const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    GridView w = v;
+    bool affine = false;
+    for (int a = 0; a < 3; ++a) {
+        w.n[a] = g.cn[ca][a];
+        for (int side = 0; side < 2; ++side) {
+            const int code = a < v.ax0 ? PHIHIP_BC_PERIODIC : g.bc[a][side];
+            w.op_rule[a][side] = code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_OPEN ? NB_CLAMP : NB_ZERO);
+            if (a >= v.ax0 && code == PHIHIP_BC_CLOSED && g.bcv[a][side][ca] != 0.0) affine = true;
+        }
+    }
+    w.cells = g.ccells[ca];
+    w.halo[0] = w.halo[1] = 0;
+    w.op_custom = 1;
+    w.op_ident = 1.0;
+    w.op_scale = -kdt;
+    if (w.cells >= (1LL << 31)) { set_error("diffuse_implicit: more than 2^31 samples per batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
+    const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
+    const size_t bytes = (size_t)v.batch * w.cells * esize;
+    const void* rhs = in;
+    if (affine) {
+        PHIHIP_TRY(ensure_buffer(ctx->ws_adj_q, bytes));
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        const long long nb = (w.cells + kBlock - 1) / kBlock;
+        const dim3 grid((unsigned)(nb < 65536 ? nb : 65536), v.batch);
+        if (v.dtype == PHIHIP_F64) hipLaunchKernelGGL(implicit_rhs_kernel<double>, grid, dim3(kBlock), 0, s, g, ca, (const double*)in, (double*)ctx->ws_adj_q.ptr, kdt);
+        else hipLaunchKernelGGL(implicit_rhs_kernel<float>, grid, dim3(kBlock), 0, s, g, ca, (const float*)in, (float*)ctx->ws_adj_q.ptr, (float)kdt);
+        PHIHIP_CHECK_HIP(hipGetLastError());
+        rhs = ctx->ws_adj_q.ptr;
+    }
+    PHIHIP_CHECK_HIP(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, s));      // x0 = field (diffuse.py:90-91)
+    return run_cg(ctx, w, nullptr, 1, rhs, out, solve, info, s);
+}
+
+int run_diffuse_implicit(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, const phihip_solve* solve,
+                         phihip_solve_info* info, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    for (int ca = v.ax0; ca < 3; ++ca)
+        PHIHIP_TRY(diffuse_implicit_lattice(ctx, v, g, ca, vin[ca], vout[ca], kdt, solve, info ? info + (size_t)(ca - v.ax0) * v.batch : nullptr, s));
+    return PHIHIP_OK;
+}
+
+int run_diffuse_implicit_centered(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2], void* out,
+                                  double kdt, const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
+    const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    const VelGrid g = scalar_as_component(v, sb);
+    return diffuse_implicit_lattice(ctx, v, g, 2, sfield, out, kdt, solve, info, s);
+}
+
 }  // namespace phihip

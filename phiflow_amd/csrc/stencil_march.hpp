@@ -184,7 +184,8 @@ struct MarchArgs {
     int pend_buf;          // UPDATE_R: index of the d buffer this launch reads (recorded with the pending flag)
     unsigned long long* host_flags;   // MATVEC: host-mapped [batch] array that receives (seq << 32 | continue flag), or nullptr
     unsigned int seq;
-    T w0, w1, w2;          // 1 / dx^2 per internal axis
+    T w0, w1, w2;          // scale / dx^2 per internal axis (scale = 1: the pressure operator)
+    T ident;               // the kernels apply ident * S + sum_a w_a (d^2 S)_a: 0 for the pressure, 1 for implicit diffusion (I - k dt L)
     // slab decomposition along a0: one plane [batch][n1][n2] of the source array(s) below plane 0 / above plane
     // n0 - 1, received from the neighbouring rank; read where g.nb[0][side] == NB_HALO
     const T* a_lo; const T* a_hi;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     if (f & 8u) r += (dn.v[v] - c) * p.w1;
                     if (f & 16u) r += (lo2 - c) * p.w2;
                     if (f & 32u) r += (hi2 - c) * p.w2;
+                    r = fma(p.ident, c, r);
                     if (!(f & 64u)) r = c;   // inactive cell: identity row (fluid.py:202)
                 } else {
                     // flux form like the reference (differences of neighbours first, then the difference of the two face
@@ -646,6 +648,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     const T t1 = ((dn.v[v] - c) - (c - up.v[v])) * p.w1;
                     if (DIM3) r = ((Sn[rr].v[v] - c) - (c - Sp[rr].v[v])) * p.w0 + t1 + t2;
                     else r = t1 + t2;
+                    r = fma(p.ident, c, r);
                 }
                 q.v[v] = r;
             }

@@ -1,5 +1,5 @@
 """
-Explicit diffusion on the HIP backend (reference: phi/physics/diffuse.py:13-60).
+Explicit and implicit diffusion on the HIP backend (reference: phi/physics/diffuse.py:13-92).
 """
 import warnings
 
@@ -55,3 +55,49 @@ def explicit(u: Field, diffusivity: float, dt: float, substeps: int = 1, order: 
             be.ctx.diffuse_explicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, False, be.stream())
             cur = out
     return u.with_values(cur)
+
+
+def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int = 2) -> Field:
+    """ Implicit Euler diffusion (`diffuse.implicit`, phi/physics/diffuse.py:63-92; Heat_Flow.ipynb, Burgers.ipynb): solves
+    `(1 - diffusivity * dt * laplace) u = field` with CG from `x0 = field` -- `solve_linear(sharpen, y=field, solve)` with
+    `sharpen(x) = explicit(x, diffusivity, -dt)`. The solver is the matrix-free CG of the pressure path (same kernels, operator
+    I - k dt L) on the field's own lattice and extrapolation; every component of a StaggeredGrid is solved separately (the
+    operator does not couple them). `solve`: `Solve('CG' | 'CG-adaptive', rel_tol, abs_tol, max_iterations)`; raises
+    `NotConverged` / `Diverged` like `solve_linear` unless suppressed. Not differentiable on this backend (use `explicit`). """
+    from .field import require_plain, _torch_dtype_code
+    from .solve import Solve, SolveInfo
+    from .fluid import _raise_if_failed
+    from . import _capi
+    require_plain(field, 'diffuse.implicit')
+    if order != 2:
+        raise NotImplementedError("HIP backend: diffuse.implicit implements order=2 only")
+    solve = Solve('CG') if solve is None else solve
+    if solve.x0 is not None:
+        raise NotImplementedError("HIP backend: diffuse.implicit starts from x0 = field (the reference's default); pass solve.x0=None")
+    vals = field.values if field.is_staggered else [field.values]
+    if autodiff.needs_grad(*vals):
+        raise NotImplementedError("HIP backend: diffuse.implicit has no backward pass; use diffuse.explicit inside differentiated code")
+    be = field.backend
+    fp64 = field.dtype == torch.float64
+    csolve = solve.to_c(fp64)
+    kdt = float(diffusivity) * float(dt)
+    if field.is_staggered:
+        cur = [t.contiguous() for t in field.values]
+        out = [torch.empty_like(t) for t in cur]
+        infos = be.ctx.diffuse_implicit(field.grid_struct(), _ptrs(cur), _ptrs(out), kdt, csolve, be.stream())
+        result = field.with_values(out)
+    else:
+        s_codes, s_vals = resolve(field.boundary, field.dims)
+        s_val = [[s_vals[a][s][0] if isinstance(field.boundary.side(d, bool(s)), ConstantExtrapolation) else 0.0 for s in range(2)]
+                 for a, d in enumerate(field.dims)]
+        grid = _capi.make_grid(field.spatial_rank, _torch_dtype_code(field.dtype), field.batch_size, list(field.resolution.values()), field.bounds.lower,
+                               field.bounds.upper, [[0 if c == 0 else 2 for c in pair] for pair in s_codes])
+        cur = field.values.contiguous()
+        out = torch.empty_like(cur)
+        infos = be.ctx.diffuse_implicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, csolve, be.stream())
+        result = field.with_values(out)
+    info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+    _raise_if_failed(info)
+    result.solve_info = info
+    return result

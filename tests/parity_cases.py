@@ -564,6 +564,46 @@ def check_diffuse(ctx, mem, dom, grid, dtype, rng, kdt=0.1):
         assert err <= tol(dtype)['stencil'] * 4, f"diffuse[{d}] rel err {err}"
 
 
+def check_diffuse_implicit(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, kdt=None):
+    """ diffuse.implicit (phi/physics/diffuse.py:63-92) through the C ABI vs the oracle: the staggered velocity (component lattices with
+    the velocity's extrapolation, constant wall values = affine part) and a centred scalar with its own extrapolation. Both run CG from
+    x0 = field; compared at a tolerance tight enough that the stopping iteration does not matter, plus the residual of the HIP result
+    through the ORACLE's operator and (centred, fp64: identical algorithm) the iteration counts. """
+    B = grid.batch
+    fp64 = np.dtype(dtype) == np.float64
+    rtol = 1e-11 if fp64 else 2e-6
+    bound = 1e-8 if fp64 else 2e-4
+    kdt = kdt if kdt is not None else 1.5 * min(dom.dx) ** 2          # beyond the explicit stability limit (0.5 dx^2 / D)
+    s = C.Solve(rtol, 0.0, 500, 50, 10, 0)
+    # staggered
+    v = random_velocity(dom, B, dtype, rng)
+    dv = [mem.to_dev(a) for a in v]
+    dout = [mem.empty(a.shape, dtype) for a in v]
+    infos = ctx.diffuse_implicit(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], kdt, s)
+    mem.sync()
+    ref, ref_infos = O.diffuse_implicit(v, kdt, 1.0, dom, rtol, 0.0, 500)
+    assert len(infos) == dom.rank * B
+    for d in range(dom.rank):
+        u = mem.to_host(dout[d])
+        assert all(i.converged and not i.diverged for i in infos[d * B:(d + 1) * B]), f"diffuse_implicit[{d}] did not converge"
+        back = u - dtype(kdt) * O.laplace_component(u, d, dom)            # sharpen(u) must reproduce the input
+        res = rel_l2(back, v[d])
+        err = rel_l2(u, ref[d])
+        assert res <= bound and err <= bound, f"diffuse_implicit[{d}] residual {res} err {err}"
+    # centred scalar
+    sc = rng.standard_normal((B,) + dom.res).astype(dtype)
+    ds, dso = mem.to_dev(sc), mem.empty(sc.shape, dtype)
+    cinfo = ctx.diffuse_implicit_centered(grid, mem.ptr(ds), s_codes, s_consts, mem.ptr(dso), kdt, s)
+    mem.sync()
+    refc, refi = O.diffuse_implicit_centered(sc, kdt, 1.0, dom, s_codes, s_consts, rtol, 0.0, 500)
+    u = mem.to_host(dso)
+    res = rel_l2(O.diffuse_explicit_centered(u, kdt, -1.0, dom, s_codes, s_consts), sc)
+    err = rel_l2(u, refc)
+    assert all(i.converged for i in cinfo) and res <= bound and err <= bound, f"diffuse_implicit_centered residual {res} err {err}"
+    if fp64:
+        assert all(abs(i.iterations - int(r)) <= 1 for i, r in zip(cinfo, refi.iterations)), ([i.iterations for i in cinfo], refi.iterations)
+
+
 def solve_params(dtype, max_iter=1000, rtol=None, atol=0.0, refresh=50, check=10, method=0):
     rtol = rtol if rtol is not None else (1e-5 if np.dtype(dtype) == np.float32 else 1e-10)
     return C.Solve(rtol, atol, max_iter, refresh, check, method)

@@ -69,6 +69,18 @@ def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
 
 
 @pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:3])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_implicit_diffusion_matches_oracle(emu_ctx, res, bc, dtype):
+    """ diffuse.implicit (phi/physics/diffuse.py:63-92): the CG kernels of the pressure path with the operator I - k dt L on the field's lattice """
+    rng = np.random.default_rng(21)
+    D = len(res)
+    bc_val = rng.uniform(-0.5, 0.5, (D, 2, D))           # wall values (tangential ones matter; a lid): the affine part of the operator
+    dom, grid = pc.make_case(res, bc, dtype, batch=2, bc_val=bc_val)
+    s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+    pc.check_diffuse_implicit(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, [(0.0, 0.25)] * D)
+
+
+@pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D[:3])
 def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
     """ backward kernels vs finite differences / linear responses of the oracle's forward functions (fp64) """
     rng = np.random.default_rng(14)

@@ -52,6 +52,7 @@ def test_reference_style_scenarios(gpu_backend):
     host.test_user_active_mask_plain_and_batched(gpu_backend)
     host.test_convergence_exceptions(gpu_backend)
     host.test_lid_driven_cavity_boundaries_and_diffusion(gpu_backend)
+    host.test_implicit_diffusion(gpu_backend)
     host.test_spatial_gradient_at_faces(gpu_backend)
     host.test_fp64_precision_context(gpu_backend)
 

@@ -55,6 +55,18 @@ def test_stencils_match_oracle(ctx, mem, res, bc, dtype):
     pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)
 
 
+@pytest.mark.parametrize("res,bc", GRIDS[:10])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_implicit_diffusion_matches_oracle(ctx, mem, res, bc, dtype):
+    """ diffuse.implicit (phi/physics/diffuse.py:63-92): the CG kernels of the pressure path with the operator I - k dt L on the field's
+    lattice (staggered components with wall values, centred scalar with a constant side) vs the oracle's CG on `sharpen` """
+    rng = np.random.default_rng(21)
+    D = len(res)
+    dom, grid = pc.make_case(res, bc, dtype, batch=2, bc_val=rng.uniform(-0.5, 0.5, (D, 2, D)))
+    s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+    pc.check_diffuse_implicit(ctx, mem, dom, grid, dtype, rng, s_codes, [(0.0, 0.25)] * D)
+
+
 @pytest.mark.parametrize("res,bc", GRIDS)
 def test_advection_matches_oracle(ctx, mem, res, bc):
     rng = np.random.default_rng(2)

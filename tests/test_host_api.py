@@ -414,6 +414,52 @@ def test_convergence_exceptions(emu_backend):
         fluid.make_incompressible(v, (), order=4)
 
 
+def test_implicit_diffusion(emu_backend):
+    """ diffuse.implicit the way tests/commit/physics/test_diffuse.py:30-66 uses it (2-D instead of 1-D grids: the backend has rank 2 / 3),
+    Heat_Flow.ipynb (constant boundary temperature) and a staggered velocity with a lid, against the oracle """
+    from oracle import phi_oracle as O
+    # test_constant_diffusion: a constant stays constant (the solve starts converged)
+    grid = CenteredGrid(1, PERIODIC, x=5, y=5, backend=emu_backend)
+    out = diffuse.implicit(grid, 1, 1)
+    np.testing.assert_allclose(out.numpy(), 1.0, atol=1e-6)
+    assert out.solve_info.iterations == [0]
+    # test_equality_1d_periodic / test_implicit_stability: explicit with substeps ~ implicit; maximum principle at a large diffusivity
+    step = np.zeros((40, 8), np.float32); step[:20] = 1
+    grid = CenteredGrid(step, PERIODIC, x=40, y=8, backend=emu_backend)
+    ex, im = diffuse.explicit(grid, 0.5, 1, substeps=10), diffuse.implicit(grid, 0.5, 1)
+    assert np.abs(ex.numpy() - im.numpy()).max() <= 0.1        # (one implicit Euler step vs ten explicit ones: 0.064 next to the jump, the analytic difference)
+    assert abs(float(im.numpy()[19, 0]) - 0.5 * (1 + 3 ** -0.5)) <= 1e-5      # closed form of the implicit step at the jump for k dt / dx^2 = 1/2
+    stiff = diffuse.implicit(grid, 10, 1, Solve('CG', 1e-6, 0)).numpy()
+    assert stiff.min() >= -1e-4 and stiff.max() <= 1.0001
+    # Heat_Flow.ipynb: constant temperature on one side, insulated (zero-gradient) on the others; the constant is the affine part
+    rng = np.random.default_rng(31)
+    t0 = rng.standard_normal((12, 10)).astype(np.float32)
+    ext = combine_sides(x=(1.0, ZERO_GRADIENT), y=ZERO_GRADIENT)
+    t = CenteredGrid(t0, ext, x=12, y=10, bounds=Box['x,y', 0:6, 0:5], backend=emu_backend)
+    out = diffuse.implicit(t, 0.8, 0.5, Solve('CG', 1e-6, 0))
+    dom = O.Domain((12, 10), (0, 0), (6, 5), ((O.CLOSED, O.OPEN), (O.OPEN, O.OPEN)))
+    ref, info = O.diffuse_implicit_centered(t0[None], 0.8, 0.5, dom, ((O.CLOSED, O.OPEN), (O.OPEN, O.OPEN)), [(1.0, 0.0), (0.0, 0.0)], 1e-6, 0.0, 1000)
+    np.testing.assert_allclose(out.numpy(), ref[0], atol=2e-5)
+    assert abs(out.solve_info.iterations[0] - int(info.iterations[0])) <= 2
+    # staggered velocity in a lid-driven cavity: every component on its own lattice, the lid value drags the top row
+    boundary = {'x': 0, 'y-': 0, 'y+': vec(x=1, y=0)}
+    v = StaggeredGrid(0, boundary, x=8, y=8, backend=emu_backend)
+    v = diffuse.implicit(v, 0.1, 1.0, Solve('CG', 1e-6, 0))
+    bcv = np.zeros((2, 2, 2)); bcv[1, 1, 0] = 1.0
+    dom = O.Domain((8, 8), (0, 0), (8, 8), ((O.CLOSED, O.CLOSED),) * 2, bcv)
+    ref, _ = O.diffuse_implicit([np.zeros((1, 7, 8), np.float32), np.zeros((1, 8, 7), np.float32)], 0.1, 1.0, dom, 1e-6, 0.0, 1000)
+    vx, vy = v.numpy()
+    np.testing.assert_allclose(vx, ref[0][0], atol=2e-6)
+    np.testing.assert_allclose(vy, ref[1][0], atol=2e-6)
+    assert vx[:, -1].min() > 0.05 and np.all(vy == 0)
+    # solve_linear semantics: NotConverged unless suppressed; what the backend does not do is refused
+    with pytest.raises(NotConverged):
+        diffuse.implicit(t, 50.0, 1.0, Solve('CG', 1e-7, 0, max_iterations=2))
+    diffuse.implicit(t, 50.0, 1.0, Solve('CG', 1e-7, 0, max_iterations=2, suppress=[NotConverged]))
+    with pytest.raises(Exception):
+        diffuse.implicit(t, 0.5, -1.0)
+
+
 def test_lid_driven_cavity_boundaries_and_diffusion(emu_backend):
     """ Lid_Driven_Cavity.ipynb cell 5 boundary: {'x': 0, 'y-': 0, 'y+': vec(x=1, y=0)}; diffuse.explicit pads with it """
     from oracle import phi_oracle as O
