@@ -158,6 +158,61 @@ class DiffuseStaggered(torch.autograd.Function):
         return (None, *gin)
 
 
+def _homogeneous(grid):
+    """ copy of a phihip_grid with zero wall values: the constants of an extrapolation do not depend on the inputs """
+    import ctypes
+    from . import _capi
+    g = _capi.Grid.from_buffer_copy(grid)
+    ctypes.memset(ctypes.addressof(g.bc_val), 0, ctypes.sizeof(g.bc_val))
+    return g
+
+
+class DiffuseImplicitStaggered(torch.autograd.Function):
+    """ diffuse.implicit of a staggered field: out = (I - k dt L)^-1 v. The operator is symmetric, so the vector-Jacobian product is one
+    more solve of the same system with the upstream gradient as right-hand side and homogeneous wall values (implicit-function gradient,
+    like phiml's solve_linear backward); the gradient solve uses `solve.gradient_solve` (default: the same solve). """
+
+    @staticmethod
+    def forward(ctx, meta, *vel):
+        v = [t.contiguous() for t in vel]
+        out = [torch.empty_like(t) for t in v]
+        meta['infos'] = meta['be'].ctx.diffuse_implicit(meta['grid'], _ptrs(v), _ptrs(out), meta['kdt'], meta['csolve'], meta['be'].stream())
+        ctx.meta = meta
+        ctx.shapes = [tuple(t.shape) for t in v]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta = ctx.meta
+        be = meta['be']
+        g = [gi.contiguous() if gi is not None else be.zeros(shape, meta['dtype']) for gi, shape in zip(grads, ctx.shapes)]
+        gin = [torch.empty_like(t) for t in g]
+        be.ctx.diffuse_implicit(_homogeneous(meta['grid']), _ptrs(g), _ptrs(gin), meta['kdt'], meta['csolve_bwd'], be.stream())
+        return (None, *gin)
+
+
+class DiffuseImplicitCentered(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, s):
+        s = s.contiguous()
+        out = torch.empty_like(s)
+        be = meta['be']
+        meta['infos'] = be.ctx.diffuse_implicit_centered(meta['grid'], s.data_ptr(), meta['s_codes'], meta['s_val'], out.data_ptr(), meta['kdt'],
+                                                         meta['csolve'], be.stream())
+        ctx.meta = meta
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        meta = ctx.meta
+        be = meta['be']
+        g = grad.contiguous()
+        gin = torch.empty_like(g)
+        zero = [[0.0, 0.0] for _ in meta['s_val']]
+        be.ctx.diffuse_implicit_centered(meta['grid'], g.data_ptr(), meta['s_codes'], zero, gin.data_ptr(), meta['kdt'], meta['csolve_bwd'], be.stream())
+        return None, gin
+
+
 class DiffuseCentered(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, s):

@@ -63,7 +63,8 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
     `sharpen(x) = explicit(x, diffusivity, -dt)`. The solver is the matrix-free CG of the pressure path (same kernels, operator
     I - k dt L) on the field's own lattice and extrapolation; every component of a StaggeredGrid is solved separately (the
     operator does not couple them). `solve`: `Solve('CG' | 'CG-adaptive', rel_tol, abs_tol, max_iterations)`; raises
-    `NotConverged` / `Diverged` like `solve_linear` unless suppressed. Not differentiable on this backend (use `explicit`). """
+    `NotConverged` / `Diverged` like `solve_linear` unless suppressed. Differentiable w.r.t. the field: the operator is symmetric, the
+    backward pass is one more solve (with `solve.gradient_solve` if given) of the same system with homogeneous boundary constants. """
     from .field import require_plain, _torch_dtype_code
     from .solve import Solve, SolveInfo
     from .fluid import _raise_if_failed
@@ -75,16 +76,21 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
     if solve.x0 is not None:
         raise NotImplementedError("HIP backend: diffuse.implicit starts from x0 = field (the reference's default); pass solve.x0=None")
     vals = field.values if field.is_staggered else [field.values]
-    if autodiff.needs_grad(*vals):
-        raise NotImplementedError("HIP backend: diffuse.implicit has no backward pass; use diffuse.explicit inside differentiated code")
+    tracked = autodiff.needs_grad(*vals)
     be = field.backend
     fp64 = field.dtype == torch.float64
     csolve = solve.to_c(fp64)
+    csolve_bwd = (solve.gradient_solve or solve).to_c(fp64)
     kdt = float(diffusivity) * float(dt)
     if field.is_staggered:
         cur = [t.contiguous() for t in field.values]
-        out = [torch.empty_like(t) for t in cur]
-        infos = be.ctx.diffuse_implicit(field.grid_struct(), _ptrs(cur), _ptrs(out), kdt, csolve, be.stream())
+        if tracked:
+            meta = dict(be=be, grid=field.grid_struct(), kdt=kdt, dtype=field.dtype, csolve=csolve, csolve_bwd=csolve_bwd)
+            out = list(autodiff.DiffuseImplicitStaggered.apply(meta, *cur))
+            infos = meta['infos']
+        else:
+            out = [torch.empty_like(t) for t in cur]
+            infos = be.ctx.diffuse_implicit(field.grid_struct(), _ptrs(cur), _ptrs(out), kdt, csolve, be.stream())
         result = field.with_values(out)
     else:
         s_codes, s_vals = resolve(field.boundary, field.dims)
@@ -93,8 +99,13 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
         grid = _capi.make_grid(field.spatial_rank, _torch_dtype_code(field.dtype), field.batch_size, list(field.resolution.values()), field.bounds.lower,
                                field.bounds.upper, [[0 if c == 0 else 2 for c in pair] for pair in s_codes])
         cur = field.values.contiguous()
-        out = torch.empty_like(cur)
-        infos = be.ctx.diffuse_implicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, csolve, be.stream())
+        if tracked:
+            meta = dict(be=be, grid=grid, kdt=kdt, s_codes=s_codes, s_val=s_val, csolve=csolve, csolve_bwd=csolve_bwd)
+            out = autodiff.DiffuseImplicitCentered.apply(meta, cur)
+            infos = meta['infos']
+        else:
+            out = torch.empty_like(cur)
+            infos = be.ctx.diffuse_implicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, csolve, be.stream())
         result = field.with_values(out)
     info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
                      [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])

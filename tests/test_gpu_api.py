@@ -60,6 +60,7 @@ def test_reference_style_scenarios(gpu_backend):
 def test_gradients(gpu_backend):
     """ adjoint kernels behind torch.autograd on the GPU vs finite differences of the forward path """
     host.test_make_incompressible_gradient(gpu_backend)
+    host.test_implicit_diffusion_gradient(gpu_backend)
     host.test_functional_gradient_through_a_fluid_step(gpu_backend)
     host.test_gradient_through_sampling_between_grids(gpu_backend)
     host.test_colab_tutorial_functional_gradient(gpu_backend, full=True)

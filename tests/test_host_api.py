@@ -538,6 +538,29 @@ def test_make_incompressible_gradient(emu_backend):
             _fd_gradient_check(loss_np, vals, grad.numpy(), rng, tol=1e-6)
 
 
+def test_implicit_diffusion_gradient(emu_backend):
+    """ gradient of a loss on diffuse.implicit(field) w.r.t. the field: one more solve with the symmetric operator and homogeneous wall
+    values, against finite differences of the forward path (staggered velocity with a lid, centred scalar with a constant side) """
+    import torch
+    from phiflow_amd.flow import jacobian, l2_loss, precision
+    rng = np.random.default_rng(23)
+    with precision(64):
+        solve = Solve('CG', 1e-13, 0)
+        boundary = {'x': 0, 'y-': 0, 'y+': vec(x=1, y=0)}
+        shapes = StaggeredGrid(0, boundary, x=10, y=8, backend=emu_backend).component_shapes
+        vals = [rng.standard_normal(s) for s in shapes]
+        sim = lambda v: l2_loss(diffuse.implicit(v, 0.7, 1.0, solve))
+        grad, = jacobian(sim, get_output=False)(StaggeredGrid(vals, boundary, x=10, y=8, backend=emu_backend))
+        loss_np = lambda vs: float(sim(StaggeredGrid(vs, boundary, x=10, y=8, backend=emu_backend)))
+        _fd_gradient_check(loss_np, vals, grad.numpy(), rng, tol=1e-6)
+        ext = combine_sides(x=(1.0, ZERO_GRADIENT), y=PERIODIC)
+        t0 = rng.standard_normal((9, 8))
+        sim_c = lambda t: l2_loss(diffuse.implicit(t, 0.4, 2.0, solve))
+        grad_c, = jacobian(sim_c, get_output=False)(CenteredGrid(t0, ext, x=9, y=8, backend=emu_backend))
+        loss_c = lambda vs: float(sim_c(CenteredGrid(vs[0], ext, x=9, y=8, backend=emu_backend)))
+        _fd_gradient_check(loss_c, [t0], [grad_c.numpy()], rng, tol=1e-6)
+
+
 def test_functional_gradient_through_a_fluid_step(emu_backend):
     """ tests/commit/test_colab_fluids_tutorial.py:11-34 pattern: gradient of a loss on the smoke after several steps of
     {advect smoke, buoyancy, self-advection, projection} w.r.t. the initial velocity (semi-Lagrangian smoke advection: the
