@@ -200,6 +200,12 @@ int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t
 /* x holds x0 on entry and the solution on exit. info: array of grid->batch entries or NULL (no host sync). */
 int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* rhs,
                     void* x, const phihip_solve* solve, phihip_solve_info* info, void* stream);
+/* The same CG on  (identity * I + scale * L) x = rhs,  L = the operator of phihip_cg_solve on this grid without obstacle flags
+ * (neighbour rule from the codes: PERIODIC wraps, CLOSED = no flux / zero-gradient, OPEN = zero ghost). identity = 1, scale = -k dt is
+ * the system of implicit diffusion; this entry is what the PhiML plug-in uses when `solve_linear` hands it such a matrix. The system
+ * must be definite (e.g. identity > 0, scale < 0); no rank-deficiency handling. */
+int phihip_cg_solve_shifted(phihip_ctx* ctx, const phihip_grid* grid, double identity, double scale, const void* rhs, void* x,
+                            const phihip_solve* solve, phihip_solve_info* info, void* stream);
 
 /* Device-side result of the most recent solve on this context: out[2*b] = ||r||^2, out[2*b+1] = ||rhs||^2 per batch entry,
  * written asynchronously on `stream` into DEVICE memory (no host sync) -- the operand of the one all-reduce per step that a

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = (
     "phihip_set_tuning_kernel", "phihip_query_plan", "phihip_obstacle_accessible", "phihip_apply_obstacles",
     "phihip_advect_staggered_backward", "phihip_advect_centered_backward", "phihip_centered_to_staggered_backward",
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
-    "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered",
+    "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered", "phihip_cg_solve_shifted",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
     "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg",
 )
@@ -209,6 +209,7 @@ class Library:
         d.phihip_make_incompressible.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_void_p, c_int, c_int, c_void_p,
                                                  c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_diffuse_explicit.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, c_void_p]
+        d.phihip_cg_solve_shifted.argtypes = [c_void_p, POINTER(Grid), c_double, c_double, c_void_p, c_void_p, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_diffuse_implicit.argtypes = [c_void_p, POINTER(Grid), POINTER(_Ptr3), POINTER(_Ptr3), c_double, POINTER(Solve), POINTER(SolveInfo), c_void_p]
         d.phihip_diffuse_implicit_centered.argtypes = [c_void_p, POINTER(Grid), c_void_p, POINTER((c_int32 * 2) * 3), POINTER((c_double * 2) * 3), c_void_p,
                                                        c_double, POINTER(Solve), POINTER(SolveInfo), c_void_p]
@@ -427,6 +428,13 @@ class Context:
         info = (SolveInfo * grid.batch)() if want_info else None
         self.lib.check(self.lib.dll.phihip_cg_solve(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), rhs, x,
                                                     ctypes.byref(solve), info, stream or None))
+        return list(info) if want_info else None
+
+    def cg_solve_shifted(self, grid, identity, scale, rhs, x, solve: Solve, want_info=True, stream=0):
+        """ CG on (identity * I + scale * L) x = rhs with the pressure operator L of `grid` (no obstacle flags) """
+        info = (SolveInfo * grid.batch)() if want_info else None
+        self.lib.check(self.lib.dll.phihip_cg_solve_shifted(self.handle, ctypes.byref(grid), float(identity), float(scale), rhs, x,
+                                                            ctypes.byref(solve), info, stream or None))
         return list(info) if want_info else None
 
     def solve_residuals(self, batch, out_device, stream=0):

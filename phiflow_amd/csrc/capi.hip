@@ -493,6 +493,24 @@ int phihip_cg_solve(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* fla
     return run_cg(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
 }
 
+int phihip_cg_solve_shifted(phihip_ctx* ctx, const phihip_grid* grid, double identity, double scale, const void* rhs, void* x,
+                            const phihip_solve* solve, phihip_solve_info* info, void* stream) {
+    PHIHIP_ENTER(ctx, grid);
+    PHIHIP_REQUIRE(rhs && x && rhs != x, "cg_solve_shifted: rhs / x NULL or aliased");
+    PHIHIP_REQUIRE(scale != 0.0, "cg_solve_shifted: scale must not be 0");
+    PHIHIP_TRY(check_solve(solve));
+    note_align(v, rhs); note_align(v, x);
+    v.op_custom = 1;
+    v.op_ident = identity;
+    v.op_scale = scale;
+    for (int ax = 0; ax < 3; ++ax)
+        for (int side = 0; side < 2; ++side) {
+            const int code = v.bc[ax][side];      // the pressure's rule for the velocity codes, as phihip_cg_solve applies it
+            v.op_rule[ax][side] = code == PHIHIP_BC_PERIODIC ? 0 : (code == PHIHIP_BC_CLOSED ? 1 : 2);      // NB_WRAP / NB_CLAMP / NB_ZERO
+        }
+    return run_cg(ctx, v, nullptr, 1, rhs, x, solve, info, s);
+}
+
 // ---- f4: slab-decomposed CG phases -----------------------------------------------------------------------------------
 static int slab_view(const phihip_grid* grid, int halo_lo, int halo_hi, GridView* v) {
     PHIHIP_TRY(make_view(grid, v));

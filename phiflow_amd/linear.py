@@ -263,6 +263,41 @@ def recognise_laplace_stencil(matrix, resolution: Sequence[int], rtol: float = 1
     raise NotALaplaceStencil("the matrix is not reproduced by the recognised (spacing, boundary, mask) description")
 
 
+def recognise_shifted_laplace(matrix, resolution: Sequence[int], rtol: float = 1e-5) -> Dict:
+    """ `identity * I + scale * L` with L a Laplace stencil `recognise_laplace_stencil` knows and no inactive cells -- the matrix PhiML
+    assembles for `diffuse.implicit` (`sharpen(x) = x - k dt laplace(x)`, phi/physics/diffuse.py:86-92). Returns the description of L with
+    `weights` = |scale| / dx^2 plus `identity` and `scale` = +-1. The identity is the row sum of the rows away from every boundary (the
+    Laplacian's vanish there). Raises NotALaplaceStencil. """
+    import scipy.sparse as sp
+    res = tuple(int(r) for r in resolution)
+    N = int(np.prod(res))
+    A = sp.csr_matrix(matrix).astype(np.float64)
+    if A.shape != (N, N) or len(res) not in (2, 3):
+        raise NotALaplaceStencil(f"matrix shape {A.shape} does not match the grid {res}")
+    interior = np.ones(N, bool)
+    for a in range(len(res)):
+        for shift in (-1, 1):
+            interior &= _neighbour_index(res, a, shift, False) >= 0
+    if not np.any(interior):
+        raise NotALaplaceStencil("no cell away from the boundaries: cannot separate the identity from the stencil")
+    row_sum = np.asarray(A.sum(axis=1)).ravel()
+    ident = float(np.median(row_sum[interior]))
+    amax = float(np.abs(A.data).max()) if A.nnz else 0.0
+    if abs(ident) <= rtol * amax:
+        raise NotALaplaceStencil("no identity part")
+    if np.any(np.abs(row_sum[interior] - ident) > rtol * amax):
+        raise NotALaplaceStencil("the row sums of the interior rows are not one constant")
+    off = A - sp.diags(A.diagonal())
+    if off.nnz == 0:
+        raise NotALaplaceStencil("diagonal matrix")
+    scale = 1.0 if float(np.median(off.tocoo().data)) > 0 else -1.0
+    L = (A - ident * sp.identity(N, format='csr')) * scale
+    d = recognise_laplace_stencil(L, res, rtol)
+    if d['flags'] is not None:
+        raise NotALaplaceStencil("shifted operator with inactive cells / obstacles")
+    return dict(d, identity=ident, scale=scale)
+
+
 def infer_resolution(matrix) -> Tuple[int, ...]:
     """ Grid resolution of a 5 / 7-point matrix over cells in C order, read off the matrix itself: the couplings of an interior row sit
     at column offsets +-1, +-n_last, +-n_last * n_mid, and every such offset occurs in more than half of the rows (a wrap-around offset of a
@@ -322,7 +357,8 @@ def matrix_fingerprint(lin) -> Tuple:
 class HipLinearSolveMixin:
     """ `linear_solve` / `conjugate_gradient` override for a PhiML `Backend` ([PHIML-RECALL] signatures of phiml.backend.Backend:
     `linear_solve(self, method, lin, y, x0, rtol, atol, max_iter, pre, matrix_offset)`). `lin` = the sparse matrix PhiML assembled;
-    when it is recognised as `masked_laplace` on a uniform grid the solve runs on `phihip_cg_solve`; otherwise `super()` handles it.
+    when it is recognised as `masked_laplace` on a uniform grid the solve runs on `phihip_cg_solve`, when it is `identity * I + scale * L`
+    (the matrix of `diffuse.implicit`) on `phihip_cg_solve_shifted`; otherwise `super()` handles it.
 
     * The grid resolution is read off the matrix (`infer_resolution`); `set_grid_resolution` overrides it (needed only for axes of fewer
       than three cells).
@@ -381,12 +417,15 @@ class HipLinearSolveMixin:
             res = self.hip_resolution
             if res is None or int(np.prod(res)) != N:
                 res = infer_resolution(A)
-            d = recognise_laplace_stencil(A, res)
+            try:
+                d = recognise_laplace_stencil(A, res)
+            except NotALaplaceStencil:
+                d = recognise_shifted_laplace(A, res)          # identity * I + scale * L (implicit diffusion)
         except NotALaplaceStencil as err:
             entry = err
         else:
             entry = dict(d, res=tuple(res), flags_dev=None if d['flags'] is None else torch.as_tensor(d['flags']).to(be.device).contiguous(),
-                         singular=all(c != _capi.BC_OPEN for pair in d['bc'] for c in pair))
+                         singular='identity' not in d and all(c != _capi.BC_OPEN for pair in d['bc'] for c in pair))
         if len(self._hip_cache) >= self.hip_cache_size:
             self._hip_cache.pop(next(iter(self._hip_cache)))
         self._hip_cache[key] = entry
@@ -439,7 +478,11 @@ class HipLinearSolveMixin:
         scalar = lambda v, default: float(np.max(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else (v if v is not None else default), dtype=np.float64)))
         csolve = _capi.Solve(scalar(rtol, 1e-5), scalar(atol, 0.0), int(scalar(max_iter, 1000)), 20 if method == 'CG-adaptive' else 50, 10,
                              1 if method == 'CG-adaptive' else 0)
-        infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, 1, yt.data_ptr(), xt.data_ptr(), csolve, True, be.stream())
+        if 'identity' in d:
+            infos = be.ctx.cg_solve_shifted(grid, d['identity'], d['scale'], yt.data_ptr(), xt.data_ptr(), csolve, True, be.stream())
+            self.hip_stats['shifted_solves'] = self.hip_stats.get('shifted_solves', 0) + 1
+        else:
+            infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, 1, yt.data_ptr(), xt.data_ptr(), csolve, True, be.stream())
         self.hip_stats['hip_solves'] += 1
         return (xt.reshape(B, N), [i.iterations for i in infos], [i.residual_sq for i in infos], [bool(i.converged) for i in infos],
                 [bool(i.diverged) for i in infos])

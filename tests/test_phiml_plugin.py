@@ -248,6 +248,44 @@ def test_level_b_rank_deficient_solves_reach_the_hip_kernels(emu_backend):
         ctx.set_small_grid_solver(True)
 
 
+def test_level_b_implicit_diffusion_matrix_reaches_the_hip_kernels(emu_backend):
+    """ diffuse.implicit under `with HIP:` (phi/physics/diffuse.py:86-92): solve_linear hands the backend the matrix of
+    sharpen(x) = x - k dt laplace(x); recognised as identity * I + scale * L it runs on phihip_cg_solve_shifted (march kernels) """
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from phiml import backend as pb
+    with emu_backend:
+        be = linear.make_phiml_backend()
+        for res, codes in (((12, 10), ((O.CLOSED, O.OPEN), (O.PERIODIC, O.PERIODIC))), ((6, 8, 12), ((O.OPEN, O.OPEN), (O.CLOSED, O.CLOSED), (O.PERIODIC, O.PERIODIC)))):
+            # field extrapolation: CLOSED code = constant 0 (zero ghost), OPEN code = zero-gradient; the matrix of sharpen from the oracle's stencil
+            D, N = len(res), int(np.prod(res))
+            dom = O.Domain(res, (0.0,) * D, tuple(0.5 * n for n in res), ((O.PERIODIC, O.PERIODIC),) * D)
+            kdt = 0.9
+            cols = []
+            for k in range(N):
+                e = np.zeros((1,) + tuple(res)); e.reshape(-1)[k] = 1.0
+                cols.append(O.diffuse_explicit_centered(e, kdt, -1.0, dom, codes, [(0.0, 0.0)] * D).reshape(-1))
+            M = sp.csr_matrix(np.stack(cols, axis=1))
+            d = linear.recognise_shifted_laplace(M, res)
+            assert abs(d['identity'] - 1.0) <= 1e-12 and d['scale'] == -1.0 and d['flags'] is None
+            rng = np.random.default_rng(3)
+            y = rng.standard_normal((2, N))
+            ctx = be._hip_backend().ctx
+            ctx.profile_enable(True); ctx.profile_read(reset=True)
+            r = be.linear_solve('CG', M, torch.as_tensor(y), torch.as_tensor(y.copy()), 1e-10, 0.0, 500)
+            prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+            assert r.method == 'HIP CG' and bool(r.converged.all())
+            launches = sum(prof[k][0] for k in ('cg_matvec_dot', 'cg_update', 'cg_update_r', 'cg_residual') if k in prof)      # (small grids: the one-launch form)
+            assert launches >= 3 and be.hip_stats.get('shifted_solves', 0) >= 1, prof
+            exact = np.stack([spla.spsolve(M.tocsc(), y[b]) for b in range(2)])
+            assert np.linalg.norm(r.x.numpy() - exact) / np.linalg.norm(exact) <= 1e-8
+        # a rank-deficiency offset makes no sense for a definite system: generic path
+        before = be.hip_stats['fallbacks']
+        be.linear_solve('CG', M, torch.as_tensor(y), torch.zeros(2, N, dtype=torch.float64), 1e-6, 0.0, 50, None, -1.0 / N)
+        assert be.hip_stats['fallbacks'] == before + 1
+        pb.BACKENDS.remove(be)
+
+
 def test_resolution_is_read_off_the_matrix():
     for res in ((64, 64), (4096 // 64, 64), (16, 16, 16), (5, 7, 9), (30, 4), (3, 50, 3)):
         for bc in (((O.PERIODIC, O.PERIODIC),) * len(res), ((O.CLOSED, O.OPEN),) * len(res)):
