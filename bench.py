@@ -460,7 +460,8 @@ def sync_launch_plans(ctx, sim, dist, rank, device):
     plans = torch.zeros(len(fams), 3, dtype=torch.int64, device=device)
     if rank == 0:
         sim.step(None)
-        torch.cuda.synchronize(device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
         for i, f in enumerate(fams):
             q = ctx.query_plan(sim.grid, False, f)
             plans[i] = torch.tensor([q["rows"], q["tpr"], q["chunk"]], dtype=torch.int64)
@@ -481,6 +482,25 @@ def bit_checksum(tensors):
         pos = (torch.arange(w.numel(), device=w.device) % 65521) + 1
         out += [int(w.sum().item()), int((w * pos).sum().item())]
     return out
+
+
+def gather_replicas(dist, world, its_local, ok_local, fields, device, pinned_plans):
+    """ N > 1: every rank contributes the iteration counts of its verification step, whether they are the ones the line claims, and the bit
+    checksums + pressure norm of its fields; returns (iterations of all ranks, `replicas` record). `fields[0]` is the pressure. """
+    mine = torch.tensor(list(its_local) + [int(ok_local)] + bit_checksum(fields), dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    rows = [g.tolist() for g in gathered]
+    iterations_all = [r[:len(its_local)] for r in rows]
+    sums = [r[len(its_local) + 1:] for r in rows]
+    p_norm = torch.tensor([float(fields[0].double().norm())], dtype=torch.float64, device=device)
+    norms = [torch.zeros_like(p_norm) for _ in range(world)]
+    dist.all_gather(norms, p_norm)
+    replicas = {"bit_identical_to_rank0": [s_ == sums[0] for s_ in sums], "all_bit_identical": all(s_ == sums[0] for s_ in sums),
+                "pressure_norm_rel_diff_vs_rank0": [abs(float(x) - float(norms[0])) / max(float(norms[0]), 1e-300) for x in norms],
+                "verified_ok": [bool(r[len(its_local)]) for r in rows], "pinned_launch_plans": pinned_plans,
+                "note": "every rank advanced the same initial state with the launch plans rank 0 tuned: checksums of the bit patterns of p and v"}
+    return iterations_all, replicas
 
 
 def main():
@@ -573,19 +593,7 @@ def main():
     replicas = None
     iterations_all = [its_local]
     if dist is not None and world > 1:
-        mine = torch.tensor(its_local + [int(ok_local)] + bit_checksum([sim.p] + sim.v), dtype=torch.int64, device=device)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        rows = [g.tolist() for g in gathered]
-        iterations_all = [r[:len(its_local)] for r in rows]
-        sums = [r[len(its_local) + 1:] for r in rows]
-        p_norm = torch.tensor([float(sim.p.double().norm())], dtype=torch.float64, device=device)
-        norms = [torch.zeros_like(p_norm) for _ in range(world)]
-        dist.all_gather(norms, p_norm)
-        replicas = {"bit_identical_to_rank0": [s_ == sums[0] for s_ in sums], "all_bit_identical": all(s_ == sums[0] for s_ in sums),
-                    "pressure_norm_rel_diff_vs_rank0": [abs(float(x) - float(norms[0])) / max(float(norms[0]), 1e-300) for x in norms],
-                    "verified_ok": [bool(r[len(its_local)]) for r in rows], "pinned_launch_plans": pinned_plans,
-                    "note": "every rank advanced the same initial state with the launch plans rank 0 tuned: checksums of the bit patterns of p and v"}
+        iterations_all, replicas = gather_replicas(dist, world, its_local, ok_local, [sim.p] + sim.v, device, pinned_plans)
         assert all(replicas["verified_ok"]), iterations_all
     else:
         assert ok_local, [(i.iterations, i.diverged, i.residual_sq) for i in info]
