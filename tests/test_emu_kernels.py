@@ -68,7 +68,7 @@ def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
         pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
-@pytest.mark.parametrize("res,bc,dtype", [(r, b, np.float32) for r, b in GRIDS_2D + GRIDS_3D[:2]] + [(r, b, np.float64) for r, b in (GRIDS_2D[3], GRIDS_3D[1], GRIDS_3D[2])])
+@pytest.mark.parametrize("res,bc,dtype", [(r, b, np.float32) for r, b in GRIDS_2D + GRIDS_3D[:2]] + [(r, b, np.float64) for r, b in (GRIDS_2D[3], GRIDS_2D[4], GRIDS_3D[1])])
 def test_implicit_diffusion_matches_oracle(emu_ctx, res, bc, dtype):
     """ diffuse.implicit (phi/physics/diffuse.py:63-92): the CG kernels of the pressure path with the operator I - k dt L on the field's lattice """
     rng = np.random.default_rng(21)
@@ -481,7 +481,7 @@ def test_autotuned_launch_plans_stay_correct(emu_library):
 
 
 @pytest.mark.parametrize("res,bc", [((20, 24), ((CLO, CLO), (PER, PER))), ((16, 20), ((OPN, OPN), (CLO, OPN))), ((8, 12, 16), ((PER, PER), (CLO, OPN), (PER, PER))),
-                                    ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)))])
+                                    ((4, 12, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)))])
 def test_single_reduction_cg_matches_oracle(emu_ctx, res, bc):
     """ the one-launch-per-iteration (Chronopoulos-Gear) form of 'CG' (stencil_march.hpp MODE_CG1): same iterates as PhiML's cg in exact
     arithmetic -- fixed iteration counts incl. refreshes, tolerance mode with per-entry freezing, obstacles, both dtypes """
@@ -492,9 +492,10 @@ def test_single_reduction_cg_matches_oracle(emu_ctx, res, bc):
             dom, grid = pc.make_case(res, bc, dtype, batch=2)
             pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(7), max_iter=7, fixed_iterations=True)
             pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(8), max_iter=11, refresh=4, fixed_iterations=True)
-            pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(9))
-            pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(10))
-        if len(res) == 3:
+            if dtype == np.float32 or len(res) == 2:          # (tolerance mode to 1e-10 in fp64 costs the emulation a minute on the 3-D grids)
+                pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(9))
+                pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(10))
+        if res == (8, 12, 16):
             dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float32, batch=1)
             pc.check_make_incompressible(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(11), obstacles=[pc.O.BoxObstacle((4.0, 3.0, 5.0), (8.0, 7.0, 11.0))])
     finally:
