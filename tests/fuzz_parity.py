@@ -72,6 +72,7 @@ def main():
             step = "mac_cormack_staggered"; pc.check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng)
             step = "centered_to_staggered"; pc.check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
             step = "diffuse"; pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)
+            step = "diffuse_implicit"; pc.check_diffuse_implicit(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
             step = "grid_sample"; pc.check_grid_sample(ctx, mem, res, s_codes, [c for c in s_consts], dtype, rng, batch=batch, points=97)
             for small in (True, False):
                 ctx.set_small_grid_solver(small)
