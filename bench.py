@@ -538,7 +538,8 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     dist = None
-    if world > 1 or os.environ.get("PHIHIP_BENCH_FORCE_DIST") == "1":     # the env switch lets a 1-GPU box exercise the RCCL path
+    force_dist = os.environ.get("PHIHIP_BENCH_FORCE_DIST") == "1"          # lets a 1-GPU box exercise the RCCL path incl. the replica validation
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -564,7 +565,7 @@ def main():
     if args.workload == "slab":
         return bench_slab(args, lib, device, rank, world, dist, barrier)
     sim = FluidStep(ctx, n, B, args.cg_iters, device)
-    pinned_plans = sync_launch_plans(ctx, sim, dist, rank, device) if dist is not None and world > 1 else None
+    pinned_plans = sync_launch_plans(ctx, sim, dist, rank, device) if dist is not None and (world > 1 or force_dist) else None
 
     for _ in range(args.warmup):
         sim.step(allreduce)
@@ -592,7 +593,7 @@ def main():
     ok_local = all(i.iterations == args.cg_iters and not i.diverged for i in info)
     replicas = None
     iterations_all = [its_local]
-    if dist is not None and world > 1:
+    if dist is not None and (world > 1 or force_dist):
         iterations_all, replicas = gather_replicas(dist, world, its_local, ok_local, [sim.p] + sim.v, device, pinned_plans)
         assert all(replicas["verified_ok"]), iterations_all
     else:
