@@ -97,73 +97,260 @@ __device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const 
     }
 }
 
-template <typename T, int DIM, int CA>
-__global__ __launch_bounds__(kBlock) void advect_staggered_bwd_kernel(VelGrid g, CComp3a<T> field, CComp3a<T> vel, const T* __restrict__ gout,
-                                                                      T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel, T dt) {
+// the index a tap of make_pair resolves to, as ONE index: false = outside a constant side (the tap is a constant: no gradient)
+__device__ __forceinline__ bool resolve_index(int i, int n, int code_lo, int code_hi, int& r) {
+    if ((unsigned)i < (unsigned)n) { r = i; return true; }
+    if (code_lo == PHIHIP_BC_PERIODIC) { r = wrap_index(i, n); return true; }
+    if (i < 0) { r = 0; return code_lo != PHIHIP_BC_CLOSED; }
+    r = n - 1;
+    return code_hi != PHIHIP_BC_CLOSED;
+}
+
+// =====================================================================================================================
+// Gather form of the semi-Lagrangian adjoints (r3). The scatter form above needs 17 global atomics per sample and runs at 0.08-0.10 of the
+// HBM rate; accumulating them in LDS is no faster (LDS float atomics retire ~0.5 lane-operations per clock and CU: measured).
+// Without atomics:
+//   pass A  per sample: back-trace, store the lookup coordinate x* (per axis), g, and g d(out)/d(x*) (-dt / dx) per axis. A sample whose
+//           lookup left the cell neighbourhood (|x*_a - i_a| >= 1 for some axis, or not finite) scatters its taps atomically as before and
+//           stores g = 0.
+//   pass B  per cell t of the advected field:  g_field[t] += sum over the 3^D neighbouring samples s of  g_s prod_a hat(x*_a(s) - t_a),
+//           hat(x) = max(0, 1 - |x|) -- the multilinear weight of tap t in the lookup of s. The boundary rule is folded into the staging of the
+//           neighbourhood: the slot at unresolved index i beyond the array holds, per axis, the sample of the periodic image with its
+//           coordinate shifted by i - s, the EDGE sample itself with the coordinate shifted by s - i under a clamped (zero-gradient) side -- the
+//           taps beyond the edge are the edge cell --, nothing beyond a constant side (those taps are constants).
+//   pass C  per sample j of velocity component cb: the transposed means -- sum over the samples whose velocity lookup read j of their
+//           g d(out)/d(x*_cb) with the forward weights (own component 1, 4-point means 1/4 each, cell-centre means 1/2 each), the candidates'
+//           taps resolved with the forward index rule.
+// =====================================================================================================================
+template <typename T>
+struct TraceOut {
+    T* cx[3];     // lookup coordinate per axis (index space of the sample's own array)
+    T* gw;        // upstream gradient of the sample (0: handled atomically in pass A)
+    T* du[3];     // g * d(out)/d(x*_a) * d(x*_a)/d(u_a)
+};
+
+template <typename T, int DIM, int CA, bool STAG>
+__global__ __launch_bounds__(kBlock) void advect_bwd_trace_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ fieldp, CComp3a<T> vel,
+                                                                  const T* __restrict__ gout, T* __restrict__ gfield, TraceOut<T> out, int want_gvel, T dt) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
     const int b = blockIdx.y;
-    const int total = (int)g.ccells[ca];
-    const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
-    const T* __restrict__ F = field.p[ca] + (long long)b * total;
+    const int total = STAG ? (int)g.ccells[ca] : (int)g.cells;
+    const int n[3] = {STAG ? g.cn[ca][0] : g.n[0], STAG ? g.cn[ca][1] : g.n[1], STAG ? g.cn[ca][2] : g.n[2]};
+    const T* __restrict__ F = fieldp + (long long)b * total;
     T* __restrict__ GF = gfield ? gfield + (long long)b * total : nullptr;
     int bc[3][2];
     T cv[3][2];
-    comp_rule<T>(g, ca, bc, cv);
+    if (STAG) comp_rule<T>(g, ca, bc, cv); else scalar_rule<T>(sb, bc, cv);
     for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
-        const T go = gout[(long long)b * total + f];
+        const long long o = (long long)b * total + f;
+        const T go = gout[o];
         int idx[3];
         unravel(f, n[1], n[2], idx);
         T u[3];
-        face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
+        if (STAG) face_velocity<T, DIM, CA>(g, vel, b, idx, f, u); else center_velocity<T, DIM>(g, vel, b, idx, u);
         T coord[3] = {T(0), T(0), T(0)};
+        bool near = true;
 #pragma unroll
-        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+        for (int a = A0; a < 3; ++a) {
+            coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+            near = near && fabs(coord[a] - (T)idx[a]) < T(1);          // (false for NaN)
+        }
         AxisPair<T> ax[3];
         T fr[3], dfr[3];
         lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
-        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
-        if (want_gvel) {
-            T du[3] = {T(0), T(0), T(0)};
+        gather_adjoint<T, DIM>(F, near ? nullptr : GF, ax, fr, go, dfr);
 #pragma unroll
-            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
-            face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du);
+        for (int a = A0; a < 3; ++a) out.cx[a][o] = coord[a];
+        out.gw[o] = near ? go : T(0);
+        if (want_gvel) {
+#pragma unroll
+            for (int a = A0; a < 3; ++a) out.du[a][o] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
         }
     }
 }
 
+// ---- pass B ---------------------------------------------------------------------------------------------------------------
+constexpr int kGatherT1 = 8, kGatherT2 = 32;
+template <typename T, int DIM> constexpr int gather_t0() { return DIM == 3 ? (sizeof(T) == 4 ? 4 : 2) : 1; }
+template <typename T, int DIM> constexpr int gather_cells() { return (gather_t0<T, DIM>() + (DIM == 3 ? 2 : 0)) * (kGatherT1 + 2) * (kGatherT2 + 2); }
+
+// the sample a staging slot at unresolved index i holds along one axis, and the shift of its coordinate (see the header of this section)
+template <typename T>
+__device__ __forceinline__ bool gather_slot(int i, int n, int code_lo, int code_hi, int& s, T& shift) {
+    s = i;
+    shift = T(0);
+    if ((unsigned)i < (unsigned)n) return true;
+    if (code_lo == PHIHIP_BC_PERIODIC) {
+        s = wrap_index(i, n);
+        shift = (T)(i - s);
+        return true;
+    }
+    const int code = i < 0 ? code_lo : code_hi;
+    if (code == PHIHIP_BC_CLOSED) return false;          // constant side: the taps beyond it are constants
+    s = i < 0 ? 0 : n - 1;                               // clamped side: the taps beyond it ARE the edge cell
+    shift = (T)(s - i);
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ T hat(T x) { return fmax(T(0), T(1) - fabs(x)); }
+
+template <typename T>
+struct alignas(4 * sizeof(T)) GatherSlot {
+    T c0, c1, c2, g;      // shifted lookup coordinate of the staged sample and its upstream gradient: one 16 / 32-byte LDS access per neighbour
+};
+
 template <typename T, int DIM>
-__global__ __launch_bounds__(kBlock) void advect_centered_bwd_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ sfield, CComp3a<T> vel,
-                                                                     const T* __restrict__ gout, T* __restrict__ gs, Comp3w<T> gvel, int want_gvel,
-                                                                     T dt) {
-    constexpr int A0 = 3 - DIM;
+__global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0, int n1, int n2, ScalarBc rule, TraceOut<T> in, T* __restrict__ gfield,
+                                                                         int nb1, int nb2) {
+    constexpr int T0 = gather_t0<T, DIM>(), T1 = kGatherT1, T2 = kGatherT2;
+    constexpr int E0 = DIM == 3 ? T0 + 2 : 1, E1 = T1 + 2, E2 = T2 + 2;
+    __shared__ GatherSlot<T> slots[E0 * E1 * E2];
     const int b = blockIdx.y;
-    const int total = (int)g.cells;
-    const int n[3] = {g.n[0], g.n[1], g.n[2]};
-    const T* __restrict__ F = sfield + (long long)b * total;
-    T* __restrict__ GF = gs ? gs + (long long)b * total : nullptr;
-    int bc[3][2];
-    T cv[3][2];
-    scalar_rule<T>(sb, bc, cv);
-    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
-        const T go = gout[(long long)b * total + f];
-        int idx[3];
-        unravel(f, n[1], n[2], idx);
-        T u[3];
-        center_velocity<T, DIM>(g, vel, b, idx, u);
-        T coord[3] = {T(0), T(0), T(0)};
-#pragma unroll
-        for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
-        AxisPair<T> ax[3];
-        T fr[3], dfr[3];
-        lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
-        gather_adjoint<T, DIM>(F, GF, ax, fr, go, dfr);
-        if (want_gvel) {
-            T du[3] = {T(0), T(0), T(0)};
-#pragma unroll
-            for (int a = A0; a < 3; ++a) du[a] = go * dfr[a] * -(dt * (T)g.rdx[a]);
-            center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
+    const long long total = (long long)n0 * n1 * n2;
+    const long long base = (long long)b * total;
+    const int bid = blockIdx.x;
+    const int g2 = (bid % nb2) * T2, g1 = ((bid / nb2) % nb1) * T1, g0 = DIM == 3 ? (bid / (nb2 * nb1)) * T0 : 0;
+    // staging: every slot of the tile grown by one cell; tiles whose grown window lies inside the array skip the boundary rule (uniform)
+    const bool inside = (DIM != 3 || (g0 >= 1 && g0 + T0 + 1 <= n0)) && g1 >= 1 && g1 + T1 + 1 <= n1 && g2 >= 1 && g2 + T2 + 1 <= n2;
+    for (int e = threadIdx.x; e < E0 * E1 * E2; e += kBlock) {
+        const int l2 = e % E2, t = e / E2;
+        const int l1 = t % E1, l0 = t / E1;
+        int s0 = DIM == 3 ? g0 - 1 + l0 : 0, s1 = g1 - 1 + l1, s2 = g2 - 1 + l2;
+        T h0 = T(0), h1 = T(0), h2 = T(0);
+        bool ok = true;
+        if (!inside) {
+            if (DIM == 3) ok = gather_slot<T>(g0 - 1 + l0, n0, rule.bc[0][0], rule.bc[0][1], s0, h0);
+            ok = gather_slot<T>(g1 - 1 + l1, n1, rule.bc[1][0], rule.bc[1][1], s1, h1) && ok;
+            ok = gather_slot<T>(g2 - 1 + l2, n2, rule.bc[2][0], rule.bc[2][1], s2, h2) && ok;
         }
+        GatherSlot<T> v;
+        v.c0 = v.c1 = v.c2 = v.g = T(0);
+        if (ok) {
+            const long long o = base + ((long long)s0 * n1 + s1) * n2 + s2;
+            v.g = in.gw[o];
+            if (DIM == 3) v.c0 = in.cx[0][o] + h0;
+            v.c1 = in.cx[1][o] + h1;
+            v.c2 = in.cx[2][o] + h2;
+        }
+        slots[e] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % T2, ty = threadIdx.x / T2;
+#pragma unroll
+    for (int k0 = 0; k0 < T0; ++k0) {
+        const int t0 = g0 + k0, t1 = g1 + ty, t2 = g2 + tx;
+        if (t0 >= n0 || t1 >= n1 || t2 >= n2) continue;
+        T acc = T(0);
+#pragma unroll
+        for (int d0 = 0; d0 < (DIM == 3 ? 3 : 1); ++d0)
+#pragma unroll
+            for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+                for (int d2 = 0; d2 < 3; ++d2) {
+                    const GatherSlot<T> v = slots[((k0 + d0) * E1 + (ty + d1)) * E2 + tx + d2];
+                    T w = v.g * hat<T>(v.c1 - (T)t1) * hat<T>(v.c2 - (T)t2);
+                    if (DIM == 3) w *= hat<T>(v.c0 - (T)t0);
+                    acc += w;
+                }
+        gfield[base + ((long long)t0 * n1 + t1) * n2 + t2] += acc;
+    }
+}
+
+// ---- pass C ---------------------------------------------------------------------------------------------------------------
+// One axis of a transposed pair stencil. Forward: the source at index q reads the taps (q + d, q + d + 1) of an array of n_t samples under the
+// boundary codes of the axis (d = off - 1: the cell pair (m - 1, m) of a face; d = -off: the face pair (s, s + 1)). Transposed: target j receives
+// from every source q in [0, n_src) one of whose taps resolves, non-constant, to j. The unresolved positions that resolve to j are j itself and,
+// at the ends of the array, the ghost position beyond a clamped side next to it or the periodic image: at most three. Every (position, tap)
+// pair names one source index; a source named twice reads the target twice (both taps clamp onto the edge sample) -- entries may repeat.
+struct AxisSources {
+    int q[6];
+    bool on[6];
+};
+
+__device__ __forceinline__ AxisSources transposed_sources(int j, int n_t, int code_lo, int code_hi, int d, int n_src) {
+    const bool periodic = code_lo == PHIHIP_BC_PERIODIC;
+    int p[3] = {j, 0, 0};
+    bool have[3] = {true, false, false};
+    if (j == 0) {                       // ... the position below the array: clamps onto sample 0; the image above the array wraps onto it
+        p[1] = periodic ? n_t : -1;
+        have[1] = periodic || code_lo == PHIHIP_BC_OPEN;
+    }
+    if (j == n_t - 1) {
+        p[2] = periodic ? -1 : n_t;
+        have[2] = periodic || code_hi == PHIHIP_BC_OPEN;
+    }
+    AxisSources r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = p[k] - d - t;
+            r.q[2 * k + t] = q;
+            r.on[2 * k + t] = have[k] && q >= 0 && q < n_src;
+        }
+    return r;
+}
+
+template <typename T>
+struct DuIn {
+    const T* p[3];     // per SOURCE component ca (STAG) -- or [0] only (cell samples): g d(out)/d(x*_cb) of that source's samples
+};
+
+template <typename T, int DIM, int CB, bool STAG>
+__global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelGrid g, DuIn<T> du, T* __restrict__ gvel) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int cb = CB;
+    const int b = blockIdx.y;
+    const int total = (int)g.ccells[cb];
+    const int n[3] = {g.cn[cb][0], g.cn[cb][1], g.cn[cb][2]};
+    for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
+        int j[3];
+        unravel(f, n[1], n[2], j);
+        T acc = T(0);
+        if (STAG) {
+            acc = du.p[cb][(long long)b * total + f];                       // own component: the sample reads itself with weight 1
+#pragma unroll
+            for (int ca = A0; ca < 3; ++ca) {
+                if (ca == cb) continue;
+                // faces of component ca (array shape cn[ca]) whose 4-point mean of component cb reads sample j: cells (m - 1, m) along ca with
+                // m = idx[ca] + off[ca], faces (s, s + 1) along cb with s = idx[cb] - off[cb]; the other axis is shared
+                const int s1 = g.cn[ca][1], s2 = g.cn[ca][2];
+                const int stride[3] = {s1 * s2, s2, 1};
+                const AxisSources A = transposed_sources(j[ca], g.cn[cb][ca], g.bc[ca][0], g.bc[ca][1], g.off[ca] - 1, g.cn[ca][ca]);
+                const AxisSources B = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.cn[ca][cb]);
+                long long rest = 0;
+#pragma unroll
+                for (int ax = A0; ax < 3; ++ax)
+                    if (ax != ca && ax != cb) rest += (long long)j[ax] * stride[ax];
+                const T* __restrict__ D = du.p[ca] + (long long)b * g.ccells[ca];
+                T part = T(0);
+#pragma unroll
+                for (int ka = 0; ka < 6; ++ka) {
+                    if (!wave_any(A.on[ka])) continue;
+#pragma unroll
+                    for (int kb = 0; kb < 6; ++kb)
+                        if (A.on[ka] && B.on[kb]) part += D[rest + (long long)A.q[ka] * stride[ca] + (long long)B.q[kb] * stride[cb]];
+                }
+                acc += T(0.25) * part;
+            }
+        } else {
+            // cells whose centre mean of component cb reads face j: faces (s, s + 1) along cb with s = idx[cb] - off[cb]
+            const int stride[3] = {g.n[1] * g.n[2], g.n[2], 1};
+            const AxisSources B = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.n[cb]);
+            long long rest = 0;
+#pragma unroll
+            for (int ax = A0; ax < 3; ++ax)
+                if (ax != cb) rest += (long long)j[ax] * stride[ax];
+            const T* __restrict__ D = du.p[0] + (long long)b * g.cells;
+            T part = T(0);
+#pragma unroll
+            for (int kb = 0; kb < 6; ++kb)
+                if (B.on[kb]) part += D[rest + (long long)B.q[kb] * stride[cb]];
+            acc = T(0.5) * part;
+        }
+        gvel[(long long)b * total + f] += acc;
     }
 }
 
@@ -284,20 +471,56 @@ static inline int bwd_blocks(long long total) {
     return (int)(nb < 65536 ? nb : 65536);
 }
 
+// scratch of the gather-form adjoints: [cx0 | cx1 | cx2 | gw] of one sample array at a time + the du arrays of every source (9 staggered, 3 centred)
+template <typename T>
+static int adjoint_scratch(phihip_ctx* ctx, size_t max_samples, int batch, int n_du, T* trace[4], T* du[9]) {
+    const size_t slot = (((size_t)batch * max_samples * sizeof(T) + 255) / 256) * 256;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adj_g, slot * (4 + n_du)));
+    for (int k = 0; k < 4; ++k) trace[k] = (T*)((char*)ctx->ws_adj_g.ptr + slot * k);
+    for (int k = 0; k < 9; ++k) du[k] = k < n_du ? (T*)((char*)ctx->ws_adj_g.ptr + slot * (4 + k)) : nullptr;
+    return PHIHIP_OK;
+}
+
 template <typename T, int DIM>
-static void launch_advect_staggered_bwd(const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3],
-                                        const void* const gout[3], void* const gf[3], void* const gv[3], double dt, hipStream_t s) {
-    CComp3a<T> ff{{(const T*)f[0], (const T*)f[1], (const T*)f[2]}};
+static void launch_field_gather(const int n[3], const int bc[3][2], int batch, const TraceOut<T>& tr, T* gfield, hipStream_t s) {
+    ScalarBc rule;
+    memset(&rule, 0, sizeof(rule));
+    for (int a = 0; a < 3; ++a)
+        for (int side = 0; side < 2; ++side) rule.bc[a][side] = bc[a][side];
+    const int nb2 = ceil_div(n[2], kGatherT2), nb1 = ceil_div(n[1], kGatherT1), nb0 = DIM == 3 ? ceil_div(n[0], gather_t0<T, DIM>()) : 1;
+    hipLaunchKernelGGL((advect_bwd_field_gather_kernel<T, DIM>), dim3((unsigned)nb0 * nb1 * nb2, batch), dim3(kBlock), 0, s, n[0], n[1], n[2], rule, tr, gfield,
+                       nb1, nb2);
+}
+
+template <typename T, int DIM>
+static int advect_staggered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3],
+                                  const void* const gout[3], void* const gf[3], void* const gv[3], double dt, hipStream_t s) {
+    size_t max_samples = 0;
+    for (int ca = v.ax0; ca < 3; ++ca) max_samples = (size_t)v.ccells[ca] > max_samples ? (size_t)v.ccells[ca] : max_samples;
+    T *trace[4], *du[9];
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du));
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
-    const int want = gv ? 1 : 0;
-    if (DIM == 3)
-        hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 0>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
-                           (const T*)gout[0], gf ? (T*)gf[0] : nullptr, gg, want, (T)dt);
-    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 1>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
-                       (const T*)gout[1], gf ? (T*)gf[1] : nullptr, gg, want, (T)dt);
-    hipLaunchKernelGGL((advect_staggered_bwd_kernel<T, DIM, 2>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, ff, vv,
-                       (const T*)gout[2], gf ? (T*)gf[2] : nullptr, gg, want, (T)dt);
+    ScalarBc none;
+    memset(&none, 0, sizeof(none));
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        TraceOut<T> tr{{trace[0], trace[1], trace[2]}, trace[3], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
+        const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);
+        T* gfield = gf ? (T*)gf[ca] : nullptr;
+#define PHIHIP_TRACE(CA) hipLaunchKernelGGL((advect_bwd_trace_kernel<T, DIM, CA, true>), grid, dim3(kBlock), 0, s, g, none, (const T*)f[ca], vv, (const T*)gout[ca], gfield, tr, gv ? 1 : 0, (T)dt)
+        if (ca == 0) PHIHIP_TRACE(0); else if (ca == 1) PHIHIP_TRACE(1); else PHIHIP_TRACE(2);
+#undef PHIHIP_TRACE
+        if (gfield) launch_field_gather<T, DIM>(v.cn[ca], v.bc, v.batch, tr, gfield, s);
+    }
+    if (gv) {
+        for (int cb = v.ax0; cb < 3; ++cb) {
+            DuIn<T> in{{du[0 + cb], du[3 + cb], du[6 + cb]}};      // du[3 ca + cb]: source component ca, velocity axis cb
+            const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
+            if (cb == 0) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 0, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[0]);
+            else if (cb == 1) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 1, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[1]);
+            else hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 2, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[2]);
+        }
+    }
+    return PHIHIP_OK;
 }
 
 int run_advect_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3], const void* const gout[3],
@@ -305,23 +528,36 @@ int run_advect_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void* con
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     if (v.dtype == PHIHIP_F64) {
-        if (v.rank == 3) launch_advect_staggered_bwd<double, 3>(v, g, f, vel, gout, gf, gv, dt, s);
-        else launch_advect_staggered_bwd<double, 2>(v, g, f, vel, gout, gf, gv, dt, s);
+        if (v.rank == 3) PHIHIP_TRY((advect_staggered_bwd_t<double, 3>(ctx, v, g, f, vel, gout, gf, gv, dt, s)));
+        else PHIHIP_TRY((advect_staggered_bwd_t<double, 2>(ctx, v, g, f, vel, gout, gf, gv, dt, s)));
     } else {
-        if (v.rank == 3) launch_advect_staggered_bwd<float, 3>(v, g, f, vel, gout, gf, gv, dt, s);
-        else launch_advect_staggered_bwd<float, 2>(v, g, f, vel, gout, gf, gv, dt, s);
+        if (v.rank == 3) PHIHIP_TRY((advect_staggered_bwd_t<float, 3>(ctx, v, g, f, vel, gout, gf, gv, dt, s)));
+        else PHIHIP_TRY((advect_staggered_bwd_t<float, 2>(ctx, v, g, f, vel, gout, gf, gv, dt, s)));
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
 
 template <typename T, int DIM>
-static void launch_advect_centered_bwd(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
-                                       const void* gout, void* gs, void* const gv[3], double dt, hipStream_t s) {
+static int advect_centered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
+                                 const void* gout, void* gs, void* const gv[3], double dt, hipStream_t s) {
+    T *trace[4], *du[9];
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, (size_t)v.cells, v.batch, gv ? 3 : 0, trace, du));
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
-    hipLaunchKernelGGL((advect_centered_bwd_kernel<T, DIM>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
-                       (const T*)gout, (T*)gs, gg, gv ? 1 : 0, (T)dt);
+    TraceOut<T> tr{{trace[0], trace[1], trace[2]}, trace[3], {du[0], du[1], du[2]}};
+    hipLaunchKernelGGL((advect_bwd_trace_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
+                       (const T*)gout, (T*)gs, tr, gv ? 1 : 0, (T)dt);
+    if (gs) launch_field_gather<T, DIM>(v.n, sb.bc, v.batch, tr, (T*)gs, s);
+    if (gv) {
+        for (int cb = v.ax0; cb < 3; ++cb) {
+            DuIn<T> in{{du[cb], nullptr, nullptr}};
+            const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
+            if (cb == 0) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 0, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[0]);
+            else if (cb == 1) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 1, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[1]);
+            else hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 2, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[2]);
+        }
+    }
+    return PHIHIP_OK;
 }
 
 int run_advect_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
@@ -330,11 +566,11 @@ int run_advect_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfie
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     if (v.dtype == PHIHIP_F64) {
-        if (v.rank == 3) launch_advect_centered_bwd<double, 3>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
-        else launch_advect_centered_bwd<double, 2>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+        if (v.rank == 3) PHIHIP_TRY((advect_centered_bwd_t<double, 3>(ctx, v, g, sb, sfield, vel, gout, gs, gv, dt, s)));
+        else PHIHIP_TRY((advect_centered_bwd_t<double, 2>(ctx, v, g, sb, sfield, vel, gout, gs, gv, dt, s)));
     } else {
-        if (v.rank == 3) launch_advect_centered_bwd<float, 3>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
-        else launch_advect_centered_bwd<float, 2>(v, g, sb, sfield, vel, gout, gs, gv, dt, s);
+        if (v.rank == 3) PHIHIP_TRY((advect_centered_bwd_t<float, 3>(ctx, v, g, sb, sfield, vel, gout, gs, gv, dt, s)));
+        else PHIHIP_TRY((advect_centered_bwd_t<float, 2>(ctx, v, g, sb, sfield, vel, gout, gs, gv, dt, s)));
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

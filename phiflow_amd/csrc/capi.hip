@@ -205,7 +205,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1, &ctx->ws_adj_g};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -223,7 +223,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes + ctx->ws_cg1.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes + ctx->ws_cg1.bytes + ctx->ws_adj_g.bytes;
     return PHIHIP_OK;
 }
 

@@ -82,6 +82,7 @@ def main():
             ctx.set_small_grid_solver(True)
             if dtype == np.float64 and min(res) >= 2:
                 step = "project_backward"; pc.check_project_backward(ctx, mem, dom, grid, rng)
+                step = "advect_backward"; pc.check_advect_backward(ctx, mem, dom, grid, rng, s_codes, s_consts, dt=float(r.uniform(0.1, 1.5)))
             print("ok  ", tag, flush=True)
         except Exception as e:   # noqa: BLE001 -- report and go on
             fails += 1

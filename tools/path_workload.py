@@ -155,10 +155,16 @@ def group_f32_256(ctx, dev, n, reps):
         ctx.centered_to_staggered_backward(grid, s_bc, (0.0, 0.0, 0.1), P(g_out), gs.data_ptr())
         ctx.make_incompressible_backward(grid, 0, 1, True, P(g_out), 0, solve, want_info=False)
     sync(dev)
-    note(r"advect_staggered_bwd_kernel<float, 3", "f5 adjoint of the staggered advection, one component per launch (atomic scatter)", 9 * w * N, 9,
-         "read grad_out, field, 3 velocity components; read-modify-write grad_field and (partly) 3 grad_velocity components: >= 9 words, atomics")
-    note(r"advect_centered_bwd_kernel<float, 3", "f5 adjoint of the centred advection (atomic scatter)", 10 * w * N, 10,
-         "read grad_out, scalar, 3 components; rmw grad_s, 3 grad_velocity components")
+    note(r"advect_bwd_trace_kernel<float, 3, \d, true>", "f5 advection adjoint pass A, one staggered component per launch: back-trace, store x*, g, g d(out)/d(x*)", 12 * w * N, 12,
+         "read grad_out, field, 3 velocity components; write 3 coordinates, g, 3 du (7 scratch words)")
+    note(r"advect_bwd_trace_kernel<float, 3, 2, false>", "f5 advection adjoint pass A, centred scalar", 12 * w * N, 12,
+         "read grad_out, scalar, 3 velocity components; write 3 coordinates, g, 3 du")
+    note(r"advect_bwd_field_gather_kernel<float, 3>", "f5 advection adjoint pass B: field gradient as a gather of hat weights over the 27 neighbouring samples", 6 * w * N, 6,
+         "read 3 coordinates + g (with a one-cell halo, staged in LDS), read + write grad_field")
+    note(r"advect_bwd_velocity_gather_kernel<float, 3, \d, true>", "f5 advection adjoint pass C (staggered): transposed 4-point means, one velocity component per launch", 5 * w * N, 5,
+         "read du of the 3 source components, read + write grad_velocity")
+    note(r"advect_bwd_velocity_gather_kernel<float, 3, \d, false>", "f5 advection adjoint pass C (centred samples): transposed cell-centre means", 3 * w * N, 3,
+         "read du, read + write grad_velocity")
     note(r"mac_cormack_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass (centred scalar / one staggered component per launch)", 12 * w * N, 12,
          "read grad_out, field, forward result, 3 velocity components; rmw grad_field, grad_fwd, 3 grad_velocity components")
     note(r"diffuse_kernel<float, true>", "f5 adjoint of explicit diffusion as a gather (no atomics), one component per launch", 3 * w * N, 3, "read grad_out, read + write grad_in")
