@@ -123,9 +123,13 @@ __device__ __forceinline__ bool resolve_index(int i, int n, int code_lo, int cod
 //           taps resolved with the forward index rule.
 // =====================================================================================================================
 template <typename T>
+struct alignas(4 * sizeof(T)) GatherSlot {
+    T c0, c1, c2, g;      // lookup coordinate per axis (index space of the sample's own array) and the upstream gradient of the sample (0: handled
+};                        // atomically in pass A): one 16 / 32-byte record per sample -- one store in pass A, one load per staged slot in pass B
+
+template <typename T>
 struct TraceOut {
-    T* cx[3];     // lookup coordinate per axis (index space of the sample's own array)
-    T* gw;        // upstream gradient of the sample (0: handled atomically in pass A)
+    GatherSlot<T>* rec;
     T* du[3];     // g * d(out)/d(x*_a) * d(x*_a)/d(u_a)
 };
 
@@ -160,9 +164,10 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_trace_kernel(VelGrid g, Sca
         T fr[3], dfr[3];
         lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
         gather_adjoint<T, DIM>(F, near ? nullptr : GF, ax, fr, go, dfr);
-#pragma unroll
-        for (int a = A0; a < 3; ++a) out.cx[a][o] = coord[a];
-        out.gw[o] = near ? go : T(0);
+        GatherSlot<T> rec;
+        rec.c0 = coord[0]; rec.c1 = coord[1]; rec.c2 = coord[2];
+        rec.g = near ? go : T(0);
+        out.rec[o] = rec;
         if (want_gvel) {
 #pragma unroll
             for (int a = A0; a < 3; ++a) out.du[a][o] = go * dfr[a] * -(dt * (T)g.rdx[a]);   // coord_a = idx_a - dt u_a / dx_a
@@ -196,11 +201,6 @@ __device__ __forceinline__ bool gather_slot(int i, int n, int code_lo, int code_
 template <typename T>
 __device__ __forceinline__ T hat(T x) { return fmax(T(0), T(1) - fabs(x)); }
 
-template <typename T>
-struct alignas(4 * sizeof(T)) GatherSlot {
-    T c0, c1, c2, g;      // shifted lookup coordinate of the staged sample and its upstream gradient: one 16 / 32-byte LDS access per neighbour
-};
-
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0, int n1, int n2, ScalarBc rule, TraceOut<T> in, T* __restrict__ gfield,
                                                                          int nb1, int nb2) {
@@ -214,47 +214,73 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0,
     const int g2 = (bid % nb2) * T2, g1 = ((bid / nb2) % nb1) * T1, g0 = DIM == 3 ? (bid / (nb2 * nb1)) * T0 : 0;
     // staging: every slot of the tile grown by one cell; tiles whose grown window lies inside the array skip the boundary rule (uniform)
     const bool inside = (DIM != 3 || (g0 >= 1 && g0 + T0 + 1 <= n0)) && g1 >= 1 && g1 + T1 + 1 <= n1 && g2 >= 1 && g2 + T2 + 1 <= n2;
-    for (int e = threadIdx.x; e < E0 * E1 * E2; e += kBlock) {
+    constexpr int kSlots = E0 * E1 * E2, kIters = (kSlots + kBlock - 1) / kBlock;
+    GatherSlot<T> rec[kIters];
+    T sh[kIters][3];
+    bool okv[kIters];
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {                // every record of the thread is requested before the first one is used
+        const int e = threadIdx.x + it * kBlock;
         const int l2 = e % E2, t = e / E2;
         const int l1 = t % E1, l0 = t / E1;
         int s0 = DIM == 3 ? g0 - 1 + l0 : 0, s1 = g1 - 1 + l1, s2 = g2 - 1 + l2;
         T h0 = T(0), h1 = T(0), h2 = T(0);
-        bool ok = true;
-        if (!inside) {
+        bool ok = e < kSlots;
+        if (!inside && ok) {
             if (DIM == 3) ok = gather_slot<T>(g0 - 1 + l0, n0, rule.bc[0][0], rule.bc[0][1], s0, h0);
             ok = gather_slot<T>(g1 - 1 + l1, n1, rule.bc[1][0], rule.bc[1][1], s1, h1) && ok;
             ok = gather_slot<T>(g2 - 1 + l2, n2, rule.bc[2][0], rule.bc[2][1], s2, h2) && ok;
         }
-        GatherSlot<T> v;
-        v.c0 = v.c1 = v.c2 = v.g = T(0);
-        if (ok) {
-            const long long o = base + ((long long)s0 * n1 + s1) * n2 + s2;
-            v.g = in.gw[o];
-            if (DIM == 3) v.c0 = in.cx[0][o] + h0;
-            v.c1 = in.cx[1][o] + h1;
-            v.c2 = in.cx[2][o] + h2;
-        }
-        slots[e] = v;
+        rec[it] = in.rec[ok ? base + ((long long)s0 * n1 + s1) * n2 + s2 : base];
+        sh[it][0] = h0; sh[it][1] = h1; sh[it][2] = h2;
+        okv[it] = ok;
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int e = threadIdx.x + it * kBlock;
+        GatherSlot<T> v = rec[it];
+        v.c0 += sh[it][0]; v.c1 += sh[it][1]; v.c2 += sh[it][2];
+        if (!okv[it]) v.c0 = v.c1 = v.c2 = v.g = T(0);
+        if (e < kSlots) slots[e] = v;
     }
     __syncthreads();
+    // a thread owns the T0 targets (g0 .. g0 + T0 - 1, t1, t2): every staged slot is read once and serves up to three of them -- the in-plane
+    // weights hat(c1 - t1) hat(c2 - t2) are the same for all, only the a0 weight differs
     const int tx = threadIdx.x % T2, ty = threadIdx.x / T2;
-#pragma unroll
-    for (int k0 = 0; k0 < T0; ++k0) {
-        const int t0 = g0 + k0, t1 = g1 + ty, t2 = g2 + tx;
-        if (t0 >= n0 || t1 >= n1 || t2 >= n2) continue;
-        T acc = T(0);
-#pragma unroll
-        for (int d0 = 0; d0 < (DIM == 3 ? 3 : 1); ++d0)
+    const int t1 = g1 + ty, t2 = g2 + tx;
+    const bool col_ok = t1 < n1 && t2 < n2;
+    if (DIM == 3) {
+        // plane pl of the staged window serves the targets pl - 2, pl - 1, pl (tile-local): three running sums rotate through the planes
+        T a0 = T(0), a1 = T(0), a2 = T(0);
+#pragma unroll 1
+        for (int pl = 0; pl < E0; ++pl) {
+            const T z = (T)(g0 + pl);
+            T s0 = T(0), s1 = T(0), s2 = T(0);
 #pragma unroll
             for (int d1 = 0; d1 < 3; ++d1)
 #pragma unroll
                 for (int d2 = 0; d2 < 3; ++d2) {
-                    const GatherSlot<T> v = slots[((k0 + d0) * E1 + (ty + d1)) * E2 + tx + d2];
-                    T w = v.g * hat<T>(v.c1 - (T)t1) * hat<T>(v.c2 - (T)t2);
-                    if (DIM == 3) w *= hat<T>(v.c0 - (T)t0);
-                    acc += w;
+                    const GatherSlot<T> v = slots[(pl * E1 + (ty + d1)) * E2 + tx + d2];
+                    const T w12 = v.g * hat<T>(v.c1 - (T)t1) * hat<T>(v.c2 - (T)t2);
+                    s0 += w12 * hat<T>(v.c0 - (z - T(2)));          // slot plane pl sits at unresolved index g0 - 1 + pl and serves the
+                    s1 += w12 * hat<T>(v.c0 - (z - T(1)));          // targets g0 + pl - 2, g0 + pl - 1, g0 + pl
+                    s2 += w12 * hat<T>(v.c0 - z);
                 }
-        gfield[base + ((long long)t0 * n1 + t1) * n2 + t2] += acc;
+            a0 += s0; a1 += s1; a2 += s2;
+            const int k0 = pl - 2;                                  // the target one plane below the slot plane has seen its three planes
+            if (k0 >= 0 && g0 + k0 < n0 && col_ok) gfield[base + ((long long)(g0 + k0) * n1 + t1) * n2 + t2] += a0;
+            a0 = a1; a1 = a2; a2 = T(0);
+        }
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+            for (int d2 = 0; d2 < 3; ++d2) {
+                const GatherSlot<T> v = slots[(ty + d1) * E2 + tx + d2];
+                acc += v.g * hat<T>(v.c1 - (T)t1) * hat<T>(v.c2 - (T)t2);
+            }
+        if (col_ok) gfield[base + (long long)t1 * n2 + t2] += acc;
     }
 }
 
@@ -320,18 +346,41 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelG
                 const int stride[3] = {s1 * s2, s2, 1};
                 const AxisSources A = transposed_sources(j[ca], g.cn[cb][ca], g.bc[ca][0], g.bc[ca][1], g.off[ca] - 1, g.cn[ca][ca]);
                 const AxisSources B = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.cn[ca][cb]);
-                long long rest = 0;
+                int rest = 0;                                         // (32-bit offsets within one batch entry: < 2^31 samples, checked by the caller)
 #pragma unroll
                 for (int ax = A0; ax < 3; ++ax)
-                    if (ax != ca && ax != cb) rest += (long long)j[ax] * stride[ax];
+                    if (ax != ca && ax != cb) rest += j[ax] * stride[ax];
                 const T* __restrict__ D = du.p[ca] + (long long)b * g.ccells[ca];
+                int oa[6], ob[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { oa[k] = rest + A.q[k] * stride[ca]; ob[k] = B.q[k] * stride[cb]; }
+                // the target's own position (entries 0, 1 of both axes) branch-free: four independent loads in flight; the ghost positions at the
+                // ends of the array under uniform branches
+                T val[2][2];
+#pragma unroll
+                for (int ka = 0; ka < 2; ++ka)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) val[ka][kb] = D[(A.on[ka] && B.on[kb]) ? oa[ka] + ob[kb] : 0];
                 T part = T(0);
 #pragma unroll
-                for (int ka = 0; ka < 6; ++ka) {
-                    if (!wave_any(A.on[ka])) continue;
+                for (int ka = 0; ka < 2; ++ka)
 #pragma unroll
-                    for (int kb = 0; kb < 6; ++kb)
-                        if (A.on[ka] && B.on[kb]) part += D[rest + (long long)A.q[ka] * stride[ca] + (long long)B.q[kb] * stride[cb]];
+                    for (int kb = 0; kb < 2; ++kb) part += (A.on[ka] && B.on[kb]) ? val[ka][kb] : T(0);
+                bool ghost = false;
+#pragma unroll
+                for (int k = 2; k < 6; ++k) ghost = ghost || A.on[k] || B.on[k];
+                if (wave_any(ghost)) {                              // wavefronts at an end of the array: the 32 remaining slots, again all loads first
+                    T gval[32];
+                    int m = 0;
+#pragma unroll
+                    for (int ka = 0; ka < 6; ++ka)
+#pragma unroll
+                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) gval[m++] = D[(A.on[ka] && B.on[kb]) ? oa[ka] + ob[kb] : 0];
+                    m = 0;
+#pragma unroll
+                    for (int ka = 0; ka < 6; ++ka)
+#pragma unroll
+                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) part += (A.on[ka] && B.on[kb]) ? gval[m++] : (m++, T(0));
                 }
                 acc += T(0.25) * part;
             }
@@ -339,15 +388,20 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelG
             // cells whose centre mean of component cb reads face j: faces (s, s + 1) along cb with s = idx[cb] - off[cb]
             const int stride[3] = {g.n[1] * g.n[2], g.n[2], 1};
             const AxisSources B = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.n[cb]);
-            long long rest = 0;
+            int rest = 0;
 #pragma unroll
             for (int ax = A0; ax < 3; ++ax)
-                if (ax != cb) rest += (long long)j[ax] * stride[ax];
+                if (ax != cb) rest += j[ax] * stride[ax];
             const T* __restrict__ D = du.p[0] + (long long)b * g.cells;
-            T part = T(0);
+            const T v0 = D[B.on[0] ? rest + B.q[0] * stride[cb] : 0], v1 = D[B.on[1] ? rest + B.q[1] * stride[cb] : 0];
+            T part = (B.on[0] ? v0 : T(0)) + (B.on[1] ? v1 : T(0));
+            if (wave_any(B.on[2] || B.on[3] || B.on[4] || B.on[5])) {
+                T gval[4];
 #pragma unroll
-            for (int kb = 0; kb < 6; ++kb)
-                if (B.on[kb]) part += D[rest + (long long)B.q[kb] * stride[cb]];
+                for (int kb = 2; kb < 6; ++kb) gval[kb - 2] = D[B.on[kb] ? rest + B.q[kb] * stride[cb] : 0];
+#pragma unroll
+                for (int kb = 2; kb < 6; ++kb) part += B.on[kb] ? gval[kb - 2] : T(0);
+            }
             acc = T(0.5) * part;
         }
         gvel[(long long)b * total + f] += acc;
@@ -503,7 +557,7 @@ static int advect_staggered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelG
     ScalarBc none;
     memset(&none, 0, sizeof(none));
     for (int ca = v.ax0; ca < 3; ++ca) {
-        TraceOut<T> tr{{trace[0], trace[1], trace[2]}, trace[3], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
+        TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};      // (the four trace slots are contiguous)
         const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);
         T* gfield = gf ? (T*)gf[ca] : nullptr;
 #define PHIHIP_TRACE(CA) hipLaunchKernelGGL((advect_bwd_trace_kernel<T, DIM, CA, true>), grid, dim3(kBlock), 0, s, g, none, (const T*)f[ca], vv, (const T*)gout[ca], gfield, tr, gv ? 1 : 0, (T)dt)
@@ -544,7 +598,7 @@ static int advect_centered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelGr
     T *trace[4], *du[9];
     PHIHIP_TRY(adjoint_scratch<T>(ctx, (size_t)v.cells, v.batch, gv ? 3 : 0, trace, du));
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    TraceOut<T> tr{{trace[0], trace[1], trace[2]}, trace[3], {du[0], du[1], du[2]}};
+    TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[0], du[1], du[2]}};
     hipLaunchKernelGGL((advect_bwd_trace_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
                        (const T*)gout, (T*)gs, tr, gv ? 1 : 0, (T)dt);
     if (gs) launch_field_gather<T, DIM>(v.n, sb.bc, v.batch, tr, (T*)gs, s);
