@@ -461,7 +461,7 @@ __device__ __forceinline__ void gather_minmax_arg(const T* __restrict__ F, const
 template <typename T, int DIM, int CA, bool STAG>
 __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield,
                                                                  CComp3a<T> vel, const T* __restrict__ fwd, const T* __restrict__ gout,
-                                                                 T* __restrict__ gfwd, T* __restrict__ gfield, Comp3w<T> gvel, int want_gvel,
+                                                                 T* __restrict__ gfwd, T* __restrict__ gfield, TraceOut<T> out, int want_gvel,
                                                                  T dt, T ch) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
         T lo, hi;
         int off_lo, off_hi;
         gather_minmax_arg<T, DIM>(F, axl, lo, hi, off_lo, off_hi);
+        // the forward lookup's scatter (into g_fwd) and the velocity means go through the gather passes: record (x + dt u, gb), gb d(out)/d(x*)
+        GatherSlot<T> rec;
+        rec.c0 = cf_[0]; rec.c1 = cf_[1]; rec.c2 = cf_[2];
+        rec.g = T(0);
+        T du[3] = {T(0), T(0), T(0)};
         if (nv < lo) {
             if (off_lo >= 0) atomicAdd(GF + off_lo, go);
         } else if (nv > hi) {
@@ -508,14 +513,20 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
             atomicAdd(GW + f, go);
             atomicAdd(GF + f, ch * go);
             const T gb = -ch * go;
-            T dfr[3];
-            gather_adjoint<T, DIM>(W, GW, ax, fr, gb, dfr);
-            if (want_gvel) {
-                T du[3] = {T(0), T(0), T(0)};
+            bool near = true;
 #pragma unroll
-                for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt * (T)g.rdx[a]);   // cf_a = idx_a + dt u_a / dx_a
-                if (STAG) face_velocity_adjoint<T, DIM, CA>(g, gvel, b, idx, f, du); else center_velocity_adjoint<T, DIM>(g, gvel, b, idx, du);
-            }
+            for (int a = A0; a < 3; ++a) near = near && fabs(cf_[a] - (T)idx[a]) < T(1);
+            T dfr[3];
+            gather_adjoint<T, DIM>(W, near ? nullptr : GW, ax, fr, gb, dfr);
+            rec.g = near ? gb : T(0);
+#pragma unroll
+            for (int a = A0; a < 3; ++a) du[a] = gb * dfr[a] * (dt * (T)g.rdx[a]);   // cf_a = idx_a + dt u_a / dx_a
+        }
+        const long long o = (long long)b * total + f;
+        out.rec[o] = rec;
+        if (want_gvel) {
+#pragma unroll
+            for (int a = A0; a < 3; ++a) out.du[a][o] = du[a];
         }
     }
 }
@@ -546,6 +557,18 @@ static void launch_field_gather(const int n[3], const int bc[3][2], int batch, c
                        nb1, nb2);
 }
 
+// pass C for every velocity component: du[3 ca + cb] = source component ca (staggered samples) resp. du[cb] (cell samples)
+template <typename T, int DIM, bool STAG>
+static void launch_velocity_gathers(const GridView& v, const VelGrid& g, T* const du[9], void* const gv[3], hipStream_t s) {
+    for (int cb = v.ax0; cb < 3; ++cb) {
+        DuIn<T> in{{STAG ? du[0 + cb] : du[cb], STAG ? du[3 + cb] : nullptr, STAG ? du[6 + cb] : nullptr}};
+        const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
+        if (cb == 0) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 0, STAG>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[0]);
+        else if (cb == 1) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 1, STAG>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[1]);
+        else hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 2, STAG>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[2]);
+    }
+}
+
 template <typename T, int DIM>
 static int advect_staggered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3],
                                   const void* const gout[3], void* const gf[3], void* const gv[3], double dt, hipStream_t s) {
@@ -565,15 +588,7 @@ static int advect_staggered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelG
 #undef PHIHIP_TRACE
         if (gfield) launch_field_gather<T, DIM>(v.cn[ca], v.bc, v.batch, tr, gfield, s);
     }
-    if (gv) {
-        for (int cb = v.ax0; cb < 3; ++cb) {
-            DuIn<T> in{{du[0 + cb], du[3 + cb], du[6 + cb]}};      // du[3 ca + cb]: source component ca, velocity axis cb
-            const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
-            if (cb == 0) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 0, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[0]);
-            else if (cb == 1) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 1, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[1]);
-            else hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 2, true>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[2]);
-        }
-    }
+    if (gv) launch_velocity_gathers<T, DIM, true>(v, g, du, gv, s);
     return PHIHIP_OK;
 }
 
@@ -602,15 +617,7 @@ static int advect_centered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelGr
     hipLaunchKernelGGL((advect_bwd_trace_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, (const T*)sfield, vv,
                        (const T*)gout, (T*)gs, tr, gv ? 1 : 0, (T)dt);
     if (gs) launch_field_gather<T, DIM>(v.n, sb.bc, v.batch, tr, (T*)gs, s);
-    if (gv) {
-        for (int cb = v.ax0; cb < 3; ++cb) {
-            DuIn<T> in{{du[cb], nullptr, nullptr}};
-            const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
-            if (cb == 0) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 0, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[0]);
-            else if (cb == 1) hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 1, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[1]);
-            else hipLaunchKernelGGL((advect_bwd_velocity_gather_kernel<T, DIM, 2, false>), grid, dim3(kBlock), 0, s, g, in, (T*)gv[2]);
-        }
-    }
+    if (gv) launch_velocity_gathers<T, DIM, false>(v, g, du, gv, s);
     return PHIHIP_OK;
 }
 
@@ -653,22 +660,29 @@ int run_advect_centered(phihip_ctx*, const GridView&, const void* s, const int32
                         void* out, double dt, hipStream_t);
 
 template <typename T, int DIM>
-static void launch_mc_staggered_bwd(const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3], void* const fwd[3],
-                                    const void* const gout[3], void* const gfwd[3], void* const gf[3], void* const gv[3], double dt, double ch,
-                                    hipStream_t s) {
+static int launch_mc_staggered_bwd(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const void* const f[3], const void* const vel[3], void* const fwd[3],
+                                   const void* const gout[3], void* const gfwd[3], void* const gf[3], void* const gv[3], double dt, double ch,
+                                   hipStream_t s) {
     CComp3a<T> ff{{(const T*)f[0], (const T*)f[1], (const T*)f[2]}};
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
     ScalarBc sb;
     memset(&sb, 0, sizeof(sb));
     const int want = gv ? 1 : 0;
-    if (DIM == 3)
-        hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 0, true>), dim3(bwd_blocks(v.ccells[0]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
-                           (const T*)nullptr, vv, (const T*)fwd[0], (const T*)gout[0], (T*)gfwd[0], (T*)gf[0], gg, want, (T)dt, (T)ch);
-    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 1, true>), dim3(bwd_blocks(v.ccells[1]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
-                       (const T*)nullptr, vv, (const T*)fwd[1], (const T*)gout[1], (T*)gfwd[1], (T*)gf[1], gg, want, (T)dt, (T)ch);
-    hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, true>), dim3(bwd_blocks(v.ccells[2]), v.batch), dim3(kBlock), 0, s, g, sb, ff,
-                       (const T*)nullptr, vv, (const T*)fwd[2], (const T*)gout[2], (T*)gfwd[2], (T*)gf[2], gg, want, (T)dt, (T)ch);
+    size_t max_samples = 0;
+    for (int ca = v.ax0; ca < 3; ++ca) max_samples = (size_t)v.ccells[ca] > max_samples ? (size_t)v.ccells[ca] : max_samples;
+    T *trace[4], *du[9];
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du));
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
+        const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);
+#define PHIHIP_MC(CA) hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, CA, true>), grid, dim3(kBlock), 0, s, g, sb, ff, (const T*)nullptr, vv, (const T*)fwd[ca], \
+                                         (const T*)gout[ca], (T*)gfwd[ca], (T*)gf[ca], tr, want, (T)dt, (T)ch)
+        if (ca == 0) PHIHIP_MC(0); else if (ca == 1) PHIHIP_MC(1); else PHIHIP_MC(2);
+#undef PHIHIP_MC
+        launch_field_gather<T, DIM>(v.cn[ca], v.bc, v.batch, tr, (T*)gfwd[ca], s);          // the forward lookup's taps -> g_fwd
+    }
+    if (gv) launch_velocity_gathers<T, DIM, true>(v, g, du, gv, s);
+    return PHIHIP_OK;
 }
 
 // scratch layout for the MacCormack adjoints: [fwd | g_fwd] per component, 256-byte aligned
@@ -699,11 +713,11 @@ int run_mac_cormack_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void
     {
         LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
         if (v.dtype == PHIHIP_F64) {
-            if (v.rank == 3) launch_mc_staggered_bwd<double, 3>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
-            else launch_mc_staggered_bwd<double, 2>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_mc_staggered_bwd<double, 3>(ctx, v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s)));
+            else PHIHIP_TRY((launch_mc_staggered_bwd<double, 2>(ctx, v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s)));
         } else {
-            if (v.rank == 3) launch_mc_staggered_bwd<float, 3>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
-            else launch_mc_staggered_bwd<float, 2>(v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_mc_staggered_bwd<float, 3>(ctx, v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s)));
+            else PHIHIP_TRY((launch_mc_staggered_bwd<float, 2>(ctx, v, g, f, vel, fwd, gout, gfwd, gf, gv, dt, 0.5 * strength, s)));
         }
     }
     const void* cg[3] = {gfwd[0], gfwd[1], gfwd[2]};
@@ -713,14 +727,19 @@ int run_mac_cormack_staggered_bwd(phihip_ctx* ctx, const GridView& v, const void
 }
 
 template <typename T, int DIM>
-static void launch_mc_centered_bwd(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
-                                   const void* fwd, const void* gout, void* gfwd, void* gs, void* const gv[3], double dt, double ch,
-                                   hipStream_t s) {
+static int launch_mc_centered_bwd(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const void* const vel[3],
+                                  const void* fwd, const void* gout, void* gfwd, void* gs, void* const gv[3], double dt, double ch,
+                                  hipStream_t s) {
     CComp3a<T> none{{nullptr, nullptr, nullptr}};
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    Comp3w<T> gg{{gv ? (T*)gv[0] : nullptr, gv ? (T*)gv[1] : nullptr, gv ? (T*)gv[2] : nullptr}};
+    T *trace[4], *du[9];
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, (size_t)v.cells, v.batch, gv ? 3 : 0, trace, du));
+    TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[0], du[1], du[2]}};
     hipLaunchKernelGGL((mac_cormack_bwd_kernel<T, DIM, 2, false>), dim3(bwd_blocks(v.cells), v.batch), dim3(kBlock), 0, s, g, sb, none,
-                       (const T*)sfield, vv, (const T*)fwd, (const T*)gout, (T*)gfwd, (T*)gs, gg, gv ? 1 : 0, (T)dt, (T)ch);
+                       (const T*)sfield, vv, (const T*)fwd, (const T*)gout, (T*)gfwd, (T*)gs, tr, gv ? 1 : 0, (T)dt, (T)ch);
+    launch_field_gather<T, DIM>(v.n, sb.bc, v.batch, tr, (T*)gfwd, s);
+    if (gv) launch_velocity_gathers<T, DIM, false>(v, g, du, gv, s);
+    return PHIHIP_OK;
 }
 
 int run_mac_cormack_centered_bwd(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
@@ -736,11 +755,11 @@ int run_mac_cormack_centered_bwd(phihip_ctx* ctx, const GridView& v, const void*
     {
         LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
         if (v.dtype == PHIHIP_F64) {
-            if (v.rank == 3) launch_mc_centered_bwd<double, 3>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
-            else launch_mc_centered_bwd<double, 2>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_mc_centered_bwd<double, 3>(ctx, v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s)));
+            else PHIHIP_TRY((launch_mc_centered_bwd<double, 2>(ctx, v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s)));
         } else {
-            if (v.rank == 3) launch_mc_centered_bwd<float, 3>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
-            else launch_mc_centered_bwd<float, 2>(v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_mc_centered_bwd<float, 3>(ctx, v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s)));
+            else PHIHIP_TRY((launch_mc_centered_bwd<float, 2>(ctx, v, g, sb, sfield, vel, fwd[2], gout, gfwd[2], gs, gv, dt, 0.5 * strength, s)));
         }
     }
     PHIHIP_TRY(run_advect_centered_bwd(ctx, v, sfield, s_bc, s_val, vel, gfwd[2], gs, gv, dt, s));
