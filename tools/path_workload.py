@@ -165,7 +165,7 @@ def group_f32_256(ctx, dev, n, reps):
          "read du of the 3 source components, read + write grad_velocity")
     note(r"advect_bwd_velocity_gather_kernel<float, 3, \d, false>", "f5 advection adjoint pass C (centred samples): transposed cell-centre means", 3 * w * N, 3,
          "read du, read + write grad_velocity")
-    note(r"mac_cormack_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass (centred scalar / one staggered component per launch)", 12 * w * N, 12,
+    note(r"mac_cormack_bwd_kernel<float, 3", "f5 adjoint of the MacCormack correction pass (centred scalar / one staggered component per launch); lookup scatter via passes B / C", 15 * w * N, 15,
          "read grad_out, field, forward result, 3 velocity components; rmw grad_field, grad_fwd, 3 grad_velocity components")
     note(r"diffuse_kernel<float, true>", "f5 adjoint of explicit diffusion as a gather (no atomics), one component per launch", 3 * w * N, 3, "read grad_out, read + write grad_in")
     note(r"c2s_bwd_kernel<float", "f5 adjoint of the buoyancy resample", 3 * w * N, 3, "read grad_out component, rmw grad_s")
