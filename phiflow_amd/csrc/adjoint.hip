@@ -1,8 +1,9 @@
 // adjoint.hip -- backward passes (vector-Jacobian products) of the fluid step, SURVEY §8 f5: PhiFlow is differentiable through
 // its backends' autodiff (/root/reference tests/commit/physics/test_fluid.py:55-73, tests/commit/test_colab_fluids_tutorial.py:11-34);
 // here every forward kernel gets a hand-written adjoint:
-//   * semi-Lagrangian advection: the gather becomes a scatter-add (atomicAdd) into the advected field AND, through the lookup
-//     coordinates x* = x - dt u, into the advecting velocity (own component + the 4-point means of the others);
+//   * semi-Lagrangian advection: the transposed gather into the advected field AND, through the lookup coordinates x* = x - dt u, into the
+//     advecting velocity (own component + the 4-point means of the others) -- as three gather passes without atomics (r3, below); the
+//     scatter-add form (atomicAdd per tap) remains for samples whose lookup left their cell neighbourhood and for grid_sample;
 //   * centred -> staggered resample: adjoint scatter into the cells;
 //   * make_incompressible: the implicit-function adjoint of the linear solve (A is symmetric: one more CG solve with the
 //     same matrix-free operator), divergence and gradient swap roles (G^T = -D with homogeneous boundary values).
@@ -45,55 +46,6 @@ __device__ __forceinline__ void gather_adjoint(const T* __restrict__ F, T* __res
         if (DIM == 3) dfr[0] += val * (b0 ? T(1) : T(-1)) * w1 * w2;
         dfr[1] += val * (b1 ? T(1) : T(-1)) * w0 * w2;
         dfr[2] += val * (b2 ? T(1) : T(-1)) * w0 * w1;
-    }
-}
-
-// adjoint of face_velocity: du[cb] (physical units) scattered into the velocity gradient
-template <typename T, int DIM, int CA>
-__device__ __forceinline__ void face_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], int f, const T (&du)[3]) {
-    constexpr int A0 = 3 - DIM;
-    constexpr int ca = CA;
-#pragma unroll
-    for (int cb = A0; cb < 3; ++cb) {
-        if (cb == ca) {
-            atomicAdd(gvel.p[ca] + (long long)b * g.ccells[ca] + f, du[cb]);
-        } else {
-            const int m = idx[ca] + g.off[ca];
-            const int s = idx[cb] - g.off[cb];
-            const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
-            const int stride[3] = {n1 * n2, n2, 1};
-            T* __restrict__ C = gvel.p[cb] + (long long)b * g.ccells[cb];
-            const AxisPair<T> pa = make_pair<T>(m - 1, g.cn[cb][ca], stride[ca], g.bc[ca][0], g.bc[ca][1], (T)g.bcv[ca][0][cb], (T)g.bcv[ca][1][cb]);
-            const AxisPair<T> pb = make_pair<T>(s, g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
-            int rest = 0;
-#pragma unroll
-            for (int ax = A0; ax < 3; ++ax)
-                if (ax != ca && ax != cb) rest += idx[ax] * stride[ax];
-            const T q = du[cb] * T(0.25);
-#pragma unroll
-            for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
-                    if (!pa.cst[ia] && !pb.cst[ib]) atomicAdd(C + rest + pa.off[ia] + pb.off[ib], q);
-        }
-    }
-}
-
-template <typename T, int DIM>
-__device__ __forceinline__ void center_velocity_adjoint(const VelGrid& g, const Comp3w<T>& gvel, int b, const int (&idx)[3], const T (&du)[3]) {
-    constexpr int A0 = 3 - DIM;
-#pragma unroll
-    for (int cb = A0; cb < 3; ++cb) {
-        const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
-        const int stride[3] = {n1 * n2, n2, 1};
-        T* __restrict__ C = gvel.p[cb] + (long long)b * g.ccells[cb];
-        const AxisPair<T> pb = make_pair<T>(idx[cb] - g.off[cb], g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
-        int rest = 0;
-#pragma unroll
-        for (int ax = A0; ax < 3; ++ax)
-            if (ax != cb) rest += idx[ax] * stride[ax];
-        if (!pb.cst[0]) atomicAdd(C + rest + pb.off[0], du[cb] * T(0.5));
-        if (!pb.cst[1]) atomicAdd(C + rest + pb.off[1], du[cb] * T(0.5));
     }
 }
 
