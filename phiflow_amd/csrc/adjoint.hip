@@ -71,8 +71,8 @@ __device__ __forceinline__ bool resolve_index(int i, int n, int code_lo, int cod
 //           coordinate shifted by i - s, the EDGE sample itself with the coordinate shifted by s - i under a clamped (zero-gradient) side -- the
 //           taps beyond the edge are the edge cell --, nothing beyond a constant side (those taps are constants).
 //   pass C  per sample j of velocity component cb: the transposed means -- sum over the samples whose velocity lookup read j of their
-//           g d(out)/d(x*_cb) with the forward weights (own component 1, 4-point means 1/4 each, cell-centre means 1/2 each), the candidates'
-//           taps resolved with the forward index rule.
+//           g d(out)/d(x*_cb) with the forward weights (own component 1, 4-point means 1/4 each, cell-centre means 1/2 each); per axis the
+//           unresolved positions that resolve to j -- itself and the ghost positions at the ends of the array -- name the sources.
 // =====================================================================================================================
 template <typename T>
 struct alignas(4 * sizeof(T)) GatherSlot {
@@ -288,51 +288,58 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelG
         unravel(f, n[1], n[2], j);
         T acc = T(0);
         if (STAG) {
-            acc = du.p[cb][(long long)b * total + f];                       // own component: the sample reads itself with weight 1
+            // faces of component ca (array shape cn[ca]) whose 4-point mean of component cb reads sample j: cells (m - 1, m) along ca with
+            // m = idx[ca] + off[ca], faces (s, s + 1) along cb with s = idx[cb] - off[cb]; the other axis is shared. Phase 1 requests the own
+            // sample and the own-position sources of BOTH other components (entries 0, 1 of both axes: branch-free, nine loads in flight);
+            // phase 2 sums them and handles the ghost positions at the ends of the array under one uniform branch per component.
+            AxisSources A[3], B[3];
+            int oa[3][6], ob[3][6];
+            T val[3][2][2];
+            const T* D[3] = {nullptr, nullptr, nullptr};
+            const T own = du.p[cb][(long long)b * total + f];                   // own component: the sample reads itself with weight 1
 #pragma unroll
             for (int ca = A0; ca < 3; ++ca) {
                 if (ca == cb) continue;
-                // faces of component ca (array shape cn[ca]) whose 4-point mean of component cb reads sample j: cells (m - 1, m) along ca with
-                // m = idx[ca] + off[ca], faces (s, s + 1) along cb with s = idx[cb] - off[cb]; the other axis is shared
                 const int s1 = g.cn[ca][1], s2 = g.cn[ca][2];
                 const int stride[3] = {s1 * s2, s2, 1};
-                const AxisSources A = transposed_sources(j[ca], g.cn[cb][ca], g.bc[ca][0], g.bc[ca][1], g.off[ca] - 1, g.cn[ca][ca]);
-                const AxisSources B = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.cn[ca][cb]);
+                A[ca] = transposed_sources(j[ca], g.cn[cb][ca], g.bc[ca][0], g.bc[ca][1], g.off[ca] - 1, g.cn[ca][ca]);
+                B[ca] = transposed_sources(j[cb], g.cn[cb][cb], g.bc[cb][0], g.bc[cb][1], -g.off[cb], g.cn[ca][cb]);
                 int rest = 0;                                         // (32-bit offsets within one batch entry: < 2^31 samples, checked by the caller)
 #pragma unroll
                 for (int ax = A0; ax < 3; ++ax)
                     if (ax != ca && ax != cb) rest += j[ax] * stride[ax];
-                const T* __restrict__ D = du.p[ca] + (long long)b * g.ccells[ca];
-                int oa[6], ob[6];
+                D[ca] = du.p[ca] + (long long)b * g.ccells[ca];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { oa[k] = rest + A.q[k] * stride[ca]; ob[k] = B.q[k] * stride[cb]; }
-                // the target's own position (entries 0, 1 of both axes) branch-free: four independent loads in flight; the ghost positions at the
-                // ends of the array under uniform branches
-                T val[2][2];
+                for (int k = 0; k < 6; ++k) { oa[ca][k] = rest + A[ca].q[k] * stride[ca]; ob[ca][k] = B[ca].q[k] * stride[cb]; }
 #pragma unroll
                 for (int ka = 0; ka < 2; ++ka)
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) val[ka][kb] = D[(A.on[ka] && B.on[kb]) ? oa[ka] + ob[kb] : 0];
+                    for (int kb = 0; kb < 2; ++kb) val[ca][ka][kb] = D[ca][(A[ca].on[ka] && B[ca].on[kb]) ? oa[ca][ka] + ob[ca][kb] : 0];
+            }
+            acc = own;
+#pragma unroll
+            for (int ca = A0; ca < 3; ++ca) {
+                if (ca == cb) continue;
                 T part = T(0);
 #pragma unroll
                 for (int ka = 0; ka < 2; ++ka)
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) part += (A.on[ka] && B.on[kb]) ? val[ka][kb] : T(0);
+                    for (int kb = 0; kb < 2; ++kb) part += (A[ca].on[ka] && B[ca].on[kb]) ? val[ca][ka][kb] : T(0);
                 bool ghost = false;
 #pragma unroll
-                for (int k = 2; k < 6; ++k) ghost = ghost || A.on[k] || B.on[k];
+                for (int k = 2; k < 6; ++k) ghost = ghost || A[ca].on[k] || B[ca].on[k];
                 if (wave_any(ghost)) {                              // wavefronts at an end of the array: the 32 remaining slots, again all loads first
                     T gval[32];
                     int m = 0;
 #pragma unroll
                     for (int ka = 0; ka < 6; ++ka)
 #pragma unroll
-                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) gval[m++] = D[(A.on[ka] && B.on[kb]) ? oa[ka] + ob[kb] : 0];
+                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) gval[m++] = D[ca][(A[ca].on[ka] && B[ca].on[kb]) ? oa[ca][ka] + ob[ca][kb] : 0];
                     m = 0;
 #pragma unroll
                     for (int ka = 0; ka < 6; ++ka)
 #pragma unroll
-                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) part += (A.on[ka] && B.on[kb]) ? gval[m++] : (m++, T(0));
+                        for (int kb = (ka < 2 ? 2 : 0); kb < 6; ++kb) part += (A[ca].on[ka] && B[ca].on[kb]) ? gval[m++] : (m++, T(0));
                 }
                 acc += T(0.25) * part;
             }
