@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""
+Forward and backward time of ONE differentiated fluid step through the phi-level API (the pattern of tests/commit/physics/test_fluid.py:55-73
+and test_colab_fluids_tutorial.py:11-34 at benchmark size): loss = l2(make_incompressible(semi_lagrangian(v, v, dt))), gradient w.r.t. v.
+The backward pass = the implicit-function adjoint of the projection (one more CG solve with the same iteration count) + the gather-form
+adjoint of the self-advection.
+    python tools/time_backward_step.py --size 256 --iters 100
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phiflow_amd.flow import *   # noqa: E402,F401,F403
+from phiflow_amd.flow import default_backend, functional_gradient, l2_loss, NotConverged   # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    n, L = args.size, 2 * math.pi
+    be = default_backend()
+    h = L / n
+    face = torch.arange(n, dtype=torch.float32) * h
+    cent = (torch.arange(n, dtype=torch.float32) + 0.5) * h
+    u = (torch.cos(face)[:, None, None] * torch.sin(cent)[None, :, None]).expand(n, n, n)
+    w = (-torch.sin(cent)[:, None, None] * torch.cos(face)[None, :, None]).expand(n, n, n)
+    comps = [t.contiguous()[None].to(be.device) for t in (u, w, torch.zeros(n, n, n))]
+    mk = lambda: StaggeredGrid([c.clone() for c in comps], PERIODIC, Box(x=L, y=L, z=L), x=n, y=n, z=n)
+    solve = Solve('CG', 0, 0, max_iterations=args.iters, suppress=[NotConverged])       # benchmark mode: exactly `iters` iterations, forward and backward
+    dt = 0.5 * h
+
+    def simulate(v):
+        v = advect.semi_lagrangian(v, v, dt)
+        v, p = fluid.make_incompressible(v, (), solve)
+        return l2_loss(v)
+
+    grad = functional_gradient(simulate, wrt=[0], get_output=True)
+
+    def sync():
+        torch.cuda.synchronize()
+
+    simulate(mk()); grad(mk()); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        with torch.no_grad():
+            simulate(mk())
+    sync()
+    t_fwd = (time.perf_counter() - t0) / args.reps
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        loss, (g,) = grad(mk())
+    sync()
+    t_both = (time.perf_counter() - t0) / args.reps
+    gn = math.sqrt(sum(float((c.astype('float64') ** 2).sum()) for c in g.numpy()))
+    print(json.dumps({"size": n, "cg_iterations": args.iters, "ms_forward_only": t_fwd * 1e3, "ms_forward_plus_backward": t_both * 1e3,
+                      "ms_backward": (t_both - t_fwd) * 1e3, "loss": float(loss.detach()), "gradient_norm": gn, "finite": math.isfinite(gn)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
