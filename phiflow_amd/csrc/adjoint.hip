@@ -367,27 +367,40 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelG
     }
 }
 
-// adjoint of centered_to_staggered_kernel: gs[cell] += 0.5 * scale * gout[face] for both cells of every stored face
+// adjoint of centered_to_staggered_kernel (face = 0.5 * scale * (cell left + cell right)) as a gather: every cell sums the faces whose pair
+// (phys - 1, phys) resolves to it under the scalar's extrapolation -- the transposed pair stencil of pass C, all components in one launch
 template <typename T>
-__global__ __launch_bounds__(kBlock) void c2s_bwd_kernel(VelGrid g, ScalarBc sb, int ca, const T* __restrict__ gout, T* __restrict__ gs, T scale) {
+__global__ __launch_bounds__(kBlock) void c2s_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> gout, T* __restrict__ gs, T sc0, T sc1, T sc2) {
     const int b = blockIdx.y;
-    const int total = (int)g.ccells[ca];
-    const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
-    const int n = g.n[ca];
-    const int pstride = ca == 0 ? g.n[1] * g.n[2] : (ca == 1 ? g.n[2] : 1);
-    T* __restrict__ S = gs + (long long)b * g.cells;
+    const int total = (int)g.cells;
+    const T scale[3] = {sc0, sc1, sc2};
     for (int f = blockIdx.x * kBlock + threadIdx.x; f < total; f += gridDim.x * kBlock) {
         int idx[3];
-        unravel(f, c1, c2, idx);
-        const int phys = idx[ca] + g.off[ca];
-        int l = phys - 1, r = phys;
-        bool cl = false, cr = false;
-        if (l < 0) { if (sb.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { cl = sb.bc[ca][0] == PHIHIP_BC_CLOSED; l = 0; } }
-        if (r >= n) { if (sb.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { cr = sb.bc[ca][1] == PHIHIP_BC_CLOSED; r = n - 1; } }
-        const int rest = (idx[0] * g.n[1] + idx[1]) * g.n[2] + idx[2] - idx[ca] * pstride;
-        const T q = gout[(long long)b * total + f] * T(0.5) * scale;
-        if (!cl) atomicAdd(S + rest + l * pstride, q);
-        if (!cr) atomicAdd(S + rest + r * pstride, q);
+        unravel(f, g.n[1], g.n[2], idx);
+        T acc = T(0);
+#pragma unroll
+        for (int ca = 0; ca < 3; ++ca) {
+            if (ca < g.ax0 || scale[ca] == T(0)) continue;
+            const int s1 = g.cn[ca][1], s2 = g.cn[ca][2];
+            const int stride[3] = {s1 * s2, s2, 1};
+            const AxisSources A = transposed_sources(idx[ca], g.n[ca], sb.bc[ca][0], sb.bc[ca][1], g.off[ca] - 1, g.cn[ca][ca]);
+            int rest = 0;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax)
+                if (ax != ca) rest += idx[ax] * stride[ax];
+            const T* __restrict__ D = gout.p[ca] + (long long)b * g.ccells[ca];
+            const T v0 = D[A.on[0] ? rest + A.q[0] * stride[ca] : 0], v1 = D[A.on[1] ? rest + A.q[1] * stride[ca] : 0];
+            T part = (A.on[0] ? v0 : T(0)) + (A.on[1] ? v1 : T(0));
+            if (wave_any(A.on[2] || A.on[3] || A.on[4] || A.on[5])) {
+                T gval[4];
+#pragma unroll
+                for (int k = 2; k < 6; ++k) gval[k - 2] = D[A.on[k] ? rest + A.q[k] * stride[ca] : 0];
+#pragma unroll
+                for (int k = 2; k < 6; ++k) part += A.on[k] ? gval[k - 2] : T(0);
+            }
+            acc += T(0.5) * scale[ca] * part;
+        }
+        gs[(long long)b * total + f] += acc;
     }
 }
 
@@ -601,15 +614,13 @@ int run_centered_to_staggered_bwd(phihip_ctx* ctx, const GridView& v, const int3
     const VelGrid g = make_velgrid(v);
     const ScalarBc sb = make_scalar_bc(v, s_bc, nullptr);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    for (int ca = v.ax0; ca < 3; ++ca) {
-        if (vector[ca] == 0.0) continue;
-        if (v.dtype == PHIHIP_F64)
-            hipLaunchKernelGGL(c2s_bwd_kernel<double>, dim3(bwd_blocks(v.ccells[ca]), v.batch), dim3(kBlock), 0, s, g, sb, ca, (const double*)gout[ca],
-                               (double*)gs, vector[ca]);
-        else
-            hipLaunchKernelGGL(c2s_bwd_kernel<float>, dim3(bwd_blocks(v.ccells[ca]), v.batch), dim3(kBlock), 0, s, g, sb, ca, (const float*)gout[ca],
-                               (float*)gs, (float)vector[ca]);
-    }
+    const dim3 grid(bwd_blocks(v.cells), v.batch);
+    if (v.dtype == PHIHIP_F64)
+        hipLaunchKernelGGL(c2s_bwd_kernel<double>, grid, dim3(kBlock), 0, s, g, sb, (CComp3a<double>{{(const double*)gout[0], (const double*)gout[1], (const double*)gout[2]}}),
+                           (double*)gs, vector[0], vector[1], vector[2]);
+    else
+        hipLaunchKernelGGL(c2s_bwd_kernel<float>, grid, dim3(kBlock), 0, s, g, sb, (CComp3a<float>{{(const float*)gout[0], (const float*)gout[1], (const float*)gout[2]}}),
+                           (float*)gs, (float)vector[0], (float)vector[1], (float)vector[2]);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
