@@ -563,8 +563,8 @@ def test_implicit_diffusion_gradient(emu_backend):
 
 def test_functional_gradient_through_a_fluid_step(emu_backend):
     """ tests/commit/test_colab_fluids_tutorial.py:11-34 pattern: gradient of a loss on the smoke after several steps of
-    {advect smoke, buoyancy, self-advection, projection} w.r.t. the initial velocity (semi-Lagrangian smoke advection: the
-    MacCormack adjoint is not implemented), with an obstacle in the way. """
+    {advect smoke, buoyancy, self-advection, projection} w.r.t. the initial velocity (semi-Lagrangian smoke advection: smooth between the
+    kinks of the lookup, so finite differences are a usable check; the MacCormack variant is test_colab_tutorial_functional_gradient), with an obstacle in the way. """
     from phiflow_amd.flow import functional_gradient, l2_loss, precision, resample
     rng = np.random.default_rng(21)
     with precision(64):
