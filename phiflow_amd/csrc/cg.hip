@@ -49,7 +49,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         }
     g->flags_per_batch = mask_batch > 1 ? 1 : 0;
     c->batch = v.batch;
-    c->vec = (v.n[2] % vmax == 0 && !v.unaligned) ? vmax : 1;
+    c->vec = march_vector_width(v.n[2], esize, v.unaligned);
     const Tuning& t = ctx->tuning[family];
     const int mode = family_mode(family);
     const double src_share = family == FAM_MATVEC ? 2.0 / 3.0 : (family == FAM_UPDATE ? 0.2 : (family == FAM_CG1 ? 0.3 : 1.0 / 3.0));   // UPDATE_R: d is 1 of 3 words
@@ -140,6 +140,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             set_error("tuning: no tile config with rows=%d threads_per_row=%d", t.rows, t.tpr);
             return PHIHIP_ERR_BAD_ARG;
         }
+        if (!march_tile_available(c->vec, esize, id)) id = 5;          // (a pinned tile that this vector width does not have: the full-row tile)
         chunk = best_chunk(id, &score);
     } else {
         // candidate order + a small preference factor per family (from the family sweeps): UPDATE / residual favour large tiles
@@ -151,6 +152,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
         double best_score = -1.0;
         for (int k = 0; k < kNumTileConfigs; ++k) {
             const int cand = pref[k];
+            if (!march_tile_available(c->vec, esize, cand)) continue;
             int t1, t2;
             tile_of(cand, &t1, &t2);
             const double waste = (double)tiles_of(cand) * t1 * t2 / ((double)v.n[1] * v.n[2]);
@@ -350,7 +352,7 @@ template <typename T>
 static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, T* r, T* d0, T* d1, double* part, hipStream_t s) {
     const bool has_flags = flags != nullptr;
     const int esize = (int)sizeof(T);
-    const int vec = (v.n[2] % (16 / esize) == 0 && !v.unaligned) ? 16 / esize : 1;
+    const int vec = march_vector_width(v.n[2], esize, v.unaligned);
     static const int kChunks[12] = {128, 96, 64, 48, 32, 24, 16, 12, 8, 4, 2, 1};
     struct Cand { int id, chunk; float us; };
     const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
@@ -379,7 +381,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         std::vector<Cand> cands;
         cands.push_back({c_model.id, c_model.chunk, 0.f});                      // the model's choice goes first (ties keep it)
         for (int id = 0; id < kNumTileConfigs; ++id) {
-            if (vec == 1 && id != 5) continue;
+            if (!march_tile_available(vec, esize, id)) continue;
             if (v.rank != 3) {
                 const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
                 const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec);

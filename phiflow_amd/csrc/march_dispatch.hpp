@@ -15,9 +15,26 @@ struct TileShape {
 constexpr int kNumTileConfigs = 8;
 constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}};
 
+// Elements per thread along the fast axis: 16 bytes when the rows allow (n2 a multiple of 16 B / sizeof(T), 16-byte-aligned buffers); fp32 rows of
+// EVEN length take 8-byte vectors (V = 2: the code path of the fp64 kernels; 250^3, 190^3 ... run 20-37 % slower on the scalar instantiation,
+// profiles/r03_size_scan_ragged_rows.jsonl); everything else V = 1.
+inline int march_vector_width(int n2, int esize, bool unaligned) {
+    const int vmax = 16 / esize;
+    if (unaligned) return 1;
+    if (n2 % vmax == 0) return vmax;
+    return (esize == 4 && n2 % 2 == 0) ? 2 : 1;
+}
+// which tile configurations are instantiated for a vector width: all for 16-byte vectors, (1,64) alone for V = 1, the three 64-thread-row tiles
+// (4,64), (1,64), (2,64) for the fp32 V = 2 kernels (128 cells per tile row)
+inline bool march_tile_available(int vec, int esize, int id) {
+    if (vec == 1) return id == 5;
+    if (vec == 2 && esize == 4) return id == 4 || id == 5 || id == 6;
+    return true;
+}
+
 struct MarchConfig {
     int id;      // index into kTileShapes (ignored when vec == 1)
-    int vec;     // elements per thread along the fast axis: 16 B / sizeof(T), or 1 when n2 is not a multiple of it
+    int vec;     // elements per thread along the fast axis (march_vector_width)
     int t1, t2;  // tile extent
     int chunk;   // planes per workgroup (pieces of the linearised (tile, plane) space)
     int batch;

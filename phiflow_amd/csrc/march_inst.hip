@@ -87,6 +87,13 @@ static int occupancy_cfg(int mode, bool flags) {
 template <>
 int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
     if (vec == 1) return occupancy_cfg<1, 1, 64>(mode, flags);
+    if (vec == 2 && kVmax == 4) {
+        switch (id) {
+            case 4: return occupancy_cfg<(kVmax == 4 ? 2 : kVmax), 4, 64>(mode, flags);
+            case 6: return occupancy_cfg<(kVmax == 4 ? 2 : kVmax), 2, 64>(mode, flags);
+            default: return occupancy_cfg<(kVmax == 4 ? 2 : kVmax), 1, 64>(mode, flags);
+        }
+    }
     switch (id) {
         case 0: return occupancy_cfg<kVmax, 1, 16>(mode, flags);
         case 1: return occupancy_cfg<kVmax, 2, 16>(mode, flags);
@@ -120,6 +127,16 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
     }
     dim3 grid(g.nblk, c.batch);
     if (c.vec == 1) return launch_cfg<1, 1, 64>(mode, flags, g, a, grid, s);
+    if (c.vec == 2 && kVmax == 4) {      // fp32 rows of even length (march_vector_width): the three 64-thread-row tiles
+        switch (c.id) {
+            case 4: return launch_cfg<(kVmax == 4 ? 2 : kVmax), 4, 64>(mode, flags, g, a, grid, s);
+            case 5: return launch_cfg<(kVmax == 4 ? 2 : kVmax), 1, 64>(mode, flags, g, a, grid, s);
+            case 6: return launch_cfg<(kVmax == 4 ? 2 : kVmax), 2, 64>(mode, flags, g, a, grid, s);
+            default:
+                set_error("march: tile config %d is not instantiated for 8-byte vectors", c.id);
+                return PHIHIP_ERR_BAD_ARG;
+        }
+    }
     switch (c.id) {
         case 0: return launch_cfg<kVmax, 1, 16>(mode, flags, g, a, grid, s);
         case 1: return launch_cfg<kVmax, 2, 16>(mode, flags, g, a, grid, s);

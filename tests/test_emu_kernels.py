@@ -18,6 +18,7 @@ GRIDS_2D = [
     ((16, 20), ((PER, PER), (PER, PER))),
     ((16, 20), ((OPN, OPN), (CLO, OPN))),      # combine_sides(x=BOUNDARY, y=(ZERO, BOUNDARY)), test_fluid.py:51
     ((7, 13), ((CLO, OPN), (PER, PER))),       # ragged: scalar fallback path (n2 % 4 != 0)
+    ((10, 18), ((OPN, CLO), (PER, PER))),      # fp32 rows of even length: the 8-byte-vector instantiation (V = 2)
 ]
 GRIDS_3D = [
     ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER))),
@@ -25,6 +26,7 @@ GRIDS_3D = [
     ((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO))),   # more than one tile along a2, partial tiles
     ((3, 5, 264), ((PER, PER), (CLO, CLO), (OPN, OPN))),   # open fast axis: rows of n2 + 1 faces, two patches of the vector kernels
     ((4, 5, 24), ((OPN, OPN), (OPN, CLO), (OPN, CLO))),    # lower face stored, upper wall face not: rows of n2 faces without wrap
+    ((5, 6, 134), ((PER, PER), (CLO, OPN), (CLO, CLO))),   # fp32 V = 2 (134 % 4 = 2): two 128-cell tiles per row, the second nearly empty
 ]
 
 
