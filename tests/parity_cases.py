@@ -366,7 +366,7 @@ def _fd_agrees(fun, x_list, d_list, analytic, tol):
     boundary): a step that straddles such a kink is wrong by itself (by up to half the jump, whatever the step size, until the step is
     shorter than the distance to the kink), so shrinking step sizes are tried and one of them has to agree """
     errs = []
-    for eps in (1e-6, 2.5e-7, 6e-8):
+    for eps in (1e-6, 2.5e-7, 6e-8, 1.5e-8):
         fd = _fd(fun, x_list, d_list, eps)
         errs.append((abs(fd - analytic) / max(abs(fd), abs(analytic), 1.0), fd))
         if errs[-1][0] <= tol:
