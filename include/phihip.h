@@ -188,7 +188,15 @@ int phihip_apply_obstacles(phihip_ctx* ctx, const phihip_grid* grid, const phihi
                            void* const velocity[3], void* stream);
 
 /* ---- a2/a3: field.divergence (phi/field/_field_math.py:589,617-626) and fluid._balance_divergence (fluid.py:205-209) */
-/* div = divergence(v) [* active]; flags may be NULL. balance != 0 additionally subtracts mean (active-weighted). */
+/* div = divergence(v) [* active]; flags may be NULL. `balance` is a bit set: PHIHIP_DIV_BALANCE additionally subtracts the
+ * (active-weighted) mean -- fluid.py:145-148: non-flexible boundaries and no user-supplied `active`; PHIHIP_DIV_FINITE_GUARD
+ * replaces non-finite divergence values by 0 on EVERY cell -- `field.where(field.is_finite(div), div, 0)`, fluid.py:143-144:
+ * the user supplied `active`, "the velocity may take NaN values where it does not contribute to the pressure". Without the
+ * guard only INACTIVE cells are zeroed (div * active with a select instead of the reference's multiplication: where the
+ * reference would hand NaN * 0 = NaN to its solver, this library solves with 0 there). The same bits apply to the `balance`
+ * argument of phihip_make_incompressible. */
+#define PHIHIP_DIV_BALANCE 1
+#define PHIHIP_DIV_FINITE_GUARD 4
 int phihip_divergence(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], const uint8_t* flags,
                       int mask_batch, int balance, void* div, void* stream);
 

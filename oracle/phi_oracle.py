@@ -944,18 +944,28 @@ def balance_divergence(div: np.ndarray, active: Optional[np.ndarray]):
 
 def make_incompressible(v: List[np.ndarray], dom: Domain, obstacles=(), x0: Optional[np.ndarray] = None,
                         rtol: float = 1e-5, atol: float = 0.0, max_iter: int = 1000, refresh: Optional[int] = None,
-                        balance: Optional[bool] = None, method: str = 'CG'):
-    """ returns (velocity, pressure, SolveInfo, div_rhs). `method`: 'CG' (refresh 50) or 'CG-adaptive' (refresh 20). """
+                        balance: Optional[bool] = None, method: str = 'CG', active_user: Optional[np.ndarray] = None):
+    """ returns (velocity, pressure, SolveInfo, div_rhs). `method`: 'CG' (refresh 50) or 'CG-adaptive' (refresh 20).
+    `active_user` = the `active` argument of fluid.make_incompressible (fluid.py:97): cells where the pressure is solved; with it the
+    divergence is never balanced (fluid.py:145: `and all_active`) and non-finite divergence values become 0 (fluid.py:143-144). """
     dtype = v[0].dtype
     hard = active = None
+    all_active = active_user is None                                       # fluid.py:124
     if obstacles:
         active, hard, soft = obstacle_masks(obstacles, dom, dtype.type)
+        if active_user is not None:
+            active = np.asarray(active_user, dtype) * active               # fluid.py:136 "no pressure inside obstacles"
         v = apply_boundary_conditions(v, obstacles, dom)
+    elif active_user is not None:
+        active = np.broadcast_to(np.asarray(active_user, dtype), (v[0].shape[0],) + tuple(dom.res)).copy()
     div = divergence(v, dom)
     if active is not None:
-        div = div * active
+        with np.errstate(invalid='ignore'):
+            div = div * active                                             # fluid.py:139-140 (a plain product: NaN * 0 = NaN)
+    if not all_active:
+        div = np.where(np.isfinite(div), div, dtype.type(0))               # fluid.py:143-144
     if balance is None:
-        balance = not dom.flexible()
+        balance = (not dom.flexible()) and all_active                      # fluid.py:145
     rhs = balance_divergence(div, active) if balance else div
     if x0 is None:
         x0 = np.zeros_like(div)

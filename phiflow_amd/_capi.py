@@ -60,6 +60,7 @@ class ObstacleStruct(ctypes.Structure):
 
 
 OBSTACLE_BOX, OBSTACLE_SPHERE = 0, 1
+DIV_BALANCE, DIV_FINITE_GUARD = 1, 4      # bits of the `balance` argument (include/phihip.h PHIHIP_DIV_*)
 
 
 def make_obstacles(items) -> "ctypes.Array":
@@ -418,7 +419,7 @@ class Context:
 
     def divergence(self, grid, velocity, flags, mask_batch, balance, div, stream=0):
         self.lib.check(self.lib.dll.phihip_divergence(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), flags or None,
-                                                      int(mask_batch), int(bool(balance)), div, stream or None))
+                                                      int(mask_batch), int(balance), div, stream or None))
 
     def laplace_apply(self, grid, flags, mask_batch, p, out, stream=0):
         self.lib.check(self.lib.dll.phihip_laplace_apply(self.handle, ctypes.byref(grid), flags or None, int(mask_batch), p, out,
@@ -455,7 +456,7 @@ class Context:
         sm = ptr3(soft_mask)
         self.lib.check(self.lib.dll.phihip_make_incompressible(
             self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), ctypes.byref(sm) if sm is not None else None, flags or None,
-            int(mask_batch), int(bool(balance)), pressure, div_out or None, ctypes.byref(solve), info, stream or None))
+            int(mask_batch), int(balance), pressure, div_out or None, ctypes.byref(solve), info, stream or None))
         return list(info) if want_info else None
 
     def diffuse_explicit(self, grid, velocity, out, diffusivity_dt, stream=0):

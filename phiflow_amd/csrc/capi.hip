@@ -662,12 +662,14 @@ int phihip_make_incompressible(phihip_ctx* ctx, const phihip_grid* grid, void* c
         div = ctx->ws_rhs.ptr;
     }
     const void* cu[3] = {u[0], u[1], u[2]};
+    const int guard = balance & PHIHIP_DIV_FINITE_GUARD;
+    balance = (balance & ~PHIHIP_DIV_FINITE_GUARD) ? PHIHIP_DIV_BALANCE : 0;
     if (balance && cg_uses_marching(ctx, v) && !v.unaligned) {
         // divergence + partial sums in one pass; the mean is subtracted inside the solver's initial residual (no extra pass over div)
-        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, 2, div, s));
+        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, 2 | guard, div, s));
         PHIHIP_TRY(run_cg_balancing(ctx, v, flags, mask_batch, div, pressure, solve, info, (const double*)ctx->ws_scalars.ptr, s));
     } else {
-        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, balance, div, s));
+        PHIHIP_TRY(run_divergence(ctx, v, cu, flags, mask_batch, balance | guard, div, s));
         PHIHIP_TRY(run_cg(ctx, v, flags, mask_batch, div, pressure, solve, info, s));
     }
     PHIHIP_TRY(run_grad_subtract(ctx, v, flags, mask_batch, pressure, u, s));
@@ -785,7 +787,7 @@ int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid
     void* gu[3];
     remap3w(v, grad_velocity, gu);
     note_align(v, grad_pressure); note_align(v, flags, 3u);
-    return run_project_bwd(ctx, v, flags, mask_batch, balance, gu, grad_pressure, solve, info, s);
+    return run_project_bwd(ctx, v, flags, mask_batch, (balance & ~PHIHIP_DIV_FINITE_GUARD) ? 1 : 0, gu, grad_pressure, solve, info, s);
 }
 
 int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3],

@@ -14,6 +14,11 @@ template <typename T>
 struct CComp3 {
     const T* p[3];
 };
+// V elements at ELEMENT alignment (rows of n2 - 1 / n2 + 1 faces do not start on 16-byte boundaries; gfx950 takes dwordx4 at any 4-byte address)
+template <typename T, int V>
+struct __attribute__((packed, aligned(sizeof(T)))) VecU {
+    T v[V];
+};
 
 // Value of velocity component `ca` at stored index (i0,i1,i2) with the velocity extrapolation applied outside the array.
 // Mixed boundaries follow PhiML's sequential padding: the LAST axis that lies outside a constant side decides.
@@ -71,7 +76,7 @@ __device__ __forceinline__ int face_index(int i, int n, int code_lo, int code_hi
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
                                                             T* __restrict__ div, double* part_sum, double* part_act, int nblk, int tiles1,
-                                                            int tiles2, int chunk) {
+                                                            int tiles2, int chunk, int finite_guard) {
     __shared__ double red[kBlock / kWave];
     const int b = blockIdx.y;
     const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
@@ -127,9 +132,133 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
                 act = (f & 64u) ? T(1) : T(0);
                 sum = (f & 64u) ? sum : T(0);   // div * active, and non-finite values of inactive cells do not leak (fluid.py:139-144)
             }
+            if (finite_guard) sum = __builtin_isfinite(sum) ? sum : T(0);   // field.where(field.is_finite(div), div, 0) on EVERY cell (fluid.py:143-144)
             D[cell] = sum;
             acc_val += sum;
             acc_act += act;
+        }
+    }
+    const double s1 = block_sum((double)acc_val, red);
+    const double s2 = block_sum((double)acc_act, red);
+    if (threadIdx.x == 0) {
+        part_sum[(long long)b * nblk + blockIdx.x] = s1;
+        part_act[(long long)b * nblk + blockIdx.x] = s2;
+    }
+}
+
+// The same pass with one 16-byte vector of the fast axis per thread (r4; the scalar kernel above issues 5 dword loads and 1 dword store per
+// cell and ran at 0.50 of the HBM rate, bound by the address units like every one-dword-per-lane kernel here): per V cells
+//   a0: ONE aligned vector of component 0 per plane (the upper faces of this plane are the lower faces of the next: registers),
+//   a1: the two rows of component 1 around the cells (aligned vectors; the second is an L1 / L2 hit of the neighbouring thread row),
+//   a2: the V + 1 faces around the cells = one vector of component 2 at ELEMENT alignment (its rows hold n2 - 1 / n2 / n2 + 1 faces) plus
+//       the face at the open end as a scalar with the velocity's boundary rule (wrap / wall constant),
+//   flags as one V-byte load, div as one aligned vector store. Rows must be whole vectors (n2 % V == 0), else the scalar kernel runs.
+// `ltpr`: log2 of the threads along a row (narrow grids put more rows into a workgroup instead of idle lanes).
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void divergence_vec_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
+                                                                T* __restrict__ div, double* part_sum, double* part_act, int nblk, int tiles1,
+                                                                int tiles2, int chunk, int ltpr, int finite_guard) {
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
+    using VU = VecU<T, V>;
+    using VF = Vec<uint8_t, V>;
+    __shared__ double red[kBlock / kWave];
+    const int b = blockIdx.y;
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const int tx = threadIdx.x & ((1 << ltpr) - 1), ty = threadIdx.x >> ltpr;
+    const int bid = xcd_order(blockIdx.x, nblk);                // neighbouring columns share an XCD's L2 (the a1 rows between them)
+    const int t2 = bid % tiles2;
+    const int t1 = (bid / tiles2) % tiles1;
+    const int c0 = bid / (tiles2 * tiles1);
+    const int i1 = t1 * (kBlock >> ltpr) + ty, i2 = ((t2 << ltpr) + tx) * V;
+    const bool inside = i1 < n1 && i2 < n2;
+    const int p0 = DIM == 3 ? c0 * chunk : 0, p1 = DIM == 3 ? min(p0 + chunk, n0) : 1;
+    const T r0 = (T)g.rdx[0], r1 = (T)g.rdx[1], r2 = (T)g.rdx[2];
+    const int cn2 = g.cn[2][2];
+    // component 1: rows (i1 - off1, + 1); component 2: main vector at stored columns i2 .. i2 + V - 1 (faces k = 0 .. V - 1 of the V + 1 when
+    // the lower face of a cell is stored, off2 = 0; faces k = 1 .. V when the wall face is not, off2 = 1) + the face at the other end
+    int o1[2] = {0, 0};
+    T k1[2] = {T(0), T(0)};
+    bool c1f[2] = {false, false};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int f1 = face_index(i1 - g.off[1] + k, g.cn[1][1], g.bc[1][0], g.bc[1][1]);
+        c1f[k] = f1 < 0; k1[k] = (T)(f1 == -1 ? g.bcv[1][0][1] : g.bcv[1][1][1]); o1[k] = (f1 < 0 ? 0 : f1) * g.cn[1][2] + i2;
+    }
+    const int off2 = g.off[2];
+    const bool full2 = i2 + V <= cn2;                                      // (false only for the last vector of a row between two CLOSED sides)
+    const int fe = face_index(off2 ? i2 - 1 : i2 + V, cn2, g.bc[2][0], g.bc[2][1]);
+    const bool cef = fe < 0;
+    const T ke = (T)(fe == -1 ? g.bcv[2][0][2] : g.bcv[2][1][2]);
+    const int o2 = i1 * cn2 + i2, oe = i1 * cn2 + (fe < 0 ? 0 : fe);
+    int ft[V];                                                             // tail vector: per-element face rule
+    T kt[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int f = face_index(i2 + e, cn2, g.bc[2][0], g.bc[2][1]);
+        ft[e] = f < 0 ? -1 : i1 * cn2 + f;
+        kt[e] = (T)(f == -1 ? g.bcv[2][0][2] : g.bcv[2][1][2]);
+    }
+    const int o0 = i1 * g.cn[0][2] + i2;
+    const long long ps0 = (long long)g.cn[0][1] * g.cn[0][2], ps1 = (long long)g.cn[1][1] * g.cn[1][2], ps2 = (long long)g.cn[2][1] * cn2;
+    const T* __restrict__ C0 = DIM == 3 ? v.p[0] + (long long)b * g.ccells[0] : nullptr;
+    const T* __restrict__ C1 = v.p[1] + (long long)b * g.ccells[1];
+    const T* __restrict__ C2 = v.p[2] + (long long)b * g.ccells[2];
+    const uint8_t* F = flags ? flags + (flags_per_batch ? (long long)b * g.cells : 0) : nullptr;
+    T* __restrict__ D = div + (long long)b * g.cells;
+    auto splat = [](T x) { VT r;
+#pragma unroll
+        for (int e = 0; e < V; ++e) r.v[e] = x;
+        return r; };
+    auto face0 = [&](int phys) -> VT {
+        const int f = face_index(phys - g.off[0], g.cn[0][0], g.bc[0][0], g.bc[0][1]);
+        if (f < 0) return splat((T)(f == -1 ? g.bcv[0][0][0] : g.bcv[0][1][0]));
+        return vec_load<T, V>(C0 + (long long)f * ps0 + o0);
+    };
+    T acc_val = T(0), acc_act = T(0);
+    if (inside && p0 < p1) {
+        VT lo0 = DIM == 3 ? face0(p0) : splat(T(0));
+        for (int p = p0; p < p1; ++p) {
+            VT hi0 = lo0;
+            if (DIM == 3) hi0 = face0(p + 1);
+            const VT a = c1f[0] ? splat(k1[0]) : vec_load<T, V>(C1 + (long long)p * ps1 + o1[0]);
+            const VT bb = c1f[1] ? splat(k1[1]) : vec_load<T, V>(C1 + (long long)p * ps1 + o1[1]);
+            const T* R2 = C2 + (long long)p * ps2;
+            VT m;
+            if (full2) {
+                const VU u = *reinterpret_cast<const VU*>(R2 + o2);
+#pragma unroll
+                for (int e = 0; e < V; ++e) m.v[e] = u.v[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) m.v[e] = ft[e] < 0 ? kt[e] : R2[ft[e]];
+            }
+            const T edge = cef ? ke : R2[oe];
+            const long long cell = ((long long)p * n1 + i1) * n2 + i2;
+            VF fl;
+            if (F) fl = *reinterpret_cast<const VF*>(F + cell);
+            VT out;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T c = off2 ? (e > 0 ? m.v[e > 0 ? e - 1 : 0] : edge) : m.v[e];
+                const T d = off2 ? m.v[e] : (e < V - 1 ? m.v[e < V - 1 ? e + 1 : e] : edge);
+                T sum = T(0);
+                if (DIM == 3) sum += (hi0.v[e] - lo0.v[e]) * r0;
+                sum += (bb.v[e] - a.v[e]) * r1;
+                sum += (d - c) * r2;
+                T act = T(1);
+                if (F) {
+                    const unsigned f = fl.v[e];
+                    act = (f & 64u) ? T(1) : T(0);
+                    sum = (f & 64u) ? sum : T(0);
+                }
+                if (finite_guard) sum = __builtin_isfinite(sum) ? sum : T(0);
+                out.v[e] = sum;
+                acc_val += sum;
+                acc_act += act;
+            }
+            vec_store<T, V>(D + cell, out);
+            lo0 = hi0;
         }
     }
     const double s1 = block_sum((double)acc_val, red);
@@ -208,24 +337,28 @@ int run_balance(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     return PHIHIP_OK;
 }
 
-template <typename T, int DIM>
-static void launch_divergence(const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
-                              double* part_sum, double* part_act, int nblk, int chunk_planes, hipStream_t s) {
-    CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    const int tiles1 = ceil_div(v.n[1], kPatchRows), tiles2 = ceil_div(v.n[2], kPatchCols);
-    hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
-                       tiles1, tiles2, chunk_planes);
+// vector path: rows of whole 16-byte vectors, 16-byte aligned div / a0 / a1 components (their rows have the cells' length), V-byte aligned
+// flags; the a2 component only needs element alignment
+template <typename T>
+static bool divergence_vec_ok(const GridView& v, const void* const vel[3], const uint8_t* flags, const void* div) {
+    constexpr int V = 16 / (int)sizeof(T);
+    bool ok = v.n[2] % V == 0 && ((uintptr_t)div & 15u) == 0 && (!flags || ((uintptr_t)flags & (V - 1)) == 0);
+    for (int ca = v.ax0; ca < 2; ++ca) ok = ok && ((uintptr_t)vel[ca] & 15u) == 0;
+    return ok && ((uintptr_t)vel[2] & (sizeof(T) - 1)) == 0;
 }
 
-int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const uint8_t* flags, int mask_batch, int balance,
-                   void* div, hipStream_t s) {
-    if (v.cells >= (1LL << 31)) {
-        set_error("divergence: more than 2^31 cells per batch entry are not supported");
-        return PHIHIP_ERR_UNSUPPORTED;
-    }
-    const VelGrid g = make_velgrid(v);
-    // (4 x 64)-cell columns x chunks of planes: ~4096 workgroups per batch entry when the grid allows (2 rounds of 8 per CU)
-    const long long tiles = (long long)ceil_div(v.n[1], kPatchRows) * ceil_div(v.n[2], kPatchCols);
+template <typename T, int DIM>
+static int launch_divergence(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
+                             int finite_guard, int* nblk_out, hipStream_t s) {
+    CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool vec = divergence_vec_ok<T>(v, vel, flags, div);
+    int ltpr = 6;                                                 // threads along a row: 64, fewer on narrow grids (whole workgroup rows instead of idle lanes)
+    if (vec) while (ltpr > 0 && (1 << (ltpr - 1)) * V >= v.n[2]) --ltpr;
+    const int rows = vec ? kBlock >> ltpr : kPatchRows, cols = vec ? (1 << ltpr) * V : kPatchCols;
+    // (rows x cols)-cell columns x chunks of planes: ~4096 workgroups per batch entry when the grid allows (2 rounds of 8 per CU)
+    const int tiles1 = ceil_div(v.n[1], rows), tiles2 = ceil_div(v.n[2], cols);
+    const long long tiles = (long long)tiles1 * tiles2;
     PHIHIP_REQUIRE(tiles <= (1 << 24), "divergence: grid too large");
     int chunks = v.rank == 3 ? (int)((4096 + tiles - 1) / tiles) : 1;
     chunks = chunks > v.n[0] ? v.n[0] : (chunks < 1 ? 1 : chunks);
@@ -233,21 +366,45 @@ int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3],
     chunks = ceil_div(v.n[0], chunk_planes);
     const int nblk = (int)tiles * chunks;
     PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
-    PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
     double* part_sum = (double*)ctx->ws_div.ptr;
     double* part_act = part_sum + (size_t)v.batch * nblk;
-    double* shift = (double*)ctx->ws_scalars.ptr;
+    if (vec)
+        hipLaunchKernelGGL((divergence_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
+                           tiles1, tiles2, chunk_planes, ltpr, finite_guard);
+    else
+        hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
+                           tiles1, tiles2, chunk_planes, finite_guard);
+    *nblk_out = nblk;
+    return PHIHIP_OK;
+}
+
+// balance: bit 0 = subtract the active-weighted mean (fluid._balance_divergence); value 2 (internal) = leave the shift in ctx->ws_scalars for the
+// solver's first residual; PHIHIP_DIV_FINITE_GUARD (4) = non-finite divergence -> 0 on every cell (fluid.py:143-144: the user passed `active`)
+int run_divergence(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const uint8_t* flags, int mask_batch, int balance,
+                   void* div, hipStream_t s) {
+    if (v.cells >= (1LL << 31)) {
+        set_error("divergence: more than 2^31 cells per batch entry are not supported");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
+    const int finite_guard = (balance & PHIHIP_DIV_FINITE_GUARD) ? 1 : 0;
+    balance &= ~PHIHIP_DIV_FINITE_GUARD;
+    const VelGrid g = make_velgrid(v);
+    PHIHIP_TRY(ensure_buffer(ctx->ws_scalars, (size_t)v.batch * sizeof(double)));
     const int fpb = mask_batch > 1 ? 1 : 0;
+    int nblk = 0;
     {
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         if (v.dtype == PHIHIP_F64) {
-            if (v.rank == 3) launch_divergence<double, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
-            else launch_divergence<double, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_divergence<double, 3>(ctx, v, g, vel, flags, fpb, div, finite_guard, &nblk, s)));
+            else PHIHIP_TRY((launch_divergence<double, 2>(ctx, v, g, vel, flags, fpb, div, finite_guard, &nblk, s)));
         } else {
-            if (v.rank == 3) launch_divergence<float, 3>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
-            else launch_divergence<float, 2>(v, g, vel, flags, fpb, div, part_sum, part_act, nblk, chunk_planes, s);
+            if (v.rank == 3) PHIHIP_TRY((launch_divergence<float, 3>(ctx, v, g, vel, flags, fpb, div, finite_guard, &nblk, s)));
+            else PHIHIP_TRY((launch_divergence<float, 2>(ctx, v, g, vel, flags, fpb, div, finite_guard, &nblk, s)));
         }
     }
+    double* part_sum = (double*)ctx->ws_div.ptr;
+    double* part_act = part_sum + (size_t)v.batch * nblk;
+    double* shift = (double*)ctx->ws_scalars.ptr;
     if (balance) {
         LaunchScope ls(ctx, PHIHIP_K_DIVERGENCE, s);
         hipLaunchKernelGGL(balance_scalar_kernel, dim3(v.batch), dim3(kBlock), 0, s, (const double*)part_sum, (const double*)part_act,
@@ -327,11 +484,6 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<
 //       (VecU: the hardware takes dwordx4 at any 4-byte address); the last, partial vector of a row and the extra face of an OPEN upper
 //       side (j = n2) are scalar. r3: closed and open boxes -- and with them every obstacle scenario -- used to send this component
 //       through the scalar kernel in a second launch that read p and the flags again.
-template <typename T, int V>
-struct __attribute__((packed, aligned(sizeof(T)))) VecU {
-    T v[V];
-};
-
 template <typename T, int DIM>
 __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
                                                                    int nmax0, int patches1, int patches2, int comps) {

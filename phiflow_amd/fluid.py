@@ -232,6 +232,9 @@ def make_incompressible(velocity: Field,
     fp64 = velocity.dtype == torch.float64
     solve = solve.with_defaults(fp64)
     balance = (not velocity.boundary.is_flexible) and all_active   # fluid.py:145
+    # `balance` argument of the C ABI: PHIHIP_DIV_BALANCE | PHIHIP_DIV_FINITE_GUARD -- "if not all_active: div = where(is_finite(div), div, 0)"
+    # (fluid.py:143-144: with a user-supplied `active` the velocity may hold NaN where it does not contribute to the pressure)
+    div_bits = (_capi.DIV_BALANCE if balance else 0) | (0 if all_active else _capi.DIV_FINITE_GUARD)
     p_ext = pressure_extrapolation(velocity.boundary, velocity.dims)
     B = velocity.batch_size
     res_shape = tuple(velocity.resolution.values())
@@ -254,7 +257,7 @@ def make_incompressible(velocity: Field,
             vin = list(_apply_obstacles_autograd(velocity, obstacles, vin))
         gsolve = solve.gradient_solve if getattr(solve, 'gradient_solve', None) is not None else solve
         csolve_bwd = gsolve.to_c(fp64)
-        meta = dict(be=be, grid=velocity.grid_struct(), flags_ptr=flags.data_ptr() if flags is not None else 0, flags=flags, balance=balance,
+        meta = dict(be=be, grid=velocity.grid_struct(), flags_ptr=flags.data_ptr() if flags is not None else 0, flags=flags, balance=div_bits,
                     csolve=csolve, csolve_bwd=csolve_bwd, shapes=shapes, dtype=velocity.dtype)
         *new_v, pressure = autodiff.MakeIncompressible.apply(meta, pressure.detach(), *vin)
         new_v = list(new_v)
@@ -264,7 +267,7 @@ def make_incompressible(velocity: Field,
         if obstacles:   # v = apply_boundary_conditions(v, obstacles)   (fluid.py:137)
             _apply_obstacles_in_place(velocity, obstacles, new_v)
         infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
-                                           flags.data_ptr() if flags is not None else 0, mask_batch, balance, pressure.data_ptr(), 0, csolve,
+                                           flags.data_ptr() if flags is not None else 0, mask_batch, div_bits, pressure.data_ptr(), 0, csolve,
                                            True, be.stream())
     info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
                      [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])

@@ -143,6 +143,59 @@ def check_divergence(ctx, mem, dom, grid, dtype, rng, balance):
         assert m <= (1e-6 if np.dtype(dtype) == np.float32 else 1e-14) * max(1.0, np.abs(ref).max())
 
 
+def check_divergence_flags(ctx, mem, dom, grid, dtype, rng):
+    """ div * active with the packed cell flags of a box obstacle (fluid.py:139-140), the balance over the active cells (fluid.py:205-209), and
+    the is_finite guard of fluid.py:143-144 (PHIHIP_DIV_FINITE_GUARD): with NaN velocities scattered over the grid the guarded result is
+    0 wherever the reference's `where(is_finite(div), div, 0)` is -- on ACTIVE cells too -- and equal elsewhere; without the guard the NaN
+    stays on the active cells it reaches (and only there: inactive cells are selected, not multiplied). """
+    B = grid.batch
+    lo = [dom.lower[d] + 0.30 * (dom.upper[d] - dom.lower[d]) for d in range(dom.rank)]
+    hi = [dom.lower[d] + 0.62 * (dom.upper[d] - dom.lower[d]) for d in range(dom.rank)]
+    active, hard, _ = O.obstacle_masks([O.BoxObstacle(tuple(lo), tuple(hi))], dom, dtype)
+    acc = np.ascontiguousarray((active[0] > 0).astype(np.uint8))
+    g1 = C.make_grid(dom.rank, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    dacc, dflags = mem.to_dev(acc), mem.empty(dom.res, np.uint8)
+    ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    v = random_velocity(dom, B, dtype, rng)
+    ddiv = mem.empty((B,) + dom.res, dtype)
+    for balance in (0, C.DIV_BALANCE):
+        dv = [mem.to_dev(a) for a in v]
+        ctx.divergence(grid, [mem.ptr(a) for a in dv], mem.ptr(dflags), 1, balance, mem.ptr(ddiv))
+        mem.sync()
+        ref = O.divergence(v, dom) * active
+        if balance:
+            ref = O.balance_divergence(ref, np.broadcast_to(active, ref.shape))
+        err = rel_err(mem.to_host(ddiv), ref)
+        assert err <= tol(dtype)['stencil'], f"divergence * active (balance {balance}) rel err {err}"
+    # NaN velocities: a few samples per component, some next to active cells, some inside the obstacle
+    vn = [a.copy() for a in v]
+    for a in vn:
+        flat = a.reshape(-1)
+        flat[rng.integers(0, flat.size, size=max(2, flat.size // 40))] = np.nan
+    dv = [mem.to_dev(a) for a in vn]
+    with np.errstate(invalid='ignore'):
+        raw = O.divergence(vn, dom)
+        prod = raw * active                                                      # the reference's product: NaN * 0 = NaN
+    assert np.isnan(prod[np.broadcast_to(active, prod.shape) > 0]).any(), "the case must put NaN next to active cells"
+    guarded = np.where(np.isfinite(prod), prod, dtype(0))
+    ctx.divergence(grid, [mem.ptr(a) for a in dv], mem.ptr(dflags), 1, C.DIV_FINITE_GUARD, mem.ptr(ddiv))
+    mem.sync()
+    got = mem.to_host(ddiv)
+    assert np.isfinite(got).all(), "PHIHIP_DIV_FINITE_GUARD left a non-finite divergence"
+    assert (got[~np.isfinite(prod)] == 0).all()
+    assert rel_err(got, guarded) <= tol(dtype)['stencil']
+    ctx.divergence(grid, [mem.ptr(a) for a in dv], mem.ptr(dflags), 1, 0, mem.ptr(ddiv))
+    mem.sync()
+    got = mem.to_host(ddiv)
+    act_b = np.broadcast_to(active, got.shape) > 0
+    assert (np.isnan(got) == (np.isnan(raw) & act_b)).all(), "without the guard NaN stays exactly on the active cells it reaches"
+    # the guard without flags (user `active` of all ones): every non-finite value goes
+    ctx.divergence(grid, [mem.ptr(a) for a in dv], 0, 1, C.DIV_FINITE_GUARD, mem.ptr(ddiv))
+    mem.sync()
+    got = mem.to_host(ddiv)
+    assert np.isfinite(got).all() and rel_err(got, np.where(np.isfinite(raw), raw, dtype(0))) <= tol(dtype)['stencil']
+
+
 def check_grad_subtract(ctx, mem, dom, grid, dtype, rng):
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)

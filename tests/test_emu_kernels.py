@@ -39,6 +39,7 @@ def test_stencils_match_oracle(emu_ctx, res, bc, dtype):
     pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, rng)
     pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=False)
     pc.check_divergence(emu_ctx, MEM, dom, grid, dtype, rng, balance=True)
+    pc.check_divergence_flags(emu_ctx, MEM, dom, grid, dtype, rng)
     pc.check_grad_subtract(emu_ctx, MEM, dom, grid, dtype, rng)
     pc.check_grad_subtract_flags(emu_ctx, MEM, dom, grid, dtype, rng)
     pc.check_diffuse(emu_ctx, MEM, dom, grid, dtype, rng)

@@ -50,6 +50,7 @@ def test_reference_style_scenarios(gpu_backend):
         host.test_fields_on_different_grids(gpu_backend, dtype_name)
         host.test_rk4_integrator(gpu_backend, dtype_name)
     host.test_user_active_mask_plain_and_batched(gpu_backend)
+    host.test_user_active_mask_with_nan_velocity(gpu_backend)
     host.test_convergence_exceptions(gpu_backend)
     host.test_lid_driven_cavity_boundaries_and_diffusion(gpu_backend)
     host.test_implicit_diffusion(gpu_backend)

@@ -51,6 +51,7 @@ def test_stencils_match_oracle(ctx, mem, res, bc, dtype):
     pc.check_laplace(ctx, mem, dom, grid, dtype, rng)
     pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=False)
     pc.check_divergence(ctx, mem, dom, grid, dtype, rng, balance=True)
+    pc.check_divergence_flags(ctx, mem, dom, grid, dtype, rng)
     pc.check_grad_subtract(ctx, mem, dom, grid, dtype, rng)
     pc.check_grad_subtract_flags(ctx, mem, dom, grid, dtype, rng)
     pc.check_diffuse(ctx, mem, dom, grid, dtype, rng)

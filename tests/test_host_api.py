@@ -398,6 +398,37 @@ def test_user_active_mask_plain_and_batched(emu_backend):
         assert np.abs(p.numpy()[inactive]).max() == 0.0
 
 
+def test_user_active_mask_with_nan_velocity(emu_backend):
+    """ "If given [`active`], the velocity may take NaN values where it does not contribute to the pressure" (phi/physics/fluid.py:112-113):
+    `div = field.where(field.is_finite(div), div, 0)` (fluid.py:143-144) zeroes the non-finite divergence on EVERY cell -- also next to an
+    active one -- before the solve; against the oracle's restatement of those lines (oracle.make_incompressible(active_user=...)). """
+    from oracle import phi_oracle as O
+    rng = np.random.default_rng(31)
+    n = 16
+    bounds = Box(x=1, y=1)
+    shapes = StaggeredGrid(0, 0, bounds, x=n, y=n, backend=emu_backend).component_shapes
+    v_np = [rng.standard_normal((1,) + sh).astype(np.float32) for sh in shapes]
+    mask = np.ones((1, n, n), np.float32)
+    mask[0, 3:7, 4:9] = 0
+    v_np[0][0, 4, 5] = np.nan            # x-face between two inactive cells
+    v_np[1][0, 3, 8] = np.nan            # y-face between an inactive (3, 8) and an ACTIVE cell (3, 9): its divergence is NaN on an active cell
+    v_np[0][0, 10, 10] = np.nan          # far from the mask: both neighbours active
+    dom = O.Domain((n, n), (0, 0), (1, 1), ((O.CLOSED, O.CLOSED),) * 2)
+    v = StaggeredGrid([a[0] for a in v_np], 0, bounds, x=n, y=n, backend=emu_backend)
+    active = CenteredGrid(mask[0], 0, bounds, x=n, y=n, backend=emu_backend)
+    v_new, p = fluid.make_incompressible(v, (), Solve('CG', 1e-5, 1e-5), active=active)
+    vo, po, info, rhs = O.make_incompressible(v_np, dom, (), None, 1e-5, 1e-5, 1000, active_user=mask)
+    assert np.isfinite(po).all() and np.isfinite(p.numpy()).all(), "the guard must keep NaN out of the solve"
+    assert abs(p.solve_info.iterations[0] - int(info.iterations[0])) <= 2
+    np.testing.assert_allclose(p.numpy(), po[0], atol=3e-4 * np.abs(po).max())
+    for a, b in zip(v_new.numpy(), vo):
+        assert (np.isnan(a) == np.isnan(b[0])).all()                 # the NaN samples stay NaN (v - grad p), nothing else does
+        np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b[0]), atol=3e-4 * np.nanmax(np.abs(b)))
+    # without `active` the reference offers no such guarantee: a NaN next to an active cell reaches the solver (here: reported as diverged)
+    with pytest.raises((Diverged, NotConverged)):
+        fluid.make_incompressible(v, (), Solve('CG', 1e-5, 1e-5, max_iterations=20))
+
+
 def test_convergence_exceptions(emu_backend):
     """ phiml.math.solve_linear raises NotConverged / Diverged unless suppressed (tests/commit/physics/test_diffuse.py:60-66) """
     rng = np.random.default_rng(5)
