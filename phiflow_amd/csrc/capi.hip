@@ -761,6 +761,7 @@ int phihip_diffuse_explicit_centered(phihip_ctx* ctx, const phihip_grid* grid, c
     PHIHIP_ENTER(ctx, grid);
     PHIHIP_REQUIRE(sfield && out && s_bc && sfield != out, "diffuse_explicit_centered: NULL or aliased argument");
     PHIHIP_TRY(check_scalar_bc(v, s_bc, "diffuse_explicit_centered"));
+    note_align(v, sfield); note_align(v, out);
     return run_diffuse_centered(ctx, v, sfield, s_bc, s_val, out, diffusivity_dt, adjoint, s);
 }
 
@@ -800,6 +801,7 @@ int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void
     void* o[3];
     remap3(v, velocity, u);
     remap3w(v, out, o);
+    for (int d = v.ax0; d < 3; ++d) { note_align(v, u[d]); note_align(v, o[d]); }      // (the marching kernels' vector paths need 16-byte aligned lattices)
     return run_diffuse(ctx, v, u, o, diffusivity_dt, s);
 }
 
@@ -815,6 +817,7 @@ int phihip_diffuse_implicit(phihip_ctx* ctx, const phihip_grid* grid, const void
     void* o[3];
     remap3(v, velocity, u);
     remap3w(v, out, o);
+    for (int d = v.ax0; d < 3; ++d) { note_align(v, u[d]); note_align(v, o[d]); }
     return run_diffuse_implicit(ctx, v, u, o, diffusivity_dt, solve, info, s);
 }
 

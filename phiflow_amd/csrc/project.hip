@@ -697,6 +697,128 @@ __global__ __launch_bounds__(kBlock) void centered_to_staggered_kernel(VelGrid g
     }
 }
 
+// ONE launch for all components with one 16-byte vector of the fast axis per thread (r4; the per-component kernel above re-derives three
+// indices per sample with integer divisions and reads the scalar once per component with dword loads: 69 us per component at 256^3, 0.36
+// of the HBM rate). Same structure as grad_subtract_vec_kernel -- both are "face value from the two adjacent cells":
+//   a0 / a1: the two cells of a face are whole rows (same columns, neighbouring plane / row): two aligned vector loads of s;
+//   a2: the faces of a row lie between the cells of ONE aligned vector and that vector shifted by one cell; the cell beyond the open end
+//       comes from one scalar load or from the scalar's extrapolation (wrap / edge cell / constant). Rows of this component hold
+//       n2 - 1 / n2 / n2 + 1 faces: element-aligned vector access, masked tail, the extra face of an OPEN upper side as a scalar.
+// `comps`: bit mask of the components to write (accumulate: those with a non-zero vector entry).
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void centered_to_staggered_vec_kernel(VelGrid g, ScalarBc sb, Comp3<T> oc, const T* __restrict__ sfield, T sc0, T sc1,
+                                                                           T sc2, int accumulate, int comps, int nmax0, int patches1, int patches2,
+                                                                           int ltpr) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int V = 16 / (int)sizeof(T);
+    using VT = Vec<T, V>;
+    using VU = VecU<T, V>;
+    const int b = blockIdx.y;
+    const T* __restrict__ S = sfield + (long long)b * g.cells;
+    const int tx = threadIdx.x & ((1 << ltpr) - 1), ty = threadIdx.x >> ltpr;
+    const int rows = kBlock >> ltpr;
+    const int npatch = nmax0 * patches1 * patches2;
+    const int n2 = g.n[2];
+    const int cn2 = g.cn[2][2], off2 = g.off[2];
+    const T scale[3] = {sc0, sc1, sc2};
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        int idx[3];
+        const int t = patch / patches2;
+        idx[0] = t / patches1;
+        idx[1] = (t - idx[0] * patches1) * rows + ty;
+        idx[2] = (((patch - t * patches2) << ltpr) + tx) * V;
+        if (idx[2] >= n2) continue;
+#pragma unroll
+        for (int ca = A0; ca < 2; ++ca) {
+            if (!((comps >> ca) & 1)) continue;
+            if (idx[0] >= g.cn[ca][0] || idx[1] >= g.cn[ca][1]) continue;
+            const int n = g.n[ca];
+            const int pstride = ca == 0 ? g.n[1] * n2 : n2;
+            const int phys = idx[ca] + g.off[ca];
+            int l = phys - 1, r = phys;
+            bool cl = false, cr = false;
+            if (l < 0) { if (sb.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { cl = sb.bc[ca][0] == PHIHIP_BC_CLOSED; l = 0; } }
+            if (r >= n) { if (sb.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { cr = sb.bc[ca][1] == PHIHIP_BC_CLOSED; r = n - 1; } }
+            const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
+            VT sl = vec_load<T, V>(S + rest + l * pstride), sr = vec_load<T, V>(S + rest + r * pstride);
+            T* __restrict__ Op = oc.p[ca] + (long long)b * g.ccells[ca] + ((long long)(idx[0] * g.cn[ca][1] + idx[1]) * n2 + idx[2]);
+            VT o;
+            if (accumulate) o = vec_load<T, V>(Op);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T a = (cl ? (T)sb.val[ca][0] : sl.v[e]) * scale[ca], c = (cr ? (T)sb.val[ca][1] : sr.v[e]) * scale[ca];
+                const T val = a * T(0.5) + c * T(0.5);
+                o.v[e] = accumulate ? o.v[e] + val : val;
+            }
+            vec_store<T, V>(Op, o);
+        }
+        if (((comps >> 2) & 1) && idx[0] < g.cn[2][0] && idx[1] < g.cn[2][1]) {
+            const int c = idx[2];
+            const int row = (idx[0] * g.n[1] + idx[1]) * n2;
+            const VT pc = vec_load<T, V>(S + row + c);
+            // the cell beyond the open end of the vector under the scalar's extrapolation: wrap, the edge cell itself (zero-gradient), or the constant
+            T edge;
+            if (off2 == 0) {
+                if (c > 0) edge = S[row + c - 1];
+                else edge = sb.bc[2][0] == PHIHIP_BC_PERIODIC ? S[row + n2 - 1] : (sb.bc[2][0] == PHIHIP_BC_CLOSED ? (T)sb.val[2][0] : pc.v[0]);
+            } else {
+                if (c + V < n2) edge = S[row + c + V];
+                else edge = sb.bc[2][1] == PHIHIP_BC_PERIODIC ? S[row] : (sb.bc[2][1] == PHIHIP_BC_CLOSED ? (T)sb.val[2][1] : pc.v[V - 1]);
+            }
+            T val[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T left = off2 == 0 ? (e > 0 ? pc.v[e > 0 ? e - 1 : 0] : edge) : pc.v[e];
+                const T right = off2 == 0 ? pc.v[e] : (e < V - 1 ? pc.v[e < V - 1 ? e + 1 : e] : edge);
+                val[e] = (left * scale[2]) * T(0.5) + (right * scale[2]) * T(0.5);
+            }
+            T* __restrict__ Op = oc.p[2] + (long long)b * g.ccells[2] + ((long long)(idx[0] * g.cn[2][1] + idx[1]) * cn2 + c);
+            if (c + V <= cn2) {
+                VU o;
+                if (accumulate) o = *reinterpret_cast<const VU*>(Op);
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = accumulate ? o.v[e] + val[e] : val[e];
+                *reinterpret_cast<VU*>(Op) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (c + e < cn2) Op[e] = accumulate ? Op[e] + val[e] : val[e];
+            }
+            if (off2 == 0 && cn2 > n2 && c + V == n2) {     // OPEN upper side of the velocity: the extra face j = n2 between the last cell and the scalar's outside value
+                const T outside = sb.bc[2][1] == PHIHIP_BC_PERIODIC ? S[row] : (sb.bc[2][1] == PHIHIP_BC_CLOSED ? (T)sb.val[2][1] : pc.v[V - 1]);
+                const T v2 = (pc.v[V - 1] * scale[2]) * T(0.5) + (outside * scale[2]) * T(0.5);
+                Op[V] = accumulate ? Op[V] + v2 : v2;
+            }
+        }
+    }
+}
+
+template <typename T, int DIM>
+static bool launch_c2s_vec(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const double vector[3], int accumulate,
+                           void* const out[3], hipStream_t s) {
+    constexpr int V = 16 / (int)sizeof(T);
+    bool ok = v.n[2] % V == 0 && ((uintptr_t)sfield & 15u) == 0;
+    for (int ca = v.ax0; ca < 2; ++ca) ok = ok && ((uintptr_t)out[ca] & 15u) == 0;
+    ok = ok && ((uintptr_t)out[2] & (sizeof(T) - 1)) == 0;
+    if (!ok) return false;
+    int comps = 0, nmax[3] = {1, 1, 1};
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        if (accumulate && vector[ca] == 0.0) continue;   // adding 0 * s leaves the component as it is
+        comps |= 1 << ca;
+        for (int a = 0; a < 3; ++a) nmax[a] = v.cn[ca][a] > nmax[a] ? v.cn[ca][a] : nmax[a];
+    }
+    if (!comps) return true;
+    int ltpr = 6;
+    while (ltpr > 0 && (1 << (ltpr - 1)) * V >= v.n[2]) --ltpr;
+    const int patches1 = ceil_div(nmax[1], kBlock >> ltpr), patches2 = ceil_div(v.n[2], (1 << ltpr) * V);
+    const long long npatch = (long long)nmax[0] * patches1 * patches2;
+    const int nblk = npatch < 16384 ? (int)npatch : 16384;
+    Comp3<T> oc{{(T*)out[0], (T*)out[1], (T*)out[2]}};
+    hipLaunchKernelGGL((centered_to_staggered_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, oc, (const T*)sfield, (T)vector[0],
+                       (T)vector[1], (T)vector[2], accumulate, comps, nmax[0], patches1, patches2, ltpr);
+    return true;
+}
+
 int run_centered_to_staggered(phihip_ctx* ctx, const GridView& v, const void* sfield, const int32_t s_bc[3][2], const double s_val[3][2],
                               const double vector[3], int accumulate, void* const out[3], hipStream_t s) {
     for (int ca = v.ax0; ca < 3; ++ca)
@@ -707,7 +829,16 @@ int run_centered_to_staggered(phihip_ctx* ctx, const GridView& v, const void* sf
     const VelGrid g = make_velgrid(v);
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    for (int ca = v.ax0; ca < 3; ++ca) {
+    {
+        bool done;
+        if (v.dtype == PHIHIP_F64) done = v.rank == 3 ? launch_c2s_vec<double, 3>(v, g, sb, sfield, vector, accumulate, out, s) : launch_c2s_vec<double, 2>(v, g, sb, sfield, vector, accumulate, out, s);
+        else done = v.rank == 3 ? launch_c2s_vec<float, 3>(v, g, sb, sfield, vector, accumulate, out, s) : launch_c2s_vec<float, 2>(v, g, sb, sfield, vector, accumulate, out, s);
+        if (done) {
+            PHIHIP_CHECK_HIP(hipGetLastError());
+            return PHIHIP_OK;
+        }
+    }
+    for (int ca = v.ax0; ca < 3; ++ca) {      // rows that are not whole vectors / unaligned buffers: one scalar launch per component
         if (accumulate && vector[ca] == 0.0) continue;   // adding 0 * s leaves the component as it is
         const int nblk = ceil_div(v.ccells[ca], kBlock) < 16384 ? ceil_div(v.ccells[ca], kBlock) : 16384;
         if (v.dtype == PHIHIP_F64)
@@ -1177,15 +1308,71 @@ static void launch_diffuse(const VelGrid& g, int ca, int batch, const void* in, 
     hipLaunchKernelGGL((diffuse_kernel<T, ADJ>), dim3((unsigned)(tiles * chunks), batch), dim3(kBlock), 0, s, g, ca, (const T*)in, (T*)out, (T)kdt, tiles1, tiles2, chunk);
 }
 
+// The lattice of one staggered component (or of a centred scalar described as component `ca` of g) as a grid of the marching kernels with the
+// operator ident * I + scale * L and the field's own extrapolation as the neighbour rule: PERIODIC -> wrap, OPEN (zero-gradient) -> clamp,
+// CLOSED (constant c) -> zero ghost + the affine part scale * c / dx_a^2 in the samples next to that side (`affine`: some c != 0).
+static GridView lattice_view(const GridView& v, const VelGrid& g, int ca, double ident, double scale, bool* affine) {
+    GridView w = v;
+    *affine = false;
+    for (int a = 0; a < 3; ++a) {
+        w.n[a] = g.cn[ca][a];
+        for (int side = 0; side < 2; ++side) {
+            const int code = a < v.ax0 ? PHIHIP_BC_PERIODIC : g.bc[a][side];
+            w.op_rule[a][side] = code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_OPEN ? NB_CLAMP : NB_ZERO);
+            if (a >= v.ax0 && code == PHIHIP_BC_CLOSED && g.bcv[a][side][ca] != 0.0) *affine = true;
+        }
+    }
+    w.cells = g.ccells[ca];
+    w.halo[0] = w.halo[1] = 0;
+    w.op_custom = 1;
+    w.op_ident = ident;
+    w.op_scale = scale;
+    return w;
+}
+
+// out[sample next to a CLOSED side with constant c] += kdt * c / dx_a^2: the constant's share of the stencil (the marching kernels see a
+// zero ghost there). One thread per sample of the boundary plane(s); only launched for sides with c != 0 (the lid of a cavity).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void affine_walls_kernel(VelGrid g, int ca, int axis, int side, T* __restrict__ out, T add) {
+    const int b = blockIdx.y;
+    const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
+    const int u = axis == 0 ? 1 : 0, w = axis == 2 ? 1 : 2;       // the two other axes, w the faster one
+    const long long total = (long long)n[u] * n[w];
+    for (long long f = (long long)blockIdx.x * kBlock + threadIdx.x; f < total; f += (long long)gridDim.x * kBlock) {
+        int idx[3];
+        idx[axis] = side ? n[axis] - 1 : 0;
+        idx[w] = (int)(f % n[w]);
+        idx[u] = (int)(f / n[w]);
+        out[(long long)b * g.ccells[ca] + ((long long)idx[0] * n[1] + idx[1]) * n[2] + idx[2]] += add;
+    }
+}
+
+// diffuse.explicit on one lattice = ONE pass of the marching kernels (MODE_APPLY with the operator I + k dt L: 2 words per sample, the tuned
+// tiles of the pressure operator; r4 -- the one-dword-per-lane kernel it replaces ran at 0.32 of the HBM rate)
+static int diffuse_explicit_lattice(phihip_ctx* ctx, const GridView& v, const VelGrid& g, int ca, const void* in, void* out, double kdt, hipStream_t s) {
+    bool affine;
+    const GridView w = lattice_view(v, g, ca, 1.0, kdt, &affine);
+    if (w.cells >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
+    PHIHIP_TRY(run_laplace_apply(ctx, w, nullptr, 1, in, out, s));
+    if (affine) {
+        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+        for (int a = v.ax0; a < 3; ++a)
+            for (int side = 0; side < 2; ++side) {
+                if (g.bc[a][side] != PHIHIP_BC_CLOSED || g.bcv[a][side][ca] == 0.0) continue;
+                const double add = kdt * g.bcv[a][side][ca] * g.rdx[a] * g.rdx[a];
+                const long long total = g.ccells[ca] / g.cn[ca][a];
+                const dim3 grid((unsigned)((total + kBlock - 1) / kBlock < 4096 ? (total + kBlock - 1) / kBlock : 4096), v.batch);
+                if (v.dtype == PHIHIP_F64) hipLaunchKernelGGL(affine_walls_kernel<double>, grid, dim3(kBlock), 0, s, g, ca, a, side, (double*)out, add);
+                else hipLaunchKernelGGL(affine_walls_kernel<float>, grid, dim3(kBlock), 0, s, g, ca, a, side, (float*)out, (float)add);
+            }
+        PHIHIP_CHECK_HIP(hipGetLastError());
+    }
+    return PHIHIP_OK;
+}
+
 int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
-    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    for (int ca = v.ax0; ca < 3; ++ca) {
-        if (v.ccells[ca] >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
-        if (v.dtype == PHIHIP_F64) launch_diffuse<double, false>(g, ca, v.batch, vin[ca], vout[ca], kdt, s);
-        else launch_diffuse<float, false>(g, ca, v.batch, vin[ca], vout[ca], kdt, s);
-    }
-    PHIHIP_CHECK_HIP(hipGetLastError());
+    for (int ca = v.ax0; ca < 3; ++ca) PHIHIP_TRY(diffuse_explicit_lattice(ctx, v, g, ca, vin[ca], vout[ca], kdt, s));
     return PHIHIP_OK;
 }
 
@@ -1221,15 +1408,11 @@ int run_diffuse_centered(phihip_ctx* ctx, const GridView& v, const void* sfield,
                          double kdt, int adjoint, hipStream_t s) {
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     const VelGrid g = scalar_as_component(v, sb);
-    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
     if (v.cells >= (1LL << 31)) { set_error("diffuse: more than 2^31 cells per batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
-    if (v.dtype == PHIHIP_F64) {
-        if (adjoint) launch_diffuse<double, true>(g, 2, v.batch, sfield, out, kdt, s);
-        else launch_diffuse<double, false>(g, 2, v.batch, sfield, out, kdt, s);
-    } else {
-        if (adjoint) launch_diffuse<float, true>(g, 2, v.batch, sfield, out, kdt, s);
-        else launch_diffuse<float, false>(g, 2, v.batch, sfield, out, kdt, s);
-    }
+    if (!adjoint) return diffuse_explicit_lattice(ctx, v, g, 2, sfield, out, kdt, s);
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    if (v.dtype == PHIHIP_F64) launch_diffuse<double, true>(g, 2, v.batch, sfield, out, kdt, s);
+    else launch_diffuse<float, true>(g, 2, v.batch, sfield, out, kdt, s);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
@@ -1263,21 +1446,8 @@ __global__ __launch_bounds__(kBlock) void implicit_rhs_kernel(VelGrid g, int ca,
 // one lattice (a centred scalar or one staggered component, described as component `ca` of g): out = (I - k dt L)^-1 in, CG from x0 = in
 static int diffuse_implicit_lattice(phihip_ctx* ctx, const GridView& v, const VelGrid& g, int ca, const void* in, void* out, double kdt,
                                     const phihip_solve* solve, phihip_solve_info* info, hipStream_t s) {
-    GridView w = v;
-    bool affine = false;
-    for (int a = 0; a < 3; ++a) {
-        w.n[a] = g.cn[ca][a];
-        for (int side = 0; side < 2; ++side) {
-            const int code = a < v.ax0 ? PHIHIP_BC_PERIODIC : g.bc[a][side];
-            w.op_rule[a][side] = code == PHIHIP_BC_PERIODIC ? NB_WRAP : (code == PHIHIP_BC_OPEN ? NB_CLAMP : NB_ZERO);
-            if (a >= v.ax0 && code == PHIHIP_BC_CLOSED && g.bcv[a][side][ca] != 0.0) affine = true;
-        }
-    }
-    w.cells = g.ccells[ca];
-    w.halo[0] = w.halo[1] = 0;
-    w.op_custom = 1;
-    w.op_ident = 1.0;
-    w.op_scale = -kdt;
+    bool affine;
+    const GridView w = lattice_view(v, g, ca, 1.0, -kdt, &affine);
     if (w.cells >= (1LL << 31)) { set_error("diffuse_implicit: more than 2^31 samples per batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
     const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const size_t bytes = (size_t)v.batch * w.cells * esize;

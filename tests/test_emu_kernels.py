@@ -69,6 +69,8 @@ def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
         pc.check_mac_cormack_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts, dt=2.3, strength=0.6)
         pc.check_mac_cormack_staggered(emu_ctx, MEM, dom, grid, dtype, rng)
         pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
+        swapped = tuple((PER, PER) if lo == PER else (CLO, OPN) for lo, hi in bc)      # constant below, zero-gradient above
+        pc.check_centered_to_staggered(emu_ctx, MEM, dom, grid, dtype, rng, swapped, [(0.4, 0.0)] * len(res))
 
 
 @pytest.mark.parametrize("res,bc,dtype", [(r, b, np.float32) for r, b in GRIDS_2D + GRIDS_3D[:2]] + [(r, b, np.float64) for r, b in (GRIDS_2D[3], GRIDS_2D[4], GRIDS_3D[1])])

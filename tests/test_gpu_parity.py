@@ -92,6 +92,8 @@ def test_mac_cormack_and_resample_match_oracle(ctx, mem, res, bc):
         pc.check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=2.3, strength=0.6)
         pc.check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng)
         pc.check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts)
+        swapped = tuple((PER, PER) if lo == PER else (CLO, OPN) for lo, hi in bc)      # constant below, zero-gradient above
+        pc.check_centered_to_staggered(ctx, mem, dom, grid, dtype, rng, swapped, [(0.4, 0.0)] * len(res))
 
 
 def test_obstacle_rasterisation_and_moving_obstacles(ctx, mem):
