@@ -200,6 +200,10 @@ int run_mac_cormack_staggered(phihip_ctx* ctx, const GridView& v, const void* co
         if (st == PHIHIP_OK) first_done = true;
         else if (st != PHIHIP_ERR_UNSUPPORTED) return st;
     }
+    if (first_done) {       // ... and so is the correction pass: velocity + forward pass staged in LDS windows, all components in one launch (advect_win.hip)
+        const int st = run_mc_correct_self_tiled(ctx, v, vel, tmp, out, dt, 0.5 * strength, s);
+        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     if (!first_done) dispatch_advect_staggered<0>(v, g, f, vel, nullptr, tmp, dt, 0.0, s);
     dispatch_advect_staggered<1>(v, g, f, vel, tmp, out, dt, 0.5 * strength, s);
@@ -232,6 +236,11 @@ int run_advect_centered(phihip_ctx* ctx, const GridView& v, const void* sfield, 
     PHIHIP_TRY(check_advect_sizes(v));
     const VelGrid g = make_velgrid(v);
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
+    if (ctx->adv_halo > 0) {     // scalar + velocity staged in LDS windows (advect_win.hip); phihip_set_advect_halo(ctx, 0) keeps the gather kernel
+        const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, out, dt, s);
+        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        ctx->adv_last_nblk = 0;
+    }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     dispatch_advect_centered<0>(v, g, sb, sfield, vel, nullptr, out, dt, 0.0, s);
     PHIHIP_CHECK_HIP(hipGetLastError());
@@ -245,6 +254,12 @@ int run_mac_cormack_centered(phihip_ctx* ctx, const GridView& v, const void* sfi
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     PHIHIP_TRY(ensure_buffer(ctx->ws_adv, (size_t)v.batch * v.cells * esize));
+    if (ctx->adv_halo > 0) {     // both passes from LDS windows (advect_win.hip)
+        int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, dt, s);
+        if (st == PHIHIP_OK) st = run_mc_correct_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, s);
+        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        ctx->adv_last_nblk = 0;
+    }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     dispatch_advect_centered<0>(v, g, sb, sfield, vel, nullptr, ctx->ws_adv.ptr, dt, 0.0, s);
     dispatch_advect_centered<1>(v, g, sb, sfield, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, s);

@@ -1,0 +1,788 @@
+// advect_win.hip -- the advection passes that are NOT the velocity's semi-Lagrangian self-advection (advect_tile.hip), fed from LDS (r4):
+//   WK_MC_STAG  correction pass of advect.mac_cormack(v, v, dt) on the staggered velocity, ALL components in one launch
+//               (/root/reference phi/physics/advect.py:203-215; the limiter's cell frame: phi/field/_field.py:427-429)
+//   WK_SL_CEN   advect.semi_lagrangian(s, v, dt) of a centred scalar (advect.py:156-179; velocity at the centres: _resample.py:145-157)
+//   WK_MC_CEN   correction pass of advect.mac_cormack(s, v, dt) of a centred scalar
+// Until round 3 these ran on the gather kernels of advect.hip: 17-27 scattered dword loads per sample, bound by the address units at
+// 0.26-0.38 of the HBM rate (profiles/r03_kernel_roofline.json). Here a 256-thread workgroup owns a (T1 x T2) tile of the two fast axes,
+// marches over a chunk of a0 planes and stages WINDOWS of every array a sample reads in LDS -- each window with the halo ITS taps need:
+//   MC_STAG: the D velocity components with halo 1, but 2 along the component's own axis (the limiter looks up the field in the CELL
+//            frame: its window is shifted by half a cell along that axis, taps reach -2 .. +2), and the D components of the forward pass
+//            with halo 1: 71 KB (fp32, 3-D) -- DYNAMIC LDS beyond the 64 KB static limit, two workgroups per CU of the 160 KB;
+//   SL_CEN:  the scalar with halo 1, velocity component c with halo 1 along c ONLY (u at a centre = mean of the cell's two c-faces);
+//   MC_CEN:  scalar, forward pass (halo 1) and the velocity components as above: 39 KB.
+// The boundary rule (wrap / clamp / constant; the last axis outside a constant side wins like PhiML's sequential padding) is applied while
+// filling, the fill is cooperative and coalesced (row loads along the fast axis), a ring of 2 h0 + 2 planes per window keeps every plane
+// read from HBM once per workgroup, one barrier per plane, requests two planes ahead (the discipline of advect_tile.hip: unconditional
+// loads / stores so that s_waitcnt counts). A lookup that leaves its window (|displacement| >= 1 cell) flags the workgroup; the fix-up
+// kernel (same grid, launched right behind) recomputes exactly those workgroups with the gather code of advect.hip -- the result does not
+// depend on the path taken, and a CFL > 1 field is still correct.
+#include <math.h>
+
+#include <type_traits>
+
+#include "advect_common.hpp"
+
+namespace phihip {
+
+enum WinKind { WK_MC_STAG = 0, WK_SL_CEN = 1, WK_MC_CEN = 2 };
+
+// halo of window w along internal axis a
+template <int KIND, int DIM>
+struct WinSpec;
+template <int DIM>
+struct WinSpec<WK_MC_STAG, DIM> {                       // windows: velocity components A0 .. 2, then the forward-pass components
+    static constexpr int NW = 2 * DIM;
+    static constexpr int h(int w, int a) { return w < DIM ? ((3 - DIM + w) == a ? 2 : 1) : 1; }
+};
+template <int DIM>
+struct WinSpec<WK_SL_CEN, DIM> {                        // windows: the scalar, then the velocity components
+    static constexpr int NW = 1 + DIM;
+    static constexpr int h(int w, int a) { return w == 0 ? 1 : ((3 - DIM + w - 1) == a ? 1 : 0); }
+};
+template <int DIM>
+struct WinSpec<WK_MC_CEN, DIM> {                        // windows: the scalar, the forward pass, then the velocity components
+    static constexpr int NW = 2 + DIM;
+    static constexpr int h(int w, int a) { return w < 2 ? 1 : ((3 - DIM + w - 2) == a ? 1 : 0); }
+};
+
+template <typename T, int KIND, int DIM, int T1>
+struct WinTile {
+    using Spec = WinSpec<KIND, DIM>;
+    static constexpr int NW = Spec::NW;
+    static constexpr int T2 = sizeof(T) == 4 ? 64 : 32;   // tile columns = lanes along the fast axis (256 B rows)
+    static constexpr int TY = kBlock / T2;
+    static constexpr int S = T1 / TY;                     // tile positions per thread and plane
+    static constexpr int h0(int w) { return DIM == 3 ? Spec::h(w, 0) : 0; }
+    static constexpr int h1(int w) { return Spec::h(w, 1); }
+    static constexpr int h2(int w) { return Spec::h(w, 2); }
+    static constexpr int p1(int w) { return T1 + 2 * h1(w); }
+    static constexpr int p2(int w) { return T2 + 2 * h2(w); }
+    static constexpr int plane(int w) { return p1(w) * p2(w); }
+    static constexpr int np(int w) { return DIM == 3 ? 2 * h0(w) + 2 : 1; }       // ring slots: planes p - h0 .. p + h0 in use, one being refilled
+    static constexpr int off(int w) { int o = 0; for (int k = 0; k < w; ++k) o += np(k) * plane(k); return o; }
+    static constexpr int total() { return off(NW); }
+    static constexpr int kp(int w) { return (p1(w) + TY - 1) / TY; }              // fill passes of a thread per plane
+    static constexpr int kpmax() { int m = 0; for (int w = 0; w < NW; ++w) m = kp(w) > m ? kp(w) : m; return m; }
+    static constexpr int KP = kpmax();
+    static constexpr int ntail(int w) { return p1(w) * 2 * h2(w); }               // halo columns right of the T2 main columns: one element per thread
+    static constexpr int tail_off(int w) { int o = 0; for (int k = 0; k < w; ++k) o += ntail(k); return o; }
+    static constexpr int NTAIL = tail_off(NW);
+    static constexpr int h0max() { int m = 0; for (int w = 0; w < NW; ++w) m = h0(w) > m ? h0(w) : m; return m; }
+    static constexpr int H0MAX = h0max();
+    static constexpr size_t BYTES = (size_t)total() * sizeof(T);
+    static_assert(T1 % TY == 0, "tile rows must be a multiple of the thread rows");
+    static_assert(NTAIL <= kBlock, "tail elements must fit one per thread");
+    static_assert(BYTES <= 80 * 1024, "two workgroups per CU must fit the 160 KB of LDS");
+};
+
+// one staged array: where it lives, its stored extent, its padding rule (PHIHIP_BC_PERIODIC wrap / OPEN clamp / CLOSED constant)
+template <typename T>
+struct WinArray {
+    const T* p;
+    long long bstride;
+    int n[3];
+    int bc[3][2];
+    T cv[3][2];
+};
+
+template <typename T>
+struct WinParams {
+    WinArray<T> arr[6];
+    T* out[3];               // MC_STAG: the D components; centred kinds: out[0]
+    long long ostride[3];    // elements per batch entry of out[k]
+    int on[3][3];            // stored extent of out[k]
+    int off[3];              // physical face number of stored index 0 per velocity component (runtime copy of OFFM)
+    T shift[3];              // dt / dx: displacement in index units per unit velocity
+    T ch;                    // 0.5 * correction strength (MacCormack kinds)
+    int chunk, tiles1, tiles2, nblk, nmax0;
+    int* flags;
+    T* dump;
+};
+
+__device__ __forceinline__ int win_pad_index(int i, int n, int code_lo, int code_hi) {
+    if (i < 0) {
+        if (code_lo == PHIHIP_BC_PERIODIC) return wrap_index(i, n);
+        return code_lo == PHIHIP_BC_CLOSED ? -1 : 0;
+    }
+    if (i >= n) {
+        if (code_hi == PHIHIP_BC_PERIODIC) return wrap_index(i, n);
+        return code_hi == PHIHIP_BC_CLOSED ? -2 : n - 1;
+    }
+    return i;
+}
+__device__ __forceinline__ int win_const_side(int i, int n, int code_lo, int code_hi) {
+    return (i < 0 && code_lo == PHIHIP_BC_CLOSED) ? 1 : ((i >= n && code_hi == PHIHIP_BC_CLOSED) ? 2 : 0);
+}
+__device__ __forceinline__ void win_opaque(unsigned& v) {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" : "+v"(v));
+#endif
+}
+__device__ __forceinline__ float win_clamp(float x, float lo, float hi) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_fmed3f(x, lo, hi);      // NaN -> lo, which the callers treat as "outside"
+#else
+    return x >= lo ? (x <= hi ? x : hi) : lo;
+#endif
+}
+__device__ __forceinline__ double win_clamp(double x, double lo, double hi) { return x >= lo ? (x <= hi ? x : hi) : lo; }
+
+// OFFM: bit a = the lower face of axis a is NOT stored (CLOSED lower side): the static offsets of the velocity means depend on it.
+// CONSTS: some window may need constants patched in (a CLOSED side of the velocity or a constant extrapolation of the scalar).
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS>
+__global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
+    using C = WinTile<T, KIND, DIM, T1>;
+    constexpr int A0 = 3 - DIM;
+    constexpr int NW = C::NW, T2 = C::T2, TY = C::TY, S = C::S, KP = C::KP;
+    constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
+    PHIHIP_DYNAMIC_LDS(T, lds);
+    __shared__ int slow_sh;
+
+    const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2;
+    const int b = blockIdx.y;
+    const int bid = xcd_order(blockIdx.x, P.nblk);   // neighbouring tiles share an XCD's L2
+    const int t2 = bid % P.tiles2;
+    const int t1 = (bid / P.tiles2) % P.tiles1;
+    const int c0 = bid / (P.tiles2 * P.tiles1);
+    const int lo1 = t1 * T1, lo2 = t2 * T2;
+    const int pb = DIM == 3 ? c0 * P.chunk : 0;
+    const int pe = DIM == 3 ? min(pb + P.chunk, P.nmax0) : 1;
+    if (tid == 0) slow_sh = 0;
+    bool slow_any = false;
+
+    // does this workgroup's window reach beyond a constant side? (uniform: interior tiles and boxes without one skip every select)
+    bool has_const = false;
+    if (CONSTS) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const WinArray<T>& A = P.arr[w];
+            has_const = has_const || (A.bc[1][0] == PHIHIP_BC_CLOSED && lo1 - C::h1(w) < 0) || (A.bc[1][1] == PHIHIP_BC_CLOSED && lo1 + T1 + C::h1(w) > A.n[1]) ||
+                        (A.bc[2][0] == PHIHIP_BC_CLOSED && lo2 - C::h2(w) < 0) || (A.bc[2][1] == PHIHIP_BC_CLOSED && lo2 + T2 + C::h2(w) > A.n[2]);
+            if (DIM == 3) has_const = has_const || (A.bc[0][0] == PHIHIP_BC_CLOSED && pb - C::h0(w) < 0) || (A.bc[0][1] == PHIHIP_BC_CLOSED && pe + C::h0(w) > A.n[0]);
+        }
+    }
+
+    // ---- per-thread fill descriptors (plane-invariant): byte offset within a plane of element (row ty + kp TY, column tx) of window w ----
+    unsigned eoff[NW][KP];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const WinArray<T>& A = P.arr[w];
+        const int k = win_pad_index(lo2 - C::h2(w) + tx, A.n[2], A.bc[2][0], A.bc[2][1]);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            const int row = ty + kp * TY;
+            const int j = win_pad_index(lo1 - C::h1(w) + (row < C::p1(w) ? row : 0), A.n[1], A.bc[1][0], A.bc[1][1]);
+            eoff[w][kp] = (unsigned)((j < 0 ? 0 : j * A.n[2]) + (k < 0 ? 0 : k)) * (unsigned)sizeof(T);
+        }
+    }
+    // tail element (halo columns T2 .. T2 + 2 h2 - 1 of every row of the windows that have them): window, row and column of THIS thread
+    int tail_w = -1, tail_r = 0, tail_q = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        if (C::ntail(w) > 0 && tid >= C::tail_off(w) && tid < C::tail_off(w) + C::ntail(w)) {
+            tail_w = w;
+            tail_r = (tid - C::tail_off(w)) / (2 * C::h2(w));
+            tail_q = T2 + (tid - C::tail_off(w)) % (2 * C::h2(w));
+        }
+    unsigned tail_eoff = 0;
+    int tail_lds = 0;          // LDS element offset of the tail element within slot 0 of its window
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        if (w == tail_w) {
+            const WinArray<T>& A = P.arr[w];
+            const int kk = win_pad_index(lo2 - C::h2(w) + tail_q, A.n[2], A.bc[2][0], A.bc[2][1]);
+            const int j = win_pad_index(lo1 - C::h1(w) + tail_r, A.n[1], A.bc[1][0], A.bc[1][1]);
+            tail_eoff = (unsigned)((j < 0 ? 0 : j * A.n[2]) + (kk < 0 ? 0 : kk)) * (unsigned)sizeof(T);
+            tail_lds = C::off(w) + tail_r * C::p2(w) + tail_q;
+        }
+
+    // plane of window w that supplies staged plane i0: wrapped (one +-n suffices: every axis has >= 4 samples here) or clamped; beyond a
+    // CONSTANT side any valid plane is read and patched. Branch-free scalar code.
+    auto plane_src = [&](int w, int i0) -> long long {
+        if (DIM == 2) return 0;
+        const WinArray<T>& A = P.arr[w];
+        const int n = A.n[0];
+        int q = i0;
+        if (A.bc[0][0] == PHIHIP_BC_PERIODIC) { q += q < 0 ? n : 0; q -= q >= n ? n : 0; }
+        q = min(max(q, 0), n - 1);
+        return (long long)q * ((long long)A.n[1] * A.n[2]);
+    };
+    auto slot_of = [&](int w, int i0) -> int {      // uniform
+        if (DIM == 2) return 0;
+        const int n = C::np(w);
+        const int m = i0 % n;
+        return m < 0 ? m + n : m;
+    };
+    // staged planes of window w for this chunk: pb - h0 .. pe - 1 + h0
+    auto k_lo = [&](int w) { return DIM == 3 ? pb - C::h0(w) : 0; };
+    auto k_hi = [&](int w) { return DIM == 3 ? pe - 1 + C::h0(w) : 0; };
+
+    // Every global load of the plane loop is unconditional (hipcc then counts the outstanding operations: s_waitcnt vmcnt(N > 0)); in
+    // half-step p window w requests plane p + h0(w) + 2, clamped into the range it stages.
+    auto load_planes = [&](int p, T (&R)[NW][KP], T& tailv) {
+        long long tail_src = 0;
+        const T* tail_base = P.arr[0].p;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const WinArray<T>& A = P.arr[w];
+            const int kl = min(max(p + C::h0(w) + 2, k_lo(w)), k_hi(w));
+            const long long ps = plane_src(w, kl);
+            const char* __restrict__ base = (const char*)(A.p + (long long)b * A.bstride + ps);
+#pragma unroll
+            for (int kp = 0; kp < C::kp(w); ++kp) {
+                unsigned o = eoff[w][kp];
+                win_opaque(o);
+                R[w][kp] = *(const T*)(base + o);
+            }
+            if (w == tail_w) { tail_base = A.p + (long long)b * A.bstride; tail_src = ps; }
+        }
+        if (C::NTAIL > 0) {
+            unsigned o = tail_eoff;
+            win_opaque(o);
+            tailv = *(const T*)((const char*)(tail_base + tail_src) + o);
+        }
+    };
+    // constants of CLOSED sides, patched in when a plane enters the ring (cold, uniform). The LAST axis outside a constant side decides.
+    auto patch_planes = [&](int p, T (&R)[NW][KP], T& tailv) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const WinArray<T>& A = P.arr[w];
+            const int ks = p + C::h0(w) + 1;
+            const int k = DIM == 3 ? win_const_side(ks, A.n[0], A.bc[0][0], A.bc[0][1]) : 0;
+            const T pv = k == 1 ? A.cv[0][0] : A.cv[0][1];
+            const int cside = win_const_side(lo2 - C::h2(w) + tx, A.n[2], A.bc[2][0], A.bc[2][1]);
+            const T cvv = cside == 1 ? A.cv[2][0] : A.cv[2][1];
+#pragma unroll
+            for (int kp = 0; kp < C::kp(w); ++kp) {
+                T v = R[w][kp];
+                const int j = win_const_side(lo1 - C::h1(w) + ty + kp * TY, A.n[1], A.bc[1][0], A.bc[1][1]);
+                const T rv = j == 1 ? A.cv[1][0] : A.cv[1][1];
+                v = k ? pv : v;
+                v = j ? rv : v;
+                v = cside ? cvv : v;
+                R[w][kp] = v;
+            }
+            if (w == tail_w) {
+                const int rs = win_const_side(lo1 - C::h1(w) + tail_r, A.n[1], A.bc[1][0], A.bc[1][1]);
+                const int cs = win_const_side(lo2 - C::h2(w) + tail_q, A.n[2], A.bc[2][0], A.bc[2][1]);
+                const T rv = rs == 1 ? A.cv[1][0] : A.cv[1][1], cv2 = cs == 1 ? A.cv[2][0] : A.cv[2][1];
+                tailv = k ? pv : tailv;
+                tailv = rs ? rv : tailv;
+                tailv = cs ? cv2 : tailv;
+            }
+        }
+    };
+    // what half-step p - 1 requested (plane p + h0 + 1 of every window) enters the ring
+    auto store_planes = [&](int p, const T (&R)[NW][KP], T tailv) {
+        int tail_slot = -1;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int ks = p + C::h0(w) + 1;
+            if (ks < k_lo(w) || ks > k_hi(w)) continue;             // uniform
+            const int slot = slot_of(w, ks);
+            T* L = lds + C::off(w) + slot * C::plane(w);
+#pragma unroll
+            for (int kp = 0; kp < C::kp(w); ++kp)
+                if (ty + kp * TY < C::p1(w)) L[(ty + kp * TY) * C::p2(w) + tx] = R[w][kp];
+            if (w == tail_w) tail_slot = slot * C::plane(w);
+        }
+        if (C::NTAIL > 0 && tail_slot >= 0) lds[tail_lds + tail_slot] = tailv;
+    };
+
+    // ---- one plane of samples ---------------------------------------------------------------------------------------------------
+    auto compute_plane = [&](int p) {
+        // element offset of plane p + d of window w (uniform): base[w][d + h0]
+        int pbase[NW][2 * C::H0MAX + 1];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int d = -C::H0MAX; d <= C::H0MAX; ++d)
+                pbase[w][d + C::H0MAX] = (d >= -C::h0(w) && d <= C::h0(w)) ? C::off(w) + slot_of(w, p + d) * C::plane(w) : 0;
+        // static tap: window w at (plane offset d0, row offset d1, column offset d2) from the sample at (row r, column tx)
+        auto at = [&](int w, int r, int d0, int d1, int d2) -> T {
+            return lds[pbase[w][d0 + C::H0MAX] + (r + C::h1(w) + d1) * C::p2(w) + tx + C::h2(w) + d2];
+        };
+        // multilinear lookup (or min / max over the taps) in window w at per-lane tap offsets (di = lower tap relative to the sample)
+        auto tap_base = [&](int w, int r, const int (&di)[3], int (&base)[2]) {
+            const int inplane = (r + C::h1(w) + di[1]) * C::p2(w) + tx + C::h2(w) + di[2];
+            if (DIM == 3) {
+                int s0 = slot_of(w, p) + di[0];          // slot of the lower tap plane: wrap into the ring (|di| <= h0 + 1 < np)
+                s0 += s0 < 0 ? C::np(w) : 0;
+                s0 -= s0 >= C::np(w) ? C::np(w) : 0;
+                int s1 = s0 + 1;
+                s1 -= s1 >= C::np(w) ? C::np(w) : 0;
+                base[0] = C::off(w) + s0 * C::plane(w) + inplane;
+                base[1] = C::off(w) + s1 * C::plane(w) + inplane;
+            } else {
+                base[0] = base[1] = C::off(w) + inplane;
+            }
+        };
+        auto lerp_taps = [&](int w, int r, const int (&di)[3], const T (&fr)[3]) -> T {
+            int base[2];
+            tap_base(w, r, di, base);
+            T y[2];
+#pragma unroll
+            for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+                const int bk = base[k];
+                const T a00 = lds[bk], a10 = lds[bk + C::p2(w)], a01 = lds[bk + 1], a11 = lds[bk + C::p2(w) + 1];
+                const T x0 = fma(fr[2], a01 - a00, a00), x1 = fma(fr[2], a11 - a10, a10);
+                y[k] = fma(fr[1], x1 - x0, x0);
+            }
+            return DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
+        };
+        auto minmax_taps = [&](int w, int r, const int (&di)[3], T& lo, T& hi) {
+            int base[2];
+            tap_base(w, r, di, base);
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+                const int bk = base[k];
+                const T t[4] = {lds[bk], lds[bk + C::p2(w)], lds[bk + 1], lds[bk + C::p2(w) + 1]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo = first ? t[q] : (t[q] < lo ? t[q] : lo);
+                    hi = first ? t[q] : (t[q] > hi ? t[q] : hi);
+                    first = false;
+                }
+            }
+        };
+        // integer part / fraction of a lookup coordinate relative to the sample index; `slow` when the taps leave [lo_rel, hi_rel + 1]
+        auto split = [&](T coord, T idxf, int lo_rel, int hi_rel, T& fr, int& di, bool& slow) {
+            const T fl = floor(coord);
+            fr = coord - fl;
+            const T rel = fl - idxf;
+            const T relc = win_clamp(rel, (T)lo_rel, (T)hi_rel);
+            slow = slow || !(rel == relc);          // also true for NaN
+            di = (int)relc;
+        };
+        const T idxf0 = (T)p;
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            const int r = ty + s * TY;
+            const int j1 = lo1 + r, j2 = lo2 + tx;
+            const T idxf[3] = {idxf0, (T)j1, (T)j2};
+            if (KIND == WK_MC_STAG) {
+#pragma unroll
+                for (int ca = A0; ca < 3; ++ca) {
+                    const int wv = ca - A0, wf = DIM + ca - A0;
+                    const T vc = at(wv, r, 0, 0, 0);
+                    T cb[3] = {T(0), T(0), T(0)}, cf[3] = {T(0), T(0), T(0)};
+                    cb[ca] = fma(vc, -P.shift[ca], idxf[ca]);
+                    cf[ca] = fma(vc, P.shift[ca], idxf[ca]);
+#pragma unroll
+                    for (int cbx = A0; cbx < 3; ++cbx) {
+                        if (cbx == ca) continue;
+                        // component cbx at this ca-face: cells (m - 1, m) along ca, faces (s, s + 1) along cbx (advect_common.hpp face_velocity)
+                        T v4[2][2];
+#pragma unroll
+                        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                            for (int ib = 0; ib < 2; ++ib) {
+                                int d[3] = {0, 0, 0};
+                                d[ca] = OFF[ca] - 1 + ia;
+                                d[cbx] = -OFF[cbx] + ib;
+                                v4[ia][ib] = at(cbx - A0, r, d[0], d[1], d[2]);
+                            }
+                        const T sum = (v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]);
+                        cb[cbx] = fma(sum, T(-0.25) * P.shift[cbx], idxf[cbx]);
+                        cf[cbx] = fma(sum, T(0.25) * P.shift[cbx], idxf[cbx]);
+                    }
+                    bool slow = false;
+                    T fr[3] = {T(0), T(0), T(0)};
+                    int di[3] = {0, 0, 0};
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], di[a], slow);
+                    const T bwd = lerp_taps(wf, r, di, fr);
+                    const T nv = at(wf, r, 0, 0, 0) + P.ch * (vc - bwd);
+                    // limiter: closest grid values of the backward lookup in the CELL frame (own axis: m - 1/2 instead of the stored index)
+                    cb[ca] += (T)OFF[ca] - T(0.5);
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], di[a], slow);
+                    T lo = T(0), hi = T(0);
+                    minmax_taps(wv, r, di, lo, hi);
+                    const T val = nv < lo ? lo : (nv > hi ? hi : nv);      // math.clip = minimum(maximum(x, lo), hi)
+                    const bool valid = p < P.on[ca][0] && j1 < P.on[ca][1] && j2 < P.on[ca][2];
+                    slow_any = slow_any || (valid && slow);
+                    T* const slot = P.out[ca] + (long long)b * P.ostride[ca] + ((long long)p * P.on[ca][1] + j1) * P.on[ca][2] + j2;
+                    *(valid ? slot : P.dump) = val;
+                }
+            } else {
+                constexpr int WV0 = KIND == WK_SL_CEN ? 1 : 2;      // first velocity window
+                T cb[3] = {T(0), T(0), T(0)}, cf[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                for (int c = A0; c < 3; ++c) {
+                    // staggered velocity at the cell centre: mean of the cell's two c-faces (advect_common.hpp center_velocity)
+                    int d[3] = {0, 0, 0};
+                    d[c] = -OFF[c];
+                    const T lo_f = at(WV0 + c - A0, r, d[0], d[1], d[2]);
+                    d[c] = -OFF[c] + 1;
+                    const T hi_f = at(WV0 + c - A0, r, d[0], d[1], d[2]);
+                    const T u = hi_f * T(0.5) + lo_f * T(0.5);
+                    const T sft = u * P.shift[c];
+                    cb[c] = idxf[c] - sft;
+                    cf[c] = idxf[c] + sft;
+                }
+                bool slow = false;
+                T fr[3] = {T(0), T(0), T(0)};
+                int di[3] = {0, 0, 0};
+                T val;
+                if (KIND == WK_SL_CEN) {
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], di[a], slow);
+                    val = lerp_taps(0, r, di, fr);
+                } else {
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], di[a], slow);
+                    const T bwd = lerp_taps(1, r, di, fr);
+                    const T nv = at(1, r, 0, 0, 0) + P.ch * (at(0, r, 0, 0, 0) - bwd);
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], di[a], slow);
+                    T lo = T(0), hi = T(0);
+                    minmax_taps(0, r, di, lo, hi);
+                    val = nv < lo ? lo : (nv > hi ? hi : nv);
+                }
+                const bool valid = p < P.on[0][0] && j1 < P.on[0][1] && j2 < P.on[0][2];
+                slow_any = slow_any || (valid && slow);
+                T* const slot = P.out[0] + (long long)b * P.ostride[0] + ((long long)p * P.on[0][1] + j1) * P.on[0][2] + j2;
+                *(valid ? slot : P.dump) = val;
+            }
+        }
+    };
+
+    // ---- pipeline: two planes per trip so that the two register sets keep static names ------------------------------------------
+    T RA[NW][KP], RB[NW][KP];
+    T tailA = T(0), tailB = T(0);
+    auto half_step = [&](int p, bool compute, T (&Rld)[NW][KP], T& tail_ld, T (&Rst)[NW][KP], T& tail_st) {
+        load_planes(p, Rld, tail_ld);
+        if (compute) compute_plane(p);
+        if (CONSTS && has_const) patch_planes(p, Rst, tail_st);
+        store_planes(p, Rst, tail_st);
+        __syncthreads();
+    };
+    if (DIM == 3) {
+        // window w's first staged plane pb - h0 is requested in half-step pb - 2 h0 - 2: 2 H0MAX + 2 warm-up half-steps fill the rings
+        int p = pb - 2 * C::H0MAX - 2;
+        for (; p < pb; p += 2) {
+            half_step(p, false, RA, tailA, RB, tailB);
+            half_step(p + 1, false, RB, tailB, RA, tailA);
+        }
+        for (; p + 1 < pe; p += 2) {
+            half_step(p, true, RA, tailA, RB, tailB);
+            half_step(p + 1, true, RB, tailB, RA, tailA);
+        }
+        if (p < pe) half_step(p, true, RA, tailA, RB, tailB);
+    } else {
+        // 2-D: one plane. Request it (half-step -2), let it enter the windows (half-step -1), compute (half-step 0).
+        load_planes(-2, RA, tailA);
+        if (CONSTS && has_const) patch_planes(-1, RA, tailA);
+        store_planes(-1, RA, tailA);
+        __syncthreads();
+        compute_plane(0);
+    }
+    if (slow_any) slow_sh = 1;
+    __syncthreads();
+    if (tid == 0) P.flags[(long long)b * P.nblk + blockIdx.x] = slow_sh;
+}
+
+// ---- fix-up: the flagged workgroups' samples with the gather code of advect.hip ------------------------------------------------------
+template <typename T, int KIND, int DIM, int T1>
+__global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield, CComp3a<T> vel,
+                                                                  CComp3a<T> fwd3, const T* __restrict__ fwd1, T* o0, T* o1, T* o2, T dt, T ch,
+                                                                  int chunk, int tiles1, int tiles2, int nblk, int nmax0, const int* __restrict__ flags) {
+    using C = WinTile<T, KIND, DIM, T1>;
+    constexpr int A0 = 3 - DIM;
+    const int b = blockIdx.y;
+    if (flags[(long long)b * nblk + blockIdx.x] == 0) return;
+    const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
+    const int bid = xcd_order(blockIdx.x, nblk);
+    const int t2 = bid % tiles2;
+    const int t1 = (bid / tiles2) % tiles1;
+    const int c0 = bid / (tiles2 * tiles1);
+    const int pb = DIM == 3 ? c0 * chunk : 0;
+    const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
+    T* const outp[3] = {o0, o1, o2};
+    for (int p = pb; p < pe; ++p)
+        for (int s = 0; s < C::S; ++s) {
+            const int j1 = t1 * T1 + ty + s * C::TY, j2 = t2 * C::T2 + tx;
+            const int idx[3] = {p, j1, j2};
+            if (KIND == WK_MC_STAG) {
+#pragma unroll
+                for (int ca = A0; ca < 3; ++ca) {
+                    if (p >= g.cn[ca][0] || j1 >= g.cn[ca][1] || j2 >= g.cn[ca][2]) continue;
+                    const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
+                    const int f = (p * n[1] + j1) * n[2] + j2;
+                    T u[3];
+                    if (ca == 0) face_velocity<T, DIM, 0>(g, vel, b, idx, f, u);
+                    else if (ca == 1) face_velocity<T, DIM, 1>(g, vel, b, idx, f, u);
+                    else face_velocity<T, DIM, 2>(g, vel, b, idx, f, u);
+                    T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) {
+                        const T sft = u[a] * (dt * (T)g.rdx[a]);
+                        cb_[a] = (T)idx[a] - sft;
+                        cf_[a] = (T)idx[a] + sft;
+                    }
+                    int bc[3][2];
+                    T cv[3][2];
+                    comp_rule<T>(g, ca, bc, cv);
+                    AxisPair<T> ax[3];
+                    T fr[3];
+                    const long long total = g.ccells[ca];
+                    const T* __restrict__ F = field.p[ca] + (long long)b * total;
+                    const T* __restrict__ W = fwd3.p[ca] + (long long)b * total;
+                    lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+                    const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
+                    const T nv = W[f] + ch * (F[f] - bwd);
+                    cb_[ca] += (T)g.off[ca] - T(0.5);
+                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    T lo, hi;
+                    gather_minmax<T, DIM>(F, ax, lo, hi);
+                    outp[ca][(long long)b * total + f] = nv < lo ? lo : (nv > hi ? hi : nv);
+                }
+            } else {
+                if (p >= g.n[0] || j1 >= g.n[1] || j2 >= g.n[2]) continue;
+                const int n[3] = {g.n[0], g.n[1], g.n[2]};
+                const int f = (p * n[1] + j1) * n[2] + j2;
+                T u[3];
+                center_velocity<T, DIM>(g, vel, b, idx, u);
+                T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+#pragma unroll
+                for (int a = A0; a < 3; ++a) {
+                    const T sft = u[a] * (dt * (T)g.rdx[a]);
+                    cb_[a] = (T)idx[a] - sft;
+                    cf_[a] = (T)idx[a] + sft;
+                }
+                int bc[3][2];
+                T cv[3][2];
+                scalar_rule<T>(sb, bc, cv);
+                AxisPair<T> ax[3];
+                T fr[3];
+                const T* __restrict__ F = sfield + (long long)b * g.cells;
+                if (KIND == WK_SL_CEN) {
+                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    o0[(long long)b * g.cells + f] = gather_multilinear<T, DIM>(F, ax, fr);
+                } else {
+                    const T* __restrict__ W = fwd1 + (long long)b * g.cells;
+                    lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+                    const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
+                    const T nv = W[f] + ch * (F[f] - bwd);
+                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    T lo, hi;
+                    gather_minmax<T, DIM>(F, ax, lo, hi);
+                    o0[(long long)b * g.cells + f] = nv < lo ? lo : (nv > hi ? hi : nv);
+                }
+            }
+        }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static WinArray<T> component_array(const VelGrid& g, int c, const void* p) {
+    WinArray<T> a;
+    memset(&a, 0, sizeof(a));
+    a.p = (const T*)p;
+    a.bstride = g.ccells[c];
+    for (int ax = 0; ax < 3; ++ax) {
+        a.n[ax] = g.cn[c][ax];
+        for (int s = 0; s < 2; ++s) {
+            a.bc[ax][s] = ax < g.ax0 ? PHIHIP_BC_PERIODIC : g.bc[ax][s];
+            a.cv[ax][s] = (T)g.bcv[ax][s][c];
+        }
+    }
+    return a;
+}
+template <typename T>
+static WinArray<T> scalar_array(const VelGrid& g, const ScalarBc& sb, const void* p) {
+    WinArray<T> a;
+    memset(&a, 0, sizeof(a));
+    a.p = (const T*)p;
+    a.bstride = g.cells;
+    for (int ax = 0; ax < 3; ++ax) {
+        a.n[ax] = g.n[ax];
+        for (int s = 0; s < 2; ++s) {
+            a.bc[ax][s] = ax < g.ax0 ? PHIHIP_BC_PERIODIC : sb.bc[ax][s];
+            a.cv[ax][s] = (T)sb.val[ax][s];
+        }
+    }
+    return a;
+}
+
+struct WinCall {
+    const void* field[3];      // MC_STAG: the advected components (= the velocity)
+    const void* sfield;        // centred kinds: the scalar
+    const void* vel[3];
+    const void* fwd[3];        // MC_STAG: forward-pass components; MC_CEN: fwd[0]
+    void* out[3];
+    const ScalarBc* sb;
+    double dt, ch;
+};
+
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS>
+static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
+    using C = WinTile<T, KIND, DIM, T1>;
+    constexpr int A0 = 3 - DIM;
+    WinParams<T> P;
+    memset(&P, 0, sizeof(P));
+    int nmax[3] = {1, 1, 1};
+    ScalarBc sb0;
+    memset(&sb0, 0, sizeof(sb0));
+    const ScalarBc& sb = call.sb ? *call.sb : sb0;
+    if (KIND == WK_MC_STAG) {
+        for (int c = A0; c < 3; ++c) {
+            P.arr[c - A0] = component_array<T>(g, c, call.vel[c]);
+            P.arr[DIM + c - A0] = component_array<T>(g, c, call.fwd[c]);
+            P.out[c] = (T*)call.out[c];
+            P.ostride[c] = g.ccells[c];
+            for (int a = 0; a < 3; ++a) { P.on[c][a] = g.cn[c][a]; nmax[a] = g.cn[c][a] > nmax[a] ? g.cn[c][a] : nmax[a]; }
+        }
+    } else {
+        P.arr[0] = scalar_array<T>(g, sb, call.sfield);
+        int wv0 = 1;
+        if (KIND == WK_MC_CEN) { P.arr[1] = scalar_array<T>(g, sb, call.fwd[0]); wv0 = 2; }
+        for (int c = A0; c < 3; ++c) P.arr[wv0 + c - A0] = component_array<T>(g, c, call.vel[c]);
+        P.out[0] = (T*)call.out[0];
+        P.ostride[0] = g.cells;
+        for (int a = 0; a < 3; ++a) { P.on[0][a] = g.n[a]; nmax[a] = g.n[a]; }
+    }
+    for (int a = 0; a < 3; ++a) {
+        P.off[a] = g.off[a];
+        P.shift[a] = (T)call.dt * (T)g.rdx[a];
+    }
+    P.ch = (T)call.ch;
+    const int tiles1 = ceil_div(nmax[1], T1), tiles2 = ceil_div(nmax[2], C::T2);
+    auto kernel = advect_win_kernel<T, KIND, DIM, T1, OFFM, CONSTS>;
+    // LDS beyond the 64 KB a kernel gets by default: opt in once per instantiation and device
+    static bool attr_set[16] = {false};
+    bool& done = attr_set[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
+    if (!done) {
+        if (C::BYTES > 48 * 1024)
+            PHIHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES));
+        done = true;
+    }
+    int chunk = 1;
+    if (DIM == 3) {
+        // chunks of planes: every chunk stages 2 h0 + 1 extra planes of its windows; a launch that needs 1 < rounds < 2 of resident workgroups
+        // costs two rounds. Score = (slot efficiency of the last round) x (useful / staged planes), as for the self-advection (advect_tile.hip)
+        static int occ_dev[16] = {0};
+        int& occ = occ_dev[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
+        if (occ == 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlock, C::BYTES) != hipSuccess || n < 1) n = 1;
+            occ = n;
+        }
+        const double slots = (double)occ * ctx->num_cu;
+        const long long tiles = (long long)tiles1 * tiles2 * v.batch;
+        double best = -1.0;
+        for (int c = 1; c <= nmax[0]; ++c) {
+            const int ch = ceil_div(nmax[0], c);
+            if (c > 1 && ch < 4) break;
+            if (ceil_div(nmax[0], ch) != c) continue;
+            const double rounds = (double)tiles * c / slots;
+            const double eff = rounds / ceil(rounds - 1e-9);
+            const double score = eff * ch / (ch + 2 * C::H0MAX + 1) * (rounds >= 2.0 ? 1.0 : (rounds >= 1.0 ? 0.97 : 0.9));
+            if (score > best * 1.0001) { best = score; chunk = ch; }
+        }
+        if (ctx->adv_chunk > 0) chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
+    }
+    const int chunks0 = DIM == 3 ? ceil_div(nmax[0], chunk) : 1;
+    const int nblk = tiles1 * tiles2 * chunks0;
+    const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
+    P.chunk = chunk; P.tiles1 = tiles1; P.tiles2 = tiles2; P.nblk = nblk; P.nmax0 = nmax[0];
+    P.flags = (int*)ctx->ws_adv_flags.ptr;
+    P.dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);
+    hipLaunchKernelGGL(kernel, dim3(nblk, v.batch), dim3(kBlock), C::BYTES, s, P);
+    ctx->adv_last_nblk = nblk * v.batch;
+    CComp3a<T> ff{{(const T*)call.field[0], (const T*)call.field[1], (const T*)call.field[2]}};
+    CComp3a<T> vv{{(const T*)call.vel[0], (const T*)call.vel[1], (const T*)call.vel[2]}};
+    CComp3a<T> ww{{(const T*)call.fwd[0], (const T*)call.fwd[1], (const T*)call.fwd[2]}};
+    hipLaunchKernelGGL((advect_win_fixup_kernel<T, KIND, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ff, (const T*)call.sfield, vv, ww,
+                       (const T*)call.fwd[0], (T*)call.out[0], (T*)call.out[1], (T*)call.out[2], (T)call.dt, (T)call.ch, chunk, tiles1, tiles2, nblk,
+                       nmax[0], (const int*)P.flags);
+    return PHIHIP_OK;
+}
+
+template <typename T, int KIND, int DIM, int T1, int OFFM>
+static int launch_win_off(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
+    bool consts = false;
+    for (int a = v.ax0; a < 3; ++a) {
+        consts = consts || v.bc[a][0] == PHIHIP_BC_CLOSED || v.bc[a][1] == PHIHIP_BC_CLOSED;
+        if (call.sb) consts = consts || call.sb->bc[a][0] == PHIHIP_BC_CLOSED || call.sb->bc[a][1] == PHIHIP_BC_CLOSED;
+    }
+    if constexpr (OFFM == 0) {
+        if (!consts) return launch_win_inst<T, KIND, DIM, T1, OFFM, false>(ctx, v, g, call, s);
+    }
+    return launch_win_inst<T, KIND, DIM, T1, OFFM, true>(ctx, v, g, call, s);
+}
+
+template <typename T, int KIND, int DIM, int T1>
+static int launch_win(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
+    const int m = (g.off[0] & 1) | ((g.off[1] & 1) << 1) | ((g.off[2] & 1) << 2);     // (2-D: off[0] = 0)
+    switch (m) {
+        case 0: return launch_win_off<T, KIND, DIM, T1, 0>(ctx, v, g, call, s);
+        case 2: return launch_win_off<T, KIND, DIM, T1, 2>(ctx, v, g, call, s);
+        case 4: return launch_win_off<T, KIND, DIM, T1, 4>(ctx, v, g, call, s);
+        case 6: return launch_win_off<T, KIND, DIM, T1, 6>(ctx, v, g, call, s);
+        default: break;
+    }
+    if (DIM == 3) switch (m) {
+        case 1: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 1 : 0)>(ctx, v, g, call, s);
+        case 3: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 3 : 0)>(ctx, v, g, call, s);
+        case 5: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 5 : 0)>(ctx, v, g, call, s);
+        case 7: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 7 : 0)>(ctx, v, g, call, s);
+        default: break;
+    }
+    set_error("advect: unexpected face-offset pattern %d", m);
+    return PHIHIP_ERR_BAD_ARG;
+}
+
+template <int KIND>
+static int run_win(phihip_ctx* ctx, const GridView& v, const WinCall& call, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+    for (int c = v.ax0; c < 3; ++c)
+        for (int a = v.ax0; a < 3; ++a)
+            if (v.cn[c][a] < 4 || v.n[a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a window wider than the axis: the caller keeps the gather kernels
+    LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    if (v.dtype == PHIHIP_F64) {
+        if (v.rank == 3) PHIHIP_TRY((launch_win<double, KIND, 3, 8>(ctx, v, g, call, s)));
+        else PHIHIP_TRY((launch_win<double, KIND, 2, 8>(ctx, v, g, call, s)));
+    } else {
+        if (v.rank == 3) PHIHIP_TRY((launch_win<float, KIND, 3, 8>(ctx, v, g, call, s)));
+        else PHIHIP_TRY((launch_win<float, KIND, 2, 8>(ctx, v, g, call, s)));
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+// correction pass of mac_cormack(v, v, dt): fwd = the semi-Lagrangian result (advect_tile.hip), out = the corrected, limited velocity
+int run_mc_correct_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const void* const fwd[3], void* const out[3], double dt,
+                              double ch, hipStream_t s) {
+    WinCall c;
+    memset(&c, 0, sizeof(c));
+    for (int k = 0; k < 3; ++k) { c.field[k] = vel[k]; c.vel[k] = vel[k]; c.fwd[k] = fwd[k]; c.out[k] = out[k]; }
+    c.dt = dt; c.ch = ch;
+    return run_win<WK_MC_STAG>(ctx, v, c, s);
+}
+
+int run_advect_centered_tiled(phihip_ctx* ctx, const GridView& v, const void* sfield, const ScalarBc& sb, const void* const vel[3], void* out, double dt,
+                              hipStream_t s) {
+    WinCall c;
+    memset(&c, 0, sizeof(c));
+    c.sfield = sfield; c.sb = &sb; c.out[0] = out;
+    for (int k = 0; k < 3; ++k) c.vel[k] = vel[k];
+    c.dt = dt;
+    return run_win<WK_SL_CEN>(ctx, v, c, s);
+}
+
+int run_mc_correct_centered_tiled(phihip_ctx* ctx, const GridView& v, const void* sfield, const ScalarBc& sb, const void* const vel[3], const void* fwd,
+                                  void* out, double dt, double ch, hipStream_t s) {
+    WinCall c;
+    memset(&c, 0, sizeof(c));
+    c.sfield = sfield; c.sb = &sb; c.out[0] = out; c.fwd[0] = fwd;
+    for (int k = 0; k < 3; ++k) c.vel[k] = vel[k];
+    c.dt = dt; c.ch = ch;
+    return run_win<WK_MC_CEN>(ctx, v, c, s);
+}
+
+}  // namespace phihip

@@ -90,6 +90,16 @@ ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const doubl
 
 }  // namespace phihip
 
+// Dynamic LDS (kernels that need more than the 64 KB a static allocation may have: hipFuncSetAttribute(...MaxDynamicSharedMemorySize) up to
+// the 160 KB of a gfx950 CU). The g++ emulation build of the tests (tests/hipemu) runs one workgroup at a time on one buffer.
+#if defined(__HIPCC__)
+#define PHIHIP_DYNAMIC_LDS(T, name)                                                  \
+    extern __shared__ __attribute__((aligned(16))) unsigned char phihip_dyn_lds_raw[]; \
+    T* const name = reinterpret_cast<T*>(phihip_dyn_lds_raw)
+#else
+#define PHIHIP_DYNAMIC_LDS(T, name) T* const name = reinterpret_cast<T*>(hipemu::dynamic_lds())
+#endif
+
 namespace phihip {
 // true when the predicate holds for any lane of the wavefront: lets interior wavefronts skip the constant-side selects with a
 // SCALAR branch (a per-lane `if` makes the compiler predicate both sides). The CPU emulation build has no wavefronts; there the
@@ -200,6 +210,11 @@ inline bool stream_is_capturing(hipStream_t s) {
 // ---- phases implemented in the .hip files ---------------------------------------------------------------------------
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
 int run_advect_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double dt, int halo, hipStream_t);
+// LDS-windowed passes of advect_win.hip (PHIHIP_ERR_UNSUPPORTED: an axis with fewer than 4 samples -- the caller keeps the gather kernels)
+int run_mc_correct_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], const void* const fwd[3], void* const out[3], double dt, double ch, hipStream_t);
+int run_advect_centered_tiled(phihip_ctx*, const GridView&, const void* s, const ScalarBc& sb, const void* const v[3], void* out, double dt, hipStream_t);
+int run_mc_correct_centered_tiled(phihip_ctx*, const GridView&, const void* s, const ScalarBc& sb, const void* const v[3], const void* fwd, void* out, double dt,
+                                  double ch, hipStream_t);
 int run_grid_sample(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,
                     const void* const coords[3], long long npts, void* out, void* out_min, void* out_max, hipStream_t);
 int run_grid_sample_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,

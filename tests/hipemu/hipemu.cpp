@@ -26,6 +26,8 @@ static const std::function<void()>* g_body = nullptr;
 static unsigned char g_xchg[64][64][16];   // [wave][lane][16 bytes]
 static const size_t kStack = 256 * 1024;
 
+static unsigned char g_dyn_lds[160 * 1024] __attribute__((aligned(64)));
+void* dynamic_lds() { return g_dyn_lds; }
 dim3& cur_thread_idx() { return g_cur->tid; }
 int cur_lane() { return g_cur->linear & 63; }
 void* wave_slot(int lane) { return g_xchg[g_cur->linear >> 6][lane]; }

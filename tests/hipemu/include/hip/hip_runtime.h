@@ -49,6 +49,7 @@ void sync_block();
 void sync_wave();
 void* wave_slot(int lane);   // 16-byte exchange slot of `lane` in the calling fiber's wave
 int cur_lane();
+void* dynamic_lds();         // 160 KB shared by the (one) running workgroup: `extern __shared__` of the device build
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur_thread_idx())
@@ -109,6 +110,8 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* prop, int d);
 // emulation: pretend 4 resident workgroups per CU for every kernel
 template <typename F>
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 4; return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int bytes) { return bytes <= 160 * 1024 ? hipSuccess : hipErrorInvalidValue; }
 // emulation: streams never capture (the library asks before it synchronises inside a call, e.g. the first-call autotune)
 enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
 inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }

@@ -283,6 +283,25 @@ def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
         assert err <= advect_tol(dtype, dom), f"advect field != velocity [{d}] rel err {err}"
 
 
+def gentle_fields(v, dom, dt, dtype, rng):
+    """ (name, velocity) pairs derived from v: "gentle" = every displacement below 0.9 cells (the LDS-staged advection kernels serve every
+    lookup from their windows), "spots" = gentle with a few samples 2.7 times faster (some workgroups are redone by the gather path) """
+    vmax = max(float(np.abs(a).max()) for a in v)
+    h = min(dom.dx)
+    gentle = [a * dtype(0.9 * h / (abs(dt) * vmax)) for a in v] if dt != 0 else v
+    spots = [a.copy() for a in gentle]
+    for a in spots:
+        flat = a.reshape(-1)
+        flat[rng.integers(0, flat.size, size=max(1, flat.size // 500))] *= dtype(2.7)
+    return (("gentle", gentle), ("spots", spots))
+
+
+def assert_no_fallback(ctx, dom, what):
+    tiled = all(n >= 4 for d in range(dom.rank) for n in dom.comp_shape(d)) and all(n >= 4 for n in dom.res)
+    redone, total = ctx.advect_fallback_stats()
+    assert (total > 0) == tiled and redone == 0, f"{what}: {redone} of {total} workgroups fell back although every displacement is < 0.9 cells"
+
+
 def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=0.9):
     B = grid.batch
     v = random_velocity(dom, B, dtype, rng)
@@ -294,6 +313,22 @@ def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt
     ref = O.semi_lagrangian_centered(s, v, dt, dom, s_codes, s_consts)
     err = rel_err(mem.to_host(dout), ref)
     assert err <= advect_tol(dtype, dom), f"advect_centered rel err {err}"
+    # every displacement below 0.9 cells: served from the LDS windows of advect_win.hip alone (asserted through the fallback statistics);
+    # a few fast spots: mixed; halo 0: the gather kernel
+    for name, vel in gentle_fields(v, dom, dt, dtype, rng):
+        dv = [mem.to_dev(a) for a in vel]
+        ref = O.semi_lagrangian_centered(s, vel, dt, dom, s_codes, s_consts)
+        for halo in (1, 0):
+            ctx.set_advect_halo(halo)
+            try:
+                ctx.advect_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), dt)
+                mem.sync()
+            finally:
+                ctx.set_advect_halo(1)
+            err = rel_err(mem.to_host(dout), ref)
+            assert err <= advect_tol(dtype, dom), f"advect_centered {name} field, halo {halo}: rel err {err}"
+            if halo and name == "gentle":
+                assert_no_fallback(ctx, dom, "advect_centered")
 
 
 def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=0.9, strength=1.0):
@@ -311,6 +346,20 @@ def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_const
     # a lookup that lands within rounding distance of a cell boundary may pick the neighbouring clamp window: compare robustly
     bad = np.abs(out - ref) > advect_tol(dtype, dom) * max(np.abs(ref).max(), 1e-30)
     assert bad.mean() <= 2e-3, f"mac_cormack_centered: {bad.mean():.2%} of the samples differ"
+    for name, vel in gentle_fields(v, dom, dt, dtype, rng):
+        dg = [mem.to_dev(a) for a in vel]
+        ref = O.mac_cormack_centered(s, vel, dt, dom, s_codes, s_consts, strength)
+        for halo in (1, 0):
+            ctx.set_advect_halo(halo)
+            try:
+                ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dg], mem.ptr(dout), dt, strength)
+                mem.sync()
+            finally:
+                ctx.set_advect_halo(1)
+            bad = np.abs(mem.to_host(dout) - ref) > advect_tol(dtype, dom) * max(np.abs(ref).max(), 1e-30)
+            assert bad.mean() <= 2e-3, f"mac_cormack_centered {name} field, halo {halo}: {bad.mean():.2%} of the samples differ"
+            if halo and name == "gentle":
+                assert_no_fallback(ctx, dom, "mac_cormack_centered")
     ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), 0.0, strength)
     mem.sync()
     assert rel_err(mem.to_host(dout), s) <= 1e-6
@@ -328,6 +377,21 @@ def check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, strengt
         out = mem.to_host(dout[d])
         bad = np.abs(out - ref[d]) > advect_tol(dtype, dom) * max(np.abs(ref[d]).max(), 1e-30)
         assert bad.mean() <= 2e-3, f"mac_cormack_staggered[{d}]: {bad.mean():.2%} of the samples differ"
+    for name, vel in gentle_fields(v, dom, dt, dtype, rng):
+        dg = [mem.to_dev(a) for a in vel]
+        ref = O.mac_cormack_staggered(vel, vel, dt, dom, strength)
+        for halo in (1, 0):
+            ctx.set_advect_halo(halo)
+            try:
+                ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dout], dt, strength)
+                mem.sync()
+            finally:
+                ctx.set_advect_halo(1)
+            for d in range(dom.rank):
+                bad = np.abs(mem.to_host(dout[d]) - ref[d]) > advect_tol(dtype, dom) * max(np.abs(ref[d]).max(), 1e-30)
+                assert bad.mean() <= 2e-3, f"mac_cormack_staggered[{d}] {name} field, halo {halo}: {bad.mean():.2%} of the samples differ"
+            if halo and name == "gentle":
+                assert_no_fallback(ctx, dom, "mac_cormack_staggered")
     ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], 0.0, strength)
     mem.sync()
     for d in range(dom.rank):
