@@ -291,36 +291,50 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
     };
 
     // ---- one plane of samples ---------------------------------------------------------------------------------------------------
+    // per-thread output bookkeeping (plane-invariant): in-plane element offset of position s = 0 per output (unsigned 32-bit + a uniform
+    // 64-bit plane base: the address arithmetic of the stores stays scalar) and one bit per (position, output): the sample exists
+    constexpr int NOUT = KIND == WK_MC_STAG ? 3 : 1;
+    constexpr int O0 = KIND == WK_MC_STAG ? A0 : 0;
+    unsigned obase[3] = {0, 0, 0};
+    unsigned vbits = 0;
+#pragma unroll
+    for (int c = O0; c < NOUT; ++c) {
+        obase[c] = (unsigned)((lo1 + ty) * P.on[c][2] + lo2 + tx);
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+            if (lo1 + ty + k * TY < P.on[c][1] && lo2 + tx < P.on[c][2]) vbits |= 1u << (k * 3 + c);
+    }
     auto compute_plane = [&](int p) {
-        // element offset of plane p + d of window w (uniform): base[w][d + h0]
+        // element offset of plane p + d of window w (uniform): pbase[w][d + H0MAX]
         int pbase[NW][2 * C::H0MAX + 1];
 #pragma unroll
         for (int w = 0; w < NW; ++w)
 #pragma unroll
             for (int d = -C::H0MAX; d <= C::H0MAX; ++d)
                 pbase[w][d + C::H0MAX] = (d >= -C::h0(w) && d <= C::h0(w)) ? C::off(w) + slot_of(w, p + d) * C::plane(w) : 0;
-        // static tap: window w at (plane offset d0, row offset d1, column offset d2) from the sample at (row r, column tx)
-        auto at = [&](int w, int r, int d0, int d1, int d2) -> T {
-            return lds[pbase[w][d0 + C::H0MAX] + (r + C::h1(w) + d1) * C::p2(w) + tx + C::h2(w) + d2];
-        };
-        // multilinear lookup (or min / max over the taps) in window w at per-lane tap offsets (di = lower tap relative to the sample)
-        auto tap_base = [&](int w, int r, const int (&di)[3], int (&base)[2]) {
-            const int inplane = (r + C::h1(w) + di[1]) * C::p2(w) + tx + C::h2(w) + di[2];
+        // multilinear lookup (or min / max over the taps) in window w: `rel` = lower tap relative to the sample per axis (integral values in
+        // the element type, within [-h, h - 1]), `cen` = the sample's in-plane position in the window. The two tap planes are SELECTED among
+        // the uniform plane bases (no per-lane multiplication / ring arithmetic).
+        auto tap_base = [&](int w, int cen, const T (&rel)[3], int (&base)[2]) {
+            const int inplane = cen + __mul24((int)rel[1], C::p2(w)) + (int)rel[2];
             if (DIM == 3) {
-                int s0 = slot_of(w, p) + di[0];          // slot of the lower tap plane: wrap into the ring (|di| <= h0 + 1 < np)
-                s0 += s0 < 0 ? C::np(w) : 0;
-                s0 -= s0 >= C::np(w) ? C::np(w) : 0;
-                int s1 = s0 + 1;
-                s1 -= s1 >= C::np(w) ? C::np(w) : 0;
-                base[0] = C::off(w) + s0 * C::plane(w) + inplane;
-                base[1] = C::off(w) + s1 * C::plane(w) + inplane;
+                int b0 = pbase[w][C::H0MAX], b1 = pbase[w][C::H0MAX + 1];      // rel = 0: planes p, p + 1
+#pragma unroll
+                for (int d = -C::h0(w); d < C::h0(w); ++d) {
+                    if (d == 0) continue;
+                    const bool hit = d < 0 ? rel[0] <= (T)d : rel[0] >= (T)d;      // (descending for d < 0: the last match wins)
+                    if (d < 0) { b0 = rel[0] == (T)d ? pbase[w][d + C::H0MAX] : b0; b1 = rel[0] == (T)d ? pbase[w][d + 1 + C::H0MAX] : b1; }
+                    else { b0 = hit ? pbase[w][d + C::H0MAX] : b0; b1 = hit ? pbase[w][d + 1 + C::H0MAX] : b1; }
+                }
+                base[0] = b0 + inplane;
+                base[1] = b1 + inplane;
             } else {
                 base[0] = base[1] = C::off(w) + inplane;
             }
         };
-        auto lerp_taps = [&](int w, int r, const int (&di)[3], const T (&fr)[3]) -> T {
+        auto lerp_taps = [&](int w, int cen, const T (&rel)[3], const T (&fr)[3]) -> T {
             int base[2];
-            tap_base(w, r, di, base);
+            tap_base(w, cen, rel, base);
             T y[2];
 #pragma unroll
             for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
@@ -331,42 +345,46 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             }
             return DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
         };
-        auto minmax_taps = [&](int w, int r, const int (&di)[3], T& lo, T& hi) {
+        auto minmax_taps = [&](int w, int cen, const T (&rel)[3], T& lo, T& hi) {
             int base[2];
-            tap_base(w, r, di, base);
-            bool first = true;
+            tap_base(w, cen, rel, base);
+            lo = hi = lds[base[0]];
 #pragma unroll
             for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
                 const int bk = base[k];
                 const T t[4] = {lds[bk], lds[bk + C::p2(w)], lds[bk + 1], lds[bk + C::p2(w) + 1]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    lo = first ? t[q] : (t[q] < lo ? t[q] : lo);
-                    hi = first ? t[q] : (t[q] > hi ? t[q] : hi);
-                    first = false;
+                    lo = fmin(lo, t[q]);
+                    hi = fmax(hi, t[q]);
                 }
             }
         };
-        // integer part / fraction of a lookup coordinate relative to the sample index; `slow` when the taps leave [lo_rel, hi_rel + 1]
-        auto split = [&](T coord, T idxf, int lo_rel, int hi_rel, T& fr, int& di, bool& slow) {
+        // integer part / fraction of a lookup coordinate relative to the sample index; `dev` accumulates (rel - clamp(rel))^2: non-zero (or
+        // NaN) when some tap leaves [lo_rel, hi_rel + 1] -- no lane masks in scalar registers, no compare per axis
+        auto split = [&](T coord, T idxf, int lo_rel, int hi_rel, T& fr, T& rel, T& dev) {
             const T fl = floor(coord);
             fr = coord - fl;
-            const T rel = fl - idxf;
-            const T relc = win_clamp(rel, (T)lo_rel, (T)hi_rel);
-            slow = slow || !(rel == relc);          // also true for NaN
-            di = (int)relc;
+            const T r0 = fl - idxf;
+            rel = win_clamp(r0, (T)lo_rel, (T)hi_rel);
+            const T d = r0 - rel;
+            dev = fma(d, d, dev);
         };
         const T idxf0 = (T)p;
 #pragma unroll 1
         for (int s = 0; s < S; ++s) {
             const int r = ty + s * TY;
-            const int j1 = lo1 + r, j2 = lo2 + tx;
-            const T idxf[3] = {idxf0, (T)j1, (T)j2};
+            const T idxf[3] = {idxf0, (T)(lo1 + r), (T)(lo2 + tx)};
+            int cen[NW];                    // the sample's in-plane position in every window
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cen[w] = (r + C::h1(w)) * C::p2(w) + tx + C::h2(w);
+            // static tap: window w at (plane offset d0, row offset d1, column offset d2) from the sample
+            auto at = [&](int w, int d0, int d1, int d2) -> T { return lds[pbase[w][d0 + C::H0MAX] + cen[w] + (d1 * C::p2(w) + d2)]; };
             if (KIND == WK_MC_STAG) {
 #pragma unroll
                 for (int ca = A0; ca < 3; ++ca) {
                     const int wv = ca - A0, wf = DIM + ca - A0;
-                    const T vc = at(wv, r, 0, 0, 0);
+                    const T vc = at(wv, 0, 0, 0);
                     T cb[3] = {T(0), T(0), T(0)}, cf[3] = {T(0), T(0), T(0)};
                     cb[ca] = fma(vc, -P.shift[ca], idxf[ca]);
                     cf[ca] = fma(vc, P.shift[ca], idxf[ca]);
@@ -382,29 +400,29 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                                 int d[3] = {0, 0, 0};
                                 d[ca] = OFF[ca] - 1 + ia;
                                 d[cbx] = -OFF[cbx] + ib;
-                                v4[ia][ib] = at(cbx - A0, r, d[0], d[1], d[2]);
+                                v4[ia][ib] = at(cbx - A0, d[0], d[1], d[2]);
                             }
                         const T sum = (v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]);
                         cb[cbx] = fma(sum, T(-0.25) * P.shift[cbx], idxf[cbx]);
                         cf[cbx] = fma(sum, T(0.25) * P.shift[cbx], idxf[cbx]);
                     }
-                    bool slow = false;
-                    T fr[3] = {T(0), T(0), T(0)};
-                    int di[3] = {0, 0, 0};
+                    T dev = T(0);
+                    T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], di[a], slow);
-                    const T bwd = lerp_taps(wf, r, di, fr);
-                    const T nv = at(wf, r, 0, 0, 0) + P.ch * (vc - bwd);
+                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    const T bwd = lerp_taps(wf, cen[wf], rel, fr);
+                    const T nv = at(wf, 0, 0, 0) + P.ch * (vc - bwd);
                     // limiter: closest grid values of the backward lookup in the CELL frame (own axis: m - 1/2 instead of the stored index)
                     cb[ca] += (T)OFF[ca] - T(0.5);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], di[a], slow);
-                    T lo = T(0), hi = T(0);
-                    minmax_taps(wv, r, di, lo, hi);
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], rel[a], dev);
+                    T lo, hi;
+                    minmax_taps(wv, cen[wv], rel, lo, hi);
                     const T val = nv < lo ? lo : (nv > hi ? hi : nv);      // math.clip = minimum(maximum(x, lo), hi)
-                    const bool valid = p < P.on[ca][0] && j1 < P.on[ca][1] && j2 < P.on[ca][2];
-                    slow_any = slow_any || (valid && slow);
-                    T* const slot = P.out[ca] + (long long)b * P.ostride[ca] + ((long long)p * P.on[ca][1] + j1) * P.on[ca][2] + j2;
+                    const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < P.on[ca][0];
+                    slow_any = slow_any || (valid && !(dev == T(0)));
+                    T* const slot = P.out[ca] + (long long)b * P.ostride[ca] + (long long)p * ((long long)P.on[ca][1] * P.on[ca][2]) +
+                                    (obase[ca] + (unsigned)(s * TY * P.on[ca][2]));
                     *(valid ? slot : P.dump) = val;
                 }
             } else {
@@ -415,36 +433,36 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     // staggered velocity at the cell centre: mean of the cell's two c-faces (advect_common.hpp center_velocity)
                     int d[3] = {0, 0, 0};
                     d[c] = -OFF[c];
-                    const T lo_f = at(WV0 + c - A0, r, d[0], d[1], d[2]);
+                    const T lo_f = at(WV0 + c - A0, d[0], d[1], d[2]);
                     d[c] = -OFF[c] + 1;
-                    const T hi_f = at(WV0 + c - A0, r, d[0], d[1], d[2]);
+                    const T hi_f = at(WV0 + c - A0, d[0], d[1], d[2]);
                     const T u = hi_f * T(0.5) + lo_f * T(0.5);
                     const T sft = u * P.shift[c];
                     cb[c] = idxf[c] - sft;
                     cf[c] = idxf[c] + sft;
                 }
-                bool slow = false;
-                T fr[3] = {T(0), T(0), T(0)};
-                int di[3] = {0, 0, 0};
+                T dev = T(0);
+                T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
                 T val;
                 if (KIND == WK_SL_CEN) {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], di[a], slow);
-                    val = lerp_taps(0, r, di, fr);
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    val = lerp_taps(0, cen[0], rel, fr);
                 } else {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], di[a], slow);
-                    const T bwd = lerp_taps(1, r, di, fr);
-                    const T nv = at(1, r, 0, 0, 0) + P.ch * (at(0, r, 0, 0, 0) - bwd);
+                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    const T bwd = lerp_taps(1, cen[1], rel, fr);
+                    const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], di[a], slow);
-                    T lo = T(0), hi = T(0);
-                    minmax_taps(0, r, di, lo, hi);
+                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    T lo, hi;
+                    minmax_taps(0, cen[0], rel, lo, hi);
                     val = nv < lo ? lo : (nv > hi ? hi : nv);
                 }
-                const bool valid = p < P.on[0][0] && j1 < P.on[0][1] && j2 < P.on[0][2];
-                slow_any = slow_any || (valid && slow);
-                T* const slot = P.out[0] + (long long)b * P.ostride[0] + ((long long)p * P.on[0][1] + j1) * P.on[0][2] + j2;
+                const bool valid = ((vbits >> (s * 3)) & 1u) && p < P.on[0][0];
+                slow_any = slow_any || (valid && !(dev == T(0)));
+                T* const slot = P.out[0] + (long long)b * P.ostride[0] + (long long)p * ((long long)P.on[0][1] * P.on[0][2]) +
+                                (obase[0] + (unsigned)(s * TY * P.on[0][2]));
                 *(valid ? slot : P.dump) = val;
             }
         }
