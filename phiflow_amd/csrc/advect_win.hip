@@ -23,6 +23,10 @@
 
 #include "advect_common.hpp"
 
+#ifndef PHIHIP_WIN_UNROLL_S
+#define PHIHIP_WIN_UNROLL_S 0      // experiment switch: both tile positions of a thread in one straight-line body
+#endif
+
 namespace phihip {
 
 enum WinKind { WK_MC_STAG = 0, WK_SL_CEN = 1, WK_MC_CEN = 2 };
@@ -60,8 +64,15 @@ struct WinTile {
     static constexpr int p2(int w) { return T2 + 2 * h2(w); }
     static constexpr int plane(int w) { return p1(w) * p2(w); }
     static constexpr int np(int w) { return DIM == 3 ? 2 * h0(w) + 2 : 1; }       // ring slots: planes p - h0 .. p + h0 in use, one being refilled
-    static constexpr int off(int w) { int o = 0; for (int k = 0; k < w; ++k) o += np(k) * plane(k); return o; }
-    static constexpr int total() { return off(NW); }
+    // LDS layout: windows of EQUAL ring depth form a group whose slots are plane-major -- slot t of the group holds plane t of every member,
+    // so the element offset of (window w, slot t) is gbase(w) + t * gstride(w) + gin(w) with gin a compile-time constant: one uniform plane
+    // base per (group, relative plane) serves all its windows (per-window bases cost 20 scalar registers in the sample loop and spilled)
+    static constexpr int gstride(int w) { int o = 0; for (int k = 0; k < NW; ++k) o += np(k) == np(w) ? plane(k) : 0; return o; }
+    static constexpr int gin(int w) { int o = 0; for (int k = 0; k < w; ++k) o += np(k) == np(w) ? plane(k) : 0; return o; }
+    static constexpr bool first_of_group(int w) { for (int k = 0; k < w; ++k) if (np(k) == np(w)) return false; return true; }
+    static constexpr int gfirst(int w) { for (int k = 0; k < w; ++k) if (np(k) == np(w)) return k; return w; }
+    static constexpr int gbase(int w) { int o = 0; for (int k = 0; k < gfirst(w); ++k) o += first_of_group(k) ? np(k) * gstride(k) : 0; return o; }
+    static constexpr int total() { int o = 0; for (int k = 0; k < NW; ++k) o += np(k) * plane(k); return o; }
     static constexpr int kp(int w) { return (p1(w) + TY - 1) / TY; }              // fill passes of a thread per plane
     static constexpr int kpmax() { int m = 0; for (int w = 0; w < NW; ++w) m = kp(w) > m ? kp(w) : m; return m; }
     static constexpr int KP = kpmax();
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             const int kk = win_pad_index(lo2 - C::h2(w) + tail_q, A.n[2], A.bc[2][0], A.bc[2][1]);
             const int j = win_pad_index(lo1 - C::h1(w) + tail_r, A.n[1], A.bc[1][0], A.bc[1][1]);
             tail_eoff = (unsigned)((j < 0 ? 0 : j * A.n[2]) + (kk < 0 ? 0 : kk)) * (unsigned)sizeof(T);
-            tail_lds = C::off(w) + tail_r * C::p2(w) + tail_q;
+            tail_lds = C::gbase(w) + C::gin(w) + tail_r * C::p2(w) + tail_q;
         }
 
     // plane of window w that supplies staged plane i0: wrapped (one +-n suffices: every axis has >= 4 samples here) or clamped; beyond a
@@ -243,33 +254,63 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             tailv = *(const T*)((const char*)(tail_base + tail_src) + o);
         }
     };
-    // constants of CLOSED sides, patched in when a plane enters the ring (cold, uniform). The LAST axis outside a constant side decides.
-    auto patch_planes = [&](int p, T (&R)[NW][KP], T& tailv) {
+    // Constants of CLOSED sides, patched in when a plane enters the ring (cold, uniform: only workgroups whose windows cross such a side).
+    // The LAST axis outside a constant side decides (PhiML pads axis after axis): a2 over a1 over a0. Everything the patch needs is prepared
+    // ONCE: the in-plane decision per fill element lives in registers (value + one bit), the per-window plane rule in a small LDS table --
+    // read from the kernel arguments inside the plane loop, the boundary codes / constants / extents of six windows are ~100 live scalar
+    // registers, i.e. several hundred SGPR spill instructions per plane also in the workgroups that never take this path.
+    __shared__ T ctab[NW > 0 ? NW : 1][2];        // constant of the lower / upper a0 side of window w
+    __shared__ int ztab[NW > 0 ? NW : 1][2];      // staged planes < ztab[w][0] / >= ztab[w][1] lie beyond a CLOSED a0 side
+    T cval[NW][KP];
+    T tail_cval = T(0);
+    unsigned cbits = 0;                           // bit w * KP + kp: element (w, kp) of this thread is a constant; bit 31: its tail element
+    if (CONSTS) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const WinArray<T>& A = P.arr[w];
-            const int ks = p + C::h0(w) + 1;
-            const int k = DIM == 3 ? win_const_side(ks, A.n[0], A.bc[0][0], A.bc[0][1]) : 0;
-            const T pv = k == 1 ? A.cv[0][0] : A.cv[0][1];
             const int cside = win_const_side(lo2 - C::h2(w) + tx, A.n[2], A.bc[2][0], A.bc[2][1]);
-            const T cvv = cside == 1 ? A.cv[2][0] : A.cv[2][1];
 #pragma unroll
-            for (int kp = 0; kp < C::kp(w); ++kp) {
-                T v = R[w][kp];
+            for (int kp = 0; kp < KP; ++kp) {
                 const int j = win_const_side(lo1 - C::h1(w) + ty + kp * TY, A.n[1], A.bc[1][0], A.bc[1][1]);
-                const T rv = j == 1 ? A.cv[1][0] : A.cv[1][1];
-                v = k ? pv : v;
-                v = j ? rv : v;
-                v = cside ? cvv : v;
-                R[w][kp] = v;
+                cval[w][kp] = cside ? (cside == 1 ? A.cv[2][0] : A.cv[2][1]) : (j == 1 ? A.cv[1][0] : A.cv[1][1]);
+                if (cside || j) cbits |= 1u << (w * KP + kp);
             }
             if (w == tail_w) {
                 const int rs = win_const_side(lo1 - C::h1(w) + tail_r, A.n[1], A.bc[1][0], A.bc[1][1]);
                 const int cs = win_const_side(lo2 - C::h2(w) + tail_q, A.n[2], A.bc[2][0], A.bc[2][1]);
-                const T rv = rs == 1 ? A.cv[1][0] : A.cv[1][1], cv2 = cs == 1 ? A.cv[2][0] : A.cv[2][1];
-                tailv = k ? pv : tailv;
-                tailv = rs ? rv : tailv;
-                tailv = cs ? cv2 : tailv;
+                tail_cval = cs ? (cs == 1 ? A.cv[2][0] : A.cv[2][1]) : (rs == 1 ? A.cv[1][0] : A.cv[1][1]);
+                if (cs || rs) cbits |= 1u << 31;
+            }
+            if (tid == w) {
+                ctab[w][0] = A.cv[0][0];
+                ctab[w][1] = A.cv[0][1];
+                ztab[w][0] = (DIM == 3 && A.bc[0][0] == PHIHIP_BC_CLOSED) ? 0 : -(1 << 30);
+                ztab[w][1] = (DIM == 3 && A.bc[0][1] == PHIHIP_BC_CLOSED) ? A.n[0] : (1 << 30);
+            }
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) cval[w][kp] = T(0);
+    }
+    auto patch_planes = [&](int p, T (&R)[NW][KP], T& tailv) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int ks = p + C::h0(w) + 1;
+            const bool below = ks < ztab[w][0], above = ks >= ztab[w][1];       // uniform (LDS broadcast reads)
+            const T pv = below ? ctab[w][0] : ctab[w][1];
+#pragma unroll
+            for (int kp = 0; kp < C::kp(w); ++kp) {
+                T v = R[w][kp];
+                v = (below || above) ? pv : v;
+                v = ((cbits >> (w * KP + kp)) & 1u) ? cval[w][kp] : v;
+                R[w][kp] = v;
+            }
+            if (C::ntail(w) > 0 && w == tail_w) {
+                tailv = (below || above) ? pv : tailv;
+                tailv = (cbits >> 31) ? tail_cval : tailv;
             }
         }
     };
@@ -281,11 +322,11 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             const int ks = p + C::h0(w) + 1;
             if (ks < k_lo(w) || ks > k_hi(w)) continue;             // uniform
             const int slot = slot_of(w, ks);
-            T* L = lds + C::off(w) + slot * C::plane(w);
+            T* L = lds + C::gbase(w) + slot * C::gstride(w) + C::gin(w);
 #pragma unroll
             for (int kp = 0; kp < C::kp(w); ++kp)
                 if (ty + kp * TY < C::p1(w)) L[(ty + kp * TY) * C::p2(w) + tx] = R[w][kp];
-            if (w == tail_w) tail_slot = slot * C::plane(w);
+            if (w == tail_w) tail_slot = slot * C::gstride(w);
         }
         if (C::NTAIL > 0 && tail_slot >= 0) lds[tail_lds + tail_slot] = tailv;
     };
@@ -311,12 +352,12 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
         for (int w = 0; w < NW; ++w)
 #pragma unroll
             for (int d = -C::H0MAX; d <= C::H0MAX; ++d)
-                pbase[w][d + C::H0MAX] = (d >= -C::h0(w) && d <= C::h0(w)) ? C::off(w) + slot_of(w, p + d) * C::plane(w) : 0;
+                pbase[w][d + C::H0MAX] = (d >= -C::h0(w) && d <= C::h0(w)) ? C::gbase(w) + slot_of(w, p + d) * C::gstride(w) : 0;
         // multilinear lookup (or min / max over the taps) in window w: `rel` = lower tap relative to the sample per axis (integral values in
         // the element type, within [-h, h - 1]), `cen` = the sample's in-plane position in the window. The two tap planes are SELECTED among
         // the uniform plane bases (no per-lane multiplication / ring arithmetic).
         auto tap_base = [&](int w, int cen, const T (&rel)[3], int (&base)[2]) {
-            const int inplane = cen + __mul24((int)rel[1], C::p2(w)) + (int)rel[2];
+            const int inplane = cen + C::gin(w) + __mul24((int)rel[1], C::p2(w)) + (int)rel[2];
             if (DIM == 3) {
                 int b0 = pbase[w][C::H0MAX], b1 = pbase[w][C::H0MAX + 1];      // rel = 0: planes p, p + 1
 #pragma unroll
@@ -329,7 +370,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                 base[0] = b0 + inplane;
                 base[1] = b1 + inplane;
             } else {
-                base[0] = base[1] = C::off(w) + inplane;
+                base[0] = base[1] = C::gbase(w) + inplane;
             }
         };
         auto lerp_taps = [&](int w, int cen, const T (&rel)[3], const T (&fr)[3]) -> T {
@@ -371,7 +412,11 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             dev = fma(d, d, dev);
         };
         const T idxf0 = (T)p;
+#if PHIHIP_WIN_UNROLL_S
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int s = 0; s < S; ++s) {
             const int r = ty + s * TY;
             const T idxf[3] = {idxf0, (T)(lo1 + r), (T)(lo2 + tx)};
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) cen[w] = (r + C::h1(w)) * C::p2(w) + tx + C::h2(w);
             // static tap: window w at (plane offset d0, row offset d1, column offset d2) from the sample
-            auto at = [&](int w, int d0, int d1, int d2) -> T { return lds[pbase[w][d0 + C::H0MAX] + cen[w] + (d1 * C::p2(w) + d2)]; };
+            auto at = [&](int w, int d0, int d1, int d2) -> T { return lds[pbase[w][d0 + C::H0MAX] + cen[w] + (C::gin(w) + d1 * C::p2(w) + d2)]; };
             if (KIND == WK_MC_STAG) {
 #pragma unroll
                 for (int ca = A0; ca < 3; ++ca) {
