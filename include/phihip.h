@@ -350,6 +350,11 @@ int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
  * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
  * measurements, tests); halo = 3 is an experimental variant (halo 1 with 16-row tiles, 3-D only; 2-D grids treat it as 2). Default: 1. */
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
+/* The other advection passes -- the correction pass of mac_cormack(v, v), semi_lagrangian / mac_cormack of a centred scalar -- are served from
+ * LDS windows too (advect_win.hip; halo 1, gather fix-up for larger displacements) whenever halo != 0, on 3-D grids. On 2-D grids the gather
+ * kernels are faster (one plane per workgroup: nothing to overlap the fill with) and stay the default; enable != 0 switches the windows on
+ * there as well (parity tests, A/B measurements). */
+int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable);
 /* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup

@@ -23,10 +23,6 @@
 
 #include "advect_common.hpp"
 
-#ifndef PHIHIP_WIN_UNROLL_S
-#define PHIHIP_WIN_UNROLL_S 0      // experiment switch: both tile positions of a thread in one straight-line body
-#endif
-
 namespace phihip {
 
 enum WinKind { WK_MC_STAG = 0, WK_SL_CEN = 1, WK_MC_CEN = 2 };
@@ -412,11 +408,9 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             dev = fma(d, d, dev);
         };
         const T idxf0 = (T)p;
-#if PHIHIP_WIN_UNROLL_S
+        // both tile positions of a thread in one straight-line body: at two workgroups per CU (LDS) the registers are there, and the second
+        // position's LDS reads overlap the first one's arithmetic (same-box A/B, profiles/r04_time_frow_session_c.jsonl: 2-8 %)
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
         for (int s = 0; s < S; ++s) {
             const int r = ty + s * TY;
             const T idxf[3] = {idxf0, (T)(lo1 + r), (T)(lo2 + tx)};
@@ -803,6 +797,10 @@ static int launch_win(phihip_ctx* ctx, const GridView& v, const VelGrid& g, cons
 template <int KIND>
 static int run_win(phihip_ctx* ctx, const GridView& v, const WinCall& call, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
+    // 2-D grids keep the gather kernels: a 2-D workgroup has ONE plane, i.e. fill -> barrier -> compute without any overlap and 512 samples
+    // per fill; measured on the same box (profiles/r04_time_frow_session_c.jsonl) 8 x 512^2: semi_lagrangian(s, v) 12.9 us gather / 24.0 us
+    // windows, mac_cormack(s, v) 28.3 / 54.4, mac_cormack(v, v) 55.0 / 54.6; 2048^2: 22.5 / 40.5, 49.5 / 91.3, 94.4 / 93.1
+    if (v.rank != 3 && !ctx->adv_win_2d) return PHIHIP_ERR_UNSUPPORTED;
     for (int c = v.ax0; c < 3; ++c)
         for (int a = v.ax0; a < 3; ++a)
             if (v.cn[c][a] < 4 || v.n[a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a window wider than the axis: the caller keeps the gather kernels

@@ -896,6 +896,12 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     return PHIHIP_OK;
 }
 
+int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->adv_win_2d = enable != 0;
+    return PHIHIP_OK;
+}
+
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes) {
     PHIHIP_REQUIRE(ctx != nullptr && planes >= 0, "ctx is NULL or planes < 0");
     ctx->adv_chunk = planes;

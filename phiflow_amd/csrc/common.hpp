@@ -140,6 +140,7 @@ struct phihip_ctx {
     int adv_last_nblk = 0;        // workgroup flags of the most recent tiled advection (ws_adv_flags): count
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
+    bool adv_win_2d = false;      // advect_win.hip on 2-D grids (slower than the gather kernels there; phihip_set_advect_halo(ctx, 4) switches it on for the parity tests)
     // first-call autotune of the CG marching kernels: the candidates of the plan model are timed once per (grid, family) on the
     // context's own workspace and the fastest is cached here. PHIHIP_AUTOTUNE=0 in the environment / phihip_set_autotune(ctx, 0)
     // keep the analytic plan (bit-reproducible launch geometry across processes).

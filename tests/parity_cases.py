@@ -320,11 +320,13 @@ def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt
         ref = O.semi_lagrangian_centered(s, vel, dt, dom, s_codes, s_consts)
         for halo in (1, 0):
             ctx.set_advect_halo(halo)
+            ctx.set_advect_windows_2d(True)      # (2-D grids keep the gather kernels by default: exercise the windows there, too)
             try:
                 ctx.advect_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), dt)
                 mem.sync()
             finally:
                 ctx.set_advect_halo(1)
+                ctx.set_advect_windows_2d(False)
             err = rel_err(mem.to_host(dout), ref)
             assert err <= advect_tol(dtype, dom), f"advect_centered {name} field, halo {halo}: rel err {err}"
             if halo and name == "gentle":
@@ -351,11 +353,13 @@ def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_const
         ref = O.mac_cormack_centered(s, vel, dt, dom, s_codes, s_consts, strength)
         for halo in (1, 0):
             ctx.set_advect_halo(halo)
+            ctx.set_advect_windows_2d(True)      # (2-D grids keep the gather kernels by default: exercise the windows there, too)
             try:
                 ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dg], mem.ptr(dout), dt, strength)
                 mem.sync()
             finally:
                 ctx.set_advect_halo(1)
+                ctx.set_advect_windows_2d(False)
             bad = np.abs(mem.to_host(dout) - ref) > advect_tol(dtype, dom) * max(np.abs(ref).max(), 1e-30)
             assert bad.mean() <= 2e-3, f"mac_cormack_centered {name} field, halo {halo}: {bad.mean():.2%} of the samples differ"
             if halo and name == "gentle":
@@ -382,11 +386,13 @@ def check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, strengt
         ref = O.mac_cormack_staggered(vel, vel, dt, dom, strength)
         for halo in (1, 0):
             ctx.set_advect_halo(halo)
+            ctx.set_advect_windows_2d(True)      # (2-D grids keep the gather kernels by default: exercise the windows there, too)
             try:
                 ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dout], dt, strength)
                 mem.sync()
             finally:
                 ctx.set_advect_halo(1)
+                ctx.set_advect_windows_2d(False)
             for d in range(dom.rank):
                 bad = np.abs(mem.to_host(dout[d]) - ref[d]) > advect_tol(dtype, dom) * max(np.abs(ref[d]).max(), 1e-30)
                 assert bad.mean() <= 2e-3, f"mac_cormack_staggered[{d}] {name} field, halo {halo}: {bad.mean():.2%} of the samples differ"
