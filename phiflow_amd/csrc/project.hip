@@ -14,6 +14,26 @@ template <typename T>
 struct CComp3 {
     const T* p[3];
 };
+// V elements at 16-byte alignment: 16 bytes (fp32 V = 4, fp64 V = 2) or 32 bytes (fp64 V = 4: two dwordx4 -- r4: with V = 2 the fp64
+// instantiations of the vector kernels below issue one address per 16 bytes and are bound by the address units, not by HBM)
+template <typename T, int V>
+struct alignas(16) VecA {
+    T v[V];
+};
+template <typename T, int V>
+__device__ __forceinline__ VecA<T, V> veca_load(const T* p) { return *reinterpret_cast<const VecA<T, V>*>(p); }
+template <typename T, int V>
+__device__ __forceinline__ void veca_store(T* p, const VecA<T, V>& x) { *reinterpret_cast<VecA<T, V>*>(p) = x; }
+template <typename T, int V>
+__device__ __forceinline__ VecA<T, V> veca_zero() {
+    VecA<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = T(0);
+    return r;
+}
+// cells per thread of the vector kernels: fp32 4 (16 bytes), fp64 4 (32 bytes) when the rows allow, else 2
+template <typename T>
+static inline int vec_cells(int n2) { return sizeof(T) == 4 ? 4 : (n2 % 4 == 0 ? 4 : 2); }
 // V elements at ELEMENT alignment (rows of n2 - 1 / n2 + 1 faces do not start on 16-byte boundaries; gfx950 takes dwordx4 at any 4-byte address)
 template <typename T, int V>
 struct __attribute__((packed, aligned(sizeof(T)))) VecU {
@@ -154,12 +174,11 @@ __global__ __launch_bounds__(kBlock) void divergence_kernel(VelGrid g, CComp3<T>
 //       the face at the open end as a scalar with the velocity's boundary rule (wrap / wall constant),
 //   flags as one V-byte load, div as one aligned vector store. Rows must be whole vectors (n2 % V == 0), else the scalar kernel runs.
 // `ltpr`: log2 of the threads along a row (narrow grids put more rows into a workgroup instead of idle lanes).
-template <typename T, int DIM>
+template <typename T, int DIM, int V>
 __global__ __launch_bounds__(kBlock) void divergence_vec_kernel(VelGrid g, CComp3<T> v, const uint8_t* flags, int flags_per_batch,
                                                                 T* __restrict__ div, double* part_sum, double* part_act, int nblk, int tiles1,
                                                                 int tiles2, int chunk, int ltpr, int finite_guard) {
-    constexpr int V = 16 / (int)sizeof(T);
-    using VT = Vec<T, V>;
+    using VT = VecA<T, V>;
     using VU = VecU<T, V>;
     using VF = Vec<uint8_t, V>;
     __shared__ double red[kBlock / kWave];
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void divergence_vec_kernel(VelGrid g, CComp
     auto face0 = [&](int phys) -> VT {
         const int f = face_index(phys - g.off[0], g.cn[0][0], g.bc[0][0], g.bc[0][1]);
         if (f < 0) return splat((T)(f == -1 ? g.bcv[0][0][0] : g.bcv[0][1][0]));
-        return vec_load<T, V>(C0 + (long long)f * ps0 + o0);
+        return veca_load<T, V>(C0 + (long long)f * ps0 + o0);
     };
     T acc_val = T(0), acc_act = T(0);
     if (inside && p0 < p1) {
@@ -221,8 +240,8 @@ __global__ __launch_bounds__(kBlock) void divergence_vec_kernel(VelGrid g, CComp
         for (int p = p0; p < p1; ++p) {
             VT hi0 = lo0;
             if (DIM == 3) hi0 = face0(p + 1);
-            const VT a = c1f[0] ? splat(k1[0]) : vec_load<T, V>(C1 + (long long)p * ps1 + o1[0]);
-            const VT bb = c1f[1] ? splat(k1[1]) : vec_load<T, V>(C1 + (long long)p * ps1 + o1[1]);
+            const VT a = c1f[0] ? splat(k1[0]) : veca_load<T, V>(C1 + (long long)p * ps1 + o1[0]);
+            const VT bb = c1f[1] ? splat(k1[1]) : veca_load<T, V>(C1 + (long long)p * ps1 + o1[1]);
             const T* R2 = C2 + (long long)p * ps2;
             VT m;
             if (full2) {
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void divergence_vec_kernel(VelGrid g, CComp
                 acc_val += sum;
                 acc_act += act;
             }
-            vec_store<T, V>(D + cell, out);
+            veca_store<T, V>(D + cell, out);
             lo0 = hi0;
         }
     }
@@ -340,8 +359,7 @@ int run_balance(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
 // vector path: rows of whole 16-byte vectors, 16-byte aligned div / a0 / a1 components (their rows have the cells' length), V-byte aligned
 // flags; the a2 component only needs element alignment
 template <typename T>
-static bool divergence_vec_ok(const GridView& v, const void* const vel[3], const uint8_t* flags, const void* div) {
-    constexpr int V = 16 / (int)sizeof(T);
+static bool divergence_vec_ok(const GridView& v, const void* const vel[3], const uint8_t* flags, const void* div, int V) {
     bool ok = v.n[2] % V == 0 && ((uintptr_t)div & 15u) == 0 && (!flags || ((uintptr_t)flags & (V - 1)) == 0);
     for (int ca = v.ax0; ca < 2; ++ca) ok = ok && ((uintptr_t)vel[ca] & 15u) == 0;
     return ok && ((uintptr_t)vel[2] & (sizeof(T) - 1)) == 0;
@@ -351,8 +369,8 @@ template <typename T, int DIM>
 static int launch_divergence(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const void* const vel[3], const uint8_t* flags, int fpb, void* div,
                              int finite_guard, int* nblk_out, hipStream_t s) {
     CComp3<T> c{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
-    constexpr int V = 16 / (int)sizeof(T);
-    const bool vec = divergence_vec_ok<T>(v, vel, flags, div);
+    const int V = vec_cells<T>(v.n[2]);
+    const bool vec = divergence_vec_ok<T>(v, vel, flags, div, V);
     int ltpr = 6;                                                 // threads along a row: 64, fewer on narrow grids (whole workgroup rows instead of idle lanes)
     if (vec) while (ltpr > 0 && (1 << (ltpr - 1)) * V >= v.n[2]) --ltpr;
     const int rows = vec ? kBlock >> ltpr : kPatchRows, cols = vec ? (1 << ltpr) * V : kPatchCols;
@@ -368,8 +386,11 @@ static int launch_divergence(phihip_ctx* ctx, const GridView& v, const VelGrid& 
     PHIHIP_TRY(ensure_buffer(ctx->ws_div, (size_t)2 * v.batch * nblk * sizeof(double)));
     double* part_sum = (double*)ctx->ws_div.ptr;
     double* part_act = part_sum + (size_t)v.batch * nblk;
-    if (vec)
-        hipLaunchKernelGGL((divergence_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
+    if (vec && V == 4)
+        hipLaunchKernelGGL((divergence_vec_kernel<T, DIM, 4>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
+                           tiles1, tiles2, chunk_planes, ltpr, finite_guard);
+    else if (vec)
+        hipLaunchKernelGGL((divergence_vec_kernel<T, DIM, 2>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
                            tiles1, tiles2, chunk_planes, ltpr, finite_guard);
     else
         hipLaunchKernelGGL((divergence_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, flags, fpb, (T*)div, part_sum, part_act, nblk,
@@ -484,12 +505,11 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_kernel(VelGrid g, Comp3<
 //       (VecU: the hardware takes dwordx4 at any 4-byte address); the last, partial vector of a row and the extra face of an OPEN upper
 //       side (j = n2) are scalar. r3: closed and open boxes -- and with them every obstacle scenario -- used to send this component
 //       through the scalar kernel in a second launch that read p and the flags again.
-template <typename T, int DIM>
+template <typename T, int DIM, int V>
 __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Comp3<T> vc, const T* __restrict__ p, const uint8_t* flags, int flags_per_batch,
                                                                    int nmax0, int patches1, int patches2, int comps) {
     constexpr int A0 = 3 - DIM;
-    constexpr int V = 16 / (int)sizeof(T);
-    using VT = Vec<T, V>;
+    using VT = VecA<T, V>;
     using VU = VecU<T, V>;
     using VF = Vec<uint8_t, V>;
     const int b = blockIdx.y;
@@ -525,26 +545,26 @@ __global__ __launch_bounds__(kBlock) void grad_subtract_vec_kernel(VelGrid g, Co
             if (!r_in) { if (g.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { zr = true; r = n - 1; } }
             const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
             const int offL = rest + l * pstride, offR = rest + r * pstride;
-            pl = zl ? vec_zero<T, V>() : vec_load<T, V>(P + offL);
-            pr = zr ? vec_zero<T, V>() : vec_load<T, V>(P + offR);
+            pl = zl ? veca_zero<T, V>() : veca_load<T, V>(P + offL);
+            pr = zr ? veca_zero<T, V>() : veca_load<T, V>(P + offR);
             if (F) {
                 if (r_in || g.bc[ca][1] == PHIHIP_BC_PERIODIC) { fl = *reinterpret_cast<const VF*>(F + offR); use_f = true; }
                 else if (l_in) { fl = *reinterpret_cast<const VF*>(F + offL); use_f = true; fshift = 2 * ca + 1; }
             }
             T* __restrict__ Vp = vc.p[ca] + (long long)b * g.ccells[ca] + ((long long)(idx[0] * g.cn[ca][1] + idx[1]) * n2 + idx[2]);
-            VT u = vec_load<T, V>(Vp);
+            VT u = veca_load<T, V>(Vp);
             const T rd = (T)g.rdx[ca];
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const T h = use_f ? (((fl.v[e] >> fshift) & 1u) ? T(1) : T(0)) : T(1);
                 u.v[e] = u.v[e] - h * ((pr.v[e] - pl.v[e]) * rd);
             }
-            vec_store<T, V>(Vp, u);
+            veca_store<T, V>(Vp, u);
         }
         if (((comps >> 2) & 1) && idx[0] < g.cn[2][0] && idx[1] < g.cn[2][1]) {
             const int c = idx[2];
             const int row = (idx[0] * g.n[1] + idx[1]) * n2;
-            const VT pc = vec_load<T, V>(P + row + c);
+            const VT pc = veca_load<T, V>(P + row + c);
             VF fc;
             if (F) fc = *reinterpret_cast<const VF*>(F + row + c);
             // the cell beyond the open end of the vector, with the pressure's boundary rule (periodic wrap; ghost 0 outside an open / closed side:
@@ -589,7 +609,7 @@ static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint
     for (int a = 0; a < 3; ++a)
         for (int c = v.ax0; c < 3; ++c) nmax[a] = v.cn[c][a] > nmax[a] ? v.cn[c][a] : nmax[a];
     Comp3<T> c{{(T*)vel[0], (T*)vel[1], (T*)vel[2]}};
-    constexpr int V = 16 / (int)sizeof(T);
+    const int V = vec_cells<T>(v.n[2]);
     int scalar_comps = 7;
     // vector path: rows of the pressure are whole vectors and the buffers of p, of the flags and of the a0 / a1 components are 16-byte
     // aligned (flags: V bytes); the a2 component only needs element alignment
@@ -601,8 +621,12 @@ static void launch_grad_subtract(const GridView& v, const VelGrid& g, const uint
         const int patches1 = ceil_div(nmax[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols * V);
         const long long npatch = (long long)nmax[0] * patches1 * patches2;
         const int nblk = npatch < 16384 ? (int)npatch : 16384;
-        hipLaunchKernelGGL((grad_subtract_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1, patches2,
-                           vec_comps);
+        if (V == 4)
+            hipLaunchKernelGGL((grad_subtract_vec_kernel<T, DIM, 4>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1,
+                               patches2, vec_comps);
+        else
+            hipLaunchKernelGGL((grad_subtract_vec_kernel<T, DIM, 2>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, c, (const T*)p, flags, fpb, nmax[0], patches1,
+                               patches2, vec_comps);
         scalar_comps = 7 & ~vec_comps;
     }
     if (scalar_comps) {
@@ -705,13 +729,12 @@ __global__ __launch_bounds__(kBlock) void centered_to_staggered_kernel(VelGrid g
 //       comes from one scalar load or from the scalar's extrapolation (wrap / edge cell / constant). Rows of this component hold
 //       n2 - 1 / n2 / n2 + 1 faces: element-aligned vector access, masked tail, the extra face of an OPEN upper side as a scalar.
 // `comps`: bit mask of the components to write (accumulate: those with a non-zero vector entry).
-template <typename T, int DIM>
+template <typename T, int DIM, int V>
 __global__ __launch_bounds__(kBlock) void centered_to_staggered_vec_kernel(VelGrid g, ScalarBc sb, Comp3<T> oc, const T* __restrict__ sfield, T sc0, T sc1,
                                                                            T sc2, int accumulate, int comps, int nmax0, int patches1, int patches2,
                                                                            int ltpr) {
     constexpr int A0 = 3 - DIM;
-    constexpr int V = 16 / (int)sizeof(T);
-    using VT = Vec<T, V>;
+    using VT = VecA<T, V>;
     using VU = VecU<T, V>;
     const int b = blockIdx.y;
     const T* __restrict__ S = sfield + (long long)b * g.cells;
@@ -740,22 +763,22 @@ __global__ __launch_bounds__(kBlock) void centered_to_staggered_vec_kernel(VelGr
             if (l < 0) { if (sb.bc[ca][0] == PHIHIP_BC_PERIODIC) l += n; else { cl = sb.bc[ca][0] == PHIHIP_BC_CLOSED; l = 0; } }
             if (r >= n) { if (sb.bc[ca][1] == PHIHIP_BC_PERIODIC) r -= n; else { cr = sb.bc[ca][1] == PHIHIP_BC_CLOSED; r = n - 1; } }
             const int rest = (idx[0] * g.n[1] + idx[1]) * n2 + idx[2] - idx[ca] * pstride;
-            VT sl = vec_load<T, V>(S + rest + l * pstride), sr = vec_load<T, V>(S + rest + r * pstride);
+            VT sl = veca_load<T, V>(S + rest + l * pstride), sr = veca_load<T, V>(S + rest + r * pstride);
             T* __restrict__ Op = oc.p[ca] + (long long)b * g.ccells[ca] + ((long long)(idx[0] * g.cn[ca][1] + idx[1]) * n2 + idx[2]);
             VT o;
-            if (accumulate) o = vec_load<T, V>(Op);
+            if (accumulate) o = veca_load<T, V>(Op);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const T a = (cl ? (T)sb.val[ca][0] : sl.v[e]) * scale[ca], c = (cr ? (T)sb.val[ca][1] : sr.v[e]) * scale[ca];
                 const T val = a * T(0.5) + c * T(0.5);
                 o.v[e] = accumulate ? o.v[e] + val : val;
             }
-            vec_store<T, V>(Op, o);
+            veca_store<T, V>(Op, o);
         }
         if (((comps >> 2) & 1) && idx[0] < g.cn[2][0] && idx[1] < g.cn[2][1]) {
             const int c = idx[2];
             const int row = (idx[0] * g.n[1] + idx[1]) * n2;
-            const VT pc = vec_load<T, V>(S + row + c);
+            const VT pc = veca_load<T, V>(S + row + c);
             // the cell beyond the open end of the vector under the scalar's extrapolation: wrap, the edge cell itself (zero-gradient), or the constant
             T edge;
             if (off2 == 0) {
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(kBlock) void centered_to_staggered_vec_kernel(VelGr
 template <typename T, int DIM>
 static bool launch_c2s_vec(const GridView& v, const VelGrid& g, const ScalarBc& sb, const void* sfield, const double vector[3], int accumulate,
                            void* const out[3], hipStream_t s) {
-    constexpr int V = 16 / (int)sizeof(T);
+    const int V = vec_cells<T>(v.n[2]);
     bool ok = v.n[2] % V == 0 && ((uintptr_t)sfield & 15u) == 0;
     for (int ca = v.ax0; ca < 2; ++ca) ok = ok && ((uintptr_t)out[ca] & 15u) == 0;
     ok = ok && ((uintptr_t)out[2] & (sizeof(T) - 1)) == 0;
@@ -814,8 +837,12 @@ static bool launch_c2s_vec(const GridView& v, const VelGrid& g, const ScalarBc& 
     const long long npatch = (long long)nmax[0] * patches1 * patches2;
     const int nblk = npatch < 16384 ? (int)npatch : 16384;
     Comp3<T> oc{{(T*)out[0], (T*)out[1], (T*)out[2]}};
-    hipLaunchKernelGGL((centered_to_staggered_vec_kernel<T, DIM>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, oc, (const T*)sfield, (T)vector[0],
-                       (T)vector[1], (T)vector[2], accumulate, comps, nmax[0], patches1, patches2, ltpr);
+    if (V == 4)
+        hipLaunchKernelGGL((centered_to_staggered_vec_kernel<T, DIM, 4>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, oc, (const T*)sfield, (T)vector[0],
+                           (T)vector[1], (T)vector[2], accumulate, comps, nmax[0], patches1, patches2, ltpr);
+    else
+        hipLaunchKernelGGL((centered_to_staggered_vec_kernel<T, DIM, 2>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, oc, (const T*)sfield, (T)vector[0],
+                           (T)vector[1], (T)vector[2], accumulate, comps, nmax[0], patches1, patches2, ltpr);
     return true;
 }
 
