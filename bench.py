@@ -145,6 +145,61 @@ class SmokeBatchStep:
         return rel
 
 
+class Smoke3DStep:
+    """ `--workload smoke256`: ONE 3-D smoke plume of n^3 cells fp32 in a closed box (the 3-D form of Smoke_Plume.ipynb cell 5 with the
+    diffusion of Taylor_Green.ipynb cell 12) -- the step in which the NON-CG kernels matter:
+        smoke = mac_cormack(smoke, v, dt) + inflow                   (advect.py:182-215)
+        v     = semi_lagrangian(v, v, dt) + resample(smoke * (0, 0, 0.1), to=v)   (advect.py:156-179; _resample.py:156-157,272-276)
+        v     = diffuse.explicit(v, 0.01, dt)                        (diffuse.py:13-60)
+        v, p  = make_incompressible(v, (), Solve('CG', x0=p))        with exactly `cg_iters` (default 20) iterations from the previous pressure
+    `op_ms` times every operation of one extra step with an event pair around the C call (several launches each). """
+
+    def __init__(self, ctx, n, cg_iters, device):
+        self.ctx, self.n, self.device = ctx, n, device
+        clo = ((C.BC_CLOSED, C.BC_CLOSED),) * 3
+        self.grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (100.0, 100.0, 100.0), clo)
+        h = 100.0 / n
+        c = (torch.arange(n, device=device, dtype=torch.float64) + 0.5) * h
+        inside = ((c[:, None, None] - 50.0) ** 2 + (c[None, :, None] - 50.0) ** 2 + (c[None, None, :] - 9.5) ** 2) <= 25.0
+        self.inflow = (0.2 * inside).to(torch.float32).unsqueeze(0).contiguous()
+        z = lambda *shape: torch.zeros(1, *shape, device=device, dtype=torch.float32)
+        self.smoke, self.smoke2 = z(n, n, n), z(n, n, n)
+        shapes = [tuple(ctx.component_shape(self.grid, d)) for d in range(3)]
+        self.v, self.v2 = [z(*sh) for sh in shapes], [z(*sh) for sh in shapes]
+        self.p = z(n, n, n)
+        self.rel = torch.zeros(1, device=device, dtype=torch.float64)
+        self.solve = C.Solve(0.0, 0.0, cg_iters, 50, 0, 0)
+        self.s_bc = ((C.BC_OPEN, C.BC_OPEN),) * 3            # ZERO_GRADIENT smoke
+        self.dt = 1.0
+        self.kdt = 0.01 * self.dt
+        self.stream = int(torch.cuda.current_stream(device).cuda_stream)
+
+    def ops(self):
+        """ the step as (name, callable) pairs; buffers rotate v -> v2 -> v -> v2 (advect out of place, diffuse out of place) """
+        ctx, s, g = self.ctx, self.stream, self.grid
+        P = lambda ts: [t.data_ptr() for t in ts]
+
+        def inflow():
+            self.smoke2 += self.inflow
+        return [
+            ("mac_cormack_smoke", lambda: ctx.mac_cormack_centered(g, self.smoke.data_ptr(), self.s_bc, None, P(self.v), self.smoke2.data_ptr(), self.dt, 1.0, s)),
+            ("inflow_add", inflow),
+            ("semi_lagrangian_v", lambda: ctx.advect_staggered(g, P(self.v), P(self.v), P(self.v2), self.dt, s)),
+            ("buoyancy_resample", lambda: ctx.centered_to_staggered(g, self.smoke2.data_ptr(), self.s_bc, None, (0.0, 0.0, 0.1), True, P(self.v2), s)),
+            ("diffuse_explicit", lambda: ctx.diffuse_explicit(g, P(self.v2), P(self.v), self.kdt, s)),
+            ("make_incompressible", lambda: ctx.make_incompressible(g, P(self.v), None, 0, 1, True, self.p.data_ptr(), 0, self.solve, want_info=False, stream=s)),
+            ("residual_export", lambda: ctx.solve_relative_residual(1, self.rel.data_ptr(), s)),
+        ]
+
+    def step(self, allreduce=None):
+        for _, fn in self.ops():
+            fn()
+        self.smoke, self.smoke2 = self.smoke2, self.smoke       # (v ends in self.v again: advect v -> v2, diffuse v2 -> v, projection in place)
+        if allreduce is not None:
+            allreduce(self.rel)
+        return self.rel
+
+
 _RECORD_FD = None
 
 
@@ -174,6 +229,29 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- self-validation on EVERY rank (the first multi-GPU run of this workload will be the driver's): one reporting step on the owned
+    # entries, then batch entry 0 recomputed alone on this rank with the analytic launch plans -- its bits must agree across ranks ----
+    its_local, ok_local = [], True
+    if sim.batch > 0:
+        P = lambda ts: [t.data_ptr() for t in ts]
+        g, s_ = sim.grid, sim.stream
+        ctx.mac_cormack_centered(g, sim.smoke.data_ptr(), sim.s_bc, None, P(sim.v), sim.smoke2.data_ptr(), 1.0, 1.0, s_)
+        sim.smoke2 += sim.inflow
+        ctx.advect_staggered(g, P(sim.v), P(sim.v), P(sim.v2), 1.0, s_)
+        ctx.centered_to_staggered(g, sim.smoke2.data_ptr(), sim.s_bc, None, (0.0, 0.1), True, P(sim.v2), s_)
+        info = ctx.make_incompressible(g, P(sim.v2), None, 0, 1, True, sim.p.data_ptr(), 0, sim.solve, want_info=True, stream=s_)
+        sim.smoke, sim.smoke2 = sim.smoke2, sim.smoke
+        sim.v, sim.v2 = sim.v2, sim.v
+        its_local = [int(i.iterations) for i in info]
+        ok_local = all(i.iterations == args.cg_iters and not i.diverged for i in info)
+    ctx.set_autotune(False)
+    ref = SmokeBatchStep(ctx, n, total, 0, total, args.cg_iters, device)          # rank 0 of a world of `total`: entry 0 alone
+    for _ in range(args.warmup + args.steps + 1):
+        ref.step(None)
+    torch.cuda.synchronize(device)
+    ctx.set_autotune(True)
+    shards = gather_shards(dist, world, total, its_local, ok_local, [sim.p, sim.smoke] + sim.v, [ref.p, ref.smoke] + ref.v, device)
+    assert all(shards["verified_ok"]), shards["iterations_per_rank"]
     if rank == 0:
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
@@ -191,9 +269,74 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
                                    f"{args.cg_iters} CG iterations per projection", "sims_total": total, "sims_rank0": sim.batch, "cg_iterations": args.cg_iters,
                        "parallelism": f"batch-parallel x{world}, no data-path collective, 1 all-reduce(max residual)/step"},
             "final_relative_residual": float(rel.item()), "us_per_cg_iteration_rank0": round(it_us, 3),
+            "iterations_verified": shards["iterations_per_rank"], "shards": shards, "build_id": ctx.lib.build_id(),
+            "scaling_measured": "one point of a strong-scaling curve; no multi-GPU curve has been measured by the builder (single-GPU boxes only)",
             "kernel_ms_per_step_rank0": {k: round(v[1], 5) for k, v in prof.items()},
             "plan": {name: ctx.query_plan(sim.grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))}})
     if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_smoke3d(args, ctx, lib, device, rank, world, dist, barrier, allreduce):
+    """ `--workload smoke256`: replicas of the 3-D smoke step (weak scaling like the headline workload); the record carries the share of every
+    operation of the step -- with 20 warm-started CG iterations the advection / resample / diffusion kernels are ~half of it. """
+    n = args.size
+    iters = args.cg_iters if args.cg_iters != 100 else 20
+    sim = Smoke3DStep(ctx, n, iters, device)
+    for _ in range(max(args.warmup, 30)):          # the plume has to exist before the step is representative (smoke rises ~1 cell per step at first)
+        sim.step(allreduce)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rel = sim.step(allreduce)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        # one more step with an event pair around every operation (C call) + the library's per-launch events for the projection's parts
+        evs = []
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        e_begin = torch.cuda.Event(enable_timing=True)
+        e_begin.record()
+        for name, fn in sim.ops():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            evs.append((name, a, b))
+        e_end = torch.cuda.Event(enable_timing=True)
+        e_end.record()
+        torch.cuda.synchronize(device)
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        sim.smoke, sim.smoke2 = sim.smoke2, sim.smoke
+        op_ms = {name: round(a.elapsed_time(b), 5) for name, a, b in evs}
+        wall = e_begin.elapsed_time(e_end)
+        fb = list(ctx.advect_fallback_stats())
+        cells = n ** 3
+        ms_step = elapsed / args.steps * 1e3
+        non_cg = sum(v for k, v in op_ms.items() if k != "make_incompressible") + prof["divergence"][1] + prof["grad_subtract"][1] + prof["cg_residual"][1]
+        emit_record({
+            "metric": f"cell-updates/sec (mac_cormack smoke + advect + buoyancy + diffuse + {iters} CG iters), {n}^3 fp32 closed box", "value": cells * world * args.steps / elapsed,
+            "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 30), "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D smoke plume {n}^3 fp32, closed box: mac_cormack(smoke) + inflow, semi_lagrangian(v), buoyancy resample, diffuse.explicit, "
+                                   f"projection with {iters} CG iterations from the previous pressure (Smoke_Plume.ipynb cell 5 in 3-D; NOT a BASELINE.json config: "
+                                   f"the step in which the non-CG kernels count)", "cells_per_gpu": cells, "cg_iterations": iters,
+                       "parallelism": f"batch-parallel replicas x{world}, 1 all-reduce(max residual)/step"},
+            "final_relative_residual": float(rel.item()),
+            "op_ms_profiled_step": op_ms, "profiled_step_wall_ms": round(wall, 5),
+            "projection_parts_ms": {k: round(v[1], 5) for k, v in prof.items() if v[0] and k not in ("advect", "other")},
+            "non_cg_share_of_profiled_step": round(non_cg / wall, 4),
+            "advect_fallback_last_call": fb, "build_id": lib.build_id(),
+            "note": "op_ms: event pairs around each C call of ONE extra step (the per-launch events of the profiling mode add ~2 us per launch: the "
+                    "profiled step is slower than ms_per_step); smoke_max %.4f" % float(sim.smoke.max().item())})
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -503,6 +646,30 @@ def gather_replicas(dist, world, its_local, ok_local, fields, device, pinned_pla
     return iterations_all, replicas
 
 
+def gather_shards(dist, world, total, its_local, ok_local, own_fields, ref_fields, device):
+    """ sharded batch (config4), N >= 1: every rank reports the iteration counts of its verification step (one per OWNED entry), whether they
+    are the ones the line claims, a bit checksum of its owned entries, and a bit checksum of batch entry 0 recomputed on THIS rank as a
+    batch of one with the analytic launch plans (same inputs, same launch geometry on every rank => the same bits on every rank: a GPU or
+    rank that computes something else shows up without any cross-rank data exchange of fields). Returns the `shards` record. """
+    pad = [-1] * (total - len(its_local))
+    mine = torch.tensor(list(its_local) + pad + [len(its_local), int(ok_local)] + bit_checksum(own_fields) + bit_checksum(ref_fields),
+                        dtype=torch.int64, device=device)
+    if dist is not None:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = [g.tolist() for g in gathered]
+    else:
+        rows = [mine.tolist()]
+    n_own = 2 * len(own_fields)
+    its = [r[:r[total]] for r in rows]
+    ref_sums = [r[total + 2 + n_own:] for r in rows]
+    return {"iterations_per_rank": its, "entries_per_rank": [r[total] for r in rows], "verified_ok": [bool(r[total + 1]) for r in rows],
+            "owned_checksums": [r[total + 2:total + 2 + n_own] for r in rows],
+            "entry0_bit_identical_to_rank0": [x == ref_sums[0] for x in ref_sums], "entry0_all_bit_identical": all(x == ref_sums[0] for x in ref_sums),
+            "note": "entry0_*: every rank re-ran batch entry 0 alone (analytic launch plans, same number of steps) and the bit checksums of "
+                    "(p, smoke, v) were compared; owned_checksums identify the state each rank ended with"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -512,14 +679,14 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=100)
     ap.add_argument("--cpu-size", type=int, default=256, help="grid size of the CPU baseline sample and of the parity block (0 = skip); 256 = the metric's own configuration, ~30 s of NumPy")
     ap.add_argument("--profile-steps", type=int, default=1, help="extra steps with per-launch hipEvent timing for the roofline")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "slab"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config4", "slab", "smoke256"],
                     help="config2 (default, the BASELINE metric): 256^3 Taylor-Green replicas, weak scaling. config4: 8 x 512^2 batched smoke, the batch "
-                         "sharded over the GPUs, strong scaling. slab: ONE --size^3 simulation decomposed into x-slabs over the GPUs (SURVEY §8 f4)")
+                         "sharded over the GPUs, strong scaling. slab: ONE --size^3 simulation decomposed into x-slabs over the GPUs (SURVEY §8 f4). smoke256: a 3-D smoke "
+                         "plume step (MacCormack smoke, advection, buoyancy, diffusion, 20 warm-started CG iterations): the share of the non-CG kernels")
     ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
-    ap.add_argument("--overlap", type=int, default=1, help="slab: 1 = ghost exchange on a side stream while the interior planes are advected")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 behind Python's back (RCCL prints a
@@ -564,6 +731,8 @@ def main():
         return bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce)
     if args.workload == "slab":
         return bench_slab(args, lib, device, rank, world, dist, barrier)
+    if args.workload == "smoke256":
+        return bench_smoke3d(args, ctx, lib, device, rank, world, dist, barrier, allreduce)
     sim = FluidStep(ctx, n, B, args.cg_iters, device)
     pinned_plans = sync_launch_plans(ctx, sim, dist, rank, device) if dist is not None and (world > 1 or force_dist) else None
 
@@ -605,12 +774,25 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(args.profile_steps):
             sim.step(None)
+        e1.record()
         torch.cuda.synchronize(device)
         prof = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
         per = {k: (v[1] / v[0] if v[0] else None, v[0], v[1]) for k, v in prof.items()}
+        # The per-launch figures come from EXTRA steps with a hipEvent pair around every launch: the pairs serialise what the timed region
+        # overlaps (the next launch's dispatch behind the running kernel) and add ~2 us each, so their sum exceeds `ms_per_step` -- it must not
+        # exceed the wall time of the profiled steps themselves, which is reported next to it
+        profiled_ms = e0.elapsed_time(e1) / args.profile_steps
+        ksum = sum(v[2] for v in per.values()) / args.profile_steps
+        assert ksum <= 1.02 * profiled_ms, (ksum, profiled_ms)
+        extra["profiled_step"] = {"ms_wall": round(profiled_ms, 5), "sum_kernel_ms": round(ksum, 5), "launches": int(sum(v[1] for v in per.values()) / args.profile_steps),
+                                  "note": "kernel_ms_per_step / kernel_ms_per_launch are hipEvent intervals of these extra steps (one event pair per launch: "
+                                          "slower than the untouched step of ms_per_step by the events' own cost); rocprofv3 --kernel-trace figures of the "
+                                          "untouched step: profiles/r04_bench256_kernel_stats.csv"}
         roofline_bench, it = roofline_block(n, per, False, world, cache_assisted=4 * 4 * n ** 3 <= 256 * 2 ** 20,
                                             where="profiled steps of the timed benchmark configuration")
         if it:

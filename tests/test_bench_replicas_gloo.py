@@ -73,6 +73,17 @@ def _worker(rank, world, port, drift):
     assert rep["pressure_norm_rel_diff_vs_rank0"] == [0.0, 0.0] and rep["pinned_launch_plans"] == plans
     its, rep = bench.gather_replicas(dist, world, [100 - rank], rank == 0, [p] + v, dev, plans)       # a rank that stopped early is reported
     assert its == [[100], [99]] and rep["verified_ok"] == [True, False]
+    # the sharded batch (`--workload config4`): 5 entries over 2 ranks = 3 + 2; entry 0 recomputed on every rank must agree bit for bit
+    total = 5
+    own = [torch.full((3 - rank, 4, 4), float(rank + 1))]
+    ref = [p.clone()] + [t.clone() for t in v]                                                             # (v[2] of rank 1 carries the drift)
+    sh = bench.gather_shards(dist, world, total, [50] * (3 - rank), True, own, ref, dev)
+    assert sh["iterations_per_rank"] == [[50, 50, 50], [50, 50]] and sh["entries_per_rank"] == [3, 2] and sh["verified_ok"] == [True, True]
+    assert sh["entry0_all_bit_identical"] is (not drift) and sh["entry0_bit_identical_to_rank0"] == [True, not drift]
+    assert sh["owned_checksums"][0] != sh["owned_checksums"][1]
+    sh = bench.gather_shards(dist, world, total, [50] * (3 - rank - (rank == 1)), rank == 0, own, ref, dev)     # rank 1 lost an entry / stopped early
+    assert sh["iterations_per_rank"] == [[50, 50, 50], [50]] and sh["verified_ok"] == [True, False]
+    assert bench.gather_shards(None, 1, 2, [7, 7], True, own, ref, dev)["iterations_per_rank"] == [[7, 7]]      # one process, no collective
     dist.barrier()
     dist.destroy_process_group()
 
