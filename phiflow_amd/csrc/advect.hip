@@ -56,25 +56,25 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_kernel(VelGrid g, CCo
         if (!decode_sample(n[1], n[2], idx, f)) return;
         T u[3];
         face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
-        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};      // displacements in index units (lookup_pairs_rel: exact integer part)
 #pragma unroll
         for (int a = A0; a < 3; ++a) {
             const T sft = u[a] * (dt * (T)g.rdx[a]);
-            cb_[a] = (T)idx[a] - sft;
-            cf_[a] = (T)idx[a] + sft;
+            cb_[a] = -sft;
+            cf_[a] = sft;
         }
         AxisPair<T> ax[3];
         T fr[3];
         if (MODE == 0) {
-            lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             O[f] = gather_multilinear<T, DIM>(F, ax, fr);
         } else {
             const T* __restrict__ W = fwd + (long long)b * total;
-            lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
             const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
             const T nv = W[f] + ch * (F[f] - bwd);
             cb_[ca] += (T)g.off[ca] - T(0.5);
-            lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             T lo, hi;
             gather_minmax<T, DIM>(F, ax, lo, hi);
             O[f] = nv < lo ? lo : (nv > hi ? hi : nv);   // math.clip = minimum(maximum(x, lo), hi)
@@ -99,24 +99,24 @@ __global__ __launch_bounds__(kBlock) void advect_centered_kernel(VelGrid g, Scal
         if (!decode_sample(n[1], n[2], idx, f)) return;
         T u[3];
         center_velocity<T, DIM>(g, vel, b, idx, u);
-        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};      // displacements in index units
 #pragma unroll
         for (int a = A0; a < 3; ++a) {
             const T sft = u[a] * (dt * (T)g.rdx[a]);
-            cb_[a] = (T)idx[a] - sft;
-            cf_[a] = (T)idx[a] + sft;
+            cb_[a] = -sft;
+            cf_[a] = sft;
         }
         AxisPair<T> ax[3];
         T fr[3];
         if (MODE == 0) {
-            lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             O[f] = gather_multilinear<T, DIM>(F, ax, fr);
         } else {
             const T* __restrict__ W = fwd + (long long)b * total;
-            lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
             const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
             const T nv = W[f] + ch * (F[f] - bwd);
-            lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+            lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             T lo, hi;
             gather_minmax<T, DIM>(F, ax, lo, hi);
             O[f] = nv < lo ? lo : (nv > hi ? hi : nv);

@@ -202,6 +202,30 @@ __device__ __forceinline__ void lookup_pairs(const T (&coord)[3], const int (&n)
     if (DIM == 2) { ax[0].off[0] = ax[0].off[1] = 0; ax[0].cst[0] = ax[0].cst[1] = false; ax[0].cv[0] = ax[0].cv[1] = T(0); }
 }
 
+// The same for a lookup given as (sample index, displacement in index units): coordinate = idx + disp, but integer part and fraction are
+// formed from the DISPLACEMENT alone -- floor(disp), disp - floor(disp) -- and the integer part is added to the index exactly. r4: the
+// advection kernels used to round idx - dt u / dx to the element type first, which costs n eps / 2 of the lookup position on an axis of n
+// samples (2.3e-5 cells at n = 384 in fp32: the parity tolerance had to grow with n); now the error is eps |disp| whatever the index, i.e.
+// the kernels are MORE accurate than the NumPy path (absolute fp32 coordinates) they are checked against, and equal the fp64 evaluation of
+// the same fp32 inputs to ~1e-7 of the field's variation per cell (tests/parity_cases.py check_advect_*: ground truth = fp64 oracle).
+template <typename T, int DIM>
+__device__ __forceinline__ void lookup_pairs_rel(const int (&idx)[3], const T (&disp)[3], const int (&n)[3], const int (&bc)[3][2], const T (&cv)[3][2],
+                                                 AxisPair<T> (&ax)[3], T (&fr)[3]) {
+    constexpr int A0 = 3 - DIM;
+    const int stride[3] = {n[1] * n[2], n[2], 1};
+    fr[0] = fr[1] = fr[2] = T(0);
+#pragma unroll
+    for (int a = A0; a < 3; ++a) {
+        const T fl = floor(disp[a]);
+        fr[a] = disp[a] - fl;
+        // NaN / infinite / absurd displacements must not become wild indices: clamped to +-1e9 (NaN -> -1e9; idx + 1e9 < 2^31), the taps then
+        // resolve through the boundary rule and the result is NaN
+        const T fc = fmin(fmax(fl, T(-1.0e9)), T(1.0e9));
+        ax[a] = make_pair<T>(idx[a] + (int)fc, n[a], stride[a], bc[a][0], bc[a][1], cv[a][0], cv[a][1]);
+    }
+    if (DIM == 2) { ax[0].off[0] = ax[0].off[1] = 0; ax[0].cst[0] = ax[0].cst[1] = false; ax[0].cv[0] = ax[0].cv[1] = T(0); }
+}
+
 // component boundary rule as the (codes, constants) pair lookup_pairs wants
 template <typename T>
 __device__ __forceinline__ void comp_rule(const VelGrid& g, int comp, int (&bc)[3][2], T (&cv)[3][2]) {

@@ -306,18 +306,17 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // sample's own LDS position, blend as nested lerps along a2, a1, a0.
     auto compute_plane = [&](int p) {
         const int so_m = slot_of(p - 1) * PLANE, so_0 = slot_of(p) * PLANE, so_p = slot_of(p + 1) * PLANE;   // uniform element offsets
-        const T idxf0 = (T)p;
 #pragma unroll 1
         for (int s = 0; s < S; ++s) {
             const int center = (ty + s * TY + H) * P2 + tx + H;
             const int cen[3] = {center + so_m, center + so_0, center + so_p};     // this position in the planes p-1, p, p+1
-            const T idxf[3] = {idxf0, (T)(lo1 + ty + s * TY), (T)(lo2 + tx)};
 #pragma unroll
             for (int ca = A0; ca < 3; ++ca) {
                 // component x at (plane offset d0 in {-1,0,1}, row offset d1, column offset d2) from the sample: immediate offsets
                 auto at = [&](int x, int d0, int d1, int d2) -> T { return lds[cen[d0 + 1] + ((x - A0) * NP * PLANE + d1 * P2 + d2)]; };
-                T coord[3] = {T(0), T(0), T(0)};
-                coord[ca] = fma(at(ca, 0, 0, 0), -g.shift[ca], idxf[ca]);
+                T coord[3] = {T(0), T(0), T(0)};      // lookup position RELATIVE to the sample, in index units (r4: integer part and fraction are
+                                                      // formed from the displacement alone, advect_common.hpp lookup_pairs_rel)
+                coord[ca] = at(ca, 0, 0, 0) * -g.shift[ca];
 #pragma unroll
                 for (int cb = A0; cb < 3; ++cb) {
                     if (cb == ca) continue;
@@ -333,9 +332,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                             d[cb] = -OFF[cb] + ib;
                             v4[ia][ib] = at(cb, d[0], d[1], d[2]);
                         }
-                    coord[cb] = fma((v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]), T(-0.25) * g.shift[cb], idxf[cb]);
+                    coord[cb] = ((v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1])) * (T(-0.25) * g.shift[cb]);
                 }
-                // taps relative to the sample: rel = floor(coord) - index in [-H, H-1] or the lookup leaves the window
+                // taps relative to the sample: rel = floor(displacement) in [-H, H-1] or the lookup leaves the window
                 T fr[3] = {T(0), T(0), T(0)};
                 int di[3] = {0, 0, 0};
                 bool slow = false;
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                 for (int a = A0; a < 3; ++a) {
                     const T fl = floor(coord[a]);
                     fr[a] = coord[a] - fl;
-                    const T rel = fl - idxf[a];
+                    const T rel = fl;
                     const T relc = clamp_real(rel, T(-H), T(H - 1));
                     slow = slow || !(rel == relc);                 // also true for NaN
                     di[a] = (int)relc;
@@ -456,16 +455,16 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
                 if (ca == 0) face_velocity<T, DIM, 0>(g, vel, b, idx, f, u);
                 else if (ca == 1) face_velocity<T, DIM, 1>(g, vel, b, idx, f, u);
                 else face_velocity<T, DIM, 2>(g, vel, b, idx, f, u);
-                T coord[3] = {T(0), T(0), T(0)};
+                T disp[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                for (int a = A0; a < 3; ++a) coord[a] = (T)idx[a] - u[a] * (dt * (T)g.rdx[a]);
+                for (int a = A0; a < 3; ++a) disp[a] = -(u[a] * (dt * (T)g.rdx[a]));
                 const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
                 int bc[3][2];
                 T cv[3][2];
                 comp_rule<T>(g, ca, bc, cv);
                 AxisPair<T> ax[3];
                 T fr[3];
-                lookup_pairs<T, DIM>(coord, n, bc, cv, ax, fr);
+                lookup_pairs_rel<T, DIM>(idx, disp, n, bc, cv, ax, fr);
                 outp[ca][(long long)b * g.ccells[ca] + f] = gather_multilinear<T, DIM>(vel.p[ca] + (long long)b * g.ccells[ca], ax, fr);
             }
         }

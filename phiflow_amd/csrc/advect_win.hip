@@ -397,23 +397,21 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                 }
             }
         };
-        // integer part / fraction of a lookup coordinate relative to the sample index; `dev` accumulates (rel - clamp(rel))^2: non-zero (or
+        // integer part / fraction of a lookup DISPLACEMENT (position relative to the sample, in index units: the integer part is exact whatever the
+        // index -- advect_common.hpp lookup_pairs_rel); `dev` accumulates (rel - clamp(rel))^2: non-zero (or
         // NaN) when some tap leaves [lo_rel, hi_rel + 1] -- no lane masks in scalar registers, no compare per axis
-        auto split = [&](T coord, T idxf, int lo_rel, int hi_rel, T& fr, T& rel, T& dev) {
-            const T fl = floor(coord);
-            fr = coord - fl;
-            const T r0 = fl - idxf;
+        auto split = [&](T disp, int lo_rel, int hi_rel, T& fr, T& rel, T& dev) {
+            const T r0 = floor(disp);
+            fr = disp - r0;
             rel = win_clamp(r0, (T)lo_rel, (T)hi_rel);
             const T d = r0 - rel;
             dev = fma(d, d, dev);
         };
-        const T idxf0 = (T)p;
         // both tile positions of a thread in one straight-line body: at two workgroups per CU (LDS) the registers are there, and the second
         // position's LDS reads overlap the first one's arithmetic (same-box A/B, profiles/r04_time_frow_session_c.jsonl: 2-8 %)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int r = ty + s * TY;
-            const T idxf[3] = {idxf0, (T)(lo1 + r), (T)(lo2 + tx)};
             int cen[NW];                    // the sample's in-plane position in every window
 #pragma unroll
             for (int w = 0; w < NW; ++w) cen[w] = (r + C::h1(w)) * C::p2(w) + tx + C::h2(w);
@@ -425,8 +423,8 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     const int wv = ca - A0, wf = DIM + ca - A0;
                     const T vc = at(wv, 0, 0, 0);
                     T cb[3] = {T(0), T(0), T(0)}, cf[3] = {T(0), T(0), T(0)};
-                    cb[ca] = fma(vc, -P.shift[ca], idxf[ca]);
-                    cf[ca] = fma(vc, P.shift[ca], idxf[ca]);
+                    cf[ca] = vc * P.shift[ca];
+                    cb[ca] = -cf[ca];
 #pragma unroll
                     for (int cbx = A0; cbx < 3; ++cbx) {
                         if (cbx == ca) continue;
@@ -442,19 +440,19 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                                 v4[ia][ib] = at(cbx - A0, d[0], d[1], d[2]);
                             }
                         const T sum = (v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]);
-                        cb[cbx] = fma(sum, T(-0.25) * P.shift[cbx], idxf[cbx]);
-                        cf[cbx] = fma(sum, T(0.25) * P.shift[cbx], idxf[cbx]);
+                        cf[cbx] = sum * (T(0.25) * P.shift[cbx]);
+                        cb[cbx] = -cf[cbx];
                     }
                     T dev = T(0);
                     T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cf[a], -1, 0, fr[a], rel[a], dev);
                     const T bwd = lerp_taps(wf, cen[wf], rel, fr);
                     const T nv = at(wf, 0, 0, 0) + P.ch * (vc - bwd);
                     // limiter: closest grid values of the backward lookup in the CELL frame (own axis: m - 1/2 instead of the stored index)
                     cb[ca] += (T)OFF[ca] - T(0.5);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cb[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], rel[a], dev);
                     T lo, hi;
                     minmax_taps(wv, cen[wv], rel, lo, hi);
                     const T val = nv < lo ? lo : (nv > hi ? hi : nv);      // math.clip = minimum(maximum(x, lo), hi)
@@ -477,23 +475,23 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     const T hi_f = at(WV0 + c - A0, d[0], d[1], d[2]);
                     const T u = hi_f * T(0.5) + lo_f * T(0.5);
                     const T sft = u * P.shift[c];
-                    cb[c] = idxf[c] - sft;
-                    cf[c] = idxf[c] + sft;
+                    cb[c] = -sft;
+                    cf[c] = sft;
                 }
                 T dev = T(0);
                 T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
                 T val;
                 if (KIND == WK_SL_CEN) {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cb[a], -1, 0, fr[a], rel[a], dev);
                     val = lerp_taps(0, cen[0], rel, fr);
                 } else {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cf[a], -1, 0, fr[a], rel[a], dev);
                     const T bwd = lerp_taps(1, cen[1], rel, fr);
                     const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], idxf[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cb[a], -1, 0, fr[a], rel[a], dev);
                     T lo, hi;
                     minmax_taps(0, cen[0], rel, lo, hi);
                     val = nv < lo ? lo : (nv > hi ? hi : nv);
@@ -577,8 +575,8 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
 #pragma unroll
                     for (int a = A0; a < 3; ++a) {
                         const T sft = u[a] * (dt * (T)g.rdx[a]);
-                        cb_[a] = (T)idx[a] - sft;
-                        cf_[a] = (T)idx[a] + sft;
+                        cb_[a] = -sft;
+                        cf_[a] = sft;
                     }
                     int bc[3][2];
                     T cv[3][2];
@@ -588,11 +586,11 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                     const long long total = g.ccells[ca];
                     const T* __restrict__ F = field.p[ca] + (long long)b * total;
                     const T* __restrict__ W = fwd3.p[ca] + (long long)b * total;
-                    lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+                    lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
                     const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
                     const T nv = W[f] + ch * (F[f] - bwd);
                     cb_[ca] += (T)g.off[ca] - T(0.5);
-                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
                     T lo, hi;
                     gather_minmax<T, DIM>(F, ax, lo, hi);
                     outp[ca][(long long)b * total + f] = nv < lo ? lo : (nv > hi ? hi : nv);
@@ -607,8 +605,8 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
 #pragma unroll
                 for (int a = A0; a < 3; ++a) {
                     const T sft = u[a] * (dt * (T)g.rdx[a]);
-                    cb_[a] = (T)idx[a] - sft;
-                    cf_[a] = (T)idx[a] + sft;
+                    cb_[a] = -sft;
+                    cf_[a] = sft;
                 }
                 int bc[3][2];
                 T cv[3][2];
@@ -617,14 +615,14 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                 T fr[3];
                 const T* __restrict__ F = sfield + (long long)b * g.cells;
                 if (KIND == WK_SL_CEN) {
-                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
                     o0[(long long)b * g.cells + f] = gather_multilinear<T, DIM>(F, ax, fr);
                 } else {
                     const T* __restrict__ W = fwd1 + (long long)b * g.cells;
-                    lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
+                    lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
                     const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
                     const T nv = W[f] + ch * (F[f] - bwd);
-                    lookup_pairs<T, DIM>(cb_, n, bc, cv, ax, fr);
+                    lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
                     T lo, hi;
                     gather_minmax<T, DIM>(F, ax, lo, hi);
                     o0[(long long)b * g.cells + f] = nv < lo ? lo : (nv > hi ? hi : nv);

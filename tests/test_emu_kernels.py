@@ -97,6 +97,11 @@ def test_adjoint_kernels_match_oracle_derivatives(emu_ctx, res, bc):
     pc.check_mac_cormack_and_diffuse_backward(emu_ctx, MEM, dom, grid, rng, s_codes, s_consts)
 
 
+def test_adjoint_next_to_a_lookup_kink(emu_ctx):
+    """ the round-3 GPU observation (fuzz seed 40062) as a constructed, asserted case """
+    pc.check_adjoint_next_to_a_lookup_kink(emu_ctx, MEM)
+
+
 def test_adjoint_projection_with_obstacles(emu_ctx):
     rng = np.random.default_rng(15)
     dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float64, batch=1)

@@ -127,6 +127,11 @@ def test_adjoint_kernels_match_oracle_derivatives(ctx, mem, res, bc):
     pc.check_mac_cormack_and_diffuse_backward(ctx, mem, dom, grid, rng, s_codes, [(0.0, 0.25)] * len(res))
 
 
+def test_adjoint_next_to_a_lookup_kink(ctx, mem):
+    """ round-3 fuzz seed 40062 (adjoint vs finite differences 3e-4 apart on the GPU) as a constructed case with the kink distance asserted """
+    pc.check_adjoint_next_to_a_lookup_kink(ctx, mem)
+
+
 def test_adjoint_projection_with_obstacles(ctx, mem):
     rng = np.random.default_rng(15)
     dom, grid = pc.make_case((12, 10, 16), ((CLO, CLO),) * 3, np.float64, batch=1)
