@@ -298,6 +298,186 @@ def recognise_shifted_laplace(matrix, resolution: Sequence[int], rtol: float = 1
     return dict(d, identity=ident, scale=scale)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the same recognition WHERE THE MATRIX LIVES (r4): torch ops on the index / value arrays of a torch sparse matrix, no host copy.
+# The SciPy pass above moves 7 N entries to the host and walks them with NumPy -- seconds at 256^3, once per (grid, obstacle set)
+# thanks to the fingerprint cache, but a MOVING obstacle (Moving_Obstacles.ipynb) changes the matrix every step and pays it every
+# step. On the device the pass is a few dozen elementwise / scatter kernels over the entries: milliseconds.
+# ---------------------------------------------------------------------------------------------------------------------
+def _torch_entries(lin):
+    """ (row, col, val) int64 / float64 tensors of a torch sparse CSR / COO matrix on its own device, duplicates summed """
+    if lin.layout == torch.sparse_csr:
+        crow, col, val = lin.crow_indices(), lin.col_indices(), lin.values()
+        n = crow.numel() - 1
+        row = torch.repeat_interleave(torch.arange(n, device=crow.device, dtype=torch.int64), (crow[1:] - crow[:-1]).to(torch.int64))
+        return row, col.to(torch.int64), val.to(torch.float64)
+    m = lin.coalesce()
+    i = m.indices()
+    return i[0].to(torch.int64), i[1].to(torch.int64), m.values().to(torch.float64)
+
+
+def infer_resolution_torch(row, col, N: int) -> Tuple[int, ...]:
+    """ `infer_resolution` on tensors (any device) """
+    d = col - row
+    d = d[d > 0]
+    if d.numel() == 0:
+        raise NotALaplaceStencil("no off-diagonal couplings")
+    offs, counts = torch.unique(d, return_counts=True)
+    keep = counts > 0.45 * N
+    strides = [int(o) for o in offs[keep].tolist()]
+    if not strides or strides[0] != 1 or len(strides) not in (2, 3):
+        raise NotALaplaceStencil(f"coupling offsets {strides} are not the strides of a 2-D / 3-D grid")
+    res = []
+    for lo, hi in zip(strides, strides[1:] + [N]):
+        if hi % lo:
+            raise NotALaplaceStencil(f"coupling offsets {strides} do not divide the matrix size {N}")
+        res.append(hi // lo)
+    return tuple(reversed(res))
+
+
+def recognise_laplace_stencil_torch(row, col, val, resolution: Sequence[int], rtol: float = 1e-5) -> Dict:
+    """ `recognise_laplace_stencil` on the (row, col, val) tensors of a coalesced matrix, on their device. Returns the same description;
+    `flags` is a uint8 TENSOR of shape `resolution` on that device (or None). The neighbour tests are index arithmetic per entry
+    (coordinate of the row's cell along the axis, column = row -+ stride or the wrap-around image), the final comparison with the assembled
+    operator is the row-wise identity diag = -(sum of couplings) - w * (faces towards an OPEN side) [active rows] / 1 [identity rows]. """
+    res = tuple(int(r) for r in resolution)
+    D = len(res)
+    N = int(np.prod(res))
+    dev = val.device
+    if D not in (2, 3) or val.numel() > (2 * D + 1) * N:
+        raise NotALaplaceStencil("more than 2 D + 1 entries per row")
+    strides = [int(np.prod(res[a + 1:])) for a in range(D)]
+    offm = row != col
+    diag = torch.zeros(N, dtype=torch.float64, device=dev).index_add_(0, row[~offm], val[~offm])
+    r_off, c_off, v_off = row[offm], col[offm], val[offm]
+    cells = torch.arange(N, device=dev, dtype=torch.int64)
+    face_bits = torch.zeros(N, dtype=torch.int32, device=dev)
+    claimed = torch.zeros(r_off.numel(), dtype=torch.bool, device=dev)
+    weights, wraps_axis = [], []
+    for a in range(D):
+        n, st = res[a], strides[a]
+        coord = (r_off // st) % n
+        per_axis = []
+        for side in (0, 1):
+            if side == 0:
+                hit_in = (c_off == r_off - st) & (coord > 0)
+                wraps = (coord == 0) & (c_off == r_off + (n - 1) * st) & (n > 2)
+            else:
+                hit_in = (c_off == r_off + st) & (coord < n - 1)
+                wraps = (coord == n - 1) & (c_off == r_off - (n - 1) * st) & (n > 2)
+            per_axis.append((hit_in, wraps))
+        sel_axis = per_axis[0][0] | per_axis[0][1] | per_axis[1][0] | per_axis[1][1]
+        if not bool(sel_axis.any()):
+            raise NotALaplaceStencil(f"no coupling along axis {a}")
+        first = per_axis[0][0] | per_axis[0][1]
+        w_axis = float(torch.median(v_off[first] if bool(first.any()) else v_off[sel_axis]))
+        if w_axis <= 0:
+            raise NotALaplaceStencil(f"no coupling along axis {a}")
+        if bool(((v_off[sel_axis] - w_axis).abs() > rtol * w_axis).any()):
+            raise NotALaplaceStencil(f"couplings along axis {a} are not one constant 1/dx^2")
+        sides = []
+        for side, (hit_in, wraps) in enumerate(per_axis):
+            sel = hit_in | wraps
+            claimed |= sel
+            bit = 1 << (2 * (a + 3 - D) + side)
+            cnt = torch.zeros(N, dtype=torch.int32, device=dev).index_add_(0, r_off[sel], torch.ones(int(sel.sum()), dtype=torch.int32, device=dev))
+            if bool((cnt > 1).any()):
+                raise NotALaplaceStencil("duplicate couplings")
+            face_bits |= cnt * bit
+            sides.append(bool(wraps.any()))
+        weights.append(w_axis)
+        wraps_axis.append(tuple(sides))
+    if not bool(claimed.all()):
+        raise NotALaplaceStencil("couplings between cells that are not face neighbours")
+    row_sum = torch.zeros(N, dtype=torch.float64, device=dev).index_add_(0, r_off, v_off)
+    inactive = (row_sum == 0) & ((diag - 1.0).abs() <= rtol) & (face_bits == 0)
+    deficit = -(diag + row_sum)
+    edge = {}
+    for a in range(D):
+        ca = (cells // strides[a]) % res[a]
+        edge[(a, 0)], edge[(a, 1)] = ca == 0, ca == res[a] - 1
+    bc_codes = []
+    for a in range(D):
+        codes = []
+        for side in (0, 1):
+            if wraps_axis[a][side]:
+                codes.append(_capi.BC_PERIODIC)
+                continue
+            cand = edge[(a, side)] & ~inactive
+            only = cand.clone()
+            for a2 in range(D):
+                for side2 in (0, 1):
+                    if (a2, side2) != (a, side) and not wraps_axis[a2][side2]:
+                        only &= ~edge[(a2, side2)]
+            pick = only if bool(only.any()) else cand
+            if not bool(pick.any()):
+                codes.append(_capi.BC_CLOSED)
+                continue
+            frac = float(torch.median(deficit[pick])) / weights[a]
+            codes.append(_capi.BC_OPEN if frac > 0.5 else _capi.BC_CLOSED)
+        if (codes[0] == _capi.BC_PERIODIC) != (codes[1] == _capi.BC_PERIODIC):
+            raise NotALaplaceStencil(f"axis {a} wraps on one side only")
+        bc_codes.append(tuple(codes))
+    flags = face_bits.clone()
+    open_w = torch.zeros(N, dtype=torch.float64, device=dev)        # w * (faces of the row towards an OPEN side)
+    plain_bits = torch.zeros(N, dtype=torch.int32, device=dev)      # the obstacle-free operator's face bits
+    for a in range(D):
+        for side in (0, 1):
+            bit = 1 << (2 * (a + 3 - D) + side)
+            e = edge[(a, side)]
+            if bc_codes[a][side] == _capi.BC_OPEN:
+                flags |= (e & ~inactive).to(torch.int32) * bit
+                open_w += (e & ~inactive).to(torch.float64) * weights[a]
+            inside_or_wrap = ~e if bc_codes[a][side] != _capi.BC_PERIODIC else torch.ones_like(e)
+            plain_bits |= (inside_or_wrap | (e & (bc_codes[a][side] == _capi.BC_OPEN))).to(torch.int32) * bit
+    flags |= (~inactive).to(torch.int32) * 64
+    # the operator the kernels apply for (weights, bc, flags) has diag = -(couplings + open faces) on active rows: compare
+    tolv = rtol * max(weights)
+    if bool(((deficit - open_w).abs()[~inactive] > tolv * (2 * D + 1)).any()):
+        raise NotALaplaceStencil("the matrix is not reproduced by the recognised (spacing, boundary, mask) description")
+    # active rows must couple symmetrically: a face bit of cell c towards an ACTIVE cell inside the grid needs the partner's bit (else the
+    # matrix is not a flux-form operator; masked_laplace always is)
+    plain = bool((~inactive).all()) and bool((flags == (plain_bits | 64)).all())
+    return dict(weights=weights, bc=bc_codes, flags=None if plain else flags.to(torch.uint8).reshape(res))
+
+
+def recognise_shifted_laplace_torch(row, col, val, resolution: Sequence[int], rtol: float = 1e-5) -> Dict:
+    """ `recognise_shifted_laplace` on tensors: identity * I + scale * L """
+    res = tuple(int(r) for r in resolution)
+    N = int(np.prod(res))
+    dev = val.device
+    D = len(res)
+    if D not in (2, 3):
+        raise NotALaplaceStencil(f"grid {res}")
+    cells = torch.arange(N, device=dev, dtype=torch.int64)
+    interior = torch.ones(N, dtype=torch.bool, device=dev)
+    for a in range(D):
+        ca = (cells // int(np.prod(res[a + 1:]))) % res[a]
+        interior &= (ca > 0) & (ca < res[a] - 1)
+    if not bool(interior.any()):
+        raise NotALaplaceStencil("no cell away from the boundaries: cannot separate the identity from the stencil")
+    row_sum = torch.zeros(N, dtype=torch.float64, device=dev).index_add_(0, row, val)
+    ident = float(torch.median(row_sum[interior]))
+    amax = float(val.abs().max()) if val.numel() else 0.0
+    if abs(ident) <= rtol * amax:
+        raise NotALaplaceStencil("no identity part")
+    if bool(((row_sum[interior] - ident).abs() > rtol * amax).any()):
+        raise NotALaplaceStencil("the row sums of the interior rows are not one constant")
+    offm = row != col
+    if not bool(offm.any()):
+        raise NotALaplaceStencil("diagonal matrix")
+    scale = 1.0 if float(torch.median(val[offm])) > 0 else -1.0
+    # L = (A - ident I) * scale: the diagonal entries may be missing as stored entries only if they are zero -- add the full diagonal
+    v2 = torch.cat([val * scale, torch.full((N,), -ident * scale, dtype=torch.float64, device=dev)])
+    r2, c2 = torch.cat([row, cells]), torch.cat([col, cells])
+    m = torch.sparse_coo_tensor(torch.stack([r2, c2]), v2, (N, N)).coalesce()
+    i = m.indices()
+    d = recognise_laplace_stencil_torch(i[0], i[1], m.values(), res, rtol)
+    if d['flags'] is not None:
+        raise NotALaplaceStencil("shifted operator with inactive cells / obstacles")
+    return dict(d, identity=ident, scale=scale)
+
+
 def infer_resolution(matrix) -> Tuple[int, ...]:
     """ Grid resolution of a 5 / 7-point matrix over cells in C order, read off the matrix itself: the couplings of an interior row sit
     at column offsets +-1, +-n_last, +-n_last * n_mid, and every such offset occurs in more than half of the rows (a wrap-around offset of a
@@ -375,6 +555,8 @@ class HipLinearSolveMixin:
 
     hip_resolution: Optional[Tuple[int, ...]] = None
     hip_cache_size = 8
+    hip_recognise_on_device = True      # torch matrices on an accelerator are recognised THERE (False: host copy + SciPy, the r3 path;
+                                        # 'always': torch path for CPU tensors too -- slower than SciPy there, used by the tests)
 
     def set_grid_resolution(self, resolution: Optional[Sequence[int]]):
         self.hip_resolution = tuple(int(r) for r in resolution) if resolution is not None else None
@@ -412,15 +594,28 @@ class HipLinearSolveMixin:
             return hit
         self.hip_stats['cache_misses'] += 1
         try:
-            A = self._as_scipy(lin)
-            N = A.shape[0]
-            res = self.hip_resolution
-            if res is None or int(np.prod(res)) != N:
-                res = infer_resolution(A)
-            try:
-                d = recognise_laplace_stencil(A, res)
-            except NotALaplaceStencil:
-                d = recognise_shifted_laplace(A, res)          # identity * I + scale * L (implicit diffusion)
+            if isinstance(lin, torch.Tensor) and (self.hip_recognise_on_device == 'always' or (self.hip_recognise_on_device and lin.device.type != 'cpu')):
+                # the matrix stays where it is (r4): index arithmetic + scatter sums on its device, a handful of scalars come back
+                row, col, val = _torch_entries(lin)
+                N = int(lin.shape[0])
+                res = self.hip_resolution
+                if res is None or int(np.prod(res)) != N:
+                    res = infer_resolution_torch(row, col, N)
+                try:
+                    d = recognise_laplace_stencil_torch(row, col, val, res)
+                except NotALaplaceStencil:
+                    d = recognise_shifted_laplace_torch(row, col, val, res)
+                self.hip_stats['device_recognitions'] = self.hip_stats.get('device_recognitions', 0) + 1
+            else:
+                A = self._as_scipy(lin)
+                N = A.shape[0]
+                res = self.hip_resolution
+                if res is None or int(np.prod(res)) != N:
+                    res = infer_resolution(A)
+                try:
+                    d = recognise_laplace_stencil(A, res)
+                except NotALaplaceStencil:
+                    d = recognise_shifted_laplace(A, res)          # identity * I + scale * L (implicit diffusion)
         except NotALaplaceStencil as err:
             entry = err
         else:

@@ -69,6 +69,51 @@ def test_recogniser_with_obstacle_masks_and_rejections():
         linear.recognise_laplace_stencil(sp.identity(41, format='csr'), dom.res)
 
 
+def _torch_csr(A):
+    import torch
+    A = sp.csr_matrix(A)
+    return torch.sparse_csr_tensor(torch.as_tensor(A.indptr, dtype=torch.int64), torch.as_tensor(A.indices, dtype=torch.int64), torch.as_tensor(A.data))
+
+
+def test_recognition_where_the_matrix_lives_matches_the_host_pass():
+    """ r4: torch matrices are recognised with torch ops on their own device (no host copy; a moving obstacle changes the matrix every step).
+    The tensor implementation must return what the SciPy pass returns: every boundary mix without a mask, obstacle masks, the shifted
+    operator of diffuse.implicit, the resolution read off the matrix, and the same rejections. (CPU tensors here; tests/test_gpu_api.py runs
+    the plug-in with device-resident matrices.) """
+    sides = [(O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED), (O.OPEN, O.OPEN), (O.CLOSED, O.OPEN), (O.OPEN, O.CLOSED)]
+    for res in ((6, 5), (4, 5, 6)):
+        upper = tuple(float(n) * (0.5 + 0.25 * a) for a, n in enumerate(res))
+        for bc in itertools.product(sides, repeat=len(res)):
+            dom = O.Domain(res, (0.0,) * len(res), upper, bc)
+            A = O.laplace_csr(dom, np.float64)
+            row, col, val = linear._torch_entries(_torch_csr(A))
+            d0, d1 = linear.recognise_laplace_stencil(A, res), linear.recognise_laplace_stencil_torch(row, col, val, res)
+            assert d1['flags'] is None and d1['bc'] == d0['bc'], (bc, d0['bc'], d1['bc'])
+            np.testing.assert_allclose(d1['weights'], d0['weights'], rtol=1e-12)
+            if all(n >= 3 for n in res):
+                assert linear.infer_resolution_torch(row, col, A.shape[0]) == linear.infer_resolution(A) == res
+    dom = O.Domain((7, 6), (0, 0), (7, 6), ((O.CLOSED, O.OPEN), (O.PERIODIC, O.PERIODIC)))
+    active, hard, _ = O.obstacle_masks([O.BoxObstacle((2.0, 1.0), (4.0, 3.0))], dom, np.float64)
+    dense = _dense_operator(dom, hard, active)
+    row, col, val = linear._torch_entries(_torch_csr(dense))
+    d0, d1 = linear.recognise_laplace_stencil(sp.csr_matrix(dense), dom.res), linear.recognise_laplace_stencil_torch(row, col, val, dom.res)
+    assert d1['bc'] == d0['bc'] and np.array_equal(d1['flags'].numpy(), d0['flags'])
+    for mutate in (lambda M: M.__setitem__((3, 20), 0.5), lambda M: M.__setitem__((8, 9), M[8, 9] * 1.5)):
+        bad = sp.csr_matrix(dense).tolil()
+        mutate(bad)
+        with pytest.raises(linear.NotALaplaceStencil):
+            linear.recognise_laplace_stencil_torch(*linear._torch_entries(_torch_csr(bad.tocsr())), dom.res)
+    with pytest.raises(linear.NotALaplaceStencil):
+        linear.recognise_laplace_stencil_torch(*linear._torch_entries(_torch_csr(sp.identity(42, format='csr'))), dom.res)
+    # identity * I + scale * L (diffuse.implicit)
+    dom3 = O.Domain((6, 7, 8), (0, 0, 0), (3, 7, 4), ((O.PERIODIC, O.PERIODIC), (O.CLOSED, O.CLOSED), (O.OPEN, O.OPEN)))
+    S = sp.identity(6 * 7 * 8, format='csr') - 0.3 * O.laplace_csr(dom3, np.float64)
+    d0 = linear.recognise_shifted_laplace(S, dom3.res)
+    d1 = linear.recognise_shifted_laplace_torch(*linear._torch_entries(_torch_csr(S)), dom3.res)
+    assert d1['bc'] == d0['bc'] and d1['scale'] == d0['scale'] and abs(d1['identity'] - d0['identity']) <= 1e-12
+    np.testing.assert_allclose(d1['weights'], d0['weights'], rtol=1e-10)
+
+
 def test_solve_linear_matches_make_incompressible_and_the_oracle(emu_backend):
     rng = np.random.default_rng(3)
     for ext, bc in ((ZERO, ((O.CLOSED, O.CLOSED),) * 2), (PERIODIC, ((O.PERIODIC, O.PERIODIC),) * 2),
