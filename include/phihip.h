@@ -357,6 +357,10 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
 int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable);
 /* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
+/* planes per workgroup the most recent tiled self-advection of this context ran with (3-D; 0 = none yet / 2-D): what the first-call
+ * measurement settled on -- tools/path_workload.py pins it (phihip_set_advect_chunk) in the profiled runs so that no candidate launch shares
+ * the kernel's name */
+int phihip_query_advect_chunk(phihip_ctx* ctx, int32_t* planes);
 /* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
  * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);

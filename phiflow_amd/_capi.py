@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered", "phihip_cg_solve_shifted",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg",
 )
 
 
@@ -224,6 +224,7 @@ class Library:
         d.phihip_set_advect_halo.argtypes = [c_void_p, c_int]
         d.phihip_set_advect_chunk.argtypes = [c_void_p, c_int]
         d.phihip_set_advect_windows_2d.argtypes = [c_void_p, c_int]
+        d.phihip_query_advect_chunk.argtypes = [c_void_p, POINTER(c_int32)]
         d.phihip_set_autotune.argtypes = [c_void_p, c_int]
         d.phihip_set_single_reduction_cg.argtypes = [c_void_p, c_int, ctypes.c_longlong]
         d.phihip_allreduce_residual.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -502,6 +503,12 @@ class Context:
     def set_deferred_x_update(self, enable: bool):
         if hasattr(self.lib.dll, "phihip_set_deferred_x_update"):
             self.lib.check(self.lib.dll.phihip_set_deferred_x_update(self.handle, int(bool(enable))))
+
+    def query_advect_chunk(self) -> int:
+        """ planes per workgroup of the most recent tiled self-advection (0: none yet / 2-D) """
+        out = c_int32(0)
+        self.lib.check(self.lib.dll.phihip_query_advect_chunk(self.handle, ctypes.byref(out)))
+        return int(out.value)
 
     def set_advect_windows_2d(self, enable: bool):
         """ LDS-windowed MacCormack / centred advection passes on 2-D grids as well (default: 3-D only; the gather kernels are faster in 2-D) """

@@ -557,6 +557,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     }
     PHIHIP_TRY(launch(chunk));
     ctx->adv_last_nblk = nblk * v.batch;
+    ctx->adv_last_chunk = DIM == 3 ? chunk : 0;
     hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
                        (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;

@@ -896,6 +896,12 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     return PHIHIP_OK;
 }
 
+int phihip_query_advect_chunk(phihip_ctx* ctx, int32_t* planes) {
+    PHIHIP_REQUIRE(ctx != nullptr && planes != nullptr, "query_advect_chunk: NULL argument");
+    *planes = ctx->adv_last_chunk;
+    return PHIHIP_OK;
+}
+
 int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     ctx->adv_win_2d = enable != 0;

@@ -139,6 +139,7 @@ struct phihip_ctx {
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g;
     int adv_last_nblk = 0;        // workgroup flags of the most recent tiled advection (ws_adv_flags): count
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
+    int adv_last_chunk = 0;       // planes per workgroup the most recent tiled self-advection ran with (phihip_query_advect_chunk)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
     bool adv_win_2d = false;      // advect_win.hip on 2-D grids (slower than the gather kernels there; phihip_set_advect_halo(ctx, 4) switches it on for the parity tests)
     // first-call autotune of the CG marching kernels: the candidates of the plan model are timed once per (grid, family) on the

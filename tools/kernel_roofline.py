@@ -72,8 +72,9 @@ def group_table(d):
         if not names:
             rows.append(dict(label=e["label"], kernel_pattern=e["kernel"], launches=0, note="kernel did not run in this group"))
             continue
-        if short(names[0]).startswith("march_kernel"):
-            # the first-call autotune launches every (tile, chunk) candidate a few times: the plan the solve ran is the variant with the most launches
+        if short(names[0]).startswith("march_kernel") and not man.get("pinned_plans"):
+            # (runs without pinned plans only) the first-call autotune launches every (tile, chunk) candidate a few times: the plan the solve ran
+            # is the variant with the most launches
             names = [max(names, key=lambda n: len(dur[n]))]
         t = [x for n in names for x in dur[n]]
         t_sorted = sorted(t)
@@ -92,8 +93,26 @@ def group_table(d):
             if unit_f and unit_w:
                 row["pmc_bytes_calibrated"] = int(sum(f) / len(f) * unit_f + sum(w) / len(w) * unit_w)
         rows.append(row)
-    return dict(group=man["group"], size=man["size"], build_id=man.get("build_id"), fetch_unit_calibrated_B=unit_f, write_unit_calibrated_B=unit_w,
-                kernels=rows)
+    out = dict(group=man["group"], size=man["size"], build_id=man.get("build_id"), source_matches_tree=man.get("source_matches_tree"),
+               fetch_unit_calibrated_B=unit_f, write_unit_calibrated_B=unit_w)
+    pinned = man.get("pinned_plans")
+    if pinned:
+        # consistency of the evidence: the traced CG iteration (MATVEC + the mean of the two UPDATE forms, kernel durations only) against the wall
+        # time of an UNTRACED iteration of the same process image and launch plans (which additionally contains two kernel boundaries)
+        def avg_of(mode):
+            r = [x for x in rows if x.get("kernels") and re.search(r"march_kernel<\w+, \d, \d, \d+, %d," % mode, x["kernels"][0])]
+            return r[0]["avg_us"] if r else None
+        mv, ur, ux = avg_of(2), avg_of(6), avg_of(7)
+        out["pinned_plans"] = pinned.get("plans")
+        if mv and ur and ux:
+            traced = mv + 0.5 * (ur + ux)
+            wall = pinned["untraced_ms_per_cg_iteration"] * 1e3
+            out["cg_iteration_check"] = dict(traced_kernel_sum_us=round(traced, 2), untraced_wall_us=round(wall, 2), ratio=round(traced / wall, 4),
+                                             within_3_percent=abs(traced / wall - 1.0) <= 0.03,
+                                             note="traced = avg MATVEC + (avg UPDATE_R + avg UPDATE_X2) / 2 under rocprofv3 --kernel-trace; wall = 100 untraced "
+                                                  "iterations (hipEvents) / 100 incl. the two kernel boundaries of an iteration; same build, same pinned plans")
+    out["kernels"] = rows
+    return out
 
 
 def main():

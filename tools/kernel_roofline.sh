@@ -10,9 +10,11 @@ export TMPDIR=/tmp
 mkdir -p "$OUT"
 for G in "${GROUPS_[@]}"; do
   D="$OUT/$G"; rm -rf "$D"; mkdir -p "$D"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o k -- python "$REPO/tools/path_workload.py" --group $G --manifest "$D/manifest.json" > "$D/stats.log" 2>&1); echo "$G stats rc=$?"
+  # untraced: first-call autotune + wall time of one CG iteration; the traced passes pin these plans (no candidate shares a kernel name)
+  (cd /tmp && timeout 600 python "$REPO/tools/path_workload.py" --group $G --write-plans "$D/plans.json" > "$D/plans.log" 2>&1); echo "$G plans rc=$?"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o k -- python "$REPO/tools/path_workload.py" --group $G --plans "$D/plans.json" --manifest "$D/manifest.json" > "$D/stats.log" 2>&1); echo "$G stats rc=$?"
   for CTR in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$D/$CTR" -o pmc -- python "$REPO/tools/path_workload.py" --group $G --reps 2 > "$D/$CTR.log" 2>&1); echo "$G $CTR rc=$?"
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $CTR --output-format csv -d "$D/$CTR" -o pmc -- python "$REPO/tools/path_workload.py" --group $G --plans "$D/plans.json" --reps 2 > "$D/$CTR.log" 2>&1); echo "$G $CTR rc=$?"
   done
 done
 python "$REPO/tools/kernel_roofline.py" $(for G in "${GROUPS_[@]}"; do echo "$OUT/$G"; done) > "$OUT/kernel_roofline.json"; echo "table rc=$?"

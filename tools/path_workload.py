@@ -83,10 +83,13 @@ def group_f32_256(ctx, dev, n, reps):
         ctx.set_advect_halo(0)
         ctx.advect_staggered(grid, P(vel), P(vel), P(out), dt)
         ctx.set_advect_halo(1)
-        # f2: centred scalar (smoke), MacCormack (centred / staggered), buoyancy resample
-        ctx.advect_centered(grid, s.data_ptr(), s_bc, None, P(vel), s2.data_ptr(), dt)
-        ctx.mac_cormack_centered(grid, s.data_ptr(), s_bc, None, P(vel), s2.data_ptr(), dt, 1.0)
-        ctx.mac_cormack_staggered(grid, P(vel), P(vel), P(tmp), dt, 1.0)
+        # f2: centred scalar (smoke), MacCormack (centred / staggered): LDS windows (advect_win.hip), then the gather kernels (halo 0)
+        for halo in (1, 0):
+            ctx.set_advect_halo(halo)
+            ctx.advect_centered(grid, s.data_ptr(), s_bc, None, P(vel), s2.data_ptr(), dt)
+            ctx.mac_cormack_centered(grid, s.data_ptr(), s_bc, None, P(vel), s2.data_ptr(), dt, 1.0)
+            ctx.mac_cormack_staggered(grid, P(vel), P(vel), P(tmp), dt, 1.0)
+        ctx.set_advect_halo(1)
         ctx.centered_to_staggered(grid, s.data_ptr(), s_bc, None, (0.0, 0.0, 0.1), True, P(tmp))
         # f1: explicit diffusion, staggered and centred
         ctx.diffuse_explicit(grid, P(vel), P(tmp), 0.1 * dt)
@@ -98,18 +101,26 @@ def group_f32_256(ctx, dev, n, reps):
     sync(dev)
     note(r"advect_self_tile_kernel<float, 3", "a1 semi-Lagrangian self-advection, LDS tiles (benchmark step)", 6 * w * N, 6, "read 3 + write 3 components")
     note(r"advect_staggered_kernel<float, 3, \d, 0>", "a1 gather kernel, one component per launch", 4 * w * N, 4, "read 3 components (taps) + write 1")
-    note(r"advect_centered_kernel<float, 3, 0>", "f2 semi-Lagrangian advection of a centred scalar", 5 * w * N, 5, "read scalar + 3 components, write scalar")
-    note(r"advect_centered_kernel<float, 3, 1>", "f2 MacCormack correction pass, centred scalar", 6 * w * N, 6, "read scalar, forward result, 3 components; write 1")
-    note(r"advect_staggered_kernel<float, 3, \d, 1>", "f2 MacCormack correction pass, one staggered component", 6 * w * N, 6, "read field, forward result, 3 components; write 1")
-    note(r"centered_to_staggered_kernel<float>", "f2 buoyancy: resample(s * vector, to=v), one component", 3 * w * N, 3, "read scalar, read + write the component")
-    note(r"diffuse_kernel<float, false>", "f1 diffuse.explicit, one component / centred scalar per launch", 2 * w * N, 2, "read + write one array")
-    note(r"divergence_kernel<float, 3>", "a2 divergence + balance sums", 4 * w * N, 4, "read 3 components, write div")
+    note(r"advect_win_kernel<float, 1, 3", "f2 semi-Lagrangian advection of a centred scalar, LDS windows (r4)", 5 * w * N, 5, "read scalar + 3 components, write scalar")
+    note(r"advect_win_kernel<float, 2, 3", "f2 MacCormack correction pass, centred scalar, LDS windows (r4)", 6 * w * N, 6, "read scalar, forward result, 3 components; write 1")
+    note(r"advect_win_kernel<float, 0, 3", "f2 MacCormack correction pass of the staggered velocity, ALL components, LDS windows (r4)", 9 * w * N, 9,
+         "read 3 velocity + 3 forward-pass components; write 3")
+    note(r"advect_win_fixup_kernel<float", "fix-up launch behind every LDS-window pass (workgroups whose lookups left the window; none here)", 0, 0, "reads one flag per workgroup")
+    note(r"advect_self_fixup_kernel<float", "fix-up launch behind the tiled self-advection (none flagged here)", 0, 0, "reads one flag per workgroup")
+    note(r"advect_centered_kernel<float, 3, 0>", "f2 semi-Lagrangian advection of a centred scalar, gather kernel (halo 0)", 5 * w * N, 5, "read scalar + 3 components, write scalar")
+    note(r"advect_centered_kernel<float, 3, 1>", "f2 MacCormack correction pass, centred scalar, gather kernel (halo 0)", 6 * w * N, 6, "read scalar, forward result, 3 components; write 1")
+    note(r"advect_staggered_kernel<float, 3, \d, 1>", "f2 MacCormack correction pass, one staggered component, gather kernel (halo 0)", 6 * w * N, 6, "read field, forward result, 3 components; write 1")
+    note(r"centered_to_staggered_vec_kernel<float, 3", "f2 buoyancy: v += resample(s * (0, 0, 0.1)), one launch (r4: 16-byte vectors; one component has a non-zero factor)", 3 * w * N, 3,
+         "read scalar, read + write the component")
+    note(r"centered_to_staggered_kernel<float>", "f2 buoyancy resample, scalar kernel (rows that are not whole vectors)", 3 * w * N, 3, "read scalar, read + write the component")
+    note(r"divergence_vec_kernel<float, 3", "a2 divergence + balance sums (r4: 16-byte vectors)", 4 * w * N, 4, "read 3 components, write div")
+    note(r"divergence_kernel<float, 3>", "a2 divergence + balance sums, scalar kernel", 4 * w * N, 4, "read 3 components, write div")
     note(r"march_kernel<float, 4, \d, \d+, 8, false", "a3+a5 initial residual with the balance shift folded in", 4 * w * N, 4, "read x, y; write y, r")
     note(r"march_kernel<float, 4, \d, \d+, 2, false", "a5 CG MATVEC d = r + beta d, d.Ad", 3 * w * N, 3, "read r, d; write d")
     note(r"march_kernel<float, 4, \d, \d+, 6, false", "a5 CG UPDATE_R r -= alpha A d", 3 * w * N, 3, "read r, d; write r")
     note(r"march_kernel<float, 4, \d, \d+, 7, false", "a5 CG UPDATE_X2 x += two steps, r -= alpha A d", 5 * w * N, 5, "read x, r, d; write x, r")
-    note(r"march_kernel<float, 4, \d, \d+, 0, false", "a4 masked_laplace apply", 2 * w * N, 2, "read p, write A p")
-    note(r"grad_subtract_vec_kernel<float, 3>", "a6 gradient subtraction, all components", 7 * w * N, 7, "read p, read + write 3 components")
+    note(r"march_kernel<float, 4, \d, \d+, 0, false", "a4 masked_laplace apply AND (r4) f1 diffuse.explicit: one MODE_APPLY pass per component / scalar with the operator I + k dt L", 2 * w * N, 2, "read p, write A p")
+    note(r"grad_subtract_vec_kernel<float, 3", "a6 gradient subtraction, all components", 7 * w * N, 7, "read p, read + write 3 components")
     note(r"mask_faces_kernel<float", "f5 projection adjoint: hard_bcs mask of the face gradients", 2 * w * N, 2, "read + write one component")
 
     # f3: obstacles on the device
@@ -213,18 +224,72 @@ def group_f64_384(ctx, dev, n, reps):
     sync(dev)
     Nf = sum(int(np.prod(s)) for s in shapes)
     note(r"advect_self_tile_kernel<double, 3", "a1 self-advection, closed box, LDS tiles", 2 * w * Nf, 6, "read 3 + write 3 components")
-    note(r"divergence_kernel<double, 3>", "a2 divergence * active + balance sums", w * (Nf + N) + N, 4, "read 3 components + flags, write div")
+    note(r"divergence_vec_kernel<double, 3", "a2 divergence * active + balance sums (r4: vector kernel)", w * (Nf + N) + N, 4, "read 3 components + flags, write div")
+    note(r"divergence_kernel<double, 3>", "a2 divergence * active + balance sums, scalar kernel", w * (Nf + N) + N, 4, "read 3 components + flags, write div")
     note(r"march_kernel<double, 2, \d, \d+, 8, true", "a3+a5 initial residual with balance shift, flags", 4 * w * N + N, 4, "read x, y, flags; write y, r")
     note(r"march_kernel<double, 2, \d, \d+, 2, true", "a5 CG MATVEC with cell flags", 3 * w * N + N, 3, "read r, d, flags; write d")
     note(r"march_kernel<double, 2, \d, \d+, 6, true", "a5 CG UPDATE_R with cell flags", 3 * w * N + N, 3, "read r, d, flags; write r")
     note(r"march_kernel<double, 2, \d, \d+, 7, true", "a5 CG UPDATE_X2 with cell flags", 5 * w * N + N, 5, "read x, r, d, flags; write x, r")
-    note(r"grad_subtract_vec_kernel<double, 3>", "a6 gradient subtraction with hard_bcs flags, all components", w * (N + 2 * Nf) + N, 7, "read p, flags; read + write 3 components")
+    note(r"grad_subtract_vec_kernel<double, 3", "a6 gradient subtraction with hard_bcs flags, all components", w * (N + 2 * Nf) + N, 7, "read p, flags; read + write 3 components")
     note(r"grad_subtract_kernel<double, 3>", "a6 scalar gradient kernel (only when the vector path is not taken)", w * (N + 2 * Nf // 3) + N, 3, "read p, flags; read + write 1 component")
     return grid
 
 
+def tune_and_time(ctx, dev, group, n):
+    """ `--write-plans` (run WITHOUT a profiler): the first-call autotune runs, its winners are read back (phihip_query_plan) together with the
+    chunk the tiled advection settled on, and the untraced wall time of one CG iteration is measured -- the traced runs pin exactly these
+    plans (`--plans`), so that no autotune candidate shares a kernel name with the kernel that is being profiled, and
+    tools/kernel_roofline.py checks the traced per-iteration sum against this wall time. """
+    L = 2 * math.pi
+    if group == "f64_384":
+        grid = C.make_grid(3, C.PHIHIP_F64, 1, (n, n, n), (0, 0, 0), (1, 1, 1), ((1, 1),) * 3)
+        c = (np.arange(n) + 0.5) / n
+        inside = np.abs(c - 0.5) <= 0.125
+        acc = torch.from_numpy((~(inside[:, None, None] & inside[None, :, None] & inside[None, None, :])).astype(np.uint8)).to(dev)
+        flags = torch.empty(n, n, n, dtype=torch.uint8, device=dev)
+        ctx.build_cellflags(grid, acc.data_ptr(), 0, 1, flags.data_ptr())
+        dtype, fptr = torch.float64, flags.data_ptr()
+    else:
+        grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
+        dtype, fptr, flags = torch.float32, 0, None
+    rhs = torch.randn(1, n, n, n, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=dtype)
+    if flags is not None:
+        rhs *= (flags & 64 != 0)
+    rhs -= rhs.mean()
+    x = torch.zeros_like(rhs)
+    iters = 100
+    ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 10, 0, 0, 0), want_info=False)       # tunes
+    sync(dev)
+    x.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 0, 0, 0), want_info=False)
+    e1.record()
+    sync(dev)
+    plans = {str(f): ctx.query_plan(grid, flags is not None, f) for f in (0, 1, 2, 3)}
+    out = {"group": group, "size": n, "plans": plans, "untraced_ms_per_cg_iteration": e0.elapsed_time(e1) / iters, "iterations_timed": iters}
+    if group == "f32_256" and hasattr(ctx, "query_advect_chunk"):
+        shapes = [ctx.component_shape(grid, d) for d in range(3)]
+        v = [torch.randn(1, *sh, device=dev) * 0.01 for sh in shapes]
+        o = [torch.empty_like(t) for t in v]
+        ctx.advect_staggered(grid, [t.data_ptr() for t in v], [t.data_ptr() for t in v], [t.data_ptr() for t in o], 0.5 * L / n)
+        sync(dev)
+        out["advect_chunk"] = ctx.query_advect_chunk()
+    return out
+
+
+def pin_plans(ctx, plans):
+    ctx.set_autotune(False)
+    for fam, q in plans.get("plans", {}).items():
+        ctx.set_tuning_kernel(int(fam), int(q["rows"]), int(q["tpr"]), int(q["chunk"]))
+    if plans.get("advect_chunk"):
+        ctx.set_advect_chunk(int(plans["advect_chunk"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--write-plans", default="", help="tune, time one CG iteration untraced and write the launch plans here (run without a profiler)")
+    ap.add_argument("--plans", default="", help="pin the launch plans of this file (written by --write-plans) and switch the autotune off")
     ap.add_argument("--group", default="f32_256", choices=["f32_256", "f32_512", "f64_384"])
     ap.add_argument("--size", type=int, default=0, help="cells per axis (default: the group's size)")
     ap.add_argument("--reps", type=int, default=4)
@@ -235,12 +300,24 @@ def main():
     dev = torch.device(args.device)
     lib = C.Library(args.lib) if args.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
-    calibration_copy(dev)
     n = args.size or {"f32_256": 256, "f32_512": 512, "f64_384": 384}[args.group]
+    if args.write_plans:
+        rec = tune_and_time(ctx, dev, args.group, n)
+        rec["build_id"] = lib.build_id()
+        with open(args.write_plans, "w") as f:
+            json.dump(rec, f, indent=1)
+        return
+    plans = None
+    if args.plans:
+        with open(args.plans) as f:
+            plans = json.load(f)
+        assert plans["build_id"] == lib.build_id(), (plans["build_id"], lib.build_id())
+        pin_plans(ctx, plans)
+    calibration_copy(dev)
     {"f32_256": group_f32_256, "f32_512": group_f32_512, "f64_384": group_f64_384}[args.group](ctx, dev, n, args.reps)
     if args.manifest:
         with open(args.manifest, "w") as f:
-            json.dump(dict(group=args.group, size=n, build_id=lib.build_id(), kernels=MANIFEST), f, indent=1)
+            json.dump(dict(group=args.group, size=n, build_id=lib.build_id(), source_matches_tree=lib.built_from_tree(), pinned_plans=plans, kernels=MANIFEST), f, indent=1)
 
 
 if __name__ == "__main__":

@@ -3,6 +3,9 @@
 CG throughput versus problem size (does the 256 MiB Infinity Cache carry the working set?): times the CG iteration at a range
 of cubic sizes with the default tile plan and prints one JSON line per size.
     python tools/size_scan.py --sizes 128,160,192,224,256,288,320,384,448,512
+An entry may be a box `n0xn1xn2` (x slow ... z fast): the ROW-PITCH experiment of DESIGN.md §8 -- does the rate of the 288^3 ... 448^3 sizes
+change when only the row length (the phase of the rows against the HBM channel interleave) or only the number of rows / planes changes?
+    python tools/size_scan.py --sizes 288,288x288x320,288x320x288,320x288x288,320
 """
 import argparse
 import json
@@ -31,19 +34,21 @@ def main():
     L = 2 * math.pi
     tdt = torch.float64 if args.dtype == "f64" else torch.float32
     esize = 8 if args.dtype == "f64" else 4
-    for n in [int(v) for v in args.sizes.split(",")]:
-        grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((args.bc, args.bc),) * 3)
-        rhs = torch.randn(1, n, n, n, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=tdt)   # on the device: 1024^3 = 4 GiB
+    for entry in args.sizes.split(","):
+        shape = tuple(int(v) for v in entry.split("x")) if "x" in entry else (int(entry),) * 3
+        n = entry if "x" in entry else int(entry)
+        grid = C.make_grid(3, C.PHIHIP_F64 if args.dtype == "f64" else C.PHIHIP_F32, 1, shape, (0, 0, 0), tuple(L * k / shape[0] for k in shape), ((args.bc, args.bc),) * 3)
+        rhs = torch.randn(1, *shape, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=tdt)   # on the device: 1024^3 = 4 GiB
         rhs -= rhs.mean()
         x = torch.zeros_like(rhs)
         fl = 0
         if args.flags:
-            acc = torch.ones(n, n, n, dtype=torch.uint8, device=dev)
-            flags = torch.empty(n, n, n, dtype=torch.uint8, device=dev)
+            acc = torch.ones(*shape, dtype=torch.uint8, device=dev)
+            flags = torch.empty(*shape, dtype=torch.uint8, device=dev)
             ctx.build_cellflags(grid, acc.data_ptr(), 0, 1, flags.data_ptr())
             fl = flags.data_ptr()
         solve = C.Solve(0.0, 0.0, args.iters, 0, 0, 0)
-        rec = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "flags": args.flags, "working_set_MB": round(4 * esize * n ** 3 / 2 ** 20, 1)}
+        rec = {"lib": os.path.basename(args.lib) if args.lib else "default", "size": n, "dtype": args.dtype, "bc": args.bc, "flags": args.flags, "working_set_MB": round(4 * esize * math.prod(shape) / 2 ** 20, 1)}
         for label, tune in (("model", False), ("tuned", True)):          # analytic plan, then the first-call autotune (cg.hip)
             if not hasattr(ctx.lib.dll, "phihip_set_autotune"):
                 if tune:
@@ -62,7 +67,7 @@ def main():
             per = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}
             mv, x2, ur = per["cg_matvec_dot"], per["cg_update"], per.get("cg_update_r", 0.0)
             it = mv + 0.5 * (x2 + (ur or x2))
-            cells = n ** 3
+            cells = math.prod(shape)
             plans = {f: ctx.query_plan(grid, bool(args.flags), f) for f in (1, 2, 3)}
             rec[label] = {"plan_mv": list(plans[1].values()), "plan_x2": list(plans[2].values()), "plan_ur": list(plans[3].values()),
                           "us_matvec": round(mv * 1e3, 2), "us_update_x2": round(x2 * 1e3, 2), "us_update_r": round(ur * 1e3, 2), "us_iteration": round(it * 1e3, 2),
