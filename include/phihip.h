@@ -361,8 +361,9 @@ int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
  * measurement settled on -- tools/path_workload.py pins it (phihip_set_advect_chunk) in the profiled runs so that no candidate launch shares
  * the kernel's name */
 int phihip_query_advect_chunk(phihip_ctx* ctx, int32_t* planes);
-/* Diagnostics of the most recent tiled self-advection on this context (synchronises `stream`): out[0] = workgroups that met a lookup
- * outside their LDS window and were redone by the gather path, out[1] = workgroups launched. {0, 0} if none has run. */
+/* Diagnostics of the most recent LDS-staged advection launch on this context (synchronises `stream`): out[0] = (tile, plane) units that met
+ * a lookup outside their LDS window and were redone by the gather path, out[1] = units of the launch (tiles x planes x batch entries).
+ * {0, 0} if none has run. (Until r3 the unit was a workgroup's whole chunk of planes.) */
 int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
 /* Solve('CG') on grids whose iteration is bound by the two kernel boundaries rather than by memory traffic (batched 2-D, small 3-D) runs the
  * SINGLE-REDUCTION form of CG (Chronopoulos & Gear): one launch per iteration that carries w = A r and s = A p as vectors -- the same

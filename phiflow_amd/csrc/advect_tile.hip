@@ -127,7 +127,7 @@ __device__ __forceinline__ double clamp_real(double x, double lo, double hi) { r
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
 __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T) == 4 ? 4 : 2) : 2) void advect_self_tile_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1,
                                                                   T* __restrict__ o2, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
-                                                                  int* __restrict__ flags, T* __restrict__ dump) {
+                                                                  FixList fix, T* __restrict__ dump) {
     using C = AdvTile<T, DIM, H, T1>;
     constexpr int A0 = 3 - DIM;
     constexpr int T2 = C::T2, TY = C::TY, S = C::S, P1 = C::P1, P2 = C::P2, PLANE = C::PLANE, NC = C::NC, NP = C::NP, KP = C::KP;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // an immediate LDS offset from three per-position addresses (27 scalar offsets per plane otherwise -- they spilled)
     constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
     __shared__ T lds[NC * NP * PLANE];
-    __shared__ int slow_sh;
+    __shared__ int slow_sh[2];          // "a lookup of plane p left the window", by the parity of p (read by thread 0 after the plane's barrier)
 
     const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2;
     const int b = blockIdx.y;
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     const int pb = DIM == 3 ? c0 * chunk : 0;
     const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
     T* const outp[3] = {o0, o1, o2};
-    if (tid == 0) slow_sh = 0;
-    bool slow_any = false;
+    if (tid < 2) slow_sh[tid] = 0;      // (a barrier of the ring warm-up / of the 2-D fill lies between this and the first plane of samples)
     // per-thread output bookkeeping: element offset of position s = 0 in plane 0 per component, plane strides, and one bit per
     // (position, component): the sample exists in that component's array
     unsigned obase[3] = {0, 0, 0};      // in-plane element offset (unsigned 32-bit + uniform 64-bit base: address arithmetic stays scalar)
@@ -306,6 +305,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // sample's own LDS position, blend as nested lerps along a2, a1, a0.
     auto compute_plane = [&](int p) {
         const int so_m = slot_of(p - 1) * PLANE, so_0 = slot_of(p) * PLANE, so_p = slot_of(p + 1) * PLANE;   // uniform element offsets
+        bool slow_any = false;
 #pragma unroll 1
         for (int s = 0; s < S; ++s) {
             const int center = (ty + s * TY + H) * P2 + tx + H;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                     di[a] = (int)relc;
                 }
                 const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0];
-                slow_any = slow_any || (valid && slow);          // -> the whole workgroup is redone by advect_self_fixup_kernel
+                slow_any = slow_any || (valid && slow);          // -> this plane of the tile is redone by advect_self_fixup_kernel
                 int base0 = (ca - A0) * NP * PLANE + center + __mul24(di[1], P2) + di[2], base1 = base0;
                 if (DIM == 3) {
                     if (H == 1) {                                  // lower tap plane p-1 or p, upper p or p+1
@@ -376,6 +376,14 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                 sched_fence();     // one sample's LDS reads in flight at a time (fence per position or none: +10 % time, profiles/r02_ab_advect*.jsonl)
             }
         }
+        if (slow_any) slow_sh[p & 1] = 1;
+    };
+    // after the barrier that ends plane p's half-step: one entry in the fix-up work list if any sample of the plane left the window
+    auto report_plane = [&](int p) {
+        if (tid == 0 && slow_sh[p & 1]) {
+            slow_sh[p & 1] = 0;
+            fix_append(fix, b * nblk + (int)blockIdx.x, p);
+        }
     };
 
     // Pipeline, two planes per trip so that the two register sets keep static names. In half-step p: plane p+H+2 is requested, plane p
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
             store_plane(slot_of(ks), Rst, tail_st);
         }
         __syncthreads();
+        if (MODE_ == 2 || (MODE_ == 0 && p >= pb && p < pe)) report_plane(p);
     };
     const int p_first = k_lo - H - 2;     // the half-step that requests the first staged plane
     if (DIM == 3) {
@@ -419,31 +428,26 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
             half_step(p + 1, std::integral_constant<int, 0>{}, RB, tailB, RA, tailA);
         }
     }
-    if (slow_any) slow_sh = 1;
-    __syncthreads();
-    if (tid == 0) flags[(long long)b * nblk + blockIdx.x] = slow_sh;
 }
 
-// Redo of the workgroups that met lookups outside their LDS window (flag set by advect_self_tile_kernel): every sample of the same
-// (tile, chunk) with the gather code of the per-component kernels (advect.hip), reading the untouched input velocity.
+// Redo of the (tile, plane) units that met lookups outside their LDS window (work list filled by advect_self_tile_kernel): every sample of
+// the plane with the gather code of the per-component kernels (advect.hip), reading the untouched input velocity. Fixed grid; the
+// workgroups stride over the list.
 template <typename T, int DIM, int T1>
 __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
-                                                                   T dt, int chunk, int tiles1, int tiles2, int nblk, int nmax0,
-                                                                   const int* __restrict__ flags) {
+                                                                   T dt, int tiles1, int tiles2, int nblk, FixList fix) {
     using C = AdvTile<T, DIM, 1, T1>;
     constexpr int A0 = 3 - DIM;
-    const int b = blockIdx.y;
-    if (flags[(long long)b * nblk + blockIdx.x] == 0) return;
     const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
-    int bid = blockIdx.x;
-    bid = xcd_order(bid, nblk);
-    const int t2 = bid % tiles2;
-    const int t1 = (bid / tiles2) % tiles1;
-    const int c0 = bid / (tiles2 * tiles1);
-    const int pb = DIM == 3 ? c0 * chunk : 0;
-    const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
     T* const outp[3] = {o0, o1, o2};
-    for (int p = pb; p < pe; ++p)
+    const int count = fix_count(fix);
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const FixItem e = fix.items[item];
+        const int b = e.wg / nblk;
+        const int bid = xcd_order(e.wg - b * nblk, nblk);
+        const int t2 = bid % tiles2;
+        const int t1 = (bid / tiles2) % tiles1;
+        const int p = e.plane;
         for (int s = 0; s < C::S; ++s) {
             const int j1 = t1 * T1 + ty + s * C::TY, j2 = t2 * C::T2 + tx;
 #pragma unroll
@@ -468,6 +472,9 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
                 outp[ca][(long long)b * g.ccells[ca] + f] = gather_multilinear<T, DIM>(vel.p[ca] + (long long)b * g.ccells[ca], ax, fr);
             }
         }
+    }
+    __syncthreads();          // every thread of this workgroup has read the count (the last workgroup's thread 0 clears it)
+    if (tid == 0) fix_done(fix);
 }
 
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
@@ -505,16 +512,18 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     }
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     int nblk = 0;
-    int* flags = nullptr;
+    FixList fix;
+    void* dump = nullptr;
+    PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump));
+    // the tile kernel + its fix-up launch (fixed grid striding over the work list: it also resets the list, so the two always go together)
     auto launch = [&](int ch) -> int {
         chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
         nblk = tiles1 * tiles2 * chunks0;
-        const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
-        PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
-        flags = (int*)ctx->ws_adv_flags.ptr;
-        T* dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);   // where samples outside a component's array are stored
         hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
-                           (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], flags, dump);
+                           (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], fix, (T*)dump);
+        const int fgrid = fix.cap < kFixupBlocks ? fix.cap : kFixupBlocks;
+        hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(fgrid), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2], (T)dt,
+                           tiles1, tiles2, nblk, fix);
         return PHIHIP_OK;
     };
     if (DIM == 3 && ctx->adv_chunk > 0) {
@@ -556,10 +565,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
         }
     }
     PHIHIP_TRY(launch(chunk));
-    ctx->adv_last_nblk = nblk * v.batch;
     ctx->adv_last_chunk = DIM == 3 ? chunk : 0;
-    hipLaunchKernelGGL((advect_self_fixup_kernel<T, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, vg, vv, (T*)out[0], (T*)out[1], (T*)out[2],
-                       (T)dt, chunk, tiles1, tiles2, nblk, nmax[0], (const int*)flags);
     return PHIHIP_OK;
 }
 

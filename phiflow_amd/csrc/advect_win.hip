@@ -103,7 +103,7 @@ struct WinParams {
     T shift[3];              // dt / dx: displacement in index units per unit velocity
     T ch;                    // 0.5 * correction strength (MacCormack kinds)
     int chunk, tiles1, tiles2, nblk, nmax0;
-    int* flags;
+    FixList fix;             // (workgroup, plane) units whose lookups left a window: redone by the fix-up launch (advect_common.hpp)
     T* dump;
 };
 
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
     constexpr int NW = C::NW, T2 = C::T2, TY = C::TY, S = C::S, KP = C::KP;
     constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
     PHIHIP_DYNAMIC_LDS(T, lds);
-    __shared__ int slow_sh;
+    __shared__ int slow_sh[2];          // "a lookup of plane p left its window", by the parity of p (read by thread 0 after the plane's barrier)
 
     const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2;
     const int b = blockIdx.y;
@@ -155,8 +155,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
     const int lo1 = t1 * T1, lo2 = t2 * T2;
     const int pb = DIM == 3 ? c0 * P.chunk : 0;
     const int pe = DIM == 3 ? min(pb + P.chunk, P.nmax0) : 1;
-    if (tid == 0) slow_sh = 0;
-    bool slow_any = false;
+    if (tid < 2) slow_sh[tid] = 0;      // (barriers of the ring warm-up / of the 2-D fill lie between this and the first plane of samples)
 
     // does this workgroup's window reach beyond a constant side? (uniform: interior tiles and boxes without one skip every select)
     bool has_const = false;
@@ -342,6 +341,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             if (lo1 + ty + k * TY < P.on[c][1] && lo2 + tx < P.on[c][2]) vbits |= 1u << (k * 3 + c);
     }
     auto compute_plane = [&](int p) {
+        bool slow_any = false;
         // element offset of plane p + d of window w (uniform): pbase[w][d + H0MAX]
         int pbase[NW][2 * C::H0MAX + 1];
 #pragma unroll
@@ -503,6 +503,14 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                 *(valid ? slot : P.dump) = val;
             }
         }
+        if (slow_any) slow_sh[p & 1] = 1;
+    };
+    // after the barrier that ends plane p's half-step: one entry in the fix-up work list if any sample of the plane left a window
+    auto report_plane = [&](int p) {
+        if (tid == 0 && slow_sh[p & 1]) {
+            slow_sh[p & 1] = 0;
+            fix_append(P.fix, b * P.nblk + (int)blockIdx.x, p);
+        }
     };
 
     // ---- pipeline: two planes per trip so that the two register sets keep static names ------------------------------------------
@@ -514,6 +522,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
         if (CONSTS && has_const) patch_planes(p, Rst, tail_st);
         store_planes(p, Rst, tail_st);
         __syncthreads();
+        if (compute) report_plane(p);
     };
     if (DIM == 3) {
         // window w's first staged plane pb - h0 is requested in half-step pb - 2 h0 - 2: 2 H0MAX + 2 warm-up half-steps fill the rings
@@ -534,30 +543,28 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
         store_planes(-1, RA, tailA);
         __syncthreads();
         compute_plane(0);
+        __syncthreads();
+        report_plane(0);
     }
-    if (slow_any) slow_sh = 1;
-    __syncthreads();
-    if (tid == 0) P.flags[(long long)b * P.nblk + blockIdx.x] = slow_sh;
 }
 
 // ---- fix-up: the flagged workgroups' samples with the gather code of advect.hip ------------------------------------------------------
 template <typename T, int KIND, int DIM, int T1>
 __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield, CComp3a<T> vel,
                                                                   CComp3a<T> fwd3, const T* __restrict__ fwd1, T* o0, T* o1, T* o2, T dt, T ch,
-                                                                  int chunk, int tiles1, int tiles2, int nblk, int nmax0, const int* __restrict__ flags) {
+                                                                  int tiles1, int tiles2, int nblk, FixList fix) {
     using C = WinTile<T, KIND, DIM, T1>;
     constexpr int A0 = 3 - DIM;
-    const int b = blockIdx.y;
-    if (flags[(long long)b * nblk + blockIdx.x] == 0) return;
     const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
-    const int bid = xcd_order(blockIdx.x, nblk);
-    const int t2 = bid % tiles2;
-    const int t1 = (bid / tiles2) % tiles1;
-    const int c0 = bid / (tiles2 * tiles1);
-    const int pb = DIM == 3 ? c0 * chunk : 0;
-    const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
     T* const outp[3] = {o0, o1, o2};
-    for (int p = pb; p < pe; ++p)
+    const int count = fix_count(fix);
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const FixItem e = fix.items[item];
+        const int b = e.wg / nblk;
+        const int bid = xcd_order(e.wg - b * nblk, nblk);
+        const int t2 = bid % tiles2;
+        const int t1 = (bid / tiles2) % tiles1;
+        const int p = e.plane;
         for (int s = 0; s < C::S; ++s) {
             const int j1 = t1 * T1 + ty + s * C::TY, j2 = t2 * C::T2 + tx;
             const int idx[3] = {p, j1, j2};
@@ -629,6 +636,9 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                 }
             }
         }
+    }
+    __syncthreads();          // every thread of this workgroup has read the count (the last workgroup's thread 0 clears it)
+    if (tid == 0) fix_done(fix);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------------
@@ -742,19 +752,17 @@ static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g,
     }
     const int chunks0 = DIM == 3 ? ceil_div(nmax[0], chunk) : 1;
     const int nblk = tiles1 * tiles2 * chunks0;
-    const size_t flag_bytes = ((size_t)nblk * v.batch * sizeof(int) + 63) / 64 * 64;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, flag_bytes + 64));
+    void* dump = nullptr;
+    PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &P.fix, &dump));
     P.chunk = chunk; P.tiles1 = tiles1; P.tiles2 = tiles2; P.nblk = nblk; P.nmax0 = nmax[0];
-    P.flags = (int*)ctx->ws_adv_flags.ptr;
-    P.dump = (T*)((char*)ctx->ws_adv_flags.ptr + flag_bytes);
+    P.dump = (T*)dump;
     hipLaunchKernelGGL(kernel, dim3(nblk, v.batch), dim3(kBlock), C::BYTES, s, P);
-    ctx->adv_last_nblk = nblk * v.batch;
     CComp3a<T> ff{{(const T*)call.field[0], (const T*)call.field[1], (const T*)call.field[2]}};
     CComp3a<T> vv{{(const T*)call.vel[0], (const T*)call.vel[1], (const T*)call.vel[2]}};
     CComp3a<T> ww{{(const T*)call.fwd[0], (const T*)call.fwd[1], (const T*)call.fwd[2]}};
-    hipLaunchKernelGGL((advect_win_fixup_kernel<T, KIND, DIM, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, sb, ff, (const T*)call.sfield, vv, ww,
-                       (const T*)call.fwd[0], (T*)call.out[0], (T*)call.out[1], (T*)call.out[2], (T)call.dt, (T)call.ch, chunk, tiles1, tiles2, nblk,
-                       nmax[0], (const int*)P.flags);
+    const int fgrid = P.fix.cap < kFixupBlocks ? P.fix.cap : kFixupBlocks;
+    hipLaunchKernelGGL((advect_win_fixup_kernel<T, KIND, DIM, T1>), dim3(fgrid), dim3(kBlock), 0, s, g, sb, ff, (const T*)call.sfield, vv, ww,
+                       (const T*)call.fwd[0], (T*)call.out[0], (T*)call.out[1], (T*)call.out[2], (T)call.dt, (T)call.ch, tiles1, tiles2, nblk, P.fix);
     return PHIHIP_OK;
 }
 

@@ -98,6 +98,26 @@ ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const doubl
     return sb;
 }
 
+int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump) {
+    if (units >= (1LL << 28)) {
+        set_error("advect: more than 2^28 (tile, plane) units in one launch");
+        return PHIHIP_ERR_UNSUPPORTED;
+    }
+    const size_t bytes = 128 + (size_t)units * sizeof(FixItem);
+    void* before = ctx->ws_adv_flags.ptr;
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, bytes));
+    if (ctx->ws_adv_flags.ptr != before || !ctx->adv_ctl_clear) {        // a fresh buffer: the control block starts at zero (the fix-up launch keeps it so)
+        PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_adv_flags.ptr, 0, 64, s));
+        ctx->adv_ctl_clear = true;
+    }
+    list->ctl = (int*)ctx->ws_adv_flags.ptr;
+    list->items = (FixItem*)((char*)ctx->ws_adv_flags.ptr + 128);
+    list->cap = (int)units;
+    *dump = (char*)ctx->ws_adv_flags.ptr + 64;
+    ctx->adv_last_nblk = (int)units;
+    return PHIHIP_OK;
+}
+
 int ensure_buffer(DeviceBuffer& buf, size_t bytes) {
     if (buf.bytes >= bytes && buf.ptr) return PHIHIP_OK;
     if (buf.ptr) {
@@ -919,10 +939,10 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) 
     out[0] = out[1] = 0;
     if (ctx->adv_last_nblk <= 0 || !ctx->ws_adv_flags.ptr) return PHIHIP_OK;
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
-    std::vector<int> host((size_t)ctx->adv_last_nblk);
-    PHIHIP_CHECK_HIP(hipMemcpyAsync(host.data(), ctx->ws_adv_flags.ptr, host.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    int host[4] = {0, 0, 0, 0};         // control block of the work list (advect_common.hpp): [2] = entries of the most recent fix-up launch
+    PHIHIP_CHECK_HIP(hipMemcpyAsync(host, ctx->ws_adv_flags.ptr, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
     PHIHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    for (int f : host) out[0] += f != 0;
+    out[0] = host[2] < ctx->adv_last_nblk ? host[2] : ctx->adv_last_nblk;
     out[1] = ctx->adv_last_nblk;
     return PHIHIP_OK;
 }

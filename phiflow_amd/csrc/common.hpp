@@ -137,7 +137,8 @@ struct phihip_ctx {
     phihip::Tuning tuning[5];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE, 3 = UPDATE_R, 4 = CG1 (fused iteration)
     // workspace (grown on demand, reused between calls)
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g;
-    int adv_last_nblk = 0;        // workgroup flags of the most recent tiled advection (ws_adv_flags): count
+    int adv_last_nblk = 0;        // (tile, plane) units of the most recent LDS-staged advection launch (capacity of its fix-up work list)
+    bool adv_ctl_clear = false;   // the work list's control block in ws_adv_flags has been zeroed
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_last_chunk = 0;       // planes per workgroup the most recent tiled self-advection ran with (phihip_query_advect_chunk)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
@@ -201,6 +202,19 @@ struct LaunchScope {
 };
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// work list of the LDS-staged advection kernels' fix-up pass (device side: advect_common.hpp)
+struct FixItem {
+    int wg, plane;
+};
+struct FixList {
+    int* ctl;
+    FixItem* items;
+    int cap;
+};
+// ws_adv_flags = [16 control ints | 64-byte dump slot | work list]; `units` = (tile, plane) pairs of the launch = capacity of the list
+int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump);
+constexpr int kFixupBlocks = 1024;       // fix-up grid (4 workgroups per CU), whatever the list holds
 
 // The first-call autotunes time candidate launches with hipEventSynchronize -- illegal while `s` is being captured into a hipGraph (and
 // the timings would be meaningless there): a capturing stream keeps the analytic plan, the next eager call on the grid tunes.

@@ -61,6 +61,7 @@ void* dynamic_lds();         // 160 KB shared by the (one) running workgroup: `e
     hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { hipemu::sync_block(); }
+inline void __threadfence() {}        // one fiber runs at a time, in program order
 inline int __mul24(int a, int b) { return a * b; }
 
 // fibers of the emulation run one at a time: a plain read-modify-write is atomic

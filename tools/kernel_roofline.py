@@ -86,6 +86,9 @@ def group_table(d):
         row = dict(label=e["label"], kernels=sorted({short(n) for n in names}), launches=len(t), words_per_cell=e["words_per_cell"],
                    basis=e["basis"], avg_us=round(avg, 2), median_us=round(med, 2), min_us=round(t_sorted[0], 2),
                    moved_bytes_per_launch=moved, moved_GBs=round(moved / avg / 1e3, 1), frac_of_8TBs=round(moved / (avg * 1e-6) / HBM_PEAK, 4))
+        if moved <= 0:           # (a launch that moves nothing by construction: the empty fix-up kernels -- their time is the point)
+            rows.append(row)
+            continue
         if f and w:
             rb, wb = sum(f) / len(f) * 2048.0, sum(w) / len(w) * 1024.0
             row.update(pmc_read_bytes=int(rb), pmc_write_bytes=int(wb), pmc_bytes_per_launch=int(rb + wb),

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--cfl", type=float, default=0.5, help="max |u| dt / dx of the smooth test field (> 1: the fastest regions leave the LDS windows: fix-up pass)")
     ap.add_argument("--device", default="cuda:0", help="cpu + --lib tests/hipemu/libphihip_emu.so = dry run of the call sequence")
     a = ap.parse_args()
     lib = C.Library(a.lib, strict=False) if a.lib else C.load_default_library()
@@ -64,7 +65,7 @@ def main():
     s2 = torch.empty_like(s)
     p = torch.randn((B,) + res, device=dev, dtype=tdt, generator=g)
     div = torch.empty_like(p)
-    dt = 0.5 * h
+    dt = a.cfl * h
     s_bc = ((C.BC_PERIODIC, C.BC_PERIODIC),) * D if a.bc == "periodic" else ((C.BC_OPEN, C.BC_OPEN),) * D
     P = lambda ts: [t.data_ptr() for t in ts]
     N = B * n ** D
@@ -107,7 +108,7 @@ def main():
     }
     only = [x for x in a.only.split(",") if x]
     rec = {"lib": os.path.basename(a.lib) if a.lib else "default", "build_id": lib.build_id() if hasattr(lib, "build_id") else None,
-           "size": n, "rank": D, "batch": B, "dtype": a.dtype, "bc": a.bc, "reps": a.reps, "kernels": {}}
+           "size": n, "rank": D, "batch": B, "dtype": a.dtype, "bc": a.bc, "cfl": a.cfl, "reps": a.reps, "kernels": {}}
     for name, (fn, nbytes) in cases.items():
         if only and name not in only:
             continue
