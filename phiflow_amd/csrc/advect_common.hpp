@@ -23,26 +23,17 @@ struct AxisPair {
 // fix-up launch behind it has a FIXED modest grid whose workgroups stride over the list and recompute exactly those planes with the gather
 // code. Until r3 the unit was a workgroup's whole chunk of planes and the fix-up launch had one workgroup per tile workgroup: a plume that
 // crosses CFL 1 in 5 % of the workgroups left 60 fix-up workgroups marching 64 planes each while 250 CUs idled -- the 0.14 ms advection of
-// the smoke workload took 0.46 ms (profiles/r04_bench_smoke256_first.json). Control block: ctl[0] = entries appended, ctl[1] = ticket of the
-// fix-up workgroups (the last one publishes ctl[2] = entries of this launch for phihip_advect_fallback_stats and clears 0 and 1).
+// the smoke workload took 0.46 ms (profiles/r04_bench_smoke256_first.json). Two counters alternate between launches (common.hpp FixList): a tile
+// kernel appends to one and clears the other for the launch after it -- the fix-up launch only reads, no tickets, no atomics.
 __device__ __forceinline__ void fix_append(const FixList& L, int wg, int plane) {
-    const int k = atomicAdd(&L.ctl[0], 1);
+    const int k = atomicAdd(L.count, 1);
     if (k < L.cap) L.items[k] = FixItem{wg, plane};
 }
 __device__ __forceinline__ int fix_count(const FixList& L) {
-    const int c = L.ctl[0];
+    const int c = *L.count;
     return c < L.cap ? c : L.cap;
 }
-// thread 0 of every fix-up workgroup, after its loop over the list (every workgroup has read the count by then)
-__device__ __forceinline__ void fix_done(const FixList& L) {
-    __threadfence();
-    const int t = atomicAdd(&L.ctl[1], 1);
-    if (t == (int)(gridDim.x * gridDim.y) - 1) {
-        L.ctl[2] = L.ctl[0];
-        L.ctl[0] = 0;
-        L.ctl[1] = 0;
-    }
-}
+
 // wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
 // branch that no wavefront takes at sensible CFL numbers
 __device__ __forceinline__ int wrap_index(int i, int n) {

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     const int pe = DIM == 3 ? min(pb + chunk, nmax0) : 1;
     T* const outp[3] = {o0, o1, o2};
     if (tid < 2) slow_sh[tid] = 0;      // (a barrier of the ring warm-up / of the 2-D fill lies between this and the first plane of samples)
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fix.next = 0;      // the work list's other counter, for the launch after this one
     // per-thread output bookkeeping: element offset of position s = 0 in plane 0 per component, plane strides, and one bit per
     // (position, component): the sample exists in that component's array
     unsigned obase[3] = {0, 0, 0};      // in-plane element offset (unsigned 32-bit + uniform 64-bit base: address arithmetic stays scalar)
@@ -473,8 +474,6 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
             }
         }
     }
-    __syncthreads();          // every thread of this workgroup has read the count (the last workgroup's thread 0 clears it)
-    if (tid == 0) fix_done(fix);
 }
 
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
@@ -512,11 +511,11 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     }
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     int nblk = 0;
-    FixList fix;
-    void* dump = nullptr;
-    PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump));
-    // the tile kernel + its fix-up launch (fixed grid striding over the work list: it also resets the list, so the two always go together)
+    // the tile kernel + its fix-up launch (fixed grid striding over the work list)
     auto launch = [&](int ch) -> int {
+        FixList fix;
+        void* dump = nullptr;
+        PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump));
         chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
         nblk = tiles1 * tiles2 * chunks0;
         hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],

@@ -27,28 +27,31 @@ namespace phihip {
 
 enum WinKind { WK_MC_STAG = 0, WK_SL_CEN = 1, WK_MC_CEN = 2 };
 
-// halo of window w along internal axis a
-template <int KIND, int DIM>
+// halo of window w along internal axis a. H (1 or 2, phihip_set_advect_halo): reach of the multilinear lookups of the centred kinds -- with 2
+// a displacement below two cells stays in LDS (a smoke plume at dt = 1 moves faster than one cell per step in its core); the velocity
+// windows of those kinds do not grow (the centre velocity is a mean of the cell's own faces), and the staggered correction pass has H = 1 only
+// (six windows: 98 KB with H = 2, one workgroup per CU).
+template <int KIND, int DIM, int H>
 struct WinSpec;
-template <int DIM>
-struct WinSpec<WK_MC_STAG, DIM> {                       // windows: velocity components A0 .. 2, then the forward-pass components
+template <int DIM, int H>
+struct WinSpec<WK_MC_STAG, DIM, H> {                    // windows: velocity components A0 .. 2, then the forward-pass components
     static constexpr int NW = 2 * DIM;
     static constexpr int h(int w, int a) { return w < DIM ? ((3 - DIM + w) == a ? 2 : 1) : 1; }
 };
-template <int DIM>
-struct WinSpec<WK_SL_CEN, DIM> {                        // windows: the scalar, then the velocity components
+template <int DIM, int H>
+struct WinSpec<WK_SL_CEN, DIM, H> {                     // windows: the scalar, then the velocity components
     static constexpr int NW = 1 + DIM;
-    static constexpr int h(int w, int a) { return w == 0 ? 1 : ((3 - DIM + w - 1) == a ? 1 : 0); }
+    static constexpr int h(int w, int a) { return w == 0 ? H : ((3 - DIM + w - 1) == a ? 1 : 0); }
 };
-template <int DIM>
-struct WinSpec<WK_MC_CEN, DIM> {                        // windows: the scalar, the forward pass, then the velocity components
+template <int DIM, int H>
+struct WinSpec<WK_MC_CEN, DIM, H> {                     // windows: the scalar, the forward pass, then the velocity components
     static constexpr int NW = 2 + DIM;
-    static constexpr int h(int w, int a) { return w < 2 ? 1 : ((3 - DIM + w - 2) == a ? 1 : 0); }
+    static constexpr int h(int w, int a) { return w < 2 ? H : ((3 - DIM + w - 2) == a ? 1 : 0); }
 };
 
-template <typename T, int KIND, int DIM, int T1>
+template <typename T, int KIND, int DIM, int T1, int H = 1>
 struct WinTile {
-    using Spec = WinSpec<KIND, DIM>;
+    using Spec = WinSpec<KIND, DIM, H>;
     static constexpr int NW = Spec::NW;
     static constexpr int T2 = sizeof(T) == 4 ? 64 : 32;   // tile columns = lanes along the fast axis (256 B rows)
     static constexpr int TY = kBlock / T2;
@@ -137,9 +140,9 @@ __device__ __forceinline__ double win_clamp(double x, double lo, double hi) { re
 
 // OFFM: bit a = the lower face of axis a is NOT stored (CLOSED lower side): the static offsets of the velocity means depend on it.
 // CONSTS: some window may need constants patched in (a CLOSED side of the velocity or a constant extrapolation of the scalar).
-template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS>
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H>
 __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
-    using C = WinTile<T, KIND, DIM, T1>;
+    using C = WinTile<T, KIND, DIM, T1, H>;
     constexpr int A0 = 3 - DIM;
     constexpr int NW = C::NW, T2 = C::T2, TY = C::TY, S = C::S, KP = C::KP;
     constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
     const int pb = DIM == 3 ? c0 * P.chunk : 0;
     const int pe = DIM == 3 ? min(pb + P.chunk, P.nmax0) : 1;
     if (tid < 2) slow_sh[tid] = 0;      // (barriers of the ring warm-up / of the 2-D fill lie between this and the first plane of samples)
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *P.fix.next = 0;    // the work list's other counter, for the launch after this one
 
     // does this workgroup's window reach beyond a constant side? (uniform: interior tiles and boxes without one skip every select)
     bool has_const = false;
@@ -483,15 +487,15 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                 T val;
                 if (KIND == WK_SL_CEN) {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cb[a], -H, H - 1, fr[a], rel[a], dev);
                     val = lerp_taps(0, cen[0], rel, fr);
                 } else {
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cf[a], -H, H - 1, fr[a], rel[a], dev);
                     const T bwd = lerp_taps(1, cen[1], rel, fr);
                     const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], -1, 0, fr[a], rel[a], dev);
+                    for (int a = A0; a < 3; ++a) split(cb[a], -H, H - 1, fr[a], rel[a], dev);
                     T lo, hi;
                     minmax_taps(0, cen[0], rel, lo, hi);
                     val = nv < lo ? lo : (nv > hi ? hi : nv);
@@ -637,8 +641,6 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
             }
         }
     }
-    __syncthreads();          // every thread of this workgroup has read the count (the last workgroup's thread 0 clears it)
-    if (tid == 0) fix_done(fix);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------------
@@ -683,9 +685,9 @@ struct WinCall {
     double dt, ch;
 };
 
-template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS>
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H>
 static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
-    using C = WinTile<T, KIND, DIM, T1>;
+    using C = WinTile<T, KIND, DIM, T1, H>;
     constexpr int A0 = 3 - DIM;
     WinParams<T> P;
     memset(&P, 0, sizeof(P));
@@ -716,7 +718,7 @@ static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g,
     }
     P.ch = (T)call.ch;
     const int tiles1 = ceil_div(nmax[1], T1), tiles2 = ceil_div(nmax[2], C::T2);
-    auto kernel = advect_win_kernel<T, KIND, DIM, T1, OFFM, CONSTS>;
+    auto kernel = advect_win_kernel<T, KIND, DIM, T1, OFFM, CONSTS, H>;
     // LDS beyond the 64 KB a kernel gets by default: opt in once per instantiation and device
     static bool attr_set[16] = {false};
     bool& done = attr_set[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
@@ -766,7 +768,7 @@ static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g,
     return PHIHIP_OK;
 }
 
-template <typename T, int KIND, int DIM, int T1, int OFFM>
+template <typename T, int KIND, int DIM, int T1, int OFFM, int H>
 static int launch_win_off(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
     bool consts = false;
     for (int a = v.ax0; a < 3; ++a) {
@@ -774,26 +776,26 @@ static int launch_win_off(phihip_ctx* ctx, const GridView& v, const VelGrid& g, 
         if (call.sb) consts = consts || call.sb->bc[a][0] == PHIHIP_BC_CLOSED || call.sb->bc[a][1] == PHIHIP_BC_CLOSED;
     }
     if constexpr (OFFM == 0) {
-        if (!consts) return launch_win_inst<T, KIND, DIM, T1, OFFM, false>(ctx, v, g, call, s);
+        if (!consts) return launch_win_inst<T, KIND, DIM, T1, OFFM, false, H>(ctx, v, g, call, s);
     }
-    return launch_win_inst<T, KIND, DIM, T1, OFFM, true>(ctx, v, g, call, s);
+    return launch_win_inst<T, KIND, DIM, T1, OFFM, true, H>(ctx, v, g, call, s);
 }
 
-template <typename T, int KIND, int DIM, int T1>
+template <typename T, int KIND, int DIM, int T1, int H>
 static int launch_win(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
     const int m = (g.off[0] & 1) | ((g.off[1] & 1) << 1) | ((g.off[2] & 1) << 2);     // (2-D: off[0] = 0)
     switch (m) {
-        case 0: return launch_win_off<T, KIND, DIM, T1, 0>(ctx, v, g, call, s);
-        case 2: return launch_win_off<T, KIND, DIM, T1, 2>(ctx, v, g, call, s);
-        case 4: return launch_win_off<T, KIND, DIM, T1, 4>(ctx, v, g, call, s);
-        case 6: return launch_win_off<T, KIND, DIM, T1, 6>(ctx, v, g, call, s);
+        case 0: return launch_win_off<T, KIND, DIM, T1, 0, H>(ctx, v, g, call, s);
+        case 2: return launch_win_off<T, KIND, DIM, T1, 2, H>(ctx, v, g, call, s);
+        case 4: return launch_win_off<T, KIND, DIM, T1, 4, H>(ctx, v, g, call, s);
+        case 6: return launch_win_off<T, KIND, DIM, T1, 6, H>(ctx, v, g, call, s);
         default: break;
     }
     if (DIM == 3) switch (m) {
-        case 1: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 1 : 0)>(ctx, v, g, call, s);
-        case 3: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 3 : 0)>(ctx, v, g, call, s);
-        case 5: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 5 : 0)>(ctx, v, g, call, s);
-        case 7: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 7 : 0)>(ctx, v, g, call, s);
+        case 1: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 1 : 0), H>(ctx, v, g, call, s);
+        case 3: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 3 : 0), H>(ctx, v, g, call, s);
+        case 5: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 5 : 0), H>(ctx, v, g, call, s);
+        case 7: return launch_win_off<T, KIND, DIM, T1, (DIM == 3 ? 7 : 0), H>(ctx, v, g, call, s);
         default: break;
     }
     set_error("advect: unexpected face-offset pattern %d", m);
@@ -811,12 +813,13 @@ static int run_win(phihip_ctx* ctx, const GridView& v, const WinCall& call, hipS
         for (int a = v.ax0; a < 3; ++a)
             if (v.cn[c][a] < 4 || v.n[a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a window wider than the axis: the caller keeps the gather kernels
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+    const bool wide = KIND != WK_MC_STAG && ctx->adv_halo >= 2;       // phihip_set_advect_halo(ctx, 2): lookups of the centred kinds reach two cells
     if (v.dtype == PHIHIP_F64) {
-        if (v.rank == 3) PHIHIP_TRY((launch_win<double, KIND, 3, 8>(ctx, v, g, call, s)));
-        else PHIHIP_TRY((launch_win<double, KIND, 2, 8>(ctx, v, g, call, s)));
+        if (v.rank == 3) { if (wide) PHIHIP_TRY((launch_win<double, KIND, 3, 8, (KIND != WK_MC_STAG ? 2 : 1)>(ctx, v, g, call, s))); else PHIHIP_TRY((launch_win<double, KIND, 3, 8, 1>(ctx, v, g, call, s))); }
+        else PHIHIP_TRY((launch_win<double, KIND, 2, 8, 1>(ctx, v, g, call, s)));
     } else {
-        if (v.rank == 3) PHIHIP_TRY((launch_win<float, KIND, 3, 8>(ctx, v, g, call, s)));
-        else PHIHIP_TRY((launch_win<float, KIND, 2, 8>(ctx, v, g, call, s)));
+        if (v.rank == 3) { if (wide) PHIHIP_TRY((launch_win<float, KIND, 3, 8, (KIND != WK_MC_STAG ? 2 : 1)>(ctx, v, g, call, s))); else PHIHIP_TRY((launch_win<float, KIND, 3, 8, 1>(ctx, v, g, call, s))); }
+        else PHIHIP_TRY((launch_win<float, KIND, 2, 8, 1>(ctx, v, g, call, s)));
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

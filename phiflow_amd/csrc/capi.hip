@@ -110,7 +110,19 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
         PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_adv_flags.ptr, 0, 64, s));
         ctx->adv_ctl_clear = true;
     }
-    list->ctl = (int*)ctx->ws_adv_flags.ptr;
+    if (stream_is_capturing(s)) {
+        // a captured launch is replayed with the kernel arguments of the capture: the alternation below would leave a stale count when a
+        // graph holds an odd number of such launches. Captured launches get their own counter, cleared by a memset node in front of them.
+        list->count = (int*)ctx->ws_adv_flags.ptr + 3;
+        list->next = (int*)ctx->ws_adv_flags.ptr + 4;
+        PHIHIP_CHECK_HIP(hipMemsetAsync(list->count, 0, sizeof(int), s));
+        ctx->adv_seq_captured = true;
+    } else {
+        ctx->adv_seq += 1;
+        ctx->adv_seq_captured = false;
+        list->count = (int*)ctx->ws_adv_flags.ptr + (ctx->adv_seq & 1u);
+        list->next = (int*)ctx->ws_adv_flags.ptr + ((ctx->adv_seq + 1u) & 1u);
+    }
     list->items = (FixItem*)((char*)ctx->ws_adv_flags.ptr + 128);
     list->cap = (int)units;
     *dump = (char*)ctx->ws_adv_flags.ptr + 64;
@@ -939,10 +951,11 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) 
     out[0] = out[1] = 0;
     if (ctx->adv_last_nblk <= 0 || !ctx->ws_adv_flags.ptr) return PHIHIP_OK;
     PHIHIP_CHECK_HIP(hipSetDevice(ctx->device));
-    int host[4] = {0, 0, 0, 0};         // control block of the work list (advect_common.hpp): [2] = entries of the most recent fix-up launch
+    int host[4] = {0, 0, 0, 0};         // the work list's counters (advect_common.hpp): the most recent launch used the one of its parity ([3]: captured launches)
     PHIHIP_CHECK_HIP(hipMemcpyAsync(host, ctx->ws_adv_flags.ptr, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
     PHIHIP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    out[0] = host[2] < ctx->adv_last_nblk ? host[2] : ctx->adv_last_nblk;
+    const int n = ctx->adv_seq_captured ? host[3] : host[ctx->adv_seq & 1u];
+    out[0] = n < ctx->adv_last_nblk ? n : ctx->adv_last_nblk;
     out[1] = ctx->adv_last_nblk;
     return PHIHIP_OK;
 }

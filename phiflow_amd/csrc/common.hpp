@@ -139,6 +139,8 @@ struct phihip_ctx {
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g;
     int adv_last_nblk = 0;        // (tile, plane) units of the most recent LDS-staged advection launch (capacity of its fix-up work list)
     bool adv_ctl_clear = false;   // the work list's control block in ws_adv_flags has been zeroed
+    unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter
+    bool adv_seq_captured = false;   // the most recent such launch was captured into a hipGraph (its own counter, cleared by a memset node)
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_last_chunk = 0;       // planes per workgroup the most recent tiled self-advection ran with (phihip_query_advect_chunk)
     int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
@@ -208,13 +210,16 @@ struct FixItem {
     int wg, plane;
 };
 struct FixList {
-    int* ctl;
+    int* count;          // entries appended by THIS launch's tile kernel (zero when it starts: cleared by the previous launch's tile kernel)
+    int* next;           // the other counter: this launch's tile kernel clears it for the next launch (its last reader, the fix-up launch of
+                         // the previous launch, has completed -- stream order); no atomics / tickets in the fix-up launch
     FixItem* items;
     int cap;
 };
-// ws_adv_flags = [16 control ints | 64-byte dump slot | work list]; `units` = (tile, plane) pairs of the launch = capacity of the list
+// ws_adv_flags = [16 control ints | 64-byte dump slot | work list]; `units` = (tile, plane) pairs of the launch = capacity of the list.
+// Call once per tile-kernel launch (the two counters alternate).
 int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump);
-constexpr int kFixupBlocks = 1024;       // fix-up grid (4 workgroups per CU), whatever the list holds
+constexpr int kFixupBlocks = 2048;       // fix-up grid (8 workgroups per CU), whatever the list holds
 
 // The first-call autotunes time candidate launches with hipEventSynchronize -- illegal while `s` is being captured into a hipGraph (and
 // the timings would be meaningless there): a capturing stream keeps the analytic plan, the next eager call on the grid tunes.

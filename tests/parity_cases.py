@@ -347,7 +347,7 @@ def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt
     for name, vel in gentle_fields(v, dom, dt, dtype, rng):
         dv = [mem.to_dev(a) for a in vel]
         ref = O.semi_lagrangian_centered(s, vel, dt, dom, s_codes, s_consts)
-        for halo in (1, 0):
+        for halo in (1, 2, 0):       # LDS windows reaching 1 / 2 cells, gather kernels
             ctx.set_advect_halo(halo)
             ctx.set_advect_windows_2d(True)      # (2-D grids keep the gather kernels by default: exercise the windows there, too)
             try:
@@ -383,7 +383,7 @@ def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_const
     for name, vel in gentle_fields(v, dom, dt, dtype, rng):
         dg = [mem.to_dev(a) for a in vel]
         ref = O.mac_cormack_centered(s, vel, dt, dom, s_codes, s_consts, strength)
-        for halo in (1, 0):
+        for halo in (1, 2, 0):       # LDS windows reaching 1 / 2 cells, gather kernels
             ctx.set_advect_halo(halo)
             ctx.set_advect_windows_2d(True)      # (2-D grids keep the gather kernels by default: exercise the windows there, too)
             try:

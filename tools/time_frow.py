@@ -32,11 +32,14 @@ def main():
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--halo", type=int, default=1, help="phihip_set_advect_halo: 0 gather kernels, 1 / 2 reach of the LDS windows")
     ap.add_argument("--cfl", type=float, default=0.5, help="max |u| dt / dx of the smooth test field (> 1: the fastest regions leave the LDS windows: fix-up pass)")
     ap.add_argument("--device", default="cuda:0", help="cpu + --lib tests/hipemu/libphihip_emu.so = dry run of the call sequence")
     a = ap.parse_args()
     lib = C.Library(a.lib, strict=False) if a.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
+    if a.halo != 1:
+        ctx.set_advect_halo(a.halo)
     dev = torch.device(a.device)
     gpu = dev.type == "cuda"
     n, D, B = a.size, a.rank, a.batch
@@ -108,7 +111,7 @@ def main():
     }
     only = [x for x in a.only.split(",") if x]
     rec = {"lib": os.path.basename(a.lib) if a.lib else "default", "build_id": lib.build_id() if hasattr(lib, "build_id") else None,
-           "size": n, "rank": D, "batch": B, "dtype": a.dtype, "bc": a.bc, "cfl": a.cfl, "reps": a.reps, "kernels": {}}
+           "size": n, "rank": D, "batch": B, "dtype": a.dtype, "bc": a.bc, "cfl": a.cfl, "halo": a.halo, "reps": a.reps, "kernels": {}}
     for name, (fn, nbytes) in cases.items():
         if only and name not in only:
             continue
