@@ -345,10 +345,16 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable);
  * iteration moves 7 instead of 8 words per cell. Same iterates r, d, alpha, beta; x equal up to rounding. enable = 0 updates x in
  * every iteration (A/B measurements, tests). Default: enabled. */
 int phihip_set_deferred_x_update(phihip_ctx* ctx, int enable);
-/* Self-advection of the staggered velocity (field == velocity pointers) runs as ONE launch whose taps come from LDS tiles staged with a
- * halo of `halo` samples (1 or 2: lookups displaced by less than that many cells never leave LDS; larger displacements fall back to a
- * global gather per wavefront, same result). halo = 0 selects the one-launch-per-component gather kernels for every call (A/B
- * measurements, tests); halo = 3 is an experimental variant (halo 1 with 16-row tiles, 3-D only; 2-D grids treat it as 2). Default: 1. */
+/* Reach of the LDS-staged advection kernels (advect_tile.hip: self-advection of the staggered velocity, one launch for all components;
+ * advect_win.hip: correction pass of mac_cormack(v, v), semi_lagrangian / mac_cormack of a centred scalar). Lookups displaced by less than
+ * `halo` cells are served from LDS; (tile, plane) units with a larger displacement are recomputed by a fix-up launch with the gather code --
+ * same result on either path.
+ *   -1 (default)  adaptive per kind of pass: the fix-up launch publishes how many units fell back, the next pass of that kind picks
+ *                 1 cell (fastest below CFL 1), 2 cells (+10-25 % time, immune below CFL 2) or the gather kernels (flat cost) from that
+ *                 fraction, and probes the cheaper form every 64 calls. The choice depends on the data only, not on timing.
+ *    0            the one-launch-per-component gather kernels for every call
+ *    1 / 2        fixed reach (the staggered MacCormack correction has reach 1 only)
+ *    3            experimental: reach 1 with 16-row tiles for the self-advection (3-D) */
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
 /* The other advection passes -- the correction pass of mac_cormack(v, v), semi_lagrangian / mac_cormack of a centred scalar -- are served from
  * LDS windows too (advect_win.hip; halo 1, gather fix-up for larger displacements) whenever halo != 0, on 3-D grids. On 2-D grids the gather

@@ -515,7 +515,7 @@ class Context:
         self.lib.check(self.lib.dll.phihip_set_advect_windows_2d(self.handle, int(bool(enable))))
 
     def set_advect_halo(self, halo: int):
-        """ 0: gather kernels (one launch per component); 1 / 2: LDS-staged tiles with that halo for self-advection (default 1) """
+        """ -1 (default): adaptive reach of the LDS-staged advection kernels; 0: gather kernels; 1 / 2: fixed reach in cells (include/phihip.h) """
         self.lib.check(self.lib.dll.phihip_set_advect_halo(self.handle, int(halo)))
 
     def allreduce_residual(self, comm, values_device, count, op=2, stream=0):

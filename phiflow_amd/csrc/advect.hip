@@ -160,14 +160,27 @@ static int check_advect_sizes(const GridView& v) {
     return PHIHIP_OK;
 }
 
+// reach of an LDS-staged pass of `kind`: the user's fixed setting (phihip_set_advect_halo 0 / 1 / 2 / 3), or the adaptive choice (-1, default)
+static int pass_reach(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s) {
+    if (ctx->adv_halo >= 0) return (!has_wide && ctx->adv_halo > 1) ? 1 : ctx->adv_halo;
+    return adv_choose(ctx, kind, has_wide, s);
+}
+static int pass_done(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
+    return ctx->adv_halo < 0 ? adv_record(ctx, kind, reach, s) : PHIHIP_OK;
+}
+
 int run_advect_staggered(phihip_ctx* ctx, const GridView& v, const void* const f[3], const void* const vel[3], void* const out[3],
                          double dt, hipStream_t s) {
     PHIHIP_TRY(check_advect_sizes(v));
-    bool self = ctx->adv_halo > 0;
+    bool self = true;
     for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
     if (self) {   // one launch, taps from LDS (advect_tile.hip); axes with fewer than 4 samples keep the gather kernels
-        const int st = run_advect_self_tiled(ctx, v, vel, out, dt, ctx->adv_halo, s);
-        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        const int reach = pass_reach(ctx, AK_SL_SELF, true, s);
+        if (reach > 0) {
+            const int st = run_advect_self_tiled(ctx, v, vel, out, dt, reach, AK_SL_SELF, s);
+            if (st == PHIHIP_OK) return pass_done(ctx, AK_SL_SELF, reach, s);
+            if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
         ctx->adv_last_nblk = 0;
     }
     const VelGrid g = make_velgrid(v);
@@ -193,16 +206,28 @@ int run_mac_cormack_staggered(phihip_ctx* ctx, const GridView& v, const void* co
     for (int ca = v.ax0; ca < 3; ++ca) tmp[ca] = (char*)ctx->ws_adv.ptr + offs[ca];
     // the semi-Lagrangian pass of mac_cormack(v, v, dt) is the self-advection: one LDS-tiled launch instead of D gather launches
     bool first_done = false;
-    bool self = ctx->adv_halo > 0;
+    bool self = true;
     for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
     if (self) {
-        const int st = run_advect_self_tiled(ctx, v, vel, tmp, dt, ctx->adv_halo, s);
-        if (st == PHIHIP_OK) first_done = true;
-        else if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        const int reach = pass_reach(ctx, AK_SL_SELF, true, s);
+        if (reach > 0) {
+            const int st = run_advect_self_tiled(ctx, v, vel, tmp, dt, reach, AK_SL_SELF, s);
+            if (st == PHIHIP_OK) { first_done = true; PHIHIP_TRY(pass_done(ctx, AK_SL_SELF, reach, s)); }
+            else if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
     }
-    if (first_done) {       // ... and so is the correction pass: velocity + forward pass staged in LDS windows, all components in one launch (advect_win.hip)
-        const int st = run_mc_correct_self_tiled(ctx, v, vel, tmp, out, dt, 0.5 * strength, s);
-        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    if (self) {             // ... and so is the correction pass: velocity + forward pass staged in LDS windows, all components in one launch (advect_win.hip)
+        const int reach = pass_reach(ctx, AK_MC_STAG, false, s);
+        if (reach > 0) {
+            if (!first_done) {      // (the self-advection chose the gather kernels: the correction's windows still read their result)
+                LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+                dispatch_advect_staggered<0>(v, g, f, vel, nullptr, tmp, dt, 0.0, s);
+                first_done = true;
+            }
+            const int st = run_mc_correct_self_tiled(ctx, v, vel, tmp, out, dt, 0.5 * strength, AK_MC_STAG, s);
+            if (st == PHIHIP_OK) return pass_done(ctx, AK_MC_STAG, reach, s);
+            if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
     }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
     if (!first_done) dispatch_advect_staggered<0>(v, g, f, vel, nullptr, tmp, dt, 0.0, s);
@@ -236,9 +261,13 @@ int run_advect_centered(phihip_ctx* ctx, const GridView& v, const void* sfield, 
     PHIHIP_TRY(check_advect_sizes(v));
     const VelGrid g = make_velgrid(v);
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
-    if (ctx->adv_halo > 0) {     // scalar + velocity staged in LDS windows (advect_win.hip); phihip_set_advect_halo(ctx, 0) keeps the gather kernel
-        const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, out, dt, s);
-        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    {   // scalar + velocity staged in LDS windows (advect_win.hip); phihip_set_advect_halo(ctx, 0) keeps the gather kernel
+        const int reach = pass_reach(ctx, AK_SL_CEN, true, s);
+        if (reach > 0) {
+            const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, out, dt, reach, AK_SL_CEN, s);
+            if (st == PHIHIP_OK) return pass_done(ctx, AK_SL_CEN, reach, s);
+            if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
         ctx->adv_last_nblk = 0;
     }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
@@ -254,14 +283,31 @@ int run_mac_cormack_centered(phihip_ctx* ctx, const GridView& v, const void* sfi
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     const size_t esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     PHIHIP_TRY(ensure_buffer(ctx->ws_adv, (size_t)v.batch * v.cells * esize));
-    if (ctx->adv_halo > 0) {     // both passes from LDS windows (advect_win.hip)
-        int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, dt, s);
-        if (st == PHIHIP_OK) st = run_mc_correct_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, s);
-        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    // both passes from LDS windows (advect_win.hip), each with the reach its own history asks for; a pass that keeps the gather kernel reads /
+    // writes the same buffers
+    bool first_done = false;
+    {
+        const int reach = pass_reach(ctx, AK_SL_CEN, true, s);
+        if (reach > 0) {
+            const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, dt, reach, AK_SL_CEN, s);
+            if (st == PHIHIP_OK) { first_done = true; PHIHIP_TRY(pass_done(ctx, AK_SL_CEN, reach, s)); }
+            else if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
+    }
+    if (!first_done) {
+        LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
+        dispatch_advect_centered<0>(v, g, sb, sfield, vel, nullptr, ctx->ws_adv.ptr, dt, 0.0, s);
+    }
+    {
+        const int reach = pass_reach(ctx, AK_MC_CEN, true, s);
+        if (reach > 0) {
+            const int st = run_mc_correct_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, reach, AK_MC_CEN, s);
+            if (st == PHIHIP_OK) return pass_done(ctx, AK_MC_CEN, reach, s);
+            if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+        }
         ctx->adv_last_nblk = 0;
     }
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
-    dispatch_advect_centered<0>(v, g, sb, sfield, vel, nullptr, ctx->ws_adv.ptr, dt, 0.0, s);
     dispatch_advect_centered<1>(v, g, sb, sfield, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, s);
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

@@ -33,6 +33,15 @@ __device__ __forceinline__ int fix_count(const FixList& L) {
     const int c = *L.count;
     return c < L.cap ? c : L.cap;
 }
+// fix-up launch, one thread: the count of this launch goes to pinned host memory for the adaptive reach of the next pass (common.hpp AdvPolicy)
+__device__ __forceinline__ void fix_publish(const FixList& L, int count) {
+    if (!L.publish) return;
+#ifdef __HIP_DEVICE_COMPILE__
+    __hip_atomic_store(L.publish, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *reinterpret_cast<volatile int*>(L.publish) = count;
+#endif
+}
 
 // wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
 // branch that no wavefront takes at sensible CFL numbers

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
     const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
     T* const outp[3] = {o0, o1, o2};
     const int count = fix_count(fix);
+    if (blockIdx.x == 0 && tid == 0) fix_publish(fix, count);
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const FixItem e = fix.items[item];
         const int b = e.wg / nblk;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
 }
 
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
-static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, int kind, hipStream_t s) {
     const TileGrid<T> g = make_tilegrid<T>(vg, dt);
     using C = AdvTile<T, DIM, H, T1>;
     int nmax[3] = {1, 1, 1};
@@ -515,7 +516,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     auto launch = [&](int ch) -> int {
         FixList fix;
         void* dump = nullptr;
-        PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump));
+        PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump, kind));
         chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
         nblk = tiles1 * tiles2 * chunks0;
         hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
@@ -571,30 +572,30 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
 // a stored lower face (OFFM bit clear) on every axis does not exclude a CLOSED upper side (mixed boxes): the periodic / open code without
 // the wall-value patch path is a separate instantiation of OFFM = 0 only
 template <typename T, int DIM, int H, int T1, int OFFM>
-static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+static int launch_tile_off(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, int kind, hipStream_t s) {
     bool closed = false;
     for (int a = v.ax0; a < 3; ++a) closed = closed || v.bc[a][0] == PHIHIP_BC_CLOSED || v.bc[a][1] == PHIHIP_BC_CLOSED;
     if constexpr (OFFM == 0) {
-        if (!closed) return launch_tile_consts<T, DIM, H, T1, OFFM, false>(ctx, v, vg, vel, out, dt, s);
+        if (!closed) return launch_tile_consts<T, DIM, H, T1, OFFM, false>(ctx, v, vg, vel, out, dt, kind, s);
     }
-    return launch_tile_consts<T, DIM, H, T1, OFFM, true>(ctx, v, vg, vel, out, dt, s);
+    return launch_tile_consts<T, DIM, H, T1, OFFM, true>(ctx, v, vg, vel, out, dt, kind, s);
 }
 
 template <typename T, int DIM, int H, int T1>
-static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, hipStream_t s) {
+static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, int kind, hipStream_t s) {
     const int m = (vg.off[0] & 1) | ((vg.off[1] & 1) << 1) | ((vg.off[2] & 1) << 2);     // (2-D: off[0] = 0)
     switch (m) {
-        case 0: return launch_tile_off<T, DIM, H, T1, 0>(ctx, v, vg, vel, out, dt, s);
-        case 2: return launch_tile_off<T, DIM, H, T1, 2>(ctx, v, vg, vel, out, dt, s);
-        case 4: return launch_tile_off<T, DIM, H, T1, 4>(ctx, v, vg, vel, out, dt, s);
-        case 6: return launch_tile_off<T, DIM, H, T1, 6>(ctx, v, vg, vel, out, dt, s);
+        case 0: return launch_tile_off<T, DIM, H, T1, 0>(ctx, v, vg, vel, out, dt, kind, s);
+        case 2: return launch_tile_off<T, DIM, H, T1, 2>(ctx, v, vg, vel, out, dt, kind, s);
+        case 4: return launch_tile_off<T, DIM, H, T1, 4>(ctx, v, vg, vel, out, dt, kind, s);
+        case 6: return launch_tile_off<T, DIM, H, T1, 6>(ctx, v, vg, vel, out, dt, kind, s);
         default: break;
     }
     if (DIM == 3) switch (m) {
-        case 1: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 1 : 0)>(ctx, v, vg, vel, out, dt, s);
-        case 3: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 3 : 0)>(ctx, v, vg, vel, out, dt, s);
-        case 5: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 5 : 0)>(ctx, v, vg, vel, out, dt, s);
-        case 7: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 7 : 0)>(ctx, v, vg, vel, out, dt, s);
+        case 1: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 1 : 0)>(ctx, v, vg, vel, out, dt, kind, s);
+        case 3: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 3 : 0)>(ctx, v, vg, vel, out, dt, kind, s);
+        case 5: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 5 : 0)>(ctx, v, vg, vel, out, dt, kind, s);
+        case 7: return launch_tile_off<T, DIM, H, T1, (DIM == 3 ? 7 : 0)>(ctx, v, vg, vel, out, dt, kind, s);
         default: break;
     }
     set_error("advect: unexpected face-offset pattern %d", m);
@@ -602,7 +603,7 @@ static int launch_tile(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, co
 }
 
 // halo: 1 or 2 samples (taps reach |displacement| < halo cells without leaving LDS)
-int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], void* const out[3], double dt, int halo, hipStream_t s) {
+int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], void* const out[3], double dt, int halo, int kind, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     for (int c = v.ax0; c < 3; ++c)
         for (int a = v.ax0; a < 3; ++a)
@@ -613,13 +614,13 @@ int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const 
     // 384^3 closed 1.14 -> 0.94 ms, 256^3 periodic 0.232 -> 0.227 ms; fp32 keeps the 8-row tile (256^3: 0.119 vs 0.146 ms)
     // (profiles/r03_time_advect.jsonl). halo == 3 selects the 16-row tile for fp32 as well (A/B measurements).
     if (v.rank == 3 && (halo == 3 || (halo == 1 && f64))) {
-        if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 16>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 16>(ctx, v, g, vel, out, dt, s)));
+        if (f64) PHIHIP_TRY((launch_tile<double, 3, 1, 16>(ctx, v, g, vel, out, dt, kind, s))); else PHIHIP_TRY((launch_tile<float, 3, 1, 16>(ctx, v, g, vel, out, dt, kind, s)));
     } else if (v.rank == 3) {
-        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 3, 2, 8>(ctx, v, g, vel, out, dt, s))); }
-        else PHIHIP_TRY((launch_tile<float, 3, 1, 8>(ctx, v, g, vel, out, dt, s)));      // (fp64 halo 1 took the 16-row tile above)
+        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 3, 2, 8>(ctx, v, g, vel, out, dt, kind, s))); else PHIHIP_TRY((launch_tile<float, 3, 2, 8>(ctx, v, g, vel, out, dt, kind, s))); }
+        else PHIHIP_TRY((launch_tile<float, 3, 1, 8>(ctx, v, g, vel, out, dt, kind, s)));      // (fp64 halo 1 took the 16-row tile above)
     } else {
-        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 2, 8>(ctx, v, g, vel, out, dt, s))); }
-        else { if (f64) PHIHIP_TRY((launch_tile<double, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); else PHIHIP_TRY((launch_tile<float, 2, 1, 8>(ctx, v, g, vel, out, dt, s))); }
+        if (halo >= 2) { if (f64) PHIHIP_TRY((launch_tile<double, 2, 2, 8>(ctx, v, g, vel, out, dt, kind, s))); else PHIHIP_TRY((launch_tile<float, 2, 2, 8>(ctx, v, g, vel, out, dt, kind, s))); }
+        else { if (f64) PHIHIP_TRY((launch_tile<double, 2, 1, 8>(ctx, v, g, vel, out, dt, kind, s))); else PHIHIP_TRY((launch_tile<float, 2, 1, 8>(ctx, v, g, vel, out, dt, kind, s))); }
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
     const int tid = threadIdx.x, tx = tid % C::T2, ty = tid / C::T2;
     T* const outp[3] = {o0, o1, o2};
     const int count = fix_count(fix);
+    if (blockIdx.x == 0 && tid == 0) fix_publish(fix, count);
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const FixItem e = fix.items[item];
         const int b = e.wg / nblk;
@@ -683,6 +684,7 @@ struct WinCall {
     void* out[3];
     const ScalarBc* sb;
     double dt, ch;
+    int halo, kind;            // reach of the lookups of the centred kinds (1 / 2); AdvKind of the adaptive-reach bookkeeping
 };
 
 template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H>
@@ -755,7 +757,7 @@ static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g,
     const int chunks0 = DIM == 3 ? ceil_div(nmax[0], chunk) : 1;
     const int nblk = tiles1 * tiles2 * chunks0;
     void* dump = nullptr;
-    PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &P.fix, &dump));
+    PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &P.fix, &dump, call.kind));
     P.chunk = chunk; P.tiles1 = tiles1; P.tiles2 = tiles2; P.nblk = nblk; P.nmax0 = nmax[0];
     P.dump = (T*)dump;
     hipLaunchKernelGGL(kernel, dim3(nblk, v.batch), dim3(kBlock), C::BYTES, s, P);
@@ -813,7 +815,7 @@ static int run_win(phihip_ctx* ctx, const GridView& v, const WinCall& call, hipS
         for (int a = v.ax0; a < 3; ++a)
             if (v.cn[c][a] < 4 || v.n[a] < 4) return PHIHIP_ERR_UNSUPPORTED;   // a window wider than the axis: the caller keeps the gather kernels
     LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
-    const bool wide = KIND != WK_MC_STAG && ctx->adv_halo >= 2;       // phihip_set_advect_halo(ctx, 2): lookups of the centred kinds reach two cells
+    const bool wide = KIND != WK_MC_STAG && call.halo >= 2;           // lookups of the centred kinds reach two cells
     if (v.dtype == PHIHIP_F64) {
         if (v.rank == 3) { if (wide) PHIHIP_TRY((launch_win<double, KIND, 3, 8, (KIND != WK_MC_STAG ? 2 : 1)>(ctx, v, g, call, s))); else PHIHIP_TRY((launch_win<double, KIND, 3, 8, 1>(ctx, v, g, call, s))); }
         else PHIHIP_TRY((launch_win<double, KIND, 2, 8, 1>(ctx, v, g, call, s)));
@@ -827,31 +829,31 @@ static int run_win(phihip_ctx* ctx, const GridView& v, const WinCall& call, hipS
 
 // correction pass of mac_cormack(v, v, dt): fwd = the semi-Lagrangian result (advect_tile.hip), out = the corrected, limited velocity
 int run_mc_correct_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], const void* const fwd[3], void* const out[3], double dt,
-                              double ch, hipStream_t s) {
+                              double ch, int kind, hipStream_t s) {
     WinCall c;
     memset(&c, 0, sizeof(c));
     for (int k = 0; k < 3; ++k) { c.field[k] = vel[k]; c.vel[k] = vel[k]; c.fwd[k] = fwd[k]; c.out[k] = out[k]; }
-    c.dt = dt; c.ch = ch;
+    c.dt = dt; c.ch = ch; c.halo = 1; c.kind = kind;
     return run_win<WK_MC_STAG>(ctx, v, c, s);
 }
 
 int run_advect_centered_tiled(phihip_ctx* ctx, const GridView& v, const void* sfield, const ScalarBc& sb, const void* const vel[3], void* out, double dt,
-                              hipStream_t s) {
+                              int halo, int kind, hipStream_t s) {
     WinCall c;
     memset(&c, 0, sizeof(c));
     c.sfield = sfield; c.sb = &sb; c.out[0] = out;
     for (int k = 0; k < 3; ++k) c.vel[k] = vel[k];
-    c.dt = dt;
+    c.dt = dt; c.halo = halo; c.kind = kind;
     return run_win<WK_SL_CEN>(ctx, v, c, s);
 }
 
 int run_mc_correct_centered_tiled(phihip_ctx* ctx, const GridView& v, const void* sfield, const ScalarBc& sb, const void* const vel[3], const void* fwd,
-                                  void* out, double dt, double ch, hipStream_t s) {
+                                  void* out, double dt, double ch, int halo, int kind, hipStream_t s) {
     WinCall c;
     memset(&c, 0, sizeof(c));
     c.sfield = sfield; c.sb = &sb; c.out[0] = out; c.fwd[0] = fwd;
     for (int k = 0; k < 3; ++k) c.vel[k] = vel[k];
-    c.dt = dt; c.ch = ch;
+    c.dt = dt; c.ch = ch; c.halo = halo; c.kind = kind;
     return run_win<WK_MC_CEN>(ctx, v, c, s);
 }
 

@@ -98,7 +98,48 @@ ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const doubl
     return sb;
 }
 
-int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump) {
+static int ensure_adv_host(phihip_ctx* ctx) {
+    if (ctx->adv_host) return PHIHIP_OK;
+    void* h = nullptr;
+    PHIHIP_CHECK_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    memset(h, 0, 64);
+    void* d = nullptr;
+    PHIHIP_CHECK_HIP(hipHostGetDevicePointer(&d, h, 0));
+    ctx->adv_host = (int*)h;
+    ctx->adv_host_dev = (int*)d;
+    return PHIHIP_OK;
+}
+
+int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s) {
+    phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
+    const bool capturing = stream_is_capturing(s);
+    if (P.pending && !capturing) {
+        PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));        // (the pass is one step old: free unless the host runs more than a step ahead)
+        P.pending = false;
+        const double frac = P.units > 0 ? (double)ctx->adv_host[kind] / (double)P.units : 0.0;
+        if (P.last == 1) P.mode = frac > (has_wide ? 0.02 : 0.15) ? (has_wide ? 2 : 0) : 1;
+        else if (P.last == 2) P.mode = frac > 0.25 ? 0 : 2;
+    }
+    P.calls += 1;
+    if (!capturing && P.calls % 64 == 0) {                  // is the cheaper form good enough again?
+        if (P.mode == 2) return 1;
+        if (P.mode == 0) return has_wide ? 2 : 1;
+    }
+    return P.mode;
+}
+
+int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
+    if (stream_is_capturing(s)) return PHIHIP_OK;           // (an event record would become a node of the graph; captured passes keep their reach)
+    phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
+    if (!P.ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
+    PHIHIP_CHECK_HIP(hipEventRecord(P.ev, s));
+    P.pending = true;
+    P.last = reach;
+    P.units = ctx->adv_last_nblk;
+    return PHIHIP_OK;
+}
+
+int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump, int kind) {
     if (units >= (1LL << 28)) {
         set_error("advect: more than 2^28 (tile, plane) units in one launch");
         return PHIHIP_ERR_UNSUPPORTED;
@@ -124,6 +165,11 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
         list->next = (int*)ctx->ws_adv_flags.ptr + ((ctx->adv_seq + 1u) & 1u);
     }
     list->items = (FixItem*)((char*)ctx->ws_adv_flags.ptr + 128);
+    list->publish = nullptr;
+    if (kind != AK_NONE && ctx->adv_halo < 0) {
+        PHIHIP_TRY(ensure_adv_host(ctx));
+        list->publish = ctx->adv_host_dev + kind;
+    }
     list->cap = (int)units;
     *dump = (char*)ctx->ws_adv_flags.ptr + 64;
     ctx->adv_last_nblk = (int)units;
@@ -242,6 +288,9 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    if (ctx->adv_host) (void)hipHostFree(ctx->adv_host);
+    for (auto& P : ctx->adv_policy)
+        if (P.ev) (void)hipEventDestroy(P.ev);
     for (int i = 0; i < 2; ++i)
         if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     for (auto& p : ctx->ev_pool) {
@@ -923,8 +972,9 @@ int phihip_set_small_grid_solver(phihip_ctx* ctx, int enable) {
 
 int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
-    PHIHIP_REQUIRE(halo >= 0 && halo <= 3, "advect halo must be 0 (gather kernels), 1, 2 or 3 (experimental: halo 1 with 16-row tiles, 3-D only)");
+    PHIHIP_REQUIRE(halo >= -1 && halo <= 3, "advect halo must be -1 (adaptive), 0 (gather kernels), 1, 2 or 3 (experimental: halo 1 with 16-row tiles, 3-D only)");
     ctx->adv_halo = halo;
+    for (auto& P : ctx->adv_policy) { P.mode = 1; P.calls = 0; P.pending = false; }
     return PHIHIP_OK;
 }
 

@@ -139,11 +139,30 @@ struct phihip_ctx {
     phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g;
     int adv_last_nblk = 0;        // (tile, plane) units of the most recent LDS-staged advection launch (capacity of its fix-up work list)
     bool adv_ctl_clear = false;   // the work list's control block in ws_adv_flags has been zeroed
+    // Adaptive reach (r4). Each LDS-staged pass publishes how many (tile, plane) units fell back to the gather path (the fix-up launch writes
+    // the count into pinned, device-mapped host memory); the NEXT pass of the same kind waits for that launch's event -- it is one time step
+    // old, the wait is free unless the host runs more than a step ahead -- and picks its reach from the fraction: narrow (1 cell: fastest
+    // while the flow stays below CFL 1) -> wide (2 cells: +10-25 % time, immune below CFL 2) -> gather kernels (no windows: flat cost at any
+    // CFL), with a probe of the cheaper form every 64 calls. The decision depends on data only (not on timing): replicas that advance the
+    // same state take the same path. Measured (profiles/r04_time_frow_session_f.jsonl, 256^3 fp32): semi_lagrangian(s, v) at CFL 0.5 / 1.3 /
+    // 1.8: narrow 0.078 / 0.200 / 0.396 ms, wide 0.086 / 0.085 / 0.086, gather 0.105 / 0.106 / 0.107.
+    struct AdvPolicy {
+        int mode = 1;            // 0 gather, 1 narrow, 2 wide
+        int last = 0;            // reach of the pass that `pending` refers to
+        int calls = 0;
+        long long units = 0;     // (tile, plane) units of that pass
+        bool pending = false;    // an event + a published count are outstanding
+        hipEvent_t ev = nullptr;
+    };
+    AdvPolicy adv_policy[4];      // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
+    int* adv_host = nullptr;      // pinned, device-mapped: fallback count per kind
+    int* adv_host_dev = nullptr;
     unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter
     bool adv_seq_captured = false;   // the most recent such launch was captured into a hipGraph (its own counter, cleared by a memset node)
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_last_chunk = 0;       // planes per workgroup the most recent tiled self-advection ran with (phihip_query_advect_chunk)
-    int adv_halo = 1;             // self-advection: halo of the LDS-staged tiles (advect_tile.hip); 0 = the gather kernels of advect.hip
+    int adv_halo = -1;            // phihip_set_advect_halo: reach of the LDS-staged advection kernels. -1 (default) = adaptive per kind of pass (AdvPolicy below),
+                                  // 0 = the gather kernels of advect.hip, 1 / 2 = fixed (3 = experimental 16-row tiles of the self-advection)
     bool adv_win_2d = false;      // advect_win.hip on 2-D grids (slower than the gather kernels there; phihip_set_advect_halo(ctx, 4) switches it on for the parity tests)
     // first-call autotune of the CG marching kernels: the candidates of the plan model are timed once per (grid, family) on the
     // context's own workspace and the fastest is cached here. PHIHIP_AUTOTUNE=0 in the environment / phihip_set_autotune(ctx, 0)
@@ -209,7 +228,9 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 struct FixItem {
     int wg, plane;
 };
+enum AdvKind { AK_SL_SELF = 0, AK_MC_STAG = 1, AK_SL_CEN = 2, AK_MC_CEN = 3, AK_NONE = -1 };
 struct FixList {
+    int* publish;        // host-mapped slot that receives this launch's count from the fix-up launch (adaptive reach), or nullptr
     int* count;          // entries appended by THIS launch's tile kernel (zero when it starts: cleared by the previous launch's tile kernel)
     int* next;           // the other counter: this launch's tile kernel clears it for the next launch (its last reader, the fix-up launch of
                          // the previous launch, has completed -- stream order); no atomics / tickets in the fix-up launch
@@ -218,7 +239,11 @@ struct FixList {
 };
 // ws_adv_flags = [16 control ints | 64-byte dump slot | work list]; `units` = (tile, plane) pairs of the launch = capacity of the list.
 // Call once per tile-kernel launch (the two counters alternate).
-int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump);
+int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump, int kind = AK_NONE);
+// adaptive reach of the LDS-staged advection passes (advect.hip): reach for the next pass of `kind` (0 gather / 1 / 2), and the bookkeeping
+// after a windowed pass was enqueued
+int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s);
+int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s);
 constexpr int kFixupBlocks = 2048;       // fix-up grid (8 workgroups per CU), whatever the list holds
 
 // The first-call autotunes time candidate launches with hipEventSynchronize -- illegal while `s` is being captured into a hipGraph (and
@@ -230,12 +255,12 @@ inline bool stream_is_capturing(hipStream_t s) {
 
 // ---- phases implemented in the .hip files ---------------------------------------------------------------------------
 int run_advect_staggered(phihip_ctx*, const GridView&, const void* const f[3], const void* const v[3], void* const out[3], double dt, hipStream_t);
-int run_advect_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double dt, int halo, hipStream_t);
+int run_advect_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], void* const out[3], double dt, int halo, int kind, hipStream_t);
 // LDS-windowed passes of advect_win.hip (PHIHIP_ERR_UNSUPPORTED: an axis with fewer than 4 samples -- the caller keeps the gather kernels)
-int run_mc_correct_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], const void* const fwd[3], void* const out[3], double dt, double ch, hipStream_t);
-int run_advect_centered_tiled(phihip_ctx*, const GridView&, const void* s, const ScalarBc& sb, const void* const v[3], void* out, double dt, hipStream_t);
+int run_mc_correct_self_tiled(phihip_ctx*, const GridView&, const void* const v[3], const void* const fwd[3], void* const out[3], double dt, double ch, int kind, hipStream_t);
+int run_advect_centered_tiled(phihip_ctx*, const GridView&, const void* s, const ScalarBc& sb, const void* const v[3], void* out, double dt, int halo, int kind, hipStream_t);
 int run_mc_correct_centered_tiled(phihip_ctx*, const GridView&, const void* s, const ScalarBc& sb, const void* const v[3], const void* fwd, void* out, double dt,
-                                  double ch, hipStream_t);
+                                  double ch, int halo, int kind, hipStream_t);
 int run_grid_sample(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,
                     const void* const coords[3], long long npts, void* out, void* out_min, void* out_max, hipStream_t);
 int run_grid_sample_bwd(phihip_ctx*, const GridView&, const int32_t s_bc[3][2], const double s_val[3][2], const void* values, int values_batch,

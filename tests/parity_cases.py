@@ -294,7 +294,7 @@ def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
                     redone, total = ctx.advect_fallback_stats()
                     assert total > 0 and (redone < total or total <= 4), "displacements up to 2.4 cells at a few spots flagged every workgroup"
         finally:
-            ctx.set_advect_halo(1)
+            ctx.set_advect_halo(-1)     # back to the default: adaptive reach
     dv = [mem.to_dev(a) for a in v]
     f = random_velocity(dom, B, dtype, rng, scale)
     df = [mem.to_dev(a) for a in f]
@@ -354,7 +354,7 @@ def check_advect_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt
                 ctx.advect_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dv], mem.ptr(dout), dt)
                 mem.sync()
             finally:
-                ctx.set_advect_halo(1)
+                ctx.set_advect_halo(-1)     # back to the default: adaptive reach
                 ctx.set_advect_windows_2d(False)
             err = rel_err(mem.to_host(dout), ref)
             assert err <= advect_tol(dtype, dom), f"advect_centered {name} field, halo {halo}: rel err {err}"
@@ -390,7 +390,7 @@ def check_mac_cormack_centered(ctx, mem, dom, grid, dtype, rng, s_codes, s_const
                 ctx.mac_cormack_centered(grid, mem.ptr(ds), s_codes, s_consts, [mem.ptr(a) for a in dg], mem.ptr(dout), dt, strength)
                 mem.sync()
             finally:
-                ctx.set_advect_halo(1)
+                ctx.set_advect_halo(-1)     # back to the default: adaptive reach
                 ctx.set_advect_windows_2d(False)
             bad = np.abs(mem.to_host(dout) - ref) > advect_tol(dtype, dom) * max(np.abs(ref).max(), 1e-30)
             assert bad.mean() <= 2e-3, f"mac_cormack_centered {name} field, halo {halo}: {bad.mean():.2%} of the samples differ"
@@ -423,7 +423,7 @@ def check_mac_cormack_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, strengt
                 ctx.mac_cormack_staggered(grid, [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dg], [mem.ptr(a) for a in dout], dt, strength)
                 mem.sync()
             finally:
-                ctx.set_advect_halo(1)
+                ctx.set_advect_halo(-1)     # back to the default: adaptive reach
                 ctx.set_advect_windows_2d(False)
             for d in range(dom.rank):
                 bad = np.abs(mem.to_host(dout[d]) - ref[d]) > advect_tol(dtype, dom) * max(np.abs(ref[d]).max(), 1e-30)
