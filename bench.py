@@ -350,7 +350,7 @@ def bench_slab(args, lib, device, rank, world, dist, barrier):
     n = args.size if args.size != 256 else 512
     L = 2 * math.pi
     per = ((C.BC_PERIODIC, C.BC_PERIODIC),) * 3
-    fluid = SlabFluid(be, (n, n, n), (0.0, 0.0, 0.0), (L, L, L), per, torch.float32, batch=1, ghost=2)
+    fluid = SlabFluid(be, (n, n, n), (0.0, 0.0, 0.0), (L, L, L), per, torch.float32, batch=1, ghost=2, overlap=bool(args.overlap))
     h = L / n
     idx = torch.arange(n, device=device, dtype=torch.float64)
     face, cent = idx * h, (idx + 0.5) * h
@@ -388,6 +388,7 @@ def bench_slab(args, lib, device, rank, world, dist, barrier):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3D periodic Taylor-Green {n}^3 fp32 as ONE simulation on {world} x-slab(s) (SURVEY §8 f4), {args.cg_iters} CG iterations/step",
                        "planes_rank0": fluid.end - fluid.begin, "ghost_planes": fluid.ghost, "cg_iterations": args.cg_iters,
+                       "advect_exchange_overlap": bool(fluid.overlap and world > 1 and fluid._overlap_windows() is not None),
                        "parallelism": f"slab decomposition x{world}: per CG iteration 2 boundary-plane exchanges (point-to-point) + 2 all-reduces of 8 B"},
             "iterations_verified": [[int(x) for x in e.tolist()] for e in every], "final_relative_residual": math.sqrt(infos[0].residual_sq / infos[0].rhs_sq),
             "build_id": lib.build_id(),
@@ -683,6 +684,8 @@ def main():
                     help="config2 (default, the BASELINE metric): 256^3 Taylor-Green replicas, weak scaling. config4: 8 x 512^2 batched smoke, the batch "
                          "sharded over the GPUs, strong scaling. slab: ONE --size^3 simulation decomposed into x-slabs over the GPUs (SURVEY §8 f4). smoke256: a 3-D smoke "
                          "plume step (MacCormack smoke, advection, buoyancy, diffusion, 20 warm-started CG iterations): the share of the non-CG kernels")
+    ap.add_argument("--overlap", type=int, default=0, help="slab: 1 = SlabFluid(overlap=True): the ghost-plane exchange of the advection is in flight while the "
+                    "whole slab is advected, the planes within reach of a cut are redone on windows afterwards (same bits; tests/test_parallel_gloo.py)")
     ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")

@@ -145,9 +145,11 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
         return PHIHIP_ERR_UNSUPPORTED;
     }
     const size_t bytes = 128 + (size_t)units * sizeof(FixItem);
-    void* before = ctx->ws_adv_flags.ptr;
+    // (a reallocation is recognised by the SIZE: an allocator may well hand the freed address out again, with its own bookkeeping in the
+    // first bytes -- glibc does under the emulation -- and a stale count would send the fix-up launch over `cap` garbage entries)
+    const size_t had = ctx->ws_adv_flags.ptr ? ctx->ws_adv_flags.bytes : 0;
     PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, bytes));
-    if (ctx->ws_adv_flags.ptr != before || !ctx->adv_ctl_clear) {        // a fresh buffer: the control block starts at zero (the fix-up launch keeps it so)
+    if (ctx->ws_adv_flags.bytes != had || !ctx->adv_ctl_clear) {        // a fresh buffer: the control block starts at zero (the fix-up launch keeps it so)
         PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_adv_flags.ptr, 0, 64, s));
         ctx->adv_ctl_clear = true;
     }

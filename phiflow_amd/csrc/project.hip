@@ -2,6 +2,8 @@
 // divergence of the staggered velocity (+ active mask, + mean balance), pressure-gradient subtraction, obstacle flags,
 // soft obstacle scaling, and the explicit diffusion stencil (phi/physics/diffuse.py:13-60).
 // All are single-pass HBM-bound kernels: one thread per output sample, fast axis on consecutive lanes.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace phihip {
@@ -31,9 +33,16 @@ __device__ __forceinline__ VecA<T, V> veca_zero() {
     for (int i = 0; i < V; ++i) r.v[i] = T(0);
     return r;
 }
-// cells per thread of the vector kernels: fp32 4 (16 bytes), fp64 4 (32 bytes) when the rows allow, else 2
+// cells per thread of the vector kernels: 16 bytes (fp32 4, fp64 2). The 32-byte fp64 form (4 cells: two dwordx4 per lane at a lane stride
+// of 32 bytes, so each instruction touches every other 16 bytes of its lines) was the default for a few commits of r4 and LOST on the same
+// box against the 16-byte form: 384^3 fp64 closed gradient subtraction 0.64 -> 0.885 ms, divergence 0.384 -> 0.432, resample 0.56 -> 0.78
+// (profiles/r04_time_frow_session_h.jsonl). It stays instantiated behind PHIHIP_F64_VEC_CELLS=4 for A/B runs only.
+static inline int f64_vec_cells_setting() {
+    static const int v = [] { const char* e = getenv("PHIHIP_F64_VEC_CELLS"); return (e && e[0] == '4') ? 4 : 2; }();
+    return v;
+}
 template <typename T>
-static inline int vec_cells(int n2) { return sizeof(T) == 4 ? 4 : (n2 % 4 == 0 ? 4 : 2); }
+static inline int vec_cells(int n2) { return sizeof(T) == 4 ? 4 : ((f64_vec_cells_setting() == 4 && n2 % 4 == 0) ? 4 : 2); }
 // V elements at ELEMENT alignment (rows of n2 - 1 / n2 + 1 faces do not start on 16-byte boundaries; gfx950 takes dwordx4 at any 4-byte address)
 template <typename T, int V>
 struct __attribute__((packed, aligned(sizeof(T)))) VecU {

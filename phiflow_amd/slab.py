@@ -162,11 +162,12 @@ class SlabFluid:
     the owner, flags packed on the extended grid; `apply_boundary_conditions` runs on the extended velocity after the advection. """
 
     def __init__(self, backend, res, lower, upper, bc, dtype=torch.float32, batch: int = 1, bc_val=None, ghost: int = 2, group=None,
-                 obstacles=None):
+                 obstacles=None, overlap: bool = False):
         """ obstacles: list of obstacle descriptions as `_capi.make_obstacles` takes them (GLOBAL coordinates; Box / Sphere, linear and angular
         velocity) -- phi/physics/fluid.py:130-137,212-240 on slabs: see `set_obstacles`. """
         assert len(res) == 3 and ghost >= 1
         self.be, self.group, self.dtype, self.batch, self.ghost = backend, group, dtype, int(batch), int(ghost)
+        self.overlap = bool(overlap)      # advect(): ghost exchange in flight while the whole slab is advected, cut-side windows redone after it
         self.res, self.bc = tuple(int(r) for r in res), [tuple(int(c) for c in p) for p in bc]
         self.solver = SlabSolver(backend, res, lower, upper, bc, dtype, batch, group)
         s = self.solver
@@ -248,11 +249,22 @@ class SlabFluid:
         """ own[k]: (batch, planes_k, ...) -> arrays with lo_n[k] / hi_n[k] planes of the neighbours' adjacent samples around them. The
         neighbour sends its top lo_n[k] planes to the rank above and its bottom hi_n[k] planes to the rank below (the counts are the same
         on every rank with a neighbour on that side). """
+        ext, finish = self._extend_begin(own, lo_n, hi_n, shapes)
+        finish()
+        return ext
+
+    def _extend_begin(self, own, lo_n, hi_n, shapes, zero_ghosts: bool = False):
+        """ `_extend` in two halves: posts the messages and returns (ext, finish) -- `ext` holds the own samples (ghost planes: unset, or zero
+        with `zero_ghosts`), `finish()` waits for the neighbours' planes and stores them. With the "nccl" (= RCCL) backend the wait is a stream
+        dependency, so kernels enqueued between the two halves run while the planes cross xGMI. """
         ext = [self.be.empty(shapes[k], self.dtype) for k in range(len(own))]
         for k, t in enumerate(own):
             ext[k][:, lo_n[k]: lo_n[k] + t.shape[1]] = t
+            if zero_ghosts:
+                ext[k][:, : lo_n[k]] = 0
+                ext[k][:, lo_n[k] + t.shape[1]:] = 0
         if self.world == 1:
-            return ext
+            return ext, (lambda: None)
         # what goes UP is what the rank above lacks below its own samples (ghost planes of every field), what goes DOWN what the rank below
         # lacks above them (ghost cell planes, ghost + 1 x faces: the upper face of its last ghost cell included)
         up_counts = [self.ghost] * len(own)
@@ -270,22 +282,64 @@ class SlabFluid:
             ops += [dist.P2POp(dist.isend, send_up, gr(self.hi_rank), self.group), dist.P2POp(dist.irecv, recv_hi, gr(self.hi_rank), self.group)]
         if self.world == 2 and self.lo_rank == self.hi_rank and self.lo_rank is not None and self.rank == 1:
             ops = [ops[2], ops[3], ops[0], ops[1]]        # two ranks on a periodic axis: match my "up" with the peer's "down"
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for side, buf, counts in ((0, recv_lo, lo_n), (1, recv_hi, hi_n)):
-            if buf is None:
-                continue
-            pos = 0
-            for k in range(len(own)):
-                n = counts[k] * plane[k]
-                if n:
-                    block = buf[pos: pos + n].reshape((self.batch, counts[k]) + tuple(shapes[k][2:]))
-                    if side == 0:
-                        ext[k][:, : counts[k]] = block
-                    else:
-                        ext[k][:, shapes[k][1] - counts[k]:] = block
-                pos += n
-        return ext
+        pending = list(dist.batch_isend_irecv(ops))
+
+        def finish():
+            for req in pending:
+                req.wait()
+            for side, buf, counts in ((0, recv_lo, lo_n), (1, recv_hi, hi_n)):
+                if buf is None:
+                    continue
+                pos = 0
+                for k in range(len(own)):
+                    n = counts[k] * plane[k]
+                    if n:
+                        block = buf[pos: pos + n].reshape((self.batch, counts[k]) + tuple(shapes[k][2:]))
+                        if side == 0:
+                            ext[k][:, : counts[k]] = block
+                        else:
+                            ext[k][:, shapes[k][1] - counts[k]:] = block
+                    pos += n
+            _keep = (send_up, send_down)      # the send buffers live until the requests have completed
+        return ext, finish
+
+    def _overlap_windows(self):
+        """ Windows of the extended slab that `advect(overlap)` recomputes once the ghost planes have arrived: per cut side (window grid,
+        [plane range of the extended array per component], [planes to take from the window per component]). The whole-slab pass that ran
+        on empty ghosts is exact except within reach = ghost + 1 planes of a ghost zone; a window holds the ghosts, those planes and another
+        reach of own planes behind them. None: the slab is too thin for two disjoint windows (the plain order is used). """
+        if hasattr(self, "_windows"):
+            return self._windows
+        reach = self.ghost + 1
+        own_cells = self.end - self.begin
+        self._windows = None
+        if own_cells < 4 * reach + 2:
+            return None
+        code = _capi.PHIHIP_F64 if self.dtype == torch.float64 else _capi.PHIHIP_F32
+        dx = (self.grid.upper[0] - self.grid.lower[0]) / self.ext_cells
+        bc = [[self.grid.bc[d][s] for s in range(2)] for d in range(3)]
+        faces = self.ext_shape[0][1]
+        wins = []
+        if self.lo_rank is not None:
+            wc = self.gl + 2 * reach                   # cells [0, wc) of the extended grid; its lower side is the cut (OPEN): stored face 0 = face 0
+            wbc = [list(p) for p in bc]; wbc[0] = [bc[0][0], _capi.BC_OPEN]
+            lo0 = self.grid.lower[0]
+            g = _capi.make_grid(3, code, self.batch, (wc, self.res[1], self.res[2]), (lo0, self.grid.lower[1], self.grid.lower[2]),
+                                (lo0 + wc * dx, self.grid.upper[1], self.grid.upper[2]), wbc, self._bc_val)
+            src = [(0, wc + 1), (0, wc), (0, wc)]
+            take = [(self.own0[c], self.own0[c] + reach) for c in range(3)]
+            wins.append((g, src, take))
+        if self.hi_rank is not None:
+            wc = self.gr + 2 * reach                   # cells [ext_cells - wc, ext_cells); both sides OPEN: wc + 1 faces, the last stored ones
+            wbc = [list(p) for p in bc]; wbc[0] = [_capi.BC_OPEN, bc[0][1]]
+            hi0 = self.grid.upper[0]
+            g = _capi.make_grid(3, code, self.batch, (wc, self.res[1], self.res[2]), (hi0 - wc * dx, self.grid.lower[1], self.grid.lower[2]),
+                                (hi0, self.grid.upper[1], self.grid.upper[2]), wbc, self._bc_val)
+            src = [(faces - (wc + 1), faces), (self.ext_cells - wc, self.ext_cells), (self.ext_cells - wc, self.ext_cells)]
+            take = [(self.own0[c] + self.own_n[c] - reach, self.own0[c] + self.own_n[c]) for c in range(3)]
+            wins.append((g, src, take))
+        self._windows = wins
+        return wins
 
     def _extend_velocity(self, v: List[torch.Tensor]) -> List[torch.Tensor]:
         return self._extend(v, self.lo_n, self.hi_n, self.ext_shape)
@@ -304,16 +358,36 @@ class SlabFluid:
         verifies the bound on this rank's extended x component -- its own lookups and the 4-point means they use only see those samples, so
         the check needs no collective -- and raises `ValueError` instead of returning rank-dependent values; it costs one small reduction
         and a host read per call (the step's pressure solve synchronises anyway). Construct with a larger `ghost` for faster flows. """
-        ext = self._extend_velocity(v)
+        P = lambda ts: [t.data_ptr() for t in ts]
+        windows = self._overlap_windows() if (self.overlap and self.world > 1) else None
+        if windows is None:
+            ext = self._extend_velocity(v)
+        else:
+            # the exchange is in flight while the WHOLE extended slab is advected with empty (zero) ghost planes: exact for every sample whose
+            # reach -- back-trace, taps, 4-point means: ghost + 1 planes -- stays inside the own samples
+            ext, finish = self._extend_begin(v, self.lo_n, self.hi_n, self.ext_shape, zero_ghosts=True)
+            out = [torch.empty_like(t) for t in ext]
+            self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
+            finish()
         if check_cfl and self.world > 1:
             dx0 = (self.grid.upper[0] - self.grid.lower[0]) / self.ext_cells
             cfl = float(ext[0].abs().max()) * abs(float(dt)) / dx0
             if not cfl <= self.ghost - 1:
                 raise ValueError(f"SlabFluid.advect: |u_x| dt / dx = {cfl:.3f} exceeds ghost - 1 = {self.ghost - 1} on rank {self.rank}: back-traces "
                                  f"would leave the exchanged ghost planes. Use SlabFluid(..., ghost={int(cfl) + 2}) or a smaller dt.")
-        out = [torch.empty_like(t) for t in ext]
-        P = lambda ts: [t.data_ptr() for t in ts]
-        self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
+        if windows is None:
+            out = [torch.empty_like(t) for t in ext]
+            self.be.ctx.advect_staggered(self.grid, P(ext), P(ext), P(out), float(dt), self.be.stream())
+        else:
+            # ... and the few planes next to each cut are redone on a window of the completed arrays: the lookups are formed relative to
+            # the sample (advect_common.hpp lookup_pairs_rel), so a window reproduces the bits of the whole-slab launch
+            for wgrid, src, take in windows:
+                win = [ext[c][:, src[c][0]: src[c][1]].contiguous() for c in range(3)]
+                wout = [torch.empty_like(t) for t in win]
+                self.be.ctx.advect_staggered(wgrid, P(win), P(win), P(wout), float(dt), self.be.stream())
+                for c in range(3):
+                    a, b = take[c]
+                    out[c][:, a: b] = wout[c][:, a - src[c][0]: b - src[c][0]]
         if self.n_obstacles:     # fluid.apply_boundary_conditions (fluid.py:212-240): pointwise in physical coordinates, own samples are exact
             self.be.ctx.apply_obstacles(self.grid, self.obstacles, self.n_obstacles, P(out), self.be.stream())
         return self._own_velocity(out)

@@ -247,6 +247,59 @@ def test_slab_decomposed_fluid_step_world2_gloo(emu_library, emu_ctx, tmp_path, 
         assert np.abs(cat(f"out{c}") - out[c]).max() <= 2e-4, (c, np.abs(cat(f"out{c}") - out[c]).max())
 
 
+OVERLAP_CASES = {
+    "periodic": dict(res=(30, 8, 12), bc=((0, 0), (0, 0), (0, 0))),               # 15 + 15 planes: both cut sides of every rank get a window
+    "closed_open": dict(res=(45, 6, 10), bc=((1, 2), (1, 1), (0, 0))),            # three ranks 15 + 15 + 15: wall below rank 0, open end above rank 2
+}
+
+
+def _overlap_worker(rank, world, port, emu_path, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PHIHIP_AUTOTUNE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phiflow_amd import _capi
+    from phiflow_amd.backend import HipBackend
+    from phiflow_amd.slab import SlabFluid
+    backend = HipBackend(library=_capi.Library(emu_path), device="cpu")
+    res, bc = OVERLAP_CASES[case]["res"], OVERLAP_CASES[case]["bc"]
+    grid = _capi.make_grid(3, _capi.PHIHIP_F32, 2, res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    v = _smooth_velocity(backend.ctx, grid, np.random.default_rng(11), grid.batch)
+    results = []
+    for overlap in (False, True):
+        fluid = SlabFluid(backend, res, (0.0, 0.0, 0.0), tuple(float(r) for r in res), bc, torch.float32, batch=grid.batch, overlap=overlap)
+        off = 0 if bc[0][0] != _capi.BC_CLOSED else 1
+        own = [torch.from_numpy(np.ascontiguousarray(v[0][:, fluid.face_begin - off: fluid.face_end - off])),
+               torch.from_numpy(np.ascontiguousarray(v[1][:, fluid.begin: fluid.end])), torch.from_numpy(np.ascontiguousarray(v[2][:, fluid.begin: fluid.end]))]
+        results.append(fluid.advect(own, 0.9))
+        n_windows = len(fluid._overlap_windows() or []) if overlap else 0
+    np.savez(os.path.join(out_dir, f"ovl{rank}.npz"), windows=n_windows, expected=int(fluid.lo_rank is not None) + int(fluid.hi_rank is not None),
+             same=[bool(torch.equal(a, b)) for a, b in zip(*results)], adv0=results[1][0].numpy(), adv1=results[1][1].numpy(), adv2=results[1][2].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("periodic", 2), ("closed_open", 3)])
+def test_slab_advection_overlapped_exchange_gloo(emu_library, emu_ctx, tmp_path, case, world):
+    """ SlabFluid(overlap=True): the ghost exchange is posted, the whole slab is advected on empty ghosts while it is in flight, the planes
+    within reach of a cut are redone on windows of the completed arrays -- the SAME bits as the plain order on every rank, and the
+    single-process advection within rounding """
+    from phiflow_amd import _capi as C
+    mp.spawn(_overlap_worker, args=(world, _free_port(), emu_library.path, str(tmp_path), case), nprocs=world, join=True)
+    res, bc = OVERLAP_CASES[case]["res"], OVERLAP_CASES[case]["bc"]
+    grid = C.make_grid(3, C.PHIHIP_F32, 2, res, (0, 0, 0), tuple(float(r) for r in res), bc)
+    v = _smooth_velocity(emu_ctx, grid, np.random.default_rng(11), grid.batch)
+    adv = [np.empty_like(t) for t in v]
+    emu_ctx.advect_staggered(grid, [t.ctypes.data for t in v], [t.ctypes.data for t in v], [t.ctypes.data for t in adv], 0.9)
+    parts = [np.load(tmp_path / f"ovl{r}.npz") for r in range(world)]
+    for r, q in enumerate(parts):
+        assert int(q["windows"]) == int(q["expected"]) > 0, f"rank {r}: {int(q['windows'])} windows for {int(q['expected'])} cut sides"
+        assert all(bool(x) for x in q["same"]), f"rank {r}: overlapped advection differs from the plain order: {list(q['same'])}"
+    for c in range(3):
+        got = np.concatenate([q[f"adv{c}"] for q in parts], axis=1)
+        assert got.shape == adv[c].shape and np.abs(got - adv[c]).max() <= 2e-5, (c, np.abs(got - adv[c]).max())
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # SURVEY §8 f4 with obstacles (fluid.py:130-137,212-240 on slabs): masks rasterised per rank, ghost-cell masks from the owner, flags on the
 # extended grid, apply_boundary_conditions after the advection, balance over the active cells of the WHOLE domain
