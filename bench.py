@@ -261,6 +261,8 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         ctx.profile_enable(False)
         cells = total * n * n
         it_us = (prof["cg_matvec_dot"][1] + prof["cg_update"][1] + prof["cg_update_r"][1]) / max(1, prof["cg_matvec_dot"][0]) * 1e3
+        if args.resident_cg and prof["cg_matvec_dot"][0] == 0:          # the resident solver: one launch for the whole solve
+            it_us = prof["cg_update"][1] / max(1, args.cg_iters) * 1e3
         emit_record({
             "metric": f"cell-updates/sec (mac_cormack + advect + {args.cg_iters} CG iters), {total} x {n}^2 fp32 batched smoke", "value": cells * args.steps / elapsed,
             "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -268,7 +270,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
             "config": {"workload": f"batched 2D smoke {total} x {n}^2 (BASELINE.json configs[3]), batch block-distributed over {world} GPU(s), "
                                    f"{args.cg_iters} CG iterations per projection", "sims_total": total, "sims_rank0": sim.batch, "cg_iterations": args.cg_iters,
                        "parallelism": f"batch-parallel x{world}, no data-path collective, 1 all-reduce(max residual)/step"},
-            "final_relative_residual": float(rel.item()), "us_per_cg_iteration_rank0": round(it_us, 3),
+            "final_relative_residual": float(rel.item()), "us_per_cg_iteration_rank0": round(it_us, 3), "resident_cg": int(args.resident_cg),
             "iterations_verified": shards["iterations_per_rank"], "shards": shards, "build_id": ctx.lib.build_id(),
             "scaling_measured": "one point of a strong-scaling curve; no multi-GPU curve has been measured by the builder (single-GPU boxes only)",
             "kernel_ms_per_step_rank0": {k: round(v[1], 5) for k, v in prof.items()},
@@ -686,6 +688,8 @@ def main():
                          "plume step (MacCormack smoke, advection, buoyancy, diffusion, 20 warm-started CG iterations): the share of the non-CG kernels")
     ap.add_argument("--overlap", type=int, default=0, help="slab: 1 = SlabFluid(overlap=True): the ghost-plane exchange of the advection is in flight while the "
                     "whole slab is advected, the planes within reach of a cut are redone on windows afterwards (same bits; tests/test_parallel_gloo.py)")
+    ap.add_argument("--resident-cg", type=int, default=0, choices=[0, 1, 2], help="opt-in resident solver for 2-D fp32 projections (phihip_set_resident_cg; config4: "
+                    "the projection's CG iterations become ONE launch): 0 off (default), 1 up to the built-in cell limit, 2 whenever applicable")
     ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
@@ -717,6 +721,8 @@ def main():
     lib = C.load_default_library()
     assert lib.built_from_tree(), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
     ctx = C.Context(lib, local_rank)
+    if args.resident_cg:
+        ctx.set_resident_cg(args.resident_cg)
     if args.tuning:
         ctx.set_tuning(*[int(x) for x in args.tuning.split(",")])
     n, B = args.size, 1

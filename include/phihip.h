@@ -380,6 +380,17 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream);
  * (512^2: 10.7 -> 8.2 us). mode 0: never; 1 (default): when cells x batch <= max_cells (0 = built-in threshold, 1.2 M fp32 / 0.6 M fp64);
  * 2: always. 'CG-adaptive', slab-decomposed solves and grids of the single-workgroup solver are not affected. */
 int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cells);
+/* Resident solver for 2-D fp32 grids (cg_resident.hip; r4): the WHOLE 'CG' solve of a batch is ONE launch. A batch entry is owned by
+ * ceil(n_y / 16) workgroups of 1024 threads that keep r, A r, A p, p and x in registers for the whole solve and meet at one barrier per
+ * iteration (boundary rows + five partial sums through L2); the control logic (tolerances, divergence test, true-residual refresh --
+ * phiml's cg loop) runs on the device, the launch ends when its entries have converged, the host never polls. Same
+ * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids without cell flags, rows of whole 16-byte vectors up to
+ * 512 cells, batch x workgroups <= compute units; everything else (and any stream under capture) keeps the launch-per-iteration kernels.
+ * mode 0 (default): never; 1: when cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever applicable.
+ * Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14 -> 11, 16 x 256^2 11.5 -> 8, 1 x 512^2 7.8 -> 7.6. Opt-in
+ * because the launch has to be resident as a whole: with other streams busy on the device a workgroup may wait for a peer that has not been
+ * scheduled; every wait is bounded (~1 s), the solve then fails with PHIHIP_ERR_HIP instead of hanging. */
+int phihip_set_resident_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or
  * PHIHIP_AUTOTUNE=0 in the environment when the context is created) keeps the analytic launch plan: same launch geometry, hence the same

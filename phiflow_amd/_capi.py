@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered", "phihip_cg_solve_shifted",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg", "phihip_set_resident_cg",
 )
 
 
@@ -227,6 +227,7 @@ class Library:
         d.phihip_query_advect_chunk.argtypes = [c_void_p, POINTER(c_int32)]
         d.phihip_set_autotune.argtypes = [c_void_p, c_int]
         d.phihip_set_single_reduction_cg.argtypes = [c_void_p, c_int, ctypes.c_longlong]
+        d.phihip_set_resident_cg.argtypes = [c_void_p, c_int, ctypes.c_longlong]
         d.phihip_allreduce_residual.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
         d.phihip_advect_fallback_stats.argtypes = [c_void_p, POINTER(c_int32 * 2), c_void_p]
         d.phihip_query_plan.argtypes = [c_void_p, POINTER(Grid), c_int, c_int, POINTER(c_int32 * 6)]
@@ -526,6 +527,11 @@ class Context:
         """ 0: two launches per CG iteration always; 1: one fused launch per iteration for latency-bound solves (cells x batch <= max_cells,
         0 = built-in threshold); 2: always the fused form """
         self.lib.check(self.lib.dll.phihip_set_single_reduction_cg(self.handle, int(mode), int(max_cells)))
+
+    def set_resident_cg(self, mode: int, max_cells: int = 0):
+        """ resident solver for 2-D fp32 grids (the whole 'CG' solve in ONE launch, cg_resident.hip): 0 never, 1 when cells x batch <= max_cells
+        (0 = keep the limit), 2 whenever applicable """
+        self.lib.check(self.lib.dll.phihip_set_resident_cg(self.handle, int(mode), int(max_cells)))
 
     def set_autotune(self, enable: bool):
         """ first-call timing of the CG launch-plan candidates (default on; off = the analytic plan, reproducible launch geometry) """

@@ -285,7 +285,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1, &ctx->ws_adj_g};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1, &ctx->ws_adj_g, &ctx->ws_res};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
@@ -306,7 +306,7 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
 int phihip_workspace_bytes(const phihip_ctx* ctx, size_t* bytes) {
     PHIHIP_REQUIRE(ctx && bytes, "ctx / bytes is NULL");
     *bytes = ctx->ws_r.bytes + ctx->ws_d0.bytes + ctx->ws_d1.bytes + ctx->ws_div.bytes + ctx->ws_part.bytes + ctx->ws_state.bytes +
-             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes + ctx->ws_cg1.bytes + ctx->ws_adj_g.bytes;
+             ctx->ws_scalars.bytes + ctx->ws_rhs.bytes + ctx->ws_adv.bytes + ctx->ws_adv_flags.bytes + ctx->ws_adj_q.bytes + ctx->ws_adj_l.bytes + ctx->ws_cg1.bytes + ctx->ws_adj_g.bytes + ctx->ws_res.bytes;
     return PHIHIP_OK;
 }
 
@@ -1009,6 +1009,13 @@ int phihip_advect_fallback_stats(phihip_ctx* ctx, int32_t out[2], void* stream) 
     const int n = ctx->adv_seq_captured ? host[3] : host[ctx->adv_seq & 1u];
     out[0] = n < ctx->adv_last_nblk ? n : ctx->adv_last_nblk;
     out[1] = ctx->adv_last_nblk;
+    return PHIHIP_OK;
+}
+
+int phihip_set_resident_cg(phihip_ctx* ctx, int mode, long long max_cells) {
+    PHIHIP_REQUIRE(ctx != nullptr && mode >= 0 && mode <= 2 && max_cells >= 0, "set_resident_cg: mode must be 0, 1 or 2, max_cells >= 0");
+    ctx->resident_cg = mode;
+    if (max_cells > 0) ctx->resident_cg_cells = max_cells;
     return PHIHIP_OK;
 }
 

@@ -343,6 +343,44 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
     return PHIHIP_OK;
 }
 
+// 2-D fp32 grids whose iteration is bound by kernel boundaries: the whole solve in ONE launch of resident workgroups (cg_resident.hip)
+bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve);
+int run_cg_resident(phihip_ctx*, const GridView&, const void* rhs, void* x, const phihip_solve*, void* st_out, const double* shift, hipStream_t);
+
+static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x, const phihip_solve* solve, phihip_solve_info* info,
+                            const double* shift, hipStream_t s) {
+    PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
+    CgState* st = (CgState*)ctx->ws_state.ptr;
+    PHIHIP_TRY(run_cg_resident(ctx, v, rhs, x, solve, st, shift, s));
+    ctx->last_state = st;
+    ctx->last_state_batch = v.batch;
+    if (info) {
+        if (ctx->host_state_bytes < (size_t)v.batch * sizeof(CgState)) {
+            if (ctx->host_state) (void)hipHostFree(ctx->host_state);
+            ctx->host_state = nullptr;
+            ctx->host_state_bytes = 0;
+            PHIHIP_CHECK_HIP(hipHostMalloc(&ctx->host_state, (size_t)v.batch * sizeof(CgState), hipHostMallocDefault));
+            ctx->host_state_bytes = (size_t)v.batch * sizeof(CgState);
+        }
+        CgState* hst = (CgState*)ctx->host_state;
+        PHIHIP_CHECK_HIP(hipMemcpyAsync(hst, st, (size_t)v.batch * sizeof(CgState), hipMemcpyDeviceToHost, s));
+        PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < v.batch; ++b) {
+            if (hst[b].iterations < 0) {
+                set_error("cg (resident): a workgroup waited at a barrier for ~1 s -- the launch was not resident as a whole (is another stream using the device?)");
+                return PHIHIP_ERR_HIP;
+            }
+            info[b].residual_sq = hst[b].rsq;
+            info[b].rhs_sq = hst[b].rhs_sq;
+            info[b].iterations = hst[b].iterations;
+            info[b].converged = hst[b].converged;
+            info[b].diverged = hst[b].diverged;
+            info[b].reserved = 0;
+        }
+    }
+    return PHIHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // first-call autotune: time the (tile, chunk) candidates of MATVEC / UPDATE_X2 / UPDATE_R for this grid on the context's workspace
 // (r, d0, d1 -- the solve that follows initialises them) and cache the fastest. The analytic plan of plan_march misses by up to
@@ -770,6 +808,11 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     }
+    // 2-D fp32 grids up to the resident solver's cell limit: ONE launch for the whole solve (cg_resident.hip). A stream under capture keeps the
+    // launch-per-iteration forms (a graph replay next to other work could find the device occupied: the launch must be resident as a whole)
+    if (!v.op_custom && ctx->resident_cg > 0 && ctx->small_cg && !std::is_same<T, double>::value && cg_resident_applicable(ctx, v, flags, solve) &&
+        (ctx->resident_cg == 2 || (long long)v.cells * v.batch <= ctx->resident_cg_cells) && !stream_is_capturing(s))
+        return cg_resident_path(ctx, v, rhs, x, solve, info, shift, s);
     // (phihip_set_small_grid_solver(ctx, 0) = "the two-launch marching kernels at every size": it also switches the automatic choice off)
     if (solve->method == PHIHIP_METHOD_CG && !v.halo[0] && !v.halo[1] &&
         (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && ctx->small_cg && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))

@@ -136,7 +136,7 @@ struct phihip_ctx {
     int num_cu = 256;
     phihip::Tuning tuning[5];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE, 3 = UPDATE_R, 4 = CG1 (fused iteration)
     // workspace (grown on demand, reused between calls)
-    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g;
+    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g, ws_res;
     int adv_last_nblk = 0;        // (tile, plane) units of the most recent LDS-staged advection launch (capacity of its fix-up work list)
     bool adv_ctl_clear = false;   // the work list's control block in ws_adv_flags has been zeroed
     // Adaptive reach (r4). Each LDS-staged pass publishes how many (tile, plane) units fell back to the gather path (the fix-up launch writes
@@ -175,6 +175,10 @@ struct phihip_ctx {
     // by the kernel boundaries (cg1_cells: cells x batch at most this), 2 = always ('CG' only)
     int cg1_mode = 1;
     long long cg1_cells = 0;      // 0 = built-in threshold
+    // resident solver (cg_resident.hip): 0 = off, 1 = 2-D fp32 'CG' solves of at most resident_cg_cells cells x batch, 2 = whenever applicable
+    unsigned res_solve_no = 0;    // 12-bit solve number in the tags of the resident solver's granules (ws_res)
+    int resident_cg = 0;
+    long long resident_cg_cells = 4LL << 20;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule
     bool small_cg = true;         // grids that fit one CU's LDS are solved by the single-kernel CG (cg_small.hip)

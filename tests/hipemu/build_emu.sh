@@ -20,7 +20,7 @@ pids=()
 $CXX -c "$here/hipemu.cpp" -o "$build/hipemu.o" & pids+=($!)
 src_hash=$(cd "$src" && cat $(ls *.hip *.hpp | LC_ALL=C sort) ../../include/phihip.h | sha1sum | cut -c1-16)
 $CXX -x c++ -DPHIHIP_BUILD_ID="\"emulation src:$src_hash\"" -c "$src/capi.hip" -o "$build/capi.o" & pids+=($!)
-for f in cg project advect advect_tile advect_win adjoint cg_small; do
+for f in cg project advect advect_tile advect_win adjoint cg_small cg_resident; do
   $CXX -x c++ -c "$src/$f.hip" -o "$build/$f.o" & pids+=($!)
 done
 for t in 0 1; do for d in 0 1; do

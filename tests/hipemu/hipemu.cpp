@@ -27,10 +27,13 @@ static unsigned char g_xchg[64][64][16];   // [wave][lane][16 bytes]
 static const size_t kStack = 256 * 1024;
 
 static unsigned char g_dyn_lds[160 * 1024] __attribute__((aligned(64)));
-void* dynamic_lds() { return g_dyn_lds; }
+// the workgroup whose fiber runs: its dynamic LDS and its shuffle exchange slots (launch(): the one static set; launch_resident(): per block)
+static unsigned char* g_lds_cur = g_dyn_lds;
+static unsigned char (*g_xchg_cur)[64][16] = g_xchg;
+void* dynamic_lds() { return g_lds_cur; }
 dim3& cur_thread_idx() { return g_cur->tid; }
 int cur_lane() { return g_cur->linear & 63; }
-void* wave_slot(int lane) { return g_xchg[g_cur->linear >> 6][lane]; }
+void* wave_slot(int lane) { return g_xchg_cur[g_cur->linear >> 6][lane]; }
 
 static void yield_with(State s) {
     Fiber* f = g_cur;
@@ -115,6 +118,111 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                 g_block_idx = dim3(x, y, z);
                 run_block(nthreads);
             }
+    g_body = nullptr;
+}
+
+// ---- resident launch: EVERY workgroup of the grid is alive at the same time (persistent kernels with inter-workgroup barriers) --------------
+// Each block has its own fibers, dynamic LDS and exchange slots; the scheduler visits the blocks round-robin, one pass of ready fibers + barrier
+// releases per visit. A fiber that polls another workgroup's flag calls spin_yield() (device build: s_sleep) and stays READY. Kernels launched
+// this way must keep ALL their LDS in the dynamic allocation (`__shared__` statics of the emulation are one array for all blocks).
+struct ResBlock {
+    dim3 idx;
+    std::vector<Fiber> fibers;
+    unsigned char* lds = nullptr;
+    unsigned char (*xchg)[64][16] = nullptr;
+    int alive = 0;
+};
+static bool g_resident = false;
+
+void spin_yield() {
+    if (!g_resident) return;          // (an ordinary launch runs one block at a time: nobody else could make progress)
+    yield_with(READY);
+}
+
+void launch_resident(dim3 grid, dim3 block, const std::function<void()>& body) {
+    g_body = &body;
+    g_grid_dim = grid;
+    g_block_dim = block;
+    g_resident = true;
+    const int nthreads = block.x * block.y * block.z;
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    std::vector<ResBlock> blocks(nblocks);
+    size_t bi = 0;
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x, ++bi) {
+                ResBlock& B = blocks[bi];
+                B.idx = dim3(x, y, z);
+                B.lds = (unsigned char*)aligned_alloc(64, 160 * 1024);
+                B.xchg = (unsigned char(*)[64][16])malloc(sizeof(g_xchg));
+                B.fibers.resize(nthreads);
+                B.alive = nthreads;
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = B.fibers[t];
+                    f.stack = (char*)malloc(kStack);
+                    f.linear = t;
+                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = &g_sched;
+                    makecontext(&f.ctx, fiber_main, 0);
+                    f.state = READY;
+                }
+            }
+    size_t alive_blocks = nblocks;
+    unsigned long long idle_rounds = 0;
+    while (alive_blocks > 0) {
+        bool progressed = false;
+        for (ResBlock& B : blocks) {
+            if (B.alive == 0) continue;
+            g_block_idx = B.idx;
+            g_lds_cur = B.lds;
+            g_xchg_cur = B.xchg;
+            for (int t = 0; t < nthreads; ++t) {
+                Fiber& f = B.fibers[t];
+                if (f.state != READY) continue;
+                g_cur = &f;
+                swapcontext(&g_sched, &f.ctx);
+                progressed = true;
+                if (f.state == DONE) --B.alive;
+            }
+            bool all_block = B.alive > 0;
+            for (int t = 0; t < nthreads && all_block; ++t)
+                if (B.fibers[t].state != DONE && B.fibers[t].state != WAIT_BLOCK) all_block = false;
+            if (all_block) {
+                for (int t = 0; t < nthreads; ++t)
+                    if (B.fibers[t].state == WAIT_BLOCK) B.fibers[t].state = READY;
+                progressed = true;
+            }
+            for (int w = 0; w * 64 < nthreads; ++w) {
+                bool all_wave = true, any = false;
+                for (int t = w * 64; t < nthreads && t < (w + 1) * 64; ++t) {
+                    if (B.fibers[t].state == DONE) continue;
+                    if (B.fibers[t].state != WAIT_WAVE) all_wave = false;
+                    else any = true;
+                }
+                if (all_wave && any) {
+                    for (int t = w * 64; t < nthreads && t < (w + 1) * 64; ++t)
+                        if (B.fibers[t].state == WAIT_WAVE) B.fibers[t].state = READY;
+                    progressed = true;
+                }
+            }
+            if (B.alive == 0) --alive_blocks;
+        }
+        if (!progressed && ++idle_rounds > 4) {
+            fprintf(stderr, "hipemu: deadlock in a resident launch (divergent barrier)\n");
+            abort();
+        }
+    }
+    for (ResBlock& B : blocks) {
+        for (Fiber& f : B.fibers) free(f.stack);
+        free(B.lds);
+        free(B.xchg);
+    }
+    g_lds_cur = g_dyn_lds;
+    g_xchg_cur = g_xchg;
+    g_resident = false;
     g_body = nullptr;
 }
 

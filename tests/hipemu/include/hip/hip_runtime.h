@@ -45,6 +45,8 @@ extern Fiber* g_cur;
 extern dim3 g_block_idx, g_block_dim, g_grid_dim;
 dim3& cur_thread_idx();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void launch_resident(dim3 grid, dim3 block, const std::function<void()>& body);   // all workgroups alive at once (persistent kernels)
+void spin_yield();           // a fiber polling another workgroup's flag lets the others run
 void sync_block();
 void sync_wave();
 void* wave_slot(int lane);   // 16-byte exchange slot of `lane` in the calling fiber's wave
@@ -59,6 +61,9 @@ void* dynamic_lds();         // 160 KB shared by the (one) running workgroup: `e
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+// launch of a kernel whose workgroups synchronise with each other (device build: a plain launch of a grid that is resident as a whole)
+#define hipemuLaunchResident(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch_resident((grid), (block), [&]() { kernel(__VA_ARGS__); })
 
 inline void __syncthreads() { hipemu::sync_block(); }
 inline void __threadfence() {}        // one fiber runs at a time, in program order

@@ -465,6 +465,21 @@ def test_tiled_advection_across_tiles_and_chunks(emu_ctx, res, bc):
             pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=dt)
 
 
+@pytest.mark.parametrize("res,bc,batch", [((33, 264), ((OPN, OPN), (CLO, OPN)), 2), ((72, 128), ((PER, PER), (PER, PER)), 1), ((40, 216), ((CLO, CLO), (CLO, CLO)), 1)])
+def test_resident_cg_matches_oracle(emu_ctx, res, bc, batch):
+    """ cg_resident.hip under the emulation's RESIDENT launch (tests/hipemu: every workgroup of the grid alive at once, a polling fiber
+    yields): rows split over 3-5 workgroups per entry incl. a ragged last one, one and two vectors per thread, wrap / clamp / zero rows and
+    columns, true-residual refreshes inside the launch; the closed box also through make_incompressible (balance shift in the first pass) """
+    try:
+        emu_ctx.set_resident_cg(2)
+        dom, grid = pc.make_case(res, bc, np.float32, batch=batch)
+        pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(3), max_iter=12, refresh=5, fixed_iterations=True)
+        if bc[0][0] == CLO and bc[1][0] == CLO:
+            pc.check_make_incompressible(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(6))
+    finally:
+        emu_ctx.set_resident_cg(0)
+
+
 def test_autotuned_launch_plans_stay_correct(emu_library):
     """ first-call autotune of the CG marching kernels (cg.hip autotune_cg): whatever (tile, chunk) the timings pick -- noise under the
     emulation -- the solve must equal the oracle's, explicit tunings still win, and disabling it restores the analytic plan """

@@ -619,6 +619,45 @@ def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
         rccl.ncclCommDestroy(comm)
 
 
+def test_resident_cg(ctx, mem):
+    """ phihip_set_resident_cg (cg_resident.hip): the whole 2-D fp32 solve in ONE launch of resident workgroups -- vectors in registers, one
+    barrier per iteration among the workgroups of a batch entry, control logic on the device. Same iterates as the launch forms / the
+    oracle: fixed iteration counts incl. true-residual refreshes, tolerance mode (BASELINE configs[3]'s 8 x 512^2 among the shapes), every
+    boundary kind on both axes, a ragged last workgroup (n_y % 16 != 0), the balanced projection (shift folded into the first pass) """
+    try:
+        ctx.set_resident_cg(2)
+        for res, bc, batch in (((512, 512), ((CLO, CLO), (CLO, CLO)), 8), ((200, 264), ((PER, PER), (CLO, OPN)), 3), ((100, 96), ((OPN, CLO), (PER, PER)), 2),
+                               ((512, 512), ((PER, PER), (PER, PER)), 1)):
+            dom, grid = pc.make_case(res, bc, np.float32, batch=batch)
+            pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(3), max_iter=120, refresh=50, fixed_iterations=True)
+            if res[0] < 512:      # (tolerance mode on a white-noise right-hand side: thousands of iterations at 512^2)
+                pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(4))
+        dom, grid = pc.make_case((256, 384), ((CLO, CLO), (CLO, CLO)), np.float32, batch=4)
+        pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, np.random.default_rng(6))
+        # the resident launch against the launch-per-iteration default on the same right-hand side: same iteration count (+- 5 %), same solution
+        n = 512
+        dom, grid = pc.make_case((n, n), ((CLO, CLO), (CLO, CLO)), np.float32, batch=1, upper=(100.0, 100.0))
+        y = np.zeros((1, n, n), np.float32)
+        y[0, n // 2 - 5:n // 2 + 5, 5:15], y[0, n // 2 - 5:n // 2 + 5, 15:25] = 0.1, -0.1
+        y -= y.mean(dtype=np.float64).astype(np.float32)
+        out = {}
+        for mode in (0, 2):
+            ctx.set_resident_cg(mode)
+            dy, dx = mem.to_dev(y), mem.to_dev(np.zeros_like(y))
+            info = ctx.cg_solve(grid, 0, 1, mem.ptr(dy), mem.ptr(dx), pc.C.Solve(1e-4, 0.0, 4000, 50, 10, 0))
+            mem.sync()
+            x = mem.to_host(dx).astype(np.float64)
+            true_res = np.linalg.norm(y.astype(np.float64) - pc.O.masked_laplace(x, dom, None, None)) / np.linalg.norm(y.astype(np.float64))
+            out[mode] = (info[0].iterations, bool(info[0].converged), true_res, x - x.mean())
+            print(f"closed 512^2 fp32 rtol 1e-4, resident mode {mode}: {info[0].iterations} iterations, converged {bool(info[0].converged)}, true relative residual {true_res:.3e}")
+        assert out[0][1] and out[2][1]
+        assert abs(out[2][0] - out[0][0]) <= 0.05 * out[0][0], (out[0][0], out[2][0])
+        assert out[2][2] <= 2e-4
+        assert np.linalg.norm(out[2][3] - out[0][3]) <= 2e-3 * np.linalg.norm(out[0][3])
+    finally:
+        ctx.set_resident_cg(0)
+
+
 def test_single_reduction_cg_opt_in(ctx, mem):
     """ phihip_set_single_reduction_cg: ONE fused launch per iteration (Chronopoulos-Gear recurrences). Same iterates as PhiML's cg while
     far from the rounding floor (fixed iteration counts, fp32), converged solutions in fp64; off by default (fp32 accuracy floor) """

@@ -82,8 +82,29 @@ def config4():
         ctx.make_incompressible(grid, [t.data_ptr() for t in v2], None, 0, 1, True, p.data_ptr(), 0, solve, want_info=False)
     t = timed(step, 5)
     prof = kernel_profile(step)
-    print(json.dumps({"config": "4: batched 2-D smoke 8 x 512^2 fp32 closed box, advect + 100 CG iterations, one GPU", "ms_per_step": t * 1e3,
-                      "cell_updates_per_s": B * n * n / t, "us_per_cg_iteration": t * 1e6 / iters, "kernel_ms": prof}), flush=True)
+    rec = {"config": "4: batched 2-D smoke 8 x 512^2 fp32 closed box, advect + 100 CG iterations, one GPU", "ms_per_step": t * 1e3,
+           "cell_updates_per_s": B * n * n / t, "us_per_cg_iteration": t * 1e6 / iters, "kernel_ms": prof}
+    # the same step with the opt-in resident solver (cg_resident.hip: the projection's 100 iterations are ONE launch), and ONE simulation
+    # alone = what a GPU of the 8-GPU sharded run does
+    p_launch = p.clone()
+    ctx.set_resident_cg(2)
+    p.zero_()
+    tr = timed(step, 5)
+    rec["resident_cg"] = {"ms_per_step": tr * 1e3, "cell_updates_per_s": B * n * n / tr, "us_per_cg_iteration": tr * 1e6 / iters, "kernel_ms": kernel_profile(step)}
+    ctx.set_resident_cg(0)
+    grid1 = C.make_grid(2, C.PHIHIP_F32, 1, (n, n), (0, 0), (100, 100), ((1, 1), (1, 1)))
+    v1, v21, p1 = [t[:1].contiguous() for t in v], [torch.empty_like(t[:1]) for t in v], torch.zeros(1, n, n, device=dev)
+
+    def step1():
+        ctx.advect_staggered(grid1, [t.data_ptr() for t in v1], [t.data_ptr() for t in v1], [t.data_ptr() for t in v21], 0.5)
+        ctx.make_incompressible(grid1, [t.data_ptr() for t in v21], None, 0, 1, True, p1.data_ptr(), 0, solve, want_info=False)
+    rec["one_entry"] = {}
+    for label, mode in (("launches", 0), ("resident_cg", 2)):
+        ctx.set_resident_cg(mode)
+        t1 = timed(step1, 5)
+        rec["one_entry"][label] = {"ms_per_step": t1 * 1e3, "us_per_cg_iteration": t1 * 1e6 / iters}
+    ctx.set_resident_cg(0)
+    print(json.dumps(rec), flush=True)
 
 
 def config5():

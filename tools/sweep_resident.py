@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""
+The launch-per-iteration CG forms (two launches, or the single-reduction MODE_CG1 launch -- whatever the library picks by default) against the
+RESIDENT solver (cg_resident.hip: the whole solve in one launch, vectors in registers, one barrier among an entry's workgroups per
+iteration): wall time per iteration of a fixed-iteration solve and the time / iterations of a tolerance-mode solve, one JSON line per grid.
+    python tools/sweep_resident.py [iterations]
+"""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phiflow_amd import _capi as C   # noqa: E402
+
+CASES = [((512, 512), 1), ((512, 512), 8), ((256, 256), 8), ((256, 256), 16), ((384, 384), 4), ((512, 256), 8), ((128, 128), 16), ((256, 512), 2), ((192, 192), 1)]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = C.load_default_library()
+    ctx = C.Context(lib, 0)
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    for res, batch in CASES:
+        for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC)):
+            D = len(res)
+            grid = C.make_grid(D, C.PHIHIP_F32, batch, res, (0.0,) * D, tuple(float(n) for n in res), ((bc, bc),) * D)
+            rhs = torch.randn(batch, *res, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=torch.float32)
+            rhs -= rhs.mean(dim=tuple(range(1, D + 1)), keepdim=True)
+            x = torch.zeros_like(rhs)
+            rec = {"res": list(res), "batch": batch, "bc": bc_name, "cells_x_batch": batch * int(torch.tensor(res).prod()), "build": lib.build_id()}
+            sols = {}
+            for label, mode in (("launches", 0), ("resident", 2)):
+                ctx.set_resident_cg(mode)
+                ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 5, 50, 0, 0), want_info=False)   # plans, workspace
+                best = 1e30
+                for _ in range(3):
+                    x.zero_()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 50, 0, 0), want_info=True)
+                    best = min(best, time.perf_counter() - t0)
+                rec[label] = {"us_per_iteration": round(best / iters * 1e6, 3), "rel_residual": math.sqrt(info[0].residual_sq / info[0].rhs_sq),
+                              "iterations": info[0].iterations}
+                # tolerance mode: 1e-5, host polling every 10 iterations for the launch forms, none for the resident kernel
+                tb = 1e30
+                for _ in range(3):
+                    x.zero_()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(1e-5, 0.0, 4000, 50, 10, 0), want_info=True)
+                    tb = min(tb, time.perf_counter() - t0)
+                rec[label]["tolerance_solve"] = {"ms": round(tb * 1e3, 4), "iterations": [i.iterations for i in info][:4], "converged": all(i.converged for i in info)}
+                sols[label] = x.clone()
+            d = (sols["resident"] - sols["launches"])
+            d = d - d.mean(dim=tuple(range(1, D + 1)), keepdim=True)
+            ref = sols["launches"] - sols["launches"].mean(dim=tuple(range(1, D + 1)), keepdim=True)
+            rec["rel_l2_resident_vs_launches"] = float(d.norm() / ref.norm())
+            rec["speedup_resident"] = round(rec["launches"]["us_per_iteration"] / rec["resident"]["us_per_iteration"], 3)
+            print(json.dumps(rec), flush=True)
+            del rhs, x
+    ctx.set_resident_cg(0)
+
+
+if __name__ == "__main__":
+    main()
