@@ -924,8 +924,8 @@ int phihip_query_plan(phihip_ctx* ctx, const phihip_grid* grid, int has_flags, i
     MarchConfig c;
     MarchGrid g;
     PHIHIP_TRY(plan_march(ctx, v, 1, has_flags != 0, family, &c, &g));
-    out[0] = c.vec == 1 ? 1 : kTileShapes[c.id].rows;
-    out[1] = c.vec == 1 ? 64 : kTileShapes[c.id].tpr;
+    out[0] = march_one_tile(c.vec) ? 1 : kTileShapes[c.id].rows;
+    out[1] = march_one_tile(c.vec) ? 64 : kTileShapes[c.id].tpr;
     out[2] = c.chunk;
     out[3] = g.nblk;
     out[4] = march_occupancy_any(v, c.id, c.vec, family_mode(family), has_flags != 0);

@@ -59,9 +59,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R || (family == FAM_APPLY && (double)v.cells * v.batch * esize <= 72e6);
 
     auto tile_of = [&](int id, int* t1, int* t2) {
-        const int rows = c->vec == 1 ? 1 : kTileShapes[id].rows, tpr = c->vec == 1 ? 64 : kTileShapes[id].tpr;
+        const int rows = march_one_tile(c->vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(c->vec) ? 64 : kTileShapes[id].tpr;
         *t1 = kBlock / tpr * rows;
-        *t2 = tpr * c->vec;
+        *t2 = tpr * march_vec_elems(c->vec);
     };
     auto tiles_of = [&](int id) -> long long {
         int t1, t2;
@@ -130,8 +130,8 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     if (tuned != ctx->tuned.end()) {   // measured on this device (autotune_cg)
         id = tuned->second.id;
         chunk = tuned->second.chunk;
-    } else if (c->vec == 1) {
-        id = 5;   // (1, 64): the only scalar instantiation
+    } else if (march_one_tile(c->vec)) {
+        id = 5;   // (1, 64): the only scalar / UNAL instantiation
         chunk = best_chunk(id, &score);
     } else if (t.rows > 0 && t.tpr > 0) {
         for (int k = 0; k < kNumTileConfigs; ++k)
@@ -421,8 +421,8 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         for (int id = 0; id < kNumTileConfigs; ++id) {
             if (!march_tile_available(vec, esize, id)) continue;
             if (v.rank != 3) {
-                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
-                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec);
+                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
+                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec));
                 if (id != c_model.id && blocks <= maxblk) cands.push_back({id, 1, 0.f});
                 continue;
             }
@@ -432,8 +432,8 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
                 bool dup = false;
                 for (const Cand& o : cands) dup = dup || (o.id == id && o.chunk == ch);
                 if (dup) continue;
-                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
-                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * ceil_div(v.n[0], ch);
+                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
+                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec)) * ceil_div(v.n[0], ch);
                 // starved chip (but a little under one workgroup per CU is a candidate: 384^3 fp64 UPDATE_X2 runs fastest with 216 (4,64) workgroups of
                 // 128 planes, profiles/r03_sweep_config5.jsonl) / partial-sum lists too long
                 if (blocks * v.batch < ctx->num_cu * 3 / 4 || blocks > 8192) continue;
@@ -443,8 +443,8 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
             // 384^3 MATVEC (1,16): 1152 workgroups of 48 planes (4.5 per CU) 146 us, 1008 of 55 planes (3.9) or 1440 of 39 (5.6) 137 us
             // (profiles/r02_midsize_chunks.jsonl) -- the fixed list above has no such member for most sizes
             {
-                const int rows = vec == 1 ? 1 : kTileShapes[id].rows, tpr = vec == 1 ? 64 : kTileShapes[id].tpr;
-                const long long tiles = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * vec) * v.batch;
+                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
+                const long long tiles = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec)) * v.batch;
                 const int occ = march_occupancy_any(v, id, vec, mode, has_flags);
                 for (int m = 1; m <= occ + 1; ++m) {
                     const long long target = (long long)(m <= occ ? m : 2 * occ) * ctx->num_cu;
@@ -462,8 +462,8 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         }
         const Tuning saved = ctx->tuning[family];
         auto run = [&](Cand& cd, int reps) -> int {
-            ctx->tuning[family].rows = vec == 1 ? 1 : kTileShapes[cd.id].rows;
-            ctx->tuning[family].tpr = vec == 1 ? 64 : kTileShapes[cd.id].tpr;
+            ctx->tuning[family].rows = march_one_tile(vec) ? 1 : kTileShapes[cd.id].rows;
+            ctx->tuning[family].tpr = march_one_tile(vec) ? 64 : kTileShapes[cd.id].tpr;
             ctx->tuning[family].chunk = v.rank == 3 ? cd.chunk : 0;
             MarchConfig c;
             MarchGrid g;
@@ -539,8 +539,8 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
             MarchConfig c[FAM_COUNT];
             MarchGrid g[FAM_COUNT];
             for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) {
-                ctx->tuning[f].rows = vec == 1 ? 1 : kTileShapes[pk[f].id].rows;
-                ctx->tuning[f].tpr = vec == 1 ? 64 : kTileShapes[pk[f].id].tpr;
+                ctx->tuning[f].rows = march_one_tile(vec) ? 1 : kTileShapes[pk[f].id].rows;
+                ctx->tuning[f].tpr = march_one_tile(vec) ? 64 : kTileShapes[pk[f].id].tpr;
                 ctx->tuning[f].chunk = v.rank == 3 ? pk[f].chunk : 0;
                 PHIHIP_TRY(plan_march(ctx, v, mask_batch, has_flags, f, &c[f], &g[f]));
             }

@@ -18,16 +18,25 @@ constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {
 // Elements per thread along the fast axis: 16 bytes when the rows allow (n2 a multiple of 16 B / sizeof(T), 16-byte-aligned buffers); fp32 rows of
 // EVEN length take 8-byte vectors (V = 2: the code path of the fp64 kernels; 250^3, 190^3 ... run 20-37 % slower on the scalar instantiation,
 // profiles/r03_size_scan_ragged_rows.jsonl); everything else V = 1.
+// r4: rows that are not whole 16-byte vectors (255^3 ...) and buffers that are not 16-byte aligned take the UNAL instantiation -- 16-byte vectors
+// at element alignment, the partial vector at the end of a row loaded early and rotated (stencil_march.hpp) -- reported as a NEGATIVE width
+// (-4 fp32, -2 fp64); the scalar instantiation is left with rows shorter than two vectors. (255^3 ran 19 % below 256^3 on the scalar kernels.)
 inline int march_vector_width(int n2, int esize, bool unaligned) {
     const int vmax = 16 / esize;
-    if (unaligned) return 1;
-    if (n2 % vmax == 0) return vmax;
-    return (esize == 4 && n2 % 2 == 0) ? 2 : 1;
+    if (!unaligned && n2 % vmax == 0) return vmax;
+    if (!unaligned && esize == 4 && n2 % 2 == 0) return 2;
+    // (the overlapping last vector must lie inside ONE tile -- its first cell's left neighbour has to be staged: a last tile of fewer than vmax
+    // cells, n2 mod (64 vmax) in 1 .. vmax - 1, e.g. 257-259, keeps the scalar instantiation)
+    const int rem = n2 % (64 * vmax);
+    if (rem != 0 && rem < vmax) return 1;
+    return n2 >= 2 * vmax ? -vmax : 1;
 }
-// which tile configurations are instantiated for a vector width: all for 16-byte vectors, (1,64) alone for V = 1, the three 64-thread-row tiles
-// (4,64), (1,64), (2,64) for the fp32 V = 2 kernels (128 cells per tile row)
+inline int march_vec_elems(int vec) { return vec < 0 ? -vec : vec; }          // elements per thread along the fast axis
+inline bool march_one_tile(int vec) { return vec == 1 || vec < 0; }            // only the (1, 64) tile is instantiated
+// which tile configurations are instantiated for a vector width: all for 16-byte vectors, (1,64) alone for V = 1 and for the UNAL kernels, the
+// three 64-thread-row tiles (4,64), (1,64), (2,64) for the fp32 V = 2 kernels (128 cells per tile row)
 inline bool march_tile_available(int vec, int esize, int id) {
-    if (vec == 1) return id == 5;
+    if (march_one_tile(vec)) return id == 5;
     if (vec == 2 && esize == 4) return id == 4 || id == 5 || id == 6;
     return true;
 }

@@ -13,8 +13,12 @@ using InstT = float;
 constexpr bool kInstDim3 = PHIHIP_INST_DIM3 != 0;
 constexpr int kVmax = 16 / sizeof(InstT);
 
-template <int V, int R, int TPR, int MODE, bool FLAGS>
+template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false>
 static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
+    if (UNAL) {      // rows that are not whole vectors / unaligned buffers (stencil_march.hpp): one marching direction
+        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL>), grid, dim3(kBlock), 0, s, g, a);
+        return;
+    }
     // the bidirectional variant exists for 3-D MATVEC and UPDATE_R (the 3-word phases: the stencil source's halo planes weigh most there)
     constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_R;
     if (mv && kInstDim3 && g.bidir)
@@ -23,12 +27,12 @@ static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid,
         hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false>), grid, dim3(kBlock), 0, s, g, a);
 }
 
-template <int V, int R, int TPR>
+template <int V, int R, int TPR, bool UNAL = false>
 static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
 #define PHIHIP_MODE_CASE(M)                                                \
     case M:                                                                \
-        if (flags) launch_one<V, R, TPR, M, true>(g, a, grid, s);          \
-        else launch_one<V, R, TPR, M, false>(g, a, grid, s);               \
+        if (flags) launch_one<V, R, TPR, M, true, UNAL>(g, a, grid, s);    \
+        else launch_one<V, R, TPR, M, false, UNAL>(g, a, grid, s);         \
         break;
     switch (mode) {
         PHIHIP_MODE_CASE(MODE_APPLY)
@@ -50,23 +54,23 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
     return PHIHIP_OK;
 }
 
-template <int V, int R, int TPR, int MODE, bool FLAGS>
+template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false>
 static int occupancy_one() {
     // cached per process, not per device: occupancy is a property of (code object, architecture), and every device this library can run
     // on is a gfx950 with the same register file / LDS -- the devices of one node give the same answer
     static int cached = 0;
     if (cached == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL>, kBlock, 0) != hipSuccess || n < 1) n = 1;
         cached = n > 8 ? 8 : n;
     }
     return cached;
 }
 
-template <int V, int R, int TPR>
+template <int V, int R, int TPR, bool UNAL = false>
 static int occupancy_cfg(int mode, bool flags) {
 #define PHIHIP_OCC_CASE(M) \
-    case M: return flags ? occupancy_one<V, R, TPR, M, true>() : occupancy_one<V, R, TPR, M, false>();
+    case M: return flags ? occupancy_one<V, R, TPR, M, true, UNAL>() : occupancy_one<V, R, TPR, M, false, UNAL>();
     switch (mode) {
         PHIHIP_OCC_CASE(MODE_APPLY)
         PHIHIP_OCC_CASE(MODE_RESID)
@@ -87,6 +91,7 @@ static int occupancy_cfg(int mode, bool flags) {
 template <>
 int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
     if (vec == 1) return occupancy_cfg<1, 1, 64>(mode, flags);
+    if (vec < 0) return occupancy_cfg<kVmax, 1, 64, true>(mode, flags);
     if (vec == 2 && kVmax == 4) {
         switch (id) {
             case 4: return occupancy_cfg<(kVmax == 4 ? 2 : kVmax), 4, 64>(mode, flags);
@@ -127,6 +132,7 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
     }
     dim3 grid(g.nblk, c.batch);
     if (c.vec == 1) return launch_cfg<1, 1, 64>(mode, flags, g, a, grid, s);
+    if (c.vec < 0) return launch_cfg<kVmax, 1, 64, true>(mode, flags, g, a, grid, s);      // UNAL: ragged rows / unaligned buffers
     if (c.vec == 2 && kVmax == 4) {      // fp32 rows of even length (march_vector_width): the three 64-thread-row tiles
         switch (c.id) {
             case 4: return launch_cfg<(kVmax == 4 ? 2 : kVmax), 4, 64>(mode, flags, g, a, grid, s);

@@ -226,6 +226,49 @@ __device__ __forceinline__ void vec_store(T* p, const Vec<T, V>& x) {
     *reinterpret_cast<Vec<T, V>*>(p) = x;
 }
 
+// ---- rows that are not whole 16-byte vectors / buffers that are not 16-byte aligned (UNAL instantiation of march_kernel, r4) -----------------
+// Global accesses take the vector at ELEMENT alignment (gfx950 serves dwordx4 at any 4-byte address), and the thread that would own the
+// partial vector at the end of a row owns the row's LAST V cells instead: its vector overlaps its left neighbour's by V - (n2 mod V) cells,
+// both compute the same bits for those cells from the same operands and store them twice, only the sums count them once. No element is
+// rotated or masked in registers (a first version that loaded the partial vector early and rotated it with selects was turned into a
+// dynamically indexed array in SCRATCH by the compiler: 80-270 bytes per lane), no byte outside the arrays is touched.
+template <typename T, int V>
+struct __attribute__((packed, aligned(sizeof(T)))) VecP {
+    T v[V];
+};
+template <typename T, int V, bool UNAL>
+__device__ __forceinline__ Vec<T, V> vec_load_g(const T* p) {
+    if (!UNAL) return *reinterpret_cast<const Vec<T, V>*>(p);
+    const VecP<T, V> t = *reinterpret_cast<const VecP<T, V>*>(p);
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = t.v[i];
+    return r;
+}
+template <typename T, int V, bool UNAL>
+__device__ __forceinline__ void vec_store_g(T* p, const Vec<T, V>& x) {
+    if (!UNAL) { *reinterpret_cast<Vec<T, V>*>(p) = x; return; }
+    VecP<T, V> t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t.v[i] = x.v[i];
+    *reinterpret_cast<VecP<T, V>*>(p) = t;
+}
+// LDS copy of the tile: vectors sit on 16-byte boundaries except the overlapping last vector of a ragged row (`odd`: element by element)
+template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> lds_load(const T* p, bool odd) {
+    if (!odd) return *reinterpret_cast<const Vec<T, V>*>(p);
+    Vec<T, V> r;
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.v[i] = p[i];
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void lds_store(T* p, const Vec<T, V>& x, bool odd) {
+    if (!odd) { *reinterpret_cast<Vec<T, V>*>(p) = x; return; }
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = x.v[i];
+}
+
 // index of the neighbour one step outside [0, n): wrap / clamp / zero ghost
 __device__ __forceinline__ int nb_index(int i, int n, int rule_lo, int rule_hi, bool& zero) {
     if (i < 0) {
@@ -333,8 +376,8 @@ constexpr int march_min_waves() {
     return (sizeof(T) == 4 && !FLAGS && R == 1 && (MODE == MODE_APPLY || MODE == MODE_RESID || MODE == MODE_MATVEC || MODE == MODE_UPDATE_R)) ? 6 : 1;
 }
 
-template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false>
-__global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
+template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false>
+__global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
     constexpr int TR = kBlock / TPR;   // thread rows
     constexpr int T1 = TR * R;         // tile rows (axis a1)
     constexpr int T2 = TPR * V;        // tile columns (axis a2)
@@ -372,7 +415,11 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     const int c0 = bid / (g.tiles2 * g.tiles1);
 
     const int tx = tid % TPR, ty = tid / TPR;
-    const int j2 = t2 * T2 + tx * V;
+    const int j2_grid = t2 * T2 + tx * V;
+    // UNAL: the thread whose vector would cross the end of the row owns the row's last V cells instead; `tsh` of them belong to its neighbour too
+    const int tsh = (UNAL && j2_grid < g.n2 && j2_grid + V > g.n2) ? j2_grid + V - g.n2 : 0;
+    const bool odd = UNAL && tsh != 0;
+    const int j2 = j2_grid - tsh;
     const int j1b = t1 * T1 + ty * R;
     const int i_begin = c0 * g.chunk;
     const int i_end = min(i_begin + g.chunk, g.n0);
@@ -423,9 +470,9 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
         }
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            A[rr] = vec_load<T, V>(pa + own_off[rr]);
-            if (IS_MV) B[rr] = vec_load<T, V>(pb + own_off[rr]);
-            if (IS_CG1) Cc[rr] = vec_load<T, V>(pc + own_off[rr]);
+            A[rr] = vec_load_g<T, V, UNAL>(pa + own_off[rr]);
+            if (IS_MV) B[rr] = vec_load_g<T, V, UNAL>(pb + own_off[rr]);
+            if (IS_CG1) Cc[rr] = vec_load_g<T, V, UNAL>(pc + own_off[rr]);
         }
     };
     VT Ra_p[R], Rb_p[R], Rc_p[R], Ra_c[R], Rb_c[R], Rc_c[R];
@@ -462,7 +509,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                 if (AD && own && ok[rr]) {
                     T sa = T(0);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) sa += S[rr].v[v] * A[rr].v[v];
+                    for (int v = 0; v < V; ++v) sa += (UNAL && v < tsh) ? T(0) : S[rr].v[v] * A[rr].v[v];      // (overlap cells: the neighbour counts them)
                     acc2 += (double)sa;
                 }
             }
@@ -483,8 +530,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     int hv_lrow = 0, hs_lcol = 0;
     int h_o = 0, hs_e = 0;    // ONE vector load per thread and source plane serves both kinds of item: offset of the 16-byte vector within a
                               // plane (0 = a harmless address for lanes that have nothing to fetch); scalar items pick element hs_e of it
+    bool hv_odd = false;          // UNAL: the halo-row vector at the end of a ragged row is the row's last V cells, like the own cells
     if (hv_role) {
-        const int jh2 = t2 * T2 + hv_col * V;
+        int jh2 = t2 * T2 + hv_col * V;
+        if (UNAL && jh2 < n2 && jh2 + V > n2) { jh2 = n2 - V; hv_odd = true; }
         const int jh1 = hv_side == 0 ? t1 * T1 - 1 : t1 * T1 + rows_here;
         hv_lrow = hv_side == 0 ? 0 : rows_here + 1;
         const int jt1 = nb_index(jh1, n1, g.nb[1][0], g.nb[1][1], hv_zero);
@@ -498,8 +547,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
         const int jt2 = nb_index(jh2, n2, g.nb[2][0], g.nb[2][1], hs_zero);
         hs_ok = jh1 < n1;
         if (hs_ok && !hs_zero) {
-            h_o = jh1 * n2 + (jt2 / V) * V;      // rows start on vector boundaries (n2 % V == 0 on the vector path)
-            hs_e = jt2 % V;
+            int vs = (jt2 / V) * V;              // rows start on vector boundaries (n2 % V == 0 on the vector path) ...
+            if (UNAL && vs + V > n2) vs = n2 - V;      // ... or the vector that ENDS with the row holds the element (UNAL; n2 >= V)
+            h_o = jh1 * n2 + vs;
+            hs_e = jt2 - vs;
         }
     }
     struct HaloRaw {
@@ -507,9 +558,9 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
     };
     auto load_halo = [&](int i, HaloRaw& H) {
         const long long poff = base + (long long)i * plane;
-        H.va = vec_load<T, V>(p.a + poff + h_o);
-        if (IS_MV) H.vb = vec_load<T, V>(p.b + poff + h_o);
-        if (IS_CG1) H.vc = vec_load<T, V>(p.c + poff + h_o);
+        H.va = vec_load_g<T, V, UNAL>(p.a + poff + h_o);
+        if (IS_MV) H.vb = vec_load_g<T, V, UNAL>(p.b + poff + h_o);
+        if (IS_CG1) H.vc = vec_load_g<T, V, UNAL>(p.c + poff + h_o);
     };
     auto combine_halo = [&](const HaloRaw& H, VT& hv, T& hs) {
         hv = H.va;
@@ -540,27 +591,28 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const long long off = poff + own_off[rr];
-            if (IS_RES) E.e1[rr] = vec_load<T, V>(p.b + off);
+            if (IS_RES) E.e1[rr] = vec_load_g<T, V, UNAL>(p.b + off);
             if (IS_UP) {
-                if (HAS_X) E.e1[rr] = vec_load<T, V>(p.o1 + off);
-                E.e2[rr] = vec_load<T, V>(p.o2 + off);
+                if (HAS_X) E.e1[rr] = vec_load_g<T, V, UNAL>(p.o1 + off);
+                E.e2[rr] = vec_load_g<T, V, UNAL>(p.o2 + off);
             }
             if (MODE == MODE_APPLY_DOT && p.c) {      // refresh of the single-reduction CG: mu, nu, sigma against the standing p and s
-                E.e1[rr] = vec_load<T, V>(p.o4 + off);
-                E.e5[rr] = vec_load<T, V>(p.c + off);
+                E.e1[rr] = vec_load_g<T, V, UNAL>(p.o4 + off);
+                E.e5[rr] = vec_load_g<T, V, UNAL>(p.c + off);
             }
             if (IS_CG1) {
-                E.e1[rr] = vec_load<T, V>(p.o4 + off);
-                E.e2[rr] = vec_load<T, V>(p.o5 + off);
-                E.e3[rr] = vec_load<T, V>(p.a + off);
-                E.e4[rr] = vec_load<T, V>(p.b + off);
-                E.e5[rr] = vec_load<T, V>(p.c + off);
+                E.e1[rr] = vec_load_g<T, V, UNAL>(p.o4 + off);
+                E.e2[rr] = vec_load_g<T, V, UNAL>(p.o5 + off);
+                E.e3[rr] = vec_load_g<T, V, UNAL>(p.a + off);
+                E.e4[rr] = vec_load_g<T, V, UNAL>(p.b + off);
+                E.e5[rr] = vec_load_g<T, V, UNAL>(p.c + off);
             }
             if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + (fbase - base) + off);
         }
     };
     // destination of a store: the cell's slot, or the dump slot for lanes outside the grid
     auto dst = [&](T* arr, long long off, int rr) -> T* { return ok[rr] ? arr + off : p.dump; };
+    auto put = [&](T* arr, long long off, int rr, const VT& val) { vec_store_g<T, V, UNAL>(dst(arr, off, rr), val); };
 
     // ---- prologue ---------------------------------------------------------------------------------------------------
     VT Sp[R], Sc[R], Sn[R];
@@ -582,7 +634,7 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
 
     int buf = 0;
     const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
-    const int lcol = V + tx * V;             // LDS column of this thread's vector
+    const int lcol = V + tx * V - tsh;       // LDS column of this thread's vector
 
     // Sp = the plane behind, Sn = the plane ahead in marching direction (the a0 stencil is symmetric in them)
     const unsigned bit_behind = step > 0 ? 1u : 2u, bit_ahead = step > 0 ? 2u : 1u;
@@ -604,8 +656,8 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
         T* L = lds[buf];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr)
-            if (ok[rr]) vec_store<T, V>(L + (lrow0 + rr) * LS + lcol, Sc[rr]);
-        if (hv_ok) vec_store<T, V>(L + hv_lrow * LS + V + hv_col * V, hv_c);
+            if (ok[rr]) lds_store<T, V>(L + (lrow0 + rr) * LS + lcol, Sc[rr], odd);
+        if (hv_ok) lds_store<T, V>(L + hv_lrow * LS + V + hv_col * V - (hv_odd ? t2 * T2 + hv_col * V + V - n2 : 0), hv_c, hv_odd);
         if (hs_ok) L[(hs_row + 1) * LS + hs_lcol] = hs_c;
         __syncthreads();
 
@@ -614,10 +666,10 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
         for (int rr = 0; rr < R; ++rr) {
             const int lr = lrow0 + rr;
             VT up, dn;
-            if (rr > 0) up = Sc[rr - 1]; else up = vec_load<T, V>(L + (lr - 1) * LS + lcol);
+            if (rr > 0) up = Sc[rr - 1]; else up = lds_load<T, V>(L + (lr - 1) * LS + lcol, odd);
             bool dn_reg = false;
             if (rr < R - 1) dn_reg = (j1b + rr + 1 < n1);
-            if (dn_reg) dn = Sc[rr < R - 1 ? rr + 1 : rr]; else dn = vec_load<T, V>(L + (lr + 1) * LS + lcol);
+            if (dn_reg) dn = Sc[rr < R - 1 ? rr + 1 : rr]; else dn = lds_load<T, V>(L + (lr + 1) * LS + lcol, odd);
             const T lf = L[lr * LS + lcol - 1];
             const T rt = L[lr * LS + lcol + V];
             VT q;
@@ -652,23 +704,28 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                 }
                 q.v[v] = r;
             }
+            // UNAL: the cells this vector shares with its left neighbour count once -- `cnt` is 0 for them (the stores keep the full values)
+            T cnt[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) cnt[v] = (UNAL && v < tsh) ? T(0) : T(1);
+            auto once = [&](int v, T x) -> T { return UNAL ? cnt[v] * x : x; };
             const long long off = poff + own_off[rr];
             T s1 = T(0), s2 = T(0);   // this row's contributions to the two dot products
             if (IS_AP) {
-                vec_store<T, V>(dst(p.o1, off, rr), q);
+                put(p.o1, off, rr, q);
                 if (MODE == MODE_APPLY_DOT) {
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        s1 += Sc[rr].v[v] * Sc[rr].v[v];
-                        s2 += q.v[v] * Sc[rr].v[v];
+                        s1 += once(v, Sc[rr].v[v] * Sc[rr].v[v]);
+                        s2 += once(v, q.v[v] * Sc[rr].v[v]);
                     }
                     if (p.c && ok[rr]) {
                         T t3 = T(0), t4 = T(0), t5 = T(0);
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
-                            t3 += Sc[rr].v[v] * Ec.e5[rr].v[v];          // r . s
-                            t4 += q.v[v] * Ec.e1[rr].v[v];               // (A r) . p
-                            t5 += Ec.e1[rr].v[v] * Ec.e5[rr].v[v];       // p . s
+                            t3 += once(v, Sc[rr].v[v] * Ec.e5[rr].v[v]);          // r . s
+                            t4 += once(v, q.v[v] * Ec.e1[rr].v[v]);               // (A r) . p
+                            t5 += once(v, Ec.e1[rr].v[v] * Ec.e5[rr].v[v]);       // p . s
                         }
                         acc3 += (double)t3; acc4 += (double)t4; acc5 += (double)t5;
                     }
@@ -680,24 +737,24 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     pn.v[v] = fma(beta_cg, Ec.e1[rr].v[v], Ec.e3[rr].v[v]);       // p = r + beta p
                     sn.v[v] = fma(beta_cg, Ec.e5[rr].v[v], Ec.e4[rr].v[v]);       // s = w + beta s  (= A p)
                     xn.v[v] = fma(-beta, pn.v[v], Ec.e2[rr].v[v]);                // x += alpha p   (beta holds -alpha here)
-                    s1 += Sc[rr].v[v] * Sc[rr].v[v];                  // gamma' = |r_new|^2
-                    s2 += q.v[v] * Sc[rr].v[v];                       // delta' = (A r_new) . r_new
+                    s1 += once(v, Sc[rr].v[v] * Sc[rr].v[v]);                  // gamma' = |r_new|^2
+                    s2 += once(v, q.v[v] * Sc[rr].v[v]);                       // delta' = (A r_new) . r_new
                 }
                 if (ok[rr]) {
                     T t3 = T(0), t4 = T(0), t5 = T(0);
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        t3 += Sc[rr].v[v] * sn.v[v];                  // mu' = r_new . s
-                        t4 += q.v[v] * pn.v[v];                       // nu' = (A r_new) . p
-                        t5 += pn.v[v] * sn.v[v];                      // sigma = p . s
+                        t3 += once(v, Sc[rr].v[v] * sn.v[v]);                  // mu' = r_new . s
+                        t4 += once(v, q.v[v] * pn.v[v]);                       // nu' = (A r_new) . p
+                        t5 += once(v, pn.v[v] * sn.v[v]);                      // sigma = p . s
                     }
                     acc3 += (double)t3; acc4 += (double)t4; acc5 += (double)t5;
                 }
-                vec_store<T, V>(dst(p.o4, off, rr), pn);
-                vec_store<T, V>(dst(p.o3, off, rr), sn);
-                vec_store<T, V>(dst(p.o5, off, rr), xn);
-                vec_store<T, V>(dst(p.o1, off, rr), Sc[rr]);
-                vec_store<T, V>(dst(p.o2, off, rr), q);
+                put(p.o4, off, rr, pn);
+                put(p.o3, off, rr, sn);
+                put(p.o5, off, rr, xn);
+                put(p.o1, off, rr, Sc[rr]);
+                put(p.o2, off, rr, q);
             } else if (IS_RES) {
                 VT r, yb;
 #pragma unroll
@@ -709,15 +766,15 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                         yb.v[v] = y;
                     }
                     r.v[v] = y - q.v[v];
-                    s1 += r.v[v] * r.v[v];
-                    s2 += y * y;
+                    s1 += once(v, r.v[v] * r.v[v]);
+                    s2 += once(v, y * y);
                 }
-                if (MODE == MODE_RESID_BAL) vec_store<T, V>(dst(p.yout, off, rr), yb);
-                vec_store<T, V>(dst(p.o1, off, rr), r);
+                if (MODE == MODE_RESID_BAL) put(p.yout, off, rr, yb);
+                put(p.o1, off, rr, r);
             } else if (IS_MV) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) s1 += Sc[rr].v[v] * q.v[v];
-                vec_store<T, V>(dst(p.o1, off, rr), Sc[rr]);
+                for (int v = 0; v < V; ++v) s1 += once(v, Sc[rr].v[v] * q.v[v]);
+                put(p.o1, off, rr, Sc[rr]);
             } else {
                 VT xn, rn;
 #pragma unroll
@@ -725,11 +782,11 @@ __global__ __launch_bounds__(kBlock, (march_min_waves<T, R, MODE, FLAGS>())) voi
                     if (MODE == MODE_UPDATE_X2) xn.v[v] = Ec.e1[rr].v[v] + beta * (Sc[rr].v[v] - Ec.e2[rr].v[v]) + alpha * Sc[rr].v[v];
                     else if (HAS_X) xn.v[v] = Ec.e1[rr].v[v] + alpha * Sc[rr].v[v];
                     rn.v[v] = Ec.e2[rr].v[v] - alpha * q.v[v];
-                    s1 += rn.v[v] * rn.v[v];
-                    if (AD) s2 += rn.v[v] * q.v[v];
+                    s1 += once(v, rn.v[v] * rn.v[v]);
+                    if (AD) s2 += once(v, rn.v[v] * q.v[v]);
                 }
-                if (HAS_X) vec_store<T, V>(dst(p.o1, off, rr), xn);
-                vec_store<T, V>(dst(p.o2, off, rr), rn);
+                if (HAS_X) put(p.o1, off, rr, xn);
+                put(p.o2, off, rr, rn);
             }
             if (ok[rr]) {   // lanes outside the grid computed on garbage (possibly NaN): keep them out of the sums
                 acc1 += (double)s1;

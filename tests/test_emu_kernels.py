@@ -422,8 +422,8 @@ def test_baseline_config_cases_at_toy_sizes(emu_ctx):
 
 
 def test_unaligned_buffers_take_the_scalar_path(emu_ctx):
-    """ field pointers that are not 16-byte aligned (offset views) must not reach the 16-byte vector loads: the plan falls
-    back to the scalar instantiation and the results stay those of the oracle """
+    """ field pointers that are not 16-byte aligned (offset views) must not reach the ALIGNED 16-byte vector loads: the plan falls
+    back to the element-aligned instantiation (r4: UNAL vectors; rows shorter than two vectors: scalar) and the results stay those of the oracle """
     dtype = np.float32
     dom, grid = pc.make_case((6, 20, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
     rng = np.random.default_rng(3)
@@ -475,9 +475,57 @@ def test_resident_cg_matches_oracle(emu_ctx, res, bc, batch):
         dom, grid = pc.make_case(res, bc, np.float32, batch=batch)
         pc.check_cg(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(3), max_iter=12, refresh=5, fixed_iterations=True)
         if bc[0][0] == CLO and bc[1][0] == CLO:
-            pc.check_make_incompressible(emu_ctx, MEM, dom, grid, np.float32, np.random.default_rng(6))
+            # the projection of a closed box hands the solver the UNBALANCED divergence + its mean (`shift`): the resident kernel subtracts it
+            # in its first pass and writes the balanced right-hand side back, like MODE_RESID_BAL -- ten iterations against the launch forms
+            v = pc.random_velocity(dom, batch, np.float32, np.random.default_rng(6), 0.1)
+            out = {}
+            for mode in (0, 2):
+                emu_ctx.set_resident_cg(mode)
+                dv = [MEM.to_dev(a) for a in v]
+                dp, ddiv = MEM.to_dev(np.zeros((batch,) + dom.res, np.float32)), MEM.empty((batch,) + dom.res, np.float32)
+                info = emu_ctx.make_incompressible(grid, [MEM.ptr(a) for a in dv], None, 0, 1, True, MEM.ptr(dp), MEM.ptr(ddiv),
+                                                   pc.solve_params(np.float32, 10, 0.0, 0.0, 50, 0, 0))
+                out[mode] = (MEM.to_host(dp), MEM.to_host(ddiv), [MEM.to_host(a) for a in dv], [i.iterations for i in info])
+            assert out[0][3] == out[2][3] == [10] * batch
+            assert pc.rel_l2(out[2][1], out[0][1]) <= 1e-6 and abs(float(out[2][1].mean())) <= 1e-6 * float(np.abs(out[2][1]).max())      # the balanced rhs
+            assert pc.rel_l2(pc.demean(out[2][0]), pc.demean(out[0][0])) <= 2e-5
+            assert all(pc.rel_l2(a, b_) <= 2e-5 for a, b_ in zip(out[2][2], out[0][2]))
     finally:
         emu_ctx.set_resident_cg(0)
+
+
+@pytest.mark.parametrize("res,bc", [((9, 13), ((CLO, OPN), (PER, PER))), ((5, 6, 11), ((PER, PER), (CLO, OPN), (OPN, CLO))), ((3, 5, 261), ((CLO, CLO), (PER, PER), (PER, PER))), ((2, 4, 257), ((PER, PER), (CLO, OPN), (PER, PER))),
+                                    ((4, 7, 15), ((OPN, OPN), (CLO, CLO), (CLO, CLO)))])
+def test_ragged_rows_on_the_vector_kernels(emu_ctx, res, bc):
+    """ r4: rows that are not whole 16-byte vectors take the UNAL instantiation of the marching kernels (16-byte vectors at element alignment,
+    the last vector of a row OVERLAPS its neighbour instead of being partial; the plan reports a negative vector width): every CG form on
+    the marching kernels -- two launches, single reduction, 'CG-adaptive', with obstacle flags, the balanced projection -- both dtypes;
+    261 cells = one full 256-cell tile + a second one that holds 5 cells; 257 = a second tile of ONE cell: the overlapping vector would reach
+    into the first tile, whose cells this workgroup does not stage -- such row lengths keep the scalar kernels in fp32 (fp64: 129 of its
+    128-cell tiles, so 257 = one cell after two tiles likewise); 11 / 13 / 15 = 1 / 3 / 1 cells of overlap in fp32 """
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        for dtype in (np.float32, np.float64):
+            dom, grid = pc.make_case(res, bc, dtype, batch=2)
+            vmax = 4 if dtype == np.float32 else 2
+            assert emu_ctx.query_plan(grid, False, 1)["vec"] == (1 if 0 < res[-1] % (64 * vmax) < vmax else -vmax)
+            for mode in (0, 2):
+                emu_ctx.set_single_reduction_cg(mode)
+                pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(1))
+                pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(7), max_iter=9, refresh=4, fixed_iterations=True)
+                if dtype == np.float32 and len(res) == 2:       # (tolerance mode: the emulation's minutes go here)
+                    pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(9))
+                    pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(10))
+            emu_ctx.set_single_reduction_cg(0)
+            if len(res) == 2 or dtype == np.float32:
+                pc.check_cg(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(12), max_iter=9, refresh=4, fixed_iterations=True, adaptive=True)
+            if res == (4, 7, 15) and dtype == np.float32:
+                obstacles = [pc.O.BoxObstacle(tuple(0.3 * n for n in res), tuple(0.7 * n for n in res))]
+                dom1, grid1 = pc.make_case(res, bc, dtype, batch=1)
+                pc.check_make_incompressible(emu_ctx, MEM, dom1, grid1, dtype, np.random.default_rng(11), obstacles=obstacles)
+    finally:
+        emu_ctx.set_small_grid_solver(True)
+        emu_ctx.set_single_reduction_cg(1)
 
 
 def test_autotuned_launch_plans_stay_correct(emu_library):

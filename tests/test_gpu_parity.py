@@ -38,6 +38,7 @@ GRIDS = [
     ((3, 5, 264), ((PER, PER), (CLO, CLO), (OPN, OPN))),
     ((4, 5, 24), ((OPN, OPN), (OPN, CLO), (OPN, CLO))),
     ((12, 10, 250), ((PER, PER), (CLO, OPN), (PER, PER))),  # fp32 rows of even length: the 8-byte-vector instantiation (V = 2)
+    ((10, 9, 261), ((CLO, OPN), (PER, PER), (PER, PER))),   # r4: odd rows on the UNAL vector kernels (one full 256-cell tile + five cells; (33, 31, 29) above: all-closed odd rows)
     ((40, 36, 384), ((CLO, CLO), (CLO, CLO), (CLO, CLO))),   # config-5 rows: three (1,64) fp64 tiles per row, vector gradient kernel with n2 - 1 faces
 ]
 
