@@ -5,13 +5,13 @@
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"
-O=gpurun_out/r4k; mkdir -p $O
+O=gpurun_out/${SESSION_TAG:-r4k}; mkdir -p $O
 export TMPDIR=/tmp
 python -c "from phiflow_amd import _capi as C; l=C.load_default_library(); print('build', l.build_id(), 'tree', l.built_from_tree())" > $O/build_id.txt 2>&1; cat $O/build_id.txt
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; head -c 300 $O/bench_n1.json; echo
-timeout 300 bash tools/prof_bench_stats.sh r4k/prof_bench > $O/prof_bench_summary.txt 2>&1; echo "prof_bench rc=$?"; head -6 $O/prof_bench_summary.txt
+timeout 300 bash tools/prof_bench_stats.sh ${SESSION_TAG:-r4k}/prof_bench > $O/prof_bench_summary.txt 2>&1; echo "prof_bench rc=$?"; head -6 $O/prof_bench_summary.txt
 timeout 900 bash tools/kernel_roofline.sh $O/roofline > $O/roofline.log 2>&1; tail -3 $O/roofline.log
 timeout 300 python bench.py --workload smoke256 --steps 20 --warmup 30 > $O/bench_smoke256.json 2> $O/bench_smoke256.err; echo "smoke256 rc=$?"
 timeout 300 python bench.py --workload config4 --steps 20 --warmup 5 > $O/bench_config4.json 2> $O/bench_config4.err; echo "config4 rc=$?"
