@@ -58,11 +58,7 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     // tiles beyond: same-box A/B 256^3 APPLY 27.5 -> 22 us, RESID 46 -> 40 us, but 512^3 APPLY 195 -> 224 us with MATVEC's (1,64) tile
     const bool mv_like = family == FAM_MATVEC || family == FAM_UPDATE_R || (family == FAM_APPLY && (double)v.cells * v.batch * esize <= 72e6);
 
-    auto tile_of = [&](int id, int* t1, int* t2) {
-        const int rows = march_one_tile(c->vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(c->vec) ? 64 : kTileShapes[id].tpr;
-        *t1 = kBlock / tpr * rows;
-        *t2 = tpr * march_vec_elems(c->vec);
-    };
+    auto tile_of = [&](int id, int* t1, int* t2) { march_tile_extent(c->vec, id, v.n[2], t1, t2); };
     auto tiles_of = [&](int id) -> long long {
         int t1, t2;
         tile_of(id, &t1, &t2);
@@ -140,19 +136,20 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
             set_error("tuning: no tile config with rows=%d threads_per_row=%d", t.rows, t.tpr);
             return PHIHIP_ERR_BAD_ARG;
         }
-        if (!march_tile_available(c->vec, esize, id)) id = 5;          // (a pinned tile that this vector width does not have: the full-row tile)
+        if (!march_tile_available(c->vec, esize, id, v.n[2])) id = 5;          // (a pinned tile that this vector width does not have: the full-row tile)
         chunk = best_chunk(id, &score);
     } else {
         // candidate order + a small preference factor per family (from the family sweeps): UPDATE / residual favour large tiles
         // at equal chunk length, MATVEC medium tiles and the full-row tile (1, 64)
-        static const int pref_mv[8] = {2, 5, 6, 7, 1, 0, 3, 4}, pref_up[8] = {4, 3, 6, 2, 7, 1, 0, 5};
-        static const double bonus_mv[8] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.93, 0.93}, bonus_up[8] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.98, 0.97, 0.97};
+        static const int pref_mv[kNumTileConfigs] = {2, 5, 6, 7, 1, 0, 3, 4, 8, 9, 10}, pref_up[kNumTileConfigs] = {4, 3, 6, 2, 7, 1, 0, 5, 10, 9, 8};
+        static const double bonus_mv[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.93, 0.93, 0.9, 0.9, 0.9}, bonus_up[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.98, 0.97, 0.97, 0.9, 0.9, 0.9};
+        // (the row tile is last and discounted in the ANALYTIC plan: it is the first-call autotune that decides for it, on the device)
         const int* pref = mv_like ? pref_mv : pref_up;
         const double* bonus = mv_like ? bonus_mv : bonus_up;
         double best_score = -1.0;
         for (int k = 0; k < kNumTileConfigs; ++k) {
             const int cand = pref[k];
-            if (!march_tile_available(c->vec, esize, cand)) continue;
+            if (!march_tile_available(c->vec, esize, cand, v.n[2])) continue;
             int t1, t2;
             tile_of(cand, &t1, &t2);
             const double waste = (double)tiles_of(cand) * t1 * t2 / ((double)v.n[1] * v.n[2]);
@@ -176,6 +173,11 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     // short chunks re-read a large share of source planes (2 / chunk): let neighbouring chunks meet at their common boundary
     // (256^3 MATVEC with chunk 8: -7 %; at chunk 64 the shared planes are 3 % of the traffic and the reversal only costs)
     g->bidir = ((family == FAM_MATVEC || family == FAM_UPDATE_R) && v.rank == 3 && chunk <= 16 && g->chunks0 > 1) ? 1 : 0;
+    g->tpr_rt = 0;
+    if (id >= kRowTile && !march_one_tile(c->vec)) {      // a row tile: lanes per row at run time, one marching direction
+        g->tpr_rt = v.n[2] / c->vec;
+        g->bidir = 0;
+    }
     return PHIHIP_OK;
 }
 
@@ -419,10 +421,11 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
         std::vector<Cand> cands;
         cands.push_back({c_model.id, c_model.chunk, 0.f});                      // the model's choice goes first (ties keep it)
         for (int id = 0; id < kNumTileConfigs; ++id) {
-            if (!march_tile_available(vec, esize, id)) continue;
+            if (!march_tile_available(vec, esize, id, v.n[2])) continue;
             if (v.rank != 3) {
-                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
-                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec));
+                int e1, e2;
+                march_tile_extent(vec, id, v.n[2], &e1, &e2);
+                const long long blocks = (long long)ceil_div(v.n[1], e1) * ceil_div(v.n[2], e2);
                 if (id != c_model.id && blocks <= maxblk) cands.push_back({id, 1, 0.f});
                 continue;
             }
@@ -432,8 +435,9 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
                 bool dup = false;
                 for (const Cand& o : cands) dup = dup || (o.id == id && o.chunk == ch);
                 if (dup) continue;
-                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
-                const long long blocks = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec)) * ceil_div(v.n[0], ch);
+                int e1, e2;
+                march_tile_extent(vec, id, v.n[2], &e1, &e2);
+                const long long blocks = (long long)ceil_div(v.n[1], e1) * ceil_div(v.n[2], e2) * ceil_div(v.n[0], ch);
                 // starved chip (but a little under one workgroup per CU is a candidate: 384^3 fp64 UPDATE_X2 runs fastest with 216 (4,64) workgroups of
                 // 128 planes, profiles/r03_sweep_config5.jsonl) / partial-sum lists too long
                 if (blocks * v.batch < ctx->num_cu * 3 / 4 || blocks > 8192) continue;
@@ -443,8 +447,9 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
             // 384^3 MATVEC (1,16): 1152 workgroups of 48 planes (4.5 per CU) 146 us, 1008 of 55 planes (3.9) or 1440 of 39 (5.6) 137 us
             // (profiles/r02_midsize_chunks.jsonl) -- the fixed list above has no such member for most sizes
             {
-                const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
-                const long long tiles = (long long)ceil_div(v.n[1], kBlock / tpr * rows) * ceil_div(v.n[2], tpr * march_vec_elems(vec)) * v.batch;
+                int e1, e2;
+                march_tile_extent(vec, id, v.n[2], &e1, &e2);
+                const long long tiles = (long long)ceil_div(v.n[1], e1) * ceil_div(v.n[2], e2) * v.batch;
                 const int occ = march_occupancy_any(v, id, vec, mode, has_flags);
                 for (int m = 1; m <= occ + 1; ++m) {
                     const long long target = (long long)(m <= occ ? m : 2 * occ) * ctx->num_cu;

@@ -12,8 +12,12 @@ struct TileShape {
 // 4 rows per tile: two halo rows per eight own rows (25 % extra L2 requests instead of 50 %) at ~105 instead of ~80 VGPRs
 // (1, 32) (r3): 8 rows x 128 fp32 / 64 fp64 cells at the register cost of the one-row tiles -- for rows that are multiples of 128 but not of 256
 // cells (384, 640), between (1, 16) (16 x 64: many halo columns) and (1, 64) (4 x 256: two halo rows per four own rows)
-constexpr int kNumTileConfigs = 8;
-constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}};
+// (1, 128) (r4) is the ROW tile (stencil_march.hpp ROWT): whole rows of 65 ... 128 vectors (fp32 rows of 260 ... 512 cells that are not 256 or
+// 512: 288, 320, 384, 448 ...), floor(256 / lanes per row) thread rows, no halo columns
+// (2, 128), (4, 128): the same with 2 / 4 rows per thread (a 384-cell row leaves two thread rows: 2 own rows per 2 halo rows with one row per thread)
+constexpr int kNumTileConfigs = 11;
+constexpr int kRowTile = 8;        // ids >= kRowTile are row tiles
+constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}, {1, 128}, {2, 128}, {4, 128}};
 
 // Elements per thread along the fast axis: 16 bytes when the rows allow (n2 a multiple of 16 B / sizeof(T), 16-byte-aligned buffers); fp32 rows of
 // EVEN length take 8-byte vectors (V = 2: the code path of the fp64 kernels; 250^3, 190^3 ... run 20-37 % slower on the scalar instantiation,
@@ -35,10 +39,22 @@ inline int march_vec_elems(int vec) { return vec < 0 ? -vec : vec; }          //
 inline bool march_one_tile(int vec) { return vec == 1 || vec < 0; }            // only the (1, 64) tile is instantiated
 // which tile configurations are instantiated for a vector width: all for 16-byte vectors, (1,64) alone for V = 1 and for the UNAL kernels, the
 // three 64-thread-row tiles (4,64), (1,64), (2,64) for the fp32 V = 2 kernels (128 cells per tile row)
-inline bool march_tile_available(int vec, int esize, int id) {
+inline bool march_tile_available(int vec, int esize, int id, int n2) {
+    if (id >= kRowTile) return vec == 16 / esize && n2 % vec == 0 && n2 / vec > 64 && n2 / vec <= 128;
     if (march_one_tile(vec)) return id == 5;
     if (vec == 2 && esize == 4) return id == 4 || id == 5 || id == 6;
     return true;
+}
+// extent of a tile configuration: rows (axis a1) x cells (axis a2)
+inline void march_tile_extent(int vec, int id, int n2, int* t1, int* t2) {
+    const int rows = march_one_tile(vec) ? 1 : kTileShapes[id].rows, tpr = march_one_tile(vec) ? 64 : kTileShapes[id].tpr;
+    if (id >= kRowTile && !march_one_tile(vec)) {
+        *t1 = 256 / (n2 / vec) * rows;
+        *t2 = n2;
+        return;
+    }
+    *t1 = 256 / tpr * rows;
+    *t2 = tpr * march_vec_elems(vec);
 }
 
 struct MarchConfig {

@@ -13,26 +13,26 @@ using InstT = float;
 constexpr bool kInstDim3 = PHIHIP_INST_DIM3 != 0;
 constexpr int kVmax = 16 / sizeof(InstT);
 
-template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false>
+template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false, bool ROWT = false>
 static void launch_one(const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
-    if (UNAL) {      // rows that are not whole vectors / unaligned buffers (stencil_march.hpp): one marching direction
-        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL>), grid, dim3(kBlock), 0, s, g, a);
-        return;
+    if constexpr (UNAL || ROWT) {      // rows that are not whole vectors / unaligned buffers, and the row tile (stencil_march.hpp): one marching direction
+        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL, ROWT>), grid, dim3(kBlock), 0, s, g, a);
+    } else {
+        // the bidirectional variant exists for 3-D MATVEC and UPDATE_R (the 3-word phases: the stencil source's halo planes weigh most there)
+        constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_R;
+        if (mv && kInstDim3 && g.bidir)
+            hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (mv && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
+        else
+            hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false>), grid, dim3(kBlock), 0, s, g, a);
     }
-    // the bidirectional variant exists for 3-D MATVEC and UPDATE_R (the 3-word phases: the stencil source's halo planes weigh most there)
-    constexpr bool mv = MODE == MODE_MATVEC || MODE == MODE_MATVEC_AD || MODE == MODE_UPDATE_R;
-    if (mv && kInstDim3 && g.bidir)
-        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, (mv && kInstDim3)>), grid, dim3(kBlock), 0, s, g, a);
-    else
-        hipLaunchKernelGGL((march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false>), grid, dim3(kBlock), 0, s, g, a);
 }
 
-template <int V, int R, int TPR, bool UNAL = false>
+template <int V, int R, int TPR, bool UNAL = false, bool ROWT = false>
 static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
 #define PHIHIP_MODE_CASE(M)                                                \
     case M:                                                                \
-        if (flags) launch_one<V, R, TPR, M, true, UNAL>(g, a, grid, s);    \
-        else launch_one<V, R, TPR, M, false, UNAL>(g, a, grid, s);         \
+        if (flags) launch_one<V, R, TPR, M, true, UNAL, ROWT>(g, a, grid, s);    \
+        else launch_one<V, R, TPR, M, false, UNAL, ROWT>(g, a, grid, s);         \
         break;
     switch (mode) {
         PHIHIP_MODE_CASE(MODE_APPLY)
@@ -54,23 +54,23 @@ static int launch_cfg(int mode, bool flags, const MarchGrid& g, const MarchArgs<
     return PHIHIP_OK;
 }
 
-template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false>
+template <int V, int R, int TPR, int MODE, bool FLAGS, bool UNAL = false, bool ROWT = false>
 static int occupancy_one() {
     // cached per process, not per device: occupancy is a property of (code object, architecture), and every device this library can run
     // on is a gfx950 with the same register file / LDS -- the devices of one node give the same answer
     static int cached = 0;
     if (cached == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL>, kBlock, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, march_kernel<InstT, V, R, TPR, MODE, FLAGS, kInstDim3, false, UNAL, ROWT>, kBlock, 0) != hipSuccess || n < 1) n = 1;
         cached = n > 8 ? 8 : n;
     }
     return cached;
 }
 
-template <int V, int R, int TPR, bool UNAL = false>
+template <int V, int R, int TPR, bool UNAL = false, bool ROWT = false>
 static int occupancy_cfg(int mode, bool flags) {
 #define PHIHIP_OCC_CASE(M) \
-    case M: return flags ? occupancy_one<V, R, TPR, M, true, UNAL>() : occupancy_one<V, R, TPR, M, false, UNAL>();
+    case M: return flags ? occupancy_one<V, R, TPR, M, true, UNAL, ROWT>() : occupancy_one<V, R, TPR, M, false, UNAL, ROWT>();
     switch (mode) {
         PHIHIP_OCC_CASE(MODE_APPLY)
         PHIHIP_OCC_CASE(MODE_RESID)
@@ -108,6 +108,9 @@ int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
         case 5: return occupancy_cfg<kVmax, 1, 64>(mode, flags);
         case 6: return occupancy_cfg<kVmax, 2, 64>(mode, flags);
         case 7: return occupancy_cfg<kVmax, 1, 32>(mode, flags);
+        case 8: return occupancy_cfg<kVmax, 1, 128, false, true>(mode, flags);
+        case 9: return occupancy_cfg<kVmax, 2, 128, false, true>(mode, flags);
+        case 10: return occupancy_cfg<kVmax, 4, 128, false, true>(mode, flags);
         default: return 1;
     }
 }
@@ -152,6 +155,9 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
         case 5: return launch_cfg<kVmax, 1, 64>(mode, flags, g, a, grid, s);
         case 6: return launch_cfg<kVmax, 2, 64>(mode, flags, g, a, grid, s);
         case 7: return launch_cfg<kVmax, 1, 32>(mode, flags, g, a, grid, s);
+        case 8: return launch_cfg<kVmax, 1, 128, false, true>(mode, flags, g, a, grid, s);      // the row tiles (lanes per row: g.tpr_rt)
+        case 9: return launch_cfg<kVmax, 2, 128, false, true>(mode, flags, g, a, grid, s);
+        case 10: return launch_cfg<kVmax, 4, 128, false, true>(mode, flags, g, a, grid, s);
         default:
             set_error("march: bad tile config %d", c.id);
             return PHIHIP_ERR_BAD_ARG;

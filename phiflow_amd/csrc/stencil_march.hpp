@@ -160,6 +160,7 @@ struct MarchGrid {
     int tiles1, tiles2, chunks0, chunk, nblk;
     int flags_per_batch;   // 1: flags array has a batch dimension, 0: shared by all batch entries
     int bidir;             // 1: launch the BIDIR instantiation: odd chunks march down (short chunks share their boundary planes in time)
+    int tpr_rt;            // ROWT instantiation: lanes per row (n2 / V), else 0
 };
 
 template <typename T>
@@ -376,14 +377,23 @@ constexpr int march_min_waves() {
     return (sizeof(T) == 4 && !FLAGS && R == 1 && (MODE == MODE_APPLY || MODE == MODE_RESID || MODE == MODE_MATVEC || MODE == MODE_UPDATE_R)) ? 6 : 1;
 }
 
-template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false>
+// ROWT (r4), the ROW tile: a tile spans WHOLE rows whose vector count is not a power of two -- 72 ... 128 lanes per row for 288 ... 512-cell
+// fp32 rows, TPR is then the upper bound (128) and MarchGrid::tpr_rt the count in use; the workgroup holds floor(256 / tpr_rt) thread
+// rows, the remaining threads idle. No halo COLUMNS exist: the neighbours beyond a row's ends are read from the row's own LDS copy with
+// the boundary rule (wrap / clamp / zero). Why: the power-of-two tiles cannot span a 288- ... 448-cell row, and their halo columns are what
+// the mid-size dip is made of (1.49 fabric read requests per needed one at 320^3 against 1.13 at 512^3).
+template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false, bool ROWT = false>
 __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
-    constexpr int TR = kBlock / TPR;   // thread rows
-    constexpr int T1 = TR * R;         // tile rows (axis a1)
-    constexpr int T2 = TPR * V;        // tile columns (axis a2)
-    constexpr int LS = T2 + 2 * V;     // LDS row stride; interior starts at column V so vector accesses stay aligned
-    constexpr int LROWS = T1 + 2;
-    static_assert(2 * TPR + 2 * T1 <= kBlock, "halo items must fit one per thread");
+    constexpr int TRc = ROWT ? kBlock / (TPR / 2 + 1) : kBlock / TPR;   // thread rows (ROWT: at most -- rows of more than TPR / 2 lanes)
+    constexpr int T1c = TRc * R;       // tile rows (axis a1)
+    constexpr int T2c = TPR * V;       // tile columns (axis a2)
+    constexpr int LS = T2c + 2 * V;    // LDS row stride; interior starts at column V so vector accesses stay aligned
+    constexpr int LROWS = T1c + 2;
+    static_assert(ROWT || 2 * TPR + 2 * T1c <= kBlock, "halo items must fit one per thread");
+    static_assert(!(ROWT && (UNAL || BIDIR)), "the row tile exists for aligned rows and one marching direction");
+    const int tpr = ROWT ? g.tpr_rt : TPR;                      // lanes per row
+    const int T1 = ROWT ? (kBlock / tpr) * R : T1c;
+    const int T2 = ROWT ? g.n2 : T2c;
     using VT = Vec<T, V>;
     using VF = Vec<uint8_t, V>;
     constexpr bool IS_CG1 = MODE == MODE_CG1;
@@ -414,7 +424,8 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
     const int t1 = (bid / g.tiles2) % g.tiles1;
     const int c0 = bid / (g.tiles2 * g.tiles1);
 
-    const int tx = tid % TPR, ty = tid / TPR;
+    const int tx = tid % tpr, ty = tid / tpr;
+    const bool lane_on = !ROWT || ty < kBlock / tpr;             // ROWT: the threads behind the last whole thread row idle
     const int j2_grid = t2 * T2 + tx * V;
     // UNAL: the thread whose vector would cross the end of the row owns the row's last V cells instead; `tsh` of them belong to its neighbour too
     const int tsh = (UNAL && j2_grid < g.n2 && j2_grid + V > g.n2) ? j2_grid + V - g.n2 : 0;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
     int own_off[R];        // in-plane element offset of the thread's vector in its row rr
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
-        ok[rr] = (j2 < n2) && (j1b + rr < n1);
+        ok[rr] = lane_on && (j2 < n2) && (j1b + rr < n1);
         own_off[rr] = ok[rr] ? (j1b + rr) * n2 + j2 : 0;
     }
     const long long plane = (long long)n1 * n2;
@@ -519,10 +530,10 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
     // vector items: rows just below / above the tile; scalar items: columns just left / right of the tile
-    const bool hv_role = tid < 2 * TPR;
-    const int hv_side = tid / TPR, hv_col = tid % TPR;
-    const int hs_idx = tid - 2 * TPR;
-    const bool hs_role = hs_idx >= 0 && hs_idx < 2 * T1;
+    const bool hv_role = tid < 2 * tpr;
+    const int hv_side = tid / tpr, hv_col = tid % tpr;
+    const int hs_idx = tid - 2 * tpr;
+    const bool hs_role = !ROWT && hs_idx >= 0 && hs_idx < 2 * T1;      // (the row tile has no halo columns)
     const int hs_side = hs_idx / T1, hs_row = hs_idx % T1;
     const int rows_here = min(T1, n1 - t1 * T1);   // valid rows of this tile
     const int cols_here = min(T2, n2 - t2 * T2);   // valid columns of this tile
@@ -633,6 +644,15 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
     load_extra(i_first, En);
 
     int buf = 0;
+    // ROWT: LDS columns of the left / right neighbour of this thread's vector (inside the row: the adjacent cells; at its ends: wrap / clamp / zero)
+    int rt_lf_col[2] = {0, 0};
+    bool rt_lf_zero[2] = {false, false};
+    if (ROWT) {
+        const int jl = nb_index(j2 - 1, n2, g.nb[2][0], g.nb[2][1], rt_lf_zero[0]);
+        const int jr = nb_index(j2 + V, n2, g.nb[2][0], g.nb[2][1], rt_lf_zero[1]);
+        rt_lf_col[0] = V + jl;
+        rt_lf_col[1] = V + jr;
+    }
     const int lrow0 = ty * R + 1;            // LDS row of this thread's first own row
     const int lcol = V + tx * V - tsh;       // LDS column of this thread's vector
 
@@ -670,8 +690,14 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
             bool dn_reg = false;
             if (rr < R - 1) dn_reg = (j1b + rr + 1 < n1);
             if (dn_reg) dn = Sc[rr < R - 1 ? rr + 1 : rr]; else dn = lds_load<T, V>(L + (lr + 1) * LS + lcol, odd);
-            const T lf = L[lr * LS + lcol - 1];
-            const T rt = L[lr * LS + lcol + V];
+            T lf, rt;
+            if (!ROWT) {
+                lf = L[lr * LS + lcol - 1];
+                rt = L[lr * LS + lcol + V];
+            } else {      // the cells beyond the ends of the row: its own LDS copy under the boundary rule
+                lf = rt_lf_zero[0] ? T(0) : L[lr * LS + rt_lf_col[0]];
+                rt = rt_lf_zero[1] ? T(0) : L[lr * LS + rt_lf_col[1]];
+            }
             VT q;
 #pragma unroll
             for (int v = 0; v < V; ++v) {

@@ -348,14 +348,33 @@ def test_tile_configurations_agree(emu_ctx):
     dtype = np.float32
     dom, grid = pc.make_case((5, 36, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
     try:
-        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)]:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32), (1, 128), (2, 128), (4, 128)]:      # (., 128): the row tiles (66 lanes per row here)
             for chunk in (2, 5):
                 emu_ctx.set_tuning(rows, tpr, chunk)
                 pc.check_laplace(emu_ctx, MEM, dom, grid, dtype, np.random.default_rng(11))
         emu_ctx.set_tuning(4, 32, 3)
         pc.check_cg(emu_ctx, MEM, dom, grid, dtype, rng, max_iter=8, fixed_iterations=True)
+        # the row tile (r4): whole rows of 66 / 72 lanes, three thread rows per workgroup, no halo columns -- every boundary rule at the row's ends,
+        # a ragged last tile (36 and 10 rows in tiles of 3), both CG forms, flags, fp64 (rows of 66 vectors of two)
+        for res, bc, dt in (((5, 36, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), np.float32), ((4, 10, 288), ((PER, PER), (CLO, CLO), (PER, PER)), np.float32),
+                            ((3, 7, 264), ((OPN, OPN), (OPN, CLO), (OPN, OPN)), np.float32), ((4, 9, 132), ((PER, PER), (CLO, OPN), (CLO, OPN)), np.float64)):
+            dom, grid = pc.make_case(res, bc, dt, batch=2)
+            emu_ctx.set_small_grid_solver(False)
+            for rows in (1, 2, 4):
+                emu_ctx.set_tuning(rows, 128, 2)
+                plan = emu_ctx.query_plan(grid, False, 1)
+                assert plan["tpr"] == 128 and plan["rows"] == rows
+                for mode in ((0, 2) if rows == 1 else (0,)):
+                    emu_ctx.set_single_reduction_cg(mode)
+                    pc.check_laplace(emu_ctx, MEM, dom, grid, dt, np.random.default_rng(11))
+                    pc.check_cg(emu_ctx, MEM, dom, grid, dt, np.random.default_rng(12), max_iter=9, refresh=4, fixed_iterations=True)
+            emu_ctx.set_tuning(1, 128, 2)
+        dom1, grid1 = pc.make_case((6, 7, 264), ((CLO, CLO),) * 3, np.float32, batch=1)
+        pc.check_make_incompressible(emu_ctx, MEM, dom1, grid1, np.float32, np.random.default_rng(13), obstacles=[pc.O.BoxObstacle((2.0, 2.0, 80.0), (4.0, 5.0, 180.0))])
     finally:
         emu_ctx.set_tuning(0, 0, 0)
+        emu_ctx.set_small_grid_solver(True)
+        emu_ctx.set_single_reduction_cg(1)
 
 
 def test_bad_arguments_are_reported(emu_ctx, emu_library):
