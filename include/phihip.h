@@ -329,7 +329,9 @@ typedef enum phihip_kernel_id {
 int phihip_profile_enable(phihip_ctx* ctx, int enable);
 /* synchronises, then returns launches and summed milliseconds per family since the last reset */
 int phihip_profile_read(phihip_ctx* ctx, int32_t launches[PHIHIP_K_COUNT], double total_ms[PHIHIP_K_COUNT], int reset);
-/* tile configuration of the CG marching kernels: rows per thread (1,2,4) and threads per row (16,32,64); 0 = auto */
+/* tile configuration of the CG marching kernels: rows per thread (1,2,4) and threads per row (16,32,64); threads_per_row = 128 selects the ROW
+ * tile (r4: whole rows of 65 ... 128 16-byte vectors, the lane count per row taken from the grid, no halo columns -- available for such rows
+ * only, otherwise the full-width tile (1, 64) is used); 0 = auto */
 int phihip_set_tuning(phihip_ctx* ctx, int rows_per_thread, int threads_per_row, int chunk_planes);
 /* the same for one kernel family only: 0 = operator apply / residual, 1 = MATVEC (d = r + beta d; d.Ad), 2 = UPDATE (x, r) */
 int phihip_set_tuning_kernel(phihip_ctx* ctx, int family, int rows_per_thread, int threads_per_row, int chunk_planes);

@@ -520,7 +520,7 @@ bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint
     return G * v.batch <= ctx->num_cu;
 #else
     (void)ctx;
-    return G * v.batch <= 64;         // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory for 1024-fiber blocks
+    return G * v.batch <= 16;         // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory: 1024 fibers of 256 KB stack per block
 #endif
 }
 

@@ -21,7 +21,7 @@ constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {
 
 // Elements per thread along the fast axis: 16 bytes when the rows allow (n2 a multiple of 16 B / sizeof(T), 16-byte-aligned buffers); fp32 rows of
 // EVEN length take 8-byte vectors (V = 2: the code path of the fp64 kernels; 250^3, 190^3 ... run 20-37 % slower on the scalar instantiation,
-// profiles/r03_size_scan_ragged_rows.jsonl); everything else V = 1.
+// profiles/r03_size_scan_ragged_rows.jsonl); everything else took V = 1 until r4:
 // r4: rows that are not whole 16-byte vectors (255^3 ...) and buffers that are not 16-byte aligned take the UNAL instantiation -- 16-byte vectors
 // at element alignment, the partial vector at the end of a row loaded early and rotated (stencil_march.hpp) -- reported as a NEGATIVE width
 // (-4 fp32, -2 fp64); the scalar instantiation is left with rows shorter than two vectors. (255^3 ran 19 % below 256^3 on the scalar kernels.)

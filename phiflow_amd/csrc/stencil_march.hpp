@@ -14,6 +14,8 @@
 //   MATVEC  S = r + beta * d_old   d_new = S                       sum S * (A S)        (q = A d is never stored)
 //   UPDATE  S = d                  x += alpha S ; r -= alpha A S   sum r_new^2          (q recomputed from d)
 // so one CG iteration moves 3 + 5 = 8 words per cell through HBM instead of the textbook 10-11.
+// Variants of the same source (template flags, r4): UNAL -- rows that are not whole vectors / unaligned buffers (element-aligned global vectors,
+// the last vector of a row overlaps its neighbour); ROWT -- tiles of WHOLE rows with a run-time lane count per row and no halo columns.
 // UPDATE_R / UPDATE_X2 halve the traffic of `x`: the solution does not enter the recurrence, so every other iteration skips it
 // (UPDATE_R: r -= alpha A S only, 3 words) and the next one adds both steps at once -- the previous search direction is recovered
 // from operands the kernel reads anyway, d_k = (d_{k+1} - r_{k+1}) / beta_{k+1}:
