@@ -513,7 +513,7 @@ static size_t resident_lds_bytes(int vpt) {
 // can the resident solver take this solve? (2-D fp32 'CG' without cell flags, rows of whole vectors up to 1024 cells, batch x G workgroups <= CUs)
 bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
     if (v.rank != 2 || v.dtype != PHIHIP_F32 || flags || v.unaligned || v.halo[0] || v.halo[1]) return false;
-    if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 500000) return false;      // (the phase number has 20 bits of the tag)
+    if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 200000) return false;      // (the phase number has 20 bits of the tag: up to 4 phases per iteration with refresh_every = 1)
     if (v.n[2] % 4 != 0 || v.n[2] > 512 || v.n[1] < 2) return false;      // (rows up to 1024 cells would need VPT = 4: 80 state registers, spills at 128)
     const long long G = (v.n[1] + kResRows - 1) / kResRows;
 #if defined(__HIPCC__)
