@@ -22,11 +22,13 @@ CASES = [((512, 512), 1), ((512, 512), 8), ((256, 256), 8), ((256, 256), 16), ((
 
 def main():
     dev = torch.device("cuda:0")
-    lib = C.load_default_library()
+    alt = os.environ.get("PHIHIP_SWEEP_LIB", "")          # another build of the library (A/B of experiments)
+    lib = C.Library(alt, strict=False) if alt else C.load_default_library()
     ctx = C.Context(lib, 0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-    for res, batch in CASES:
-        for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC)):
+    cases = CASES if not os.environ.get("PHIHIP_SWEEP_SHORT") else [((512, 512), 1), ((512, 512), 8), ((256, 256), 16), ((384, 384), 4)]
+    for res, batch in cases:
+        for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC))[: (1 if os.environ.get("PHIHIP_SWEEP_SHORT") else 2)]:
             D = len(res)
             grid = C.make_grid(D, C.PHIHIP_F32, batch, res, (0.0,) * D, tuple(float(n) for n in res), ((bc, bc),) * D)
             rhs = torch.randn(batch, *res, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=torch.float32)
