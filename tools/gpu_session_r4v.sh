@@ -4,7 +4,7 @@
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"
-O=gpurun_out/r4v; mkdir -p $O
+O=gpurun_out/${SESSION_TAG:-r4v}; mkdir -p $O
 export TMPDIR=/tmp PHIHIP_SWEEP_SHORT=1
 : > $O/sweep_rows16.jsonl
 for ROUND in 1 2; do
