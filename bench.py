@@ -124,7 +124,7 @@ class SmokeBatchStep:
         self.rel = torch.zeros(1, device=device, dtype=torch.float64)
         self.solve = C.Solve(0.0, 0.0, cg_iters, 50, 0, 0)
         self.s_bc = ((C.BC_OPEN, C.BC_OPEN),) * 2            # ZERO_GRADIENT smoke
-        self.stream = int(torch.cuda.current_stream(device).cuda_stream)
+        self.stream = int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0
 
     def step(self, allreduce=None):
         ctx, s, g = self.ctx, self.stream, self.grid
@@ -172,7 +172,7 @@ class Smoke3DStep:
         self.s_bc = ((C.BC_OPEN, C.BC_OPEN),) * 3            # ZERO_GRADIENT smoke
         self.dt = 1.0
         self.kdt = 0.01 * self.dt
-        self.stream = int(torch.cuda.current_stream(device).cuda_stream)
+        self.stream = int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0
 
     def ops(self):
         """ the step as (name, callable) pairs; buffers rotate v -> v2 -> v -> v2 (advect out of place, diffuse out of place) """
@@ -201,6 +201,30 @@ class Smoke3DStep:
 
 
 _RECORD_FD = None
+
+
+# ---- what a launch needs of the machine. bench.py has NO CPU path: these raise / use RCCL as written. tests/bench_dryrun.py replaces the four names
+# below to rehearse the driver's `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` command line on a host without GPUs (gloo, the kernel
+# sources under the fiber emulation): bookkeeping only, the record of such a run says so and is never a measurement. ----
+DIST_BACKEND = "nccl"          # = RCCL on ROCm
+
+
+def device_for_rank(local_rank: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    return device
+
+
+def load_library():
+    lib = C.load_default_library()
+    assert lib.built_from_tree(), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
+    return lib
+
+
+def device_sync(device):
+    torch.cuda.synchronize(device)
 
 
 def emit_record(record: dict):
@@ -248,7 +272,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
     ref = SmokeBatchStep(ctx, n, total, 0, total, args.cg_iters, device)          # rank 0 of a world of `total`: entry 0 alone
     for _ in range(args.warmup + args.steps + 1):
         ref.step(None)
-    torch.cuda.synchronize(device)
+    device_sync(device)
     ctx.set_autotune(True)
     shards = gather_shards(dist, world, total, its_local, ok_local, [sim.p, sim.smoke] + sim.v, [ref.p, ref.smoke] + ref.v, device)
     assert all(shards["verified_ok"]), shards["iterations_per_rank"]
@@ -256,7 +280,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         ctx.profile_enable(True)
         ctx.profile_read(reset=True)
         sim.step(None)
-        torch.cuda.synchronize(device)
+        device_sync(device)
         prof = ctx.profile_read(reset=True)
         ctx.profile_enable(False)
         cells = total * n * n
@@ -607,7 +631,7 @@ def sync_launch_plans(ctx, sim, dist, rank, device):
     if rank == 0:
         sim.step(None)
         if device.type == "cuda":
-            torch.cuda.synchronize(device)
+            device_sync(device)
         for i, f in enumerate(fams):
             q = ctx.query_plan(sim.grid, False, f)
             plans[i] = torch.tensor([q["rows"], q["tpr"], q["chunk"]], dtype=torch.int64)
@@ -707,20 +731,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
+    device = device_for_rank(local_rank)
     dist = None
     force_dist = os.environ.get("PHIHIP_BENCH_FORCE_DIST") == "1"          # lets a 1-GPU box exercise the RCCL path incl. the replica validation
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(DIST_BACKEND, rank=rank, world_size=world, **({"device_id": device} if device.type == "cuda" else {}))
 
-    lib = C.load_default_library()
-    assert lib.built_from_tree(), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
-    ctx = C.Context(lib, local_rank)
+    lib = load_library()
+    ctx = C.Context(lib, local_rank if device.type == "cuda" else 0)
     if args.resident_cg:
         ctx.set_resident_cg(args.resident_cg)
     if args.tuning:
@@ -734,7 +754,7 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        device_sync(device)
 
     if args.workload == "config4":
         return bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce)

@@ -391,7 +391,10 @@ int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cell
  * mode 0 (default): never; 1: when cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever applicable.
  * Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14 -> 11, 16 x 256^2 11.5 -> 8, 1 x 512^2 7.8 -> 7.6. Opt-in
  * because the launch has to be resident as a whole: with other streams busy on the device a workgroup may wait for a peer that has not been
- * scheduled; every wait is bounded (~1 s), the solve then fails with PHIHIP_ERR_HIP instead of hanging. */
+ * scheduled; every wait is bounded (~1 s), the solve then fails with PHIHIP_ERR_HIP instead of hanging -- the failing call itself when it
+ * asked for `info` (the only case in which the library synchronises with the launch), otherwise the NEXT resident solve of the context.
+ * r5: "applicable" asks the occupancy calculator (workgroups per CU x CUs >= batch x workgroups per entry, at most 64 per entry); a solve
+ * that does not fit takes the launch forms silently. */
 int phihip_set_resident_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or

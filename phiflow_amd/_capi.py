@@ -384,7 +384,7 @@ class Context:
                                      stream=0):
         info = (SolveInfo * grid.batch)() if want_info else None
         self.lib.check(self.lib.dll.phihip_make_incompressible_backward(
-            self.handle, ctypes.byref(grid), flags or None, int(mask_batch), int(bool(balance)), ctypes.byref(ptr3(grad_velocity)),
+            self.handle, ctypes.byref(grid), flags or None, int(mask_batch), int(balance) & DIV_BALANCE, ctypes.byref(ptr3(grad_velocity)),
             grad_pressure or None, ctypes.byref(solve), info, stream or None))
         return list(info) if want_info else None
 

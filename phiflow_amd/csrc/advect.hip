@@ -161,9 +161,15 @@ static int check_advect_sizes(const GridView& v) {
 }
 
 // reach of an LDS-staged pass of `kind`: the user's fixed setting (phihip_set_advect_halo 0 / 1 / 2 / 3), or the adaptive choice (-1, default)
-static int pass_reach(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s) {
+static long long grid_fingerprint(const GridView& v) {
+    long long h = 1469598103934665603LL;
+    const long long parts[6] = {v.n[0], v.n[1], v.n[2], v.batch, v.dtype, v.rank};
+    for (long long x : parts) h = (h ^ x) * 1099511628211LL;
+    return h ? h : 1;
+}
+static int pass_reach(phihip_ctx* ctx, const GridView& v, int kind, bool has_wide, hipStream_t s) {
     if (ctx->adv_halo >= 0) return (!has_wide && ctx->adv_halo > 1) ? 1 : ctx->adv_halo;
-    return adv_choose(ctx, kind, has_wide, s);
+    return adv_choose(ctx, kind, has_wide, grid_fingerprint(v), s);
 }
 static int pass_done(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     return ctx->adv_halo < 0 ? adv_record(ctx, kind, reach, s) : PHIHIP_OK;
@@ -175,7 +181,7 @@ int run_advect_staggered(phihip_ctx* ctx, const GridView& v, const void* const f
     bool self = true;
     for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
     if (self) {   // one launch, taps from LDS (advect_tile.hip); axes with fewer than 4 samples keep the gather kernels
-        const int reach = pass_reach(ctx, AK_SL_SELF, true, s);
+        const int reach = pass_reach(ctx, v, AK_SL_SELF, true, s);
         if (reach > 0) {
             const int st = run_advect_self_tiled(ctx, v, vel, out, dt, reach, AK_SL_SELF, s);
             if (st == PHIHIP_OK) return pass_done(ctx, AK_SL_SELF, reach, s);
@@ -209,7 +215,7 @@ int run_mac_cormack_staggered(phihip_ctx* ctx, const GridView& v, const void* co
     bool self = true;
     for (int ca = v.ax0; ca < 3; ++ca) self = self && f[ca] == vel[ca];
     if (self) {
-        const int reach = pass_reach(ctx, AK_SL_SELF, true, s);
+        const int reach = pass_reach(ctx, v, AK_SL_SELF, true, s);
         if (reach > 0) {
             const int st = run_advect_self_tiled(ctx, v, vel, tmp, dt, reach, AK_SL_SELF, s);
             if (st == PHIHIP_OK) { first_done = true; PHIHIP_TRY(pass_done(ctx, AK_SL_SELF, reach, s)); }
@@ -217,7 +223,7 @@ int run_mac_cormack_staggered(phihip_ctx* ctx, const GridView& v, const void* co
         }
     }
     if (self) {             // ... and so is the correction pass: velocity + forward pass staged in LDS windows, all components in one launch (advect_win.hip)
-        const int reach = pass_reach(ctx, AK_MC_STAG, false, s);
+        const int reach = pass_reach(ctx, v, AK_MC_STAG, false, s);
         if (reach > 0) {
             if (!first_done) {      // (the self-advection chose the gather kernels: the correction's windows still read their result)
                 LaunchScope ls(ctx, PHIHIP_K_ADVECT, s);
@@ -262,7 +268,7 @@ int run_advect_centered(phihip_ctx* ctx, const GridView& v, const void* sfield, 
     const VelGrid g = make_velgrid(v);
     const ScalarBc sb = make_scalar_bc(v, s_bc, s_val);
     {   // scalar + velocity staged in LDS windows (advect_win.hip); phihip_set_advect_halo(ctx, 0) keeps the gather kernel
-        const int reach = pass_reach(ctx, AK_SL_CEN, true, s);
+        const int reach = pass_reach(ctx, v, AK_SL_CEN, true, s);
         if (reach > 0) {
             const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, out, dt, reach, AK_SL_CEN, s);
             if (st == PHIHIP_OK) return pass_done(ctx, AK_SL_CEN, reach, s);
@@ -287,7 +293,7 @@ int run_mac_cormack_centered(phihip_ctx* ctx, const GridView& v, const void* sfi
     // writes the same buffers
     bool first_done = false;
     {
-        const int reach = pass_reach(ctx, AK_SL_CEN, true, s);
+        const int reach = pass_reach(ctx, v, AK_SL_CEN, true, s);
         if (reach > 0) {
             const int st = run_advect_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, dt, reach, AK_SL_CEN, s);
             if (st == PHIHIP_OK) { first_done = true; PHIHIP_TRY(pass_done(ctx, AK_SL_CEN, reach, s)); }
@@ -299,7 +305,7 @@ int run_mac_cormack_centered(phihip_ctx* ctx, const GridView& v, const void* sfi
         dispatch_advect_centered<0>(v, g, sb, sfield, vel, nullptr, ctx->ws_adv.ptr, dt, 0.0, s);
     }
     {
-        const int reach = pass_reach(ctx, AK_MC_CEN, true, s);
+        const int reach = pass_reach(ctx, v, AK_MC_CEN, true, s);
         if (reach > 0) {
             const int st = run_mc_correct_centered_tiled(ctx, v, sfield, sb, vel, ctx->ws_adv.ptr, out, dt, 0.5 * strength, reach, AK_MC_CEN, s);
             if (st == PHIHIP_OK) return pass_done(ctx, AK_MC_CEN, reach, s);

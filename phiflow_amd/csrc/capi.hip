@@ -110,11 +110,15 @@ static int ensure_adv_host(phihip_ctx* ctx) {
     return PHIHIP_OK;
 }
 
-int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s) {
+int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipStream_t s) {
     phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
     const bool capturing = stream_is_capturing(s);
-    if (P.pending && !capturing) {
-        PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));        // (the pass is one step old: free unless the host runs more than a step ahead)
+    if (P.fp != grid_fp) {          // another grid (SlabFluid's whole-slab and window passes, two simulations on one context): its fallback
+        P = phihip_ctx::AdvPolicy{P.ev, grid_fp};      // fraction says nothing about this one -- start from the narrow reach again
+    }
+    // The pass the count belongs to is usually a step old and its event long fired. When it has not (a host that runs ahead), the previous
+    // choice stands: the host never blocks here (hipEventSynchronize serialised host and device once per pass).
+    if (P.pending && !capturing && hipEventQuery(P.ev) == hipSuccess) {
         P.pending = false;
         const double frac = P.units > 0 ? (double)ctx->adv_host[kind] / (double)P.units : 0.0;
         if (P.last == 1) P.mode = frac > (has_wide ? 0.02 : 0.15) ? (has_wide ? 2 : 0) : 1;
@@ -127,6 +131,8 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s) {
     }
     return P.mode;
 }
+
+int ensure_adv_host_public(phihip_ctx* ctx) { return ensure_adv_host(ctx); }
 
 int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     if (stream_is_capturing(s)) return PHIHIP_OK;           // (an event record would become a node of the graph; captured passes keep their reach)
@@ -535,7 +541,8 @@ int phihip_divergence(phihip_ctx* ctx, const phihip_grid* grid, const void* cons
     PHIHIP_REQUIRE(mask_batch == 1 || mask_batch == v.batch, "mask_batch must be 1 or grid.batch");
     const void* u[3];
     remap3(v, velocity, u);
-    return run_divergence(ctx, v, u, flags, mask_batch, balance, div, s);
+    // public bit set only: 2 is the library's internal "leave the shift in ws_scalars" mode of run_divergence
+    return run_divergence(ctx, v, u, flags, mask_batch, balance & (PHIHIP_DIV_BALANCE | PHIHIP_DIV_FINITE_GUARD), div, s);
 }
 
 int phihip_laplace_apply(phihip_ctx* ctx, const phihip_grid* grid, const uint8_t* flags, int mask_batch, const void* p, void* out,
@@ -871,7 +878,7 @@ int phihip_make_incompressible_backward(phihip_ctx* ctx, const phihip_grid* grid
     void* gu[3];
     remap3w(v, grad_velocity, gu);
     note_align(v, grad_pressure); note_align(v, flags, 3u);
-    return run_project_bwd(ctx, v, flags, mask_batch, (balance & ~PHIHIP_DIV_FINITE_GUARD) ? 1 : 0, gu, grad_pressure, solve, info, s);
+    return run_project_bwd(ctx, v, flags, mask_batch, (balance & PHIHIP_DIV_BALANCE) ? 1 : 0, gu, grad_pressure, solve, info, s);
 }
 
 int phihip_diffuse_explicit(phihip_ctx* ctx, const phihip_grid* grid, const void* const velocity[3], void* const out[3],

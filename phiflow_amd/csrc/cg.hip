@@ -351,6 +351,13 @@ int run_cg_resident(phihip_ctx*, const GridView&, const void* rhs, void* x, cons
 
 static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x, const phihip_solve* solve, phihip_solve_info* info,
                             const double* shift, hipStream_t s) {
+    // A caller that passes no `info` is never synchronised with, so an aborted launch (not resident as a whole) cannot fail ITS call: the kernel
+    // raises a word in host-mapped memory and the next resident solve of the context reports it (include/phihip.h).
+    if (ctx->adv_host && ctx->adv_host[15]) {
+        ctx->adv_host[15] = 0;
+        set_error("cg (resident): an EARLIER resident solve of this context gave up (~1 s wait: the launch was not resident as a whole) -- its pressure is invalid");
+        return PHIHIP_ERR_HIP;
+    }
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
     CgState* st = (CgState*)ctx->ws_state.ptr;
     PHIHIP_TRY(run_cg_resident(ctx, v, rhs, x, solve, st, shift, s));
@@ -369,6 +376,7 @@ static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const void* rhs,
         PHIHIP_CHECK_HIP(hipStreamSynchronize(s));
         for (int b = 0; b < v.batch; ++b) {
             if (hst[b].iterations < 0) {
+                if (ctx->adv_host) ctx->adv_host[15] = 0;      // (reported here)
                 set_error("cg (resident): a workgroup waited at a barrier for ~1 s -- the launch was not resident as a whole (is another stream using the device?)");
                 return PHIHIP_ERR_HIP;
             }

@@ -58,6 +58,7 @@ struct ResArgs {
     gran_t* pub;                  // [2][batch][G][2 sides][3 arrays][ns] published boundary rows
     gran_t* part;                 // [2][batch][G][5][2] partial sums (low / high word of a double)
     int* abort_flag;              // zero at launch
+    int* abort_host;              // pinned, device-mapped: set when the launch gave up (read by the next solve of a caller that passed no `info`)
     unsigned tag_hi;              // solve number << 20: tags of an earlier solve never match
     CgState* st_out;              // [batch]
     CgParams prm;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     if (g == G - 1) { dn_g = 0; dn_kind = A.nb1_hi == NB_WRAP ? 0 : (A.nb1_hi == NB_CLAMP ? 1 : 2); }
     const bool first_row = wave == 0, last_row = wave == rows_here - 1;
     bool aborted = false;
+    if (tid == 6) bci[1] = 0;         // "a poller of this workgroup gave up" (sticky; the barrier of the initial residual lies before the first use)
 
     auto pub_ptr = [&](int slot, int gg, int side, int arr) -> gran_t* {
         return A.pub + ((((size_t)slot * A.batch + b) * G + gg) * 2 + side) * 3 * (size_t)A.ns + (size_t)arr * A.ns;
@@ -379,7 +381,13 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
                         val = double_of(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
                         break;
                     }
-                    if (++spins > kResSpinLimit || ((spins & 255u) == 0 && res_load_flag(A.abort_flag))) { res_raise_flag(A.abort_flag); break; }
+                    if (++spins > kResSpinLimit || ((spins & 255u) == 0 && res_load_flag(A.abort_flag))) {
+                        // (thread 5 may have read the global flag before this poller gave up: the workgroup's own copy is what the barrier
+                        // below orders -- without it a sum that lacks this lane's share could pass for the entry's sum)
+                        res_raise_flag(A.abort_flag);
+                        bci[1] = 1;
+                        break;
+                    }
                     res_pause();
                 }
             }
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
         if (tid == 5) bci[0] = res_load_flag(A.abort_flag);
         __syncthreads();
         sum0 = bc[0]; sum1 = bc[1]; sum2 = bc[2]; sum3 = bc[3]; sum4 = bc[4];
-        return bci[0] != 0;
+        return (bci[0] | bci[1]) != 0;
     };
 
     f4 x[VPT], r[VPT], w[VPT], s[VPT], p[VPT];
@@ -542,7 +550,16 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     for (int v = 0; v < VPT; ++v)
         if (ok[v]) f4_store(A.x + rowoff + j[v], x[v]);
     if (g == 0 && tid == 0) {
-        if (aborted) { st.diverged = 1; st.converged = 0; st.cont = 0; st.iterations = -1; }      // -1: a wait gave up (the caller reports it)
+        if (aborted) {      // -1: a wait gave up (the caller reports it)
+            st.diverged = 1; st.converged = 0; st.cont = 0; st.iterations = -1;
+            if (A.abort_host) {
+#ifdef __HIP_DEVICE_COMPILE__
+                __hip_atomic_store(A.abort_host, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+                *reinterpret_cast<volatile int*>(A.abort_host) = 1;
+#endif
+            }
+        }
         A.st_out[b] = st;
     }
 }
@@ -552,14 +569,32 @@ static size_t resident_lds_bytes(int vpt) {
     return (kResRows + 2) * ls * sizeof(float) + (5 * kResRows + 10) * sizeof(double) + 2 * sizeof(CgState) + 6 * ls * sizeof(float) + 16;
 }
 
+#if defined(__HIPCC__)
+static int resident_blocks_per_cu(const phihip_ctx* ctx, int vpt) {
+    static int cached[16][3] = {{0}};
+    int& c = cached[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0][vpt];
+    if (c == 0) {
+        int n = 0;
+        const size_t lds = resident_lds_bytes(vpt);
+        const hipError_t e = vpt == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<1>, kResBlock, lds)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<2>, kResBlock, lds);
+        c = (e == hipSuccess && n > 0) ? n : -1;
+    }
+    return c > 0 ? c : 0;
+}
+#endif
+
 // can the resident solver take this solve? (2-D fp32 'CG' without cell flags, rows of whole vectors up to 1024 cells, batch x G workgroups <= CUs)
 bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
     if (v.rank != 2 || v.dtype != PHIHIP_F32 || flags || v.unaligned || v.halo[0] || v.halo[1]) return false;
     if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 200000) return false;      // (the phase number has 20 bits of the tag: up to 4 phases per iteration with refresh_every = 1)
     if (v.n[2] % 4 != 0 || v.n[2] > 512 || v.n[1] < 2) return false;      // (rows up to 1024 cells would need VPT = 4: 80 state registers, spills at 128)
     const long long G = (v.n[1] + kResRows - 1) / kResRows;
+    if (G > kResMaxG) return false;      // (one lane per workgroup adds the entry's partial sums up: taller grids keep the launch forms)
 #if defined(__HIPCC__)
-    return G * v.batch <= ctx->num_cu;
+    // the launch must be resident as a whole: workgroups the occupancy calculator grants per CU x CUs (1024 threads at <= 128 VGPRs: one per
+    // CU today -- asked, not assumed, so that a compiler that needs more registers makes the solver fall back instead of stalling for ~1 s)
+    return G * v.batch <= (long long)resident_blocks_per_cu(ctx, v.n[2] <= 256 ? 1 : 2) * ctx->num_cu;
 #else
     (void)ctx;
     return G * v.batch <= 16;         // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory: 1024 fibers of 256 KB stack per block
@@ -607,6 +642,8 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x
     A.abort_flag = (int*)(ws + ctl_off);
     A.tag_hi = ctx->res_solve_no << 20;
     PHIHIP_CHECK_HIP(hipMemsetAsync(A.abort_flag, 0, sizeof(int), s));
+    PHIHIP_TRY(ensure_adv_host_public(ctx));
+    A.abort_host = ctx->adv_host_dev + 15;
     A.st_out = (CgState*)st_out;
     A.prm.rtol = solve->rel_tol; A.prm.atol = solve->abs_tol; A.prm.max_iter = solve->max_iterations; A.prm.pad = 0;
     A.refresh_every = solve->refresh_every;

@@ -147,12 +147,13 @@ struct phihip_ctx {
     // same state take the same path. Measured (profiles/r04_time_frow_session_f.jsonl, 256^3 fp32): semi_lagrangian(s, v) at CFL 0.5 / 1.3 /
     // 1.8: narrow 0.078 / 0.200 / 0.396 ms, wide 0.086 / 0.085 / 0.086, gather 0.105 / 0.106 / 0.107.
     struct AdvPolicy {
+        hipEvent_t ev = nullptr;
+        long long fp = 0;        // fingerprint of the grid the state below belongs to (adv_choose resets it for another grid)
         int mode = 1;            // 0 gather, 1 narrow, 2 wide
         int last = 0;            // reach of the pass that `pending` refers to
         int calls = 0;
         long long units = 0;     // (tile, plane) units of that pass
         bool pending = false;    // an event + a published count are outstanding
-        hipEvent_t ev = nullptr;
     };
     AdvPolicy adv_policy[4];      // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
     int* adv_host = nullptr;      // pinned, device-mapped: fallback count per kind
@@ -246,7 +247,8 @@ struct FixList {
 int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* list, void** dump, int kind = AK_NONE);
 // adaptive reach of the LDS-staged advection passes (advect.hip): reach for the next pass of `kind` (0 gather / 1 / 2), and the bookkeeping
 // after a windowed pass was enqueued
-int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, hipStream_t s);
+int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipStream_t s);
+int ensure_adv_host_public(phihip_ctx* ctx);     // the pinned, device-mapped words (slot 15: "a resident solve gave up")
 int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s);
 constexpr int kFixupBlocks = 2048;       // fix-up grid (8 workgroups per CU), whatever the list holds
 

@@ -30,6 +30,33 @@ def slab_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def post_p2p(specs, group):
+    """ Posts a batch of point-to-point messages, `specs` = [("send" | "recv", tensor, global peer rank), ...] in matching order, and returns
+    `wait()`. With the "nccl" (= RCCL) backend the device tensors travel as they are and `wait()` is a stream dependency. The "gloo" backend
+    has no device-tensor send / recv: device tensors are staged through host copies there (send: copied out before posting; recv: copied
+    back inside `wait()`). That path exists for tests -- two ranks sharing ONE GPU, which RCCL refuses ("duplicate GPU") -- and for
+    hosts without RCCL; it blocks the host per message, so it is not a performance path. """
+    if not specs:
+        return lambda: None
+    stage = dist.get_backend(group) == "gloo" and any(t.is_cuda for _, t, _ in specs)
+    ops, back = [], []
+    for kind, t, peer in specs:
+        buf = t
+        if stage and t.is_cuda:
+            buf = t.detach().to("cpu") if kind == "send" else torch.empty(t.shape, dtype=t.dtype, device="cpu")
+            if kind == "recv":
+                back.append((t, buf))
+        ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group))
+    pending = list(dist.batch_isend_irecv(ops))
+
+    def wait():
+        for req in pending:
+            req.wait()
+        for dev, host in back:
+            dev.copy_(host)
+    return wait
+
+
 class SlabSolver:
     """ CG on the 7-point pressure operator for a 3-D grid decomposed into x-slabs. `res`, `lower`, `upper`, `bc` describe the
     GLOBAL grid (bc = velocity boundary codes per axis side like `phihip_grid.bc`). """
@@ -79,17 +106,17 @@ class SlabSolver:
             return
         ops = []
         if self.lo_rank is not None:
-            ops += [dist.P2POp(dist.isend, self._plane(t, 0), self._global(self.lo_rank), self.group), dist.P2POp(dist.irecv, halo[0], self._global(self.lo_rank), self.group)]
+            ops += [("send", self._plane(t, 0), self._global(self.lo_rank)), ("recv", halo[0], self._global(self.lo_rank))]
         if self.hi_rank is not None:
-            ops += [dist.P2POp(dist.isend, self._plane(t, 1), self._global(self.hi_rank), self.group), dist.P2POp(dist.irecv, halo[1], self._global(self.hi_rank), self.group)]
+            ops += [("send", self._plane(t, 1), self._global(self.hi_rank)), ("recv", halo[1], self._global(self.hi_rank))]
         if self.world == 2 and self.lo_rank == self.hi_rank and self.lo_rank is not None:
             # two ranks on a periodic axis: both messages go to the same peer; order them so that lo matches the peer's hi
             ops = ops if self.rank == 0 else [ops[2], ops[3], ops[0], ops[1]]
-        pending = list(dist.batch_isend_irecv(ops)) if ops else []
-        if reduce is not None:
-            pending.append(dist.all_reduce(reduce, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for req in pending:
-            req.wait()
+        wait_planes = post_p2p(ops, self.group)
+        red = dist.all_reduce(reduce, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if reduce is not None else None
+        wait_planes()
+        if red is not None:
+            red.wait()
 
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -277,16 +304,15 @@ class SlabFluid:
         ops = []
         gr = self.solver._global
         if self.lo_rank is not None:
-            ops += [dist.P2POp(dist.isend, send_down, gr(self.lo_rank), self.group), dist.P2POp(dist.irecv, recv_lo, gr(self.lo_rank), self.group)]
+            ops += [("send", send_down, gr(self.lo_rank)), ("recv", recv_lo, gr(self.lo_rank))]
         if self.hi_rank is not None:
-            ops += [dist.P2POp(dist.isend, send_up, gr(self.hi_rank), self.group), dist.P2POp(dist.irecv, recv_hi, gr(self.hi_rank), self.group)]
+            ops += [("send", send_up, gr(self.hi_rank)), ("recv", recv_hi, gr(self.hi_rank))]
         if self.world == 2 and self.lo_rank == self.hi_rank and self.lo_rank is not None and self.rank == 1:
             ops = [ops[2], ops[3], ops[0], ops[1]]        # two ranks on a periodic axis: match my "up" with the peer's "down"
-        pending = list(dist.batch_isend_irecv(ops))
+        wait_planes = post_p2p(ops, self.group)
 
         def finish():
-            for req in pending:
-                req.wait()
+            wait_planes()
             for side, buf, counts in ((0, recv_lo, lo_n), (1, recv_hi, hi_n)):
                 if buf is None:
                     continue

@@ -19,6 +19,33 @@ import parity_cases as pc            # noqa: E402
 from phiflow_amd import _capi as C   # noqa: E402
 
 
+def resident_arm(ctx, mem, r, seed, bc, emu):
+    """ r5: the opt-in resident solver (cg_resident.hip: the whole 2-D fp32 solve as ONE launch, paired 16-byte `sc1`
+    granules) on a random eligible grid with this case's boundary mix -- rows of whole vectors up to 512 cells, a ragged last workgroup more
+    often than not, batch x workgroups <= CUs: fixed iterations across a true-residual refresh, tolerance mode, the balanced projection. The
+    launch counters assert that the resident kernel is what ran (one launch, no MATVEC launches). """
+    n2 = 4 * int(r.integers(2, 20 if emu else 129))
+    n1 = int(r.integers(2, 60 if emu else 400))
+    G = (n1 + 15) // 16
+    batch = int(r.integers(1, max(2, min(9, (16 if emu else 256) // G + 1))))
+    dom, grid = pc.make_case((n1, n2), bc, np.float32, batch=batch)
+    try:
+        ctx.set_resident_cg(2)
+        ctx.profile_enable(True)
+        ctx.profile_read(True)
+        pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 7), max_iter=int(r.integers(3, 40)), refresh=int(r.integers(2, 12)),
+                    fixed_iterations=True)
+        prof = ctx.profile_read(True)
+        assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, f"the resident solver did not run ({n1} x {n2} x {batch}): {prof}"
+        ctx.profile_enable(False)
+        if n1 * n2 <= 40000:
+            pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 8))
+        pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 9))
+    finally:
+        ctx.profile_enable(False)
+        ctx.set_resident_cg(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0)
@@ -80,6 +107,8 @@ def main():
                 step = f"cg adaptive small={small}"; pc.check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed), refresh=20, adaptive=True)
                 step = f"make_incompressible small={small}"; pc.check_make_incompressible(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 5))
             ctx.set_small_grid_solver(True)
+            if D == 2:
+                step = "resident cg"; resident_arm(ctx, mem, r, seed, bc, args.emu)
             if dtype == np.float64 and min(res) >= 2:
                 step = "project_backward"; pc.check_project_backward(ctx, mem, dom, grid, rng)
                 step = "advect_backward"; pc.check_advect_backward(ctx, mem, dom, grid, rng, s_codes, s_consts, dt=float(r.uniform(0.1, 1.5)))

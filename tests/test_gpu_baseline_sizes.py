@@ -64,3 +64,22 @@ def test_config4_batched_smoke_8x512_vs_oracle(ctx, mem):
     rep = {}
     bc.config4_batched_smoke(ctx, mem, 512, 8, 3, 60, rep)
     print("config4 parity:", rep)
+
+
+def test_config4_batched_smoke_8x512_resident_solver_vs_oracle(ctx, mem):
+    """ BASELINE configs[3] with the opt-in resident solver INSIDE the smoke step (until r5 only a bare cg_solve and one
+    projection ran resident on the GPU): the same 3 steps / 60 iterations vs the oracle, projection from the previous pressure (x0 != 0), the
+    balance shift folded into the resident kernel's first pass; the launch counters assert that the resident kernel is what solved """
+    rep = {}
+    try:
+        ctx.set_resident_cg(2)
+        ctx.profile_enable(True)
+        ctx.profile_read(True)
+        bc.config4_batched_smoke(ctx, mem, 512, 8, 3, 60, rep)
+        prof = ctx.profile_read(True)
+        assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 3, prof       # one resident launch per projection, no launch-per-iteration kernels
+    finally:
+        ctx.profile_enable(False)
+        ctx.set_resident_cg(0)
+    print("config4 parity (resident solver):", rep)
+

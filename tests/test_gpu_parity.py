@@ -403,14 +403,57 @@ def test_tile_configurations_agree(ctx, mem):
     dtype = np.float32
     dom, grid = pc.make_case((20, 72, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), dtype, batch=1)
     try:
-        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32)]:
+        for rows, tpr in [(1, 16), (2, 16), (2, 32), (4, 32), (4, 64), (1, 64), (2, 64), (1, 32), (1, 128), (2, 128), (4, 128)]:      # (., 128): the ROW tiles (66 lanes per row here)
             for chunk in (3, 20):
                 ctx.set_tuning(rows, tpr, chunk)
+                if tpr == 128:
+                    plan = ctx.query_plan(grid, False, 1)
+                    assert plan["tpr"] == 128 and plan["rows"] == rows, plan       # the row tile really is what runs (not a silent substitute)
                 pc.check_laplace(ctx, mem, dom, grid, dtype, np.random.default_rng(11))
         ctx.set_tuning(4, 32, 7)
         pc.check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=8, fixed_iterations=True)
     finally:
         ctx.set_tuning(0, 0, 0)
+
+
+@pytest.mark.parametrize("res,bc,dt", [
+    ((20, 72, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), np.float32),      # 66 vectors per row, mixed boundaries at the row's ends
+    ((12, 40, 288), ((PER, PER), (CLO, CLO), (PER, PER)), np.float32),      # 72 lanes, ragged last tile (40 rows in tiles of 3)
+    ((9, 21, 384), ((OPN, OPN), (OPN, CLO), (OPN, OPN)), np.float32),       # 96 lanes: two thread rows per workgroup
+    ((40, 36, 384), ((CLO, CLO),) * 3, np.float32),                         # the size class the first-call autotune picks row tiles for
+    ((8, 19, 132), ((PER, PER), (CLO, OPN), (CLO, OPN)), np.float64),       # fp64: rows of 66 vectors of two
+    ((6, 30, 192), ((CLO, CLO),) * 3, np.float64),                          # fp64, 96 lanes
+])
+def test_row_tiles_on_the_gpu(ctx, mem, res, bc, dt):
+    """ the ROWT instantiation of march_kernel (tile ids 8-10: whole rows of 65 ... 128 vectors, run-time lanes per row,
+    no halo columns -- the r4 kernels that carry 288^3 ... 448^3) pinned DETERMINISTICALLY on the hardware: every row-tile shape with the plan
+    asserted, the operator, fixed-iteration CG in both forms incl. a true-residual refresh, cell flags (obstacle) and fp64 -- the GPU mirror of
+    tests/test_emu_kernels.py::test_tile_configurations_agree. Reference: phi/physics/fluid.py:165-202 (masked_laplace), :156 (solve_linear). """
+    dom, grid = pc.make_case(res, bc, dt, batch=2)
+    try:
+        ctx.set_small_grid_solver(False)
+        for rows in (1, 2, 4):
+            for chunk in (2, 7):
+                ctx.set_tuning(rows, 128, chunk)
+                for flags in (False, True):
+                    plan = ctx.query_plan(grid, flags, 1)
+                    assert plan["tpr"] == 128 and plan["rows"] == rows, plan
+                pc.check_laplace(ctx, mem, dom, grid, dt, np.random.default_rng(11))
+            for mode in ((0, 2) if rows == 1 else (0,)):
+                ctx.set_single_reduction_cg(mode)
+                pc.check_cg(ctx, mem, dom, grid, dt, np.random.default_rng(12), max_iter=9, refresh=4, fixed_iterations=True)
+            ctx.set_single_reduction_cg(0)
+        # cell flags on a row tile: projection around a box obstacle (closed boxes only: the obstacle must not touch an open side's ghost)
+        if all(lo == CLO and hi == CLO for lo, hi in bc):
+            ctx.set_tuning(2, 128, 5)
+            n = res
+            ob = pc.O.BoxObstacle(tuple(0.3 * x for x in n), tuple(0.55 * x for x in n))
+            dom1, grid1 = pc.make_case(res, bc, dt, batch=1, upper=tuple(float(x) for x in n))
+            pc.check_make_incompressible(ctx, mem, dom1, grid1, dt, np.random.default_rng(13), obstacles=[ob])
+    finally:
+        ctx.set_tuning(0, 0, 0)
+        ctx.set_single_reduction_cg(1)
+        ctx.set_small_grid_solver(True)
 
 
 # ---- full-size properties (BASELINE.json sizes; the oracle is too slow there) ----------------------------------------
