@@ -1033,78 +1033,142 @@ __device__ __forceinline__ unsigned obstacles_near(const double (*box)[6], int c
     return near;
 }
 
+// r5: the patches a launch visits are those of the obstacles' INDEX-SPACE bounding box (all obstacles of the launch together), per lattice
+// (slot ca = the faces of component ca; the cell lattice uses slot 2). Until r4 every launch walked every patch of the grid and rejected
+// them one by one -- 65 536 patches per component at 256^3 for two small obstacles: apply_boundary_conditions cost 3 x 0.13 ms of which 6 %
+// of the samples were touched; the cell mask 0.11 ms. A moving obstacle pays this every step (Moving_Obstacles / Rotating_Bar notebooks).
+struct PatchBox {
+    int i0[3], n0[3];        // first plane, planes
+    int p1[3], np1[3];       // first patch row, patch rows
+    int p2[3], np2[3];       // first patch column, patch columns
+    int first[4];            // running patch count: slot l owns [first[l], first[l + 1])
+};
+
+// slot `l`: samples of component `ca` (ca >= 0) or cell centres (ca < 0) within `margin` of any obstacle of the set; conservative by one
+// sample per side (the kernels repeat the exact per-patch test)
+static void patch_box_slot(const GridView& v, const ObstacleSet& set, int ca, double margin, int l, PatchBox* pb) {
+    int lo_i[3] = {0, 0, 0}, hi_i[3] = {0, 0, 0};
+    bool empty = set.count == 0;
+    for (int a = 0; a < 3 && !empty; ++a) {
+        const int n = ca >= 0 ? v.cn[ca][a] : v.n[a];
+        if (a < v.ax0) { lo_i[a] = 0; hi_i[a] = 0; continue; }
+        double lo = 1e300, hi = -1e300;
+        for (int k = 0; k < set.count; ++k) {
+            if ((set.skip[k] >> a) & 1) { lo = -1e300; hi = 1e300; break; }
+            double h = set.kind[k] == PHIHIP_OBSTACLE_SPHERE ? set.half[k][v.ax0] : set.half[k][a];
+            if (set.rotated[k]) {
+                double r2 = 0;
+                for (int c = v.ax0; c < 3; ++c) r2 += set.half[k][c] * set.half[k][c];
+                h = sqrt(r2);
+            }
+            lo = fmin(lo, set.center[k][a] - h);
+            hi = fmax(hi, set.center[k][a] + h);
+        }
+        const double shift = (ca >= 0 && a == ca) ? (double)v.off[a] : 0.5;     // position of sample i: lower + (i + shift) dx
+        const double flo = (lo - margin - v.lower[a]) / v.dx[a] - shift, fhi = (hi + margin - v.lower[a]) / v.dx[a] - shift;
+        long long il = flo < -1e9 ? 0 : (flo > 1e9 ? (long long)n : (long long)floor(flo) - 1);
+        long long ih = fhi > 1e9 ? (long long)n - 1 : (fhi < -1e9 ? -1 : (long long)ceil(fhi) + 1);
+        il = il < 0 ? 0 : il;
+        ih = ih > n - 1 ? n - 1 : ih;
+        if (ih < il) { empty = true; break; }
+        lo_i[a] = (int)il; hi_i[a] = (int)ih;
+    }
+    if (empty) {
+        pb->i0[l] = pb->p1[l] = pb->p2[l] = 0;
+        pb->n0[l] = pb->np1[l] = pb->np2[l] = 0;
+    } else {
+        pb->i0[l] = lo_i[0]; pb->n0[l] = hi_i[0] - lo_i[0] + 1;
+        pb->p1[l] = lo_i[1] / kPatchRows; pb->np1[l] = hi_i[1] / kPatchRows - pb->p1[l] + 1;
+        pb->p2[l] = lo_i[2] / kPatchCols; pb->np2[l] = hi_i[2] / kPatchCols - pb->p2[l] + 1;
+    }
+}
+
+// patch number -> (slot, plane, first row, first column); uniform
+__device__ __forceinline__ void decode_box_patch(const PatchBox& pb, int patch, int& l, int& i0, int& r0, int& c0) {
+    l = patch >= pb.first[2] ? 2 : (patch >= pb.first[1] ? 1 : 0);
+    const int q = patch - pb.first[l];
+    const int np2 = pb.np2[l], np1 = pb.np1[l];
+    const int t = q / np2;
+    c0 = (pb.p2[l] + (q - t * np2)) * kPatchCols;
+    const int i = t / np1;
+    r0 = (pb.p1[l] + (t - i * np1)) * kPatchRows;
+    i0 = pb.i0[l] + i;
+}
+
 // r3: (4 x 64)-cell patches decoded without integer division (the 64-bit div / mod per cell and the fp64 geometry of EVERY obstacle for
 // EVERY cell made the obstacle kernels run at 1-8 % of the HBM rate); a patch evaluates only the obstacles whose bounding box it touches.
 __global__ __launch_bounds__(kBlock) void obstacle_accessible_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s,
-                                                                     int first_launch, uint8_t* accessible, int patches1, int patches2) {
+                                                                     PatchBox pb, uint8_t* accessible) {
     const double lower[3] = {lower0, lower1, lower2};
     __shared__ double box[kObstaclesPerLaunch][6];
     obstacle_boxes(s, g.ax0, box);
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
-    const int npatch = g.n[0] * patches1 * patches2;
+    const int npatch = pb.first[3];
     for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-        int i0, r0, c0;
-        decode_patch(patch, patches1, patches2, i0, r0, c0);
+        int l, i0, r0, c0;
+        decode_box_patch(pb, patch, l, i0, r0, c0);
         const int first[3] = {i0, r0, c0};
         const int last[3] = {i0, min(r0 + kPatchRows, g.n[1]) - 1, min(c0 + kPatchCols, g.n[2]) - 1};
         double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         for (int a = g.ax0; a < 3; ++a) { lo[a] = lower[a] + (first[a] + 0.5) * g.dx[a]; hi[a] = lower[a] + (last[a] + 0.5) * g.dx[a]; }
         const unsigned near = obstacles_near(box, s.count, lo, hi, 1e-9 * (hi[2] - lo[2] + g.dx[2]));
         const int idx[3] = {i0, r0 + ty, c0 + tx};
-        if (idx[1] >= g.n[1] || idx[2] >= g.n[2]) continue;
-        if (!near && !first_launch) continue;            // nothing to change in this patch
+        if (!near || idx[1] >= g.n[1] || idx[2] >= g.n[2]) continue;            // nothing to change in this patch (the array starts as all ones)
         const long long cell = ((long long)i0 * g.n[1] + idx[1]) * g.n[2] + idx[2];
         bool inside = false;
-        if (near) {
-            double x[3] = {0, 0, 0};
-            for (int a = g.ax0; a < 3; ++a) x[a] = lower[a] + (idx[a] + 0.5) * g.dx[a];
-            for (int k = 0; k < s.count; ++k)
-                if ((near >> k) & 1u) inside = inside || obstacle_inside(s, k, x, g.ax0);
-        }
-        const uint8_t prev = first_launch ? (uint8_t)1 : accessible[cell];
-        accessible[cell] = inside ? (uint8_t)0 : prev;
+        double x[3] = {0, 0, 0};
+        for (int a = g.ax0; a < 3; ++a) x[a] = lower[a] + (idx[a] + 0.5) * g.dx[a];
+        for (int k = 0; k < s.count; ++k)
+            if ((near >> k) & 1u) inside = inside || obstacle_inside(s, k, x, g.ax0);
+        if (inside) accessible[cell] = (uint8_t)0;
     }
 }
 
 int run_obstacle_accessible(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, uint8_t* accessible, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
-    const int patches1 = ceil_div(v.n[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols);
-    const long long npatch = (long long)v.n[0] * patches1 * patches2;
-    PHIHIP_REQUIRE(npatch < (1LL << 31), "obstacle_accessible: grid too large");
-    const int nblk = npatch < 16384 ? (int)npatch : 16384;
+    PHIHIP_REQUIRE((long long)v.n[0] * ceil_div(v.n[1], kPatchRows) * ceil_div(v.n[2], kPatchCols) < (1LL << 31), "obstacle_accessible: grid too large");
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    int first = 0;
-    do {
+    // accessible = ~union(geometries) (fluid.py:130-133): everything is accessible, then every launch clears the cells inside its obstacles --
+    // and visits the patches of their bounding box only (r5)
+    PHIHIP_CHECK_HIP(hipMemsetAsync(accessible, 1, (size_t)v.cells, s));
+    for (int first = 0; first < count;) {
         const int n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
         const ObstacleSet set = make_obstacle_set(v, obs, first, n);
-        hipLaunchKernelGGL(obstacle_accessible_kernel, dim3(nblk), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set,
-                           first == 0 ? 1 : 0, accessible, patches1, patches2);
+        PatchBox pb;
+        memset(&pb, 0, sizeof(pb));
+        patch_box_slot(v, set, -1, 1e-6 * (v.dx[2] + v.dx[1]), 2, &pb);
+        const long long np = (long long)pb.n0[2] * pb.np1[2] * pb.np2[2];
+        pb.first[0] = pb.first[1] = pb.first[2] = 0;
+        pb.first[3] = (int)np;
+        if (np > 0) {
+            const int nblk = np < 4096 ? (int)np : 4096;
+            hipLaunchKernelGGL(obstacle_accessible_kernel, dim3(nblk), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set, pb, accessible);
+        }
         first += n;
-    } while (first < count);
+    }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s, int ca,
-                                                                 T* __restrict__ vc, int patches1, int patches2) {
+__global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, double lower0, double lower1, double lower2, ObstacleSet s, PatchBox pb,
+                                                                 Comp3<T> vel) {
     const double lower[3] = {lower0, lower1, lower2};
     const int b = blockIdx.y;
-    const long long total = g.ccells[ca];
-    const int c0n = g.cn[ca][0], c1 = g.cn[ca][1], c2 = g.cn[ca][2];
     double r2 = 0;   // bounding radius of a face cell: |half size of a grid cell|
     for (int a = g.ax0; a < 3; ++a) r2 += 0.25 * g.dx[a] * g.dx[a];
     const double radius = sqrt(r2);
-    T* __restrict__ V = vc + (long long)b * total;
     __shared__ double box[kObstaclesPerLaunch][6];
     obstacle_boxes(s, g.ax0, box);
     const int tx = threadIdx.x & (kPatchCols - 1), ty = threadIdx.x / kPatchCols;
-    const int npatch = c0n * patches1 * patches2;
-    // position of sample i along axis a: faces of the component's own axis, cell centres otherwise
-    auto pos = [&](int a, int i) -> double { return a == ca ? lower[a] + (double)(i + g.off[a]) * g.dx[a] : lower[a] + (i + 0.5) * g.dx[a]; };
+    const int npatch = pb.first[3];
     for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
-        int i0, r0, cc0;
-        decode_patch(patch, patches1, patches2, i0, r0, cc0);
+        int ca, i0, r0, cc0;
+        decode_box_patch(pb, patch, ca, i0, r0, cc0);          // slot = component (uniform)
+        const int c1 = g.cn[ca][1], c2 = g.cn[ca][2];
+        T* __restrict__ V = (ca == 0 ? vel.p[0] : (ca == 1 ? vel.p[1] : vel.p[2])) + (long long)b * g.ccells[ca];
+        // position of sample i along axis a: faces of the component's own axis, cell centres otherwise
+        auto pos = [&](int a, int i) -> double { return a == ca ? lower[a] + (double)(i + g.off[a]) * g.dx[a] : lower[a] + (i + 0.5) * g.dx[a]; };
         const int first[3] = {i0, r0, cc0};
         const int last[3] = {i0, min(r0 + kPatchRows, c1) - 1, min(cc0 + kPatchCols, c2) - 1};
         double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
@@ -1153,6 +1217,9 @@ __global__ __launch_bounds__(kBlock) void apply_obstacles_kernel(VelGrid g, doub
 int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacle* obs, int count, void* const vel[3], hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    double r2 = 0;
+    for (int a = v.ax0; a < 3; ++a) r2 += 0.25 * v.dx[a] * v.dx[a];
+    const double radius = sqrt(r2);
     for (int first = 0, n = 0; first < count; first += n) {
         n = count - first < kObstaclesPerLaunch ? count - first : kObstaclesPerLaunch;
         // a union is applied by ONE launch: do not cut inside a group
@@ -1162,17 +1229,27 @@ int run_apply_obstacles(phihip_ctx* ctx, const GridView& v, const phihip_obstacl
             return PHIHIP_ERR_UNSUPPORTED;
         }
         const ObstacleSet set = make_obstacle_set(v, obs, first, n);
-        for (int ca = v.ax0; ca < 3; ++ca) {
-            const int patches1 = ceil_div(v.cn[ca][1], kPatchRows), patches2 = ceil_div(v.cn[ca][2], kPatchCols);
-            const long long npatch = (long long)v.cn[ca][0] * patches1 * patches2;
-            PHIHIP_REQUIRE(npatch < (1LL << 31), "apply_obstacles: grid too large");
-            const int nblk = npatch < 16384 ? (int)npatch : 16384;
-            if (v.dtype == PHIHIP_F64)
-                hipLaunchKernelGGL(apply_obstacles_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
-                                   v.lower[2], set, ca, (double*)vel[ca], patches1, patches2);
-            else
-                hipLaunchKernelGGL(apply_obstacles_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1],
-                                   v.lower[2], set, ca, (float*)vel[ca], patches1, patches2);
+        // r5: ONE launch for all components (fluid.py:212-240 is one call), over the patches of the obstacles' bounding box only
+        PatchBox pb;
+        memset(&pb, 0, sizeof(pb));
+        long long total = 0;
+        for (int ca = 0; ca < 3; ++ca) {
+            pb.first[ca] = (int)total;
+            if (ca >= v.ax0) {
+                patch_box_slot(v, set, ca, radius * 1.00001, ca, &pb);
+                total += (long long)pb.n0[ca] * pb.np1[ca] * pb.np2[ca];
+            }
+            PHIHIP_REQUIRE(total < (1LL << 31), "apply_obstacles: grid too large");
+        }
+        pb.first[3] = (int)total;
+        if (total == 0) continue;
+        const int nblk = total < 4096 ? (int)total : 4096;
+        if (v.dtype == PHIHIP_F64) {
+            Comp3<double> c{{(double*)vel[0], (double*)vel[1], (double*)vel[2]}};
+            hipLaunchKernelGGL(apply_obstacles_kernel<double>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set, pb, c);
+        } else {
+            Comp3<float> c{{(float*)vel[0], (float*)vel[1], (float*)vel[2]}};
+            hipLaunchKernelGGL(apply_obstacles_kernel<float>, dim3(nblk, v.batch), dim3(kBlock), 0, s, g, v.lower[0], v.lower[1], v.lower[2], set, pb, c);
         }
     }
     PHIHIP_CHECK_HIP(hipGetLastError());
@@ -1222,16 +1299,174 @@ __global__ __launch_bounds__(kBlock) void cellflags_kernel(VelGrid g, const uint
     }
 }
 
+// r5: W dwords = 4 W consecutive cells of a row per thread. The r4 kernel read seven single bytes per cell and wrote one: 64-byte requests per
+// wavefront, the a1 / a0 neighbour rows fetched by other wavefronts again -- PMC 3.0x the bytes, 120 us at 256^3 (0.03 of the HBM rate). Here a thread
+// loads the five byte vectors (self, a0 -+, a1 -+) as W dwords each + the two bytes beyond the row ends of its vector, forms the six face bits
+// and the active bit of its cells with byte-parallel integer operations and stores W dwords. Bytes are normalised to 0 / 1 first (a user mask
+// may hold any non-zero value).
+__device__ __forceinline__ unsigned nz_bytes(unsigned v) {      // 0x01 in every byte of v that is non-zero
+    return ((((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u) >> 7;
+}
+
+template <int W>
+struct ByteVec {
+    unsigned w[W];
+};
+struct alignas(16) U4 {
+    unsigned x, y, z, w;
+};
+template <int W>
+__device__ __forceinline__ ByteVec<W> load_bytes(const uint8_t* p) {
+    ByteVec<W> r;
+    if (W == 4) {
+        const U4 q = *reinterpret_cast<const U4*>(p);
+        r.w[0] = q.x; r.w[1 % W] = q.y; r.w[2 % W] = q.z; r.w[3 % W] = q.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; ++i) r.w[i] = reinterpret_cast<const unsigned*>(p)[i];
+    }
+    return r;
+}
+
+template <int W>
+__global__ __launch_bounds__(kBlock) void cellflags_vec_kernel(VelGrid g, const uint8_t* accessible, const uint8_t* active, int per_batch,
+                                                               uint8_t* flags, int patches1, int patches2, int ltpr) {
+    constexpr int V = 4 * W;
+    const int b = blockIdx.y;
+    const long long mb = per_batch ? (long long)b * g.cells : 0;
+    const uint8_t* __restrict__ A = accessible ? accessible + mb : nullptr;
+    // a patch = (256 >> ltpr) rows x (1 << ltpr) threads of V cells: a 256-cell row is 16 threads of 16 cells -- with the fixed 64-thread rows of
+    // the other patch kernels three quarters of the lanes had no cells
+    const int tx = threadIdx.x & ((1 << ltpr) - 1), ty = threadIdx.x >> ltpr;
+    const int prow = kBlock >> ltpr;
+    const int npatch = g.n[0] * patches1 * patches2;
+    const int n0 = g.n[0], n1 = g.n[1], n2 = g.n[2];
+    const long long stride0 = (long long)n1 * n2;
+    // outside value per (axis, side) for non-periodic sides: _accessible_extrapolation -- BOUNDARY (open) -> ONE, constant (closed) -> ZERO
+    auto outside = [&](int ax, int side) -> unsigned { return g.bc[ax][side] == PHIHIP_BC_OPEN ? 0x01010101u : 0u; };
+    for (int patch = blockIdx.x; patch < npatch; patch += gridDim.x) {
+        const int t = patch / patches2;
+        const int i0 = t / patches1;
+        const int i1 = (t - i0 * patches1) * prow + ty, i2 = (((patch - t * patches2) << ltpr) + tx) * V;
+        if (i1 >= n1 || i2 >= n2) continue;
+        const long long cell = (long long)i0 * stride0 + (long long)i1 * n2 + i2;
+        ByteVec<W> self, nb[3][2];
+        unsigned endl = 0, endr = 0;          // the bytes left of the first / right of the last cell of this vector
+        if (A) {
+            self = load_bytes<W>(A + cell);
+#pragma unroll
+            for (int i = 0; i < W; ++i) self.w[i] = nz_bytes(self.w[i]);
+            // a0 and a1 neighbours: whole vectors of the neighbouring plane / row
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                if (ax < g.ax0) continue;
+                const int idx = ax == 0 ? i0 : i1, n = ax == 0 ? n0 : n1;
+                const long long st = ax == 0 ? stride0 : (long long)n2;
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int j = idx + (side ? 1 : -1);
+                    if (j < 0 || j >= n) {
+                        if (g.bc[ax][side] == PHIHIP_BC_PERIODIC) {
+                            nb[ax][side] = load_bytes<W>(A + cell + (j < 0 ? (long long)(n - 1) : (long long)(1 - n)) * st);
+#pragma unroll
+                            for (int i = 0; i < W; ++i) nb[ax][side].w[i] = nz_bytes(nb[ax][side].w[i]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < W; ++i) nb[ax][side].w[i] = outside(ax, side);
+                        }
+                    } else {
+                        nb[ax][side] = load_bytes<W>(A + cell + (side ? st : -st));
+#pragma unroll
+                        for (int i = 0; i < W; ++i) nb[ax][side].w[i] = nz_bytes(nb[ax][side].w[i]);
+                    }
+                }
+            }
+            const long long row = cell - i2;
+            if (i2 > 0) endl = A[cell - 1] ? 1u : 0u;
+            else endl = g.bc[2][0] == PHIHIP_BC_PERIODIC ? (A[row + n2 - 1] ? 1u : 0u) : (outside(2, 0) & 1u);
+            if (i2 + V < n2) endr = A[cell + V] ? 1u : 0u;
+            else endr = g.bc[2][1] == PHIHIP_BC_PERIODIC ? (A[row] ? 1u : 0u) : (outside(2, 1) & 1u);
+        } else {
+            // no obstacle mask: every cell accessible; only the domain boundary shapes the bits
+#pragma unroll
+            for (int i = 0; i < W; ++i) self.w[i] = 0x01010101u;
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                const int idx = ax == 0 ? i0 : i1, n = ax == 0 ? n0 : n1;
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int j = idx + (side ? 1 : -1);
+                    const unsigned val = (j < 0 || j >= n) && g.bc[ax][side] != PHIHIP_BC_PERIODIC ? outside(ax, side) : 0x01010101u;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) nb[ax][side].w[i] = val;
+                }
+            }
+            endl = i2 > 0 || g.bc[2][0] == PHIHIP_BC_PERIODIC ? 1u : (outside(2, 0) & 1u);
+            endr = i2 + V < n2 || g.bc[2][1] == PHIHIP_BC_PERIODIC ? 1u : (outside(2, 1) & 1u);
+        }
+        // a2 neighbours: the vector shifted by one byte either way
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const unsigned prev = i > 0 ? self.w[i - 1] >> 24 : endl;
+            const unsigned next = i + 1 < W ? self.w[i + 1] & 0xffu : endr;
+            nb[2][0].w[i] = (self.w[i] << 8) | prev;
+            nb[2][1].w[i] = (self.w[i] >> 8) | (next << 24);
+        }
+        ByteVec<W> act;
+        if (active) {
+            act = load_bytes<W>(active + mb + cell);
+#pragma unroll
+            for (int i = 0; i < W; ++i) act.w[i] = nz_bytes(act.w[i]) & self.w[i];
+        } else {
+            act = self;
+        }
+        unsigned out[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            unsigned f = act.w[i] << 6;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                if (ax < g.ax0) continue;
+                f |= (self.w[i] & nb[ax][0].w[i]) << (2 * ax);
+                f |= (self.w[i] & nb[ax][1].w[i]) << (2 * ax + 1);
+            }
+            out[i] = f;
+        }
+        if (W == 4) {
+            *reinterpret_cast<U4*>(flags + mb + cell) = U4{out[0], out[1 % W], out[2 % W], out[3 % W]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < W; ++i) reinterpret_cast<unsigned*>(flags + mb + cell)[i] = out[i];
+        }
+    }
+}
+
 int run_build_cellflags(phihip_ctx* ctx, const GridView& v, const uint8_t* accessible, const uint8_t* active, int mask_batch,
                         uint8_t* flags, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
     PHIHIP_REQUIRE(v.cells < (1LL << 31), "build_cellflags: more than 2^31 cells per batch entry are not supported");
-    const int patches1 = ceil_div(v.n[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols);
-    const long long npatch = (long long)v.n[0] * patches1 * patches2;
-    const int nblk = npatch < 16384 ? (int)npatch : 16384;
     LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-    hipLaunchKernelGGL(cellflags_kernel, dim3(nblk, mask_batch > 1 ? mask_batch : 1), dim3(kBlock), 0, s, g, accessible, active,
-                       mask_batch > 1 ? 1 : 0, flags, patches1, patches2);
+    const dim3 gridy(1, mask_batch > 1 ? mask_batch : 1);
+    auto aligned = [](const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    // rows of whole 16-byte (4-byte) vectors at aligned addresses: the byte-parallel kernel; anything else the one-byte-per-thread kernel
+    const int W = (v.n[2] % 16 == 0 && aligned(accessible, 16) && aligned(active, 16) && aligned(flags, 16)) ? 4
+                : ((v.n[2] % 4 == 0 && aligned(accessible, 4) && aligned(active, 4) && aligned(flags, 4)) ? 1 : 0);
+    if (W) {
+        int ltpr = 0;
+        while ((1 << ltpr) < 64 && (1 << ltpr) * 4 * W < v.n[2]) ++ltpr;          // threads per row: enough for the row, at most a wavefront
+        const int patches1 = ceil_div(v.n[1], kBlock >> ltpr), patches2 = ceil_div(v.n[2], (4 * W) << ltpr);
+        const long long npatch = (long long)v.n[0] * patches1 * patches2;
+        const int nblk = npatch < 8192 ? (int)npatch : 8192;
+        if (W == 4)
+            hipLaunchKernelGGL(cellflags_vec_kernel<4>, dim3(nblk, gridy.y), dim3(kBlock), 0, s, g, accessible, active, mask_batch > 1 ? 1 : 0, flags, patches1, patches2, ltpr);
+        else
+            hipLaunchKernelGGL(cellflags_vec_kernel<1>, dim3(nblk, gridy.y), dim3(kBlock), 0, s, g, accessible, active, mask_batch > 1 ? 1 : 0, flags, patches1, patches2, ltpr);
+    } else {
+        const int patches1 = ceil_div(v.n[1], kPatchRows), patches2 = ceil_div(v.n[2], kPatchCols);
+        const long long npatch = (long long)v.n[0] * patches1 * patches2;
+        const int nblk = npatch < 16384 ? (int)npatch : 16384;
+        hipLaunchKernelGGL(cellflags_kernel, dim3(nblk, gridy.y), dim3(kBlock), 0, s, g, accessible, active, mask_batch > 1 ? 1 : 0, flags, patches1, patches2);
+    }
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
 }

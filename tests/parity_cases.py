@@ -504,6 +504,45 @@ def check_obstacle_kernels(ctx, mem, dom, grid, dtype, rng, obstacles):
         assert err <= tol(dtype)['stencil'], f"apply_obstacles[{d}] rel err {err}"
 
 
+def check_cellflags(ctx, mem, res, bc, rng, batch_masks=1, with_active=True):
+    """ phihip_build_cellflags against a plain NumPy restatement of fluid.py:130-137 (hard_bcs = stagger(accessible, minimum) with
+    _accessible_extrapolation: periodic -> wrap, BOUNDARY -> ONE, constant -> ZERO, fluid.py:277-288; active = accessible [* user mask]) on random
+    masks whose bytes are ANY value (non-zero = set). r5: rows of whole 16-byte / 4-byte vectors take the byte-parallel kernel, others the
+    one-byte-per-thread kernel -- the caller sweeps row lengths over all three. """
+    D = len(res)
+    g1 = C.make_grid(D, C.PHIHIP_F32, max(1, batch_masks), res, (0,) * D, tuple(float(n) for n in res), bc)
+    shape = ((batch_masks,) if batch_masks > 1 else ()) + tuple(res)
+    acc = (rng.random(shape) < 0.8).astype(np.uint8) * rng.integers(1, 255, shape).astype(np.uint8)
+    act = (rng.random(shape) < 0.9).astype(np.uint8) * rng.integers(1, 255, shape).astype(np.uint8) if with_active else None
+    dacc, dact, dfl = mem.to_dev(acc), (mem.to_dev(act) if act is not None else None), mem.empty(shape, np.uint8)
+    ctx.build_cellflags(g1, mem.ptr(dacc), mem.ptr(dact) if dact is not None else 0, batch_masks if batch_masks > 1 else 1, mem.ptr(dfl))
+    mem.sync()
+    got = mem.to_host(dfl)
+    a = (acc != 0).astype(np.uint8)
+    ref = np.zeros(shape, np.uint8)
+    lead = 1 if batch_masks > 1 else 0
+    for d in range(D):
+        ax = d + lead
+        for side in (0, 1):
+            code = bc[d][side]
+            if code == PER:
+                other = np.roll(a, 1 if side == 0 else -1, axis=ax)
+            else:
+                fill = 1 if code == OPN else 0
+                other = np.full_like(a, fill)
+                src = [slice(None)] * a.ndim
+                dst = [slice(None)] * a.ndim
+                if side == 0:
+                    src[ax], dst[ax] = slice(0, -1), slice(1, None)
+                else:
+                    src[ax], dst[ax] = slice(1, None), slice(0, -1)
+                other[tuple(dst)] = a[tuple(src)]
+            bit = 2 * (d + 3 - D) + side
+            ref |= ((a & other) << bit).astype(np.uint8)
+    ref |= ((a & ((act != 0).astype(np.uint8) if act is not None else 1)) << 6).astype(np.uint8)
+    assert np.array_equal(got, ref), f"cell flags differ at {np.argwhere(got != ref)[:4].tolist()} (res {res}, bc {bc})"
+
+
 # ---- SURVEY §8 f5: adjoint kernels against directional finite differences of the ORACLE's forward functions (fp64) ----------
 def _dot(a_list, b_list):
     return float(sum(np.vdot(a, b) for a, b in zip(a_list, b_list)))

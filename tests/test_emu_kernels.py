@@ -253,6 +253,17 @@ def test_obstacles(emu_ctx, dtype):
     pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, rng, obstacles=obstacles)
 
 
+def test_cellflags_byte_parallel_kernel(emu_ctx):
+    """ r5: the byte-parallel flag kernel (16 / 4 cells per thread) and the scalar one on random masks with arbitrary non-zero bytes, every
+    boundary kind per side, 2-D and 3-D, per-batch masks, with and without a user `active` mask """
+    rng = np.random.default_rng(31)
+    for res, bc in (((5, 9, 32), ((PER, PER), (CLO, OPN), (OPN, CLO))), ((4, 6, 80), ((CLO, CLO), (PER, PER), (PER, PER))), ((7, 64), ((OPN, OPN), (CLO, CLO))),
+                    ((6, 5, 20), ((OPN, CLO), (PER, PER), (CLO, OPN))), ((9, 12), ((PER, PER), (PER, PER))), ((3, 4, 18), ((CLO, OPN), (OPN, OPN), (PER, PER))),
+                    ((1, 1, 16), ((PER, PER), (OPN, OPN), (CLO, CLO))), ((5, 7), ((CLO, CLO), (OPN, OPN)))):
+        for masks, with_active in ((1, True), (1, False), (3, True)):
+            pc.check_cellflags(emu_ctx, MEM, res, bc, rng, masks, with_active)
+
+
 def test_obstacle_rasterisation_and_moving_obstacles(emu_ctx):
     """ overlapping box + sphere, linear and angular obstacle velocities, 2-D and 3-D, more than one launch worth """
     rng = np.random.default_rng(13)

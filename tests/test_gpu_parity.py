@@ -416,6 +416,16 @@ def test_tile_configurations_agree(ctx, mem):
         ctx.set_tuning(0, 0, 0)
 
 
+def test_cellflags_byte_parallel_kernel(ctx, mem):
+    """ r5: phihip_build_cellflags -- byte-parallel kernel (16 / 4 cells per thread) and the scalar kernel -- on random masks with arbitrary non-zero
+    bytes against the NumPy restatement of fluid.py:130-137,277-288; sizes that span many workgroups, every boundary kind, per-batch masks """
+    rng = np.random.default_rng(31)
+    for res, bc in (((40, 36, 256), ((PER, PER), (CLO, OPN), (OPN, CLO))), ((9, 70, 80), ((CLO, CLO), (PER, PER), (PER, PER))), ((300, 512), ((OPN, OPN), (CLO, CLO))),
+                    ((16, 15, 20), ((OPN, CLO), (PER, PER), (CLO, OPN))), ((33, 31, 29), ((CLO, OPN), (OPN, OPN), (PER, PER))), ((1, 1, 16), ((PER, PER), (OPN, OPN), (CLO, CLO)))):
+        for masks, with_active in ((1, True), (1, False), (2, True)):
+            pc.check_cellflags(ctx, mem, res, bc, rng, masks, with_active)
+
+
 @pytest.mark.parametrize("res,bc,dt", [
     ((20, 72, 264), ((CLO, OPN), (PER, PER), (CLO, CLO)), np.float32),      # 66 vectors per row, mixed boundaries at the row's ends
     ((12, 40, 288), ((PER, PER), (CLO, CLO), (PER, PER)), np.float32),      # 72 lanes, ragged last tile (40 rows in tiles of 3)

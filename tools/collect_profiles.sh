@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the records of one tools/gpu_session_r4k.sh run (gpurun_out/<tag>) into profiles/ under the names DESIGN.md / README.md cite
+# copies the records of one tools/sessions/gpu_session_r4k.sh run (gpurun_out/<tag>) into profiles/ under the names DESIGN.md / README.md cite
 #   bash tools/collect_profiles.sh r4m
 set -u
 cd "$(dirname "$0")/.."

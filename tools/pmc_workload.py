@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-Workload for the rocprofv3 PMC passes (run once per counter set, see tools/gpu_session.sh):
+Workload for the rocprofv3 PMC passes (run once per counter set, see tools/sessions/gpu_session.sh):
   1. calibration: a plain 16 B/lane streaming copy of a known size (torch copy_ of 512 MiB fp32) -- known bytes read/written
   2. the CG loop at the sizes given on the command line (default 512^3 and 256^3) fp32, a few iterations, default launch plan
      -- one size per profiled process keeps kernels with identical template arguments and grids apart

@@ -109,6 +109,18 @@ def main():
         "laplace_apply": (lambda: ctx.laplace_apply(grid, 0, 1, p.data_ptr(), div.data_ptr()), 2 * N * w),
         "grad_subtract": (lambda: ctx.grad_subtract(grid, 0, 1, p.data_ptr(), P(out)), (N + 2 * NV) * w),
     }
+    # f3 / a7 (r5): the mask kernels of a MOVING-obstacle step -- rasterisation, stencil flags, apply_boundary_conditions -- with the two obstacles of
+    # tools/path_workload.py (a moving box of L / 4 and a rotating sphere of radius L / 10)
+    if D == 3:
+        obs = C.make_obstacles([dict(kind=C.OBSTACLE_BOX, center=(L / 2, L / 2, L / 2), half_size=(L / 8, L / 8, L / 8), velocity=(0.1, 0, 0), angular_velocity=(0, 0, 0)),
+                                dict(kind=C.OBSTACLE_SPHERE, center=(L / 4, L / 4, L / 4), half_size=(L / 10, L / 10, L / 10), velocity=(0, 0, 0), angular_velocity=(0, 0, 0.2))])
+        acc = torch.empty(res, device=dev, dtype=torch.uint8)
+        fl = torch.empty(res, device=dev, dtype=torch.uint8)
+        g1 = C.make_grid(D, C.PHIHIP_F64 if f64 else C.PHIHIP_F32, 1, res, (0,) * D, (L,) * D, ((code, code),) * D)
+        tmp = [t.clone() for t in vel]
+        cases["obstacle_accessible"] = (lambda: ctx.obstacle_accessible(g1, obs, 2, acc.data_ptr()), n ** D)
+        cases["build_cellflags"] = (lambda: ctx.build_cellflags(g1, acc.data_ptr(), 0, 1, fl.data_ptr()), 2 * n ** D)
+        cases["apply_obstacles"] = (lambda: ctx.apply_obstacles(grid, obs, 2, P(tmp)), 2 * NV * w)
     only = [x for x in a.only.split(",") if x]
     rec = {"lib": os.path.basename(a.lib) if a.lib else "default", "build_id": lib.build_id() if hasattr(lib, "build_id") else None,
            "size": n, "rank": D, "batch": B, "dtype": a.dtype, "bc": a.bc, "cfl": a.cfl, "halo": a.halo, "reps": a.reps, "kernels": {}}
