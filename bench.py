@@ -503,6 +503,7 @@ def config3_block(ctx, device, n=512, iters=100):
            "algorithmic_equiv_frac": round(ALG_BYTES_PER_CELL["cg_iteration"] * cells / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "kernel_ms_per_launch": {k: (round(v, 5) if v else None) for k, v in per_k.items() if v},
            "plan": {name: ctx.query_plan(grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))},
+           "plan_all": {str(fam): ctx.query_plan(grid, False, fam) for fam in (0, 1, 2, 3)},
            "final_relative_residual": math.sqrt(info[0].residual_sq / info[0].rhs_sq),
            "note": "wall time of the whole solve (initial residual, 100 x (MATVEC + UPDATE), refresh at 50, final state) / iterations; "
                    "moved = 7 words per cell and iteration by construction (3 MATVEC + mean of 3 / 5 UPDATE_R / UPDATE_X2)"}
@@ -510,7 +511,67 @@ def config3_block(ctx, device, n=512, iters=100):
     return out
 
 
-def live_pmc_traffic(n, kernel_key):
+def phi_level_block(ctx, lib, device, cg_iters, steps=20, sizes=(256, 128), plume_n=128, plume_steps=100):
+    """ what a PhiFlow user calls -- `advect.semi_lagrangian(Field, Field, dt)` (phi/physics/advect.py:156) and
+    `fluid.make_incompressible(Field, (), Solve)` (phi/physics/fluid.py:94) through `phiflow_amd.flow` -- timed NEXT TO the raw C-ABI loop of the
+    same step on the same box: the Taylor-Green step at 256^3 and 128^3 and the BASELINE configs[0] smoke-plume step at 128^2 (Smoke_Plume.ipynb
+    cell 5). `overhead` = phi-level wall / C-ABI wall - 1: Python objects, ctypes marshalling, the functional API's copies (a Field is immutable:
+    the projection works on a clone) and the per-step host synchronisation that raising NotConverged / Diverged requires. """
+    from phiflow_amd import flow as F
+    from phiflow_amd.backend import HipBackend
+    be = HipBackend(library=lib, device=str(device))
+    be.ctx = ctx                                    # one context: the launch plans tuned by the C-ABI loop serve both
+    out = {}
+
+    def wall(fn, n_steps):
+        for _ in range(3):
+            fn()
+        device_sync(device)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            fn()
+        device_sync(device)
+        return (time.perf_counter() - t0) / n_steps * 1e3
+
+    with be:
+        for n in sizes:
+            sim = FluidStep(ctx, n, 1, cg_iters, device)
+            ms_c = wall(lambda: sim.step(None), steps)
+            L = 2 * math.pi
+            state = {"v": F.StaggeredGrid([t.clone() for t in taylor_green_velocity(n, device, torch.float32, 1)], F.PERIODIC, F.Box(x=L, y=L, z=L), x=n, y=n, z=n), "p": None}
+            solve = lambda x0: F.Solve('CG', 0, 0, x0=x0, max_iterations=cg_iters, suppress=[F.NotConverged])
+
+            def phi_step():
+                v = F.advect.semi_lagrangian(state["v"], state["v"], sim.dt)
+                state["v"], state["p"] = F.fluid.make_incompressible(v, (), solve(state["p"]))
+            ms_phi = wall(phi_step, steps)
+            its = list(state["p"].solve_info.iterations)
+            assert its == [cg_iters], its
+            out[f"taylor_green_{n}"] = {"ms_c_abi": round(ms_c, 4), "ms_phi_level": round(ms_phi, 4), "overhead": round(ms_phi / ms_c - 1, 4)}
+            del sim, state
+            if device.type == "cuda":
+                torch.cuda.empty_cache()
+        # BASELINE configs[0]: the 128^2 smoke plume (closed box, MacCormack smoke + inflow, buoyancy, projection from the previous pressure)
+        n, iters = plume_n, 50
+        sim = SmokeBatchStep(ctx, n, 1, 0, 1, iters, device)
+        ms_c = wall(lambda: sim.step(None), plume_steps)
+        dom = F.Box(x=100, y=100)
+        inflow = 0.2 * F.resample(F.Sphere(x=50, y=9.5, radius=5), to=F.CenteredGrid(0, F.ZERO_GRADIENT, dom, x=n, y=n), soft=True)
+        st = {"v": F.StaggeredGrid(0, 0, dom, x=n, y=n), "s": F.CenteredGrid(0, F.ZERO_GRADIENT, dom, x=n, y=n), "p": None}
+
+        def plume_step():
+            s_ = F.advect.mac_cormack(st["s"], st["v"], 1.0) + inflow
+            v = F.advect.semi_lagrangian(st["v"], st["v"], 1.0) + F.resample(s_ * (0, 0.1), to=st["v"])
+            st["v"], st["p"] = F.fluid.make_incompressible(v, (), F.Solve('CG', 0, 0, x0=st["p"], max_iterations=iters, suppress=[F.NotConverged]))
+            st["s"] = s_
+        ms_phi = wall(plume_step, plume_steps)
+        out[f"smoke_plume_{n}x{n}"] = {"ms_c_abi": round(ms_c, 4), "ms_phi_level": round(ms_phi, 4), "overhead": round(ms_phi / ms_c - 1, 4), "cg_iterations": iters}
+    out["note"] = ("same box, same context, back to back; C-ABI = preallocated buffers driven like the timed region of this line; phi-level = phiflow_amd.flow "
+                   "(immutable Fields, a fresh result per operator, SolveInfo read back every step)")
+    return out
+
+
+def live_pmc_traffic(n, kernel_key, plans=None):
     """ HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes run NOW (separate FETCH_SIZE / WRITE_SIZE passes of
     tools/pmc_workload.py at this size, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2048 B -- gfx950 counts half of a
     wide streaming read --, WRITE_SIZE x 1024 B). Returns (bytes or None, source string). """
@@ -526,6 +587,8 @@ def live_pmc_traffic(n, kernel_key):
         import pmc_summary
         base = tempfile.mkdtemp(prefix="phihip_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
+        if plans:      # the traced child runs exactly the launch plans of this invocation's solve (no autotune candidates under the kernel's name)
+            env["PHIHIP_PMC_PLANS"] = json.dumps({str(n): plans})
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(base, ctr), "-o", "pmc", "--",
                    sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n)]
@@ -544,8 +607,8 @@ def live_pmc_traffic(n, kernel_key):
         for _, key, e in sorted(cands, key=lambda c: -c[0])[:1]:      # the plan the solve ran: the variant with the most launches
             if True:
                 src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run inside this bench invocation on tools/pmc_workload.py {n} "
-                       f"({key}; calibration copy: fetch unit {res['units']['fetch_bytes_per_unit_calibrated']}, "
-                       f"write unit {res['units']['write_bytes_per_unit_calibrated']} B)")
+                       f"({key}; {'launch plans of this invocation pinned, autotune off' if plans else 'self-tuned child'}; calibration copy: fetch unit "
+                       f"{res['units']['fetch_bytes_per_unit_calibrated']}, write unit {res['units']['write_bytes_per_unit_calibrated']} B)")
                 return int(round(e["read_bytes_prescribed"] + e["write_bytes_prescribed"])), src
     except Exception:
         pass
@@ -583,7 +646,25 @@ CG_KERNELS = {"cg_matvec_dot": "march_kernel<MODE_MATVEC> (d = r + beta d, sum d
               "cg_update_r": "march_kernel<MODE_UPDATE_R> (r -= alpha A d, sum r^2; every other iteration)"}
 
 
-def roofline_block(n, per, pmc, world, cache_assisted, where):
+def committed_traffic_ratio(n, kernel_name):
+    """ PMC bytes / moved bytes of the same kernel in the committed per-kernel table (tools/kernel_roofline.sh -> profiles/r05_kernel_roofline.json,
+    pinned plans, tools/path_workload.py): the second, independent measurement the bench line's traffic is checked against """
+    for name in ("r05_kernel_roofline.json", "r04_kernel_roofline.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                table = json.load(f)
+            for grp in table["groups"]:
+                if grp.get("size") != n or not str(grp.get("group", "")).startswith("f32"):
+                    continue
+                for k in grp["kernels"]:
+                    if kernel_name in k.get("label", "") and k.get("pmc_over_moved"):
+                        return float(k["pmc_over_moved"]), f"profiles/{name} group {grp['group']}"
+        except Exception:
+            continue
+    return None, None
+
+
+def roofline_block(n, per, pmc, world, cache_assisted, where, plans=None):
     """ per: {kernel family: (avg ms per launch, launches, total ms)} from hipEvent pairs on the solve stream. Dominant kernel = largest share
     of the GPU time among the three CG kernels; achieved = bytes it MOVES by construction / its average launch time. """
     cells = n ** 3
@@ -597,7 +678,7 @@ def roofline_block(n, per, pmc, world, cache_assisted, where):
     gbs = moved / (t_dom * 1e-3) / 1e9
     traffic, source = (None, None)
     if pmc and world == 1:
-        traffic, source = live_pmc_traffic(n, dom_key)
+        traffic, source = live_pmc_traffic(n, dom_key, plans)
     if traffic is None:
         traffic, source = _pmc_traffic(n, dom_key)
     block = {"bound": "hbm", "kernel": CG_KERNELS[dom_key], "size": n, "measured_on": where, "infinity_cache_assisted": bool(cache_assisted),
@@ -610,6 +691,12 @@ def roofline_block(n, per, pmc, world, cache_assisted, where):
                             f"{cells} cells; `traffic` (rocprofv3 PMC) cross-checks it",
              "algorithmic_bytes_per_launch": alg, "algorithmic_equiv_frac": round(alg / (t_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "achievable_copy_GBs": 6290.0}
+    if traffic and plans:
+        label = {"cg_matvec_dot": "CG MATVEC", "cg_update": "CG UPDATE_X2", "cg_update_r": "CG UPDATE_R"}[dom_key]
+        ref_ratio, ref_src = committed_traffic_ratio(n, label)
+        if ref_ratio:
+            block["traffic_cross_check"] = {"pmc_over_moved_here": block["traffic_over_moved"], "pmc_over_moved_committed_table": ref_ratio, "table": ref_src,
+                                            "agree_within_3_percent": bool(abs(block["traffic_over_moved"] / ref_ratio - 1) <= 0.03)}
     it = {}
     t_mv, t_x2, t_ur = per["cg_matvec_dot"][0], per["cg_update"][0], per["cg_update_r"][0]
     if t_mv and (t_x2 or t_ur):
@@ -718,6 +805,7 @@ def main():
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
+    ap.add_argument("--phi-level", type=int, default=1, help="1: time the same steps through phiflow_amd.flow next to the C-ABI loop (`phi_level`; rank 0, N = 1, ~3 s)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON record: libraries that write to file descriptor 1 behind Python's back (RCCL prints a
@@ -837,6 +925,9 @@ def main():
         del ref
         extra["cpu_cg_variants"] = cpu_cg_variants(96, 20)
 
+    if rank == 0 and world == 1 and args.phi_level and n == 256:
+        extra["phi_level"] = phi_level_block(ctx, lib, device, args.cg_iters)
+
     # ---- the HBM-resident configuration: 512^3 pressure solve (BASELINE configs[2]) -> `roofline` ----
     roofline = None
     if rank == 0 and args.config3_size > 0:
@@ -846,8 +937,9 @@ def main():
         extra["config3"] = c3
         per3 = {k: (c3["kernel_ms_per_launch"].get(k), c3["launches"].get(k, 0), (c3["kernel_ms_per_launch"].get(k) or 0.0) * c3["launches"].get(k, 0))
                 for k in C.K_NAMES}
+        plans3 = {str(fam): [q["rows"], q["tpr"], q["chunk"]] for fam, q in ((fam, c3["plan_all"][str(fam)]) for fam in (0, 1, 2, 3))}
         roofline, it3 = roofline_block(args.config3_size, per3, bool(args.pmc), world, cache_assisted=False,
-                                       where=f"{args.config3_size}^3 fp32 pressure solve run inside this invocation (`config3`)")
+                                       where=f"{args.config3_size}^3 fp32 pressure solve run inside this invocation (`config3`)", plans=plans3)
         if it3:
             it3["ms_iteration_wall"] = c3["ms_per_iteration"]
             it3["moved_frac_wall"] = c3["moved_frac"]

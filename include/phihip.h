@@ -363,6 +363,12 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo);
  * kernels are faster (one plane per workgroup: nothing to overlap the fill with) and stay the default; enable != 0 switches the windows on
  * there as well (parity tests, A/B measurements). */
 int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable);
+/* r5: the tiled self-advection fills its LDS ring by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) on REGULAR grids --
+ * 3-D, reach 1, no CLOSED side, periodic fast axis with rows of whole 16-byte vectors, 16-byte aligned arrays; every other grid keeps the
+ * register-staged kernel (per-element padding). enable: 1 (default) / 0 (also: environment PHIHIP_ADVECT_DMA=0) / -1 = leave as it is;
+ * *last_was_dma (may be NULL) = 1 when the most recent tiled self-advection of this context took the LDS-DMA kernel. Same samples, same
+ * arithmetic, same bits either way (asserted by the parity tests). */
+int phihip_set_advect_dma(phihip_ctx* ctx, int enable, int32_t* last_was_dma);
 /* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* planes per workgroup the most recent tiled self-advection of this context ran with (3-D; 0 = none yet / 2-D): what the first-call

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered", "phihip_cg_solve_shifted",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg", "phihip_set_resident_cg",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg", "phihip_set_resident_cg", "phihip_set_advect_dma",
 )
 
 
@@ -226,6 +226,8 @@ class Library:
         d.phihip_set_advect_windows_2d.argtypes = [c_void_p, c_int]
         d.phihip_query_advect_chunk.argtypes = [c_void_p, POINTER(c_int32)]
         d.phihip_set_autotune.argtypes = [c_void_p, c_int]
+        if hasattr(d, 'phihip_set_advect_dma'):
+            d.phihip_set_advect_dma.argtypes = [c_void_p, c_int, POINTER(c_int32)]
         d.phihip_set_single_reduction_cg.argtypes = [c_void_p, c_int, ctypes.c_longlong]
         d.phihip_set_resident_cg.argtypes = [c_void_p, c_int, ctypes.c_longlong]
         d.phihip_allreduce_residual.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
@@ -510,6 +512,13 @@ class Context:
         out = c_int32(0)
         self.lib.check(self.lib.dll.phihip_query_advect_chunk(self.handle, ctypes.byref(out)))
         return int(out.value)
+
+    def set_advect_dma(self, enable: int = -1) -> bool:
+        """ LDS-DMA fill of the tiled self-advection on regular grids (include/phihip.h): enable 1 / 0, -1 = unchanged. Returns whether the most
+        recent tiled self-advection of this context took the LDS-DMA kernel. """
+        out = c_int32(0)
+        self.lib.check(self.lib.dll.phihip_set_advect_dma(self.handle, int(enable), ctypes.byref(out)))
+        return bool(out.value)
 
     def set_advect_windows_2d(self, enable: bool):
         """ LDS-windowed MacCormack / centred advection passes on 2-D grids as well (default: 3-D only; the gather kernels are faster in 2-D) """

@@ -43,6 +43,25 @@ __device__ __forceinline__ void fix_publish(const FixList& L, int count) {
 #endif
 }
 
+// x - floor(x) in [0, 1) as ONE instruction (v_fract_f32 / v_fract_f64; floor + subtract are two). For a tiny negative x the plain difference
+// rounds to 1.0, the instruction returns the largest value below 1 instead -- the host form restates that, so the emulation computes the same bits.
+__device__ __forceinline__ float frac_part(float x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_fractf(x);
+#else
+    const float f = x - floorf(x);
+    return f < 1.0f ? f : (f == f ? 0x1.fffffep-1f : f);
+#endif
+}
+__device__ __forceinline__ double frac_part(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_fract(x);
+#else
+    const double f = x - floor(x);
+    return f < 1.0 ? f : (f == f ? 0x1.fffffffffffffp-1 : f);
+#endif
+}
+
 // wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
 // branch that no wavefront takes at sensible CFL numbers
 __device__ __forceinline__ int wrap_index(int i, int n) {

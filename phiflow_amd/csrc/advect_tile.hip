@@ -22,6 +22,16 @@
 
 #include "advect_common.hpp"
 
+#ifndef PHIHIP_DMA_FENCE
+#define PHIHIP_DMA_FENCE 0      // r5 same-box A/B (profiles/r05_time_advect_dma_fence.jsonl): with 48-62 VGPRs and the occupancy set by LDS the scheduler may overlap the samples' LDS reads: -5 %
+#endif
+#ifndef PHIHIP_TILE_FENCE
+#define PHIHIP_TILE_FENCE 1
+#endif
+#ifndef PHIHIP_DMA_UNROLL_S
+#define PHIHIP_DMA_UNROLL_S 0
+#endif
+
 
 namespace phihip {
 
@@ -304,7 +314,13 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
     // one plane of samples. Per sample: displacement from the own component and the 4-point sums of the others (x 1/4 folded into the
     // scale), coordinate = index - displacement rounded like the reference rounds it (absolute index space), taps relative to the
     // sample's own LDS position, blend as nested lerps along a2, a1, a0.
-    auto compute_plane = [&](int p) {
+    // FULL: every sample of the tile exists in every component's array (interior tiles; a uniform test per workgroup picks the instantiation): no
+    // validity bits, no dump slot, the store is base (uniform) + 32-bit offset
+    bool tile_full = pe <= g.cn[2][0] && lo1 + T1 <= g.cn[2][1] && lo2 + T2 <= g.cn[2][2];
+#pragma unroll
+    for (int c = A0; c < 2; ++c) tile_full = tile_full && pe <= g.cn[c][0] && lo1 + T1 <= g.cn[c][1] && lo2 + T2 <= g.cn[c][2];
+    auto compute_plane = [&](int p, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int so_m = slot_of(p - 1) * PLANE, so_0 = slot_of(p) * PLANE, so_p = slot_of(p + 1) * PLANE;   // uniform element offsets
         bool slow_any = false;
 #pragma unroll 1
@@ -333,28 +349,48 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                             d[cb] = -OFF[cb] + ib;
                             v4[ia][ib] = at(cb, d[0], d[1], d[2]);
                         }
-                    coord[cb] = ((v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1])) * (T(-0.25) * g.shift[cb]);
+                    // (a chain, not a tree: the tree is packed into v_pk_add_f32 + three register moves -- 5 instructions for 3 additions)
+                    coord[cb] = (((v4[0][0] + v4[0][1]) + v4[1][0]) + v4[1][1]) * (T(-0.25) * g.shift[cb]);
                 }
                 // taps relative to the sample: rel = floor(displacement) in [-H, H-1] or the lookup leaves the window
                 T fr[3] = {T(0), T(0), T(0)};
                 int di[3] = {0, 0, 0};
                 bool slow = false;
+                int base0, base1;
+                if (H == 1) {
+                    // r5 (instruction diet, measured ~4 cycles per wave64 VALU instruction of any class on this part -- tools/micro/issue_rates.hip): inside the
+                    // window the integer part of a displacement is -1 or 0, i.e. its SIGN. No floor / clamp / convert / multiply: the fraction is ONE
+                    // v_fract, a tap offset one v_cndmask on the sign, "left the window" one v_max3 of the magnitudes and one compare (also true for NaN;
+                    // a displacement of exactly -1 cell is sent to the fix-up pass, which computes the same value). The offsets are in the window
+                    // whatever the displacement, so nothing has to be clamped: 27 -> 15 instructions per sample.
+                    const T m01 = DIM == 3 ? fmax(fabs(coord[0]), fabs(coord[1])) : fabs(coord[1]);
+                    slow = !(fmax(m01, fabs(coord[2])) < T(1));
 #pragma unroll
-                for (int a = A0; a < 3; ++a) {
-                    const T fl = floor(coord[a]);
-                    fr[a] = coord[a] - fl;
-                    const T rel = fl;
-                    const T relc = clamp_real(rel, T(-H), T(H - 1));
-                    slow = slow || !(rel == relc);                 // also true for NaN
-                    di[a] = (int)relc;
+                    for (int a = A0; a < 3; ++a) fr[a] = frac_part(coord[a]);
+                    const int off = (ca - A0) * NP * PLANE + center + (coord[1] < T(0) ? -P2 : 0) + (coord[2] < T(0) ? -1 : 0);
+                    base0 = base1 = off;
+                    if (DIM == 3) {                                // lower tap plane p-1 or p, upper p or p+1
+                        const bool down = coord[0] < T(0);
+                        base1 += down ? so_0 : so_p;
+                        base0 += down ? so_m : so_0;
+                    }
+                } else {
+#pragma unroll
+                    for (int a = A0; a < 3; ++a) {
+                        const T fl = floor(coord[a]);
+                        fr[a] = coord[a] - fl;
+                        const T rel = fl;
+                        const T relc = clamp_real(rel, T(-H), T(H - 1));
+                        slow = slow || !(rel == relc);                 // also true for NaN
+                        di[a] = (int)relc;
+                    }
+                    base0 = (ca - A0) * NP * PLANE + center + __mul24(di[1], P2) + di[2];
+                    base1 = base0;
                 }
-                const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0];
+                const bool valid = FULL || (((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0]);
                 slow_any = slow_any || (valid && slow);          // -> this plane of the tile is redone by advect_self_fixup_kernel
-                int base0 = (ca - A0) * NP * PLANE + center + __mul24(di[1], P2) + di[2], base1 = base0;
                 if (DIM == 3) {
-                    if (H == 1) {                                  // lower tap plane p-1 or p, upper p or p+1
-                        base1 += di[0] < 0 ? so_0 : so_p;
-                        base0 += di[0] < 0 ? so_m : so_0;
+                    if (H == 1) {
                     } else {
                         int s0 = slot_of(p) + di[0];
                         s0 += s0 < 0 ? NP : 0; s0 -= s0 >= NP ? NP : 0;
@@ -372,10 +408,20 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
                     y[k] = fma(fr[1], x1 - x0, x0);
                 }
                 const T val = DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
-                T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
-                *(valid ? slot : dump) = val;     // unconditional store (see load_plane)
+                if (FULL) {
+                    T* const plane = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca];      // uniform
+                    plane[obase[ca] + (unsigned)(s * TY * g.cn[ca][2])] = val;
+                } else {
+                    T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
+                    *(valid ? slot : dump) = val;     // unconditional store (see load_plane)
+                }
+#if PHIHIP_TILE_FENCE == 1
                 sched_fence();     // one sample's LDS reads in flight at a time (fence per position or none: +10 % time, profiles/r02_ab_advect*.jsonl)
+#endif
             }
+#if PHIHIP_TILE_FENCE == 2
+            sched_fence();
+#endif
         }
         if (slow_any) slow_sh[p & 1] = 1;
     };
@@ -398,10 +444,12 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
         const int kl = p + H + 2, ks = p + H + 1;
         if (MODE_ == 0) {
             if (kl >= k_lo && kl <= k_hi) load_plane(kl, Rld, tail_ld);
-            if (p >= pb && p < pe) compute_plane(p);
+            if (p >= pb && p < pe) compute_plane(p, std::false_type{});
         } else {
             load_plane(min(max(kl, k_lo), k_hi), Rld, tail_ld);   // (past the last staged plane: that plane again, nobody stores it)
-            if (MODE_ == 2) compute_plane(p);
+            if (MODE_ == 2) {
+                if (tile_full) compute_plane(p, std::true_type{}); else compute_plane(p, std::false_type{});
+            }
         }
         if (ks >= k_lo && ks <= k_hi) {
             if (CONSTS && has_const) patch_plane(ks, Rst, tail_st);
@@ -477,6 +525,219 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
     }
 }
 
+// =====================================================================================================================================
+// r5: the same pass with the ring filled by LDS-DMA (`global_load_lds_dwordx4`: HBM / L2 -> LDS without a VGPR round trip) -- the lever the
+// round-3 and round-4 verdicts asked for. Scope = grids whose staged rows are REGULAR: 3-D, reach 1, no CLOSED (constant) side, the fast axis
+// periodic with rows of whole 16-byte vectors -- the benchmark configuration. (A closed box has a component with N - 1 faces per row: its
+// windows need per-element padding, which only the register-staged kernel above can do.)
+//   * window of a (component, plane) = P1 rows x G2 = T2 / V + 2 chunks of 16 bytes: the tile's columns and ONE chunk either side (the halo column is
+//     its nearest element), contiguous in LDS in (row, chunk) order -- the destination of LDS-DMA is wave-uniform base + 16 lane, so a
+//     wavefront instruction moves 64 consecutive chunks = 1 KiB; the per-lane SOURCE resolves the row (wrap / clamp) and the chunk (wrap);
+//   * wavefront w (of 4) feeds component w: NI = ceil(P1 G2 / 64) instructions per plane (3 for the fp32 tile instead of 10 loads + 10
+//     ds_write per THREAD and ~70 VALU instructions per wavefront and plane of address arithmetic and staging);
+//   * ring of 4 planes: plane p + 2 is requested at the start of half-step p into the slot plane p - 2 left, and has to have landed at the END of
+//     the half-step (one plane of arithmetic, ~2 500 cycles, against ~1 000 of memory latency): `s_waitcnt vmcnt(#stores of this half-step)` on
+//     the feeding wavefronts -- VMEM operations retire in issue order, so that many may stay in flight --, then the workgroup barrier that makes
+//     the landed bytes visible to the other wavefronts (MI355X_MICROARCH.md: nothing else orders a ds_read behind an LDS-DMA). The transfers
+//     are inline assembly: the compiler would drain vmcnt before every LDS read that may alias an LDS-DMA destination it knows of.
+// Same samples, same arithmetic as the kernel above (compute: the H = 1 sign form); fix-up list and launch geometry are shared.
+// =====================================================================================================================================
+template <typename T, int T1>
+struct AdvDma {
+    static constexpr int V = 16 / (int)sizeof(T);
+    static constexpr int T2 = sizeof(T) == 4 ? 64 : 32;
+    static constexpr int TY = kBlock / T2, S = T1 / TY;
+    static constexpr int P1 = T1 + 2, G2 = T2 / V + 2, PITCH = G2 * V;
+    static constexpr int NCH = P1 * G2, NI = (NCH + kWave - 1) / kWave;
+    static constexpr int PLANE = NCH * V;                 // elements; the last instruction of a plane masks its idle lanes
+    static constexpr int NP = 4;
+    static_assert((size_t)3 * NP * PLANE * sizeof(T) <= 65536, "static LDS limit");
+};
+
+// 16 bytes per lane from `gsrc` (per lane) to LDS at `lds_dst` (wave-uniform) + 16 lane
+template <typename T>
+__device__ __forceinline__ void lds_dma16(const void* gsrc, T* lds_dst, int lane) {
+#ifdef __HIP_DEVICE_COMPILE__
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#else
+    memcpy(reinterpret_cast<char*>(lds_dst) + 16 * lane, gsrc, 16);
+#endif
+}
+
+template <typename T, int T1>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dma_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
+                                                                                         int chunk, int tiles1, int tiles2, int nblk, int nmax0, FixList fix, T* __restrict__ dump) {
+    using C = AdvDma<T, T1>;
+    constexpr int T2 = C::T2, TY = C::TY, S = C::S, V = C::V, PITCH = C::PITCH, PLANE = C::PLANE, NP = C::NP, NI = C::NI, G2 = C::G2;
+    __shared__ __attribute__((aligned(16))) T lds[3 * NP * PLANE];
+    __shared__ int slow_sh[2];
+
+    const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2, lane = tid & (kWave - 1);
+#ifdef __HIP_DEVICE_COMPILE__
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+#else
+    const int wave = tid / kWave;
+#endif
+    const int b = blockIdx.y;
+    const int bid = xcd_order((int)blockIdx.x, nblk);
+    const int t2 = bid % tiles2;
+    const int t1 = (bid / tiles2) % tiles1;
+    const int c0 = bid / (tiles2 * tiles1);
+    const int lo1 = t1 * T1, lo2 = t2 * T2;
+    const int pb = c0 * chunk, pe = min(pb + chunk, nmax0);
+    T* const outp[3] = {o0, o1, o2};
+    if (tid < 2) slow_sh[tid] = 0;
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fix.next = 0;
+    unsigned obase[3];
+    long long pstride[3];
+    unsigned vbits = 0;
+    bool tile_full = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        obase[c] = (unsigned)((lo1 + ty) * g.cn[c][2] + lo2 + tx);
+        pstride[c] = (long long)g.cn[c][1] * g.cn[c][2];
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+            if (lo1 + ty + k * TY < g.cn[c][1] && lo2 + tx < g.cn[c][2]) vbits |= 1u << (k * 3 + c);
+        tile_full = tile_full && pe <= g.cn[c][0] && lo1 + T1 <= g.cn[c][1] && lo2 + T2 <= g.cn[c][2];
+    }
+
+    // ---- feed: wavefront w < 3 owns component w. Plane-invariant byte offset of the chunk each lane moves, per instruction -----------------
+    const int fc = wave < 3 ? wave : 0;
+    const int fn0 = fc == 0 ? g.cn[0][0] : (fc == 1 ? g.cn[1][0] : g.cn[2][0]);
+    const int fn1 = fc == 0 ? g.cn[0][1] : (fc == 1 ? g.cn[1][1] : g.cn[2][1]);
+    const int fn2 = fc == 0 ? g.cn[0][2] : (fc == 1 ? g.cn[1][2] : g.cn[2][2]);
+    const T* const fbase = (fc == 0 ? vel.p[0] : (fc == 1 ? vel.p[1] : vel.p[2])) + (long long)b * (fc == 0 ? g.ccells[0] : (fc == 1 ? g.ccells[1] : g.ccells[2]));
+    const long long fstride = (long long)fn1 * fn2;
+    unsigned doff[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int q = k * kWave + lane;
+        const int rr = q / G2, gg = q - rr * G2;
+        int j = lo1 - 1 + rr;
+        if (g.bc[1][0] == PHIHIP_BC_PERIODIC) j = wrap_index(j, fn1);
+        j = min(max(j, 0), fn1 - 1);                           // OPEN: zero-gradient padding = the edge row
+        const int k0 = wrap_index(lo2 - V + gg * V, fn2);      // the fast axis is periodic and fn2 a multiple of V: a chunk never straddles the seam
+        doff[k] = (unsigned)(j * fn2 + k0) * (unsigned)sizeof(T);
+    }
+    auto plane_src = [&](int i0) -> long long {
+        int w = i0;
+        if (g.bc[0][0] == PHIHIP_BC_PERIODIC) { w += w < 0 ? fn0 : 0; w -= w >= fn0 ? fn0 : 0; }
+        w = min(max(w, 0), fn0 - 1);
+        return (long long)w * fstride;
+    };
+    auto feed = [&](int i0) {      // request plane i0 of the wavefront's component into its ring slot
+        if (wave < 3) {
+            const char* const src = reinterpret_cast<const char*>(fbase + plane_src(i0));
+            T* const dst = lds + (fc * NP + (i0 & (NP - 1))) * PLANE;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                if (k * kWave + lane < C::NCH) lds_dma16<T>(src + doff[k], dst + k * kWave * V, lane);
+            }
+        }
+    };
+    // the feeding wavefronts wait until at most `stores` of their VMEM operations are in flight (= everything older than this half-step's output
+    // stores has retired, the transfers included), then the workgroup meets
+    auto landed_and_barrier = [&](auto stores_tag) {
+#ifdef __HIP_DEVICE_COMPILE__
+        constexpr int N = decltype(stores_tag)::value;
+        if (wave < 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+#else
+        __syncthreads();
+#endif
+    };
+
+    auto compute_plane = [&](int p, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int so_m = ((p - 1) & (NP - 1)) * PLANE, so_0 = (p & (NP - 1)) * PLANE, so_p = ((p + 1) & (NP - 1)) * PLANE;
+        bool slow_any = false;
+#if PHIHIP_DMA_UNROLL_S
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+        for (int s = 0; s < S; ++s) {
+            const int center = (ty + s * TY + 1) * PITCH + tx + V;
+            const int cen[3] = {center + so_m, center + so_0, center + so_p};
+#pragma unroll
+            for (int ca = 0; ca < 3; ++ca) {
+                auto at = [&](int x, int d0, int d1, int d2) -> T { return lds[cen[d0 + 1] + (x * NP * PLANE + d1 * PITCH + d2)]; };
+                T coord[3] = {T(0), T(0), T(0)};
+                coord[ca] = at(ca, 0, 0, 0) * -g.shift[ca];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    if (cb == ca) continue;
+                    // component cb at this ca-face (every lower face is stored here: off = 0): cells (m - 1, m) along ca, faces (s, s + 1) along cb
+                    T v4[2][2];
+#pragma unroll
+                    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) {
+                            int d[3] = {0, 0, 0};
+                            d[ca] = -1 + ia;
+                            d[cb] = ib;
+                            v4[ia][ib] = at(cb, d[0], d[1], d[2]);
+                        }
+                    coord[cb] = (((v4[0][0] + v4[0][1]) + v4[1][0]) + v4[1][1]) * (T(-0.25) * g.shift[cb]);
+                }
+                const bool slow = !(fmax(fmax(fabs(coord[0]), fabs(coord[1])), fabs(coord[2])) < T(1));
+                T fr[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) fr[a] = frac_part(coord[a]);
+                const int off = ca * NP * PLANE + center + (coord[1] < T(0) ? -PITCH : 0) + (coord[2] < T(0) ? -1 : 0);
+                const bool down = coord[0] < T(0);
+                const int base1 = off + (down ? so_0 : so_p), base0 = off + (down ? so_m : so_0);
+                const bool valid = FULL || (((vbits >> (s * 3 + ca)) & 1u) && p < g.cn[ca][0]);
+                slow_any = slow_any || (valid && slow);
+                T y[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int bk = k ? base1 : base0;
+                    const T a00 = lds[bk], a10 = lds[bk + PITCH], a01 = lds[bk + 1], a11 = lds[bk + PITCH + 1];
+                    const T x0 = fma(fr[2], a01 - a00, a00), x1 = fma(fr[2], a11 - a10, a10);
+                    y[k] = fma(fr[1], x1 - x0, x0);
+                }
+                const T val = fma(fr[0], y[1] - y[0], y[0]);
+                if (FULL) {
+                    T* const plane = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca];
+                    plane[obase[ca] + (unsigned)(s * TY * g.cn[ca][2])] = val;
+                } else {
+                    T* const slot = outp[ca] + (long long)b * g.ccells[ca] + (long long)p * pstride[ca] + (obase[ca] + (unsigned)(s * TY * g.cn[ca][2]));
+                    *(valid ? slot : dump) = val;     // unconditional: the feeding wavefronts count their stores
+                }
+#if PHIHIP_DMA_FENCE == 1
+                sched_fence();      // one sample's LDS reads in flight at a time
+#endif
+            }
+#if PHIHIP_DMA_FENCE == 2
+            sched_fence();          // one position's (three samples') LDS reads in flight at a time
+#endif
+        }
+        if (slow_any) slow_sh[p & 1] = 1;
+    };
+    auto report_plane = [&](int p) {
+        if (tid == 0 && slow_sh[p & 1]) {
+            slow_sh[p & 1] = 0;
+            fix_append(fix, b * nblk + (int)blockIdx.x, p);
+        }
+    };
+
+    // ring warm-up: planes pb - 1, pb, pb + 1 (back to back: one memory round trip), then one plane per half-step
+    feed(pb - 1);
+    feed(pb);
+    feed(pb + 1);
+    landed_and_barrier(std::integral_constant<int, 0>{});
+    for (int p = pb; p < pe; ++p) {
+        feed(p + 2);       // (beyond the chunk's last plane + 1 nobody reads it: requested all the same, the counts stay uniform)
+        if (tile_full) compute_plane(p, std::true_type{}); else compute_plane(p, std::false_type{});
+        landed_and_barrier(std::integral_constant<int, 3 * S>{});
+        report_plane(p);
+    }
+}
+
 template <typename T, int DIM, int H, int T1, int OFFM, bool CONSTS>
 static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid& vg, const void* const vel[3], void* const out[3], double dt, int kind, hipStream_t s) {
     const TileGrid<T> g = make_tilegrid<T>(vg, dt);
@@ -513,12 +774,25 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     int nblk = 0;
     // the tile kernel + its fix-up launch (fixed grid striding over the work list)
+    // r5: regular grids (3-D, reach 1, no CLOSED side, periodic fast axis with rows of whole 16-byte vectors) fill the ring by LDS-DMA
+    bool dma = false;
+    if constexpr (DIM == 3 && H == 1 && !CONSTS && OFFM == 0 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
+        dma = ctx->adv_dma != 0 && v.bc[2][0] == PHIHIP_BC_PERIODIC;
+        for (int c = 0; c < 3; ++c) dma = dma && v.cn[c][2] % (16 / (int)sizeof(T)) == 0 && v.cn[c][2] >= 2 * (16 / (int)sizeof(T)) && v.cn[c][1] >= 4 && v.cn[c][0] >= 4;
+        for (int c = 0; c < 3; ++c) dma = dma && (reinterpret_cast<uintptr_t>(vel[c]) & 15u) == 0;
+    }
     auto launch = [&](int ch) -> int {
         FixList fix;
         void* dump = nullptr;
         PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump, kind));
         chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
         nblk = tiles1 * tiles2 * chunks0;
+        if constexpr (DIM == 3 && H == 1 && !CONSTS && OFFM == 0 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
+            if (dma)
+                hipLaunchKernelGGL((advect_self_dma_kernel<T, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2], ch, tiles1,
+                                   tiles2, nblk, nmax[0], fix, (T*)dump);
+        }
+        if (!dma)
         hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
                            (T*)out[2], ch, tiles1, tiles2, nblk, nmax[0], fix, (T*)dump);
         const int fgrid = fix.cap < kFixupBlocks ? fix.cap : kFixupBlocks;
@@ -532,7 +806,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
         // First call on this grid: the planner's chunk length against a few others, timed on the call's own operands (every length
         // writes the same values, so the output is simply overwritten; ~2 ms once per grid). The planner ranks slot efficiency x halo
         // overhead and misses e.g. the ring warm-up per chunk: 384^3 fp64 runs 6 % faster with 16 planes than with its 64.
-        const std::array<long long, 6> key = {(long long)sizeof(T), DIM, H, nmax[0], (long long)tiles1 * tiles2, v.batch};
+        const std::array<long long, 6> key = {(long long)sizeof(T) + (dma ? 100 : 0), DIM, H, nmax[0], (long long)tiles1 * tiles2, v.batch};
         const auto it = ctx->adv_tuned.find(key);
         if (it != ctx->adv_tuned.end()) {
             chunk = it->second;
@@ -566,9 +840,23 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     }
     PHIHIP_TRY(launch(chunk));
     ctx->adv_last_chunk = DIM == 3 ? chunk : 0;
+    ctx->adv_last_dma = dma ? 1 : 0;
     return PHIHIP_OK;
 }
 
+#ifdef PHIHIP_ONLY_LEAN
+// development aid (tools/kernel_resources.py, ISA audits): `hipcc -DPHIHIP_ONLY_LEAN=1 --cuda-device-only -S` compiles the benchmark configuration's
+// instantiation alone (3 s instead of 30)
+int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const vel[3], void* const out[3], double dt, int halo, int kind, hipStream_t s) {
+    const VelGrid g = make_velgrid(v);
+#if PHIHIP_ONLY_LEAN == 2
+    return launch_tile_consts<double, 3, 1, 16, 7, true>(ctx, v, g, vel, out, dt, kind, s);
+#else
+    return launch_tile_consts<float, 3, 1, 8, 0, false>(ctx, v, g, vel, out, dt, kind, s);
+#endif
+}
+}  // namespace phihip
+#else
 // a stored lower face (OFFM bit clear) on every axis does not exclude a CLOSED upper side (mixed boxes): the periodic / open code without
 // the wall-value patch path is a separate instantiation of OFFM = 0 only
 template <typename T, int DIM, int H, int T1, int OFFM>
@@ -627,3 +915,4 @@ int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const 
 }
 
 }  // namespace phihip
+#endif

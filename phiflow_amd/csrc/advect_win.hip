@@ -411,6 +411,64 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             const T d = r0 - rel;
             dev = fma(d, d, dev);
         };
+        // r5 (instruction diet; ~4 cycles per wave64 VALU instruction of any class on gfx950, tools/micro/issue_rates.hip): a lookup whose taps may only
+        // be the sample's own cell or the one below it (reach 1: the displacement lies in [-1, 1)) needs no floor / clamp / convert / multiply -- the
+        // integer part is the displacement's SIGN: fraction = ONE v_fract, tap offset = one select on the sign, "left the window" = the running maximum
+        // of the magnitudes compared with 1 once per sample (NaN included; exactly -1 goes to the fix-up pass, which computes the same value). The
+        // offsets are inside the window whatever the displacement. GEN = the one axis that keeps the general form (the limiter's own axis: reach 2).
+        auto split_sign = [&](T disp, T& fr, T& mx) {
+            fr = frac_part(disp);
+            mx = fmax(mx, fabs(disp));
+        };
+        auto tap_base_sign = [&](int w, int cen, const T (&disp)[3], const T (&rel)[3], int gen, int (&base)[2]) {
+            int inplane = cen + C::gin(w);
+            inplane += gen == 1 ? __mul24((int)rel[1], C::p2(w)) : (disp[1] < T(0) ? -C::p2(w) : 0);
+            inplane += gen == 2 ? (int)rel[2] : (disp[2] < T(0) ? -1 : 0);
+            if (DIM == 3) {
+                int b0 = pbase[w][C::H0MAX], b1 = pbase[w][C::H0MAX + 1];      // rel = 0: planes p, p + 1
+                if (gen == 0) {
+#pragma unroll
+                    for (int d = -C::h0(w); d < C::h0(w); ++d) {
+                        if (d == 0) continue;
+                        const bool hit = d < 0 ? rel[0] <= (T)d : rel[0] >= (T)d;
+                        if (d < 0) { b0 = rel[0] == (T)d ? pbase[w][d + C::H0MAX] : b0; b1 = rel[0] == (T)d ? pbase[w][d + 1 + C::H0MAX] : b1; }
+                        else { b0 = hit ? pbase[w][d + C::H0MAX] : b0; b1 = hit ? pbase[w][d + 1 + C::H0MAX] : b1; }
+                    }
+                } else {
+                    const bool down = disp[0] < T(0);
+                    b0 = down ? pbase[w][C::H0MAX > 0 ? C::H0MAX - 1 : 0] : b0;
+                    b1 = down ? pbase[w][C::H0MAX] : b1;
+                }
+                base[0] = b0 + inplane;
+                base[1] = b1 + inplane;
+            } else {
+                base[0] = base[1] = C::gbase(w) + inplane;
+            }
+        };
+        auto lerp_at = [&](int w, const int (&base)[2], const T (&fr)[3]) -> T {
+            T y[2];
+#pragma unroll
+            for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+                const int bk = base[k];
+                const T a00 = lds[bk], a10 = lds[bk + C::p2(w)], a01 = lds[bk + 1], a11 = lds[bk + C::p2(w) + 1];
+                const T x0 = fma(fr[2], a01 - a00, a00), x1 = fma(fr[2], a11 - a10, a10);
+                y[k] = fma(fr[1], x1 - x0, x0);
+            }
+            return DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
+        };
+        auto minmax_at = [&](int w, const int (&base)[2], T& lo, T& hi) {
+            lo = hi = lds[base[0]];
+#pragma unroll
+            for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+                const int bk = base[k];
+                const T t[4] = {lds[bk], lds[bk + C::p2(w)], lds[bk + 1], lds[bk + C::p2(w) + 1]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo = fmin(lo, t[q]);
+                    hi = fmax(hi, t[q]);
+                }
+            }
+        };
         // both tile positions of a thread in one straight-line body: at two workgroups per CU (LDS) the registers are there, and the second
         // position's LDS reads overlap the first one's arithmetic (same-box A/B, profiles/r04_time_frow_session_c.jsonl: 2-8 %)
 #pragma unroll
@@ -447,21 +505,29 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                         cf[cbx] = sum * (T(0.25) * P.shift[cbx]);
                         cb[cbx] = -cf[cbx];
                     }
-                    T dev = T(0);
+                    T dev = T(0), mx = T(0);
                     T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
+                    int tb[2];
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cf[a], -1, 0, fr[a], rel[a], dev);
-                    const T bwd = lerp_taps(wf, cen[wf], rel, fr);
+                    for (int a = A0; a < 3; ++a) split_sign(cf[a], fr[a], mx);
+                    tap_base_sign(wf, cen[wf], cf, rel, -1, tb);
+                    const T bwd = lerp_at(wf, tb, fr);
                     const T nv = at(wf, 0, 0, 0) + P.ch * (vc - bwd);
                     // limiter: closest grid values of the backward lookup in the CELL frame (own axis: m - 1/2 instead of the stored index)
                     cb[ca] += (T)OFF[ca] - T(0.5);
+                    {
+                        T fdummy;
+                        split(cb[ca], -2, 1, fdummy, rel[ca], dev);          // the own axis: reach 2 (general form); the others: the sign
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) split(cb[a], a == ca ? -2 : -1, a == ca ? 1 : 0, fr[a], rel[a], dev);
+                        for (int a = A0; a < 3; ++a)
+                            if (a != ca) mx = fmax(mx, fabs(cb[a]));
+                    }
+                    tap_base_sign(wv, cen[wv], cb, rel, ca, tb);
                     T lo, hi;
-                    minmax_taps(wv, cen[wv], rel, lo, hi);
+                    minmax_at(wv, tb, lo, hi);
                     const T val = nv < lo ? lo : (nv > hi ? hi : nv);      // math.clip = minimum(maximum(x, lo), hi)
                     const bool valid = ((vbits >> (s * 3 + ca)) & 1u) && p < P.on[ca][0];
-                    slow_any = slow_any || (valid && !(dev == T(0)));
+                    slow_any = slow_any || (valid && (!(dev == T(0)) || !(mx < T(1))));
                     T* const slot = P.out[ca] + (long long)b * P.ostride[ca] + (long long)p * ((long long)P.on[ca][1] * P.on[ca][2]) +
                                     (obase[ca] + (unsigned)(s * TY * P.on[ca][2]));
                     *(valid ? slot : P.dump) = val;
@@ -482,10 +548,28 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     cb[c] = -sft;
                     cf[c] = sft;
                 }
-                T dev = T(0);
+                T dev = T(0), mx = T(0);
                 T fr[3] = {T(0), T(0), T(0)}, rel[3] = {T(0), T(0), T(0)};
                 T val;
-                if (KIND == WK_SL_CEN) {
+                if (H == 1) {          // reach 1: the sign form of every lookup
+                    int tb[2];
+                    if (KIND == WK_SL_CEN) {
+#pragma unroll
+                        for (int a = A0; a < 3; ++a) split_sign(cb[a], fr[a], mx);
+                        tap_base_sign(0, cen[0], cb, rel, -1, tb);
+                        val = lerp_at(0, tb, fr);
+                    } else {
+#pragma unroll
+                        for (int a = A0; a < 3; ++a) split_sign(cf[a], fr[a], mx);      // (|cb| = |cf|: one maximum serves both lookups)
+                        tap_base_sign(1, cen[1], cf, rel, -1, tb);
+                        const T bwd = lerp_at(1, tb, fr);
+                        const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
+                        tap_base_sign(0, cen[0], cb, rel, -1, tb);
+                        T lo, hi;
+                        minmax_at(0, tb, lo, hi);
+                        val = nv < lo ? lo : (nv > hi ? hi : nv);
+                    }
+                } else if (KIND == WK_SL_CEN) {
 #pragma unroll
                     for (int a = A0; a < 3; ++a) split(cb[a], -H, H - 1, fr[a], rel[a], dev);
                     val = lerp_taps(0, cen[0], rel, fr);
@@ -501,7 +585,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     val = nv < lo ? lo : (nv > hi ? hi : nv);
                 }
                 const bool valid = ((vbits >> (s * 3)) & 1u) && p < P.on[0][0];
-                slow_any = slow_any || (valid && !(dev == T(0)));
+                slow_any = slow_any || (valid && (!(dev == T(0)) || !(mx < T(1))));
                 T* const slot = P.out[0] + (long long)b * P.ostride[0] + (long long)p * ((long long)P.on[0][1] * P.on[0][2]) +
                                 (obase[0] + (unsigned)(s * TY * P.on[0][2]));
                 *(valid ? slot : P.dump) = val;

@@ -282,6 +282,8 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
     ctx->device = device;
     const char* at = getenv("PHIHIP_AUTOTUNE");
     if (at && at[0] == '0') ctx->autotune = false;
+    const char* dma = getenv("PHIHIP_ADVECT_DMA");      // A/B switch of the LDS-DMA fill of the tiled self-advection (advect_tile.hip)
+    if (dma && (dma[0] == '0' || dma[0] == '1')) ctx->adv_dma = dma[0] - '0';
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cu = prop.multiProcessorCount;
     *out = ctx;
@@ -990,6 +992,13 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
 int phihip_query_advect_chunk(phihip_ctx* ctx, int32_t* planes) {
     PHIHIP_REQUIRE(ctx != nullptr && planes != nullptr, "query_advect_chunk: NULL argument");
     *planes = ctx->adv_last_chunk;
+    return PHIHIP_OK;
+}
+
+int phihip_set_advect_dma(phihip_ctx* ctx, int enable, int32_t* last_was_dma) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (enable >= 0) ctx->adv_dma = enable != 0;
+    if (last_was_dma) *last_was_dma = ctx->adv_last_dma;
     return PHIHIP_OK;
 }
 

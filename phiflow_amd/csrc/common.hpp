@@ -160,6 +160,8 @@ struct phihip_ctx {
     int* adv_host_dev = nullptr;
     unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter
     bool adv_seq_captured = false;   // the most recent such launch was captured into a hipGraph (its own counter, cleared by a memset node)
+    int adv_last_dma = 0;         // the most recent tiled self-advection filled its ring by LDS-DMA
+    int adv_dma = 1;              // r5: regular grids fill the self-advection's ring by LDS-DMA (PHIHIP_ADVECT_DMA=0: the register-staged kernel everywhere)
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
     int adv_last_chunk = 0;       // planes per workgroup the most recent tiled self-advection ran with (phihip_query_advect_chunk)
     int adv_halo = -1;            // phihip_set_advect_halo: reach of the LDS-staged advection kernels. -1 (default) = adaptive per kind of pass (AdvPolicy below),

@@ -310,6 +310,38 @@ def check_advect_staggered(ctx, mem, dom, grid, dtype, rng, dt=0.7, scale=1.0):
             truth_check(mem.to_host(dout[d]), ref[d], truth[d], dtype, f"advect field != velocity [{d}]")
 
 
+def check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=True):
+    """ r5: the tiled self-advection with its ring filled by LDS-DMA (regular grids: 3-D, no closed side, periodic fast axis with rows of whole
+    16-byte vectors) against the oracle, against the register-staged kernel (the SAME bits: same samples, same arithmetic) and with the path
+    asserted (phihip_set_advect_dma reports which kernel ran); gentle, random (fix-up list) and spot fields """
+    B = grid.batch
+    v = random_velocity(dom, B, dtype, rng)
+    fields = [("random", v)] + list(gentle_fields(v, dom, dt, dtype, rng))
+    try:
+        ctx.set_advect_halo(1)
+        for name, vel in fields:
+            dv = [mem.to_dev(a) for a in vel]
+            ref = O.semi_lagrangian_staggered(vel, vel, dt, dom)
+            outs = {}
+            for dma in (1, 0):
+                ctx.set_advect_dma(dma)
+                dout = [mem.empty(a.shape, dtype) for a in vel]
+                ctx.advect_staggered(grid, [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dv], [mem.ptr(a) for a in dout], dt)
+                mem.sync()
+                ran = ctx.set_advect_dma(-1)
+                assert ran == (bool(dma) and expect_dma), f"LDS-DMA kernel ran: {ran} (requested {dma}, grid regular: {expect_dma})"
+                outs[dma] = [mem.to_host(a) for a in dout]
+                if name == "gentle":
+                    assert_no_fallback(ctx, dom, f"self-advection, dma {dma}")
+            for d in range(dom.rank):
+                err = rel_err(outs[1][d], ref[d])
+                assert err <= advect_tol(dtype, dom), f"advect (LDS-DMA fill) [{d}] {name} field: rel err {err}"
+                assert np.array_equal(outs[1][d], outs[0][d]), f"advect [{d}] {name} field: the LDS-DMA kernel and the register-staged kernel differ"
+    finally:
+        ctx.set_advect_dma(1)
+        ctx.set_advect_halo(-1)
+
+
 def gentle_fields(v, dom, dt, dtype, rng):
     """ (name, velocity) pairs derived from v: "gentle" = every displacement below 0.9 cells (the LDS-staged advection kernels serve every
     lookup from their windows), "spots" = gentle with a few samples 2.7 times faster (some workgroups are redone by the gather path) """

@@ -61,3 +61,17 @@ def test_driver_command_line_sharded_batch_world8(emu_library, tmp_path):
     assert sh["entries_per_rank"] == [1] * world and sh["iterations_per_rank"] == [[8]] * world and sh["verified_ok"] == [True] * world
     assert sh["entry0_all_bit_identical"]
     assert len({tuple(c) for c in sh["owned_checksums"]}) == world          # per-entry inflow positions: every rank holds a different simulation
+
+
+def test_phi_level_block_runs_on_the_emulation(emu_library, emu_ctx, monkeypatch):
+    """ bench.py's `phi_level` block (the drop-in path timed next to the C-ABI loop) executes end to end -- tiny sizes, the kernel sources under the
+    emulation, device synchronisation replaced: the bookkeeping of the block, not a measurement """
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "device_sync", lambda device: None)
+    rec = bench.phi_level_block(emu_ctx, emu_library, torch.device("cpu"), cg_iters=4, steps=2, sizes=(8,), plume_n=16, plume_steps=2)
+    assert set(rec) == {"taylor_green_8", "smoke_plume_16x16", "note"}
+    for k in ("taylor_green_8", "smoke_plume_16x16"):
+        assert rec[k]["ms_c_abi"] > 0 and rec[k]["ms_phi_level"] > 0
+

@@ -57,6 +57,24 @@ def test_advection_matches_oracle(emu_ctx, res, bc):
         pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+@pytest.mark.parametrize("res,bc,regular", [
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True),
+    ((6, 10, 64), ((PER, PER), (PER, PER), (PER, PER)), True),
+    ((5, 9, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True),      # open slow axis (clamped planes), three tiles along the fast axis, the last one partial
+    ((9, 11, 24), ((PER, PER), (OPN, OPN), (PER, PER)), True),      # open rows: n1 + 1 faces of the a1 component, clamped halo rows, ragged last tile row
+    ((7, 8, 18), ((PER, PER), (PER, PER), (PER, PER)), False),      # rows of 18 cells: not whole fp32 vectors (fp64: regular)
+    ((6, 8, 16), ((PER, PER), (PER, PER), (OPN, OPN)), False),      # the fast axis is not periodic
+    ((6, 8, 16), ((CLO, CLO), (PER, PER), (PER, PER)), False),      # a closed side: constants to pad
+])
+def test_self_advection_lds_dma_fill(emu_ctx, res, bc, regular):
+    rng = np.random.default_rng(41)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        reg = regular or (dtype == np.float64 and res == (7, 8, 18))
+        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=0.7, expect_dma=reg)
+        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.1, expect_dma=reg)
+
+
 @pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)
 def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
     """ advect.mac_cormack (centred + staggered) and the centred -> staggered resample used for buoyancy """

@@ -416,6 +416,23 @@ def test_tile_configurations_agree(ctx, mem):
         ctx.set_tuning(0, 0, 0)
 
 
+@pytest.mark.parametrize("res,bc,regular", [
+    ((40, 36, 256), ((PER, PER), (PER, PER), (PER, PER)), True),      # the benchmark configuration's shape class: four tiles per row, 4.5 tile rows
+    ((24, 20, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True),      # clamped planes, a partial last tile along the fast axis
+    ((19, 27, 64), ((PER, PER), (OPN, OPN), (PER, PER)), True),       # clamped halo rows, n1 + 1 faces of the a1 component
+    ((12, 16, 72), ((PER, PER), (PER, PER), (OPN, OPN)), False),      # fast axis not periodic: the register-staged kernel
+    ((12, 16, 64), ((PER, PER), (CLO, CLO), (PER, PER)), False),      # a closed side
+])
+def test_self_advection_lds_dma_fill(ctx, mem, res, bc, regular):
+    """ r5: ring of the tiled self-advection filled by global_load_lds_dwordx4 (inline assembly, counted vmcnt waits, raw s_barrier): oracle parity, the
+    SAME bits as the register-staged kernel, the path asserted; many workgroups, several chunks, CFL below and above 1 (fix-up list) """
+    rng = np.random.default_rng(41)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=regular)
+        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=2.1, expect_dma=regular)
+
+
 def test_cellflags_byte_parallel_kernel(ctx, mem):
     """ r5: phihip_build_cellflags -- byte-parallel kernel (16 / 4 cells per thread) and the scalar kernel -- on random masks with arbitrary non-zero
     bytes against the NumPy restatement of fluid.py:130-137,277-288; sizes that span many workgroups, every boundary kind, per-batch masks """
