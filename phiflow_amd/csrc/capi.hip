@@ -137,6 +137,10 @@ int ensure_adv_host_public(phihip_ctx* ctx) { return ensure_adv_host(ctx); }
 int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     if (stream_is_capturing(s)) return PHIHIP_OK;           // (an event record would become a node of the graph; captured passes keep their reach)
     phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
+    // one observation at a time: while the event of an earlier pass is unresolved (a host that runs steps ahead of the device) it is NOT re-recorded --
+    // re-recording every pass kept the event forever in the future and the policy never adapted in an enqueue-only loop (found with the smoke256
+    // workload: the switch to the wide reach came 50 steps late). The published count is the newest completed pass's: same reach, fresher data.
+    if (P.pending) return PHIHIP_OK;
     if (!P.ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
     PHIHIP_CHECK_HIP(hipEventRecord(P.ev, s));
     P.pending = true;

@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_xdist_auto_num_workers(config):
+    """ `-n auto` (pytest.ini): CPU suite on up to 6 cores; with a GPU present (the `-m gpu` tiers of the driver) everything stays in ONE process """
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return 0
+    except Exception:
+        pass
+    return max(1, min(6, (os.cpu_count() or 2) - 1))
+
+
 def _emu_is_stale():
     if not os.path.exists(EMU_LIB):
         return True
@@ -33,8 +44,11 @@ def emu_library():
     # contexts on the emulation keep the analytic launch plan: timing candidates there is meaningless (and the bit-for-bit tests of
     # tests/test_parallel_gloo.py need the same launch geometry in every process)
     os.environ["PHIHIP_AUTOTUNE"] = "0"
-    if _emu_is_stale():
-        subprocess.run(["bash", os.path.join(EMU_DIR, "build_emu.sh")], check=True, stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # xdist workers: ONE of them rebuilds a stale library, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if _emu_is_stale():
+            subprocess.run(["bash", os.path.join(EMU_DIR, "build_emu.sh")], check=True, stdout=subprocess.DEVNULL)
     return _capi.Library(EMU_LIB)
 
 

@@ -80,6 +80,10 @@ def group_f32_256(ctx, dev, n, reps):
         # a1: self-advection, LDS-tiled (one launch) and the gather kernels (one launch per component)
         ctx.set_advect_halo(1)
         ctx.advect_staggered(grid, P(vel), P(vel), P(out), dt)
+        if hasattr(ctx, "set_advect_dma"):      # r5: the same pass through the register-staged kernel (what non-regular grids run)
+            ctx.set_advect_dma(0)
+            ctx.advect_staggered(grid, P(vel), P(vel), P(out), dt)
+            ctx.set_advect_dma(1)
         ctx.set_advect_halo(0)
         ctx.advect_staggered(grid, P(vel), P(vel), P(out), dt)
         ctx.set_advect_halo(1)
@@ -99,7 +103,8 @@ def group_f32_256(ctx, dev, n, reps):
         ctx.make_incompressible(grid, P(out), None, 0, 1, True, p.data_ptr(), div.data_ptr(), solve, want_info=False)
         ctx.laplace_apply(grid, 0, 1, p.data_ptr(), div.data_ptr())
     sync(dev)
-    note(r"advect_self_tile_kernel<float, 3", "a1 semi-Lagrangian self-advection, LDS tiles (benchmark step)", 6 * w * N, 6, "read 3 + write 3 components")
+    note(r"advect_self_dma_kernel<float", "a1 semi-Lagrangian self-advection, LDS ring filled by LDS-DMA (r5; the benchmark step)", 6 * w * N, 6, "read 3 + write 3 components")
+    note(r"advect_self_tile_kernel<float, 3", "a1 semi-Lagrangian self-advection, register-staged LDS tiles (grids the LDS-DMA kernel cannot take; here: PHIHIP_ADVECT_DMA=0 pass)", 6 * w * N, 6, "read 3 + write 3 components")
     note(r"advect_staggered_kernel<float, 3, \d, 0>", "a1 gather kernel, one component per launch", 4 * w * N, 4, "read 3 components (taps) + write 1")
     note(r"advect_win_kernel<float, 1, 3", "f2 semi-Lagrangian advection of a centred scalar, LDS windows (r4)", 5 * w * N, 5, "read scalar + 3 components, write scalar")
     note(r"advect_win_kernel<float, 2, 3", "f2 MacCormack correction pass, centred scalar, LDS windows (r4)", 6 * w * N, 6, "read scalar, forward result, 3 components; write 1")
@@ -134,9 +139,10 @@ def group_f32_256(ctx, dev, n, reps):
         ctx.build_cellflags(grid, acc.data_ptr(), 0, 1, flags.data_ptr())
         ctx.apply_obstacles(grid, obs, 2, P(tmp))
     sync(dev)
-    note(r"obstacle_accessible_kernel", "f3 obstacle rasterisation (2 obstacles; 1 byte per cell: not a bandwidth kernel -- fp64 geometry only in patches near an obstacle)", 1 * N, 0.25, "write 1 byte per cell")
-    note(r"cellflags_kernel", "a7 packed stencil flags", 2 * N, 0.5, "read + write 1 byte per cell")
-    note(r"apply_obstacles_kernel<float>", "f3 apply_boundary_conditions, one component per launch (2 obstacles; samples farther than one cell radius from every obstacle are neither read nor written: the bytes by construction are an upper bound)", 2 * w * N, 2, "read + write one component")
+    note(r"obstacle_accessible_kernel", "f3 obstacle rasterisation (2 obstacles; r5: memset + the patches of the obstacles' index bounding box only: the bytes by construction are an upper bound)", 1 * N, 0.25, "write 1 byte per cell")
+    note(r"cellflags_vec_kernel", "a7 packed stencil flags, byte-parallel kernel (r5: 16 cells per thread)", 2 * N, 0.5, "read + write 1 byte per cell")
+    note(r"cellflags_kernel", "a7 packed stencil flags, one byte per thread (rows that are not whole 4-byte vectors)", 2 * N, 0.5, "read + write 1 byte per cell")
+    note(r"apply_obstacles_kernel<float>", "f3 apply_boundary_conditions, r5: ALL components in one launch over the patches of the obstacles' bounding box (2 obstacles; samples farther than one cell radius from every obstacle are neither read nor written: the bytes by construction are an upper bound)", 3 * 2 * w * N, 6, "read + write three components")
 
     # math.grid_sample + adjoint (fields on different grids, rk4)
     npts = N
