@@ -116,9 +116,21 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipS
     if (P.fp != grid_fp) {          // another grid (SlabFluid's whole-slab and window passes, two simulations on one context): its fallback
         P = phihip_ctx::AdvPolicy{P.ev, grid_fp};      // fraction says nothing about this one -- start from the narrow reach again
     }
-    // The pass the count belongs to is usually a step old and its event long fired. When it has not (a host that runs ahead), the previous
-    // choice stands: the host never blocks here (hipEventSynchronize serialised host and device once per pass).
-    if (P.pending && !capturing && hipEventQuery(P.ev) == hipSuccess) {
+    // The pass the count belongs to is usually a step old and its event long fired. When it has not (a host that runs ahead), the previous choice
+    // stands and the host does not block (hipEventSynchronize serialised host and device once per pass) -- up to kAdvMaxLag passes:
+    // an enqueue-only loop queues its steps in a fraction of the time they take, so an unbounded lag means "never adapts" (measured with the smoke256
+    // workload: the switch to the wide reach arrived after the timed region). Beyond the lag the host waits for that one old event: it is at most
+    // kAdvMaxLag steps behind the device's head, i.e. the device still has work queued.
+    constexpr int kAdvMaxLag = 4;
+    bool resolved = false;
+    if (P.pending && !capturing) {
+        resolved = hipEventQuery(P.ev) == hipSuccess;
+        if (!resolved && P.age >= kAdvMaxLag) {
+            PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));
+            resolved = true;
+        }
+    }
+    if (resolved) {
         P.pending = false;
         const double frac = P.units > 0 ? (double)ctx->adv_host[kind] / (double)P.units : 0.0;
         if (P.last == 1) P.mode = frac > (has_wide ? 0.02 : 0.15) ? (has_wide ? 2 : 0) : 1;
@@ -140,7 +152,8 @@ int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     // one observation at a time: while the event of an earlier pass is unresolved (a host that runs steps ahead of the device) it is NOT re-recorded --
     // re-recording every pass kept the event forever in the future and the policy never adapted in an enqueue-only loop (found with the smoke256
     // workload: the switch to the wide reach came 50 steps late). The published count is the newest completed pass's: same reach, fresher data.
-    if (P.pending) return PHIHIP_OK;
+    if (P.pending) { P.age += 1; return PHIHIP_OK; }
+    P.age = 0;
     if (!P.ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
     PHIHIP_CHECK_HIP(hipEventRecord(P.ev, s));
     P.pending = true;

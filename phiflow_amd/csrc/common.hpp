@@ -154,6 +154,7 @@ struct phihip_ctx {
         int calls = 0;
         long long units = 0;     // (tile, plane) units of that pass
         bool pending = false;    // an event + a published count are outstanding
+        int age = 0;             // passes of this kind enqueued since that event was recorded
     };
     AdvPolicy adv_policy[4];      // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
     int* adv_host = nullptr;      // pinned, device-mapped: fallback count per kind

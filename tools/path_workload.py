@@ -274,9 +274,9 @@ def tune_and_time(ctx, dev, group, n):
     sync(dev)
     plans = {str(f): ctx.query_plan(grid, flags is not None, f) for f in (0, 1, 2, 3)}
     out = {"group": group, "size": n, "plans": plans, "untraced_ms_per_cg_iteration": e0.elapsed_time(e1) / iters, "iterations_timed": iters}
-    if group == "f32_256" and hasattr(ctx, "query_advect_chunk"):
+    if group in ("f32_256", "f64_384") and hasattr(ctx, "query_advect_chunk"):      # (r5: the fp64 group too -- its traced average used to include the chunk candidates)
         shapes = [ctx.component_shape(grid, d) for d in range(3)]
-        v = [torch.randn(1, *sh, device=dev) * 0.01 for sh in shapes]
+        v = [torch.randn(1, *sh, device=dev, dtype=dtype) * 0.01 for sh in shapes]
         o = [torch.empty_like(t) for t in v]
         ctx.advect_staggered(grid, [t.data_ptr() for t in v], [t.data_ptr() for t in v], [t.data_ptr() for t in o], 0.5 * L / n)
         sync(dev)
