@@ -219,7 +219,8 @@ def device_for_rank(local_rank: int) -> torch.device:
 
 def load_library():
     lib = C.load_default_library()
-    assert lib.built_from_tree(), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
+    # (PHIHIP_LIBRARY = same-box A/B against another BUILD of the library, e.g. the previous round's: the record carries that build's id)
+    assert lib.built_from_tree() or os.environ.get("PHIHIP_LIBRARY"), f"stale libphihip.so ({lib.build_id()}) -- sources are src:{C.source_hash()}; run __graft_entry__.build()"
     return lib
 
 
@@ -805,6 +806,7 @@ def main():
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
     ap.add_argument("--tuning", type=str, default="", help="rows,threads_per_row,chunk override of the CG tile")
+    ap.add_argument("--advect-halo", type=int, default=-1, help="phihip_set_advect_halo: -1 adaptive reach (default), 0 gather kernels, 1 / 2 fixed reach of the LDS-staged advection passes (A/B of the policy)")
     ap.add_argument("--phi-level", type=int, default=1, help="1: time the same steps through phiflow_amd.flow next to the C-ABI loop (`phi_level`; rank 0, N = 1, ~3 s)")
     args = ap.parse_args()
 
@@ -831,6 +833,8 @@ def main():
     ctx = C.Context(lib, local_rank if device.type == "cuda" else 0)
     if args.resident_cg:
         ctx.set_resident_cg(args.resident_cg)
+    if args.advect_halo != -1:
+        ctx.set_advect_halo(args.advect_halo)
     if args.tuning:
         ctx.set_tuning(*[int(x) for x in args.tuning.split(",")])
     n, B = args.size, 1

@@ -168,8 +168,10 @@ static long long grid_fingerprint(const GridView& v) {
     return h ? h : 1;
 }
 static int pass_reach(phihip_ctx* ctx, const GridView& v, int kind, bool has_wide, hipStream_t s) {
-    if (ctx->adv_halo >= 0) return (!has_wide && ctx->adv_halo > 1) ? 1 : ctx->adv_halo;
-    return adv_choose(ctx, kind, has_wide, grid_fingerprint(v), s);
+    const int reach = ctx->adv_halo >= 0 ? ((!has_wide && ctx->adv_halo > 1) ? 1 : ctx->adv_halo) : adv_choose(ctx, kind, has_wide, grid_fingerprint(v), s);
+    ctx->adv_reach_now = reach >= 2 ? 2 : (reach == 1 ? 1 : 0);       // (3 = the experimental 16-row tile: reach 1... tagged 1 below)
+    if (reach == 3) ctx->adv_reach_now = 1;
+    return reach;
 }
 static int pass_done(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     return ctx->adv_halo < 0 ? adv_record(ctx, kind, reach, s) : PHIHIP_OK;

@@ -37,9 +37,9 @@ __device__ __forceinline__ int fix_count(const FixList& L) {
 __device__ __forceinline__ void fix_publish(const FixList& L, int count) {
     if (!L.publish) return;
 #ifdef __HIP_DEVICE_COMPILE__
-    __hip_atomic_store(L.publish, count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(L.publish, count | L.reach_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #else
-    *reinterpret_cast<volatile int*>(L.publish) = count;
+    *reinterpret_cast<volatile int*>(L.publish) = count | L.reach_tag;
 #endif
 }
 

@@ -802,7 +802,9 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     };
     if (DIM == 3 && ctx->adv_chunk > 0) {
         chunk = ctx->adv_chunk < nmax[0] ? ctx->adv_chunk : nmax[0];
-    } else if (DIM == 3 && ctx->autotune && (long long)nmax[0] * nmax[1] * nmax[2] * v.batch >= (1 << 21) && !stream_is_capturing(s)) {
+    } else if (DIM == 3 && H == 1 && ctx->autotune && (long long)nmax[0] * nmax[1] * nmax[2] * v.batch >= (1 << 21) && !stream_is_capturing(s)) {
+        // (reach 1 only: the wide kernel is what the adaptive policy switches to in the middle of a run -- timing six chunk lengths there cost the step in
+        // which the switch fell ~4.5 ms at 256^3, 20 steps' worth of what the better chunk length could save; it keeps the planner's length)
         // First call on this grid: the planner's chunk length against a few others, timed on the call's own operands (every length
         // writes the same values, so the output is simply overwritten; ~2 ms once per grid). The planner ranks slot efficiency x halo
         // overhead and misses e.g. the ring warm-up per chunk: 384^3 fp64 runs 6 % faster with 16 planes than with its 64.

@@ -110,6 +110,13 @@ static int ensure_adv_host(phihip_ctx* ctx) {
     return PHIHIP_OK;
 }
 
+// Fallback fractions (share of the (tile, plane) units whose lookups left the window) at which the reach changes. r5, measured with the smoke256 workload at
+// three stages of its plume with the reach FIXED (profiles/r05_smoke256_reach.jsonl; narrow + fix-up list / wide / gather): self-advection 0.24 / 0.27 / 0.46 ms at
+// 5.6 % of the units, 0.32 / 0.31 / 0.45 at 15 %, 0.39 / 0.34 / 0.47 at 19 % -- the cross-over to the wide window is near 12 %, not at the 2 % of round 4 (the
+// work list made the fix-up cheap: a flagged unit costs one gather workgroup, a wide window costs every workgroup a third of its occupancy); the centred kinds
+// (MacCormack smoke: 0.29 / 0.34, 0.34 / 0.39, 0.36 / 0.40) are faster narrow at every fraction seen.
+constexpr double kAdvWideAtSelf = 0.12, kAdvWideAtCentred = 0.30, kAdvGatherAtNarrow = 0.15, kAdvGatherAtWide = 0.25;
+
 int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipStream_t s) {
     phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
     const bool capturing = stream_is_capturing(s);
@@ -132,9 +139,14 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipS
     }
     if (resolved) {
         P.pending = false;
-        const double frac = P.units > 0 ? (double)ctx->adv_host[kind] / (double)P.units : 0.0;
-        if (P.last == 1) P.mode = frac > (has_wide ? 0.02 : 0.15) ? (has_wide ? 2 : 0) : 1;
-        else if (P.last == 2) P.mode = frac > 0.25 ? 0 : 2;
+        // the word carries the reach of the pass that published it (r5: the count of the newest completed pass is read, which need not be the pass
+        // the event belongs to -- a probe of the narrow reach in between must not be taken for the wide reach failing)
+        const int word = ctx->adv_host[kind];
+        const int seen = (word >> 28) & 3;
+        const double frac = P.units > 0 ? (double)(word & ((1 << 28) - 1)) / (double)P.units : 0.0;
+        const double wide_at = kind == AK_SL_SELF ? kAdvWideAtSelf : kAdvWideAtCentred;
+        if (seen == 1) P.mode = frac > (has_wide ? wide_at : kAdvGatherAtNarrow) ? (has_wide ? 2 : 0) : 1;
+        else if (seen == 2) P.mode = frac > kAdvGatherAtWide ? 0 : 2;
     }
     P.calls += 1;
     if (!capturing && P.calls % 64 == 0) {                  // is the cheaper form good enough again?
@@ -196,6 +208,7 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
         list->publish = ctx->adv_host_dev + kind;
     }
     list->cap = (int)units;
+    list->reach_tag = (ctx->adv_reach_now & 3) << 28;       // (units < 2^28, checked above)
     *dump = (char*)ctx->ws_adv_flags.ptr + 64;
     ctx->adv_last_nblk = (int)units;
     return PHIHIP_OK;

@@ -161,6 +161,7 @@ struct phihip_ctx {
     int* adv_host_dev = nullptr;
     unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter
     bool adv_seq_captured = false;   // the most recent such launch was captured into a hipGraph (its own counter, cleared by a memset node)
+    int adv_reach_now = 0;        // reach of the LDS-staged pass being enqueued (advect.hip pass_reach -> prepare_fixlist)
     int adv_last_dma = 0;         // the most recent tiled self-advection filled its ring by LDS-DMA
     int adv_dma = 1;              // r5: regular grids fill the self-advection's ring by LDS-DMA (PHIHIP_ADVECT_DMA=0: the register-staged kernel everywhere)
     int adv_chunk = 0;            // planes per workgroup of the tiled advection (0 = planned from the occupancy)
@@ -244,6 +245,7 @@ struct FixList {
                          // the previous launch, has completed -- stream order); no atomics / tickets in the fix-up launch
     FixItem* items;
     int cap;
+    int reach_tag;       // reach of THIS pass (1 / 2) << 28: published with the count, so the host attributes a count to the reach that produced it
 };
 // ws_adv_flags = [16 control ints | 64-byte dump slot | work list]; `units` = (tile, plane) pairs of the launch = capacity of the list.
 // Call once per tile-kernel launch (the two counters alternate).

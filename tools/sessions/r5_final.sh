@@ -42,6 +42,21 @@ for l in open('$O/time_frow.jsonl'):
     print(d['lib'][:16].ljust(16), d['size'], d['dtype'], d['bc'], 'cfl', d.get('cfl'), ' '.join(f"{k}={v.get('ms','ERR')}" for k,v in d['kernels'].items()), d.get('advect_fallback'))
 PY
 timeout 120 tools/micro/issue_rates > $O/issue_rates.txt 2>&1; echo "micro rc=$?"
+# smoke256 as a same-box A/B against the round-4 library at three stages of the plume (where the one-off switch of the adaptive reach falls decides a single line)
+: > $O/smoke256_ab.jsonl
+for ROUND in 1 2; do for LIB in phiflow_amd/lib/libphihip_r4.so ""; do for W in 30 90 150; do
+    PHIHIP_LIBRARY=$LIB timeout 300 python bench.py --workload smoke256 --steps 40 --warmup $W > $O/tmp.json 2>> $O/smoke256_ab.err
+    python - <<PY >> $O/smoke256_ab.jsonl
+import json
+d=json.load(open('$O/tmp.json'))
+print(json.dumps({"lib": "$LIB" or "HEAD", "warmup": $W, "steps": 40, "ms_per_step": round(d["ms_per_step"],4), "op_ms_profiled_step": d.get("op_ms_profiled_step"), "non_cg_share": d.get("non_cg_share_of_profiled_step"), "fallback": d.get("advect_fallback_last_call"), "build_id": d.get("build_id")}))
+PY
+done; done; done
+python - <<PY
+import json
+for l in open('$O/smoke256_ab.jsonl'):
+    d=json.loads(l); o=d['op_ms_profiled_step']; print(d['lib'][-14:].ljust(14), 'warmup', d['warmup'], 'ms/step', d['ms_per_step'], 'mc_smoke', o['mac_cormack_smoke'], 'sl_v', o['semi_lagrangian_v'], d['fallback'])
+PY
 timeout 600 python tools/time_backward_step.py > $O/backward_step.jsonl 2> $O/backward_step.err; echo "bwd rc=$?"; cut -c1-300 $O/backward_step.jsonl
 timeout 300 python tools/time_host_api.py --size 128 > $O/host_api.jsonl 2>> $O/host_api.err; timeout 300 python tools/time_host_api.py --size 512 --batch 8 >> $O/host_api.jsonl 2>> $O/host_api.err; cat $O/host_api.jsonl
 find $O -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null

@@ -32,13 +32,13 @@ def main():
     ap.add_argument("--rank", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", default="")
-    ap.add_argument("--halo", type=int, default=1, help="phihip_set_advect_halo: 0 gather kernels, 1 / 2 reach of the LDS windows")
+    ap.add_argument("--halo", type=int, default=-1, help="phihip_set_advect_halo: -1 adaptive reach (the library's default), 0 gather kernels, 1 / 2 fixed reach of the LDS windows")
     ap.add_argument("--cfl", type=float, default=0.5, help="max |u| dt / dx of the smooth test field (> 1: the fastest regions leave the LDS windows: fix-up pass)")
     ap.add_argument("--device", default="cuda:0", help="cpu + --lib tests/hipemu/libphihip_emu.so = dry run of the call sequence")
     a = ap.parse_args()
     lib = C.Library(a.lib, strict=False) if a.lib else C.load_default_library()
     ctx = C.Context(lib, 0)
-    if a.halo != 1:
+    if a.halo != -1:
         ctx.set_advect_halo(a.halo)
     dev = torch.device(a.device)
     gpu = dev.type == "cuda"
