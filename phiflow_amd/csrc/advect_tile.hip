@@ -566,13 +566,27 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, T* lds_dst, int lane
 #endif
 }
 
-template <typename T, int T1>
+// GEN (r5, second step): grids with CLOSED / OPEN sides and rows that are not whole vectors (a closed box stores N - 1 faces of the component along its own
+// axis). The ring is still filled by LDS-DMA; what a 16-byte chunk cannot express is settled three ways:
+//   * a chunk (or row, or plane) that lies entirely beyond a CLOSED side is transferred from a small table in global memory that holds every wall constant
+//     replicated to 16 bytes (`kconst`, written when the constants change) -- PhiML pads axis after axis, so a2 wins over a1 over a0;
+//   * rows / planes beyond an OPEN side are the clamped row / plane (zero-gradient padding = the edge sample): an address, nothing else;
+//   * the few ELEMENTS left over -- the halo column beyond an open side (a copy of the edge element), the elements of a chunk that straddles a row end
+//     (N - 1 is not a multiple of 4) beyond that end, and the chunk that straddles the end of a plane's LAST row (its natural read would leave the plane: it is
+//     not transferred at all) -- are PATCHED by up to one thread each after the plane has landed: constant, copy of an LDS element of the same row, or one
+//     scalar global load. Workgroups with patches (tiles at a non-periodic fast-axis end) pay a second barrier per plane; the others run the regular loop.
+// OFFM: face-offset mask (1 below a CLOSED side), as in the register-staged kernel.
+template <typename T, int T1, int OFFM, bool GEN>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dma_kernel(TileGrid<T> g, CComp3a<T> vel, T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
-                                                                                         int chunk, int tiles1, int tiles2, int nblk, int nmax0, FixList fix, T* __restrict__ dump) {
+                                                                                         int chunk, int tiles1, int tiles2, int nblk, int nmax0, FixList fix, T* __restrict__ dump,
+                                                                                         const T* __restrict__ kconst) {
     using C = AdvDma<T, T1>;
-    constexpr int T2 = C::T2, TY = C::TY, S = C::S, V = C::V, PITCH = C::PITCH, PLANE = C::PLANE, NP = C::NP, NI = C::NI, G2 = C::G2;
+    constexpr int T2 = C::T2, TY = C::TY, S = C::S, V = C::V, PITCH = C::PITCH, PLANE = C::PLANE, NP = C::NP, NI = C::NI, G2 = C::G2, P1 = C::P1;
+    constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
+    static_assert(GEN || OFFM == 0, "regular grids store every lower face");
     __shared__ __attribute__((aligned(16))) T lds[3 * NP * PLANE];
     __shared__ int slow_sh[2];
+    __shared__ int patch_sh;            // GEN: some thread of this workgroup has an element to patch
 
     const int tid = threadIdx.x, tx = tid % T2, ty = tid / T2, lane = tid & (kWave - 1);
 #ifdef __HIP_DEVICE_COMPILE__
@@ -589,6 +603,7 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dm
     const int pb = c0 * chunk, pe = min(pb + chunk, nmax0);
     T* const outp[3] = {o0, o1, o2};
     if (tid < 2) slow_sh[tid] = 0;
+    if (GEN && tid == 2) patch_sh = 0;
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *fix.next = 0;
     unsigned obase[3];
     long long pstride[3];
@@ -611,31 +626,154 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dm
     const int fn2 = fc == 0 ? g.cn[0][2] : (fc == 1 ? g.cn[1][2] : g.cn[2][2]);
     const T* const fbase = (fc == 0 ? vel.p[0] : (fc == 1 ? vel.p[1] : vel.p[2])) + (long long)b * (fc == 0 ? g.ccells[0] : (fc == 1 ? g.ccells[1] : g.ccells[2]));
     const long long fstride = (long long)fn1 * fn2;
+    // a row index / chunk start of the window under the component's padding rule: the stored index to read and, beyond a CLOSED side, which constant replaces
+    // it (kind = axis * 2 + side, -1 = none)
+    auto resolve_row = [&](int j, int n1, int& kind) -> int {
+        kind = -1;
+        if (j < 0) {
+            if (g.bc[1][0] == PHIHIP_BC_PERIODIC) return wrap_index(j, n1);
+            if (g.bc[1][0] == PHIHIP_BC_CLOSED) kind = 2;
+            return 0;
+        }
+        if (j >= n1) {
+            if (g.bc[1][1] == PHIHIP_BC_PERIODIC) return wrap_index(j, n1);
+            if (g.bc[1][1] == PHIHIP_BC_CLOSED) kind = 3;
+            return n1 - 1;
+        }
+        return j;
+    };
     unsigned doff[NI];
+    int ckind[GEN ? NI : 1];            // GEN: -1 = transfer from the array, 0 .. 5 = from the constant table (axis * 2 + side), 7 = not transferred (patched)
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int q = k * kWave + lane;
         const int rr = q / G2, gg = q - rr * G2;
-        int j = lo1 - 1 + rr;
-        if (g.bc[1][0] == PHIHIP_BC_PERIODIC) j = wrap_index(j, fn1);
-        j = min(max(j, 0), fn1 - 1);                           // OPEN: zero-gradient padding = the edge row
-        const int k0 = wrap_index(lo2 - V + gg * V, fn2);      // the fast axis is periodic and fn2 a multiple of V: a chunk never straddles the seam
-        doff[k] = (unsigned)(j * fn2 + k0) * (unsigned)sizeof(T);
+        if (!GEN) {
+            int j = lo1 - 1 + rr;
+            if (g.bc[1][0] == PHIHIP_BC_PERIODIC) j = wrap_index(j, fn1);
+            j = min(max(j, 0), fn1 - 1);                           // OPEN: zero-gradient padding = the edge row
+            const int k0 = wrap_index(lo2 - V + gg * V, fn2);      // the fast axis is periodic and fn2 a multiple of V: a chunk never straddles the seam
+            doff[k] = (unsigned)(j * fn2 + k0) * (unsigned)sizeof(T);
+        } else {
+            int rkind, kind = -1;
+            const int j = resolve_row(lo1 - 1 + rr, fn1, rkind);
+            int k0 = lo2 - V + gg * V;
+            if (k0 + V <= 0) {                                     // entirely below the row
+                if (g.bc[2][0] == PHIHIP_BC_PERIODIC) k0 = wrap_index(k0, fn2);
+                else if (g.bc[2][0] == PHIHIP_BC_CLOSED) { kind = 4; k0 = 0; }
+                else k0 = 0;                                       // OPEN: any valid chunk -- the halo element is patched (copy of the edge element)
+            } else if (k0 >= fn2) {                                // entirely beyond the row
+                if (g.bc[2][1] == PHIHIP_BC_PERIODIC) k0 = wrap_index(k0, fn2);
+                else if (g.bc[2][1] == PHIHIP_BC_CLOSED) { kind = 5; k0 = 0; }
+                else k0 = fn2 - V;
+            } else if (k0 + V > fn2) {                             // straddles the row's end (rows of N - 1 / N + 1 faces): the elements beyond it are patched;
+                if (j == fn1 - 1) kind = 7;                        // in a plane's LAST row the read would leave the plane (the array, at its end): patched whole
+            }
+            if (kind < 0 && rkind >= 0) kind = rkind;              // (a2 wins over a1)
+            ckind[k] = kind;
+            doff[k] = (unsigned)(j * fn2 + k0) * (unsigned)sizeof(T);
+        }
     }
-    auto plane_src = [&](int i0) -> long long {
+    // plane i0 of the wavefront's component: element offset of the plane to read and, beyond a CLOSED a0 side, the constant kind (0 / 1)
+    auto plane_src = [&](int i0, int& pkind) -> long long {
         int w = i0;
+        pkind = -1;
         if (g.bc[0][0] == PHIHIP_BC_PERIODIC) { w += w < 0 ? fn0 : 0; w -= w >= fn0 ? fn0 : 0; }
+        if (GEN && w < 0 && g.bc[0][0] == PHIHIP_BC_CLOSED) pkind = 0;
+        if (GEN && w >= fn0 && g.bc[0][1] == PHIHIP_BC_CLOSED) pkind = 1;
         w = min(max(w, 0), fn0 - 1);
         return (long long)w * fstride;
     };
     auto feed = [&](int i0) {      // request plane i0 of the wavefront's component into its ring slot
         if (wave < 3) {
-            const char* const src = reinterpret_cast<const char*>(fbase + plane_src(i0));
+            int pkind;
+            const char* const src = reinterpret_cast<const char*>(fbase + plane_src(i0, pkind));
             T* const dst = lds + (fc * NP + (i0 & (NP - 1))) * PLANE;
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
-                if (k * kWave + lane < C::NCH) lds_dma16<T>(src + doff[k], dst + k * kWave * V, lane);
+                if (!GEN) {
+                    if (k * kWave + lane < C::NCH) lds_dma16<T>(src + doff[k], dst + k * kWave * V, lane);
+                } else {
+                    const int kind = ckind[k] >= 0 ? ckind[k] : pkind;      // chunk / row constants win over the plane's
+                    const char* const from = kind >= 0 ? reinterpret_cast<const char*>(kconst + (kind * 3 + fc) * V) : src + doff[k];
+                    if (k * kWave + lane < C::NCH && ckind[k] != 7) lds_dma16<T>(from, dst + k * kWave * V, lane);
+                }
             }
+        }
+    };
+    // ---- GEN: the patch element of this thread (plane-invariant): thread e of component c, window row rr -> one column --------------------------------
+    //   slot 0: the halo column below the row (OPEN: copy of column 0; CLOSED: constant -- redundant with the constant chunk, harmless)
+    //   slot 1, 2: the first / second column beyond the row's end (OPEN: copy of the last column; CLOSED: constant)
+    //   slot 3 ..: the in-row elements of a straddling chunk that is not transferred (last row of a plane): one scalar global load each
+    constexpr int PE = V + 2;
+    static_assert(3 * P1 * PE <= kBlock, "one patch element per thread");
+    int pmode = 0;                      // 0 none, 1 constant, 2 copy of an LDS element of the same (component, slot, row), 3 global element
+    int pdst = 0, psrc = 0, pcomp = 0;
+    T pval = T(0);
+    long long pgoff = 0, ppstr = 0;
+    int prow_kind = -1, pn0 = 1;
+    const T* pbase = vel.p[2];
+    if (GEN && tid < 3 * P1 * PE) {
+        const int c = tid / (P1 * PE), rr = (tid / PE) % P1, e = tid % PE;
+        const int n1 = c == 0 ? g.cn[0][1] : (c == 1 ? g.cn[1][1] : g.cn[2][1]), n2 = c == 0 ? g.cn[0][2] : (c == 1 ? g.cn[1][2] : g.cn[2][2]);
+        int rkind;
+        const int j = resolve_row(lo1 - 1 + rr, n1, rkind);
+        const int w0 = lo2 - V;                                 // stored column of window column 0
+        const int ks = (n2 / V) * V;                            // start of the chunk that straddles the row's end (if n2 % V != 0)
+        int col = 0;
+        pcomp = c;
+        prow_kind = rkind;
+        if (e == 0) {
+            col = lo2 - 1;
+            if (col < 0 && g.bc[2][0] != PHIHIP_BC_PERIODIC) {
+                pmode = g.bc[2][0] == PHIHIP_BC_CLOSED ? 1 : 2;
+                pval = c == 0 ? g.bcv[2][0][0] : (c == 1 ? g.bcv[2][0][1] : g.bcv[2][0][2]);      // (selects: a per-lane index into kernel arguments goes through scratch)
+                psrc = rr * PITCH + (0 - w0);
+            }
+        } else if (e <= 2) {
+            col = n2 + (e - 1);
+            if (g.bc[2][1] != PHIHIP_BC_PERIODIC && col >= w0 && col <= lo2 + T2 && n2 - 1 >= w0) {
+                pmode = g.bc[2][1] == PHIHIP_BC_CLOSED ? 1 : 2;
+                pval = c == 0 ? g.bcv[2][1][0] : (c == 1 ? g.bcv[2][1][1] : g.bcv[2][1][2]);
+                psrc = rr * PITCH + (n2 - 1 - w0);
+                if (pmode == 2 && n2 % V != 0 && j == n1 - 1) {      // the edge element is itself patched in this phase (slot 3 ..): read what it reads
+                    pmode = 3;
+                    pgoff = (long long)j * n2 + (n2 - 1);
+                }
+            }
+        } else {
+            col = ks + (e - 3);
+            if (n2 % V != 0 && col < n2 && j == n1 - 1 && ks >= w0 && ks < w0 + G2 * V) {
+                pmode = 3;
+                pgoff = (long long)j * n2 + col;
+            }
+        }
+        pdst = rr * PITCH + (col - w0);
+        // (the component's array, extent and plane stride of this thread's element: resolved HERE -- inside the plane loop the compiler turns the select
+        // chains into a table in scratch, and a scratch load is a VMEM operation between the counted waits)
+        pn0 = c == 0 ? g.cn[0][0] : (c == 1 ? g.cn[1][0] : g.cn[2][0]);
+        ppstr = (long long)n1 * n2;
+        pbase = (c == 0 ? vel.p[0] : (c == 1 ? vel.p[1] : vel.p[2])) + (long long)b * (c == 0 ? g.ccells[0] : (c == 1 ? g.ccells[1] : g.ccells[2]));
+        if (pmode) patch_sh = 1;
+    }
+    auto patch = [&](int i0) {          // after plane i0 has landed (and a barrier): the elements no chunk can express
+        if (pmode) {
+            const int n0 = pn0;
+            const long long pstr = ppstr;
+            int w = i0, pkind = -1;
+            if (g.bc[0][0] == PHIHIP_BC_PERIODIC) { w += w < 0 ? n0 : 0; w -= w >= n0 ? n0 : 0; }
+            if (w < 0 && g.bc[0][0] == PHIHIP_BC_CLOSED) pkind = 0;
+            if (w >= n0 && g.bc[0][1] == PHIHIP_BC_CLOSED) pkind = 1;
+            w = min(max(w, 0), n0 - 1);
+            T* const P = lds + (pcomp * NP + (i0 & (NP - 1))) * PLANE;
+            T val;
+            if (pmode == 1) val = pval;
+            else if (pmode == 2) val = P[psrc];
+            else {
+                const int kind = prow_kind >= 0 ? prow_kind : pkind;
+                val = kind >= 0 ? kconst[(kind * 3 + pcomp) * V] : pbase[(long long)w * pstr + pgoff];
+            }
+            P[pdst] = val;
         }
     };
     // the feeding wavefronts wait until at most `stores` of their VMEM operations are in flight (= everything older than this half-step's output
@@ -670,15 +808,15 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dm
 #pragma unroll
                 for (int cb = 0; cb < 3; ++cb) {
                     if (cb == ca) continue;
-                    // component cb at this ca-face (every lower face is stored here: off = 0): cells (m - 1, m) along ca, faces (s, s + 1) along cb
+                    // component cb at this ca-face: cells (m - 1, m) along ca, faces (s, s + 1) along cb, in cb's stored indices (regular grids: off = 0)
                     T v4[2][2];
 #pragma unroll
                     for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) {
                             int d[3] = {0, 0, 0};
-                            d[ca] = -1 + ia;
-                            d[cb] = ib;
+                            d[ca] = OFF[ca] - 1 + ia;
+                            d[cb] = -OFF[cb] + ib;
                             v4[ia][ib] = at(cb, d[0], d[1], d[2]);
                         }
                     coord[cb] = (((v4[0][0] + v4[0][1]) + v4[1][0]) + v4[1][1]) * (T(-0.25) * g.shift[cb]);
@@ -730,11 +868,38 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? 4 : 2) void advect_self_dm
     feed(pb);
     feed(pb + 1);
     landed_and_barrier(std::integral_constant<int, 0>{});
+    auto wg_barrier = [&]() {
+#ifdef __HIP_DEVICE_COMPILE__
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+#else
+        __syncthreads();
+#endif
+    };
+    const bool patching = GEN && patch_sh != 0;       // (uniform: written before the barrier above)
+    if (patching) {
+        patch(pb - 1); patch(pb); patch(pb + 1);
+        wg_barrier();
+    }
     for (int p = pb; p < pe; ++p) {
         feed(p + 2);       // (beyond the chunk's last plane + 1 nobody reads it: requested all the same, the counts stay uniform)
         if (tile_full) compute_plane(p, std::true_type{}); else compute_plane(p, std::false_type{});
         landed_and_barrier(std::integral_constant<int, 3 * S>{});
+        if (patching) {        // plane p + 2 has landed and is visible: its patch elements, then the workgroup meets again before anybody reads the plane
+            patch(p + 2);
+            wg_barrier();
+        }
         report_plane(p);
+    }
+}
+
+// the wall constants of a grid, every one replicated to 16 bytes: kconst[(axis * 2 + side) * 3 + component][0 .. V)
+template <typename T>
+__global__ void advect_consts_kernel(TileGrid<T> g, T* __restrict__ kconst) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int t = threadIdx.x;
+    if (t < 18 * V) {
+        const int e = t / V, c = e % 3, as = e / 3;
+        kconst[t] = g.bcv[as >> 1][as & 1][c];
     }
 }
 
@@ -774,12 +939,35 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     int nblk = 0;
     // the tile kernel + its fix-up launch (fixed grid striding over the work list)
-    // r5: regular grids (3-D, reach 1, no CLOSED side, periodic fast axis with rows of whole 16-byte vectors) fill the ring by LDS-DMA
-    bool dma = false;
-    if constexpr (DIM == 3 && H == 1 && !CONSTS && OFFM == 0 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
-        dma = ctx->adv_dma != 0 && v.bc[2][0] == PHIHIP_BC_PERIODIC;
-        for (int c = 0; c < 3; ++c) dma = dma && v.cn[c][2] % (16 / (int)sizeof(T)) == 0 && v.cn[c][2] >= 2 * (16 / (int)sizeof(T)) && v.cn[c][1] >= 4 && v.cn[c][0] >= 4;
-        for (int c = 0; c < 3; ++c) dma = dma && (reinterpret_cast<uintptr_t>(vel[c]) & 15u) == 0;
+    // r5: the ring is filled by LDS-DMA -- `dma` = 1: regular grids (no CLOSED side, periodic fast axis with rows of whole 16-byte vectors, 16-byte-aligned
+    // arrays), 2: the GEN instantiation (closed / open sides, rows of N - 1 / N + 1 faces: constants from a table, patch elements)
+    int dma = 0;
+    constexpr int VV = 16 / (int)sizeof(T);
+    if constexpr (DIM == 3 && H == 1 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
+        bool ok = ctx->adv_dma != 0, regular = !CONSTS && OFFM == 0 && v.bc[2][0] == PHIHIP_BC_PERIODIC;
+        bool any_open = false;
+        for (int a = 0; a < 3; ++a) any_open = any_open || v.bc[a][0] == PHIHIP_BC_OPEN || v.bc[a][1] == PHIHIP_BC_OPEN;
+        for (int c = 0; c < 3; ++c) {
+            ok = ok && v.cn[c][2] >= 2 * VV && v.cn[c][1] >= 4 && v.cn[c][0] >= 4;
+            if (v.bc[2][0] == PHIHIP_BC_PERIODIC) ok = ok && v.cn[c][2] % VV == 0;            // (a wrapped chunk must not straddle the seam)
+            regular = regular && v.cn[c][2] % VV == 0 && (reinterpret_cast<uintptr_t>(vel[c]) & 15u) == 0;
+        }
+        (void)any_open;                                                                        // (open a0 / a1 sides are addresses only: still regular)
+        dma = ok ? (regular ? 1 : 2) : 0;
+    }
+    const T* kconst = nullptr;
+    if (dma == 2) {
+        // the wall constants, replicated to 16 bytes each, in a table the transfers can read (rewritten when they -- or the element type -- change)
+        PHIHIP_TRY(ensure_buffer(ctx->ws_adv_const, 18 * 16));
+        double key[19];
+        for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) for (int c = 0; c < 3; ++c) key[(a * 2 + sd) * 3 + c] = (double)g.bcv[a][sd][c];
+        key[18] = (double)sizeof(T);
+        if (!ctx->adv_const_valid || memcmp(key, ctx->adv_const_key, sizeof(key)) != 0 || stream_is_capturing(s)) {
+            hipLaunchKernelGGL((advect_consts_kernel<T>), dim3(1), dim3(128), 0, s, g, (T*)ctx->ws_adv_const.ptr);
+            memcpy(ctx->adv_const_key, key, sizeof(key));
+            ctx->adv_const_valid = !stream_is_capturing(s);      // (a captured launch rewrites the table in its own graph; eager launches after it write it again)
+        }
+        kconst = (const T*)ctx->ws_adv_const.ptr;
     }
     auto launch = [&](int ch) -> int {
         FixList fix;
@@ -787,10 +975,15 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
         PHIHIP_TRY(prepare_fixlist(ctx, (long long)tiles1 * tiles2 * nmax[0] * v.batch, s, &fix, &dump, kind));
         chunks0 = DIM == 3 ? ceil_div(nmax[0], ch) : 1;
         nblk = tiles1 * tiles2 * chunks0;
-        if constexpr (DIM == 3 && H == 1 && !CONSTS && OFFM == 0 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
-            if (dma)
-                hipLaunchKernelGGL((advect_self_dma_kernel<T, T1>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2], ch, tiles1,
-                                   tiles2, nblk, nmax[0], fix, (T*)dump);
+        if constexpr (DIM == 3 && H == 1 && (sizeof(T) == 4 ? T1 == 8 : T1 == 16)) {
+            if constexpr (!CONSTS && OFFM == 0) {
+                if (dma == 1)
+                    hipLaunchKernelGGL((advect_self_dma_kernel<T, T1, 0, false>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2], ch,
+                                       tiles1, tiles2, nblk, nmax[0], fix, (T*)dump, kconst);
+            }
+            if (dma == 2)
+                hipLaunchKernelGGL((advect_self_dma_kernel<T, T1, OFFM, true>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1], (T*)out[2], ch,
+                                   tiles1, tiles2, nblk, nmax[0], fix, (T*)dump, kconst);
         }
         if (!dma)
         hipLaunchKernelGGL((advect_self_tile_kernel<T, DIM, H, T1, OFFM, CONSTS>), dim3(nblk, v.batch), dim3(kBlock), 0, s, g, vv, (T*)out[0], (T*)out[1],
@@ -842,7 +1035,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
     }
     PHIHIP_TRY(launch(chunk));
     ctx->adv_last_chunk = DIM == 3 ? chunk : 0;
-    ctx->adv_last_dma = dma ? 1 : 0;
+    ctx->adv_last_dma = dma;
     return PHIHIP_OK;
 }
 
@@ -853,6 +1046,8 @@ int run_advect_self_tiled(phihip_ctx* ctx, const GridView& v, const void* const 
     const VelGrid g = make_velgrid(v);
 #if PHIHIP_ONLY_LEAN == 2
     return launch_tile_consts<double, 3, 1, 16, 7, true>(ctx, v, g, vel, out, dt, kind, s);
+#elif PHIHIP_ONLY_LEAN == 3
+    return launch_tile_consts<float, 3, 1, 8, 7, true>(ctx, v, g, vel, out, dt, kind, s);
 #else
     return launch_tile_consts<float, 3, 1, 8, 0, false>(ctx, v, g, vel, out, dt, kind, s);
 #endif

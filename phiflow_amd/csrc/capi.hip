@@ -323,7 +323,7 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
 int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (!ctx) return PHIHIP_OK;
     (void)hipSetDevice(ctx->device);
-    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1, &ctx->ws_adj_g, &ctx->ws_res};
+    DeviceBuffer* bufs[] = {&ctx->ws_r, &ctx->ws_d0, &ctx->ws_d1, &ctx->ws_div, &ctx->ws_part, &ctx->ws_state, &ctx->ws_scalars, &ctx->ws_rhs, &ctx->ws_adv, &ctx->ws_adv_flags, &ctx->ws_adj_q, &ctx->ws_adj_l, &ctx->ws_cg1, &ctx->ws_adj_g, &ctx->ws_res, &ctx->ws_adv_const};
     for (DeviceBuffer* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);

@@ -136,7 +136,7 @@ struct phihip_ctx {
     int num_cu = 256;
     phihip::Tuning tuning[5];   // per kernel family: 0 = APPLY / RESID, 1 = MATVEC, 2 = UPDATE, 3 = UPDATE_R, 4 = CG1 (fused iteration)
     // workspace (grown on demand, reused between calls)
-    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g, ws_res;
+    phihip::DeviceBuffer ws_r, ws_d0, ws_d1, ws_div, ws_part, ws_state, ws_scalars, ws_rhs, ws_adv, ws_adv_flags, ws_adj_q, ws_adj_l, ws_cg1, ws_adj_g, ws_res, ws_adv_const;
     int adv_last_nblk = 0;        // (tile, plane) units of the most recent LDS-staged advection launch (capacity of its fix-up work list)
     bool adv_ctl_clear = false;   // the work list's control block in ws_adv_flags has been zeroed
     // Adaptive reach (r4). Each LDS-staged pass publishes how many (tile, plane) units fell back to the gather path (the fix-up launch writes
@@ -161,6 +161,8 @@ struct phihip_ctx {
     int* adv_host_dev = nullptr;
     unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter
     bool adv_seq_captured = false;   // the most recent such launch was captured into a hipGraph (its own counter, cleared by a memset node)
+    double adv_const_key[19] = {0};   // the wall constants (+ element size) the table in ws_adv_const holds
+    bool adv_const_valid = false;
     int adv_reach_now = 0;        // reach of the LDS-staged pass being enqueued (advect.hip pass_reach -> prepare_fixlist)
     int adv_last_dma = 0;         // the most recent tiled self-advection filled its ring by LDS-DMA
     int adv_dma = 1;              // r5: regular grids fill the self-advection's ring by LDS-DMA (PHIHIP_ADVECT_DMA=0: the register-staged kernel everywhere)

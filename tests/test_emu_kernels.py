@@ -57,22 +57,29 @@ def test_advection_matches_oracle(emu_ctx, res, bc):
         pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
-@pytest.mark.parametrize("res,bc,regular", [
-    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True),
-    ((6, 10, 64), ((PER, PER), (PER, PER), (PER, PER)), True),
-    ((5, 9, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True),      # open slow axis (clamped planes), three tiles along the fast axis, the last one partial
-    ((9, 11, 24), ((PER, PER), (OPN, OPN), (PER, PER)), True),      # open rows: n1 + 1 faces of the a1 component, clamped halo rows, ragged last tile row
-    ((7, 8, 18), ((PER, PER), (PER, PER), (PER, PER)), False),      # rows of 18 cells: not whole fp32 vectors (fp64: regular)
-    ((6, 8, 16), ((PER, PER), (PER, PER), (OPN, OPN)), False),      # the fast axis is not periodic
-    ((6, 8, 16), ((CLO, CLO), (PER, PER), (PER, PER)), False),      # a closed side: constants to pad
+@pytest.mark.parametrize("res,bc,dma32,dma64", [
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True, True),
+    ((6, 10, 64), ((PER, PER), (PER, PER), (PER, PER)), True, True),
+    ((5, 9, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True, True),      # open slow axis (clamped planes), three tiles along the fast axis, the last one partial
+    ((9, 11, 24), ((PER, PER), (OPN, OPN), (PER, PER)), True, True),      # open rows: n1 + 1 faces of the a1 component, clamped halo rows, ragged last tile row
+    ((7, 8, 18), ((PER, PER), (PER, PER), (PER, PER)), False, True),      # periodic rows of 18 cells: not whole fp32 vectors -> the register-staged kernel (fp64: regular)
+    # r5, second step -- the GEN instantiation: constants from the table, patch elements, face offsets
+    ((6, 8, 16), ((PER, PER), (PER, PER), (OPN, OPN)), True, True),       # open fast axis: rows of 17 faces (a straddling chunk per row), halo columns = copies of the edge
+    ((6, 8, 16), ((CLO, CLO), (PER, PER), (PER, PER)), True, True),       # closed slow axis: constant planes
+    ((9, 7, 20), ((CLO, CLO), (CLO, CLO), (CLO, CLO)), True, True),       # the closed box: 19 faces per row of the a2 component, constant rows / planes / chunks
+    ((5, 13, 72), ((CLO, OPN), (OPN, CLO), (CLO, OPN)), True, True),      # mixed sides, two tiles along the fast axis
+    ((4, 9, 67), ((OPN, CLO), (CLO, CLO), (OPN, OPN)), True, True),       # ragged cell rows (67): every component straddles; 68 faces of the a2 component
+    ((6, 5, 130), ((CLO, CLO), (PER, PER), (CLO, CLO)), True, True),      # 129 faces: the straddling chunk in the third tile; periodic rows wrap onto the last row
 ])
-def test_self_advection_lds_dma_fill(emu_ctx, res, bc, regular):
+def test_self_advection_lds_dma_fill(emu_ctx, res, bc, dma32, dma64):
     rng = np.random.default_rng(41)
-    for dtype in (np.float32, np.float64):
-        dom, grid = pc.make_case(res, bc, dtype, batch=2)
-        reg = regular or (dtype == np.float64 and res == (7, 8, 18))
-        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=0.7, expect_dma=reg)
-        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.1, expect_dma=reg)
+    for dtype, expect in ((np.float32, dma32), (np.float64, dma64)):
+        bcv = None
+        if any(side == CLO for pair in bc for side in pair):      # walls that move (tangentially and, for the constants' sake, normally too)
+            bcv = [[[float(rng.normal()) * 0.05 if bc[a][s] == CLO else 0.0 for c in range(3)] for s in range(2)] for a in range(3)]      # (small: the "gentle" fields must stay below one cell per step at the walls too)
+        dom, grid = pc.make_case(res, bc, dtype, batch=2, bc_val=bcv)
+        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=0.7, expect_dma=expect)
+        pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.1, expect_dma=expect)
 
 
 @pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)

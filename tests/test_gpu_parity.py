@@ -416,21 +416,30 @@ def test_tile_configurations_agree(ctx, mem):
         ctx.set_tuning(0, 0, 0)
 
 
-@pytest.mark.parametrize("res,bc,regular", [
-    ((40, 36, 256), ((PER, PER), (PER, PER), (PER, PER)), True),      # the benchmark configuration's shape class: four tiles per row, 4.5 tile rows
-    ((24, 20, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True),      # clamped planes, a partial last tile along the fast axis
-    ((19, 27, 64), ((PER, PER), (OPN, OPN), (PER, PER)), True),       # clamped halo rows, n1 + 1 faces of the a1 component
-    ((12, 16, 72), ((PER, PER), (PER, PER), (OPN, OPN)), False),      # fast axis not periodic: the register-staged kernel
-    ((12, 16, 64), ((PER, PER), (CLO, CLO), (PER, PER)), False),      # a closed side
+@pytest.mark.parametrize("res,bc,dma32,dma64", [
+    ((40, 36, 256), ((PER, PER), (PER, PER), (PER, PER)), True, True),      # the benchmark configuration's shape class: four tiles per row, 4.5 tile rows
+    ((24, 20, 136), ((OPN, OPN), (PER, PER), (PER, PER)), True, True),      # clamped planes, a partial last tile along the fast axis
+    ((19, 27, 64), ((PER, PER), (OPN, OPN), (PER, PER)), True, True),       # clamped halo rows, n1 + 1 faces of the a1 component
+    ((12, 16, 70), ((PER, PER), (PER, PER), (PER, PER)), False, True),      # periodic rows of 70 cells: not whole fp32 vectors -> the register-staged kernel
+    # the GEN instantiation (closed / open sides: constants from the table, patch elements, face offsets)
+    ((12, 16, 72), ((PER, PER), (PER, PER), (OPN, OPN)), True, True),       # open fast axis: 73 faces per row
+    ((40, 36, 256), ((CLO, CLO), (CLO, CLO), (CLO, CLO)), True, True),      # the closed box at the benchmark's row length: 255 faces per row of the a2 component
+    ((24, 44, 200), ((CLO, OPN), (OPN, CLO), (CLO, OPN)), True, True),      # mixed sides, partial tiles on both tiled axes
+    ((17, 30, 131), ((OPN, CLO), (CLO, CLO), (OPN, OPN)), True, True),      # ragged cell rows: every component straddles
+    ((20, 24, 192), ((CLO, CLO), (PER, PER), (CLO, CLO)), True, True),      # periodic rows wrap onto the last row (the chunk that is not transferred)
 ])
-def test_self_advection_lds_dma_fill(ctx, mem, res, bc, regular):
-    """ r5: ring of the tiled self-advection filled by global_load_lds_dwordx4 (inline assembly, counted vmcnt waits, raw s_barrier): oracle parity, the
-    SAME bits as the register-staged kernel, the path asserted; many workgroups, several chunks, CFL below and above 1 (fix-up list) """
+def test_self_advection_lds_dma_fill(ctx, mem, res, bc, dma32, dma64):
+    """ r5: ring of the tiled self-advection filled by global_load_lds_dwordx4 (inline assembly, counted vmcnt waits, raw s_barrier) -- regular grids and, second
+    step, the GEN instantiation for closed / open boxes: oracle parity, the SAME bits as the register-staged kernel, the path asserted; many workgroups, several
+    chunks, CFL below and above 1 (fix-up list), moving walls """
     rng = np.random.default_rng(41)
-    for dtype in (np.float32, np.float64):
-        dom, grid = pc.make_case(res, bc, dtype, batch=2)
-        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=regular)
-        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=2.1, expect_dma=regular)
+    for dtype, expect in ((np.float32, dma32), (np.float64, dma64)):
+        bcv = None
+        if any(side == CLO for pair in bc for side in pair):
+            bcv = [[[float(rng.normal()) * 0.05 if bc[a][s] == CLO else 0.0 for c in range(3)] for s in range(2)] for a in range(3)]
+        dom, grid = pc.make_case(res, bc, dtype, batch=2, bc_val=bcv)
+        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=expect)
+        pc.check_advect_self_dma(ctx, mem, dom, grid, dtype, rng, dt=2.1, expect_dma=expect)
 
 
 def test_cellflags_byte_parallel_kernel(ctx, mem):
