@@ -50,6 +50,12 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
     const int q = n >> 3, r = n & 7, x = b & 7;
     return x * q + (x < r ? x : r) + (b >> 3);
 }
+// the same ranges walked from their far ends: the k-th workgroup an XCD receives takes the LAST-but-k tile of that XCD's range (sawtooth, see march_kernel)
+__device__ __forceinline__ int xcd_order_rev(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    const int len = q + (x < r ? 1 : 0);
+    return x * q + (x < r ? x : r) + (len - 1 - (b >> 3));
+}
 
 
 enum NeighbourRule { NB_WRAP = 0, NB_CLAMP = 1, NB_ZERO = 2, NB_HALO = 3 };   // NB_HALO (axis a0 only): the plane comes from a
@@ -384,6 +390,9 @@ constexpr int march_min_waves() {
 // rows, the remaining threads idle. No halo COLUMNS exist: the neighbours beyond a row's ends are read from the row's own LDS copy with
 // the boundary rule (wrap / clamp / zero). Why: the power-of-two tiles cannot span a 288- ... 448-cell row, and their halo columns are what
 // the mid-size dip is made of (1.49 fabric read requests per needed one at 320^3 against 1.13 at 512^3).
+#ifndef PHIHIP_SAWTOOTH
+#define PHIHIP_SAWTOOTH 1
+#endif
 template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false, bool ROWT = false>
 __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
     constexpr int TRc = ROWT ? kBlock / (TPR / 2 + 1) : kBlock / TPR;   // thread rows (ROWT: at most -- rows of more than TPR / 2 lanes)
@@ -421,7 +430,14 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
 
     // XCD-aware block order: blocks b and b+8 share an XCD (and its L2); make consecutive tiles neighbours there.
     int bid = blockIdx.x;
-    bid = xcd_order(bid, g.nblk);
+    // Sawtooth (r5): the UPDATE kernels walk the grid BACK to front -- the planes of a chunk in descending order and, where a launch has more workgroups
+    // than the chip holds at once, every XCD its range of tiles from the far end (the SAME range: a tile stays on the XCD whose L2 the MATVEC before left
+    // its last planes in; mirroring the whole block order moved the tiles to other XCDs and took the gain away at 256^3). A CG iteration alternates MATVEC
+    // and UPDATE launches that share two of their three vectors; what one launch touched last is what is still in the L2 / the 256 MiB Infinity Cache when
+    // the next one starts, so the next one starts there (tools/micro/mall_sawtooth.hip: a plain triad over rotating vectors gains 3 % at 256^3 / 512^3
+    // and 8 ... 15 % at 320^3 ... 384^3).
+    constexpr bool DOWN = PHIHIP_SAWTOOTH && IS_UP && DIM3;
+    bid = DOWN ? xcd_order_rev(bid, g.nblk) : xcd_order(bid, g.nblk);
     const int t2 = bid % g.tiles2;
     const int t1 = (bid / g.tiles2) % g.tiles1;
     const int c0 = bid / (g.tiles2 * g.tiles1);
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
     // Odd chunks march DOWN: two neighbouring chunks of a tile then start at their common boundary, so the two planes they both
     // need (each other's first plane as halo) are requested at the same time and are served once from HBM (L2 / Infinity Cache
     // for the second requester) instead of once at the start of one chunk and again at the end of the other.
-    const int step = (DIM3 && BIDIR && (c0 & 1)) ? -1 : 1;   // compile-time +1 unless the BIDIR instantiation (MATVEC, short chunks)
+    const int step = (DIM3 && ((BIDIR && (c0 & 1)) != DOWN)) ? -1 : 1;   // compile-time unless the BIDIR instantiation (MATVEC, short chunks)
     const int i_first = step > 0 ? i_begin : i_end - 1;
     const int count = i_end - i_begin;
     const long long base = (long long)b * g.cells;
