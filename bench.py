@@ -659,10 +659,10 @@ def committed_traffic_ratio(n, kernel_name):
                     continue
                 for k in grp["kernels"]:
                     if kernel_name in k.get("label", "") and k.get("pmc_over_moved"):
-                        return float(k["pmc_over_moved"]), f"profiles/{name} group {grp['group']}"
+                        return float(k["pmc_over_moved"]), f"profiles/{name} group {grp['group']}", grp.get("pinned_plans")
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def roofline_block(n, per, pmc, world, cache_assisted, where, plans=None):
@@ -694,10 +694,18 @@ def roofline_block(n, per, pmc, world, cache_assisted, where, plans=None):
              "achievable_copy_GBs": 6290.0}
     if traffic and plans:
         label = {"cg_matvec_dot": "CG MATVEC", "cg_update": "CG UPDATE_X2", "cg_update_r": "CG UPDATE_R"}[dom_key]
-        ref_ratio, ref_src = committed_traffic_ratio(n, label)
+        ref_ratio, ref_src, ref_plans = committed_traffic_ratio(n, label)
         if ref_ratio:
+            # the halo columns / planes a tile re-reads belong to the launch plan: the two figures are the same measurement only where the first-call
+            # autotune of this invocation chose the plan the table was traced with
+            fam = {"cg_matvec_dot": "1", "cg_update": "2", "cg_update_r": "3"}[dom_key]
+            here = [int(v) for v in plans.get(fam, [])][:3]
+            ref = ref_plans.get(fam) if isinstance(ref_plans, dict) else None
+            ref = [int(ref[k]) for k in ("rows", "tpr", "chunk")] if ref else None
+            same = bool(here) and here == ref
             block["traffic_cross_check"] = {"pmc_over_moved_here": block["traffic_over_moved"], "pmc_over_moved_committed_table": ref_ratio, "table": ref_src,
-                                            "agree_within_3_percent": bool(abs(block["traffic_over_moved"] / ref_ratio - 1) <= 0.03)}
+                                            "plan_here": here, "plan_table": ref, "same_launch_plan": same,
+                                            "agree_within_3_percent": bool(abs(block["traffic_over_moved"] / ref_ratio - 1) <= 0.03) if same else None}
     it = {}
     t_mv, t_x2, t_ur = per["cg_matvec_dot"][0], per["cg_update"][0], per["cg_update_r"][0]
     if t_mv and (t_x2 or t_ur):

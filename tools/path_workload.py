@@ -229,7 +229,8 @@ def group_f64_384(ctx, dev, n, reps):
         ctx.make_incompressible(grid, P(v2), None, flags.data_ptr(), 1, True, p.data_ptr(), 0, solve, want_info=False)
     sync(dev)
     Nf = sum(int(np.prod(s)) for s in shapes)
-    note(r"advect_self_tile_kernel<double, 3", "a1 self-advection, closed box, LDS tiles", 2 * w * Nf, 6, "read 3 + write 3 components")
+    note(r"advect_self_dma_kernel<double", "a1 self-advection, closed box, LDS ring filled by LDS-DMA (r5, GEN instantiation: wall constants from a table, patch elements)", 2 * w * Nf, 6, "read 3 + write 3 components")
+    note(r"advect_self_tile_kernel<double, 3", "a1 self-advection, closed box, register-staged LDS tiles (r4; r5 only where the LDS-DMA kernel cannot take the grid)", 2 * w * Nf, 6, "read 3 + write 3 components")
     note(r"divergence_vec_kernel<double, 3", "a2 divergence * active + balance sums (r4: vector kernel)", w * (Nf + N) + N, 4, "read 3 components + flags, write div")
     note(r"divergence_kernel<double, 3>", "a2 divergence * active + balance sums, scalar kernel", w * (Nf + N) + N, 4, "read 3 components + flags, write div")
     note(r"march_kernel<double, 2, \d, \d+, 8, true", "a3+a5 initial residual with balance shift, flags", 4 * w * N + N, 4, "read x, y, flags; write y, r")
