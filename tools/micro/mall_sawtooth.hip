@@ -31,7 +31,41 @@ __global__ __launch_bounds__(256) void triad(const float4* __restrict__ a, const
     }
 }
 
+// second question (same kernel): does the RELATIVE placement of the vectors matter? n^3 fp32 vectors of 256^3 / 512^3 cells are exact powers of two long, so
+// vectors allocated back to back present every channel-interleave granule with the same phase in all three streams of a kernel. `skew`: vector i starts
+// i * skew bytes after where back-to-back placement would put it (one allocation, carved).      tools/micro/mall_sawtooth <reps> skew
+static void skew_scan(int reps) {
+    const int sizes[] = {256, 384, 512};
+    const long long skews[] = {0, 256, 1024, 4096, 4096 + 256, 16384, 65536, 65536 + 4096, 1 << 20, (1 << 20) + 4096 + 256, 2 << 20, (2 << 20) + 65536 + 4096};
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int n : sizes) {
+        const long long cells = (long long)n * n * n, vecs = cells / 4, bytes = cells * 4;
+        char* base = nullptr;
+        CHECK(hipMalloc(&base, 4 * bytes + 4 * (4 << 20)));
+        CHECK(hipMemset(base, 0, 4 * bytes + 4 * (4 << 20)));
+        for (int round = 0; round < 2; ++round)
+            for (long long skew : skews) {
+                float4* v[4];
+                for (int i = 0; i < 4; ++i) v[i] = (float4*)(base + i * (bytes + skew));
+                const int B = 1024;
+                const long long per = (vecs + B - 1) / B;
+                for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(triad, dim3(B), dim3(256), 0, 0, v[k % 4], v[(k + 1) % 4], v[(k + 2) % 4], per, vecs, k & 1, 0.5f);
+                CHECK(hipEventRecord(e0, 0));
+                for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(triad, dim3(B), dim3(256), 0, 0, v[k % 4], v[(k + 1) % 4], v[(k + 2) % 4], per, vecs, k & 1, 0.5f);
+                CHECK(hipEventRecord(e1, 0));
+                CHECK(hipEventSynchronize(e1));
+                float ms = 0;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                const double us = ms * 1000.0 / reps;
+                if (round == 1) printf("{\"n\": %d, \"skew_bytes\": %lld, \"us_per_kernel\": %.2f, \"TBs_moved\": %.3f}\n", n, skew, us, cells * 12.0 / us * 1e-6);
+            }
+        CHECK(hipFree(base));
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2) { skew_scan(atoi(argv[1])); return 0; }
     const int sizes[] = {192, 256, 288, 320, 384, 448, 512};
     const int blocks[] = {512, 1024, 2048, 8192};
     const int reps = argc > 1 ? atoi(argv[1]) : 120;
