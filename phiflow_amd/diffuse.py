@@ -67,6 +67,10 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
     backward pass is one more solve (with `solve.gradient_solve` if given) of the same system with homogeneous boundary constants. """
     from .field import require_plain, _torch_dtype_code
     from .solve import Solve, SolveInfo
+    from .jit import is_tracing
+    if is_tracing():
+        raise NotImplementedError("HIP backend: diffuse.implicit inside a jit_compile'd function is not available (its C entry point reports the solves to the "
+                                  "host); call it outside the captured function or use diffuse.explicit")
     from .fluid import _raise_if_failed
     from . import _capi
     require_plain(field, 'diffuse.implicit')

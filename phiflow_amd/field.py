@@ -31,6 +31,7 @@ def _torch_dtype_code(dtype: torch.dtype) -> int:
 class Field:
     """ A sampled scalar (centred) or vector (staggered) grid field with boundary conditions. """
     __array_ufunc__ = None     # `numpy_array * field` defers to Field.__rmul__ (a batch vector, one number per batch entry)
+    solve_info = None          # set on the pressure that a solve returns (solve.SolveInfo); None on every other field and on results of a captured function (jit.py)
 
     def __init__(self, resolution: Dict[str, int], bounds: Box, boundary: Extrapolation, values, staggered: bool,
                  backend: HipBackend, batched: bool, vector_scale: Optional[Sequence[float]] = None):

@@ -13,6 +13,7 @@ from .geom import Box, Cuboid, Sphere, embed, infinite_cylinder, union, vec
 from .fluid import Obstacle
 from .solve import ConvergenceException, Diverged, NotConverged, Solve, SolveInfo, copy_with
 from .linear import solve_linear
+from .jit import iterate, jit_compile
 
 __all__ = [
     'advect', 'diffuse', 'fluid', 'extrapolation',
@@ -22,4 +23,5 @@ __all__ = [
     'geom', 'Box', 'Cuboid', 'Sphere', 'embed', 'infinite_cylinder', 'union', 'vec', 'Obstacle',
     'functional_gradient', 'gradient', 'jacobian', 'l2_loss', 'stop_gradient',
     'ConvergenceException', 'Diverged', 'NotConverged', 'Solve', 'SolveInfo', 'copy_with', 'solve_linear',
+    'iterate', 'jit_compile',
 ]

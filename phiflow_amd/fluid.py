@@ -247,6 +247,12 @@ def make_incompressible(velocity: Field,
         pressure = x0.values.to(velocity.dtype)
         pressure = (pressure.expand(B, *res_shape) if pressure.shape[0] != B else pressure).clone().contiguous()
     csolve = solve.to_c(fp64)
+    from .jit import is_tracing
+    traced = is_tracing()       # inside a jit_compile'd function: no host read-back (jit.py) -- info = NULL, the host never polls the continue flags
+    if traced:
+        csolve.check_every = 0
+        if autodiff.needs_grad(*velocity.values):
+            raise NotImplementedError("HIP backend: gradients through a jit_compile'd function are not implemented (capture the forward step or differentiate it, not both)")
     if autodiff.needs_grad(*velocity.values):
         # differentiable path: the same kernels behind torch.autograd.Function nodes (adjoint kernels in csrc/adjoint.hip)
         vin = [t.contiguous() for t in velocity.values]
@@ -268,10 +274,12 @@ def make_incompressible(velocity: Field,
             _apply_obstacles_in_place(velocity, obstacles, new_v)
         infos = be.ctx.make_incompressible(velocity.grid_struct(), _ptrs(new_v), None,
                                            flags.data_ptr() if flags is not None else 0, mask_batch, div_bits, pressure.data_ptr(), 0, csolve,
-                                           True, be.stream())
-    info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
-                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
-    _raise_if_failed(info)
+                                           not traced, be.stream())
+    info = None
+    if infos is not None:
+        info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                         [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+        _raise_if_failed(info)
     v_out = Field(velocity.resolution, velocity.bounds, velocity.boundary, new_v, True, be, velocity.batched)
     p_out = Field(velocity.resolution, velocity.bounds, p_ext, pressure, False, be, velocity.batched)
     p_out.solve_info = info

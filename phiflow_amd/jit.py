@@ -1,0 +1,248 @@
+"""
+`jit_compile` and `iterate` -- the two PhiML functions a PhiFlow user wraps around the hot path: the step of every fluid example is
+`@jit_compile def step(v, p, dt): v = advect.semi_lagrangian(v, v, dt); ...; v, p = fluid.make_incompressible(v, obstacles, Solve(x0=p))`
+driven by `iterate(step, N, v0, p0, dt=...)` (reference: examples/grids/Smoke_Plume.ipynb cell 5, docs/Fluid_Simulation.ipynb cell 3,
+tests/commit/test_colab_fluids_tutorial.py:43, tests/commit/physics/test_higher_order.py:55-56).
+
+PhiML's `jit_compile` TRACES the function with its backend's compiler. Here there is no tracing compiler to hand the function to, and none
+is wanted: every operator of this package is already one or a few HIP kernels behind the C ABI. What a small grid pays for is the host --
+Python objects, ctypes marshalling, ~20 kernel launches of a few microseconds each (bench.py `phi_level`: +50 % at 128^2). So `jit_compile`
+here CAPTURES the function's launches into a hipGraph once (torch.cuda.CUDAGraph on a side stream) and REPLAYS the graph on every later call
+with the same signature:
+  * tensors of the arguments (the `values` of Fields, bare tensors; nested in tuples / lists / dicts) are the graph's inputs: they are copied
+    into the capture's input buffers before a replay (skipped where the caller passes the very buffer back);
+  * everything else (numbers, strings, Solve objects without x0, obstacles, boundaries, resolutions ...) is AUXILIARY like PhiML's non-tensor
+    arguments: part of the signature, a new value means a new capture (`forget_traces=True` keeps only the latest);
+  * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
+    hands out the buffers themselves for callers that consume a result before the next call.
+Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` run with `info = NULL` and
+`check_every = 0` (the library's capture-safe form: no host read-back, no synchronisation, no allocation, no first-call autotune --
+tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diverged are not raised. A tolerance solve under capture
+enqueues its whole launch budget (entries that converged early freeze on the device), so give it a `max_iterations` that fits the
+problem; grids of <= 16384 cells run the whole solve in ONE kernel with the convergence test on the device and need no such care.
+
+The function must be a pure function of its arguments (the capture runs it twice -- a warm-up that sizes the workspaces and tunes the
+launch plans, then the capture itself -- and never again). On the CPU emulation device (tests) nothing can be captured: the wrapper then
+runs the function eagerly under the same no-read-back rules, which exercises the signature / cache bookkeeping only.
+"""
+import functools
+import inspect
+from contextlib import contextmanager
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from .field import Field
+
+_TRACING = [0]
+
+
+def is_tracing() -> bool:
+    """ True while a `jit_compile`d function body runs (warm-up, capture, or the eager form on the emulation device) """
+    return _TRACING[0] > 0
+
+
+@contextmanager
+def _tracing():
+    _TRACING[0] += 1
+    try:
+        yield
+    finally:
+        _TRACING[0] -= 1
+
+
+# ---- argument trees: tensors out, tensors back in ---------------------------------------------------------------------------------------
+
+class _FieldSpec:
+    __slots__ = ("resolution", "bounds", "boundary", "staggered", "backend", "batched", "vector_scale", "count")
+
+    def __init__(self, f: Field):
+        self.resolution, self.bounds, self.boundary = dict(f.resolution), f.bounds, f.boundary
+        self.staggered, self.backend, self.batched, self.vector_scale = f.is_staggered, f.backend, f.batched, f.vector_scale
+        self.count = len(f.values) if f.is_staggered else 1
+
+    def key(self):
+        return ("Field", tuple(self.resolution.items()), repr(self.bounds), repr(self.boundary), self.staggered, id(self.backend), self.batched,
+                tuple(self.vector_scale) if self.vector_scale is not None else None)
+
+    def build(self, tensors: List[torch.Tensor]) -> Field:
+        values = list(tensors) if self.staggered else tensors[0]
+        return Field(self.resolution, self.bounds, self.boundary, values, self.staggered, self.backend, self.batched, self.vector_scale)
+
+
+class _Aux:
+    """ wrapper of an argument named in `auxiliary_args`: never descended into """
+    __slots__ = ("value",)
+
+    def __init__(self, value):
+        self.value = value
+
+
+def _flatten(obj, tensors: List[torch.Tensor]):
+    """ -> spec; appends the tensors of `obj` to `tensors` """
+    if isinstance(obj, _Aux):
+        return ("A", obj.value)
+    if isinstance(obj, torch.Tensor):
+        tensors.append(obj)
+        return ("T",)
+    if isinstance(obj, Field):
+        spec = _FieldSpec(obj)
+        tensors.extend(obj.values if obj.is_staggered else [obj.values])
+        return ("F", spec)
+    if isinstance(obj, (tuple, list)):
+        return ("L" if isinstance(obj, list) else "U", tuple(_flatten(o, tensors) for o in obj))
+    if isinstance(obj, dict):
+        return ("D", tuple((k, _flatten(v, tensors)) for k, v in obj.items()))
+    return ("A", obj)           # auxiliary: by value
+
+
+def _unflatten(spec, it):
+    kind = spec[0]
+    if kind == "T":
+        return next(it)
+    if kind == "F":
+        return spec[1].build([next(it) for _ in range(spec[1].count)])
+    if kind in ("L", "U"):
+        items = [_unflatten(s, it) for s in spec[1]]
+        return items if kind == "L" else tuple(items)
+    if kind == "D":
+        return {k: _unflatten(s, it) for k, s in spec[1]}
+    return spec[1]
+
+
+def _aux_key(value):
+    """ hashable stand-in of an auxiliary argument: its value where it is hashable, else its repr (Solve, Obstacle, Box, extrapolations print
+    their defining values) """
+    if isinstance(value, (torch.Tensor, Field)) or type(value).__module__ == "numpy" and hasattr(value, "shape") and getattr(value, "ndim", 0) > 0:
+        return ("object", id(value))        # by identity (the capture keeps the object alive, so the id stays its own)
+    try:
+        hash(value)
+        return value
+    except TypeError:
+        return repr(value)
+
+
+def _spec_key(spec):
+    kind = spec[0]
+    if kind == "T":
+        return "T"
+    if kind == "F":
+        return spec[1].key()
+    if kind in ("L", "U"):
+        return (kind,) + tuple(_spec_key(s) for s in spec[1])
+    if kind == "D":
+        return ("D",) + tuple((k, _spec_key(s)) for k, s in spec[1])
+    return ("A", type(spec[1]).__name__, _aux_key(spec[1]))
+
+
+class _Capture:
+    __slots__ = ("graph", "inputs", "outputs", "out_spec", "spec")
+
+
+class JitFunction:
+    """ the callable `jit_compile` returns """
+
+    def __init__(self, f: Callable, auxiliary_args: str = "", forget_traces: Optional[bool] = None, copy_outputs: bool = True):
+        self.f = f
+        self.auxiliary_args = tuple(a.strip() for a in auxiliary_args.split(",") if a.strip())
+        self.forget_traces = bool(forget_traces)
+        self.copy_outputs = copy_outputs
+        self.captures: Dict[Any, _Capture] = {}
+        self.traces = 0           # captures made so far (PhiML: the number of times the function was traced)
+        self.replays = 0
+        try:
+            self._sig = inspect.signature(f)
+        except (TypeError, ValueError):
+            self._sig = None
+        functools.update_wrapper(self, f)
+
+    def _mark_auxiliary(self, args, kwargs):
+        """ auxiliary_args name parameters whose tensors must NOT become graph inputs (PhiML: "not traced"): their value is part of the signature """
+        if not self.auxiliary_args or self._sig is None:
+            return args, kwargs
+        bound = self._sig.bind(*args, **kwargs)
+        for name in self.auxiliary_args:
+            if name in bound.arguments:
+                bound.arguments[name] = _Aux(bound.arguments[name])
+        return bound.args, bound.kwargs
+
+    def __call__(self, *args, **kwargs):
+        args, kwargs = self._mark_auxiliary(args, kwargs)
+        tensors: List[torch.Tensor] = []
+        spec = ("U", (_flatten(tuple(args), tensors), _flatten(dict(kwargs), tensors)))
+
+        def call(tree):
+            return self.f(*tree[0], **tree[1])
+
+        capturable = bool(tensors) and all(t.is_cuda for t in tensors)
+        if not capturable:
+            # emulation device / no tensors: the function itself, under the rules of a captured one
+            with _tracing():
+                return call(_unflatten(spec, iter(tensors)))
+        key = (_spec_key(spec), tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors))
+        cap = self.captures.get(key)
+        if cap is None:
+            if self.forget_traces:
+                self.captures.clear()
+            cap = self._capture(spec, tensors, call)
+            self.captures[key] = cap
+        else:
+            for dst, src in zip(cap.inputs, tensors):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        cap.graph.replay()
+        self.replays += 1
+        outs = [t.clone() for t in cap.outputs] if self.copy_outputs else list(cap.outputs)
+        return _unflatten(cap.out_spec, iter(outs))
+
+    def _capture(self, spec, tensors, call) -> _Capture:
+        device = tensors[0].device
+        cap = _Capture()
+        cap.spec = spec           # (keeps the auxiliary objects alive whose identity is part of the key)
+        cap.inputs = [t.detach().clone().contiguous() if t.is_contiguous() else t.detach().clone() for t in tensors]
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), _tracing():
+            call(_unflatten(spec, iter(cap.inputs)))       # warm-up on the capturing stream: workspaces grown, launch plans tuned, masks rasterised
+        side.synchronize()
+        for dst, src in zip(cap.inputs, tensors):          # (a function that wrote into its inputs would have spoilt them: Fields never do, bare tensors may)
+            dst.copy_(src)
+        torch.cuda.current_stream(device).synchronize()
+        cap.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.graph, stream=side), _tracing():
+            out = call(_unflatten(spec, iter(cap.inputs)))
+        cap.outputs = []
+        cap.out_spec = _flatten(out, cap.outputs)
+        self.traces += 1
+        return cap
+
+
+def jit_compile(f: Callable = None, auxiliary_args: str = "", forget_traces: bool = None, copy_outputs: bool = True):
+    """ `phiml.math.jit_compile(f, auxiliary_args='', forget_traces=None)`: returns a function with the signature of `f` whose GPU work is
+    captured in a hipGraph at the first call with a given signature and replayed afterwards (module docstring). Usable as `@jit_compile` and as
+    `@jit_compile(auxiliary_args='dt')`. """
+    if f is None:
+        return lambda g: JitFunction(g, auxiliary_args, forget_traces, copy_outputs)
+    return f if isinstance(f, JitFunction) else JitFunction(f, auxiliary_args, forget_traces, copy_outputs)
+
+
+def iterate(f: Callable, iterations: int, *x0, f_kwargs: dict = None, measure: Callable = None):
+    """ `phiml.math.iterate(f, iterations, *x0, f_kwargs=...)` for an integer count: x <- f(*x, **f_kwargs) `iterations` times, returns the
+    final state (a tuple if there are several state variables). `measure` (e.g. `time.perf_counter`): also returns the per-iteration
+    differences like PhiML. A trajectory (`iterations=batch(time=N)`) is not built here: append inside `f_kwargs` callbacks or loop by hand. """
+    if not isinstance(iterations, int):
+        raise NotImplementedError("iterate: pass the number of iterations as an int (a trajectory dimension is not supported on the HIP backend)")
+    f_kwargs = f_kwargs or {}
+    x = x0
+    times = []
+    t_prev = measure() if measure else None
+    for _ in range(iterations):
+        out = f(*x, **f_kwargs)
+        x = out if isinstance(out, tuple) else (out,)
+        assert len(x) == len(x0), f"function must return the {len(x0)} state variable(s) it was given, got {len(x)}"
+        if measure:
+            t_now = measure()
+            times.append(t_now - t_prev)
+            t_prev = t_now
+    result = x[0] if len(x0) == 1 else tuple(x)
+    return (result, times) if measure else result

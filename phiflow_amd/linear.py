@@ -105,11 +105,18 @@ def solve_linear(f: Callable, y: Field, solve: Solve, *f_args, grad_for_f: bool 
         x = (x.expand(B, *res_shape) if x.shape[0] != B else x).clone().contiguous()
     grid = _capi.make_grid(y.spatial_rank, _torch_dtype_code(y.dtype), B, list(res_shape), y.bounds.lower, y.bounds.upper, proto._codes, proto._bc_val)
     s = solve.with_defaults(fp64)
-    infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, mask_batch, rhs.data_ptr(), x.data_ptr(), s.to_c(fp64), True, be.stream())
-    info = SolveInfo(s, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
-                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
-    from .fluid import _raise_if_failed
-    _raise_if_failed(info)
+    from .jit import is_tracing
+    traced = is_tracing()       # inside a jit_compile'd function: no host read-back (jit.py)
+    csolve = s.to_c(fp64)
+    if traced:
+        csolve.check_every = 0
+    infos = be.ctx.cg_solve(grid, flags.data_ptr() if flags is not None else 0, mask_batch, rhs.data_ptr(), x.data_ptr(), csolve, not traced, be.stream())
+    info = None
+    if infos is not None:
+        info = SolveInfo(s, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                         [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+        from .fluid import _raise_if_failed
+        _raise_if_failed(info)
     out = Field(y.resolution, y.bounds, p_ext, x, False, be, y.batched or B > 1)
     out.solve_info = info
     return out

@@ -214,7 +214,7 @@ def test_example_scripts_run(gpu_backend):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for script, args in (("smoke_plume.py", ["--size", "64", "--steps", "3"]), ("taylor_green_3d.py", ["--size", "32", "--steps", "2"]),
+    for script, args in (("smoke_plume.py", ["--size", "64", "--steps", "3"]), ("smoke_plume.py", ["--size", "64", "--steps", "4", "--jit"]), ("taylor_green_3d.py", ["--size", "32", "--steps", "2"]),
                          ("viscous_taylor_green.py", ["--size", "64", "--steps", "4"])):
         r = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ms per step" in r.stdout, r.stderr[-2000:]

@@ -1,0 +1,177 @@
+"""
+`jit_compile` / `iterate` (phiflow_amd/jit.py; reference usage: examples/grids/Smoke_Plume.ipynb cell 5 `@jit_compile def step(...)`,
+tests/commit/physics/test_higher_order.py:55-56 `math.jit_compile(fourth_ord_runge_kutta)`, SURVEY 3.1 `iterate(step, batch(time=N), ...)`).
+
+CPU part (emulation device: nothing can be captured -- the wrapper runs the function eagerly under the rules of a captured one): argument
+trees, signature keys, the no-read-back form of the solves. GPU part (`-m gpu`): capture + replay must leave the bits of the eager steps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from phiflow_amd import jit as J
+from phiflow_amd.flow import (ZERO_GRADIENT, PERIODIC, Box, CenteredGrid, NotConverged, Obstacle, Solve, Sphere, StaggeredGrid, advect, diffuse,
+                              fluid, iterate, jit_compile, resample)
+
+
+def _plume(be, n=32):
+    dom = Box(x=100, y=100)
+    inflow = 0.2 * resample(Sphere(x=50, y=9.5, radius=5), to=CenteredGrid(0, ZERO_GRADIENT, dom, x=n, y=n, backend=be), soft=True)
+    v0 = StaggeredGrid(0, 0, dom, x=n, y=n, backend=be)
+    s0 = CenteredGrid(0, ZERO_GRADIENT, dom, x=n, y=n, backend=be)
+
+    def step(v, s, p, dt=1.0, iters=30):
+        s = advect.mac_cormack(s, v, dt) + inflow
+        v = advect.semi_lagrangian(v, v, dt) + resample(s * (0, 0.1), to=v)
+        v, p = fluid.make_incompressible(v, (), Solve('CG', 0, 0, x0=p, max_iterations=iters, suppress=[NotConverged]))
+        return v, s, p
+    return step, v0, s0
+
+
+def _np(field):
+    out = field.numpy()
+    return out if isinstance(out, list) else [out]
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(_np(fa), _np(fb)))
+
+
+def test_argument_trees_round_trip(emu_backend):
+    v = StaggeredGrid(1.5, PERIODIC, x=8, y=6, backend=emu_backend)
+    s = CenteredGrid(2.0, ZERO_GRADIENT, x=8, y=6, backend=emu_backend)
+    t = torch.arange(4.0)
+    tensors = []
+    tree = ((v, [s, t], {"k": 3, "w": (s, None)}), {"dt": 0.5, "solve": Solve('CG', 1e-3)})
+    spec = J._flatten(tree, tensors)
+    assert len(tensors) == 2 + 1 + 1 + 1                    # two components, the scalar, the tensor, the scalar again
+    back = J._unflatten(spec, iter(tensors))
+    assert back[0][0].is_staggered and back[0][0].boundary == v.boundary and back[0][0].values[1] is v.values[1]
+    assert back[0][1][1] is t and back[0][2]["k"] == 3 and back[0][2]["w"][1] is None and back[1]["dt"] == 0.5
+    # the key separates what a capture depends on: auxiliary values, boundaries, resolutions -- not the tensors' contents
+    k1 = J._spec_key(spec)
+    tensors2 = []
+    tree2 = ((v * 2.0, [s, t + 1], {"k": 3, "w": (s, None)}), {"dt": 0.5, "solve": Solve('CG', 1e-3)})
+    assert J._spec_key(J._flatten(tree2, tensors2)) == k1
+    for changed in (((v, [s, t], {"k": 4, "w": (s, None)}), {"dt": 0.5, "solve": Solve('CG', 1e-3)}),
+                    ((v, [s, t], {"k": 3, "w": (s, None)}), {"dt": 0.25, "solve": Solve('CG', 1e-3)}),
+                    ((v, [s, t], {"k": 3, "w": (s, None)}), {"dt": 0.5, "solve": Solve('CG', 1e-4)}),
+                    ((v.with_extrapolation(0), [s, t], {"k": 3, "w": (s, None)}), {"dt": 0.5, "solve": Solve('CG', 1e-3)})):
+        assert J._spec_key(J._flatten(changed, [])) != k1
+
+
+def test_jit_function_on_the_emulation_device_matches_eager(emu_backend):
+    """ no capture without a HIP device: the wrapper runs the function under the rules of a captured one (info = NULL, check_every = 0,
+    no exceptions from the solve) -- same arithmetic, so the same bits as the eager step """
+    step, v0, s0 = _plume(emu_backend)
+    jstep = jit_compile(step)
+    assert jstep.__name__ == "step"
+    seen = []
+
+    def probe(v, s, p):
+        out = step(v, s, p)
+        seen.append((J.is_tracing(), out[2].solve_info))
+        return out
+    state_e, state_j = (v0, s0, None), (v0, s0, None)
+    for _ in range(3):
+        state_e = step(*state_e)
+        state_j = jstep(*state_j)
+    assert _same(state_e, state_j)
+    assert state_e[2].solve_info.iterations == [30] and state_j[2].solve_info is None
+    jit_compile(probe)(v0, s0, None)
+    probe(v0, s0, None)
+    assert seen[0][0] is True and seen[0][1] is None and seen[1][0] is False and seen[1][1] is not None
+    assert not J.is_tracing()
+    # iterate: N steps, the final state
+    v_i, s_i, p_i = iterate(jstep, 3, v0, s0, None)
+    assert _same((v_i, s_i, p_i), state_e)
+    (v_t, s_t, p_t), times = iterate(jstep, 2, v0, s0, None, f_kwargs=dict(dt=1.0), measure=__import__("time").perf_counter)
+    assert len(times) == 2 and all(t > 0 for t in times)
+    with pytest.raises(NotImplementedError):
+        iterate(jstep, (3,), v0, s0, None)
+
+
+def test_what_a_captured_function_may_not_do(emu_backend):
+    v = StaggeredGrid(1.0, PERIODIC, x=8, y=8, backend=emu_backend)
+
+    @jit_compile
+    def bad(v):
+        return diffuse.implicit(v, 0.1, 1.0)
+    with pytest.raises(NotImplementedError, match="jit_compile"):
+        bad(v)
+    assert not J.is_tracing()              # the flag is restored when the function raises
+
+    # a tolerance solve that does not converge raises outside, stays silent inside (the host is not told)
+    rng = np.random.default_rng(1)
+    rough = StaggeredGrid([rng.standard_normal((16, 16)).astype(np.float32) for _ in range(2)], PERIODIC, x=16, y=16, backend=emu_backend)
+    with pytest.raises(NotConverged):
+        fluid.make_incompressible(rough, (), Solve('CG', 1e-7, 0, max_iterations=2))
+    v2, p2 = jit_compile(lambda u: fluid.make_incompressible(u, (), Solve('CG', 1e-7, 0, max_iterations=2)))(rough)
+    assert p2.solve_info is None and np.isfinite(p2.numpy()).all()
+
+
+# ---- GPU: capture and replay ------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,iters", [(32, 30), (128, 50), (192, 20)])       # one-kernel solve (<= 16384 cells), the benchmark's plume, the marching CG
+def test_captured_plume_step_replays_the_eager_bits(gpu_backend, n, iters):
+    step, v0, s0 = _plume(gpu_backend, n)
+    jstep = jit_compile(step)
+    state_e, state_j = (v0, s0, None), (v0, s0, None)
+    held = []
+    for k in range(6):
+        state_e = step(*state_e, iters=iters)
+        state_j = jstep(*state_j, iters=iters)
+        held.append((state_j, [a.copy() for f in state_j for a in _np(f)]))
+        assert _same(state_e, state_j), f"step {k}"
+    # signatures: (v, s, None) and (v, s, p) -- two captures, four replays of the second
+    assert jstep.traces == 2 and jstep.replays == 6
+    # results are clones: what step k returned is still what it was after later replays
+    for fields, copies in held:
+        assert all(np.array_equal(a, b) for a, b in zip([a for f in fields for a in _np(f)], copies))
+    assert state_j[2].solve_info is None and state_e[2].solve_info.iterations == [iters]
+    # an auxiliary value changes: a new capture, the same bits as eager again
+    e2 = step(*state_e, dt=0.5, iters=iters)
+    j2 = jstep(*state_j, dt=0.5, iters=iters)
+    assert jstep.traces == 3 and _same(e2, j2)
+
+
+@pytest.mark.gpu
+def test_captured_3d_step_with_obstacle_and_iterate(gpu_backend):
+    n = 40
+    dom = Box(x=1, y=1, z=1)
+    rng = np.random.default_rng(5)
+    v0 = StaggeredGrid([rng.standard_normal(s).astype(np.float32) * 0.02 for s in ((n - 1, n, n), (n, n - 1, n), (n, n, n - 1))], 0, dom, x=n, y=n, z=n,
+                       backend=gpu_backend)
+    ball = Obstacle(Sphere(x=0.5, y=0.5, z=0.4, radius=0.15))
+
+    def step(v, p, dt):
+        v = advect.semi_lagrangian(v, v, dt)
+        v = diffuse.explicit(v, 1e-3, dt)
+        return fluid.make_incompressible(v, [ball], Solve('CG', 0, 0, x0=p, max_iterations=25, suppress=[NotConverged]))
+    ve, pe = iterate(step, 4, v0, None, f_kwargs=dict(dt=0.2))
+    jstep = jit_compile(step, forget_traces=True, copy_outputs=False)
+    vj, pj = iterate(jstep, 4, v0, None, f_kwargs=dict(dt=0.2))
+    assert _same((ve, pe), (vj, pj))
+    assert len(jstep.captures) == 1 and jstep.traces == 2          # forget_traces: only the latest signature is kept
+
+
+@pytest.mark.gpu
+def test_auxiliary_args_keep_a_field_out_of_the_graph_inputs(gpu_backend):
+    n = 48
+    rng = np.random.default_rng(2)
+    v0 = StaggeredGrid([rng.standard_normal((n, n)).astype(np.float32) * 0.1 for _ in range(2)], PERIODIC, x=n, y=n, backend=gpu_backend)
+    force = CenteredGrid(np.random.default_rng(3).standard_normal((n, n)).astype(np.float32), PERIODIC, x=n, y=n, backend=gpu_backend)
+
+    def step(v, force, dt=0.1):
+        v = advect.semi_lagrangian(v, v, dt) + resample(force * (0, 0.1), to=v)
+        return fluid.make_incompressible(v, (), Solve('CG', 0, 0, max_iterations=20, suppress=[NotConverged]))[0]
+    j_in = jit_compile(step)
+    j_aux = jit_compile(step, auxiliary_args='force')
+    e = step(v0, force)
+    assert _same((e,), (j_in(v0, force),)) and _same((e,), (j_aux(v0, force),))
+    # as an input the field's NEW values reach the replay; as an auxiliary argument a new object is a new capture
+    force2 = force * 2.0
+    e2 = step(v0, force2)
+    assert _same((e2,), (j_in(v0, force2),)) and j_in.traces == 1
+    assert _same((e2,), (j_aux(v0, force2),)) and j_aux.traces == 2
