@@ -101,8 +101,8 @@ ScalarBc make_scalar_bc(const GridView& v, const int32_t s_bc[3][2], const doubl
 static int ensure_adv_host(phihip_ctx* ctx) {
     if (ctx->adv_host) return PHIHIP_OK;
     void* h = nullptr;
-    PHIHIP_CHECK_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
-    memset(h, 0, 64);
+    PHIHIP_CHECK_HIP(hipHostMalloc(&h, phihip_ctx::kAdvHostInts * sizeof(int), hipHostMallocMapped));
+    memset(h, 0, phihip_ctx::kAdvHostInts * sizeof(int));
     void* d = nullptr;
     PHIHIP_CHECK_HIP(hipHostGetDevicePointer(&d, h, 0));
     ctx->adv_host = (int*)h;
@@ -123,26 +123,25 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipS
     if (P.fp != grid_fp) {          // another grid (SlabFluid's whole-slab and window passes, two simulations on one context): its fallback
         P = phihip_ctx::AdvPolicy{P.ev, grid_fp};      // fraction says nothing about this one -- start from the narrow reach again
     }
-    // The pass the count belongs to is usually a step old and its event long fired. When it has not (a host that runs ahead), the previous choice
-    // stands and the host does not block (hipEventSynchronize serialised host and device once per pass) -- up to kAdvMaxLag passes:
-    // an enqueue-only loop queues its steps in a fraction of the time they take, so an unbounded lag means "never adapts" (measured with the smoke256
-    // workload: the switch to the wide reach arrived after the timed region). Beyond the lag the host waits for that one old event: it is at most
-    // kAdvMaxLag steps behind the device's head, i.e. the device still has work queued.
-    constexpr int kAdvMaxLag = 4;
+    // ONE observation at a time, resolved at a FIXED distance: the pass that recorded the event published its count into its own slot; exactly kAdvMaxLag
+    // passes later the host waits for that event -- it is then several steps old: the wait is free unless the host runs that far ahead of the device, and
+    // then the device still has that many passes queued -- and reads that slot. Nothing here depends on WHEN the host looks (r5, first version: hipEventQuery
+    // and "the newest completed pass's count" -- non-blocking, but the reach of a pass, and with it the last bits of its result, depended on host timing;
+    // before that, r4: a wait in every pass, which serialised host and device).
+    constexpr int kAdvMaxLag = 2;      // (the decision of pass k + 3 uses pass k: a host that only enqueues stays at most three passes ahead of the device)
+    if (!capturing) {
+        P.seq += 1;                                                        // this pass
+        if (ctx->adv_host) ctx->adv_host[phihip_ctx::kAdvSlotBase + kind * phihip_ctx::kAdvSlots + (P.seq % phihip_ctx::kAdvSlots)] = 0;   // (its slot's last user was resolved long ago)
+    }
     bool resolved = false;
-    if (P.pending && !capturing) {
-        resolved = hipEventQuery(P.ev) == hipSuccess;
-        if (!resolved && P.age >= kAdvMaxLag) {
-            PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));
-            resolved = true;
-        }
+    if (P.pending && !capturing && P.age >= kAdvMaxLag) {
+        PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));
+        resolved = true;
     }
     if (resolved) {
         P.pending = false;
-        // the word carries the reach of the pass that published it (r5: the count of the newest completed pass is read, which need not be the pass
-        // the event belongs to -- a probe of the narrow reach in between must not be taken for the wide reach failing)
-        const int word = ctx->adv_host[kind];
-        const int seen = (word >> 28) & 3;
+        const int word = ctx->adv_host[phihip_ctx::kAdvSlotBase + kind * phihip_ctx::kAdvSlots + (P.obs_seq % phihip_ctx::kAdvSlots)];
+        const int seen = (word >> 28) & 3;          // the reach the pass ran with (0: it published nothing)
         const double frac = P.units > 0 ? (double)(word & ((1 << 28) - 1)) / (double)P.units : 0.0;
         const double wide_at = kind == AK_SL_SELF ? kAdvWideAtSelf : kAdvWideAtCentred;
         if (seen == 1) P.mode = frac > (has_wide ? wide_at : kAdvGatherAtNarrow) ? (has_wide ? 2 : 0) : 1;
@@ -165,7 +164,9 @@ int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     // re-recording every pass kept the event forever in the future and the policy never adapted in an enqueue-only loop (found with the smoke256
     // workload: the switch to the wide reach came 50 steps late). The published count is the newest completed pass's: same reach, fresher data.
     if (P.pending) { P.age += 1; return PHIHIP_OK; }
+    if (reach == 0) return PHIHIP_OK;                       // a gather pass publishes nothing: no observation (the probe every 64 calls is the next one)
     P.age = 0;
+    P.obs_seq = P.seq;
     if (!P.ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
     PHIHIP_CHECK_HIP(hipEventRecord(P.ev, s));
     P.pending = true;
@@ -205,7 +206,9 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
     list->publish = nullptr;
     if (kind != AK_NONE && ctx->adv_halo < 0) {
         PHIHIP_TRY(ensure_adv_host(ctx));
-        list->publish = ctx->adv_host_dev + kind;
+        // every eager pass has its own slot (adv_choose reads the one of the pass it observes); captured passes, whose reach is fixed, share one per kind
+        list->publish = ctx->adv_host_dev + (stream_is_capturing(s) ? phihip_ctx::kAdvCaptureBase + kind
+                                                                    : phihip_ctx::kAdvSlotBase + kind * phihip_ctx::kAdvSlots + (int)(ctx->adv_policy[kind].seq % phihip_ctx::kAdvSlots));
     }
     list->cap = (int)units;
     list->reach_tag = (ctx->adv_reach_now & 3) << 28;       // (units < 2^28, checked above)

@@ -144,7 +144,9 @@ struct phihip_ctx {
     // old, the wait is free unless the host runs more than a step ahead -- and picks its reach from the fraction: narrow (1 cell: fastest
     // while the flow stays below CFL 1) -> wide (2 cells: +10-25 % time, immune below CFL 2) -> gather kernels (no windows: flat cost at any
     // CFL), with a probe of the cheaper form every 64 calls. The decision depends on data only (not on timing): replicas that advance the
-    // same state take the same path. Measured (profiles/r04_time_frow_session_f.jsonl, 256^3 fp32): semi_lagrangian(s, v) at CFL 0.5 / 1.3 /
+    // same state take the same path -- r5 (second step): the count a decision uses is that of ONE named pass, read a fixed number of passes (kAdvMaxLag + 1 = 3) after it
+    // (every pass publishes into its own slot of a ring; the first non-blocking version took whatever pass had completed when the host looked and made
+    // the path, hence the last bits of a CFL > 1 run, depend on host timing). Measured (profiles/r04_time_frow_session_f.jsonl, 256^3 fp32): semi_lagrangian(s, v) at CFL 0.5 / 1.3 /
     // 1.8: narrow 0.078 / 0.200 / 0.396 ms, wide 0.086 / 0.085 / 0.086, gather 0.105 / 0.106 / 0.107.
     struct AdvPolicy {
         hipEvent_t ev = nullptr;
@@ -155,7 +157,10 @@ struct phihip_ctx {
         long long units = 0;     // (tile, plane) units of that pass
         bool pending = false;    // an event + a published count are outstanding
         int age = 0;             // passes of this kind enqueued since that event was recorded
+        unsigned seq = 0;        // number of this kind's passes on this grid: pass `seq` publishes its count into slot seq % kAdvSlots
+        unsigned obs_seq = 0;    // the pass `ev` / `pending` belong to
     };
+    static constexpr int kAdvSlots = 8, kAdvSlotBase = 16, kAdvCaptureBase = 16 + 4 * 8, kAdvHostInts = 64;   // layout of adv_host (ints); [15]: the resident solver's abort word
     AdvPolicy adv_policy[4];      // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
     int* adv_host = nullptr;      // pinned, device-mapped: fallback count per kind
     int* adv_host_dev = nullptr;

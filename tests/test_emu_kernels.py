@@ -57,6 +57,41 @@ def test_advection_matches_oracle(emu_ctx, res, bc):
         pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+def test_adaptive_reach_is_deterministic(emu_library):
+    """ r5: the reach of an LDS-staged advection pass follows the fallback fraction of ONE named earlier pass, read a fixed number of passes after it (capi.hip
+    adv_choose) -- not of whatever pass had completed when the host looked. Pinned here: with a quarter of the field moving 1.6 cells per step the
+    self-advection leaves the narrow window at the FOURTH pass (pass 1 observed, resolved before pass 4), on every fresh context alike; the passes before it
+    carry the bits of the fixed narrow reach, the ones after it those of the fixed wide reach; a gentle field never switches. """
+    from phiflow_amd import _capi as C
+    rng = np.random.default_rng(17)
+    dom, grid = pc.make_case((16, 24, 64), ((PER, PER),) * 3, np.float32, batch=1)
+    v = pc.random_velocity(dom, 1, np.float32, rng, 1.0)
+    vmax = max(float(np.abs(a).max()) for a in v)
+    gentle = [a * np.float32(0.8 / vmax) for a in v]
+    fast = [a.copy() for a in gentle]
+    for a in fast:
+        a[:, :4] *= np.float32(2.0)                  # the first four planes of every component move up to 1.6 cells: ~ a quarter of the (tile, plane) units
+    def run(ctx, field, halo, passes):
+        ctx.set_advect_halo(halo)
+        dv = [MEM.to_dev(a) for a in field]
+        outs = []
+        for _ in range(passes):
+            dout = [MEM.empty(a.shape, np.float32) for a in field]
+            ctx.advect_staggered(grid, [MEM.ptr(a) for a in dv], [MEM.ptr(a) for a in dv], [MEM.ptr(a) for a in dout], 1.0)
+            MEM.sync()
+            outs.append(np.concatenate([MEM.to_host(a).ravel() for a in dout]).copy())
+        return outs
+    narrow = run(C.Context(emu_library, 0), fast, 1, 1)[0]
+    wide = run(C.Context(emu_library, 0), fast, 2, 1)[0]
+    assert not np.array_equal(narrow, wide) and np.allclose(narrow, wide, rtol=0, atol=2e-5)      # two forms of the same arithmetic: equal to rounding, not bit for bit
+    runs = [run(C.Context(emu_library, 0), fast, -1, 9) for _ in range(2)]
+    for outs in runs:
+        assert all(np.array_equal(o, narrow) for o in outs[:3]), "passes 1-3 run with the narrow reach"
+        assert all(np.array_equal(o, wide) for o in outs[3:]), "from pass 4 on the wide reach"
+    calm = run(C.Context(emu_library, 0), gentle, -1, 9)
+    assert all(np.array_equal(o, calm[0]) for o in calm)
+
+
 @pytest.mark.parametrize("res,bc,dma32,dma64", [
     ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True, True),
     ((6, 10, 64), ((PER, PER), (PER, PER), (PER, PER)), True, True),

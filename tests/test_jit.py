@@ -115,6 +115,16 @@ def test_what_a_captured_function_may_not_do(emu_backend):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,iters", [(32, 30), (128, 50), (192, 20)])       # one-kernel solve (<= 16384 cells), the benchmark's plume, the marching CG
 def test_captured_plume_step_replays_the_eager_bits(gpu_backend, n, iters):
+    """ the reach of the LDS-staged advection passes is pinned: a replayed graph keeps the reach it was captured with while the eager loop adapts it to the
+    plume's CFL, and window and gather kernels agree to rounding, not bit for bit (the adaptive case: next test) """
+    gpu_backend.ctx.set_advect_halo(1)
+    try:
+        _captured_plume(gpu_backend, n, iters)
+    finally:
+        gpu_backend.ctx.set_advect_halo(-1)
+
+
+def _captured_plume(gpu_backend, n, iters):
     step, v0, s0 = _plume(gpu_backend, n)
     jstep = jit_compile(step)
     state_e, state_j = (v0, s0, None), (v0, s0, None)
@@ -134,6 +144,18 @@ def test_captured_plume_step_replays_the_eager_bits(gpu_backend, n, iters):
     e2 = step(*state_e, dt=0.5, iters=iters)
     j2 = jstep(*state_j, dt=0.5, iters=iters)
     assert jstep.traces == 3 and _same(e2, j2)
+
+
+@pytest.mark.gpu
+def test_captured_plume_with_the_adaptive_reach_agrees_to_rounding(gpu_backend):
+    """ default settings, 40 steps of the 128^2 plume (its CFL passes 1 on the way): the eager loop may change the reach of its advection passes, the
+    captured step keeps its own -- two orders of the same arithmetic """
+    step, v0, s0 = _plume(gpu_backend, 128)
+    se = iterate(step, 40, v0, s0, None, f_kwargs=dict(iters=50))
+    sj = iterate(jit_compile(step), 40, v0, s0, None, f_kwargs=dict(iters=50))
+    for fe, fj in zip(se, sj):
+        for a, b in zip(_np(fe), _np(fj)):
+            assert np.isfinite(b).all() and np.abs(a - b).max() <= 2e-3 * max(1.0, np.abs(a).max()), float(np.abs(a - b).max())
 
 
 @pytest.mark.gpu
