@@ -2,10 +2,11 @@
 # Round-5 FINAL GPU session: every record of profiles/r05_* that describes the shipped build comes from ONE build on ONE box -- GPU suite, smoke,
 # the driver-style bench line, rocprofv3 kernel stats of the bench step, the per-kernel roofline table (pinned plans), smoke256 / config4 lines (launch
 # forms and the opt-in resident solver), BASELINE configs 3-5, same-box A/B against the round-4 library, randomised parity cases (resident arm included),
-# the issue-rate microbenchmark, the differentiated step.   SESSION_TAG=r5z bash tools/sessions/r5_final.sh ; then tools/collect_profiles.sh r5z
+# the issue-rate microbenchmark, the differentiated step. The A/B partner is built by tools/build_r4_library.sh (without it the A/B rows are HEAD only).   SESSION_TAG=r5z bash tools/sessions/r5_final.sh ; then tools/collect_profiles.sh r5z
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"
 O=gpurun_out/${SESSION_TAG:-r5z}; mkdir -p $O; export TMPDIR=/tmp
+R4=phiflow_amd/lib/libphihip_r4.so; [ -f $R4 ] || R4=""
 python -c "from phiflow_amd import _capi as C; l=C.load_default_library(); print('build', l.build_id(), 'tree', l.built_from_tree())" > $O/build_id.txt 2>&1; cat $O/build_id.txt
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
@@ -25,13 +26,13 @@ PY
 timeout 600 python tools/bench_configs.py 3 4 5 > $O/configs_345.jsonl 2> $O/configs_345.err; echo "configs rc=$?"; cut -c1-400 $O/configs_345.jsonl
 : > $O/time_frow.jsonl
 for ROUND in 1 2; do
-  for LIB in phiflow_amd/lib/libphihip_r4.so ""; do
+  for LIB in $R4 ""; do
     timeout 300 python tools/time_frow.py --size 256 --dtype f32 --bc periodic ${LIB:+--lib $LIB} >> $O/time_frow.jsonl 2>> $O/time_frow.err
     timeout 300 python tools/time_frow.py --size 256 --dtype f32 --bc closed ${LIB:+--lib $LIB} >> $O/time_frow.jsonl 2>> $O/time_frow.err
     timeout 300 python tools/time_frow.py --size 384 --dtype f64 --bc closed ${LIB:+--lib $LIB} >> $O/time_frow.jsonl 2>> $O/time_frow.err
   done
 done
-for LIB in phiflow_amd/lib/libphihip_r4.so ""; do
+for LIB in $R4 ""; do
   timeout 300 python tools/time_frow.py --size 512 --dtype f32 --bc periodic --reps 10 ${LIB:+--lib $LIB} >> $O/time_frow.jsonl 2>> $O/time_frow.err
   timeout 300 python tools/time_frow.py --size 256 --dtype f32 --bc periodic --cfl 1.5 ${LIB:+--lib $LIB} >> $O/time_frow.jsonl 2>> $O/time_frow.err
 done
@@ -44,7 +45,7 @@ PY
 timeout 120 tools/micro/issue_rates > $O/issue_rates.txt 2>&1; echo "micro rc=$?"
 # smoke256 as a same-box A/B against the round-4 library at three stages of the plume (where the one-off switch of the adaptive reach falls decides a single line)
 : > $O/smoke256_ab.jsonl
-for ROUND in 1 2; do for LIB in phiflow_amd/lib/libphihip_r4.so ""; do for W in 30 90 150; do
+for ROUND in 1 2; do for LIB in $R4 ""; do for W in 30 90 150; do
     PHIHIP_LIBRARY=$LIB timeout 300 python bench.py --workload smoke256 --steps 40 --warmup $W > $O/tmp.json 2>> $O/smoke256_ab.err
     python - <<PY >> $O/smoke256_ab.jsonl
 import json
