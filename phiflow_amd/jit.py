@@ -12,7 +12,7 @@ with the same signature:
   * tensors of the arguments (the `values` of Fields, bare tensors; nested in tuples / lists / dicts) are the graph's inputs: they are copied
     into the capture's input buffers before a replay (skipped where the caller passes the very buffer back);
   * everything else (numbers, strings, Solve objects without x0, obstacles, boundaries, resolutions ...) is AUXILIARY like PhiML's non-tensor
-    arguments: part of the signature, a new value means a new capture (`forget_traces=True` keeps only the latest);
+    arguments: part of the signature, a new value means a new capture (`forget_traces=True` keeps only the latest, otherwise the 16 most recent);
   * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
     hands out the buffers themselves for callers that consume a result before the next call.
 Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` run with `info = NULL` and
@@ -27,6 +27,7 @@ runs the function eagerly under the same no-read-back rules, which exercises the
 """
 import functools
 import inspect
+import threading
 from contextlib import contextmanager
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -34,21 +35,21 @@ import torch
 
 from .field import Field
 
-_TRACING = [0]
+_STATE = threading.local()         # per thread: a capture on one thread must not switch another thread's solves to the no-read-back form
 
 
 def is_tracing() -> bool:
-    """ True while a `jit_compile`d function body runs (warm-up, capture, or the eager form on the emulation device) """
-    return _TRACING[0] > 0
+    """ True while a `jit_compile`d function body runs on this thread (warm-up, capture, or the eager form on the emulation device) """
+    return getattr(_STATE, "depth", 0) > 0
 
 
 @contextmanager
 def _tracing():
-    _TRACING[0] += 1
+    _STATE.depth = getattr(_STATE, "depth", 0) + 1
     try:
         yield
     finally:
-        _TRACING[0] -= 1
+        _STATE.depth -= 1
 
 
 # ---- argument trees: tensors out, tensors back in ---------------------------------------------------------------------------------------
@@ -142,6 +143,8 @@ class _Capture:
 class JitFunction:
     """ the callable `jit_compile` returns """
 
+    MAX_CAPTURES = 16       # a capture owns its graph's memory pool: a function called with ever new auxiliary values (an adaptive dt) must not grow without bound
+
     def __init__(self, f: Callable, auxiliary_args: str = "", forget_traces: Optional[bool] = None, copy_outputs: bool = True):
         self.f = f
         self.auxiliary_args = tuple(a.strip() for a in auxiliary_args.split(",") if a.strip())
@@ -184,6 +187,8 @@ class JitFunction:
         if cap is None:
             if self.forget_traces:
                 self.captures.clear()
+            while len(self.captures) >= self.MAX_CAPTURES:
+                self.captures.pop(next(iter(self.captures)))          # the oldest signature goes (dicts keep insertion order)
             cap = self._capture(spec, tensors, call)
             self.captures[key] = cap
         else:

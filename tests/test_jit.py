@@ -89,6 +89,14 @@ def test_jit_function_on_the_emulation_device_matches_eager(emu_backend):
     assert len(times) == 2 and all(t > 0 for t in times)
     with pytest.raises(NotImplementedError):
         iterate(jstep, (3,), v0, s0, None)
+    # the flag is per thread: a function captured on one thread leaves the solves of another thread alone
+    import threading
+    other = []
+    t = threading.Thread(target=lambda: other.append(J.is_tracing()))
+    with J._tracing():
+        t.start(); t.join()
+        assert J.is_tracing()
+    assert other == [False]
 
 
 def test_what_a_captured_function_may_not_do(emu_backend):
@@ -197,3 +205,9 @@ def test_auxiliary_args_keep_a_field_out_of_the_graph_inputs(gpu_backend):
     e2 = step(v0, force2)
     assert _same((e2,), (j_in(v0, force2),)) and j_in.traces == 1
     assert _same((e2,), (j_aux(v0, force2),)) and j_aux.traces == 2
+    # a function called with ever new auxiliary values keeps a bounded number of captures (each owns its graph's memory pool)
+    j_small = jit_compile(step)
+    j_small.MAX_CAPTURES = 2
+    for dt in (0.1, 0.2, 0.3, 0.1):
+        assert _same((step(v0, force, dt=dt),), (j_small(v0, force, dt=dt),))
+    assert len(j_small.captures) == 2 and j_small.traces == 4
