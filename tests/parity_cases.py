@@ -933,7 +933,22 @@ def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=
     else:
         assert all(i.converged for i in info), [(i.iterations, i.residual_sq, i.rhs_sq) for i in info]
         assert all(abs(k - int(ko)) <= max(2, int(0.05 * ko)) for k, ko in zip(its, io.iterations)), (its, io.iterations)
-    assert err <= tol(dtype)['cg_rel_l2'], f"CG pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
+    if not fixed_iterations and err > tol(dtype)['cg_rel_l2'] and its != [int(k) for k in io.iterations]:
+        # A tolerance solve promises a RESIDUAL, not a solution: two solves that stop a few iterations apart (sums taken in another order) differ by
+        # about cond(A) * rel_tol -- a white-noise right-hand side that needs hundreds of iterations puts that above the solution bound (fuzz seed
+        # 70129, resident arm: 235 against 227 iterations, rel-L2 2.6e-4). What the library's solution has to keep then is the promise itself: its
+        # TRUE relative residual (float64 arithmetic of the oracle's operator) within a small factor of the tolerance, and a solution within the
+        # amplification a few iterations allow.
+        x64 = x.astype(np.float64)
+        r_true = rhs.astype(np.float64) - O.masked_laplace(x64, dom, hard, active)
+        if singular and active is None:
+            r_true = demean(r_true)
+        ax = tuple(range(1, r_true.ndim))
+        rel_res = np.sqrt((r_true ** 2).sum(axis=ax) / np.maximum((rhs.astype(np.float64) ** 2).sum(axis=ax), 1e-300))
+        assert float(rel_res.max()) <= 4 * s.rel_tol and err <= 10 * tol(dtype)['cg_rel_l2'], \
+            f"CG: true relative residual {rel_res} (rel_tol {s.rel_tol}), pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
+    else:
+        assert err <= tol(dtype)['cg_rel_l2'], f"CG pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
     return x, info
 
 
