@@ -192,8 +192,11 @@ class JitFunction:
             cap = self._capture(spec, tensors, call)
             self.captures[key] = cap
         else:
-            # (one copy per tensor: `torch._foreach_copy_` would make it one launch for all of them and was measured 3 % faster on the 128^2 plume, but its
-            # results were not the per-tensor copies' on this ROCm build for the 128^2 / 192^2 fields -- the bit comparison with the eager steps found it)
+            # One copy per tensor, by `copy_`. A fused `torch._foreach_copy_` (one launch, 3 % faster on the 128^2 plume) is NOT safe in front of a replay on
+            # this ROCm build: the copies are exact (checked element by element after a device synchronisation), the eager steps are unaffected, and still
+            # the replay that follows computes from the PREVIOUS call's pressure -- the graph's memcpy node of `x0.clone()` reads stale bytes when the source
+            # was last written by that fused kernel, with or without a host synchronisation in between; per-tensor `copy_` and per-tensor arithmetic
+            # kernels do not show it (tools/micro/jit_foreach_debug.py, tools/micro/foreach_copy_check.py; found by the bit comparison of tests/test_jit.py).
             for dst, src in zip(cap.inputs, tensors):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
