@@ -14,7 +14,8 @@ with the same signature:
   * everything else (numbers, strings, Solve objects without x0, obstacles, boundaries, resolutions ...) is AUXILIARY like PhiML's non-tensor
     arguments: part of the signature, a new value means a new capture (`forget_traces=True` keeps only the latest, otherwise the 16 most recent);
   * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
-    hands out the buffers themselves for callers that consume a result before the next call.
+    hands out the buffers themselves for callers that consume a result before the next call. Results that are not tensors (numbers, None, strings) are those of
+    the capture run: a replay cannot recompute them.
 Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` run with `info = NULL` and
 `check_every = 0` (the library's capture-safe form: no host read-back, no synchronisation, no allocation, no first-call autotune --
 tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diverged are not raised. A tolerance solve under capture
@@ -177,6 +178,9 @@ class JitFunction:
         def call(tree):
             return self.f(*tree[0], **tree[1])
 
+        if any(t.requires_grad for t in tensors) and torch.is_grad_enabled():
+            raise NotImplementedError("HIP backend: gradients through a jit_compile'd function are not implemented (a replay has no autograd graph): differentiate "
+                                      "the eager function, or call the captured one under torch.no_grad() / with detached inputs")
         capturable = bool(tensors) and all(t.is_cuda for t in tensors)
         if not capturable:
             # emulation device / no tensors: the function itself, under the rules of a captured one
@@ -193,10 +197,11 @@ class JitFunction:
             self.captures[key] = cap
         else:
             # One copy per tensor, by `copy_`. A fused `torch._foreach_copy_` (one launch, 3 % faster on the 128^2 plume) is NOT safe in front of a replay on
-            # this ROCm build: the copies are exact (checked element by element after a device synchronisation), the eager steps are unaffected, and still
-            # the replay that follows computes from the PREVIOUS call's pressure -- the graph's memcpy node of `x0.clone()` reads stale bytes when the source
-            # was last written by that fused kernel, with or without a host synchronisation in between; per-tensor `copy_` and per-tensor arithmetic
-            # kernels do not show it (tools/micro/jit_foreach_debug.py, tools/micro/foreach_copy_check.py; found by the bit comparison of tests/test_jit.py).
+            # this ROCm build. Established (tools/micro/jit_foreach_debug.py, found by the bit comparison of tests/test_jit.py): the fused copies are exact
+            # (checked element by element after a device synchronisation) and the eager steps are unaffected, yet the replay that follows ANY such launch --
+            # of all inputs, of all but the pressure guess, of the pressure guess alone -- leaves the eager step's bits by the same rounding-level amount in
+            # the projection's results (not in the smoke), with or without a host synchronisation in between; per-tensor `copy_` and per-tensor arithmetic
+            # kernels never do. The cause lies below this package (the fused kernel's 4-KB argument block is the visible difference); it is avoided, not fixed.
             for dst, src in zip(cap.inputs, tensors):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
@@ -209,7 +214,7 @@ class JitFunction:
         device = tensors[0].device
         cap = _Capture()
         cap.spec = spec           # (keeps the auxiliary objects alive whose identity is part of the key)
-        cap.inputs = [t.detach().clone().contiguous() if t.is_contiguous() else t.detach().clone() for t in tensors]
+        cap.inputs = [t.detach().clone() for t in tensors]
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), _tracing():

@@ -109,6 +109,13 @@ def test_what_a_captured_function_may_not_do(emu_backend):
         bad(v)
     assert not J.is_tracing()              # the flag is restored when the function raises
 
+    # no autograd graph behind a replay: inputs that require gradients are refused instead of silently detached
+    vg = StaggeredGrid([torch.ones(1, 8, 8, requires_grad=True), torch.ones(1, 8, 8)], PERIODIC, x=8, y=8, backend=emu_backend)
+    with pytest.raises(NotImplementedError, match="gradients"):
+        jit_compile(lambda u: advect.semi_lagrangian(u, u, 0.1))(vg)
+    with torch.no_grad():
+        jit_compile(lambda u: advect.semi_lagrangian(u, u, 0.1))(vg)
+
     # a tolerance solve that does not converge raises outside, stays silent inside (the host is not told)
     rng = np.random.default_rng(1)
     rough = StaggeredGrid([rng.standard_normal((16, 16)).astype(np.float32) for _ in range(2)], PERIODIC, x=16, y=16, backend=emu_backend)

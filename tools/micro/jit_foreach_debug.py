@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """
-Round 5 record: a captured phi-level step (phiflow_amd/jit.py) replayed after its inputs were written by ONE fused `torch._foreach_copy_` kernel computes from
-stale bytes -- checksums of the eager and the captured state per step for three ways of writing the inputs: 0 = per-tensor copy_, 1 = fused (plus an element-wise
-check of the copy after a device synchronisation: exact), 4 = per-tensor arithmetic kernels. Eager checksums agree across the three; the captured ones leave them at
-the first pure replay with 1 only (v and p, not s: the stale input is the pressure guess, read by the graph's memcpy node of `x0.clone()`).
+Round 5 record: a captured phi-level step (phiflow_amd/jit.py) replayed after ANY fused `torch._foreach_copy_` launch wrote (some of) its inputs leaves the bits of
+the eager step -- first difference per way of writing the inputs: 0 = per-tensor copy_, 1 = fused (plus an element-wise check of the copy after a device
+synchronisation: exact), 2 = fused + host synchronisation, 3 = fused + an unrelated small kernel, 4 = per-tensor arithmetic kernels, 5 = fused copy of all inputs but
+the pressure guess, 6 = fused copy of the pressure guess alone. Eager results agree across all of them; the captured ones differ at the first pure replay with 1, 2,
+3, 5, 6 -- by the SAME amount, in the projection's results (v, p), not in the smoke -- and never with 0 and 4.
     python tools/micro/jit_foreach_debug.py          (needs an MI355X)
 """
 import os
@@ -44,6 +45,12 @@ def make_call(fin, fout):
             elif fin == 3 and pairs:           # fused copy, then an unrelated small kernel
                 torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
                 torch.zeros(16, device=pairs[0][0].device).add_(1.0)
+            elif fin in (5, 6) and pairs:      # 5: fused copy of everything but the pressure guess (the last input), 6: of the pressure guess alone
+                fused = pairs[:-1] if fin == 5 else pairs[-1:]
+                rest = pairs[-1:] if fin == 5 else pairs[:-1]
+                torch._foreach_copy_([d for d, _ in fused], [s for _, s in fused])
+                for d, s in rest:
+                    d.copy_(s)
             elif fin == 4:                     # per-tensor copies by an arithmetic KERNEL (not the copy engine / blit path of copy_)
                 for d, s in pairs:
                     torch.add(s, 0.0, out=d)
@@ -63,7 +70,7 @@ def make_call(fin, fout):
 be = HipBackend()
 be.ctx.set_advect_halo(1)
 for n, iters in ((128, 50), (192, 20)):
-    for fin, fout in ((0, 0), (1, 0), (4, 0)):
+    for fin, fout in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0)):
         step, v0, s0 = T._plume(be, n)
         jstep = J.jit_compile(step)
         J.JitFunction.__call__ = make_call(fin, fout)
