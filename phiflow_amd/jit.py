@@ -202,7 +202,8 @@ class JitFunction:
             # of all inputs, of all but the pressure guess, of the pressure guess alone -- leaves the eager step's bits by the same rounding-level amount in
             # the projection's results (not in the smoke), with or without a host synchronisation in between; per-tensor `copy_` and per-tensor arithmetic
             # kernels never do. The replay SEES the right inputs (images taken inside the graph by a memcpy node and by a kernel node equal what was passed:
-            # tools/micro/jit_foreach_probe.py), and the projection captured alone is unaffected by such a launch. Open; avoided, not explained.
+            # tools/micro/jit_foreach_probe.py), the projection captured alone is unaffected, and it is not the data the fused kernel writes: a fused copy
+            # between UNRELATED tensors in front of the per-tensor input copies does the same, behind them it is harmless. Open; avoided, not explained.
             for dst, src in zip(cap.inputs, tensors):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)

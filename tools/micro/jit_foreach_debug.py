@@ -3,7 +3,8 @@
 Round 5 record: a captured phi-level step (phiflow_amd/jit.py) replayed after ANY fused `torch._foreach_copy_` launch wrote (some of) its inputs leaves the bits of
 the eager step -- first difference per way of writing the inputs: 0 = per-tensor copy_, 1 = fused (plus an element-wise check of the copy after a device
 synchronisation: exact), 2 = fused + host synchronisation, 3 = fused + an unrelated small kernel, 4 = per-tensor arithmetic kernels, 5 = fused copy of all inputs but
-the pressure guess, 6 = fused copy of the pressure guess alone. Eager results agree across all of them; the captured ones differ at the first pure replay with 1, 2,
+the pressure guess, 6 = fused copy of the pressure guess alone, 7 = per-tensor copy_ of the inputs followed by a fused copy between UNRELATED tensors, 8 = the same in
+the other order. Eager results agree across all of them; the captured ones differ at the first pure replay with 1, 2,
 3, 5, 6 -- by the SAME amount, in the projection's results (v, p), not in the smoke -- and never with 0 and 4.
     python tools/micro/jit_foreach_debug.py          (needs an MI355X)
 """
@@ -51,6 +52,14 @@ def make_call(fin, fout):
                 torch._foreach_copy_([d for d, _ in fused], [s for _, s in fused])
                 for d, s in rest:
                     d.copy_(s)
+            elif fin == 7:                     # per-tensor copy_ of the inputs, then a fused copy between UNRELATED tensors
+                for d, s in pairs:
+                    d.copy_(s)
+                torch._foreach_copy_(DUMMY_B, DUMMY_A)
+            elif fin == 8:                     # a fused copy between unrelated tensors FIRST, then per-tensor copy_ of the inputs
+                torch._foreach_copy_(DUMMY_B, DUMMY_A)
+                for d, s in pairs:
+                    d.copy_(s)
             elif fin == 4:                     # per-tensor copies by an arithmetic KERNEL (not the copy engine / blit path of copy_)
                 for d, s in pairs:
                     torch.add(s, 0.0, out=d)
@@ -68,9 +77,11 @@ def make_call(fin, fout):
 
 
 be = HipBackend()
+DUMMY_A = [torch.randn(1, 128, 128, device='cuda') for _ in range(4)]
+DUMMY_B = [torch.empty_like(t) for t in DUMMY_A]
 be.ctx.set_advect_halo(1)
 for n, iters in ((128, 50), (192, 20)):
-    for fin, fout in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0)):
+    for fin, fout in ((0, 0), (1, 0), (3, 0), (5, 0), (6, 0), (7, 0), (8, 0)):
         step, v0, s0 = T._plume(be, n)
         jstep = J.jit_compile(step)
         J.JitFunction.__call__ = make_call(fin, fout)
