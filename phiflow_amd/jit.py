@@ -22,6 +22,10 @@ tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diver
 enqueues its whole launch budget (entries that converged early freeze on the device), so give it a `max_iterations` that fits the
 problem; grids of <= 16384 cells run the whole solve in ONE kernel with the convergence test on the device and need no such care.
 
+Reproducibility: a replay gives the bits of the eager function (tests/test_jit.py) with one caveat measured on this ROCm build and not explained: after a fused
+`torch._foreach_*` launch on the same device between two calls (optimizers use them), the replay's projection results can differ from the eager ones in the last
+bits although it sees the right inputs (tools/micro/jit_foreach_debug.py, profiles/r05_jit_foreach_debug.txt); this wrapper itself launches none.
+
 The function must be a pure function of its arguments (the capture runs it twice -- a warm-up that sizes the workspaces and tunes the
 launch plans, then the capture itself -- and never again). On the CPU emulation device (tests) nothing can be captured: the wrapper then
 runs the function eagerly under the same no-read-back rules, which exercises the signature / cache bookkeeping only.
