@@ -468,19 +468,20 @@ class Context:
         self.lib.check(self.lib.dll.phihip_diffuse_explicit(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)),
                                                             ctypes.byref(ptr3(out)), float(diffusivity_dt), stream or None))
 
-    def diffuse_implicit(self, grid, velocity, out, diffusivity_dt, solve: Solve, stream=0):
-        """ diffuse.implicit of a staggered field: (I - k dt L) out = velocity per component, CG from x0 = velocity; returns rank x batch SolveInfo """
-        info = (SolveInfo * (grid.rank * grid.batch))()
+    def diffuse_implicit(self, grid, velocity, out, diffusivity_dt, solve: Solve, stream=0, want_info=True):
+        """ diffuse.implicit of a staggered field: (I - k dt L) out = velocity per component, CG from x0 = velocity; returns rank x batch SolveInfo
+        (want_info=False: info = NULL, no host read-back -- the capture-safe form) """
+        info = (SolveInfo * (grid.rank * grid.batch))() if want_info else None
         self.lib.check(self.lib.dll.phihip_diffuse_implicit(self.handle, ctypes.byref(grid), ctypes.byref(ptr3(velocity)), ctypes.byref(ptr3(out)),
                                                             float(diffusivity_dt), ctypes.byref(solve), info, stream or None))
-        return list(info)
+        return list(info) if want_info else None
 
-    def diffuse_implicit_centered(self, grid, s, s_bc, s_val, out, diffusivity_dt, solve: Solve, stream=0):
+    def diffuse_implicit_centered(self, grid, s, s_bc, s_val, out, diffusivity_dt, solve: Solve, stream=0, want_info=True):
         bc, val = self._scalar_bc(grid, s_bc, s_val)
-        info = (SolveInfo * grid.batch)()
+        info = (SolveInfo * grid.batch)() if want_info else None
         self.lib.check(self.lib.dll.phihip_diffuse_implicit_centered(self.handle, ctypes.byref(grid), s, ctypes.byref(bc), ctypes.byref(val), out,
                                                                      float(diffusivity_dt), ctypes.byref(solve), info, stream or None))
-        return list(info)
+        return list(info) if want_info else None
 
     def profile_enable(self, enable: bool):
         self.lib.check(self.lib.dll.phihip_profile_enable(self.handle, int(bool(enable))))

@@ -68,9 +68,7 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
     from .field import require_plain, _torch_dtype_code
     from .solve import Solve, SolveInfo
     from .jit import is_tracing
-    if is_tracing():
-        raise NotImplementedError("HIP backend: diffuse.implicit inside a jit_compile'd function is not available (its C entry point reports the solves to the "
-                                  "host); call it outside the captured function or use diffuse.explicit")
+    traced = is_tracing()       # inside a jit_compile'd function: info = NULL, no host read-back, nothing raised (jit.py)
     from .fluid import _raise_if_failed
     from . import _capi
     require_plain(field, 'diffuse.implicit')
@@ -84,6 +82,10 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
     be = field.backend
     fp64 = field.dtype == torch.float64
     csolve = solve.to_c(fp64)
+    if traced:
+        csolve.check_every = 0
+        if tracked:
+            raise NotImplementedError("HIP backend: gradients through a jit_compile'd function are not implemented")
     csolve_bwd = (solve.gradient_solve or solve).to_c(fp64)
     kdt = float(diffusivity) * float(dt)
     if field.is_staggered:
@@ -94,7 +96,7 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
             infos = meta['infos']
         else:
             out = [torch.empty_like(t) for t in cur]
-            infos = be.ctx.diffuse_implicit(field.grid_struct(), _ptrs(cur), _ptrs(out), kdt, csolve, be.stream())
+            infos = be.ctx.diffuse_implicit(field.grid_struct(), _ptrs(cur), _ptrs(out), kdt, csolve, be.stream(), want_info=not traced)
         result = field.with_values(out)
     else:
         s_codes, s_vals = resolve(field.boundary, field.dims)
@@ -109,10 +111,11 @@ def implicit(field: Field, diffusivity: float, dt: float, solve=None, order: int
             infos = meta['infos']
         else:
             out = torch.empty_like(cur)
-            infos = be.ctx.diffuse_implicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, csolve, be.stream())
+            infos = be.ctx.diffuse_implicit_centered(grid, cur.data_ptr(), s_codes, s_val, out.data_ptr(), kdt, csolve, be.stream(), want_info=not traced)
         result = field.with_values(out)
-    info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
-                     [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
-    _raise_if_failed(info)
-    result.solve_info = info
+    if infos is not None:
+        info = SolveInfo(solve, [i.iterations for i in infos], [i.residual_sq for i in infos], [i.rhs_sq for i in infos],
+                         [bool(i.converged) for i in infos], [bool(i.diverged) for i in infos])
+        _raise_if_failed(info)
+        result.solve_info = info
     return result

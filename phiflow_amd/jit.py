@@ -16,7 +16,7 @@ with the same signature:
   * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
     hands out the buffers themselves for callers that consume a result before the next call. Results that are not tensors (numbers, None, strings) are those of
     the capture run: a replay cannot recompute them.
-Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` run with `info = NULL` and
+Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` / `diffuse.implicit` run with `info = NULL` and
 `check_every = 0` (the library's capture-safe form: no host read-back, no synchronisation, no allocation, no first-call autotune --
 tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diverged are not raised. A tolerance solve under capture
 enqueues its whole launch budget (entries that converged early freeze on the device), so give it a `max_iterations` that fits the

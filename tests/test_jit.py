@@ -104,10 +104,19 @@ def test_what_a_captured_function_may_not_do(emu_backend):
 
     @jit_compile
     def bad(v):
-        return diffuse.implicit(v, 0.1, 1.0)
-    with pytest.raises(NotImplementedError, match="jit_compile"):
+        return diffuse.implicit(v, 0.1, 1.0, order=4)
+    with pytest.raises(NotImplementedError, match="order=2"):
         bad(v)
     assert not J.is_tracing()              # the flag is restored when the function raises
+
+    # diffuse.implicit inside a captured function: the same solve without the read-back (phihip_diffuse_implicit with info = NULL)
+    rng0 = np.random.default_rng(3)
+    w = StaggeredGrid([rng0.standard_normal((8, 8)).astype(np.float32) for _ in range(2)], PERIODIC, x=8, y=8, backend=emu_backend)
+    c = CenteredGrid(rng0.standard_normal((8, 8)).astype(np.float32), ZERO_GRADIENT, x=8, y=8, backend=emu_backend)
+    for f in (w, c):
+        eager = diffuse.implicit(f, 0.1, 1.0, Solve('CG', 1e-6, max_iterations=200))
+        traced = jit_compile(lambda u: diffuse.implicit(u, 0.1, 1.0, Solve('CG', 1e-6, max_iterations=200)))(f)
+        assert _same((eager,), (traced,)) and eager.solve_info is not None and traced.solve_info is None
 
     # no autograd graph behind a replay: inputs that require gradients are refused instead of silently detached
     vg = StaggeredGrid([torch.ones(1, 8, 8, requires_grad=True), torch.ones(1, 8, 8)], PERIODIC, x=8, y=8, backend=emu_backend)
@@ -191,6 +200,25 @@ def test_captured_3d_step_with_obstacle_and_iterate(gpu_backend):
     vj, pj = iterate(jstep, 4, v0, None, f_kwargs=dict(dt=0.2))
     assert _same((ve, pe), (vj, pj))
     assert len(jstep.captures) == 1 and jstep.traces == 2          # forget_traces: only the latest signature is kept
+
+
+@pytest.mark.gpu
+def test_captured_viscous_step_with_implicit_diffusion(gpu_backend):
+    """ Heat_Flow / Burgers-type step: advection + diffuse.implicit (a CG per component with the operator I - k dt L) + projection, captured and replayed """
+    n = 64
+    rng = np.random.default_rng(8)
+    v0 = StaggeredGrid([rng.standard_normal((n, n)).astype(np.float32) * 0.05 for _ in range(2)], PERIODIC, x=n, y=n, backend=gpu_backend)
+
+    def step(v, p, dt=0.5):
+        v = advect.semi_lagrangian(v, v, dt)
+        v = diffuse.implicit(v, 0.05, dt, Solve('CG', 0, 0, max_iterations=12, suppress=[NotConverged]))
+        return fluid.make_incompressible(v, (), Solve('CG', 0, 0, x0=p, max_iterations=20, suppress=[NotConverged]))
+    jstep = jit_compile(step)
+    se, sj = (v0, None), (v0, None)
+    for k in range(5):
+        se, sj = step(*se), jstep(*sj)
+        assert _same(se, sj), f"step {k}"
+    assert jstep.traces == 2 and jstep.replays == 5
 
 
 @pytest.mark.gpu
