@@ -34,7 +34,7 @@ import functools
 import inspect
 import threading
 from contextlib import contextmanager
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Callable, Dict, List, Optional
 
 import torch
 
