@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
         T fr[3];
         lookup_pairs<T, DIM>(cf_, n, bc, cv, ax, fr);
         const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-        const T nv = W[f] + ch * (F[f] - bwd);
+        const T nv = mc_correct(W[f], ch, F[f], bwd);
         AxisPair<T> axl[3];
         T frl[3];
         if (STAG) cb_[ca] += (T)g.off[ca] - T(0.5);

@@ -54,15 +54,10 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_kernel(VelGrid g, CCo
     {
         int idx[3], f;
         if (!decode_sample(n[1], n[2], idx, f)) return;
-        T u[3];
-        face_velocity<T, DIM, CA>(g, vel, b, idx, f, u);
-        T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};      // displacements in index units (lookup_pairs_rel: exact integer part)
+        T cb_[3] = {T(0), T(0), T(0)}, cf_[3];      // displacements in index units (lookup_pairs_rel: exact integer part), in the windows' arithmetic (face_disp)
+        face_disp<T, DIM, CA>(g, vel, b, idx, f, dt, cf_);
 #pragma unroll
-        for (int a = A0; a < 3; ++a) {
-            const T sft = u[a] * (dt * (T)g.rdx[a]);
-            cb_[a] = -sft;
-            cf_[a] = sft;
-        }
+        for (int a = A0; a < 3; ++a) cb_[a] = -cf_[a];
         AxisPair<T> ax[3];
         T fr[3];
         if (MODE == 0) {
@@ -72,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void advect_staggered_kernel(VelGrid g, CCo
             const T* __restrict__ W = fwd + (long long)b * total;
             lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
             const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-            const T nv = W[f] + ch * (F[f] - bwd);
+            const T nv = mc_correct(W[f], ch, F[f], bwd);
             cb_[ca] += (T)g.off[ca] - T(0.5);
             lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             T lo, hi;
@@ -115,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void advect_centered_kernel(VelGrid g, Scal
             const T* __restrict__ W = fwd + (long long)b * total;
             lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
             const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-            const T nv = W[f] + ch * (F[f] - bwd);
+            const T nv = mc_correct(W[f], ch, F[f], bwd);
             lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
             T lo, hi;
             gather_minmax<T, DIM>(F, ax, lo, hi);
@@ -162,10 +157,10 @@ static int check_advect_sizes(const GridView& v) {
 
 // reach of an LDS-staged pass of `kind`: the user's fixed setting (phihip_set_advect_halo 0 / 1 / 2 / 3), or the adaptive choice (-1, default)
 static long long grid_fingerprint(const GridView& v) {
-    long long h = 1469598103934665603LL;
+    unsigned long long h = 1469598103934665603ULL;      // FNV-1a in unsigned arithmetic (wraps by definition)
     const long long parts[6] = {v.n[0], v.n[1], v.n[2], v.batch, v.dtype, v.rank};
-    for (long long x : parts) h = (h ^ x) * 1099511628211LL;
-    return h ? h : 1;
+    for (long long x : parts) h = (h ^ (unsigned long long)x) * 1099511628211ULL;
+    return h ? (long long)h : 1;
 }
 static int pass_reach(phihip_ctx* ctx, const GridView& v, int kind, bool has_wide, hipStream_t s) {
     const int reach = ctx->adv_halo >= 0 ? ((!has_wide && ctx->adv_halo > 1) ? 1 : ctx->adv_halo) : adv_choose(ctx, kind, has_wide, grid_fingerprint(v), s);
@@ -343,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample_kernel(ScalarBc sb, int n0
         AxisPair<T> ax[3];
         T fr[3];
         lookup_pairs<T, DIM>(c, n, bc, cv, ax, fr);
-        if (out) out[o] = gather_multilinear<T, DIM>(F, ax, fr);
+        if (out) out[o] = gather_multilinear_weights<T, DIM>(F, ax, fr);
         if (omin) {
             T lo, hi;
             gather_minmax<T, DIM>(F, ax, lo, hi);

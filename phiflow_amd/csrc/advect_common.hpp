@@ -101,10 +101,67 @@ __device__ __forceinline__ AxisPair<T> make_pair(int i_lo, int n, int stride, in
     return a;
 }
 
-// multilinear interpolation from per-axis pairs; constant sides follow PhiML's sequential padding: the LAST axis that lies
-// outside a constant side decides. Weights: prod(where(bit, frac, 1 - frac)) summed in corner order (a0 = lowest bit).
+// ---- r6: ONE arithmetic per advection sample -------------------------------------------------------------------------------------------
+// Which kernel computes a sample of an advection pass is a matter of policy (LDS tile of reach 1 or 2, register-staged or LDS-DMA fill, the fix-up
+// work list, the gather kernels; eager passes adapt their reach, captured ones keep it, a slab's window passes redo planes of the whole-slab pass).
+// Until r5 these paths agreed with the oracle but not with each other in the last bits: the face means were a chain here and a tree there, the
+// interpolation a sum of weight products in the gather kernels and nested fma-lerps in the windows, the fraction `x - floor(x)` or v_fract. Now every
+// path evaluates the SAME expressions, defined here: sum4_chain, lerp_cell (a2, then a1, then a0, each as fma(fr, hi - lo, lo)), frac_part, and
+// mc_correct for MacCormack's corrected value; min / max of the taps are order-free. Same inputs => same bits whatever the path
+// (tests/parity_cases.py check_advect_paths_same_bits on the emulation and the GPU).
+template <typename T>
+__device__ __forceinline__ T sum4_chain(const T (&v)[2][2]) {      // [offset along the face's own axis][offset along the component's axis]
+    return ((v[0][0] + v[0][1]) + v[1][0]) + v[1][1];
+}
+// t[k][b1][b2]: the 2^D taps (k = a0 offset; 2-D: k = 0 only)
+template <typename T, int DIM>
+__device__ __forceinline__ T lerp_cell(const T (&t)[2][2][2], const T (&fr)[3]) {
+    T y[2];
+#pragma unroll
+    for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+        const T x0 = fma(fr[2], t[k][0][1] - t[k][0][0], t[k][0][0]), x1 = fma(fr[2], t[k][1][1] - t[k][1][0], t[k][1][0]);
+        y[k] = fma(fr[1], x1 - x0, x0);
+    }
+    return DIM == 3 ? fma(fr[0], y[1] - y[0], y[0]) : y[0];
+}
+// MacCormack's corrected value before the limiter (advect.py:208): fwd + ch (field - bwd), one explicit fma in every kernel
+template <typename T>
+__device__ __forceinline__ T mc_correct(T fwd_here, T ch, T field_here, T bwd) {
+    return fma(ch, field_here - bwd, fwd_here);
+}
+
+// the 2^D taps of a lookup from per-axis pairs; constant sides follow PhiML's sequential padding: the LAST axis that lies outside a constant side decides
+template <typename T, int DIM>
+__device__ __forceinline__ void gather_taps(const T* __restrict__ F, const AxisPair<T> (&ax)[3], T (&t)[2][2][2]) {
+    const bool any_const = wave_any(ax[2].cst[0] | ax[2].cst[1] | ax[1].cst[0] | ax[1].cst[1] | (DIM == 3 ? (ax[0].cst[0] | ax[0].cst[1]) : false));
+#pragma unroll
+    for (int b0 = 0; b0 < (DIM == 3 ? 2 : 1); ++b0)
+#pragma unroll
+        for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int o = (DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2];
+                T val;
+                if (!any_const) val = F[o];   // wave-uniform
+                else if (ax[2].cst[b2]) val = ax[2].cv[b2];
+                else if (ax[1].cst[b1]) val = ax[1].cv[b1];
+                else if (DIM == 3 && ax[0].cst[b0]) val = ax[0].cv[b0];
+                else val = F[o];
+                t[b0][b1][b2] = val;
+            }
+}
+// multilinear interpolation of an ADVECTION lookup (the windows' arithmetic: lerp_cell)
 template <typename T, int DIM>
 __device__ __forceinline__ T gather_multilinear(const T* __restrict__ F, const AxisPair<T> (&ax)[3], const T (&fr)[3]) {
+    T t[2][2][2];
+    gather_taps<T, DIM>(F, ax, t);
+    return lerp_cell<T, DIM>(t, fr);
+}
+
+// multilinear interpolation as PhiML's grid_sample writes it (phihip_grid_sample: lookups at caller-given coordinates, no window form exists):
+// weights prod(where(bit, frac, 1 - frac)) summed in corner order (a0 = lowest bit).
+template <typename T, int DIM>
+__device__ __forceinline__ T gather_multilinear_weights(const T* __restrict__ F, const AxisPair<T> (&ax)[3], const T (&fr)[3]) {
     constexpr int A0 = 3 - DIM;
     const bool any_const = wave_any(ax[2].cst[0] | ax[2].cst[1] | ax[1].cst[0] | ax[1].cst[1] | (DIM == 3 ? (ax[0].cst[0] | ax[0].cst[1]) : false));
     T out = T(0);
@@ -139,23 +196,56 @@ __device__ __forceinline__ T gather_multilinear(const T* __restrict__ F, const A
 // resolution as gather_multilinear
 template <typename T, int DIM>
 __device__ __forceinline__ void gather_minmax(const T* __restrict__ F, const AxisPair<T> (&ax)[3], T& lo, T& hi) {
+    T t[2][2][2];
+    gather_taps<T, DIM>(F, ax, t);
+    lo = hi = t[0][0][0];
 #pragma unroll
-    for (int corner = 0; corner < (1 << DIM); ++corner) {
-        const int b0 = DIM == 3 ? (corner & 1) : 0;
-        const int b1 = DIM == 3 ? ((corner >> 1) & 1) : (corner & 1);
-        const int b2 = DIM == 3 ? ((corner >> 2) & 1) : ((corner >> 1) & 1);
-        T val;
-        if (ax[2].cst[b2]) val = ax[2].cv[b2];
-        else if (ax[1].cst[b1]) val = ax[1].cv[b1];
-        else if (DIM == 3 && ax[0].cst[b0]) val = ax[0].cv[b0];
-        else val = F[(DIM == 3 ? ax[0].off[b0] : 0) + ax[1].off[b1] + ax[2].off[b2]];
-        lo = corner == 0 ? val : (val < lo ? val : lo);
-        hi = corner == 0 ? val : (val > hi ? val : hi);
+    for (int k = 0; k < (DIM == 3 ? 2 : 1); ++k) {
+        const T q[4] = {t[k][0][0], t[k][1][0], t[k][0][1], t[k][1][1]};      // (the order of advect_win.hip minmax_at; fmin / fmax like there)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo = fmin(lo, q[i]);
+            hi = fmax(hi, q[i]);
+        }
     }
 }
 
-// velocity at the stored face `idx` of component CA: own component + 4-point
-// means of the others (sample(velocity, field.geometry, at='face'), phi/field/_resample.py:158-161,279-287,341-364)
+// the four values of component cb around the stored face `idx` of component CA: cells (m-1, m) along ca, physical faces (i, i+1) along cb,
+// outside taps from the boundary rule (sample(velocity, field.geometry, at='face'), phi/field/_resample.py:158-161,279-287,341-364)
+template <typename T, int DIM, int CA>
+__device__ __forceinline__ void face_taps(const VelGrid& g, const CComp3a<T>& vel, int b, const int (&idx)[3], int cb, T (&v)[2][2]) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+    const int m = idx[ca] + g.off[ca];
+    const int s = idx[cb] - g.off[cb];
+    const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
+    const int stride[3] = {n1 * n2, n2, 1};
+    const T* __restrict__ C = vel.p[cb] + (long long)b * g.ccells[cb];
+    const AxisPair<T> pa = make_pair<T>(m - 1, g.cn[cb][ca], stride[ca], g.bc[ca][0], g.bc[ca][1], (T)g.bcv[ca][0][cb], (T)g.bcv[ca][1][cb]);
+    const AxisPair<T> pb = make_pair<T>(s, g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
+    int rest = 0;
+#pragma unroll
+    for (int ax = A0; ax < 3; ++ax)
+        if (ax != ca && ax != cb) rest += idx[ax] * stride[ax];
+    // the later axis of (ca, cb) wins when both lie outside a constant side
+    const bool a_last = ca > cb;
+    const bool any_const = wave_any(pa.cst[0] | pa.cst[1] | pb.cst[0] | pb.cst[1]);
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const bool ca_c = pa.cst[ia], cb_c = pb.cst[ib];
+            if (any_const && (ca_c || cb_c)) {
+                if (a_last) v[ia][ib] = ca_c ? pa.cv[ia] : pb.cv[ib];
+                else v[ia][ib] = cb_c ? pb.cv[ib] : pa.cv[ia];
+            } else {
+                v[ia][ib] = C[rest + pa.off[ia] + pb.off[ib]];
+            }
+        }
+}
+
+// velocity at the stored face `idx` of component CA: own component + 4-point means of the others, the means as the reference's sample_subgrid writes them
+// (lerps axis after axis with weights (0.5, 0.5)). The adjoint kernels use this form; the ADVECTION passes take face_disp below.
 template <typename T, int DIM, int CA>
 __device__ __forceinline__ void face_velocity(const VelGrid& g, const CComp3a<T>& vel, int b, const int (&idx)[3], int f, T (&u)[3]) {
     constexpr int A0 = 3 - DIM;
@@ -166,35 +256,8 @@ __device__ __forceinline__ void face_velocity(const VelGrid& g, const CComp3a<T>
         if (cb == ca) {
             u[cb] = vel.p[ca][(long long)b * g.ccells[ca] + f];
         } else {
-            // component cb at this ca-face: cells (m-1, m) along ca, physical faces (i, i+1) along cb
-            const int m = idx[ca] + g.off[ca];
-            const int s = idx[cb] - g.off[cb];
-            const int n1 = g.cn[cb][1], n2 = g.cn[cb][2];
-            const int stride[3] = {n1 * n2, n2, 1};
-            const T* __restrict__ C = vel.p[cb] + (long long)b * g.ccells[cb];
-            const AxisPair<T> pa = make_pair<T>(m - 1, g.cn[cb][ca], stride[ca], g.bc[ca][0], g.bc[ca][1], (T)g.bcv[ca][0][cb], (T)g.bcv[ca][1][cb]);
-            const AxisPair<T> pb = make_pair<T>(s, g.cn[cb][cb], stride[cb], g.bc[cb][0], g.bc[cb][1], (T)g.bcv[cb][0][cb], (T)g.bcv[cb][1][cb]);
-            int rest = 0;
-#pragma unroll
-            for (int ax = A0; ax < 3; ++ax)
-                if (ax != ca && ax != cb) rest += idx[ax] * stride[ax];
-            // the later axis of (ca, cb) wins when both lie outside a constant side
-            const bool a_last = ca > cb;
             T v[2][2];   // [ca offset][cb offset]
-            const bool any_const = wave_any(pa.cst[0] | pa.cst[1] | pb.cst[0] | pb.cst[1]);
-#pragma unroll
-            for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-                for (int ib = 0; ib < 2; ++ib) {
-                    const bool ca_c = pa.cst[ia], cb_c = pb.cst[ib];
-                    if (any_const && (ca_c || cb_c)) {
-                        if (a_last) v[ia][ib] = ca_c ? pa.cv[ia] : pb.cv[ib];
-                        else v[ia][ib] = cb_c ? pb.cv[ib] : pa.cv[ia];
-                    } else {
-                        v[ia][ib] = C[rest + pa.off[ia] + pb.off[ib]];
-                    }
-                }
-            // sample_subgrid lerps axis after axis in spatial order with weights (0.5, 0.5)
+            face_taps<T, DIM, CA>(g, vel, b, idx, cb, v);
             if (ca < cb) {
                 const T a0 = v[1][0] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[0][1] * T(0.5);
                 u[cb] = a1 * T(0.5) + a0 * T(0.5);
@@ -202,6 +265,27 @@ __device__ __forceinline__ void face_velocity(const VelGrid& g, const CComp3a<T>
                 const T a0 = v[0][1] * T(0.5) + v[0][0] * T(0.5), a1 = v[1][1] * T(0.5) + v[1][0] * T(0.5);
                 u[cb] = a1 * T(0.5) + a0 * T(0.5);
             }
+        }
+    }
+}
+
+// FORWARD displacement dt u / dx (index units) of the stored face `idx` of component CA in the arithmetic of the LDS-staged kernels (advect_tile.hip,
+// advect_win.hip): own component times shift, the others sum4_chain of their four values times (0.25 shift); shift[a] = (T)dt (T)(1 / dx[a]).
+// The back-trace displacement is its negation (exact).
+template <typename T, int DIM, int CA>
+__device__ __forceinline__ void face_disp(const VelGrid& g, const CComp3a<T>& vel, int b, const int (&idx)[3], int f, T dt, T (&cf)[3]) {
+    constexpr int A0 = 3 - DIM;
+    constexpr int ca = CA;
+    cf[0] = cf[1] = cf[2] = T(0);
+#pragma unroll
+    for (int cb = A0; cb < 3; ++cb) {
+        const T shift = dt * (T)g.rdx[cb];
+        if (cb == ca) {
+            cf[cb] = vel.p[ca][(long long)b * g.ccells[ca] + f] * shift;
+        } else {
+            T v[2][2];
+            face_taps<T, DIM, CA>(g, vel, b, idx, cb, v);
+            cf[cb] = sum4_chain<T>(v) * (T(0.25) * shift);
         }
     }
 }
@@ -247,7 +331,7 @@ __device__ __forceinline__ void lookup_pairs(const T (&coord)[3], const int (&n)
 }
 
 // The same for a lookup given as (sample index, displacement in index units): coordinate = idx + disp, but integer part and fraction are
-// formed from the DISPLACEMENT alone -- floor(disp), disp - floor(disp) -- and the integer part is added to the index exactly. r4: the
+// formed from the DISPLACEMENT alone -- floor(disp), frac_part(disp) -- and the integer part is added to the index exactly. r4: the
 // advection kernels used to round idx - dt u / dx to the element type first, which costs n eps / 2 of the lookup position on an axis of n
 // samples (2.3e-5 cells at n = 384 in fp32: the parity tolerance had to grow with n); now the error is eps |disp| whatever the index, i.e.
 // the kernels are MORE accurate than the NumPy path (absolute fp32 coordinates) they are checked against, and equal the fp64 evaluation of
@@ -261,7 +345,8 @@ __device__ __forceinline__ void lookup_pairs_rel(const int (&idx)[3], const T (&
 #pragma unroll
     for (int a = A0; a < 3; ++a) {
         const T fl = floor(disp[a]);
-        fr[a] = disp[a] - fl;
+        fr[a] = frac_part(disp[a]);      // r6: the SAME rounding as the LDS-staged kernels' v_fract (a displacement in [-eps/2, 0) gives the largest value below 1, not
+                                         // 1.0), so a sample has the same bits whichever path computes it: tile, fix-up list, gather, narrow or wide reach
         // NaN / infinite / absurd displacements must not become wild indices: clamped to +-1e9 (NaN -> -1e9; idx + 1e9 < 2^31), the taps then
         // resolve through the boundary rule and the result is NaN
         const T fc = fmin(fmax(fl, T(-1.0e9)), T(1.0e9));

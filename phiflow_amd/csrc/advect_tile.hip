@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && DIM == 3 && T1 == 8) ? (sizeof(T
 #pragma unroll
                     for (int a = A0; a < 3; ++a) {
                         const T fl = floor(coord[a]);
-                        fr[a] = coord[a] - fl;
+                        fr[a] = frac_part(coord[a]);                   // (the reach-1 form's rounding: every path gives a sample the same bits)
                         const T rel = fl;
                         const T relc = clamp_real(rel, T(-H), T(H - 1));
                         slow = slow || !(rel == relc);                 // also true for NaN
@@ -505,13 +505,13 @@ __global__ __launch_bounds__(kBlock) void advect_self_fixup_kernel(VelGrid g, CC
                 if (p >= g.cn[ca][0] || j1 >= g.cn[ca][1] || j2 >= g.cn[ca][2]) continue;
                 const int idx[3] = {p, j1, j2};
                 const int f = (p * g.cn[ca][1] + j1) * g.cn[ca][2] + j2;
-                T u[3];
-                if (ca == 0) face_velocity<T, DIM, 0>(g, vel, b, idx, f, u);
-                else if (ca == 1) face_velocity<T, DIM, 1>(g, vel, b, idx, f, u);
-                else face_velocity<T, DIM, 2>(g, vel, b, idx, f, u);
+                T cf[3];      // (the tile kernels' arithmetic: advect_common.hpp "ONE arithmetic per advection sample")
+                if (ca == 0) face_disp<T, DIM, 0>(g, vel, b, idx, f, dt, cf);
+                else if (ca == 1) face_disp<T, DIM, 1>(g, vel, b, idx, f, dt, cf);
+                else face_disp<T, DIM, 2>(g, vel, b, idx, f, dt, cf);
                 T disp[3] = {T(0), T(0), T(0)};
 #pragma unroll
-                for (int a = A0; a < 3; ++a) disp[a] = -(u[a] * (dt * (T)g.rdx[a]));
+                for (int a = A0; a < 3; ++a) disp[a] = -cf[a];
                 const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
                 int bc[3][2];
                 T cv[3][2];

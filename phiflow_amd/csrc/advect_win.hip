@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
         // NaN) when some tap leaves [lo_rel, hi_rel + 1] -- no lane masks in scalar registers, no compare per axis
         auto split = [&](T disp, int lo_rel, int hi_rel, T& fr, T& rel, T& dev) {
             const T r0 = floor(disp);
-            fr = disp - r0;
+            fr = frac_part(disp);            // (the same rounding as split_sign and lookup_pairs_rel)
             rel = win_clamp(r0, (T)lo_rel, (T)hi_rel);
             const T d = r0 - rel;
             dev = fma(d, d, dev);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                                 d[cbx] = -OFF[cbx] + ib;
                                 v4[ia][ib] = at(cbx - A0, d[0], d[1], d[2]);
                             }
-                        const T sum = (v4[0][0] + v4[0][1]) + (v4[1][0] + v4[1][1]);
+                        const T sum = sum4_chain<T>(v4);
                         cf[cbx] = sum * (T(0.25) * P.shift[cbx]);
                         cb[cbx] = -cf[cbx];
                     }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                     for (int a = A0; a < 3; ++a) split_sign(cf[a], fr[a], mx);
                     tap_base_sign(wf, cen[wf], cf, rel, -1, tb);
                     const T bwd = lerp_at(wf, tb, fr);
-                    const T nv = at(wf, 0, 0, 0) + P.ch * (vc - bwd);
+                    const T nv = mc_correct(at(wf, 0, 0, 0), P.ch, vc, bwd);
                     // limiter: closest grid values of the backward lookup in the CELL frame (own axis: m - 1/2 instead of the stored index)
                     cb[ca] += (T)OFF[ca] - T(0.5);
                     {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
                         for (int a = A0; a < 3; ++a) split_sign(cf[a], fr[a], mx);      // (|cb| = |cf|: one maximum serves both lookups)
                         tap_base_sign(1, cen[1], cf, rel, -1, tb);
                         const T bwd = lerp_at(1, tb, fr);
-                        const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
+                        const T nv = mc_correct(at(1, 0, 0, 0), P.ch, at(0, 0, 0, 0), bwd);
                         tap_base_sign(0, cen[0], cb, rel, -1, tb);
                         T lo, hi;
                         minmax_at(0, tb, lo, hi);
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
 #pragma unroll
                     for (int a = A0; a < 3; ++a) split(cf[a], -H, H - 1, fr[a], rel[a], dev);
                     const T bwd = lerp_taps(1, cen[1], rel, fr);
-                    const T nv = at(1, 0, 0, 0) + P.ch * (at(0, 0, 0, 0) - bwd);
+                    const T nv = mc_correct(at(1, 0, 0, 0), P.ch, at(0, 0, 0, 0), bwd);
 #pragma unroll
                     for (int a = A0; a < 3; ++a) split(cb[a], -H, H - 1, fr[a], rel[a], dev);
                     T lo, hi;
@@ -663,17 +663,12 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                     if (p >= g.cn[ca][0] || j1 >= g.cn[ca][1] || j2 >= g.cn[ca][2]) continue;
                     const int n[3] = {g.cn[ca][0], g.cn[ca][1], g.cn[ca][2]};
                     const int f = (p * n[1] + j1) * n[2] + j2;
-                    T u[3];
-                    if (ca == 0) face_velocity<T, DIM, 0>(g, vel, b, idx, f, u);
-                    else if (ca == 1) face_velocity<T, DIM, 1>(g, vel, b, idx, f, u);
-                    else face_velocity<T, DIM, 2>(g, vel, b, idx, f, u);
-                    T cb_[3] = {T(0), T(0), T(0)}, cf_[3] = {T(0), T(0), T(0)};
+                    T cb_[3] = {T(0), T(0), T(0)}, cf_[3];
+                    if (ca == 0) face_disp<T, DIM, 0>(g, vel, b, idx, f, dt, cf_);
+                    else if (ca == 1) face_disp<T, DIM, 1>(g, vel, b, idx, f, dt, cf_);
+                    else face_disp<T, DIM, 2>(g, vel, b, idx, f, dt, cf_);
 #pragma unroll
-                    for (int a = A0; a < 3; ++a) {
-                        const T sft = u[a] * (dt * (T)g.rdx[a]);
-                        cb_[a] = -sft;
-                        cf_[a] = sft;
-                    }
+                    for (int a = A0; a < 3; ++a) cb_[a] = -cf_[a];
                     int bc[3][2];
                     T cv[3][2];
                     comp_rule<T>(g, ca, bc, cv);
@@ -684,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                     const T* __restrict__ W = fwd3.p[ca] + (long long)b * total;
                     lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
                     const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-                    const T nv = W[f] + ch * (F[f] - bwd);
+                    const T nv = mc_correct(W[f], ch, F[f], bwd);
                     cb_[ca] += (T)g.off[ca] - T(0.5);
                     lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
                     T lo, hi;
@@ -717,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void advect_win_fixup_kernel(VelGrid g, Sca
                     const T* __restrict__ W = fwd1 + (long long)b * g.cells;
                     lookup_pairs_rel<T, DIM>(idx, cf_, n, bc, cv, ax, fr);
                     const T bwd = gather_multilinear<T, DIM>(W, ax, fr);
-                    const T nv = W[f] + ch * (F[f] - bwd);
+                    const T nv = mc_correct(W[f], ch, F[f], bwd);
                     lookup_pairs_rel<T, DIM>(idx, cb_, n, bc, cv, ax, fr);
                     T lo, hi;
                     gather_minmax<T, DIM>(F, ax, lo, hi);

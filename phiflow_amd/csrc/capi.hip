@@ -118,11 +118,23 @@ static int ensure_adv_host(phihip_ctx* ctx) {
 constexpr double kAdvWideAtSelf = 0.12, kAdvWideAtCentred = 0.30, kAdvGatherAtNarrow = 0.15, kAdvGatherAtWide = 0.25;
 
 int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipStream_t s) {
-    phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
+    phihip_ctx::AdvKindState& K = ctx->adv_policy[kind];
     const bool capturing = stream_is_capturing(s);
-    if (P.fp != grid_fp) {          // another grid (SlabFluid's whole-slab and window passes, two simulations on one context): its fallback
-        P = phihip_ctx::AdvPolicy{P.ev, grid_fp};      // fraction says nothing about this one -- start from the narrow reach again
+    // the policy of THIS grid (SlabFluid's whole-slab and window passes, several simulations on one context: each keeps its own fallback history);
+    // an unknown grid takes a free entry or the least recently used one and starts from the narrow reach
+    K.clock += 1;
+    int slot = -1, lru = 0;
+    for (int i = 0; i < phihip_ctx::kAdvGrids; ++i) {
+        if (K.e[i].fp == grid_fp) { slot = i; break; }
+        if (K.e[i].used < K.e[lru].used) lru = i;
     }
+    if (slot < 0) {
+        slot = lru;
+        K.e[slot] = phihip_ctx::AdvPolicy{K.e[slot].ev, grid_fp};
+    }
+    K.cur = slot;
+    phihip_ctx::AdvPolicy& P = K.e[slot];
+    P.used = K.clock;
     // ONE observation at a time, resolved at a FIXED distance: the pass that recorded the event published its count into its own slot; exactly kAdvMaxLag
     // passes later the host waits for that event -- it is then several steps old: the wait is free unless the host runs that far ahead of the device, and
     // then the device still has that many passes queued -- and reads that slot. Nothing here depends on WHEN the host looks (r5, first version: hipEventQuery
@@ -130,8 +142,11 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipS
     // before that, r4: a wait in every pass, which serialised host and device).
     constexpr int kAdvMaxLag = 2;      // (the decision of pass k + 3 uses pass k: a host that only enqueues stays at most three passes ahead of the device)
     if (!capturing) {
-        P.seq += 1;                                                        // this pass
-        if (ctx->adv_host) ctx->adv_host[phihip_ctx::kAdvSlotBase + kind * phihip_ctx::kAdvSlots + (P.seq % phihip_ctx::kAdvSlots)] = 0;   // (its slot's last user was resolved long ago)
+        // an observation whose slot passes of OTHER grids have reused since (the ring has kAdvSlots entries per kind) says nothing any more: dropped, by the count
+        // of passes alone -- never by timing
+        if (P.pending && K.seq + 1 - P.obs_seq >= (unsigned)phihip_ctx::kAdvSlots) P.pending = false;
+        K.seq += 1;                                                        // this pass
+        if (ctx->adv_host) ctx->adv_host[phihip_ctx::kAdvSlotBase + kind * phihip_ctx::kAdvSlots + (K.seq % phihip_ctx::kAdvSlots)] = 0;   // (its slot's last user was resolved or dropped)
     }
     bool resolved = false;
     if (P.pending && !capturing && P.age >= kAdvMaxLag) {
@@ -159,14 +174,15 @@ int ensure_adv_host_public(phihip_ctx* ctx) { return ensure_adv_host(ctx); }
 
 int adv_record(phihip_ctx* ctx, int kind, int reach, hipStream_t s) {
     if (stream_is_capturing(s)) return PHIHIP_OK;           // (an event record would become a node of the graph; captured passes keep their reach)
-    phihip_ctx::AdvPolicy& P = ctx->adv_policy[kind];
+    phihip_ctx::AdvKindState& K = ctx->adv_policy[kind];
+    phihip_ctx::AdvPolicy& P = K.e[K.cur];
     // one observation at a time: while the event of an earlier pass is unresolved (a host that runs steps ahead of the device) it is NOT re-recorded --
     // re-recording every pass kept the event forever in the future and the policy never adapted in an enqueue-only loop (found with the smoke256
     // workload: the switch to the wide reach came 50 steps late). The published count is the newest completed pass's: same reach, fresher data.
     if (P.pending) { P.age += 1; return PHIHIP_OK; }
     if (reach == 0) return PHIHIP_OK;                       // a gather pass publishes nothing: no observation (the probe every 64 calls is the next one)
     P.age = 0;
-    P.obs_seq = P.seq;
+    P.obs_seq = K.seq;
     if (!P.ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
     PHIHIP_CHECK_HIP(hipEventRecord(P.ev, s));
     P.pending = true;
@@ -332,8 +348,9 @@ int phihip_ctx_destroy(phihip_ctx* ctx) {
     if (ctx->host_state) (void)hipHostFree(ctx->host_state);
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->adv_host) (void)hipHostFree(ctx->adv_host);
-    for (auto& P : ctx->adv_policy)
-        if (P.ev) (void)hipEventDestroy(P.ev);
+    for (auto& K : ctx->adv_policy)
+        for (auto& P : K.e)
+            if (P.ev) (void)hipEventDestroy(P.ev);
     for (int i = 0; i < 2; ++i)
         if (ctx->poll_ev[i]) (void)hipEventDestroy(ctx->poll_ev[i]);
     for (auto& p : ctx->ev_pool) {
@@ -1018,7 +1035,8 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
     PHIHIP_REQUIRE(halo >= -1 && halo <= 3, "advect halo must be -1 (adaptive), 0 (gather kernels), 1, 2 or 3 (experimental: halo 1 with 16-row tiles, 3-D only)");
     ctx->adv_halo = halo;
-    for (auto& P : ctx->adv_policy) { P.mode = 1; P.calls = 0; P.pending = false; }
+    for (auto& K : ctx->adv_policy)
+        for (auto& P : K.e) { P.mode = 1; P.calls = 0; P.pending = false; }
     return PHIHIP_OK;
 }
 

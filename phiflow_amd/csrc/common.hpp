@@ -150,18 +150,28 @@ struct phihip_ctx {
     // 1.8: narrow 0.078 / 0.200 / 0.396 ms, wide 0.086 / 0.085 / 0.086, gather 0.105 / 0.106 / 0.107.
     struct AdvPolicy {
         hipEvent_t ev = nullptr;
-        long long fp = 0;        // fingerprint of the grid the state below belongs to (adv_choose resets it for another grid)
+        long long fp = 0;        // fingerprint of the grid the state below belongs to (0: free entry)
         int mode = 1;            // 0 gather, 1 narrow, 2 wide
         int last = 0;            // reach of the pass that `pending` refers to
         int calls = 0;
         long long units = 0;     // (tile, plane) units of that pass
         bool pending = false;    // an event + a published count are outstanding
         int age = 0;             // passes of this kind enqueued since that event was recorded
-        unsigned seq = 0;        // number of this kind's passes on this grid: pass `seq` publishes its count into slot seq % kAdvSlots
-        unsigned obs_seq = 0;    // the pass `ev` / `pending` belong to
+        unsigned obs_seq = 0;    // the pass (number among this KIND's passes, AdvKindState::seq) `ev` / `pending` belong to
+        unsigned used = 0;       // AdvKindState::clock of the most recent pass on this grid (least recently used entry is replaced)
+    };
+    // r6: one policy PER GRID, a few grids per kind of pass. Until r5 a kind had ONE policy that restarted whenever the grid changed: a SlabFluid in
+    // overlap mode (whole-slab pass and cut-side window passes alternate on one context) or two simulations sharing a context changed it on every call -- no
+    // observation was ever resolved, the reach never left narrow, and the restart of `seq` reused publish slots of passes still in flight.
+    static constexpr int kAdvGrids = 4;
+    struct AdvKindState {
+        AdvPolicy e[kAdvGrids];
+        unsigned seq = 0;        // number of this kind's eager passes (all grids): pass `seq` publishes its count into slot seq % kAdvSlots
+        unsigned clock = 0;
+        int cur = 0;             // the entry of the pass being enqueued (adv_choose -> adv_record / prepare_fixlist)
     };
     static constexpr int kAdvSlots = 8, kAdvSlotBase = 16, kAdvCaptureBase = 16 + 4 * 8, kAdvHostInts = 64;   // layout of adv_host (ints); [15]: the resident solver's abort word
-    AdvPolicy adv_policy[4];      // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
+    AdvKindState adv_policy[4];   // AdvKind: self-advection, staggered MacCormack correction, centred semi-Lagrangian, centred MacCormack correction
     int* adv_host = nullptr;      // pinned, device-mapped: fallback count per kind
     int* adv_host_dev = nullptr;
     unsigned adv_seq = 0;         // launches of LDS-staged advection kernels so far: parity selects the work list's counter

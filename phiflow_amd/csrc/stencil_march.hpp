@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
                 E.e4[rr] = vec_load_g<T, V, UNAL>(p.b + off);
                 E.e5[rr] = vec_load_g<T, V, UNAL>(p.c + off);
             }
-            if (FLAGS) E.fl[rr] = *reinterpret_cast<const VF*>(p.flags + (fbase - base) + off);
+            if (FLAGS) E.fl[rr] = vec_load_g<uint8_t, V, UNAL>(p.flags + (fbase - base) + off);   // (UNAL: the V flag bytes of a ragged row start at any byte)
         }
     };
     // destination of a store: the cell's slot, or the dump slot for lanes outside the grid

@@ -9,10 +9,12 @@ is wanted: every operator of this package is already one or a few HIP kernels be
 Python objects, ctypes marshalling, ~20 kernel launches of a few microseconds each (bench.py `phi_level`: +50 % at 128^2). So `jit_compile`
 here CAPTURES the function's launches into a hipGraph once (torch.cuda.CUDAGraph on a side stream) and REPLAYS the graph on every later call
 with the same signature:
-  * tensors of the arguments (the `values` of Fields, bare tensors; nested in tuples / lists / dicts) are the graph's inputs: they are copied
-    into the capture's input buffers before a replay (skipped where the caller passes the very buffer back);
-  * everything else (numbers, strings, Solve objects without x0, obstacles, boundaries, resolutions ...) is AUXILIARY like PhiML's non-tensor
-    arguments: part of the signature, a new value means a new capture (`forget_traces=True` keeps only the latest, otherwise the 16 most recent);
+  * tensors of the arguments (the `values` of Fields, bare tensors; nested in tuples / lists / dicts / dataclass instances -- r6: a `Solve` argument's `x0`
+    is traced like PhiML traces it) are the graph's inputs: they are copied into the capture's input buffers before a replay (skipped where the caller passes
+    the very buffer back);
+  * everything else (numbers, strings, obstacles, boundaries, resolutions ...) is AUXILIARY like PhiML's non-tensor arguments: part of the signature, a new
+    value means a new capture (`forget_traces=True` keeps only the latest, otherwise the 16 most recent); an unhashable auxiliary object that holds a tensor
+    is refused (its repr would not tell two tensors apart);
   * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
     hands out the buffers themselves for callers that consume a result before the next call. Results that are not tensors (numbers, None, strings) are those of
     the capture run: a replay cannot recompute them.
@@ -30,6 +32,7 @@ The function must be a pure function of its arguments (the capture runs it twice
 launch plans, then the capture itself -- and never again). On the CPU emulation device (tests) nothing can be captured: the wrapper then
 runs the function eagerly under the same no-read-back rules, which exercises the signature / cache bookkeeping only.
 """
+import dataclasses
 import functools
 import inspect
 import threading
@@ -99,6 +102,11 @@ def _flatten(obj, tensors: List[torch.Tensor]):
         return ("L" if isinstance(obj, list) else "U", tuple(_flatten(o, tensors) for o in obj))
     if isinstance(obj, dict):
         return ("D", tuple((k, _flatten(v, tensors)) for k, v in obj.items()))
+    if dataclasses.is_dataclass(obj) and not isinstance(obj, type):
+        # r6: a Solve travels as an argument in the reference's examples (`step(v, p, solve)`), and PhiML traces `Solve.x0` like any other tensor --
+        # descend into dataclass instances so that x0 becomes a graph INPUT (a new guess is copied in, not baked into / keyed on) and list-valued
+        # fields (`suppress=[NotConverged]`) need no hash
+        return ("C", type(obj), tuple((f.name, _flatten(getattr(obj, f.name), tensors)) for f in dataclasses.fields(obj) if f.init))
     return ("A", obj)           # auxiliary: by value
 
 
@@ -113,6 +121,8 @@ def _unflatten(spec, it):
         return items if kind == "L" else tuple(items)
     if kind == "D":
         return {k: _unflatten(s, it) for k, s in spec[1]}
+    if kind == "C":
+        return spec[1](**{k: _unflatten(s, it) for k, s in spec[2]})
     return spec[1]
 
 
@@ -125,7 +135,27 @@ def _aux_key(value):
         hash(value)
         return value
     except TypeError:
+        # repr() of an object that HOLDS a tensor prints no values: two calls with different tensors would share one capture and the replay would reuse the
+        # first call's buffer silently -- refuse instead of guessing
+        if _holds_tensor(value):
+            raise TypeError(f"jit_compile: the auxiliary argument {type(value).__name__} is unhashable and holds a tensor or Field; pass tensors as arguments "
+                            f"of their own, inside tuples / lists / dicts / dataclasses (these are traced), or make the object hashable") from None
         return repr(value)
+
+
+def _holds_tensor(value, depth: int = 0) -> bool:
+    if isinstance(value, (torch.Tensor, Field)):
+        return True
+    if depth > 4 or isinstance(value, (str, bytes, int, float, complex, bool, type(None), type)):
+        return False
+    if isinstance(value, dict):
+        return any(_holds_tensor(v, depth + 1) for v in value.values())
+    if isinstance(value, (tuple, list, set, frozenset)):
+        return any(_holds_tensor(v, depth + 1) for v in value)
+    members = list(getattr(value, "__dict__", {}).values())
+    for cls in type(value).__mro__:
+        members += [getattr(value, name) for name in getattr(cls, "__slots__", ()) if isinstance(name, str) and hasattr(value, name)]
+    return any(_holds_tensor(v, depth + 1) for v in members)
 
 
 def _spec_key(spec):
@@ -138,6 +168,8 @@ def _spec_key(spec):
         return (kind,) + tuple(_spec_key(s) for s in spec[1])
     if kind == "D":
         return ("D",) + tuple((k, _spec_key(s)) for k, s in spec[1])
+    if kind == "C":
+        return ("C", spec[1].__module__, spec[1].__qualname__) + tuple((k, _spec_key(s)) for k, s in spec[2])
     return ("A", type(spec[1]).__name__, _aux_key(spec[1]))
 
 

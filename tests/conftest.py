@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """ `-n auto` by default, but only where pytest-xdist exists (`addopts = -n auto` made every invocation fail with "unrecognized arguments: -n"
+    on a machine without the plugin). Runs before xdist's own hook of this name, which turns "auto" into pytest_xdist_auto_num_workers below. """
+    is_worker = hasattr(config, "workerinput") or "PYTEST_XDIST_WORKER" in os.environ        # (a worker must not start workers of its own)
+    if (config.pluginmanager.hasplugin("xdist") and not is_worker and getattr(config.option, "numprocesses", None) is None
+            and not getattr(config.option, "usepdb", False)):
+        config.option.numprocesses = "auto"
+    return None
+
+
+@pytest.hookimpl(optionalhook=True)                       # (the hook exists only where pytest-xdist is installed)
 def pytest_xdist_auto_num_workers(config):
     """ `-n auto` (pytest.ini): CPU suite on up to 6 cores; with a GPU present (the `-m gpu` tiers of the driver) everything stays in ONE process """
     try:
@@ -44,9 +56,13 @@ def emu_library():
     # contexts on the emulation keep the analytic launch plan: timing candidates there is meaningless (and the bit-for-bit tests of
     # tests/test_parallel_gloo.py need the same launch geometry in every process)
     os.environ["PHIHIP_AUTOTUNE"] = "0"
-    import fcntl
+    try:
+        import fcntl                                                   # POSIX only -- like build_emu.sh itself (bash, g++); without it: no lock, run serially
+    except ImportError:
+        fcntl = None
     with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # xdist workers: ONE of them rebuilds a stale library, the others wait
-        fcntl.flock(lock, fcntl.LOCK_EX)
+        if fcntl is not None:
+            fcntl.flock(lock, fcntl.LOCK_EX)
         if _emu_is_stale():
             subprocess.run(["bash", os.path.join(EMU_DIR, "build_emu.sh")], check=True, stdout=subprocess.DEVNULL)
     return _capi.Library(EMU_LIB)

@@ -57,6 +57,24 @@ def test_advection_matches_oracle(emu_ctx, res, bc):
         pc.check_advect_centered(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts)
 
 
+@pytest.mark.parametrize("res,bc", [GRIDS_2D[0], GRIDS_2D[2], GRIDS_2D[3], GRIDS_3D[0], GRIDS_3D[1], GRIDS_3D[2], ((12, 16, 72), ((PER, PER), (PER, PER), (OPN, OPN))),
+                                    ((20, 24, 64), ((CLO, CLO), (PER, PER), (PER, PER)))])
+def test_advection_paths_give_the_same_bits(emu_ctx, res, bc):
+    """ r6: tile (both fills, both reaches), fix-up list, windows and gather kernels evaluate ONE arithmetic per sample -- bit for bit, also where a
+    displacement is a tiny negative number (v_fract vs x - floor(x)) """
+    rng = np.random.default_rng(66)
+    s_codes = tuple((PER, PER) if lo == PER else (OPN, CLO) for lo, hi in bc)
+    s_consts = [(0.0, 0.25)] * len(res)
+    for dtype in (np.float32, np.float64):
+        bcv = None
+        if any(side == CLO for pair in bc for side in pair):
+            pad = 3 - len(res)
+            bcv = [[[float(rng.normal()) * 0.05 if a >= pad and bc[a - pad][sd] == CLO else 0.0 for c in range(3)] for sd in range(2)] for a in range(3)]
+        dom, grid = pc.make_case(res, bc, dtype, batch=2, bc_val=bcv if len(res) == 3 else None)
+        for dt in (0.7, 2.3):
+            pc.check_advect_paths_same_bits(emu_ctx, MEM, dom, grid, dtype, rng, s_codes, s_consts, dt=dt)
+
+
 def test_adaptive_reach_is_deterministic(emu_library):
     """ r5: the reach of an LDS-staged advection pass follows the fallback fraction of ONE named earlier pass, read a fixed number of passes after it (capi.hip
     adv_choose) -- not of whatever pass had completed when the host looked. Pinned here: with a quarter of the field moving 1.6 cells per step the

@@ -60,6 +60,56 @@ def test_argument_trees_round_trip(emu_backend):
         assert J._spec_key(J._flatten(changed, [])) != k1
 
 
+def test_solve_arguments_are_traced_and_tensor_holding_auxiliaries_refused(emu_backend):
+    """ r6: a Solve passed as an ARGUMENT -- PhiML traces Solve.x0 like any tensor: the guess becomes a graph input (one capture for every guess,
+    fresh values copied in), list-valued fields need no hash; an unhashable auxiliary object that holds a tensor is refused, never keyed on its repr """
+    p_a = CenteredGrid(1.0, ZERO_GRADIENT, x=8, y=6, backend=emu_backend)
+    p_b = CenteredGrid(2.0, ZERO_GRADIENT, x=8, y=6, backend=emu_backend)
+    v = StaggeredGrid(1.5, PERIODIC, x=8, y=6, backend=emu_backend)
+    solve_a = Solve('CG', 1e-3, x0=p_a, suppress=[NotConverged])
+    solve_b = Solve('CG', 1e-3, x0=p_b, suppress=[NotConverged])
+    with pytest.raises(TypeError):
+        hash(solve_a)                                  # (the list-valued field: this object went through repr() until r5)
+    ta, tb = [], []
+    spec_a, spec_b = J._flatten(((v, solve_a), {}), ta), J._flatten(((v, solve_b), {}), tb)
+    assert len(ta) == len(tb) == 3 and ta[2] is p_a.values and tb[2] is p_b.values          # x0 is among the graph inputs
+    assert J._spec_key(spec_a) == J._spec_key(spec_b)                                         # one capture serves both guesses
+    assert J._spec_key(J._flatten(((v, Solve('CG', 1e-4, x0=p_a, suppress=[NotConverged])), {}), [])) != J._spec_key(spec_a)
+    assert J._spec_key(J._flatten(((v, Solve('CG', 1e-3, x0=None, suppress=[NotConverged])), {}), [])) != J._spec_key(spec_a)
+    back = J._unflatten(spec_b, iter(tb))[0][1]
+    assert isinstance(back, Solve) and back.x0.values is p_b.values and back.rel_tol == 1e-3 and back.suppress == [NotConverged]
+
+    class Bag:                      # unhashable, holds a Field, its repr shows no values
+        __hash__ = None
+
+        def __init__(self, f):
+            self.guess = {"p": [f]}
+
+        def __repr__(self):
+            return "Bag()"
+    with pytest.raises(TypeError, match="holds a tensor"):
+        J._spec_key(J._flatten(((v, Bag(p_a)), {}), []))
+
+    class Plain:
+        __hash__ = None
+
+        def __repr__(self):
+            return "Plain(3)"
+    assert J._spec_key(J._flatten(((v, Plain()), {}), [])) == J._spec_key(J._flatten(((v, Plain()), {}), []))
+
+    # the function runs with the guess of THIS call
+    rng = np.random.default_rng(5)
+    w = StaggeredGrid([rng.standard_normal((16, 16)).astype(np.float32) for _ in range(2)], PERIODIC, x=16, y=16, backend=emu_backend)
+
+    def project(u, solve):
+        return fluid.make_incompressible(u, (), solve)
+    jproject = jit_compile(project)
+    _, p1 = project(w, Solve('CG', 0, 0, max_iterations=3, suppress=[NotConverged]))
+    for guess in (p1, p1 * 0.5):
+        s = Solve('CG', 0, 0, x0=guess, max_iterations=4, suppress=[NotConverged])
+        assert _same(project(w, s), jproject(w, s))
+
+
 def test_jit_function_on_the_emulation_device_matches_eager(emu_backend):
     """ no capture without a HIP device: the wrapper runs the function under the rules of a captured one (info = NULL, check_every = 0,
     no exceptions from the solve) -- same arithmetic, so the same bits as the eager step """
@@ -219,6 +269,22 @@ def test_captured_viscous_step_with_implicit_diffusion(gpu_backend):
         se, sj = step(*se), jstep(*sj)
         assert _same(se, sj), f"step {k}"
     assert jstep.traces == 2 and jstep.replays == 5
+
+
+@pytest.mark.gpu
+def test_solve_argument_with_a_new_guess_replays_one_capture(gpu_backend):
+    """ r6: `step(v, solve)` with Solve(x0=p): the guess is a graph input -- ONE capture, every call's own guess, the eager bits """
+    rng = np.random.default_rng(8)
+    w = StaggeredGrid([rng.standard_normal((64, 64)).astype(np.float32) for _ in range(2)], PERIODIC, x=64, y=64, backend=gpu_backend)
+
+    def project(u, solve):
+        return fluid.make_incompressible(u, (), solve)
+    jproject = jit_compile(project)
+    _, p = project(w, Solve('CG', 0, 0, max_iterations=5, suppress=[NotConverged]))
+    for k in range(4):
+        s = Solve('CG', 0, 0, x0=p * (1.0 - 0.1 * k), max_iterations=7, suppress=[NotConverged])
+        assert _same(project(w, s), jproject(w, s)), f"call {k}"
+    assert jproject.traces == 1 and jproject.replays == 3
 
 
 @pytest.mark.gpu
