@@ -554,9 +554,18 @@ def phi_level_block(ctx, lib, device, cg_iters, steps=20, sizes=(256, 128), plum
             def jit_step():
                 state["v"], state["p"] = jstep(state["v"], state["p"])
             ms_jit = wall(jit_step, steps) if device.type == "cuda" else None
+            # r6: the same captured step as a ping-pong of two captures (copy_outputs=False: a result is consumed by the next call, the loop every example writes):
+            # no 268-MB clone of the results, the inputs copied in every other step only
+            pstep = F.jit_compile(lambda v, p: F.fluid.make_incompressible(F.advect.semi_lagrangian(v, v, sim.dt), (), solve(p)), copy_outputs=False)
+
+            def pp_step():
+                state["v"], state["p"] = pstep(state["v"], state["p"])
+            ms_pp = wall(pp_step, steps) if device.type == "cuda" else None
             out[f"taylor_green_{n}"] = {"ms_c_abi": round(ms_c, 4), "ms_phi_level": round(ms_phi, 4), "overhead": round(ms_phi / ms_c - 1, 4),
-                                        "ms_phi_level_jit": round(ms_jit, 4) if ms_jit else None, "overhead_jit": round(ms_jit / ms_c - 1, 4) if ms_jit else None}
-            del jstep
+                                        "ms_phi_level_jit": round(ms_jit, 4) if ms_jit else None, "overhead_jit": round(ms_jit / ms_c - 1, 4) if ms_jit else None,
+                                        "ms_phi_level_jit_ping_pong": round(ms_pp, 4) if ms_pp else None,
+                                        "overhead_jit_ping_pong": round(ms_pp / ms_c - 1, 4) if ms_pp else None}
+            del jstep, pstep
             del sim, state
             if device.type == "cuda":
                 torch.cuda.empty_cache()
@@ -589,7 +598,8 @@ def phi_level_block(ctx, lib, device, cg_iters, steps=20, sizes=(256, 128), plum
                                        "ms_phi_level_jit": round(ms_jit, 4) if ms_jit else None, "overhead_jit": round(ms_jit / ms_c - 1, 4) if ms_jit else None}
     out["note"] = ("same box, same context, back to back; C-ABI = preallocated buffers driven like the timed region of this line; phi-level = phiflow_amd.flow "
                    "(immutable Fields, a fresh result per operator, SolveInfo read back every step); phi-level jit = the same function behind "
-                   "phiflow_amd.flow.jit_compile: captured once in a hipGraph, replayed per step (inputs copied in, results cloned out, no read-back)")
+                   "phiflow_amd.flow.jit_compile: captured once in a hipGraph, replayed per step (inputs copied in, results cloned out, no read-back); jit ping-pong = "
+                   "jit_compile(copy_outputs=False): two captures alternate, the second reads the first one's outputs in place (no clones, inputs copied every other step)")
     return out
 
 
@@ -669,9 +679,9 @@ CG_KERNELS = {"cg_matvec_dot": "march_kernel<MODE_MATVEC> (d = r + beta d, sum d
 
 
 def committed_traffic_ratio(n, kernel_name):
-    """ PMC bytes / moved bytes of the same kernel in the committed per-kernel table (tools/kernel_roofline.sh -> profiles/r05_kernel_roofline.json,
+    """ PMC bytes / moved bytes of the same kernel in the committed per-kernel table (tools/kernel_roofline.sh -> profiles/r06_kernel_roofline.json (or the r05 table),
     pinned plans, tools/path_workload.py): the second, independent measurement the bench line's traffic is checked against """
-    for name in ("r05_kernel_roofline.json", "r04_kernel_roofline.json"):
+    for name in ("r06_kernel_roofline.json", "r05_kernel_roofline.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 table = json.load(f)
@@ -701,8 +711,8 @@ def roofline_block(n, per, pmc, world, cache_assisted, where, plans=None):
     traffic, source = (None, None)
     if pmc and world == 1:
         traffic, source = live_pmc_traffic(n, dom_key, plans)
-    if traffic is None:
-        traffic, source = _pmc_traffic(n, dom_key)
+    # (r6: no fallback to a committed PMC file -- until r5 `roofline_256.traffic` came from profiles/pmc_traffic.json, a ROUND-2 measurement of other kernels on
+    # another launch plan; a figure that cannot be measured in this invocation is null)
     block = {"bound": "hbm", "kernel": CG_KERNELS[dom_key], "size": n, "measured_on": where, "infinity_cache_assisted": bool(cache_assisted),
              "share_of_gpu_time": round(per[dom_key][2] / total_ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
@@ -942,9 +952,10 @@ def main():
         extra["profiled_step"] = {"ms_wall": round(profiled_ms, 5), "sum_kernel_ms": round(ksum, 5), "launches": int(sum(v[1] for v in per.values()) / args.profile_steps),
                                   "note": "kernel_ms_per_step / kernel_ms_per_launch are hipEvent intervals of these extra steps (one event pair per launch: "
                                           "slower than the untouched step of ms_per_step by the events' own cost); rocprofv3 --kernel-trace figures of the "
-                                          "untouched step: profiles/r04_bench256_kernel_stats.csv"}
-        roofline_bench, it = roofline_block(n, per, False, world, cache_assisted=4 * 4 * n ** 3 <= 256 * 2 ** 20,
-                                            where="profiled steps of the timed benchmark configuration")
+                                          "untouched step: profiles/r06_bench256_kernel_stats.csv"}
+        plans_b = {str(fam): [q["rows"], q["tpr"], q["chunk"]] for fam, q in ((fam, ctx.query_plan(sim.grid, False, fam)) for fam in (0, 1, 2, 3))}
+        roofline_bench, it = roofline_block(n, per, bool(args.pmc) and rank == 0, world, cache_assisted=4 * 4 * n ** 3 <= 256 * 2 ** 20,
+                                            where="profiled steps of the timed benchmark configuration", plans=plans_b)
         if it:
             extra["roofline_cg_iteration_256" if n == 256 else f"roofline_cg_iteration_{n}"] = it
         extra["kernel_ms_per_launch"] = {k: (round(v[0], 5) if v[0] else None) for k, v in per.items()}
@@ -1002,20 +1013,6 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _pmc_traffic(n, kernel_key):
-    """ fallback when the PMC passes cannot run inside this invocation (no rocprofv3, nested profiler, N > 1): HBM bytes per launch
-    of the kernel from the committed passes (profiles/pmc_traffic.json, tools/pmc_summary.py). (None, None) if not collected. """
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    key = {"cg_update": "cg_update_x2"}.get(kernel_key, kernel_key)
-    try:
-        with open(path) as f:
-            data = json.load(f)
-        val = data.get(f"{key}_{n}", None)
-        return val, ("profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of an earlier run, not this invocation)" if val else None)
-    except Exception:
-        return None, None
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ static PlanKey plan_key(const GridView& v, int mask_batch, bool flags, int famil
     return PlanKey{v.dtype, v.rank, v.n[0], v.n[1], v.n[2], v.batch, flags ? 1 : 0, mask_batch > 1 ? 1 : 0, family, v.unaligned ? 0 : 1};
 }
 
-int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g) {
+int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* c, MarchGrid* g, int force_id) {
     const int esize = v.dtype == PHIHIP_F64 ? 8 : 4;
     const int vmax = 16 / esize;
     memset(g, 0, sizeof(*g));
@@ -123,7 +123,10 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     int id = -1, chunk = 1;
     double score = 0;
     const auto tuned = (t.rows > 0 || t.chunk > 0 || v.halo[0] || v.halo[1]) ? ctx->tuned.end() : ctx->tuned.find(plan_key(v, mask_batch, flags, family));
-    if (tuned != ctx->tuned.end()) {   // measured on this device (autotune_cg)
+    if (force_id >= 0 && !march_one_tile(c->vec) && march_tile_available(c->vec, esize, force_id, v.n[2])) {      // the tile of a sibling lattice (one launch for both)
+        id = force_id;
+        chunk = best_chunk(id, &score);
+    } else if (tuned != ctx->tuned.end()) {   // measured on this device (autotune_cg)
         id = tuned->second.id;
         chunk = tuned->second.chunk;
     } else if (march_one_tile(c->vec)) {
@@ -302,6 +305,48 @@ static int laplace_apply_t(phihip_ctx* ctx, const GridView& v, const uint8_t* fl
     PHIHIP_TRY(launch_march_any<T>(v, c, MODE_APPLY, flags != nullptr, g, a, s));
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;
+}
+
+// (I + k dt L) on the `count` <= 3 lattices of a staggered field (diffuse.explicit: ONE reference call, phi/physics/diffuse.py:13-60): lattices whose plans share
+// a tile configuration go into one launch of march_apply_multi_kernel -- all D components of a periodic box, the D - 1 components with whole rows of a closed
+// one -- the rest one launch each. r5: always one launch per component (3 x 35 us on HBM-resident data at 256^3 + two launch gaps).
+template <typename T>
+static int laplace_apply_multi_t(phihip_ctx* ctx, const GridView* w, int count, const void* const* in, void* const* out, hipStream_t s) {
+    MarchConfig c[3];
+    MarchGrid g[3];
+    MarchArgs<T> a[3];
+    for (int l = 0; l < count; ++l) {
+        PHIHIP_TRY(plan_march(ctx, w[l], 1, false, FAM_APPLY, &c[l], &g[l], l > 0 ? c[0].id : -1));
+        memset(&a[l], 0, sizeof(a[l]));
+        a[l].a = (const T*)in[l];
+        a[l].o1 = (T*)out[l];
+        set_operator(a[l], w[l]);
+        a[l].prologue = PRO_NONE;
+    }
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    bool done[3] = {false, false, false};
+    for (int l = 0; l < count; ++l) {
+        if (done[l]) continue;
+        int members[3], nm = 0;
+        for (int k = l; k < count; ++k)
+            if (!done[k] && c[k].id == c[l].id && c[k].vec == c[l].vec && c[k].batch == c[l].batch && a[k].w0 == a[l].w0 && a[k].w1 == a[l].w1 &&
+                a[k].w2 == a[l].w2 && a[k].ident == a[l].ident) members[nm++] = k;
+        if (nm == 1) {
+            PHIHIP_TRY(launch_march_any<T>(w[l], c[l], MODE_APPLY, false, g[l], a[l], s));
+            done[l] = true;
+            continue;
+        }
+        MarchGrid gm[3];
+        MarchArgs<T> am[3];
+        for (int k = 0; k < nm; ++k) { gm[k] = g[members[k]]; am[k] = a[members[k]]; done[members[k]] = true; }
+        PHIHIP_TRY(launch_march_multi_any<T>(w[l], c[l], nm, gm, am, s));
+    }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
+int run_laplace_apply_multi(phihip_ctx* ctx, const GridView* w, int count, const void* const* in, void* const* out, hipStream_t s) {
+    return w[0].dtype == PHIHIP_F64 ? laplace_apply_multi_t<double>(ctx, w, count, in, out, s) : laplace_apply_multi_t<float>(ctx, w, count, in, out, s);
 }
 
 int run_laplace_apply(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* p, void* out,

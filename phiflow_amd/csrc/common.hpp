@@ -336,6 +336,7 @@ int run_diffuse_implicit(phihip_ctx*, const GridView&, const void* const v[3], v
 int run_diffuse_implicit_centered(phihip_ctx*, const GridView&, const void* s, const int32_t s_bc[3][2], const double s_val[3][2], void* out, double kdt,
                                   const phihip_solve*, phihip_solve_info*, hipStream_t);
 int run_laplace_apply(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* p, void* out, hipStream_t);
+int run_laplace_apply_multi(phihip_ctx*, const GridView* lattices, int count, const void* const* in, void* const* out, hipStream_t);   // MODE_APPLY, no flags: lattices of one tile configuration share a launch
 int run_export_residuals(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_export_relative_residual(phihip_ctx*, int batch, double* out, hipStream_t);
 int run_cg(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, phihip_solve_info*, hipStream_t);

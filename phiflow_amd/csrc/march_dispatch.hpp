@@ -70,8 +70,9 @@ inline int family_mode(int family) { return family == 1 ? MODE_MATVEC : (family 
 // kernel families that may use different tile shapes (phihip_set_tuning_kernel)
 enum MarchFamily { FAM_APPLY = 0, FAM_MATVEC = 1, FAM_UPDATE = 2, FAM_UPDATE_R = 3, FAM_CG1 = 4, FAM_COUNT = 5 };   // UPDATE_R: the r-only update (3 words); CG1: the fused single-reduction iteration
 
-// choose tile + chunk for a grid (honours ctx->tuning[family]) and fill the decomposition fields of MarchGrid
-int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* cfg, MarchGrid* g);
+// choose tile + chunk for a grid (honours ctx->tuning[family]) and fill the decomposition fields of MarchGrid; force_id >= 0: that tile configuration if the
+// grid's vector width has it (lattices that share ONE launch, run_diffuse)
+int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool flags, int family, MarchConfig* cfg, MarchGrid* g, int force_id = -1);
 
 // resident workgroups per CU of one march_kernel instantiation (hipOccupancyMaxActiveBlocksPerMultiprocessor, cached)
 template <typename T, bool DIM3>
@@ -89,6 +90,16 @@ inline int march_occupancy_any(const GridView& v, int id, int vec, int mode, boo
 
 template <typename T, bool DIM3>
 int launch_march(const MarchConfig& c, int mode, bool flags, const MarchGrid& g, const MarchArgs<T>& a, hipStream_t s);
+
+// MODE_APPLY without cell flags on `count` <= 3 lattices that share the tile configuration c (id, vec, batch) in ONE launch; g[l] / a[l].a / a[l].o1 per
+// lattice, weights / ident from a[0]
+template <typename T, bool DIM3>
+int launch_march_multi(const MarchConfig& c, int count, const MarchGrid* g, const MarchArgs<T>* a, hipStream_t s);
+
+template <typename T>
+inline int launch_march_multi_any(const GridView& v, const MarchConfig& c, int count, const MarchGrid* g, const MarchArgs<T>* a, hipStream_t s) {
+    return v.rank == 3 ? launch_march_multi<T, true>(c, count, g, a, s) : launch_march_multi<T, false>(c, count, g, a, s);
+}
 
 template <typename T>
 inline int launch_march_any(const GridView& v, const MarchConfig& c, int mode, bool flags, const MarchGrid& g,

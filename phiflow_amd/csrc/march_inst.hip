@@ -164,4 +164,63 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
     }
 }
 
+// ---- MODE_APPLY on several lattices of one tile configuration in ONE launch (stencil_march.hpp march_apply_multi_kernel) -----------------------------
+template <int V, int R, int TPR, bool UNAL = false, bool ROWT = false>
+static int launch_multi_cfg(const MarchMulti<InstT>& m, const MarchArgs<InstT>& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((march_apply_multi_kernel<InstT, V, R, TPR, kInstDim3, UNAL, ROWT>), grid, dim3(kBlock), 0, s, m, a);
+    return PHIHIP_OK;
+}
+
+template <>
+int launch_march_multi<InstT, kInstDim3>(const MarchConfig& c, int count, const MarchGrid* g, const MarchArgs<InstT>* args, hipStream_t s) {
+    if (count < 1 || count > 3) {
+        set_error("march (multi): %d lattices", count);
+        return PHIHIP_ERR_BAD_ARG;
+    }
+    MarchArgs<InstT> a = args[0];
+    a.dump = march_dump_slot();
+    if (!a.dump) {
+        set_error("march: cannot allocate the dump slot");
+        return PHIHIP_ERR_ALLOC;
+    }
+    MarchMulti<InstT> m;
+    memset(&m, 0, sizeof(m));
+    unsigned nblk = 0;
+    for (int l = 0; l < count; ++l) {
+        m.g[l] = g[l];
+        m.in[l] = args[l].a;
+        m.out[l] = args[l].o1;
+        nblk = (unsigned)g[l].nblk > nblk ? (unsigned)g[l].nblk : nblk;
+    }
+    dim3 grid(nblk, c.batch, count);
+    if (c.vec == 1) return launch_multi_cfg<1, 1, 64>(m, a, grid, s);
+    if (c.vec < 0) return launch_multi_cfg<kVmax, 1, 64, true>(m, a, grid, s);
+    if (c.vec == 2 && kVmax == 4) {
+        switch (c.id) {
+            case 4: return launch_multi_cfg<(kVmax == 4 ? 2 : kVmax), 4, 64>(m, a, grid, s);
+            case 5: return launch_multi_cfg<(kVmax == 4 ? 2 : kVmax), 1, 64>(m, a, grid, s);
+            case 6: return launch_multi_cfg<(kVmax == 4 ? 2 : kVmax), 2, 64>(m, a, grid, s);
+            default:
+                set_error("march: tile config %d is not instantiated for 8-byte vectors", c.id);
+                return PHIHIP_ERR_BAD_ARG;
+        }
+    }
+    switch (c.id) {
+        case 0: return launch_multi_cfg<kVmax, 1, 16>(m, a, grid, s);
+        case 1: return launch_multi_cfg<kVmax, 2, 16>(m, a, grid, s);
+        case 2: return launch_multi_cfg<kVmax, 2, 32>(m, a, grid, s);
+        case 3: return launch_multi_cfg<kVmax, 4, 32>(m, a, grid, s);
+        case 4: return launch_multi_cfg<kVmax, 4, 64>(m, a, grid, s);
+        case 5: return launch_multi_cfg<kVmax, 1, 64>(m, a, grid, s);
+        case 6: return launch_multi_cfg<kVmax, 2, 64>(m, a, grid, s);
+        case 7: return launch_multi_cfg<kVmax, 1, 32>(m, a, grid, s);
+        case 8: return launch_multi_cfg<kVmax, 1, 128, false, true>(m, a, grid, s);
+        case 9: return launch_multi_cfg<kVmax, 2, 128, false, true>(m, a, grid, s);
+        case 10: return launch_multi_cfg<kVmax, 4, 128, false, true>(m, a, grid, s);
+        default:
+            set_error("march: bad tile config %d", c.id);
+            return PHIHIP_ERR_BAD_ARG;
+    }
+}
+
 }  // namespace phihip

@@ -1618,6 +1618,22 @@ __global__ __launch_bounds__(kBlock) void affine_walls_kernel(VelGrid g, int ca,
     }
 }
 
+// the wall constants' share of diffuse.explicit on one lattice (only sides with c != 0 launch anything: the lid of a cavity)
+static int diffuse_affine_walls(phihip_ctx* ctx, const GridView& v, const VelGrid& g, int ca, void* out, double kdt, hipStream_t s) {
+    LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
+    for (int a = v.ax0; a < 3; ++a)
+        for (int side = 0; side < 2; ++side) {
+            if (g.bc[a][side] != PHIHIP_BC_CLOSED || g.bcv[a][side][ca] == 0.0) continue;
+            const double add = kdt * g.bcv[a][side][ca] * g.rdx[a] * g.rdx[a];
+            const long long total = g.ccells[ca] / g.cn[ca][a];
+            const dim3 grid((unsigned)((total + kBlock - 1) / kBlock < 4096 ? (total + kBlock - 1) / kBlock : 4096), v.batch);
+            if (v.dtype == PHIHIP_F64) hipLaunchKernelGGL(affine_walls_kernel<double>, grid, dim3(kBlock), 0, s, g, ca, a, side, (double*)out, add);
+            else hipLaunchKernelGGL(affine_walls_kernel<float>, grid, dim3(kBlock), 0, s, g, ca, a, side, (float*)out, (float)add);
+        }
+    PHIHIP_CHECK_HIP(hipGetLastError());
+    return PHIHIP_OK;
+}
+
 // diffuse.explicit on one lattice = ONE pass of the marching kernels (MODE_APPLY with the operator I + k dt L: 2 words per sample, the tuned
 // tiles of the pressure operator; r4 -- the one-dword-per-lane kernel it replaces ran at 0.32 of the HBM rate)
 static int diffuse_explicit_lattice(phihip_ctx* ctx, const GridView& v, const VelGrid& g, int ca, const void* in, void* out, double kdt, hipStream_t s) {
@@ -1625,25 +1641,29 @@ static int diffuse_explicit_lattice(phihip_ctx* ctx, const GridView& v, const Ve
     const GridView w = lattice_view(v, g, ca, 1.0, kdt, &affine);
     if (w.cells >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
     PHIHIP_TRY(run_laplace_apply(ctx, w, nullptr, 1, in, out, s));
-    if (affine) {
-        LaunchScope ls(ctx, PHIHIP_K_OTHER, s);
-        for (int a = v.ax0; a < 3; ++a)
-            for (int side = 0; side < 2; ++side) {
-                if (g.bc[a][side] != PHIHIP_BC_CLOSED || g.bcv[a][side][ca] == 0.0) continue;
-                const double add = kdt * g.bcv[a][side][ca] * g.rdx[a] * g.rdx[a];
-                const long long total = g.ccells[ca] / g.cn[ca][a];
-                const dim3 grid((unsigned)((total + kBlock - 1) / kBlock < 4096 ? (total + kBlock - 1) / kBlock : 4096), v.batch);
-                if (v.dtype == PHIHIP_F64) hipLaunchKernelGGL(affine_walls_kernel<double>, grid, dim3(kBlock), 0, s, g, ca, a, side, (double*)out, add);
-                else hipLaunchKernelGGL(affine_walls_kernel<float>, grid, dim3(kBlock), 0, s, g, ca, a, side, (float*)out, (float)add);
-            }
-        PHIHIP_CHECK_HIP(hipGetLastError());
-    }
+    if (affine) PHIHIP_TRY(diffuse_affine_walls(ctx, v, g, ca, out, kdt, s));
     return PHIHIP_OK;
 }
 
+// diffuse.explicit of a staggered field (phi/physics/diffuse.py:13-60 -- ONE call in the reference): r6 all components in ONE launch where their lattices share a
+// tile configuration (cg.hip laplace_apply_multi_t: every periodic box; the components with whole rows of a closed box), then the wall constants
 int run_diffuse(phihip_ctx* ctx, const GridView& v, const void* const vin[3], void* const vout[3], double kdt, hipStream_t s) {
     const VelGrid g = make_velgrid(v);
-    for (int ca = v.ax0; ca < 3; ++ca) PHIHIP_TRY(diffuse_explicit_lattice(ctx, v, g, ca, vin[ca], vout[ca], kdt, s));
+    GridView w[3];
+    const void* in[3];
+    void* out[3];
+    bool affine[3] = {false, false, false};
+    int count = 0;
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        w[count] = lattice_view(v, g, ca, 1.0, kdt, &affine[ca]);
+        if (w[count].cells >= (1LL << 31)) { set_error("diffuse: more than 2^31 samples per component and batch entry are not supported"); return PHIHIP_ERR_UNSUPPORTED; }
+        in[count] = vin[ca];
+        out[count] = vout[ca];
+        ++count;
+    }
+    PHIHIP_TRY(run_laplace_apply_multi(ctx, w, count, in, out, s));
+    for (int ca = v.ax0; ca < 3; ++ca)
+        if (affine[ca]) PHIHIP_TRY(diffuse_affine_walls(ctx, v, g, ca, vout[ca], kdt, s));
     return PHIHIP_OK;
 }
 

@@ -393,8 +393,10 @@ constexpr int march_min_waves() {
 #ifndef PHIHIP_SAWTOOTH
 #define PHIHIP_SAWTOOTH 1
 #endif
+// march_body: the kernel's body as a device function (r6), so that TWO entry points share it -- march_kernel (one lattice per launch: every CG phase) and
+// march_apply_multi_kernel (MODE_APPLY on up to three lattices in ONE launch: the components of diffuse.explicit, phi/physics/diffuse.py:13-60 is one call).
 template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false, bool ROWT = false>
-__global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
+__device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T>& p) {
     constexpr int TRc = ROWT ? kBlock / (TPR / 2 + 1) : kBlock / TPR;   // thread rows (ROWT: at most -- rows of more than TPR / 2 lanes)
     constexpr int T1c = TRc * R;       // tile rows (axis a1)
     constexpr int T2c = TPR * V;       // tile columns (axis a2)
@@ -865,6 +867,31 @@ __global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLA
             }
         }
     }
+}
+
+template <typename T, int V, int R, int TPR, int MODE, bool FLAGS, bool DIM3, bool BIDIR = false, bool UNAL = false, bool ROWT = false>
+__global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE, FLAGS>())) void march_kernel(MarchGrid g, MarchArgs<T> p) {
+    march_body<T, V, R, TPR, MODE, FLAGS, DIM3, BIDIR, UNAL, ROWT>(g, p);
+}
+
+// MODE_APPLY (out = (ident + sum_a w_a d^2_a) in) on up to three lattices of one tile configuration in ONE launch: blockIdx.z selects the lattice -- its shape,
+// neighbour rules, decomposition (MarchGrid) and its arrays; weights, ident and the dump slot are common. The launch has max(nblk) workgroups per lattice and
+// batch entry, the surplus of a smaller lattice (a closed box: N - 1 faces along the component's axis) leaves at once.
+template <typename T>
+struct MarchMulti {
+    MarchGrid g[3];
+    const T* in[3];
+    T* out[3];
+};
+template <typename T, int V, int R, int TPR, bool DIM3, bool UNAL = false, bool ROWT = false>
+__global__ __launch_bounds__(kBlock, (UNAL ? 1 : march_min_waves<T, R, MODE_APPLY, false>())) void march_apply_multi_kernel(MarchMulti<T> m, MarchArgs<T> p) {
+    const int l = blockIdx.z;              // uniform: the lattice's descriptor comes from the kernel arguments with scalar loads
+    const MarchGrid g = m.g[l];
+    if ((int)blockIdx.x >= g.nblk) return;
+    MarchArgs<T> q = p;
+    q.a = m.in[l];
+    q.o1 = m.out[l];
+    march_body<T, V, R, TPR, MODE_APPLY, false, DIM3, false, UNAL, ROWT>(g, q);
 }
 
 }  // namespace phihip

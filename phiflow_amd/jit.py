@@ -17,16 +17,18 @@ with the same signature:
     is refused (its repr would not tell two tensors apart);
   * the results are cloned out of the graph's output buffers (Fields are immutable: a result must survive the next replay); `copy_outputs=False`
     hands out the buffers themselves for callers that consume a result before the next call. Results that are not tensors (numbers, None, strings) are those of
-    the capture run: a replay cannot recompute them.
+    the capture run: a replay cannot recompute them. With `copy_outputs=False` a loop `v, p = step(v, p)` runs as a PING-PONG of two captures (r6): the
+    second reads the first one's output buffers in place, so a step copies nothing out and (every other step) nothing in; a result then stays valid until
+    the call after next.
 Inside a captured function the host cannot see a solve's outcome: `make_incompressible` / `solve_linear` / `diffuse.implicit` run with `info = NULL` and
 `check_every = 0` (the library's capture-safe form: no host read-back, no synchronisation, no allocation, no first-call autotune --
 tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diverged are not raised. A tolerance solve under capture
 enqueues its whole launch budget (entries that converged early freeze on the device), so give it a `max_iterations` that fits the
 problem; grids of <= 16384 cells run the whole solve in ONE kernel with the convergence test on the device and need no such care.
 
-Reproducibility: a replay gives the bits of the eager function (tests/test_jit.py) with one caveat measured on this ROCm build and not explained: after a fused
-`torch._foreach_*` launch on the same device between two calls (optimizers use them), the replay's projection results can differ from the eager ones in the last
-bits although it sees the right inputs (tools/micro/jit_foreach_debug.py, profiles/r05_jit_foreach_debug.txt); this wrapper itself launches none.
+Reproducibility: a replay gives the bits of the eager function (tests/test_jit.py). (r5 shipped with a caveat -- after a fused `torch._foreach_*` launch a replay
+could differ from the eager step in the last bits; r6 traced it to this package: eager passes and a capture could send a sample through different advection kernels
+whose arithmetic differed in rounding. Every path now computes the same bits -- tests/parity_cases.py check_advect_paths_same_bits -- and the caveat is gone.)
 
 The function must be a pure function of its arguments (the capture runs it twice -- a warm-up that sizes the workspaces and tunes the
 launch plans, then the capture itself -- and never again). On the CPU emulation device (tests) nothing can be captured: the wrapper then
@@ -174,7 +176,7 @@ def _spec_key(spec):
 
 
 class _Capture:
-    __slots__ = ("graph", "inputs", "outputs", "out_spec", "spec")
+    __slots__ = ("graph", "inputs", "outputs", "out_spec", "spec", "input_ptrs", "output_ptrs")
 
 
 class JitFunction:
@@ -187,9 +189,10 @@ class JitFunction:
         self.auxiliary_args = tuple(a.strip() for a in auxiliary_args.split(",") if a.strip())
         self.forget_traces = bool(forget_traces)
         self.copy_outputs = copy_outputs
-        self.captures: Dict[Any, _Capture] = {}
+        self.captures: Dict[Any, List[_Capture]] = {}      # per signature: the capture and, with copy_outputs=False, its ping-pong partner
         self.traces = 0           # captures made so far (PhiML: the number of times the function was traced)
         self.replays = 0
+        self.input_copies = 0     # tensors copied into a capture's input buffers so far (a ping-pong pair copies every other step only)
         try:
             self._sig = inspect.signature(f)
         except (TypeError, ValueError):
@@ -223,42 +226,61 @@ class JitFunction:
             with _tracing():
                 return call(_unflatten(spec, iter(tensors)))
         key = (_spec_key(spec), tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors))
-        cap = self.captures.get(key)
-        if cap is None:
+        variants = self.captures.get(key)
+        cap = None
+        if variants is None:
             if self.forget_traces:
                 self.captures.clear()
             while len(self.captures) >= self.MAX_CAPTURES:
                 self.captures.pop(next(iter(self.captures)))          # the oldest signature goes (dicts keep insertion order)
-            cap = self._capture(spec, tensors, call)
-            self.captures[key] = cap
+            cap = self._capture(spec, tensors, call, alias_inputs=False)
+            self.captures[key] = [cap]
         else:
-            # One copy per tensor, by `copy_`. A fused `torch._foreach_copy_` (one launch, 3 % faster on the 128^2 plume) is NOT safe in front of a replay on
-            # this ROCm build. Established (tools/micro/jit_foreach_debug.py, found by the bit comparison of tests/test_jit.py): the fused copies are exact
-            # (checked element by element after a device synchronisation) and the eager steps are unaffected, yet the replay that follows ANY such launch --
-            # of all inputs, of all but the pressure guess, of the pressure guess alone -- leaves the eager step's bits by the same rounding-level amount in
-            # the projection's results (not in the smoke), with or without a host synchronisation in between; per-tensor `copy_` and per-tensor arithmetic
-            # kernels never do. The replay SEES the right inputs (images taken inside the graph by a memcpy node and by a kernel node equal what was passed:
-            # tools/micro/jit_foreach_probe.py), the projection captured alone is unaffected, and it is not the data the fused kernel writes: a fused copy
-            # between UNRELATED tensors in front of the per-tensor input copies does the same, behind them it is harmless. Open; avoided, not explained.
-            for dst, src in zip(cap.inputs, tensors):
-                if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src)
+            ptrs = [t.data_ptr() for t in tensors]
+            for c in variants:                                          # a capture that READS these very buffers: nothing to copy
+                if c.input_ptrs == ptrs:
+                    cap = c
+                    break
+            if cap is None and not self.copy_outputs and len(variants) < 2 and any(q in variants[0].output_ptrs for q in ptrs):
+                # r6, two-graph ping-pong (copy_outputs=False, the loop `v, p = step(v, p)`): the caller hands back what the first capture RETURNED -- a second
+                # capture is made that reads those output buffers in place; from now on the two alternate and, at 256^3, a step stops copying 268 MB in and
+                # 268 MB out (bench.py phi_level: the captured step was 3.7 % SLOWER than the eager one in r5). The first capture still needs its inputs
+                # copied in (the second one's outputs are not its input buffers): one copy every other step.
+                cap = self._capture(spec, tensors, call, alias_inputs=True)
+                variants.append(cap)
+            if cap is None:
+                cap = variants[0]
+                # Inputs are copied with ONE fused launch (`torch._foreach_copy_`; per-tensor `copy_` for a single input). Until r5 this was avoided: a replay
+                # behind any fused launch left the eager bits in the last place (profiles/r05_jit_foreach_debug.txt). The cause was in this package after all --
+                # which kernel computed a sample of an advection pass (LDS tile, fix-up list, gather) was policy, the paths did not share one arithmetic, and
+                # eager passes and a capture's fixed reach could take different ones; since r6 every path evaluates the same expressions
+                # (csrc/advect_common.hpp) and all nine variants of tools/micro/jit_foreach_debug.py give the eager bits
+                # (profiles/r06_jit_foreach_debug.txt, tests/test_jit.py).
+                pairs = [(dst, src) for dst, src in zip(cap.inputs, tensors) if dst.data_ptr() != src.data_ptr()]
+                if len(pairs) > 1:
+                    torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+                elif pairs:
+                    pairs[0][0].copy_(pairs[0][1])
+                self.input_copies += len(pairs)
         cap.graph.replay()
         self.replays += 1
         outs = [t.clone() for t in cap.outputs] if self.copy_outputs else list(cap.outputs)
         return _unflatten(cap.out_spec, iter(outs))
 
-    def _capture(self, spec, tensors, call) -> _Capture:
+    def _capture(self, spec, tensors, call, alias_inputs: bool) -> _Capture:
+        """ alias_inputs: the graph reads the caller's tensors IN PLACE (they are output buffers of this function's other capture, which the caller promised to
+        consume before the call after next: copy_outputs=False); otherwise it owns copies of them """
         device = tensors[0].device
         cap = _Capture()
         cap.spec = spec           # (keeps the auxiliary objects alive whose identity is part of the key)
-        cap.inputs = [t.detach().clone() for t in tensors]
+        cap.inputs = [t.detach() for t in tensors] if alias_inputs else [t.detach().clone() for t in tensors]
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
+        saved = [t.clone() for t in cap.inputs] if alias_inputs else None
         with torch.cuda.stream(side), _tracing():
             call(_unflatten(spec, iter(cap.inputs)))       # warm-up on the capturing stream: workspaces grown, launch plans tuned, masks rasterised
         side.synchronize()
-        for dst, src in zip(cap.inputs, tensors):          # (a function that wrote into its inputs would have spoilt them: Fields never do, bare tensors may)
+        for dst, src in zip(cap.inputs, saved if alias_inputs else tensors):      # (a function that wrote into its inputs would have spoilt them: Fields never do, bare tensors may)
             dst.copy_(src)
         torch.cuda.current_stream(device).synchronize()
         cap.graph = torch.cuda.CUDAGraph()
@@ -266,6 +288,8 @@ class JitFunction:
             out = call(_unflatten(spec, iter(cap.inputs)))
         cap.outputs = []
         cap.out_spec = _flatten(out, cap.outputs)
+        cap.input_ptrs = [t.data_ptr() for t in cap.inputs]
+        cap.output_ptrs = {t.data_ptr() for t in cap.outputs}
         self.traces += 1
         return cap
 

@@ -90,6 +90,7 @@ def test_adaptive_reach_is_deterministic(emu_library):
     for a in fast:
         a[:, :4] *= np.float32(2.0)                  # the first four planes of every component move up to 1.6 cells: ~ a quarter of the (tile, plane) units
     def run(ctx, field, halo, passes):
+        """ -> per pass: (result, units the fix-up list redid) -- the second tells WHICH reach ran: 1.6 cells leave the narrow window and stay inside the wide one """
         ctx.set_advect_halo(halo)
         dv = [MEM.to_dev(a) for a in field]
         outs = []
@@ -97,17 +98,37 @@ def test_adaptive_reach_is_deterministic(emu_library):
             dout = [MEM.empty(a.shape, np.float32) for a in field]
             ctx.advect_staggered(grid, [MEM.ptr(a) for a in dv], [MEM.ptr(a) for a in dv], [MEM.ptr(a) for a in dout], 1.0)
             MEM.sync()
-            outs.append(np.concatenate([MEM.to_host(a).ravel() for a in dout]).copy())
+            outs.append((np.concatenate([MEM.to_host(a).ravel() for a in dout]).copy(), ctx.advect_fallback_stats()[0]))
         return outs
-    narrow = run(C.Context(emu_library, 0), fast, 1, 1)[0]
-    wide = run(C.Context(emu_library, 0), fast, 2, 1)[0]
-    assert not np.array_equal(narrow, wide) and np.allclose(narrow, wide, rtol=0, atol=2e-5)      # two forms of the same arithmetic: equal to rounding, not bit for bit
+    narrow, redone_narrow = run(C.Context(emu_library, 0), fast, 1, 1)[0]
+    wide, redone_wide = run(C.Context(emu_library, 0), fast, 2, 1)[0]
+    assert redone_narrow > 0 and redone_wide == 0
+    # r6: the two reaches (and the fix-up list) evaluate ONE arithmetic -- until r5 they agreed to rounding only, and the reach of a pass showed in its last bits
+    assert np.array_equal(narrow, wide)
     runs = [run(C.Context(emu_library, 0), fast, -1, 9) for _ in range(2)]
     for outs in runs:
-        assert all(np.array_equal(o, narrow) for o in outs[:3]), "passes 1-3 run with the narrow reach"
-        assert all(np.array_equal(o, wide) for o in outs[3:]), "from pass 4 on the wide reach"
+        assert all(r > 0 for _, r in outs[:3]), "passes 1-3 run with the narrow reach"
+        assert all(r == 0 for _, r in outs[3:]), "from pass 4 on the wide reach"
+        assert all(np.array_equal(o, narrow) for o, _ in outs), "the same bits whatever the reach"
     calm = run(C.Context(emu_library, 0), gentle, -1, 9)
-    assert all(np.array_equal(o, calm[0]) for o in calm)
+    assert all(np.array_equal(o, calm[0][0]) and r == 0 for o, r in calm)
+    # r6: one policy PER GRID -- two grids that alternate on one context (SlabFluid's whole-slab and window passes, two simulations) each keep
+    # their history; until r5 every change of grid restarted the policy and the reach never left narrow
+    dom2, grid2 = pc.make_case((16, 24, 32), ((PER, PER),) * 3, np.float32, batch=1)
+    v2 = pc.random_velocity(dom2, 1, np.float32, rng, 1.0)
+    gentle2 = [a * np.float32(0.8 / max(float(np.abs(b).max()) for b in v2)) for a in v2]
+    ctx = C.Context(emu_library, 0)
+    ctx.set_advect_halo(-1)
+    dv, dv2 = [MEM.to_dev(a) for a in fast], [MEM.to_dev(a) for a in gentle2]
+    redone = []
+    for _ in range(9):
+        for g, d, field in ((grid, dv, fast), (grid2, dv2, gentle2)):
+            dout = [MEM.empty(a.shape, np.float32) for a in field]
+            ctx.advect_staggered(g, [MEM.ptr(a) for a in d], [MEM.ptr(a) for a in d], [MEM.ptr(a) for a in dout], 1.0)
+            MEM.sync()
+            if g is grid:
+                redone.append(ctx.advect_fallback_stats()[0])
+    assert all(r > 0 for r in redone[:3]) and all(r == 0 for r in redone[3:]), redone
 
 
 @pytest.mark.parametrize("res,bc,dma32,dma64", [
