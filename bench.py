@@ -286,7 +286,7 @@ def bench_config4(args, ctx, device, rank, world, dist, barrier, allreduce):
         ctx.profile_enable(False)
         cells = total * n * n
         it_us = (prof["cg_matvec_dot"][1] + prof["cg_update"][1] + prof["cg_update_r"][1]) / max(1, prof["cg_matvec_dot"][0]) * 1e3
-        if args.resident_cg and prof["cg_matvec_dot"][0] == 0:          # the resident solver: one launch for the whole solve
+        if prof["cg_matvec_dot"][0] == 0:          # the resident solver: one launch for the whole solve
             it_us = prof["cg_update"][1] / max(1, args.cg_iters) * 1e3
         emit_record({
             "metric": f"cell-updates/sec (mac_cormack + advect + {args.cg_iters} CG iters), {total} x {n}^2 fp32 batched smoke", "value": cells * args.steps / elapsed,
@@ -839,8 +839,8 @@ def main():
                          "plume step (MacCormack smoke, advection, buoyancy, diffusion, 20 warm-started CG iterations): the share of the non-CG kernels")
     ap.add_argument("--overlap", type=int, default=0, help="slab: 1 = SlabFluid(overlap=True): the ghost-plane exchange of the advection is in flight while the "
                     "whole slab is advected, the planes within reach of a cut are redone on windows afterwards (same bits; tests/test_parallel_gloo.py)")
-    ap.add_argument("--resident-cg", type=int, default=0, choices=[0, 1, 2], help="opt-in resident solver for 2-D fp32 projections (phihip_set_resident_cg; config4: "
-                    "the projection's CG iterations become ONE launch): 0 off (default), 1 up to the built-in cell limit, 2 whenever applicable")
+    ap.add_argument("--resident-cg", type=int, default=-1, choices=[-1, 0, 1, 2], help="-1: the library's default (r6: mode 1); resident solver for 2-D fp32 projections (phihip_set_resident_cg; config4: "
+                    "the projection's CG iterations become ONE launch): 0 off, 1 up to the built-in cell limit, 2 whenever applicable")
     ap.add_argument("--batch-total", type=int, default=8, help="config4: simulations in the batch (all ranks together)")
     ap.add_argument("--config3-size", type=int, default=512, help="grid size of the BASELINE configs[2] block = the `roofline` kernel (pressure solve only; 0 = skip)")
     ap.add_argument("--pmc", type=int, default=1, help="1: run the rocprofv3 FETCH_SIZE / WRITE_SIZE passes for roofline.traffic inside this invocation")
@@ -870,7 +870,7 @@ def main():
 
     lib = load_library()
     ctx = C.Context(lib, local_rank if device.type == "cuda" else 0)
-    if args.resident_cg:
+    if args.resident_cg >= 0:
         ctx.set_resident_cg(args.resident_cg)
     if args.advect_halo != -1:
         ctx.set_advect_halo(args.advect_halo)

@@ -331,6 +331,12 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
     ctx->device = device;
     const char* at = getenv("PHIHIP_AUTOTUNE");
     if (at && at[0] == '0') ctx->autotune = false;
+    const char* rc = getenv("PHIHIP_RESIDENT_CG");       // 0 / 1 / 2: phihip_set_resident_cg mode at creation (r6 default 1)
+    if (rc && rc[0] >= '0' && rc[0] <= '2') ctx->resident_cg = rc[0] - '0';
+    const char* coop = getenv("PHIHIP_RESIDENT_COOP");   // 0: the resident solver as a plain launch (A/B of the cooperative launch's cost)
+    if (coop && (coop[0] == '0' || coop[0] == '1')) ctx->res_coop = coop[0] - '0';
+    const char* coopc = getenv("PHIHIP_RESIDENT_COOP_CAPTURE");
+    if (coopc && (coopc[0] == '0' || coopc[0] == '1')) ctx->res_coop_capture = coopc[0] - '0';
     const char* dma = getenv("PHIHIP_ADVECT_DMA");      // A/B switch of the LDS-DMA fill of the tiled self-advection (advect_tile.hip)
     if (dma && (dma[0] == '0' || dma[0] == '1')) ctx->adv_dma = dma[0] - '0';
     hipDeviceProp_t prop;

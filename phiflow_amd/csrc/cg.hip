@@ -866,11 +866,13 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
         if (shift) { set_error("cg: the single-kernel solver takes a balanced right-hand side"); return PHIHIP_ERR_BAD_ARG; }
         return cg_small_path(ctx, v, flags, mask_batch, rhs, x, solve, info, s);
     }
-    // 2-D fp32 grids up to the resident solver's cell limit: ONE launch for the whole solve (cg_resident.hip). A stream under capture keeps the
-    // launch-per-iteration forms (a graph replay next to other work could find the device occupied: the launch must be resident as a whole)
+    // 2-D fp32 grids up to the resident solver's cell limit: ONE launch for the whole solve (cg_resident.hip), r6 by default and under capture too (the solve
+    // number of its tags lives on the device: a replay gets a fresh one). A launch the runtime refuses (cooperative launch too large) takes the forms below.
     if (!v.op_custom && ctx->resident_cg > 0 && ctx->small_cg && !std::is_same<T, double>::value && cg_resident_applicable(ctx, v, flags, solve) &&
-        (ctx->resident_cg == 2 || (long long)v.cells * v.batch <= ctx->resident_cg_cells) && !stream_is_capturing(s))
-        return cg_resident_path(ctx, v, rhs, x, solve, info, shift, s);
+        (ctx->resident_cg == 2 || (long long)v.cells * v.batch <= ctx->resident_cg_cells)) {
+        const int st = cg_resident_path(ctx, v, rhs, x, solve, info, shift, s);
+        if (st != PHIHIP_ERR_UNSUPPORTED) return st;
+    }
     // (phihip_set_small_grid_solver(ctx, 0) = "the two-launch marching kernels at every size": it also switches the automatic choice off)
     if (solve->method == PHIHIP_METHOD_CG && !v.halo[0] && !v.halo[1] &&
         (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && ctx->small_cg && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))

@@ -59,7 +59,8 @@ struct ResArgs {
     gran_t* part;                 // [2][batch][G][5][2] partial sums (low / high word of a double)
     int* abort_flag;              // zero at launch
     int* abort_host;              // pinned, device-mapped: set when the launch gave up (read by the next solve of a caller that passed no `info`)
-    unsigned tag_hi;              // solve number << 20: tags of an earlier solve never match
+    const unsigned* solve_ctr;    // r6: the solve number lives on the DEVICE (res_begin_kernel bumps it in front of every launch, also of every graph replay): tags =
+                                  // (solve number << 20) | phase, granules of an earlier solve never match
     CgState* st_out;              // [batch]
     CgParams prm;
     int refresh_every;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     const long long base = (long long)b * A.cells;
     const long long rowoff = base + (long long)(row0 + (row_ok ? wave : 0)) * n2;
 
+    const unsigned tag_hi = (*A.solve_ctr & 0xFFFu) << 20;      // uniform (scalar load): the launch's solve number, bumped by res_begin_kernel in front of it
     bool ok[VPT], in_row[VPT], zl[VPT], zr[VPT];
     int j[VPT], jl[VPT], jr[VPT];
 #pragma unroll
@@ -270,13 +272,13 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     // vector v of this workgroup's first / last row -> the slot the neighbours read in phase `ph`
     auto publish1 = [&](unsigned ph, int v, f4 a0) {
         if (!in_row[v]) return;
-        const unsigned tag = A.tag_hi | ph;
+        const unsigned tag = tag_hi | ph;
         if (first_row) gran_put4(pub_ptr(ph & 1, g, 0, 0) + j[v], a0, tag);
         if (last_row) gran_put4(pub_ptr(ph & 1, g, 1, 0) + j[v], a0, tag);
     };
     auto publish3 = [&](unsigned ph, int v, f4 a0, f4 a1, f4 a2) {
         if (!in_row[v]) return;
-        const unsigned tag = A.tag_hi | ph;
+        const unsigned tag = tag_hi | ph;
         if (first_row) {
             gran_put4(pub_ptr(ph & 1, g, 0, 0) + j[v], a0, tag);
             gran_put4(pub_ptr(ph & 1, g, 0, 1) + j[v], a1, tag);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     };
     // edge wavefronts: the neighbours' rows of phase `ph` (polled until their tags show it) -> hraw; three arrays (r, w, s) or one
     auto fetch_side = [&](unsigned ph, int gg, int side_of_neighbour, int slot_side, int v, bool three) {
-        const unsigned tag = A.tag_hi | ph;
+        const unsigned tag = tag_hi | ph;
         const gran_t* q = pub_ptr(ph & 1, gg, side_of_neighbour, 0) + j[v];
         if (three) {
             f4 h[3];
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
             for (int ww = 0; ww < kResRows; ++ww) t += red[tid * kResRows + ww];
             const unsigned long long bits = bits_of(t);
             gran_t* q = part_ptr(ph & 1, g) + 2 * tid;
-            gran_store(q, (unsigned)bits, A.tag_hi | ph);
-            gran_store(q + 1, (unsigned)(bits >> 32), A.tag_hi | ph);
+            gran_store(q, (unsigned)bits, tag_hi | ph);
+            gran_store(q + 1, (unsigned)(bits >> 32), tag_hi | ph);
         }
     };
     // the entry's sums of phase `ph`, added in a fixed order (every workgroup forms the same bits). This all-to-all is what orders the phases
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
             double val = 0;
             if (lane < G) {
                 const gran_t* q = part_ptr(ph & 1, lane) + 2 * k;
-                const unsigned tag = A.tag_hi | ph;
+                const unsigned tag = tag_hi | ph;
                 unsigned spins = 0;
                 for (;;) {
                     const gran_t lo = gran_load(q), hi = gran_load(q + 1);
@@ -564,6 +566,23 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     }
 }
 
+// In front of every resident launch (one workgroup; a node of the graph when the solve is captured, so every REPLAY gets a fresh number too -- until r5 the
+// number was a kernel argument written by the host, a replay would have reused the capture's tags, and the resident solver was refused under capture):
+// solve number += 1 (12 bits, 0 skipped: a zeroed buffer carries tag 0), the launch's abort flag cleared; when the number wraps, the granule buffers are
+// cleared (a granule 4096 solves old could otherwise pass for a fresh one: ~13 MB for 8 x 512^2, once per 4095 solves).
+__global__ __launch_bounds__(kResBlock) void res_begin_kernel(unsigned* ctr, int* abort_flag, unsigned long long* gran, size_t gran_words) {
+    __shared__ unsigned next;
+    if (threadIdx.x == 0) {
+        unsigned n = (*ctr + 1u) & 0xFFFu;
+        next = n;
+        *ctr = n == 0u ? 1u : n;
+        *abort_flag = 0;
+    }
+    __syncthreads();
+    if (next == 0u)
+        for (size_t i = threadIdx.x; i < gran_words; i += blockDim.x) gran[i] = 0ull;
+}
+
 static size_t resident_lds_bytes(int vpt) {
     const size_t ls = 256 * (size_t)vpt + 8;
     return (kResRows + 2) * ls * sizeof(float) + (5 * kResRows + 10) * sizeof(double) + 2 * sizeof(CgState) + 6 * ls * sizeof(float) + 16;
@@ -627,21 +646,18 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x
     const size_t pub_bytes = (size_t)2 * v.batch * G * 2 * 3 * A.ns * sizeof(gran_t);
     const size_t part_bytes = (size_t)2 * v.batch * G * 10 * sizeof(gran_t);
     const size_t ctl_off = (pub_bytes + part_bytes + 255) / 256 * 256;
-    // tags = (solve number, phase): granules of an earlier solve never match. The buffer is cleared when it is new and when the 12-bit solve
-    // number wraps (a granule 4096 solves old could otherwise pass for a fresh one)
+    // tags = (solve number, phase): granules of an earlier solve never match. A NEW buffer is zeroed (counter included); the number itself is kept and
+    // bumped on the device (res_begin_kernel)
     const size_t had = ctx->ws_res.ptr ? ctx->ws_res.bytes : 0;
     PHIHIP_TRY(ensure_buffer(ctx->ws_res, ctl_off + 256));
-    ctx->res_solve_no = (ctx->res_solve_no + 1) & 0xFFFu;
-    if (ctx->ws_res.bytes != had || ctx->res_solve_no == 0) {
-        PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_res.ptr, 0, ctx->ws_res.bytes, s));
-        if (ctx->res_solve_no == 0) ctx->res_solve_no = 1;
-    }
+    if (ctx->ws_res.bytes != had) PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_res.ptr, 0, ctx->ws_res.bytes, s));
     char* ws = (char*)ctx->ws_res.ptr;
     A.pub = (gran_t*)ws;
     A.part = (gran_t*)(ws + pub_bytes);
     A.abort_flag = (int*)(ws + ctl_off);
-    A.tag_hi = ctx->res_solve_no << 20;
-    PHIHIP_CHECK_HIP(hipMemsetAsync(A.abort_flag, 0, sizeof(int), s));
+    A.solve_ctr = (const unsigned*)(ws + ctl_off + 64);
+    hipLaunchKernelGGL(res_begin_kernel, dim3(1), dim3(kResBlock), 0, s, (unsigned*)(ws + ctl_off + 64), A.abort_flag, (unsigned long long*)ws,
+                       (pub_bytes + part_bytes) / sizeof(gran_t));
     PHIHIP_TRY(ensure_adv_host_public(ctx));
     A.abort_host = ctx->adv_host_dev + 15;
     A.st_out = (CgState*)st_out;
@@ -651,7 +667,20 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x
     const dim3 grid((unsigned)(G * v.batch)), block(kResBlock);
     LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
 #if defined(__HIPCC__)
-    if (vpt == 1) hipLaunchKernelGGL(cg_resident_kernel<1>, grid, block, lds, s, A);
+    // r6: a COOPERATIVE launch -- the runtime checks that the whole grid can be co-resident (fails cleanly otherwise: the caller falls back to the launch
+    // forms) and runs cooperative kernels of a device one after the other, so two resident solves of different streams cannot each hold half of the CUs
+    // and wait for the rest (until r5 co-residency was an assumption about an otherwise idle device, and the solver opt-in for that reason). The kernel itself
+    // is unchanged: granule exchange, no grid barrier. ctx->res_coop = 0 (PHIHIP_RESIDENT_COOP=0): the plain launch.
+    if (ctx->res_coop && (ctx->res_coop_capture || !stream_is_capturing(s))) {
+        void* params[1] = {(void*)&A};
+        const hipError_t e = vpt == 1 ? hipLaunchCooperativeKernel((const void*)cg_resident_kernel<1>, grid, block, params, (unsigned)lds, s)
+                                      : hipLaunchCooperativeKernel((const void*)cg_resident_kernel<2>, grid, block, params, (unsigned)lds, s);
+        if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported) {
+            (void)hipGetLastError();
+            return PHIHIP_ERR_UNSUPPORTED;        // (cg.hip: the launch forms take the solve)
+        }
+        PHIHIP_CHECK_HIP(e);
+    } else if (vpt == 1) hipLaunchKernelGGL(cg_resident_kernel<1>, grid, block, lds, s, A);
     else hipLaunchKernelGGL(cg_resident_kernel<2>, grid, block, lds, s, A);
 #else
     if (vpt == 1) hipemuLaunchResident(cg_resident_kernel<1>, grid, block, lds, s, A);

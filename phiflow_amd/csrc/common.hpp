@@ -198,8 +198,11 @@ struct phihip_ctx {
     int cg1_mode = 1;
     long long cg1_cells = 0;      // 0 = built-in threshold
     // resident solver (cg_resident.hip): 0 = off, 1 = 2-D fp32 'CG' solves of at most resident_cg_cells cells x batch, 2 = whenever applicable
-    unsigned res_solve_no = 0;    // 12-bit solve number in the tags of the resident solver's granules (ws_res)
-    int resident_cg = 0;
+    // r6: ON by default (mode 1) -- the launch is cooperative (co-residency checked by the runtime, cooperative kernels of a device serialised), the solve number
+    // lives on the device (capture-safe), a launch that does not fit falls back to the launch forms
+    int resident_cg = 1;
+    int res_coop = 1;             // launch the resident solver with hipLaunchCooperativeKernel (PHIHIP_RESIDENT_COOP=0: plain launch)
+    int res_coop_capture = 0;     // ... also while the stream is being captured (PHIHIP_RESIDENT_COOP_CAPTURE=1; default: the plain launch as a graph node)
     long long resident_cg_cells = 4LL << 20;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule

@@ -25,11 +25,11 @@ stage_build_id() {
 }
 stage_pytest() {            # pytest[:path or -k expression]   (default: the whole GPU suite)
   local what="${1:-tests}"; local name=$(echo "$what" | tr -c 'A-Za-z0-9' '_')
-  timeout 2400 python -m pytest $what -m gpu -q -p no:cacheprovider > $O/pytest_$name.log 2>&1; echo "pytest [$what] rc=$?"; tail -3 $O/pytest_$name.log
+  eval "timeout 2400 python -m pytest $what -m gpu -q -p no:cacheprovider" > $O/pytest_$name.log 2>&1; echo "pytest [$what] rc=$?"; tail -3 $O/pytest_$name.log
 }
 stage_pytestx() {           # like pytest but stops at the first failure and prints it
   local what="${1:-tests}"; local name=$(echo "$what" | tr -c 'A-Za-z0-9' '_')
-  timeout 2400 python -m pytest $what -m gpu -q -x -p no:cacheprovider > $O/pytest_$name.log 2>&1; echo "pytest -x [$what] rc=$?"; tail -30 $O/pytest_$name.log
+  eval "timeout 2400 python -m pytest $what -m gpu -q -x -p no:cacheprovider" > $O/pytest_$name.log 2>&1; echo "pytest -x [$what] rc=$?"; tail -30 $O/pytest_$name.log
 }
 stage_smoke() {
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
@@ -76,11 +76,24 @@ stage_smoke256() {
     py -c "import json;d=json.loads(open('$O/smoke256_w$W.json').read().strip().splitlines()[-1]);print('smoke256 warmup $W', d['ms_per_step'], d.get('op_ms_profiled_step'), d.get('advect_fallback_last_call'))"
   done
 }
-stage_config4() {
-  for R in 0 2; do
+stage_config4() {           # the launch forms (0), the library default (-1) and "whenever applicable" (2)
+  for R in 0 -1 2; do
     timeout 400 python bench.py --workload config4 --steps 20 --warmup 5 --resident-cg $R > $O/config4_res$R.json 2>> $O/config4.err
     py -c "import json;d=json.loads(open('$O/config4_res$R.json').read().strip().splitlines()[-1]);print('config4 resident $R ms/step', d['ms_per_step'], 'us/it', d.get('us_per_cg_iteration_rank0'))"
   done
+}
+stage_resident() {          # launch forms vs resident solver: the short sweep, then B x 512^2 on one GPU (configs[3]'s sharding story); resident:coop0 = plain launches
+  local env=""; [ "${1:-}" = "coop0" ] && env="PHIHIP_RESIDENT_COOP=0"
+  env $env PHIHIP_SWEEP_SHORT=1 timeout 600 python tools/sweep_resident.py 400 > $O/sweep_resident_${1:-coop}.jsonl 2>> $O/sweep_resident.err
+  env $env PHIHIP_SWEEP_BATCHES=1 timeout 900 python tools/sweep_resident.py 400 > $O/sweep_resident_batches_${1:-coop}.jsonl 2>> $O/sweep_resident.err
+  py - <<PY
+import json
+for f in ('$O/sweep_resident_${1:-coop}.jsonl', '$O/sweep_resident_batches_${1:-coop}.jsonl'):
+    for l in open(f):
+        d = json.loads(l)
+        print(d['res'], 'x', d['batch'], d['bc'], 'launches', d['launches']['us_per_iteration'], 'resident', d['resident']['us_per_iteration'], 'speedup', d['speedup_resident'],
+              'tol ms', d['launches']['tolerance_solve']['ms'], d['resident']['tolerance_solve']['ms'], 'rel', '%.1e' % d['rel_l2_resident_vs_launches'])
+PY
 }
 stage_fuzz() {
   timeout 2400 python tests/fuzz_parity.py --cases ${1:-120} --seed ${FUZZ_SEED:-60000} > $O/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -4 $O/fuzz.txt

@@ -27,8 +27,10 @@ def main():
     ctx = C.Context(lib, 0)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     cases = CASES if not os.environ.get("PHIHIP_SWEEP_SHORT") else [((512, 512), 1), ((512, 512), 8), ((256, 256), 16), ((384, 384), 4)]
+    if os.environ.get("PHIHIP_SWEEP_BATCHES"):      # r6: BASELINE configs[3]'s sharding story in numbers -- B entries of 512^2 on ONE GPU (B = 1 is what each GPU holds when
+        cases = [((512, 512), b) for b in (1, 2, 4, 8, 16, 32, 64)]      # 8 x 512^2 are sharded over 8 GPUs; "resident" = mode 2: falls back to the launch forms where B x 32 workgroups > CUs)
     for res, batch in cases:
-        for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC))[: (1 if os.environ.get("PHIHIP_SWEEP_SHORT") else 2)]:
+        for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC))[: (1 if os.environ.get("PHIHIP_SWEEP_SHORT") or os.environ.get("PHIHIP_SWEEP_BATCHES") else 2)]:
             D = len(res)
             grid = C.make_grid(D, C.PHIHIP_F32, batch, res, (0.0,) * D, tuple(float(n) for n in res), ((bc, bc),) * D)
             rhs = torch.randn(batch, *res, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=torch.float32)
@@ -65,7 +67,7 @@ def main():
             rec["speedup_resident"] = round(rec["launches"]["us_per_iteration"] / rec["resident"]["us_per_iteration"], 3)
             print(json.dumps(rec), flush=True)
             del rhs, x
-    ctx.set_resident_cg(0)
+    ctx.set_resident_cg(1)      # (the library's default since r6)
 
 
 if __name__ == "__main__":
