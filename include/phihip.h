@@ -393,14 +393,18 @@ int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cell
  * iteration (boundary rows + five partial sums through L2); the control logic (tolerances, divergence test, true-residual refresh --
  * phiml's cg loop) runs on the device, the launch ends when its entries have converged, the host never polls. Same
  * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids without cell flags, rows of whole 16-byte vectors up to
- * 512 cells, batch x workgroups <= compute units; everything else (and any stream under capture) keeps the launch-per-iteration kernels.
- * mode 0 (default): never; 1: when cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever applicable.
- * Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14 -> 11, 16 x 256^2 11.5 -> 8, 1 x 512^2 7.8 -> 7.6. Opt-in
- * because the launch has to be resident as a whole: with other streams busy on the device a workgroup may wait for a peer that has not been
- * scheduled; every wait is bounded (~1 s), the solve then fails with PHIHIP_ERR_HIP instead of hanging -- the failing call itself when it
- * asked for `info` (the only case in which the library synchronises with the launch), otherwise the NEXT resident solve of the context.
- * r5: "applicable" asks the occupancy calculator (workgroups per CU x CUs >= batch x workgroups per entry, at most 64 per entry); a solve
- * that does not fit takes the launch forms silently. */
+ * 512 cells, batch x workgroups <= compute units; everything else keeps the launch-per-iteration kernels.
+ * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries with cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever
+ * applicable. Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14.3 -> 10.1, 4 x 512^2 11.4 -> 8.5, 2 x 512^2 9.4 -> 8.1,
+ * 16 x 256^2 11.6 -> 8.4, 4 x 384^2 10.6 -> 8.1; ONE 512^2 entry 7.8 -> 8.3 (hence >= 2 entries in mode 1).
+ * r6: (i) the launch is COOPERATIVE (hipLaunchCooperativeKernel): the runtime checks that the whole grid can be co-resident -- a launch it refuses takes the
+ * launch forms -- and runs the cooperative kernels of a device one after the other, so two resident solves on different streams cannot starve each other
+ * (no measurable cost: 10.0 vs 9.8 us); (ii) the solve number of the exchange's tags lives on the DEVICE and is bumped by a one-workgroup kernel in front
+ * of every launch, so a captured solve is replayable (until r5 the solver was refused under capture); (iii) that made it safe as the default. Every wait is
+ * still bounded (~1 s: e.g. a foreign kernel that occupies CUs for that long): the solve then fails with PHIHIP_ERR_HIP instead of hanging -- the failing
+ * call itself when it asked for `info` (the only case in which the library synchronises with the launch), otherwise the NEXT resident solve of the context.
+ * "Applicable" asks the occupancy calculator (workgroups per CU x CUs >= batch x workgroups per entry, at most 64 per entry). PHIHIP_RESIDENT_CG=0|1|2 in the
+ * environment sets the mode at context creation. */
 int phihip_set_resident_cg(phihip_ctx* ctx, int mode, long long max_cells);
 /* The first CG solve on a (grid, dtype, batch) times the tile / chunk candidates of its three marching kernels on the context's workspace
  * (a few dozen launches, once) and caches the fastest per kernel family; phihip_query_plan reports the result. enable = 0 (or

@@ -869,7 +869,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     // 2-D fp32 grids up to the resident solver's cell limit: ONE launch for the whole solve (cg_resident.hip), r6 by default and under capture too (the solve
     // number of its tags lives on the device: a replay gets a fresh one). A launch the runtime refuses (cooperative launch too large) takes the forms below.
     if (!v.op_custom && ctx->resident_cg > 0 && ctx->small_cg && !std::is_same<T, double>::value && cg_resident_applicable(ctx, v, flags, solve) &&
-        (ctx->resident_cg == 2 || (long long)v.cells * v.batch <= ctx->resident_cg_cells)) {
+        (ctx->resident_cg == 2 || (v.batch >= 2 && (long long)v.cells * v.batch <= ctx->resident_cg_cells))) {      // (mode 1: batches -- one entry gains nothing, 7.8 -> 8.3 us at 512^2)
         const int st = cg_resident_path(ctx, v, rhs, x, solve, info, shift, s);
         if (st != PHIHIP_ERR_UNSUPPORTED) return st;
     }

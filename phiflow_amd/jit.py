@@ -26,9 +26,10 @@ tests/test_gpu_graph.py), `pressure.solve_info` is None and NotConverged / Diver
 enqueues its whole launch budget (entries that converged early freeze on the device), so give it a `max_iterations` that fits the
 problem; grids of <= 16384 cells run the whole solve in ONE kernel with the convergence test on the device and need no such care.
 
-Reproducibility: a replay gives the bits of the eager function (tests/test_jit.py). (r5 shipped with a caveat -- after a fused `torch._foreach_*` launch a replay
-could differ from the eager step in the last bits; r6 traced it to this package: eager passes and a capture could send a sample through different advection kernels
-whose arithmetic differed in rounding. Every path now computes the same bits -- tests/parity_cases.py check_advect_paths_same_bits -- and the caveat is gone.)
+Reproducibility: a replay gives the bits of the eager function (tests/test_jit.py), whatever reach the eager passes adapt to: every advection path computes the same
+bits since r6 (tests/parity_cases.py check_advect_paths_same_bits). One caveat stays, measured and not explained: a fused `torch._foreach_*` launch directly in front
+of a replay is not safe on this ROCm build (rounding-level differences in r5, a GPU memory fault in r6 on a context that had served other grids:
+tools/micro/jit_flaky_probe.py); this wrapper copies its inputs tensor by tensor and launches none.
 
 The function must be a pure function of its arguments (the capture runs it twice -- a warm-up that sizes the workspaces and tunes the
 launch plans, then the capture itself -- and never again). On the CPU emulation device (tests) nothing can be captured: the wrapper then
@@ -45,6 +46,8 @@ import torch
 
 from .field import Field
 
+import os
+_FUSED_COPY = os.environ.get("PHIHIP_JIT_FUSED_COPY", "0") == "1"      # see JitFunction.__call__: NOT safe in front of a replay on this ROCm build (tools/micro/jit_flaky_probe.py)
 _STATE = threading.local()         # per thread: a capture on one thread must not switch another thread's solves to the no-read-back form
 
 
@@ -250,17 +253,20 @@ class JitFunction:
                 variants.append(cap)
             if cap is None:
                 cap = variants[0]
-                # Inputs are copied with ONE fused launch (`torch._foreach_copy_`; per-tensor `copy_` for a single input). Until r5 this was avoided: a replay
-                # behind any fused launch left the eager bits in the last place (profiles/r05_jit_foreach_debug.txt). The cause was in this package after all --
-                # which kernel computed a sample of an advection pass (LDS tile, fix-up list, gather) was policy, the paths did not share one arithmetic, and
-                # eager passes and a capture's fixed reach could take different ones; since r6 every path evaluates the same expressions
-                # (csrc/advect_common.hpp) and all nine variants of tools/micro/jit_foreach_debug.py give the eager bits
-                # (profiles/r06_jit_foreach_debug.txt, tests/test_jit.py).
+                # One copy per tensor, by `copy_`. A fused `torch._foreach_copy_` (one launch, ~3 % faster on the 128^2 plume) is NOT safe in front of a replay on this
+                # ROCm build (PHIHIP_JIT_FUSED_COPY=1 switches it on for experiments). Two separate findings: (i) r5 saw the replay behind a fused launch leave the
+                # eager bits by a rounding-level amount -- r6 removed the library's share of that (which kernel computed a sample of an advection pass was policy and
+                # the paths did not share one arithmetic: csrc/advect_common.hpp; all nine variants of tools/micro/jit_foreach_debug.py then gave the eager bits in a
+                # fresh process, profiles/r06_jit_foreach_debug.txt) and switched the fused copy on; (ii) with it on, a replay on a context that had served other
+                # grids before FAULTED (GPU memory access fault at the first pure replay, tools/micro/jit_flaky_probe.py: every run with the fused copy, no run of
+                # 2 x 24 configurations with per-tensor copies -- profiles/r06_jit_flaky_probe.txt) or, in the test suite, differed from the eager step in the last
+                # bits. A torch-only reproducer was attempted (tools/micro/graph_after_foreach_repro.py). So: per-tensor copies ship.
                 pairs = [(dst, src) for dst, src in zip(cap.inputs, tensors) if dst.data_ptr() != src.data_ptr()]
-                if len(pairs) > 1:
+                if len(pairs) > 1 and _FUSED_COPY:
                     torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
-                elif pairs:
-                    pairs[0][0].copy_(pairs[0][1])
+                else:
+                    for d, s in pairs:
+                        d.copy_(s)
                 self.input_copies += len(pairs)
         cap.graph.replay()
         self.replays += 1

@@ -43,7 +43,7 @@ def resident_arm(ctx, mem, r, seed, bc, emu):
             pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 9))
     finally:
         ctx.profile_enable(False)
-        ctx.set_resident_cg(0)
+        ctx.set_resident_cg(1)          # the library's default since r6
 
 
 def main():

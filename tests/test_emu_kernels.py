@@ -620,7 +620,7 @@ def test_resident_cg_matches_oracle(emu_ctx, res, bc, batch):
             assert pc.rel_l2(pc.demean(out[2][0]), pc.demean(out[0][0])) <= 2e-5
             assert all(pc.rel_l2(a, b_) <= 2e-5 for a, b_ in zip(out[2][2], out[0][2]))
     finally:
-        emu_ctx.set_resident_cg(0)
+        emu_ctx.set_resident_cg(1)          # the library's default since r6
 
 
 @pytest.mark.parametrize("res,bc", [((9, 13), ((CLO, OPN), (PER, PER))), ((5, 6, 11), ((PER, PER), (CLO, OPN), (OPN, CLO))), ((3, 5, 261), ((CLO, CLO), (PER, PER), (PER, PER))), ((2, 4, 257), ((PER, PER), (CLO, OPN), (PER, PER))),

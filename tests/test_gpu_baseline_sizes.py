@@ -80,6 +80,6 @@ def test_config4_batched_smoke_8x512_resident_solver_vs_oracle(ctx, mem):
         assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 3, prof       # one resident launch per projection, no launch-per-iteration kernels
     finally:
         ctx.profile_enable(False)
-        ctx.set_resident_cg(0)
+        ctx.set_resident_cg(1)          # the library's default since r6
     print("config4 parity (resident solver):", rep)
 

@@ -760,7 +760,7 @@ def test_resident_cg(ctx, mem):
         assert out[2][2] <= 2e-4
         assert np.linalg.norm(out[2][3] - out[0][3]) <= 2e-3 * np.linalg.norm(out[0][3])
     finally:
-        ctx.set_resident_cg(0)
+        ctx.set_resident_cg(1)          # the library's default since r6
 
 
 def test_single_reduction_cg_opt_in(ctx, mem):

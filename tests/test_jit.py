@@ -37,6 +37,17 @@ def _same(a, b):
     return all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(_np(fa), _np(fb)))
 
 
+def _diff(a, b):
+    """ which arrays of two states differ, and by how much (assertion messages) """
+    out = []
+    for k, (fa, fb) in enumerate(zip(a, b)):
+        for c, (x, y) in enumerate(zip(_np(fa), _np(fb))):
+            if not np.array_equal(x, y):
+                d = np.abs(x.astype(np.float64) - y.astype(np.float64))
+                out.append(f"field {k} component {c}: {int((d > 0).sum())} of {d.size} differ, max {d.max():.3e} at {np.unravel_index(int(d.argmax()), d.shape)}")
+    return "; ".join(out) or "equal"
+
+
 def test_argument_trees_round_trip(emu_backend):
     v = StaggeredGrid(1.5, PERIODIC, x=8, y=6, backend=emu_backend)
     s = CenteredGrid(2.0, ZERO_GRADIENT, x=8, y=6, backend=emu_backend)
@@ -200,10 +211,14 @@ def _captured_plume(gpu_backend, n, iters):
     state_e, state_j = (v0, s0, None), (v0, s0, None)
     held = []
     for k in range(6):
+        prev_e, prev_j = state_e, state_j
         state_e = step(*state_e, iters=iters)
         state_j = jstep(*state_j, iters=iters)
         held.append((state_j, [a.copy() for f in state_j for a in _np(f)]))
-        assert _same(state_e, state_j), f"step {k}"
+        if not _same(state_e, state_j):      # which side moved? both are repeated from the same inputs
+            again_e, again_j = step(*prev_e, iters=iters), jstep(*prev_j, iters=iters)
+            raise AssertionError(f"step {k}: eager vs replay {_diff(state_e, state_j)} || eager repeated vs eager {_diff(again_e, state_e)} || replay repeated vs replay "
+                                 f"{_diff(again_j, state_j)} || fallback {gpu_backend.ctx.advect_fallback_stats()}")
     # signatures: (v, s, None) and (v, s, p) -- two captures, four replays of the second
     assert jstep.traces == 2 and jstep.replays == 6
     # results are clones: what step k returned is still what it was after later replays
