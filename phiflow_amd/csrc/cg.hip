@@ -144,8 +144,9 @@ int plan_march(const phihip_ctx* ctx, const GridView& v, int mask_batch, bool fl
     } else {
         // candidate order + a small preference factor per family (from the family sweeps): UPDATE / residual favour large tiles
         // at equal chunk length, MATVEC medium tiles and the full-row tile (1, 64)
-        static const int pref_mv[kNumTileConfigs] = {2, 5, 6, 7, 1, 0, 3, 4, 8, 9, 10}, pref_up[kNumTileConfigs] = {4, 3, 6, 2, 7, 1, 0, 5, 10, 9, 8};
-        static const double bonus_mv[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.93, 0.93, 0.9, 0.9, 0.9}, bonus_up[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.98, 0.97, 0.97, 0.9, 0.9, 0.9};
+        static const int pref_mv[kNumTileConfigs] = {2, 5, 6, 7, 1, 0, 3, 4, 8, 9, 10, 11, 12}, pref_up[kNumTileConfigs] = {4, 3, 6, 2, 7, 1, 0, 5, 10, 9, 8, 12, 11};
+        static const double bonus_mv[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.97, 0.93, 0.93, 0.9, 0.9, 0.9, 0.85, 0.85},
+                            bonus_up[kNumTileConfigs] = {1.0, 1.0, 0.99, 0.98, 0.98, 0.98, 0.97, 0.97, 0.9, 0.9, 0.9, 0.85, 0.85};
         // (the row tile is last and discounted in the ANALYTIC plan: it is the first-call autotune that decides for it, on the device)
         const int* pref = mv_like ? pref_mv : pref_up;
         const double* bonus = mv_like ? bonus_mv : bonus_up;

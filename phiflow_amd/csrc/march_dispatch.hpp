@@ -15,9 +15,13 @@ struct TileShape {
 // (1, 128) (r4) is the ROW tile (stencil_march.hpp ROWT): whole rows of 65 ... 128 vectors (fp32 rows of 260 ... 512 cells that are not 256 or
 // 512: 288, 320, 384, 448 ...), floor(256 / lanes per row) thread rows, no halo columns
 // (2, 128), (4, 128): the same with 2 / 4 rows per thread (a 384-cell row leaves two thread rows: 2 own rows per 2 halo rows with one row per thread)
-constexpr int kNumTileConfigs = 11;
+// (2, 256), (4, 256) (r6): the WIDE row tiles -- whole rows of 129 ... 256 vectors (384-cell fp64 rows = 192 lanes; BASELINE configs[4]): ONE thread row, 2 / 4 rows per
+// thread, every lane fetches both halo vectors of its column. fp64 only (fp32 rows of more than 512 cells split into (., 64) tiles of 256 cells without remainder
+// where it matters: 768, 1024).
+constexpr int kNumTileConfigs = 13;
 constexpr int kRowTile = 8;        // ids >= kRowTile are row tiles
-constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}, {1, 128}, {2, 128}, {4, 128}};
+constexpr int kWideRowTile = 11;   // ids >= kWideRowTile are the wide ones
+constexpr TileShape kTileShapes[kNumTileConfigs] = {{1, 16}, {2, 16}, {2, 32}, {4, 32}, {4, 64}, {1, 64}, {2, 64}, {1, 32}, {1, 128}, {2, 128}, {4, 128}, {2, 256}, {4, 256}};
 
 // Elements per thread along the fast axis: 16 bytes when the rows allow (n2 a multiple of 16 B / sizeof(T), 16-byte-aligned buffers); fp32 rows of
 // EVEN length take 8-byte vectors (V = 2: the code path of the fp64 kernels; 250^3, 190^3 ... run 20-37 % slower on the scalar instantiation,
@@ -40,6 +44,7 @@ inline bool march_one_tile(int vec) { return vec == 1 || vec < 0; }            /
 // which tile configurations are instantiated for a vector width: all for 16-byte vectors, (1,64) alone for V = 1 and for the UNAL kernels, the
 // three 64-thread-row tiles (4,64), (1,64), (2,64) for the fp32 V = 2 kernels (128 cells per tile row)
 inline bool march_tile_available(int vec, int esize, int id, int n2) {
+    if (id >= kWideRowTile) return esize == 8 && vec == 2 && n2 % vec == 0 && n2 / vec > 128 && n2 / vec <= 256;
     if (id >= kRowTile) return vec == 16 / esize && n2 % vec == 0 && n2 / vec > 64 && n2 / vec <= 128;
     if (march_one_tile(vec)) return id == 5;
     if (vec == 2 && esize == 4) return id == 4 || id == 5 || id == 6;

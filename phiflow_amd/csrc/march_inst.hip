@@ -111,6 +111,10 @@ int march_occupancy<InstT, kInstDim3>(int id, int vec, int mode, bool flags) {
         case 8: return occupancy_cfg<kVmax, 1, 128, false, true>(mode, flags);
         case 9: return occupancy_cfg<kVmax, 2, 128, false, true>(mode, flags);
         case 10: return occupancy_cfg<kVmax, 4, 128, false, true>(mode, flags);
+#if PHIHIP_INST_F64
+        case 11: return occupancy_cfg<kVmax, 2, 256, false, true>(mode, flags);      // the WIDE row tiles (fp64 rows of 129 ... 256 vectors)
+        case 12: return occupancy_cfg<kVmax, 4, 256, false, true>(mode, flags);
+#endif
         default: return 1;
     }
 }
@@ -158,6 +162,10 @@ int launch_march<InstT, kInstDim3>(const MarchConfig& c, int mode, bool flags, c
         case 8: return launch_cfg<kVmax, 1, 128, false, true>(mode, flags, g, a, grid, s);      // the row tiles (lanes per row: g.tpr_rt)
         case 9: return launch_cfg<kVmax, 2, 128, false, true>(mode, flags, g, a, grid, s);
         case 10: return launch_cfg<kVmax, 4, 128, false, true>(mode, flags, g, a, grid, s);
+#if PHIHIP_INST_F64
+        case 11: return launch_cfg<kVmax, 2, 256, false, true>(mode, flags, g, a, grid, s);
+        case 12: return launch_cfg<kVmax, 4, 256, false, true>(mode, flags, g, a, grid, s);
+#endif
         default:
             set_error("march: bad tile config %d", c.id);
             return PHIHIP_ERR_BAD_ARG;
@@ -217,6 +225,10 @@ int launch_march_multi<InstT, kInstDim3>(const MarchConfig& c, int count, const 
         case 8: return launch_multi_cfg<kVmax, 1, 128, false, true>(m, a, grid, s);
         case 9: return launch_multi_cfg<kVmax, 2, 128, false, true>(m, a, grid, s);
         case 10: return launch_multi_cfg<kVmax, 4, 128, false, true>(m, a, grid, s);
+#if PHIHIP_INST_F64
+        case 11: return launch_multi_cfg<kVmax, 2, 256, false, true>(m, a, grid, s);
+        case 12: return launch_multi_cfg<kVmax, 4, 256, false, true>(m, a, grid, s);
+#endif
         default:
             set_error("march: bad tile config %d", c.id);
             return PHIHIP_ERR_BAD_ARG;

@@ -402,6 +402,9 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
     constexpr int T2c = TPR * V;       // tile columns (axis a2)
     constexpr int LS = T2c + 2 * V;    // LDS row stride; interior starts at column V so vector accesses stay aligned
     constexpr int LROWS = T1c + 2;
+    // WIDE (r6): a row tile whose rows take MORE than half of the workgroup's lanes (129 ... 256 vectors: 384-cell fp64 rows = 192 lanes) -- one thread row, and each
+    // lane fetches BOTH halo-row vectors of its column (the narrower forms give every halo vector a thread of its own: 2 tpr <= 256)
+    constexpr bool WIDE = ROWT && TPR > 128;
     static_assert(ROWT || 2 * TPR + 2 * T1c <= kBlock, "halo items must fit one per thread");
     static_assert(!(ROWT && (UNAL || BIDIR)), "the row tile exists for aligned rows and one marching direction");
     const int tpr = ROWT ? g.tpr_rt : TPR;                      // lanes per row
@@ -550,8 +553,8 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
 
     // ---- halo roles (fixed per thread) ------------------------------------------------------------------------------
     // vector items: rows just below / above the tile; scalar items: columns just left / right of the tile
-    const bool hv_role = tid < 2 * tpr;
-    const int hv_side = tid / tpr, hv_col = tid % tpr;
+    const bool hv_role = WIDE ? tid < tpr : tid < 2 * tpr;
+    const int hv_side = WIDE ? 0 : tid / tpr, hv_col = tid % tpr;
     const int hs_idx = tid - 2 * tpr;
     const bool hs_role = !ROWT && hs_idx >= 0 && hs_idx < 2 * T1;      // (the row tile has no halo columns)
     const int hs_side = hs_idx / T1, hs_row = hs_idx % T1;
@@ -571,6 +574,15 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
         hv_ok = jh2 < n2;
         if (hv_ok && !hv_zero) h_o = jt1 * n2 + jh2;
     }
+    // WIDE: the same lane's second halo vector -- the row just ABOVE the tile (side 1) at its column
+    int h_o2 = 0, hv_lrow2 = 0;
+    bool hv_zero2 = false;
+    if (WIDE && hv_role) {
+        const int jh1 = t1 * T1 + rows_here;
+        hv_lrow2 = rows_here + 1;
+        const int jt1 = nb_index(jh1, n1, g.nb[1][0], g.nb[1][1], hv_zero2);
+        if (hv_ok && !hv_zero2) h_o2 = jt1 * n2 + hv_col * V;
+    }
     if (hs_role) {
         const int jh1 = t1 * T1 + hs_row;
         const int jh2 = hs_side == 0 ? t2 * T2 - 1 : t2 * T2 + cols_here;
@@ -586,12 +598,30 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
     }
     struct HaloRaw {
         VT va, vb, vc;
+        VT va2, vb2, vc2;      // WIDE only
     };
     auto load_halo = [&](int i, HaloRaw& H) {
         const long long poff = base + (long long)i * plane;
         H.va = vec_load_g<T, V, UNAL>(p.a + poff + h_o);
         if (IS_MV) H.vb = vec_load_g<T, V, UNAL>(p.b + poff + h_o);
         if (IS_CG1) H.vc = vec_load_g<T, V, UNAL>(p.c + poff + h_o);
+        if (WIDE) {
+            H.va2 = vec_load_g<T, V, false>(p.a + poff + h_o2);
+            if (IS_MV) H.vb2 = vec_load_g<T, V, false>(p.b + poff + h_o2);
+            if (IS_CG1) H.vc2 = vec_load_g<T, V, false>(p.c + poff + h_o2);
+        }
+    };
+    auto combine_halo2 = [&](const HaloRaw& H, VT& hv2) {      // WIDE: the second halo vector, combined like the first
+        hv2 = H.va2;
+        if (IS_MV) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) hv2.v[v] = fma(beta, H.vb2.v[v], H.va2.v[v]);
+        }
+        if (IS_CG1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) hv2.v[v] = fma(gam, H.vc2.v[v], hv2.v[v]);
+        }
+        if (hv_zero2) hv2 = vec_zero<T, V>();
     };
     auto combine_halo = [&](const HaloRaw& H, VT& hv, T& hs) {
         hv = H.va;
@@ -687,6 +717,8 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
         VT hv_c;
         T hs_c;
         combine_halo(Hn, hv_c, hs_c);
+        VT hv_c2;
+        if (WIDE) combine_halo2(Hn, hv_c2);
         const Extra Ec = En;
         if (has_next) {
             if (DIM3) load_raw(i + 2 * step, Rn_a, Rn_b, Rn_c, zero_n);
@@ -698,6 +730,7 @@ __device__ __forceinline__ void march_body(const MarchGrid& g, const MarchArgs<T
         for (int rr = 0; rr < R; ++rr)
             if (ok[rr]) lds_store<T, V>(L + (lrow0 + rr) * LS + lcol, Sc[rr], odd);
         if (hv_ok) lds_store<T, V>(L + hv_lrow * LS + V + hv_col * V - (hv_odd ? t2 * T2 + hv_col * V + V - n2 : 0), hv_c, hv_odd);
+        if (WIDE && hv_ok) lds_store<T, V>(L + hv_lrow2 * LS + V + hv_col * V, hv_c2, false);
         if (hs_ok) L[(hs_row + 1) * LS + hs_lcol] = hs_c;
         __syncthreads();
 

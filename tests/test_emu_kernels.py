@@ -452,6 +452,42 @@ def test_make_incompressible_matches_oracle_and_is_divergence_free(emu_ctx, res,
     pc.check_make_incompressible(emu_ctx, MEM, dom, grid, dtype, rng)
 
 
+@pytest.mark.parametrize("res,bc", [((4, 9, 264), ((PER, PER), (CLO, OPN), (CLO, OPN))), ((3, 7, 384), ((CLO, CLO), (CLO, CLO), (CLO, CLO))), ((5, 10, 512), ((OPN, OPN), (PER, PER), (PER, PER))),
+                                    ((11, 300), ((CLO, OPN), (OPN, CLO)))])
+def test_wide_row_tiles(emu_ctx, res, bc):
+    """ r6: the WIDE row tiles (ids 11 / 12: fp64 rows of 129 ... 256 vectors -- 132, 192 (BASELINE configs[4]'s 384-cell rows), 256, 150 lanes -- ONE thread
+    row, each lane fetches both halo vectors of its column): the operator, both CG forms across a refresh, cell flags; every boundary rule at the row's ends """
+    dt = np.float64
+    dom, grid = pc.make_case(res, bc, dt, batch=2)
+    try:
+        emu_ctx.set_small_grid_solver(False)
+        for rows in (2, 4):
+            for chunk in (2, 3):
+                emu_ctx.set_tuning(rows, 256, chunk)
+                for flags in (False, True):
+                    plan = emu_ctx.query_plan(grid, flags, 1)
+                    assert plan["tpr"] == 256 and plan["rows"] == rows, plan
+                pc.check_laplace(emu_ctx, MEM, dom, grid, dt, np.random.default_rng(11))
+            for mode in (0, 2):
+                emu_ctx.set_single_reduction_cg(mode)
+                pc.check_cg(emu_ctx, MEM, dom, grid, dt, np.random.default_rng(12), max_iter=9, refresh=4, fixed_iterations=True)
+            emu_ctx.set_single_reduction_cg(0)
+        if all(lo == CLO and hi == CLO for lo, hi in bc):
+            emu_ctx.set_tuning(2, 256, 2)
+            ob = pc.O.BoxObstacle(tuple(0.3 * x for x in res), tuple(0.55 * x for x in res))
+            dom1, grid1 = pc.make_case(res, bc, dt, batch=1, upper=tuple(float(x) for x in res))
+            pc.check_make_incompressible(emu_ctx, MEM, dom1, grid1, dt, np.random.default_rng(13), obstacles=[ob], max_div=1e-4)      # (a 3 x 7 x 384 sliver: the solve stops at its relative tolerance)
+        # fp32 has no wide row tile: a pinned (., 256) falls back to the full-row tile silently
+        dom32, grid32 = pc.make_case(res, bc, np.float32, batch=1)
+        emu_ctx.set_tuning(2, 256, 2)
+        assert emu_ctx.query_plan(grid32, False, 1)["tpr"] != 256
+        pc.check_laplace(emu_ctx, MEM, dom32, grid32, np.float32, np.random.default_rng(11))
+    finally:
+        emu_ctx.set_tuning(0, 0, 0)
+        emu_ctx.set_single_reduction_cg(1)
+        emu_ctx.set_small_grid_solver(True)
+
+
 def test_tile_configurations_agree(emu_ctx):
     """ every tile configuration of the marching kernel computes the same operator """
     rng = np.random.default_rng(10)

@@ -517,6 +517,38 @@ def test_row_tiles_on_the_gpu(ctx, mem, res, bc, dt):
         ctx.set_small_grid_solver(True)
 
 
+@pytest.mark.parametrize("res,bc", [((8, 19, 264), ((PER, PER), (CLO, OPN), (CLO, OPN))), ((40, 36, 384), ((CLO, CLO),) * 3), ((6, 30, 512), ((OPN, OPN), (PER, PER), (PER, PER))),
+                                    ((70, 300), ((CLO, OPN), (OPN, CLO)))])
+def test_wide_row_tiles_on_the_gpu(ctx, mem, res, bc):
+    """ r6: the WIDE row tiles -- fp64 rows of 129 ... 256 vectors as ONE tile row (ids 11 / 12; 384-cell rows of BASELINE configs[4] = 192
+    lanes), no halo columns, both halo vectors of a column fetched by its lane -- pinned with the plan asserted: operator, both CG forms incl. a refresh, flags,
+    a projection around an obstacle. Reference: phi/physics/fluid.py:156-161,165-202. """
+    dt = np.float64
+    dom, grid = pc.make_case(res, bc, dt, batch=2)
+    try:
+        ctx.set_small_grid_solver(False)
+        for rows in (2, 4):
+            for chunk in (2, 7):
+                ctx.set_tuning(rows, 256, chunk)
+                for flags in (False, True):
+                    plan = ctx.query_plan(grid, flags, 1)
+                    assert plan["tpr"] == 256 and plan["rows"] == rows, plan
+                pc.check_laplace(ctx, mem, dom, grid, dt, np.random.default_rng(11))
+            for mode in (0, 2):
+                ctx.set_single_reduction_cg(mode)
+                pc.check_cg(ctx, mem, dom, grid, dt, np.random.default_rng(12), max_iter=9, refresh=4, fixed_iterations=True)
+            ctx.set_single_reduction_cg(0)
+        if all(lo == CLO and hi == CLO for lo, hi in bc):
+            ctx.set_tuning(2, 256, 5)
+            ob = pc.O.BoxObstacle(tuple(0.3 * x for x in res), tuple(0.55 * x for x in res))
+            dom1, grid1 = pc.make_case(res, bc, dt, batch=1, upper=tuple(float(x) for x in res))
+            pc.check_make_incompressible(ctx, mem, dom1, grid1, dt, np.random.default_rng(13), obstacles=[ob])
+    finally:
+        ctx.set_tuning(0, 0, 0)
+        ctx.set_single_reduction_cg(1)
+        ctx.set_small_grid_solver(True)
+
+
 # ---- full-size properties (BASELINE.json sizes; the oracle is too slow there) ----------------------------------------
 def _eigen_rhs(n, dtype):
     """ rhs = lambda_h sin x sin y sin z at cell centres: exact discrete solution p = sin x sin y sin z """

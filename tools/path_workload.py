@@ -267,6 +267,12 @@ def tune_and_time(ctx, dev, group, n):
     iters = 100
     ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 10, 0, 0, 0), want_info=False)       # tunes
     sync(dev)
+    forced = json.loads(os.environ.get("PHIHIP_FORCE_PLANS", "{}") or "{}")      # r6: {"<family>": [rows, tpr, chunk]} -- a tile the autotune did not pick, measured
+    for fam, (rows, tpr, chunk) in forced.items():                               # with the same tooling (the wide row tiles of configs[4])
+        ctx.set_tuning_kernel(int(fam), int(rows), int(tpr), int(chunk))
+    if forced:
+        ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 10, 0, 0, 0), want_info=False)
+        sync(dev)
     x.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
