@@ -62,6 +62,21 @@ __device__ __forceinline__ double frac_part(double x) {
 #endif
 }
 
+// LDS-DMA (advect_tile.hip r5, advect_win.hip r6): HBM / L2 -> LDS without a VGPR round trip. The transfer is inline assembly, invisible to the compiler's wait
+// counters: the caller waits (s_waitcnt vmcnt) and meets at a workgroup barrier before any wavefront reads the landed bytes (MI355X_MICROARCH.md).
+// 16 bytes per lane from `gsrc` (per lane) to LDS at `lds_dst` (wave-uniform) + 16 lane
+template <typename T>
+__device__ __forceinline__ void lds_dma16(const void* gsrc, T* lds_dst, int lane) {
+#ifdef __HIP_DEVICE_COMPILE__
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#else
+    memcpy(reinterpret_cast<char*>(lds_dst) + 16 * lane, gsrc, 16);
+#endif
+}
+
+
 // wrap into [0, n): one conditional +-n covers every shift below n cells; the integer modulo (~25 instructions) stays behind a
 // branch that no wavefront takes at sensible CFL numbers
 __device__ __forceinline__ int wrap_index(int i, int n) {

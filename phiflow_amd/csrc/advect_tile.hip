@@ -554,18 +554,7 @@ struct AdvDma {
     static_assert((size_t)3 * NP * PLANE * sizeof(T) <= 65536, "static LDS limit");
 };
 
-// 16 bytes per lane from `gsrc` (per lane) to LDS at `lds_dst` (wave-uniform) + 16 lane
-template <typename T>
-__device__ __forceinline__ void lds_dma16(const void* gsrc, T* lds_dst, int lane) {
-#ifdef __HIP_DEVICE_COMPILE__
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_dst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#else
-    memcpy(reinterpret_cast<char*>(lds_dst) + 16 * lane, gsrc, 16);
-#endif
-}
-
+// (lds_dma16: advect_common.hpp)
 // GEN (r5, second step): grids with CLOSED / OPEN sides and rows that are not whole vectors (a closed box stores N - 1 faces of the component along its own
 // axis). The ring is still filled by LDS-DMA; what a 16-byte chunk cannot express is settled three ways:
 //   * a chunk (or row, or plane) that lies entirely beyond a CLOSED side is transferred from a small table in global memory that holds every wall constant

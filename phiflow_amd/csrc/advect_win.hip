@@ -18,6 +18,7 @@
 // kernel (same grid, launched right behind) recomputes exactly those workgroups with the gather code of advect.hip -- the result does not
 // depend on the path taken, and a CFL > 1 field is still correct.
 #include <math.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -49,10 +50,16 @@ struct WinSpec<WK_MC_CEN, DIM, H> {                     // windows: the scalar, 
     static constexpr int h(int w, int a) { return w < 2 ? H : ((3 - DIM + w - 2) == a ? 1 : 0); }
 };
 
-template <typename T, int KIND, int DIM, int T1, int H = 1>
+// DMA (r6): the windows are filled by LDS-DMA (global_load_lds_dwordx4, advect_common.hpp lds_dma16) instead of through registers -- the lever that took the
+// self-advection from 0.42 to 0.55 of peak in r5, carried over to these passes. A transfer moves 64 consecutive 16-byte chunks per wavefront instruction to
+// CONSECUTIVE LDS addresses, so every window row is T2 / V + 2 whole chunks (the tile's columns and one chunk either side: the halo columns are its nearest
+// elements) whatever the window's halo along the fast axis; the per-lane SOURCE resolves the row (wrap / clamp) and the chunk (wrap). Scope = regular grids:
+// 3-D, no CLOSED side, the fast axis periodic with rows of whole vectors, 16-byte-aligned arrays.
+template <typename T, int KIND, int DIM, int T1, int H = 1, bool DMA = false>
 struct WinTile {
     using Spec = WinSpec<KIND, DIM, H>;
     static constexpr int NW = Spec::NW;
+    static constexpr int V = 16 / (int)sizeof(T);
     static constexpr int T2 = sizeof(T) == 4 ? 64 : 32;   // tile columns = lanes along the fast axis (256 B rows)
     static constexpr int TY = kBlock / T2;
     static constexpr int S = T1 / TY;                     // tile positions per thread and plane
@@ -60,7 +67,13 @@ struct WinTile {
     static constexpr int h1(int w) { return Spec::h(w, 1); }
     static constexpr int h2(int w) { return Spec::h(w, 2); }
     static constexpr int p1(int w) { return T1 + 2 * h1(w); }
-    static constexpr int p2(int w) { return T2 + 2 * h2(w); }
+    static constexpr int p2(int w) { return DMA ? T2 + 2 * V : T2 + 2 * h2(w); }
+    static constexpr int c2(int w) { return DMA ? V : h2(w); }                    // window column of the tile's column 0
+    static constexpr int nch(int w) { return p1(w) * (p2(w) / V); }               // DMA: 16-byte chunks per plane of window w, in (row, chunk) order
+    static constexpr int ni(int w) { return (nch(w) + kWave - 1) / kWave; }       // DMA: wavefront instructions per plane of window w
+    static constexpr int nitems() { int o = 0; for (int k = 0; k < NW; ++k) o += ni(k); return o; }
+    static constexpr int NITEMS = nitems();                                       // DMA: (window, instruction) items per plane, dealt round-robin to the 4 wavefronts
+    static constexpr int IPW = (NITEMS + kBlock / kWave - 1) / (kBlock / kWave);
     static constexpr int plane(int w) { return p1(w) * p2(w); }
     static constexpr int np(int w) { return DIM == 3 ? 2 * h0(w) + 2 : 1; }       // ring slots: planes p - h0 .. p + h0 in use, one being refilled
     // LDS layout: windows of EQUAL ring depth form a group whose slots are plane-major -- slot t of the group holds plane t of every member,
@@ -75,7 +88,7 @@ struct WinTile {
     static constexpr int kp(int w) { return (p1(w) + TY - 1) / TY; }              // fill passes of a thread per plane
     static constexpr int kpmax() { int m = 0; for (int w = 0; w < NW; ++w) m = kp(w) > m ? kp(w) : m; return m; }
     static constexpr int KP = kpmax();
-    static constexpr int ntail(int w) { return p1(w) * 2 * h2(w); }               // halo columns right of the T2 main columns: one element per thread
+    static constexpr int ntail(int w) { return DMA ? 0 : p1(w) * 2 * h2(w); }     // halo columns right of the T2 main columns: one element per thread
     static constexpr int tail_off(int w) { int o = 0; for (int k = 0; k < w; ++k) o += ntail(k); return o; }
     static constexpr int NTAIL = tail_off(NW);
     static constexpr int h0max() { int m = 0; for (int w = 0; w < NW; ++w) m = h0(w) > m ? h0(w) : m; return m; }
@@ -84,6 +97,7 @@ struct WinTile {
     static_assert(T1 % TY == 0, "tile rows must be a multiple of the thread rows");
     static_assert(NTAIL <= kBlock, "tail elements must fit one per thread");
     static_assert(BYTES <= 80 * 1024, "two workgroups per CU must fit the 160 KB of LDS");
+    static_assert(!DMA || DIM == 3, "the LDS-DMA fill exists for 3-D grids");
 };
 
 // one staged array: where it lives, its stored extent, its padding rule (PHIHIP_BC_PERIODIC wrap / OPEN clamp / CLOSED constant)
@@ -140,9 +154,10 @@ __device__ __forceinline__ double win_clamp(double x, double lo, double hi) { re
 
 // OFFM: bit a = the lower face of axis a is NOT stored (CLOSED lower side): the static offsets of the velocity means depend on it.
 // CONSTS: some window may need constants patched in (a CLOSED side of the velocity or a constant extrapolation of the scalar).
-template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H>
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H, bool DMA = false>
 __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
-    using C = WinTile<T, KIND, DIM, T1, H>;
+    using C = WinTile<T, KIND, DIM, T1, H, DMA>;
+    static_assert(!DMA || (!CONSTS && OFFM == 0), "LDS-DMA fill: regular grids (no CLOSED side)");
     constexpr int A0 = 3 - DIM;
     constexpr int NW = C::NW, T2 = C::T2, TY = C::TY, S = C::S, KP = C::KP;
     constexpr int OFF[3] = {(OFFM >> 0) & 1, (OFFM >> 1) & 1, (OFFM >> 2) & 1};
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
             const int r = ty + s * TY;
             int cen[NW];                    // the sample's in-plane position in every window
 #pragma unroll
-            for (int w = 0; w < NW; ++w) cen[w] = (r + C::h1(w)) * C::p2(w) + tx + C::h2(w);
+            for (int w = 0; w < NW; ++w) cen[w] = (r + C::h1(w)) * C::p2(w) + tx + C::c2(w);
             // static tap: window w at (plane offset d0, row offset d1, column offset d2) from the sample
             auto at = [&](int w, int d0, int d1, int d2) -> T { return lds[pbase[w][d0 + C::H0MAX] + cen[w] + (C::gin(w) + d1 * C::p2(w) + d2)]; };
             if (KIND == WK_MC_STAG) {
@@ -612,7 +627,77 @@ __global__ __launch_bounds__(kBlock, 2) void advect_win_kernel(WinParams<T> P) {
         __syncthreads();
         if (compute) report_plane(p);
     };
-    if (DIM == 3) {
+    if constexpr (DMA) {
+        // ---- r6: the rings filled by LDS-DMA. Items = (window w, instruction k): 64 consecutive chunks of w's plane; item i belongs to wavefront i % 4. Per lane and
+        // item the byte offset of its chunk within a plane is plane-invariant (row wrapped / clamped, chunk wrapped along the periodic fast axis).
+        constexpr int NWAVE = kBlock / kWave;
+        const int lane = tid & (kWave - 1);
+#ifdef __HIP_DEVICE_COMPILE__
+        const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+#else
+        const int wave = tid / kWave;
+#endif
+        unsigned doff[C::IPW];
+#pragma unroll
+        for (int i = 0; i < C::IPW; ++i) doff[i] = 0;
+        {
+            int item = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const WinArray<T>& A = P.arr[w];
+                const int G2 = C::p2(w) / C::V;
+#pragma unroll
+                for (int k = 0; k < C::ni(w); ++k, ++item) {
+                    if ((item % NWAVE) != wave) continue;          // uniform
+                    const int q = k * kWave + lane;
+                    const int rr = q / G2, gg = q - rr * G2;
+                    int j = lo1 - C::h1(w) + rr;
+                    if (A.bc[1][0] == PHIHIP_BC_PERIODIC) j = wrap_index(j, A.n[1]);
+                    j = min(max(j, 0), A.n[1] - 1);                                   // OPEN: zero-gradient padding = the edge row
+                    const int k0 = wrap_index(lo2 - C::V + gg * C::V, A.n[2]);      // periodic fast axis, n2 a multiple of V: a chunk never straddles the seam
+                    doff[item / NWAVE] = (unsigned)(j * A.n[2] + k0) * (unsigned)sizeof(T);
+                }
+            }
+        }
+        // request plane q + h0(w) + 1 of every window (half-step q): its slot held plane q - h0 - 1, whose last readers passed the barrier of half-step q - 1
+        auto feed = [&](int q) {
+            int item = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const WinArray<T>& A = P.arr[w];
+                const int ks = q + C::h0(w) + 1;
+                const bool in_range = ks >= k_lo(w) && ks <= k_hi(w);               // uniform
+                const char* const src = (const char*)(A.p + (long long)b * A.bstride + plane_src(w, ks));
+                T* const dst = lds + C::gbase(w) + slot_of(w, ks) * C::gstride(w) + C::gin(w);
+#pragma unroll
+                for (int k = 0; k < C::ni(w); ++k, ++item) {
+                    if ((item % NWAVE) != wave || !in_range) continue;
+                    if (k * kWave + lane < C::nch(w)) lds_dma16<T>(src + doff[item / NWAVE], dst + k * kWave * C::V, lane);
+                }
+            }
+        };
+        // every wavefront waits until at most `N` of its VMEM operations are in flight -- they retire in issue order, so everything older than the last N
+        // (output stores of this half-step) has landed, the transfers included -- then the workgroup meets (nothing else orders a ds_read behind an LDS-DMA)
+        auto landed_and_barrier = [&](auto n_tag) {
+#ifdef __HIP_DEVICE_COMPILE__
+            constexpr int N = decltype(n_tag)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+#else
+            __syncthreads();
+#endif
+        };
+        for (int q = pb - 2 * C::H0MAX - 1; q < pb; ++q) feed(q);                   // warm-up: planes pb - h0 .. pb + h0 of every window, all in flight at once
+        landed_and_barrier(std::integral_constant<int, 0>{});
+        for (int p = pb; p < pe; ++p) {
+            feed(p);
+            compute_plane(p);
+            // (a half-step issues S x NOUT output stores per wavefront behind its transfers; half of that is assumed -- a wait that is too strong costs a few
+            // cycles, one that is too weak reads a plane that has not landed)
+            landed_and_barrier(std::integral_constant<int, (S * NOUT) / 2>{});
+            report_plane(p);
+        }
+    } else if (DIM == 3) {
         // window w's first staged plane pb - h0 is requested in half-step pb - 2 h0 - 2: 2 H0MAX + 2 warm-up half-steps fill the rings
         int p = pb - 2 * C::H0MAX - 2;
         for (; p < pb; p += 2) {
@@ -766,9 +851,9 @@ struct WinCall {
     int halo, kind;            // reach of the lookups of the centred kinds (1 / 2); AdvKind of the adaptive-reach bookkeeping
 };
 
-template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H>
+template <typename T, int KIND, int DIM, int T1, int OFFM, bool CONSTS, int H, bool DMA = false>
 static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g, const WinCall& call, hipStream_t s) {
-    using C = WinTile<T, KIND, DIM, T1, H>;
+    using C = WinTile<T, KIND, DIM, T1, H, DMA>;
     constexpr int A0 = 3 - DIM;
     WinParams<T> P;
     memset(&P, 0, sizeof(P));
@@ -799,7 +884,8 @@ static int launch_win_inst(phihip_ctx* ctx, const GridView& v, const VelGrid& g,
     }
     P.ch = (T)call.ch;
     const int tiles1 = ceil_div(nmax[1], T1), tiles2 = ceil_div(nmax[2], C::T2);
-    auto kernel = advect_win_kernel<T, KIND, DIM, T1, OFFM, CONSTS, H>;
+    auto kernel = advect_win_kernel<T, KIND, DIM, T1, OFFM, CONSTS, H, DMA>;
+    ctx->adv_last_dma = DMA ? 1 : 0;
     // LDS beyond the 64 KB a kernel gets by default: opt in once per instantiation and device
     static bool attr_set[16] = {false};
     bool& done = attr_set[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0];
@@ -857,6 +943,21 @@ static int launch_win_off(phihip_ctx* ctx, const GridView& v, const VelGrid& g, 
         if (call.sb) consts = consts || call.sb->bc[a][0] == PHIHIP_BC_CLOSED || call.sb->bc[a][1] == PHIHIP_BC_CLOSED;
     }
     if constexpr (OFFM == 0) {
+        if constexpr (DIM == 3 && KIND == WK_MC_STAG) {
+            // r6: regular grids fill the windows by LDS-DMA (WinTile DMA): no CLOSED side, the fast axis periodic with rows of whole 16-byte vectors, aligned arrays
+            // (the forward pass lives in the context's scratch: 256-byte aligned)
+            constexpr int V = 16 / (int)sizeof(T);
+            bool regular = !consts && ctx->adv_dma != 0 && !v.unaligned && v.bc[2][0] == PHIHIP_BC_PERIODIC;
+            for (int c = 0; c < 3; ++c) regular = regular && g.cn[c][2] % V == 0 && ((size_t)call.vel[c] % 16 == 0) && ((size_t)call.fwd[c] % 16 == 0);
+            if (regular) {
+                // (experiment switch PHIHIP_WIN_DMA_ROWS=4: 4-row tiles -- 47 KB of LDS, three workgroups per CU instead of two at 100 VGPRs)
+                static const int rows = [] { const char* e = getenv("PHIHIP_WIN_DMA_ROWS"); return e && e[0] == '4' ? 4 : 8; }();
+                if constexpr (sizeof(T) == 4 && T1 == 8) {
+                    if (rows == 4) return launch_win_inst<T, KIND, DIM, 4, OFFM, false, H, true>(ctx, v, g, call, s);
+                }
+                return launch_win_inst<T, KIND, DIM, T1, OFFM, false, H, true>(ctx, v, g, call, s);
+            }
+        }
         if (!consts) return launch_win_inst<T, KIND, DIM, T1, OFFM, false, H>(ctx, v, g, call, s);
     }
     return launch_win_inst<T, KIND, DIM, T1, OFFM, true, H>(ctx, v, g, call, s);

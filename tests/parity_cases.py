@@ -389,12 +389,14 @@ def check_advect_paths_same_bits(ctx, mem, dom, grid, dtype, rng, s_codes, s_con
             same(outs, f"semi_lagrangian(v, v), {name} field")
             # mac_cormack(v, v): windows (forward pass + correction pass) against the gather kernels
             outs = {}
-            for label, halo in (("windows 1", 1), ("gather", 0)):
+            for label, halo, dma in (("windows 1 / LDS-DMA", 1, 1), ("windows 1 / registers", 1, 0), ("gather", 0, 1)):
                 ctx.set_advect_halo(halo)
+                ctx.set_advect_dma(dma)
                 dout = [mem.empty(a.shape, dtype) for a in vel]
                 ctx.mac_cormack_staggered(grid, pv, pv, [mem.ptr(a) for a in dout], dt, strength)
                 mem.sync()
                 outs[label] = [mem.to_host(a) for a in dout]
+            ctx.set_advect_dma(1)
             same(outs, f"mac_cormack(v, v), {name} field")
             # semi_lagrangian(s, v), mac_cormack(s, v): windows of reach 1 and 2, gather kernels
             for fn, what in ((lambda o: ctx.advect_centered(grid, mem.ptr(ds), s_codes, s_consts, pv, mem.ptr(o), dt), "semi_lagrangian(s, v)"),
@@ -411,6 +413,37 @@ def check_advect_paths_same_bits(ctx, mem, dom, grid, dtype, rng, s_codes, s_con
         ctx.set_advect_dma(1)
         ctx.set_advect_halo(-1)
         ctx.set_advect_windows_2d(False)
+
+
+def check_mac_cormack_staggered_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=True, strength=1.0):
+    """ r6: the correction pass of mac_cormack(v, v) with its six windows filled by LDS-DMA (advect_win.hip WinTile DMA: regular grids) -- against the oracle,
+    against the register-staged windows (the SAME bits) and with the path asserted; gentle (no fix-up), random (fix-up list) and spot fields """
+    v = random_velocity(dom, grid.batch, dtype, rng)
+    fields = [("random", v)] + list(gentle_fields(v, dom, dt, dtype, rng))
+    try:
+        ctx.set_advect_halo(1)
+        for name, vel in fields:
+            dv = [mem.to_dev(a) for a in vel]
+            pv = [mem.ptr(a) for a in dv]
+            ref = O.mac_cormack_staggered(vel, vel, dt, dom, strength)
+            outs = {}
+            for dma in (1, 0):
+                ctx.set_advect_dma(dma)
+                dout = [mem.empty(a.shape, dtype) for a in vel]
+                ctx.mac_cormack_staggered(grid, pv, pv, [mem.ptr(a) for a in dout], dt, strength)
+                mem.sync()
+                ran = ctx.set_advect_dma(-1)
+                assert ran == (bool(dma) and expect_dma), f"LDS-DMA windows ran: {ran} (requested {dma}, grid regular: {expect_dma})"
+                outs[dma] = [mem.to_host(a) for a in dout]
+                if name == "gentle":
+                    assert_no_fallback(ctx, dom, f"mac_cormack(v, v), dma {dma}")
+            for d in range(dom.rank):
+                bad = np.abs(outs[1][d] - ref[d]) > advect_tol(dtype, dom) * max(np.abs(ref[d]).max(), 1e-30)
+                assert bad.mean() <= 2e-3, f"mac_cormack_staggered (LDS-DMA windows) [{d}] {name} field: {bad.mean():.2%} of the samples differ from the oracle"
+                assert np.array_equal(outs[1][d], outs[0][d]), f"mac_cormack_staggered [{d}] {name} field: LDS-DMA and register-staged windows differ"
+    finally:
+        ctx.set_advect_dma(1)
+        ctx.set_advect_halo(-1)
 
 
 def gentle_fields(v, dom, dt, dtype, rng):

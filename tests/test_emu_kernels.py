@@ -156,6 +156,28 @@ def test_self_advection_lds_dma_fill(emu_ctx, res, bc, dma32, dma64):
         pc.check_advect_self_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.1, expect_dma=expect)
 
 
+@pytest.mark.parametrize("res,bc,dma", [
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True),
+    ((6, 20, 72), ((PER, PER), (PER, PER), (PER, PER)), True),        # two tiles along the fast axis (the second partial), three along a1
+    ((13, 11, 24), ((OPN, OPN), (PER, PER), (PER, PER)), True),       # open slow axis: clamped planes, n0 + 1 faces of the a0 component, two chunks
+    ((9, 19, 64), ((PER, PER), (OPN, OPN), (PER, PER)), True),        # open rows: n1 + 1 faces of the a1 component, clamped halo rows, ragged last tile row
+    ((7, 8, 18), ((PER, PER), (PER, PER), (PER, PER)), None),         # rows of 18 cells: fp32 not whole vectors -> register-staged windows; fp64 regular
+    ((6, 10, 64), ((PER, PER), (PER, PER), (OPN, OPN)), False),       # open fast axis: not regular
+    ((6, 10, 64), ((CLO, CLO), (PER, PER), (PER, PER)), False),       # a closed side: constants
+])
+def test_mac_cormack_windows_lds_dma_fill(emu_ctx, res, bc, dma):
+    rng = np.random.default_rng(43)
+    for dtype in (np.float32, np.float64):
+        expect = (dtype == np.float64) if dma is None else dma
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        emu_ctx.set_advect_chunk(5 if res[0] > 8 else 0)
+        try:
+            pc.check_mac_cormack_staggered_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=0.7, expect_dma=expect)
+            pc.check_mac_cormack_staggered_dma(emu_ctx, MEM, dom, grid, dtype, rng, dt=2.1, expect_dma=expect)
+        finally:
+            emu_ctx.set_advect_chunk(0)
+
+
 @pytest.mark.parametrize("res,bc", GRIDS_2D + GRIDS_3D)
 def test_mac_cormack_and_resample_match_oracle(emu_ctx, res, bc):
     """ advect.mac_cormack (centred + staggered) and the centred -> staggered resample used for buoyancy """

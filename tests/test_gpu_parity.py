@@ -467,6 +467,25 @@ def test_advection_paths_give_the_same_bits(ctx, mem, res, bc):
             pc.check_advect_paths_same_bits(ctx, mem, dom, grid, dtype, rng, s_codes, s_consts, dt=dt)
 
 
+@pytest.mark.parametrize("res,bc,dma", [
+    ((8, 12, 16), ((PER, PER), (PER, PER), (PER, PER)), True),
+    ((24, 40, 128), ((PER, PER), (PER, PER), (PER, PER)), True),      # several tiles and chunks
+    ((64, 64, 64), ((PER, PER), (PER, PER), (PER, PER)), True),
+    ((21, 30, 136), ((OPN, OPN), (OPN, OPN), (PER, PER)), True),      # open slow axes (clamped planes and rows), partial tiles on both tiled axes
+    ((12, 16, 72), ((PER, PER), (PER, PER), (OPN, OPN)), False),      # open fast axis
+    ((20, 24, 192), ((CLO, CLO), (PER, PER), (PER, PER)), False),     # a closed side
+])
+def test_mac_cormack_windows_lds_dma_fill(ctx, mem, res, bc, dma):
+    """ r6: the staggered MacCormack correction pass with its six LDS windows filled by global_load_lds_dwordx4 (inline assembly, counted
+    vmcnt waits, raw s_barrier) on regular grids: oracle parity, the SAME bits as the register-staged windows, the path asserted; CFL below and above 1.
+    Reference: phi/physics/advect.py:182-215. """
+    rng = np.random.default_rng(43)
+    for dtype in (np.float32, np.float64):
+        dom, grid = pc.make_case(res, bc, dtype, batch=2)
+        pc.check_mac_cormack_staggered_dma(ctx, mem, dom, grid, dtype, rng, dt=0.7, expect_dma=dma)
+        pc.check_mac_cormack_staggered_dma(ctx, mem, dom, grid, dtype, rng, dt=2.1, expect_dma=dma)
+
+
 def test_cellflags_byte_parallel_kernel(ctx, mem):
     """ r5: phihip_build_cellflags -- byte-parallel kernel (16 / 4 cells per thread) and the scalar kernel -- on random masks with arbitrary non-zero
     bytes against the NumPy restatement of fluid.py:130-137,277-288; sizes that span many workgroups, every boundary kind, per-batch masks """
