@@ -8,6 +8,8 @@
 //   * make_incompressible: the implicit-function adjoint of the linear solve (A is symmetric: one more CG solve with the
 //     same matrix-free operator), divergence and gradient swap roles (G^T = -D with homogeneous boundary values).
 // Every kernel recomputes the forward quantities it needs; nothing is taped on the device.
+#include <stdlib.h>
+
 #include "advect_common.hpp"
 #include "march_dispatch.hpp"
 
@@ -86,8 +88,8 @@ struct TraceOut {
 };
 
 template <typename T, int DIM, int CA, bool STAG>
-__global__ __launch_bounds__(kBlock) void advect_bwd_trace_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ fieldp, CComp3a<T> vel,
-                                                                  const T* __restrict__ gout, T* __restrict__ gfield, TraceOut<T> out, int want_gvel, T dt) {
+__device__ __forceinline__ void advect_bwd_trace_body(const VelGrid& g, const ScalarBc& sb, const T* __restrict__ fieldp, const CComp3a<T>& vel,
+                                                      const T* __restrict__ gout, T* __restrict__ gfield, const TraceOut<T>& out, int want_gvel, T dt) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
     const int b = blockIdx.y;
@@ -127,6 +129,31 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_trace_kernel(VelGrid g, Sca
     }
 }
 
+template <typename T, int DIM, int CA, bool STAG>
+__global__ __launch_bounds__(kBlock) void advect_bwd_trace_kernel(VelGrid g, ScalarBc sb, const T* __restrict__ fieldp, CComp3a<T> vel,
+                                                                  const T* __restrict__ gout, T* __restrict__ gfield, TraceOut<T> out, int want_gvel, T dt) {
+    advect_bwd_trace_body<T, DIM, CA, STAG>(g, sb, fieldp, vel, gout, gfield, out, want_gvel, dt);
+}
+
+// r6: ALL staggered components in one launch (blockIdx.z = component - first axis; every component has its own record array, so pass B runs once for all as well).
+// The body is the per-component one: same arithmetic, same bits.
+template <typename T>
+struct TraceAll {
+    const T* f[3];
+    const T* gout[3];
+    T* gfield[3];
+    TraceOut<T> out[3];
+};
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void advect_bwd_trace_all_kernel(VelGrid g, CComp3a<T> vel, TraceAll<T> a, int want_gvel, T dt) {
+    const ScalarBc none{};                                   // (staggered samples take their rule from the grid)
+    const int ca = (3 - DIM) + (int)blockIdx.z;
+    if (ca == 0) advect_bwd_trace_body<T, DIM, 0, true>(g, none, a.f[0], vel, a.gout[0], a.gfield[0], a.out[0], want_gvel, dt);
+    else if (ca == 1) advect_bwd_trace_body<T, DIM, 1, true>(g, none, a.f[1], vel, a.gout[1], a.gfield[1], a.out[1], want_gvel, dt);
+    else advect_bwd_trace_body<T, DIM, 2, true>(g, none, a.f[2], vel, a.gout[2], a.gfield[2], a.out[2], want_gvel, dt);
+}
+
 // ---- pass B ---------------------------------------------------------------------------------------------------------------
 constexpr int kGatherT1 = 8, kGatherT2 = 32;
 template <typename T, int DIM> constexpr int gather_t0() { return DIM == 3 ? (sizeof(T) == 4 ? 4 : 2) : 1; }
@@ -154,11 +181,10 @@ template <typename T>
 __device__ __forceinline__ T hat(T x) { return fmax(T(0), T(1) - fabs(x)); }
 
 template <typename T, int DIM>
-__global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0, int n1, int n2, ScalarBc rule, TraceOut<T> in, T* __restrict__ gfield,
-                                                                         int nb1, int nb2) {
+__device__ __forceinline__ void advect_bwd_field_gather_body(GatherSlot<T>* slots, int n0, int n1, int n2, const ScalarBc& rule, const GatherSlot<T>* __restrict__ in_rec,
+                                                             T* __restrict__ gfield, int nb1, int nb2) {
     constexpr int T0 = gather_t0<T, DIM>(), T1 = kGatherT1, T2 = kGatherT2;
     constexpr int E0 = DIM == 3 ? T0 + 2 : 1, E1 = T1 + 2, E2 = T2 + 2;
-    __shared__ GatherSlot<T> slots[E0 * E1 * E2];
     const int b = blockIdx.y;
     const long long total = (long long)n0 * n1 * n2;
     const long long base = (long long)b * total;
@@ -183,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0,
             ok = gather_slot<T>(g1 - 1 + l1, n1, rule.bc[1][0], rule.bc[1][1], s1, h1) && ok;
             ok = gather_slot<T>(g2 - 1 + l2, n2, rule.bc[2][0], rule.bc[2][1], s2, h2) && ok;
         }
-        rec[it] = in.rec[ok ? base + ((long long)s0 * n1 + s1) * n2 + s2 : base];
+        rec[it] = in_rec[ok ? base + ((long long)s0 * n1 + s1) * n2 + s2 : base];
         sh[it][0] = h0; sh[it][1] = h1; sh[it][2] = h2;
         okv[it] = ok;
     }
@@ -236,6 +262,35 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0,
     }
 }
 
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_kernel(int n0, int n1, int n2, ScalarBc rule, TraceOut<T> in, T* __restrict__ gfield,
+                                                                         int nb1, int nb2) {
+    __shared__ GatherSlot<T> slots[gather_cells<T, DIM>()];
+    advect_bwd_field_gather_body<T, DIM>(slots, n0, n1, n2, rule, in.rec, gfield, nb1, nb2);
+}
+
+// r6: the record arrays of ALL staggered components in one launch (blockIdx.z = component - first axis); a component with fewer tiles than the launch's
+// blockIdx.x range lets the surplus workgroups return before the barrier
+template <typename T>
+struct GatherAll {
+    int n[3][3];
+    int bc[3][3][2];
+    int nb1[3], nb2[3], blocks[3];
+    const GatherSlot<T>* rec[3];
+    T* gfield[3];
+};
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void advect_bwd_field_gather_all_kernel(GatherAll<T> a) {
+    __shared__ GatherSlot<T> slots[gather_cells<T, DIM>()];
+    const int ca = (3 - DIM) + (int)blockIdx.z;
+    if ((int)blockIdx.x >= a.blocks[ca] || a.gfield[ca] == nullptr) return;
+    ScalarBc rule{};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { rule.bc[ax][0] = a.bc[ca][ax][0]; rule.bc[ax][1] = a.bc[ca][ax][1]; }
+    advect_bwd_field_gather_body<T, DIM>(slots, a.n[ca][0], a.n[ca][1], a.n[ca][2], rule, a.rec[ca], a.gfield[ca], a.nb1[ca], a.nb2[ca]);
+}
+
 // ---- pass C ---------------------------------------------------------------------------------------------------------------
 // One axis of a transposed pair stencil. Forward: the source at index q reads the taps (q + d, q + d + 1) of an array of n_t samples under the
 // boundary codes of the axis (d = off - 1: the cell pair (m - 1, m) of a face; d = -off: the face pair (s, s + 1)). Transposed: target j receives
@@ -277,7 +332,7 @@ struct DuIn {
 };
 
 template <typename T, int DIM, int CB, bool STAG>
-__global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelGrid g, DuIn<T> du, T* __restrict__ gvel) {
+__device__ __forceinline__ void advect_bwd_velocity_gather_body(const VelGrid& g, const DuIn<T>& du, T* __restrict__ gvel) {
     constexpr int A0 = 3 - DIM;
     constexpr int cb = CB;
     const int b = blockIdx.y;
@@ -367,6 +422,26 @@ __global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelG
     }
 }
 
+template <typename T, int DIM, int CB, bool STAG>
+__global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_kernel(VelGrid g, DuIn<T> du, T* __restrict__ gvel) {
+    advect_bwd_velocity_gather_body<T, DIM, CB, STAG>(g, du, gvel);
+}
+
+// r6: every velocity component in one launch (blockIdx.z = component - first axis)
+template <typename T>
+struct DuAll {
+    DuIn<T> in[3];
+    T* gvel[3];
+};
+
+template <typename T, int DIM, bool STAG>
+__global__ __launch_bounds__(kBlock) void advect_bwd_velocity_gather_all_kernel(VelGrid g, DuAll<T> a) {
+    const int cb = (3 - DIM) + (int)blockIdx.z;
+    if (cb == 0) advect_bwd_velocity_gather_body<T, DIM, 0, STAG>(g, a.in[0], a.gvel[0]);
+    else if (cb == 1) advect_bwd_velocity_gather_body<T, DIM, 1, STAG>(g, a.in[1], a.gvel[1]);
+    else advect_bwd_velocity_gather_body<T, DIM, 2, STAG>(g, a.in[2], a.gvel[2]);
+}
+
 // adjoint of centered_to_staggered_kernel (face = 0.5 * scale * (cell left + cell right)) as a gather: every cell sums the faces whose pair
 // (phys - 1, phys) resolves to it under the scalar's extrapolation -- the transposed pair stencil of pass C, all components in one launch
 template <typename T>
@@ -431,10 +506,10 @@ __device__ __forceinline__ void gather_minmax_arg(const T* __restrict__ F, const
 // to the field and the velocity), g_field (own value / the extremal tap when clamped) and g_velocity (forward lookup).
 // STAG: staggered component CA (limiter lookup in the cell frame like the forward pass); else centred scalar.
 template <typename T, int DIM, int CA, bool STAG>
-__global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield,
-                                                                 CComp3a<T> vel, const T* __restrict__ fwd, const T* __restrict__ gout,
-                                                                 T* __restrict__ gfwd, T* __restrict__ gfield, TraceOut<T> out, int want_gvel,
-                                                                 T dt, T ch) {
+__device__ __forceinline__ void mac_cormack_bwd_body(const VelGrid& g, const ScalarBc& sb, const CComp3a<T>& field, const T* __restrict__ sfield,
+                                                     const CComp3a<T>& vel, const T* __restrict__ fwd, const T* __restrict__ gout,
+                                                     T* __restrict__ gfwd, T* __restrict__ gfield, const TraceOut<T>& out, int want_gvel,
+                                                     T dt, T ch) {
     constexpr int A0 = 3 - DIM;
     constexpr int ca = CA;
     const int b = blockIdx.y;
@@ -503,6 +578,39 @@ __global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, Scal
     }
 }
 
+template <typename T, int DIM, int CA, bool STAG>
+__global__ __launch_bounds__(kBlock) void mac_cormack_bwd_kernel(VelGrid g, ScalarBc sb, CComp3a<T> field, const T* __restrict__ sfield,
+                                                                 CComp3a<T> vel, const T* __restrict__ fwd, const T* __restrict__ gout,
+                                                                 T* __restrict__ gfwd, T* __restrict__ gfield, TraceOut<T> out, int want_gvel,
+                                                                 T dt, T ch) {
+    mac_cormack_bwd_body<T, DIM, CA, STAG>(g, sb, field, sfield, vel, fwd, gout, gfwd, gfield, out, want_gvel, dt, ch);
+}
+
+// r6: the correction pass's adjoint for ALL staggered components in one launch (blockIdx.z = component - first axis; per-component record arrays)
+template <typename T>
+struct McAll {
+    const T* fwd[3];
+    const T* gout[3];
+    T* gfwd[3];
+    T* gfield[3];
+    TraceOut<T> out[3];
+};
+
+template <typename T, int DIM>
+__global__ __launch_bounds__(kBlock) void mac_cormack_bwd_all_kernel(VelGrid g, CComp3a<T> field, CComp3a<T> vel, McAll<T> a, int want_gvel, T dt, T ch) {
+    const ScalarBc none{};
+    const int ca = (3 - DIM) + (int)blockIdx.z;
+    if (ca == 0) mac_cormack_bwd_body<T, DIM, 0, true>(g, none, field, (const T*)nullptr, vel, a.fwd[0], a.gout[0], a.gfwd[0], a.gfield[0], a.out[0], want_gvel, dt, ch);
+    else if (ca == 1) mac_cormack_bwd_body<T, DIM, 1, true>(g, none, field, (const T*)nullptr, vel, a.fwd[1], a.gout[1], a.gfwd[1], a.gfield[1], a.out[1], want_gvel, dt, ch);
+    else mac_cormack_bwd_body<T, DIM, 2, true>(g, none, field, (const T*)nullptr, vel, a.fwd[2], a.gout[2], a.gfwd[2], a.gfield[2], a.out[2], want_gvel, dt, ch);
+}
+
+// r6: the staggered adjoints run ALL components per launch (three launches per call instead of nine); PHIHIP_ADJOINT_ALL=0 = one launch per component (A/B, tests)
+static inline bool adjoint_all_components() {
+    static const bool on = [] { const char* e = getenv("PHIHIP_ADJOINT_ALL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static inline int bwd_blocks(long long total) {
     const long long nb = (total + kBlock - 1) / kBlock;
     return (int)(nb < 65536 ? nb : 65536);
@@ -510,11 +618,12 @@ static inline int bwd_blocks(long long total) {
 
 // scratch of the gather-form adjoints: [cx0 | cx1 | cx2 | gw] of one sample array at a time + the du arrays of every source (9 staggered, 3 centred)
 template <typename T>
-static int adjoint_scratch(phihip_ctx* ctx, size_t max_samples, int batch, int n_du, T* trace[4], T* du[9]) {
+static int adjoint_scratch(phihip_ctx* ctx, size_t max_samples, int batch, int n_du, T* trace[4], T* du[9], int n_rec = 1, GatherSlot<T>** recs = nullptr) {
     const size_t slot = (((size_t)batch * max_samples * sizeof(T) + 255) / 256) * 256;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_adj_g, slot * (4 + n_du)));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_adj_g, slot * (4 * n_rec + n_du)));
     for (int k = 0; k < 4; ++k) trace[k] = (T*)((char*)ctx->ws_adj_g.ptr + slot * k);
-    for (int k = 0; k < 9; ++k) du[k] = k < n_du ? (T*)((char*)ctx->ws_adj_g.ptr + slot * (4 + k)) : nullptr;
+    for (int k = 0; k < n_rec && recs; ++k) recs[k] = (GatherSlot<T>*)((char*)ctx->ws_adj_g.ptr + slot * 4 * k);      // (the four words of a record array are contiguous)
+    for (int k = 0; k < 9; ++k) du[k] = k < n_du ? (T*)((char*)ctx->ws_adj_g.ptr + slot * (4 * n_rec + k)) : nullptr;
     return PHIHIP_OK;
 }
 
@@ -530,8 +639,36 @@ static void launch_field_gather(const int n[3], const int bc[3][2], int batch, c
 }
 
 // pass C for every velocity component: du[3 ca + cb] = source component ca (staggered samples) resp. du[cb] (cell samples)
+template <typename T, int DIM>
+static void launch_field_gather_all(const GridView& v, GatherSlot<T>* const recs[3], void* const gfield[3], hipStream_t s) {
+    GatherAll<T> a;
+    memset(&a, 0, sizeof(a));
+    int blocks = 0;
+    for (int ca = v.ax0; ca < 3; ++ca) {
+        const int* n = v.cn[ca];
+        for (int ax = 0; ax < 3; ++ax) { a.n[ca][ax] = n[ax]; a.bc[ca][ax][0] = v.bc[ax][0]; a.bc[ca][ax][1] = v.bc[ax][1]; }
+        a.nb2[ca] = ceil_div(n[2], kGatherT2); a.nb1[ca] = ceil_div(n[1], kGatherT1);
+        a.blocks[ca] = (DIM == 3 ? ceil_div(n[0], gather_t0<T, DIM>()) : 1) * a.nb1[ca] * a.nb2[ca];
+        a.rec[ca] = recs[ca - v.ax0]; a.gfield[ca] = gfield ? (T*)gfield[ca] : nullptr;
+        blocks = a.blocks[ca] > blocks ? a.blocks[ca] : blocks;
+    }
+    hipLaunchKernelGGL((advect_bwd_field_gather_all_kernel<T, DIM>), dim3((unsigned)blocks, v.batch, DIM), dim3(kBlock), 0, s, a);
+}
+
 template <typename T, int DIM, bool STAG>
 static void launch_velocity_gathers(const GridView& v, const VelGrid& g, T* const du[9], void* const gv[3], hipStream_t s) {
+    if (adjoint_all_components()) {
+        DuAll<T> a;
+        memset(&a, 0, sizeof(a));
+        long long most = 0;
+        for (int cb = v.ax0; cb < 3; ++cb) {
+            a.in[cb] = DuIn<T>{{STAG ? du[0 + cb] : du[cb], STAG ? du[3 + cb] : nullptr, STAG ? du[6 + cb] : nullptr}};
+            a.gvel[cb] = (T*)gv[cb];
+            most = v.ccells[cb] > most ? v.ccells[cb] : most;
+        }
+        hipLaunchKernelGGL((advect_bwd_velocity_gather_all_kernel<T, DIM, STAG>), dim3(bwd_blocks(most), v.batch, DIM), dim3(kBlock), 0, s, g, a);
+        return;
+    }
     for (int cb = v.ax0; cb < 3; ++cb) {
         DuIn<T> in{{STAG ? du[0 + cb] : du[cb], STAG ? du[3 + cb] : nullptr, STAG ? du[6 + cb] : nullptr}};
         const dim3 grid(bwd_blocks(v.ccells[cb]), v.batch);
@@ -547,10 +684,26 @@ static int advect_staggered_bwd_t(phihip_ctx* ctx, const GridView& v, const VelG
     size_t max_samples = 0;
     for (int ca = v.ax0; ca < 3; ++ca) max_samples = (size_t)v.ccells[ca] > max_samples ? (size_t)v.ccells[ca] : max_samples;
     T *trace[4], *du[9];
-    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du));
+    GatherSlot<T>* recs[3] = {nullptr, nullptr, nullptr};
+    const bool all = adjoint_all_components();
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du, all ? DIM : 1, recs));
     CComp3a<T> vv{{(const T*)vel[0], (const T*)vel[1], (const T*)vel[2]}};
     ScalarBc none;
     memset(&none, 0, sizeof(none));
+    if (all) {          // r6: pass A for all components, pass B for all components, pass C for all components -- three launches instead of nine
+        TraceAll<T> a;
+        memset(&a, 0, sizeof(a));
+        long long most = 0;
+        for (int ca = v.ax0; ca < 3; ++ca) {
+            a.f[ca] = (const T*)f[ca]; a.gout[ca] = (const T*)gout[ca]; a.gfield[ca] = gf ? (T*)gf[ca] : nullptr;
+            a.out[ca] = TraceOut<T>{recs[ca - v.ax0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
+            most = v.ccells[ca] > most ? v.ccells[ca] : most;
+        }
+        hipLaunchKernelGGL((advect_bwd_trace_all_kernel<T, DIM>), dim3(bwd_blocks(most), v.batch, DIM), dim3(kBlock), 0, s, g, vv, a, gv ? 1 : 0, (T)dt);
+        if (gf) launch_field_gather_all<T, DIM>(v, recs, gf, s);
+        if (gv) launch_velocity_gathers<T, DIM, true>(v, g, du, gv, s);
+        return PHIHIP_OK;
+    }
     for (int ca = v.ax0; ca < 3; ++ca) {
         TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};      // (the four trace slots are contiguous)
         const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);
@@ -641,7 +794,23 @@ static int launch_mc_staggered_bwd(phihip_ctx* ctx, const GridView& v, const Vel
     size_t max_samples = 0;
     for (int ca = v.ax0; ca < 3; ++ca) max_samples = (size_t)v.ccells[ca] > max_samples ? (size_t)v.ccells[ca] : max_samples;
     T *trace[4], *du[9];
-    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du));
+    GatherSlot<T>* recs[3] = {nullptr, nullptr, nullptr};
+    const bool all = adjoint_all_components();
+    PHIHIP_TRY(adjoint_scratch<T>(ctx, max_samples, v.batch, gv ? 9 : 0, trace, du, all ? DIM : 1, recs));
+    if (all) {
+        McAll<T> a;
+        memset(&a, 0, sizeof(a));
+        long long most = 0;
+        for (int ca = v.ax0; ca < 3; ++ca) {
+            a.fwd[ca] = (const T*)fwd[ca]; a.gout[ca] = (const T*)gout[ca]; a.gfwd[ca] = (T*)gfwd[ca]; a.gfield[ca] = (T*)gf[ca];
+            a.out[ca] = TraceOut<T>{recs[ca - v.ax0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
+            most = v.ccells[ca] > most ? v.ccells[ca] : most;
+        }
+        hipLaunchKernelGGL((mac_cormack_bwd_all_kernel<T, DIM>), dim3(bwd_blocks(most), v.batch, DIM), dim3(kBlock), 0, s, g, ff, vv, a, want, (T)dt, (T)ch);
+        launch_field_gather_all<T, DIM>(v, recs, gfwd, s);                                   // the forward lookup's taps -> g_fwd
+        if (gv) launch_velocity_gathers<T, DIM, true>(v, g, du, gv, s);
+        return PHIHIP_OK;
+    }
     for (int ca = v.ax0; ca < 3; ++ca) {
         TraceOut<T> tr{(GatherSlot<T>*)trace[0], {du[3 * ca], du[3 * ca + 1], du[3 * ca + 2]}};
         const dim3 grid(bwd_blocks(v.ccells[ca]), v.batch);

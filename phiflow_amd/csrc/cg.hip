@@ -466,6 +466,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
     PHIHIP_CHECK_HIP(hipEventCreate(&e0));
     PHIHIP_CHECK_HIP(hipEventCreate(&e1));
     int status = PHIHIP_OK;
+    if (getenv("PHIHIP_AUTOTUNE_LOG")) fprintf(stderr, "[phihip autotune] grid %d x %d x %d batch %d flags %d mask_batch %d\n", v.n[0], v.n[1], v.n[2], v.batch, (int)has_flags, mask_batch);
     struct Pick { int id, chunk; float us, us_model; };
     Pick model_pick[FAM_COUNT], tuned_pick[FAM_COUNT];
     std::vector<Pick> challengers[FAM_COUNT];
