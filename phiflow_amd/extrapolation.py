@@ -214,4 +214,8 @@ def pressure_extrapolation(vext: Extrapolation, dims: Sequence[str]) -> Extrapol
         if isinstance(e, _Boundary):
             return ZERO
         return BOUNDARY
-    return _Mixed({d: (conv(vext.side(d, False)), conv(vext.side(d, True))) for d in dims})
+    cache = vext.__dict__.setdefault('_pressure_ext', {})       # (extrapolations are immutable: one result object per velocity boundary, so `resolve` of it is cached too)
+    key = tuple(dims)
+    if key not in cache:
+        cache[key] = _Mixed({d: (conv(vext.side(d, False)), conv(vext.side(d, True))) for d in dims})
+    return cache[key]

@@ -28,6 +28,9 @@ def _torch_dtype_code(dtype: torch.dtype) -> int:
     raise TypeError(f"unsupported dtype {dtype}; the HIP backend computes in float32 or float64")
 
 
+_GRID_CACHE = {}      # (id of the resolved boundary codes, dtype, batch, resolution, lower, upper) -> (phihip_grid, codes): Field.grid_struct
+
+
 class Field:
     """ A sampled scalar (centred) or vector (staggered) grid field with boundary conditions. """
     __array_ufunc__ = None     # `numpy_array * field` defers to Field.__rmul__ (a batch vector, one number per batch entry)
@@ -41,6 +44,7 @@ class Field:
         assert vector_scale is None or (not staggered and len(vector_scale) == len(resolution))
         self.vector_scale = [float(c) for c in vector_scale] if vector_scale is not None else None
         self.resolution = dict(resolution)
+        self._dims = tuple(self.resolution)
         self.bounds = bounds
         self.boundary = boundary
         self.values = values           # Tensor (centred) or List[Tensor] (staggered)
@@ -52,7 +56,7 @@ class Field:
     # --- geometry -------------------------------------------------------------------------------------------------
     @property
     def dims(self) -> Tuple[str, ...]:
-        return tuple(self.resolution.keys())
+        return self._dims
 
     @property
     def spatial_rank(self) -> int:
@@ -93,8 +97,18 @@ class Field:
 
     def grid_struct(self, batch: Optional[int] = None, dtype: Optional[torch.dtype] = None) -> _capi.Grid:
         """ the `phihip_grid` descriptor of this field's grid + boundary """
-        return _capi.make_grid(self.spatial_rank, _torch_dtype_code(dtype or self.dtype), batch or self.batch_size,
-                               list(self.resolution.values()), self.bounds.lower, self.bounds.upper, self._codes, self._bc_val)
+        # r6: the descriptor is built once per (grid, boundary, dtype, batch) and reused by every Field on it (an eager 128^2 plume step built four per step,
+        # 13 us each, out of ~0.2 ms of host work; nothing mutates a Grid after make_grid). `_codes` is the list cached on the extrapolation object (resolve).
+        key = (id(self._codes), _torch_dtype_code(dtype or self.dtype), batch or self.batch_size, tuple(self.resolution.values()),
+               tuple(self.bounds.lower), tuple(self.bounds.upper))
+        hit = _GRID_CACHE.get(key)
+        if hit is not None and hit[1] is self._codes:
+            return hit[0]
+        g = _capi.make_grid(self.spatial_rank, key[1], key[2], key[3], key[4], key[5], self._codes, self._bc_val)
+        if len(_GRID_CACHE) >= 512:
+            _GRID_CACHE.clear()
+        _GRID_CACHE[key] = (g, self._codes)
+        return g
 
     # --- access ---------------------------------------------------------------------------------------------------
     def numpy(self):
