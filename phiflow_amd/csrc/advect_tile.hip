@@ -995,6 +995,7 @@ static int launch_tile_consts(phihip_ctx* ctx, const GridView& v, const VelGrid&
         if (it != ctx->adv_tuned.end()) {
             chunk = it->second;
         } else {
+            SlowTrace tr("advect_self_tiled: first-call chunk timing");
             hipEvent_t e0, e1;
             PHIHIP_CHECK_HIP(hipEventCreate(&e0));
             PHIHIP_CHECK_HIP(hipEventCreate(&e1));

@@ -150,6 +150,7 @@ int adv_choose(phihip_ctx* ctx, int kind, bool has_wide, long long grid_fp, hipS
     }
     bool resolved = false;
     if (P.pending && !capturing && P.age >= kAdvMaxLag) {
+        SlowTrace tr("adv_choose: hipEventSynchronize on the observed pass");
         PHIHIP_CHECK_HIP(hipEventSynchronize(P.ev));
         resolved = true;
     }
@@ -200,7 +201,9 @@ int prepare_fixlist(phihip_ctx* ctx, long long units, hipStream_t s, FixList* li
     // (a reallocation is recognised by the SIZE: an allocator may well hand the freed address out again, with its own bookkeeping in the
     // first bytes -- glibc does under the emulation -- and a stale count would send the fix-up launch over `cap` garbage entries)
     const size_t had = ctx->ws_adv_flags.ptr ? ctx->ws_adv_flags.bytes : 0;
+    SlowTrace tr("prepare_fixlist: ensure_buffer");
     PHIHIP_TRY(ensure_buffer(ctx->ws_adv_flags, bytes));
+    tr.done();
     if (ctx->ws_adv_flags.bytes != had || !ctx->adv_ctl_clear) {        // a fresh buffer: the control block starts at zero (the fix-up launch keeps it so)
         PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_adv_flags.ptr, 0, 64, s));
         ctx->adv_ctl_clear = true;
@@ -393,6 +396,7 @@ int phihip_component_shape(const phihip_grid* grid, int comp, int32_t shape[3]) 
 
 int phihip_advect_staggered(phihip_ctx* ctx, const phihip_grid* grid, const void* const field[3], const void* const velocity[3],
                             void* const out[3], double dt, void* stream) {
+    SlowTrace whole("phihip_advect_staggered (whole call)");
     PHIHIP_ENTER(ctx, grid);
     PHIHIP_TRY(check_ptrs(v, field, "field"));
     PHIHIP_TRY(check_ptrs(v, velocity, "velocity"));

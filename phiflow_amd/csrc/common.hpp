@@ -1,6 +1,9 @@
 // common.hpp -- context, error reporting, launch + profiling helpers of libphihip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -252,6 +255,22 @@ struct LaunchScope {
 };
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// PHIHIP_TRACE_SLOW=<ms>: host-side sections that block longer than that many milliseconds report themselves on stderr (where does a call stall?)
+struct SlowTrace {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    bool open = true;
+    static double limit_ms() { static const double l = [] { const char* e = getenv("PHIHIP_TRACE_SLOW"); return e ? atof(e) : -1.0; }(); return l; }
+    explicit SlowTrace(const char* w) : what(w) { if (limit_ms() >= 0) t0 = std::chrono::steady_clock::now(); }
+    void done() {
+        if (!open || limit_ms() < 0) return;
+        open = false;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > limit_ms()) fprintf(stderr, "[phihip slow] %s: %.2f ms\n", what, ms);
+    }
+    ~SlowTrace() { done(); }
+};
 
 // work list of the LDS-staged advection kernels' fix-up pass (device side: advect_common.hpp)
 struct FixItem {

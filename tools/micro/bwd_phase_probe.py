@@ -28,7 +28,7 @@ grad = functional_gradient(simulate, wrt=[0], get_output=True)
 # wall time of every C-ABI call (no extra synchronisation): which call of a slow step blocks?
 from phiflow_amd import _capi as C   # noqa
 CALLS = []
-for name in [m for m in dir(C.Context) if not m.startswith("_") and callable(getattr(C.Context, m))]:
+for name in ([m for m in dir(C.Context) if not m.startswith("_") and callable(getattr(C.Context, m))] if os.environ.get("PROBE_WRAP") else []):
     def wrap(fn, name=name):
         def inner(*a, **k):
             t = time.perf_counter()
@@ -40,11 +40,19 @@ for name in [m for m in dir(C.Context) if not m.startswith("_") and callable(get
     setattr(C.Context, name, wrap(getattr(C.Context, name)))
 simulate(mk()); grad(mk()); torch.cuda.synchronize()
 CALLS.clear()
+import gc
+if os.environ.get("PROBE_GC") == "0":
+    gc.disable()
+if os.environ.get("PROBE_GC") == "stats":
+    gc.callbacks.append(lambda phase, info: print("gc", phase, info, round(time.perf_counter() * 1e3, 2), flush=True))
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     v0 = mk(); torch.cuda.synchronize()
+    import faulthandler
+    faulthandler.dump_traceback_later(0.030, repeat=False)          # a call that blocks longer than 30 ms prints where (all threads)
     t0 = time.perf_counter()
     loss, (g,) = grad(v0)
     t1 = time.perf_counter()
+    faulthandler.cancel_dump_traceback_later()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(json.dumps({"rep": rep, "grad_call_returns_ms": round((t1 - t0) * 1e3, 2), "complete_ms": round((t2 - t0) * 1e3, 2),

@@ -50,9 +50,12 @@ def main():
         torch.cuda.synchronize()
 
     simulate(mk()); grad(mk()); grad(mk()); sync()
-    # r6: per-repetition times (each bracketed by a synchronisation) and their median -- the mean of three back-to-back calls that rounds 3-5 reported hides a one-off:
-    # with the r6 library the SECOND differentiated step of a process took 52-56 ms instead of 18 in five of five plain runs (never under rocprofv3 or with per-call
-    # timers around the C-ABI calls, never with PHIHIP_AUTOTUNE=0: profiles/r06_backward_step.txt), which made a 3-repetition mean read 30 ms
+    # r6: per-repetition times (each bracketed by a synchronisation) and their median. The mean of three back-to-back calls that rounds 3-5 reported is at the mercy of
+    # CPython's generation-2 garbage collection: with torch's object graph one collection takes 33-38 ms and falls wherever the allocation counter trips -- with the r6
+    # library in the SECOND differentiated step of this script, which made the 3-repetition mean read 30 ms instead of 18 (found with faulthandler + gc.callbacks:
+    # profiles/r06_backward_step.txt). The median of 7 does not see it; `gc.freeze()` after the warm-up keeps long-lived objects out of later collections.
+    import gc
+    gc.collect(); gc.freeze()
     def timed(fn):
         ts = []
         for _ in range(args.reps):
