@@ -528,6 +528,12 @@ def phi_level_block(ctx, lib, device, cg_iters, steps=20, sizes=(256, 128), plum
         for _ in range(3):
             fn()
         device_sync(device)
+        # r6: CPython's generation-2 garbage collection walks torch's whole object graph (33 ms on the GPU box, profiles/r06_backward_step.txt); in a 20-100-step
+        # window it either falls or not and moves an eager small-grid figure by up to 0.3 ms per step. Collect now and freeze what is alive: the loop's own garbage is
+        # still collected (generations 0 / 1), the long-lived graph is not walked again. A user's loop gains the same from `gc.freeze()` after set-up.
+        import gc
+        gc.collect()
+        gc.freeze()
         t0 = time.perf_counter()
         for _ in range(n_steps):
             fn()

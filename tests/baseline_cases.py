@@ -173,3 +173,61 @@ def config4_batched_smoke(ctx, mem, n=512, B=8, steps=3, iters=60, report=None):
         report.update(size=n, batch=B, steps=steps, iterations=iters, **{f"worst_{k}": v_ for k, v_ in worst.items()})
     assert worst['smoke'] <= 2e-5 and worst['p'] <= 1e-4 and worst['v'] <= 1e-4 and worst['res'] <= 2e-2, worst
     return worst
+
+
+def max_size_step(ctx, mem, n=1024, iters=20, report=None):
+    """ The largest grid this repository runs (1024^3 fp32: 2^30 cells, 4.3 GB per array, ~50 GB for the step) through size-INDEPENDENT properties -- the
+    oracle cannot hold it. The velocity is a Taylor-Green vortex plus a seeded rough part in the (y, z) plane, extruded along x, the SLOWEST axis
+    (where the large element offsets live), u_x = 0. One benchmark step (self-advection + projection with exactly `iters` CG iterations):
+      * every x-plane of every result equals plane 0 BIT FOR BIT (each cell of a plane sees the same operands in the same order whatever its plane; an
+        element offset that wraps at 2^31 / 2^32 bytes, a chunk boundary or a ring slot that is treated differently breaks it);
+      * plane 0 equals the 2-D oracle's step on the n x n grid of the (y, z) plane (a field that does not depend on x has no x-flux: the 3-D operator is
+        the 2-D one, every dot product is n times the 2-D one) -- velocity to the advection tolerance, pressure rel-L2 to the north-star's 1e-4. """
+    L = 2 * math.pi
+    dom, grid = pc.make_case((n, n, n), ((PER, PER),) * 3, np.float32, upper=(L,) * 3)
+    h = L / n
+    idx = np.arange(n)
+    face, cent = idx * h, (idx + 0.5) * h
+    # Taylor-Green in the (y, z) plane + a seeded rough part (0.3 N(0, 1): CFL < 1 at dt = h / 2): the vortex alone leaves a right-hand side of ONE smooth mode whose
+    # solve sits on the fp32 rounding floor after three iterations, where two summation orders agree only to ~2e-4 (measured at 1024^3); a rough right-hand side keeps
+    # CG working for all its iterations, like the seeded right-hand side of config3_solve
+    rng = np.random.default_rng(1024)
+    pv = (np.cos(face)[:, None] * np.sin(cent)[None, :] + 0.3 * rng.standard_normal((n, n))).astype(np.float32)          # y component at (y face, z centre)
+    pw = (-np.sin(cent)[:, None] * np.cos(face)[None, :] + 0.3 * rng.standard_normal((n, n))).astype(np.float32)         # z component at (y centre, z face)
+    dt = 0.5 * h
+    dv = [mem.extrude(np.zeros((n, n), np.float32), n), mem.extrude(pv, n), mem.extrude(pw, n)]
+    dv2 = [mem.empty((1, n, n, n), np.float32) for _ in range(3)]
+    dp = mem.extrude(np.zeros((n, n), np.float32), n)
+    solve = C.Solve(0.0, 0.0, iters, 50, 0, 0)
+    P = lambda ts: [mem.ptr(t) for t in ts]
+    ctx.advect_staggered(grid, P(dv), P(dv), P(dv2), dt)
+    mem.sync()
+    adv0 = [mem.first_plane(a) for a in dv2[1:]]                                     # the advected velocity, before the projection works on it in place
+    info = ctx.make_incompressible(grid, P(dv2), None, 0, 1, True, mem.ptr(dp), 0, solve)
+    mem.sync()
+    assert info[0].iterations == iters and not info[0].diverged, (info[0].iterations, info[0].diverged)
+    names = ("velocity x", "velocity y", "velocity z", "pressure")
+    for name, t in zip(names, dv2 + [dp]):
+        assert mem.planes_equal_first(t), f"{name}: an x-plane differs from plane 0 at {n}^3"
+    dom2 = O.Domain((n, n), (0.0, 0.0), (L, L), ((PER, PER),) * 2)
+    # the 2-D oracle in DOUBLE precision on the same fp32 inputs: at index ~1000 the fp32 oracle's lookup coordinate (index - dt u / dx, one rounding at ulp(1000) =
+    # 6e-5 cells) costs 1.7e-4 on this rough field (measured), the kernels look up displacement-relative and do not pay it (DESIGN 3.2a) -- the reference must not be
+    # the less accurate side
+    vel2 = [pv[None].astype(np.float64), pw[None].astype(np.float64)]
+    vo = O.semi_lagrangian_staggered(vel2, vel2, dt, dom2)
+    a_err = max(float(np.abs(a - b).max()) for a, b in zip(adv0, vo))
+    vo, po, io, _ = O.make_incompressible(vo, dom2, rtol=0.0, atol=0.0, max_iter=iters, refresh=50)
+    assert int(io.iterations[0]) == iters
+    ux = mem.first_plane(dv2[0])
+    assert float(np.abs(ux).max()) == 0.0, "the x component of an x-invariant flow without x velocity stays exactly zero"
+    v_err = max(float(np.abs(mem.first_plane(a) - b).max()) for a, b in zip(dv2[1:], vo))
+    p_err = _p_err(mem.first_plane(dp), po)
+    if report is not None:
+        report.update(size=n, iterations=iters, cells=n ** 3, advected_max_abs_vs_2d_oracle=a_err, velocity_max_abs_vs_2d_oracle=v_err, pressure_rel_l2_vs_2d_oracle=p_err)
+    assert a_err <= 2e-5, f"advected velocity of plane 0 vs the 2-D oracle: {a_err:.3e}"
+    # after the projection: v = v' - grad p with 1 / dx = n / (2 pi): rounding differences of p between two summation orders (3-D kernels: 2^30-term dot products;
+    # 2-D oracle) are multiplied by 163 at n = 1024 (41 at the 256^3 of config2_step, whose bound is 2e-5): the velocity bound scales with n / 256
+    v_tol = 2e-5 * max(1.0, n / 256.0)
+    assert v_err <= v_tol, f"velocity of plane 0 vs the 2-D oracle: {v_err:.3e} (bound {v_tol:.1e})"
+    assert p_err <= 1e-4, f"pressure of plane 0 vs the 2-D oracle: rel-L2 {p_err:.3e}"
+    return v_err, p_err

@@ -41,6 +41,17 @@ class NumpyMem:
     def sync(self):
         pass
 
+    def extrude(self, plane, n):
+        """ (1, n, *plane.shape): `plane` repeated along the first spatial axis (built where the memory lives: no host copy of the big array) """
+        return np.ascontiguousarray(np.broadcast_to(plane[None, None], (1, n) + plane.shape))
+
+    def planes_equal_first(self, h):
+        """ every plane h[:, k] equals h[:, 0] bit for bit """
+        return bool((h.view(np.uint32 if h.dtype == np.float32 else np.uint64) == h[:, :1].view(np.uint32 if h.dtype == np.float32 else np.uint64)).all())
+
+    def first_plane(self, h):
+        return np.array(h[:, 0])
+
 
 class TorchMem:
     """ real GPU: torch-ROCm tensors own the device memory """
@@ -68,6 +79,20 @@ class TorchMem:
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
+
+    def extrude(self, plane, n):
+        t = self.torch.from_numpy(np.ascontiguousarray(plane)).to(self.device)
+        return t[None, None].expand(1, n, *t.shape).contiguous()
+
+    def planes_equal_first(self, h):
+        it = self.torch.int32 if h.dtype == self.torch.float32 else self.torch.int64
+        ok = True
+        for k0 in range(0, h.shape[1], 64):                       # in slabs: the comparison's temporaries stay small next to a 4-GB array
+            ok = ok and bool((h[:, k0:k0 + 64].view(it) == h[:, :1].view(it)).all())
+        return ok
+
+    def first_plane(self, h):
+        return h[:, 0].cpu().numpy()
 
 
 def make_case(res, bc, dtype, batch=1, lower=None, upper=None, bc_val=None):

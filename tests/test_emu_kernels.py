@@ -604,6 +604,7 @@ def test_baseline_config_cases_at_toy_sizes(emu_ctx):
         bc.config3_solve(emu_ctx, MEM, 16, 8)
         bc.config5_cavity(emu_ctx, MEM, 16, 8)
         bc.config4_batched_smoke(emu_ctx, MEM, 32, 3, 2, 10)
+        bc.max_size_step(emu_ctx, MEM, 24, 8)            # (the 1024^3 case's own logic: x-planes bit-identical, plane 0 = the 2-D oracle)
     finally:
         emu_ctx.set_small_grid_solver(True)
 

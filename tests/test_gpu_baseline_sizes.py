@@ -83,3 +83,16 @@ def test_config4_batched_smoke_8x512_resident_solver_vs_oracle(ctx, mem):
         ctx.set_resident_cg(1)          # the library's default since r6
     print("config4 parity (resident solver):", rep)
 
+
+
+def test_max_size_1024_cubed_plane_invariance_and_2d_oracle(ctx, mem):
+    """ "maximum sizes": 1024^3 fp32 (2^30 cells, 4.3 GB per array -- byte offsets beyond 2^32, element offsets up to 2^30) through properties that do not
+    need a 3-D oracle at that size: bit-identical x-planes of an x-invariant flow and plane 0 against the 2-D oracle (tests/baseline_cases.py max_size_step) """
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip(f"needs ~60 GB of device memory, {free / 2 ** 30:.0f} GB free")
+    rep = {}
+    bc.max_size_step(ctx, mem, 1024, 20, rep)
+    print("max size:", rep)
+    torch.cuda.empty_cache()
