@@ -44,14 +44,17 @@ def kernel_profile(fn):
     return {k: (round(v[1] / v[0], 5) if v[0] else None) for k, v in prof.items()}
 
 
-def config3():
-    n, iters = 512, 100
+def config3(n=512, iters=100, label="3"):
     L = 2 * math.pi
     grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
-    g = torch.Generator(device="cpu").manual_seed(0)
-    rhs = torch.randn(1, n, n, n, generator=g)
-    rhs -= rhs.mean()
-    rhs = rhs.to(dev)
+    if n <= 512:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        rhs = torch.randn(1, n, n, n, generator=g)
+        rhs -= rhs.mean()
+        rhs = rhs.to(dev)
+    else:                                         # (1024^3: 4.3 GB per array -- generated on the device)
+        rhs = torch.randn(1, n, n, n, generator=torch.Generator(device=dev).manual_seed(0), device=dev)
+        rhs -= rhs.mean()
     x = torch.zeros_like(rhs)
     solve = C.Solve(0.0, 0.0, iters, 50, 0, 0)
 
@@ -62,7 +65,9 @@ def config3():
     prof = kernel_profile(run)
     cells = n ** 3
     moved = 28.0 * cells * iters          # 7 fp32 words per cell and iteration move by construction; SURVEY §8d's textbook count is 40 B
-    print(json.dumps({"config": "3: 512^3 fp32 periodic pressure solve, 100 CG iterations", "ms_per_solve": t * 1e3, "ms_per_iteration": t * 1e3 / iters,
+    print(json.dumps({"config": f"{label}: {n}^3 fp32 periodic pressure solve, {iters} CG iterations",
+                      "plans": {f: ctx.query_plan(grid, False, k) for f, k in (("matvec", 1), ("update_x2", 2), ("update_r", 3))},
+                      "ms_per_solve": t * 1e3, "ms_per_iteration": t * 1e3 / iters,
                       "moved_GBs": moved / t / 1e9, "moved_frac_of_8TBs": moved / t / 8e12, "textbook_40B_equiv_frac": 40.0 * cells * iters / t / 8e12,
                       "kernel_ms": prof}), flush=True)
 
@@ -145,4 +150,4 @@ def config5():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["3", "4", "5"]
     for w in which:
-        {"3": config3, "4": config4, "5": config5}[w]()
+        {"3": config3, "4": config4, "5": config5, "6": lambda: config3(1024, 40, "6 (beyond BASELINE: the largest grid of the test suite)")}[w]()
