@@ -1,16 +1,23 @@
 #!/bin/bash
-# copies the records of one tools/sessions/r5_final.sh run (gpurun_out/<tag>) into profiles/ under the names DESIGN.md / README.md / profiles/README.md cite
-#   bash tools/collect_profiles.sh r5z
+# copies the records of one tools/gpu_session.sh run (gpurun_out/<tag>) into profiles/ under the r06_ names DESIGN.md / README.md / profiles/README.md cite
+#   bash tools/collect_profiles.sh r6z
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/${1:-r5z}; P=profiles; R=r05
-cp $O/bench_n1.json $P/${R}_bench_n1.json; cp $O/bench_smoke256.json $P/${R}_bench_smoke256.json
-cp $O/bench_config4.json $P/${R}_bench_config4.json; cp $O/bench_config4_resident.json $P/${R}_bench_config4_resident.json
-cp $O/roofline/kernel_roofline.json $P/${R}_kernel_roofline.json
-for g in f32_256 f32_512 f64_384; do f=$(find $O/roofline/$g/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_kernel_stats_$g.csv; done
-f=$(find $O/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $P/${R}_bench256_kernel_stats.csv
-cp $O/configs_345.jsonl $P/${R}_configs_345.jsonl; cp $O/time_frow.jsonl $P/${R}_time_frow_final.jsonl
-cp $O/smoke256_ab.jsonl $P/${R}_smoke256_ab.jsonl; cp $O/issue_rates.txt $P/${R}_issue_rates.txt; cp $O/backward_step.jsonl $P/${R}_backward_step.jsonl; cp $O/host_api.jsonl $P/${R}_host_api.jsonl
-(cat $O/build_id.txt; grep -E "passed|failed" $O/pytest_gpu.log | tail -1; tail -1 $O/smoke.log) > $P/${R}_gpu_suite_final.txt
-(cat $O/build_id.txt; echo "$(grep -c '^ok' $O/fuzz.log) randomised cases ok, $(grep -c '^skip' $O/fuzz.log) skipped (tests/fuzz_parity.py --first 53000 --count 120, resident-solver arm on every 2-D case):"; tail -1 $O/fuzz.log; grep "^FAIL" $O/fuzz.log) > $P/${R}_fuzz_gpu_final.txt
-cat $P/${R}_gpu_suite_final.txt $P/${R}_fuzz_gpu_final.txt
+O=gpurun_out/${1:?tag}; P=profiles; R=r06
+c() { [ -f "$1" ] && cp "$1" "$2" && echo "  $2"; }
+c $O/bench_n1.json $P/${R}_bench_n1.json
+c $O/smoke256_w30.json $P/${R}_bench_smoke256.json
+for r in 0 -1 2; do c $O/config4_res$r.json $P/${R}_bench_config4_resident$r.json; done
+c $O/roofline/kernel_roofline.json $P/${R}_kernel_roofline.json
+for g in f32_256 f32_512 f64_384; do f=$(find $O/roofline/$g/stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && c $f $P/${R}_kernel_stats_$g.csv; done
+f=$(find $O/prof_bench -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && c $f $P/${R}_bench256_kernel_stats.csv
+c $O/configs.jsonl $P/${R}_configs_3456.jsonl
+for f in $O/time_frow_*.jsonl; do [ -f "$f" ] && c $f $P/${R}_final_$(basename $f); done
+c $O/backward_step.jsonl $P/${R}_backward_step.jsonl
+for f in $O/sweep_resident_*.jsonl; do [ -f "$f" ] && c $f $P/${R}_$(basename $f); done
+c $O/jit_foreach_debug.txt $P/${R}_jit_foreach_debug_final.txt
+if [ -f $O/pytest_tests.log ] || [ -f $O/pytest_tests_.log ]; then
+  L=$(ls $O/pytest_tests*.log | head -1)
+  (cat $O/build_id.txt; grep -E "passed|failed" $L | tail -1; tail -1 $O/smoke.log) > $P/${R}_gpu_suite_final.txt; echo "  $P/${R}_gpu_suite_final.txt"; cat $P/${R}_gpu_suite_final.txt
+fi
+if [ -f $O/fuzz.txt ]; then (cat $O/build_id.txt; tail -6 $O/fuzz.txt; grep "^FAIL" $O/fuzz.txt) > $P/${R}_fuzz_gpu_final.txt; echo "  $P/${R}_fuzz_gpu_final.txt"; tail -3 $P/${R}_fuzz_gpu_final.txt; fi

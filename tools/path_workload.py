@@ -125,6 +125,7 @@ def group_f32_256(ctx, dev, n, reps):
     note(r"march_kernel<float, 4, \d, \d+, 6, false", "a5 CG UPDATE_R r -= alpha A d", 3 * w * N, 3, "read r, d; write r")
     note(r"march_kernel<float, 4, \d, \d+, 7, false", "a5 CG UPDATE_X2 x += two steps, r -= alpha A d", 5 * w * N, 5, "read x, r, d; write x, r")
     note(r"march_kernel<float, 4, \d, \d+, 0, false", "a4 masked_laplace apply AND (r4) f1 diffuse.explicit: one MODE_APPLY pass per component / scalar with the operator I + k dt L", 2 * w * N, 2, "read p, write A p")
+    note(r"march_apply_multi_kernel<float", "f1 diffuse.explicit of the staggered velocity, r6: ALL components in one launch (I + k dt L per lattice)", 6 * w * N, 6, "read + write 3 components")
     note(r"grad_subtract_vec_kernel<float, 3", "a6 gradient subtraction, all components", 7 * w * N, 7, "read p, read + write 3 components")
     note(r"mask_faces_kernel<float", "f5 projection adjoint: hard_bcs mask of the face gradients", 2 * w * N, 2, "read + write one component")
 
@@ -174,6 +175,14 @@ def group_f32_256(ctx, dev, n, reps):
     sync(dev)
     note(r"advect_bwd_trace_kernel<float, 3, \d, true>", "f5 advection adjoint pass A, one staggered component per launch: back-trace, store x*, g, g d(out)/d(x*)", 12 * w * N, 12,
          "read grad_out, field, 3 velocity components; write 3 coordinates, g, 3 du (7 scratch words)")
+    note(r"advect_bwd_trace_all_kernel<float, 3>", "f5 advection adjoint pass A, r6: ALL staggered components in one launch", 36 * w * N, 36,
+         "per component: read grad_out, field, 3 velocity components; write 3 coordinates, g, 3 du")
+    note(r"advect_bwd_field_gather_all_kernel<float, 3>", "f5 advection adjoint pass B, r6: ALL staggered components in one launch", 18 * w * N, 18,
+         "per component: read 3 coordinates + g (one-cell halo, staged in LDS), read + write grad_field")
+    note(r"advect_bwd_velocity_gather_all_kernel<float, 3, true>", "f5 advection adjoint pass C (staggered), r6: ALL velocity components in one launch", 15 * w * N, 15,
+         "per component: read du of the 3 source components, read + write grad_velocity")
+    note(r"mac_cormack_bwd_all_kernel<float, 3>", "f5 adjoint of the MacCormack correction pass, r6: ALL staggered components in one launch", 45 * w * N, 45,
+         "per component: read grad_out, field, forward result, 3 velocity components; rmw grad_field, grad_fwd; write the sample record + 3 du")
     note(r"advect_bwd_trace_kernel<float, 3, 2, false>", "f5 advection adjoint pass A, centred scalar", 12 * w * N, 12,
          "read grad_out, scalar, 3 velocity components; write 3 coordinates, g, 3 du")
     note(r"advect_bwd_field_gather_kernel<float, 3>", "f5 advection adjoint pass B: field gradient as a gather of hat weights over the 27 neighbouring samples", 6 * w * N, 6,
