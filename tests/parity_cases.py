@@ -1062,12 +1062,14 @@ def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=
     else:
         assert all(i.converged for i in info), [(i.iterations, i.residual_sq, i.rhs_sq) for i in info]
         assert all(abs(k - int(ko)) <= max(2, int(0.05 * ko)) for k, ko in zip(its, io.iterations)), (its, io.iterations)
-    if not fixed_iterations and err > tol(dtype)['cg_rel_l2'] and its != [int(k) for k in io.iterations]:
+    if not fixed_iterations and err > tol(dtype)['cg_rel_l2']:
         # A tolerance solve promises a RESIDUAL, not a solution: two solves that stop a few iterations apart (sums taken in another order) differ by
         # about cond(A) * rel_tol -- a white-noise right-hand side that needs hundreds of iterations puts that above the solution bound (fuzz seed
-        # 70129, resident arm: 235 against 227 iterations, rel-L2 2.6e-4). What the library's solution has to keep then is the promise itself: its
-        # TRUE relative residual (float64 arithmetic of the oracle's operator) within a small factor of the tolerance, and a solution within the
-        # amplification a few iterations allow.
+        # 70129, resident arm: 235 against 227 iterations, rel-L2 2.6e-4; r6, seed 60006, resident arm: IDENTICAL counts 615 ... 625 and rel-L2 1.10e-4
+        # after 600 fp32 iterations with twelve restarts -- profiles/r06_fuzz_gpu_final.txt). What the library's solution has to keep then: (a) the promise
+        # itself -- its TRUE relative residual (float64 arithmetic of the oracle's operator) within a small factor of the tolerance; (b) a solution within the
+        # amplification a few iterations allow; (c) r6: it is no further from the TRUTH (the oracle's CG in float64 to 1e-12) than the fp32 oracle is, up to
+        # a factor 1.5 -- "as accurate as the reference's arithmetic", measured instead of assumed.
         x64 = x.astype(np.float64)
         r_true = rhs.astype(np.float64) - O.masked_laplace(x64, dom, hard, active)
         if singular and active is None:
@@ -1076,6 +1078,12 @@ def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=
         rel_res = np.sqrt((r_true ** 2).sum(axis=ax) / np.maximum((rhs.astype(np.float64) ** 2).sum(axis=ax), 1e-300))
         assert float(rel_res.max()) <= 4 * s.rel_tol and err <= 10 * tol(dtype)['cg_rel_l2'], \
             f"CG: true relative residual {rel_res} (rel_tol {s.rel_tol}), pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
+        A64 = lambda q: O.masked_laplace(q, dom, hard, active)
+        xt, _ = (O.cg_adaptive if adaptive else O.cg)(A64, rhs.astype(dtype).astype(np.float64), np.zeros(rhs.shape, np.float64), 1e-12, 0.0, 20 * max_iter, refresh)
+        at, ah, ao = (demean(xt), demean(x64), demean(xo.astype(np.float64))) if singular and active is None else (xt, x64, xo.astype(np.float64))
+        e_hip, e_ora = rel_l2(ah, at), rel_l2(ao, at)
+        assert e_hip <= 1.5 * e_ora + tol(dtype)['cg_rel_l2'], \
+            f"CG: the library's solution is {e_hip:.3e} from the float64 truth, the fp32 oracle's {e_ora:.3e} (iterations {its} vs oracle {io.iterations})"
     else:
         assert err <= tol(dtype)['cg_rel_l2'], f"CG pressure rel-L2 {err} (iterations {its} vs oracle {io.iterations})"
     return x, info

@@ -20,4 +20,4 @@ if [ -f $O/pytest_tests.log ] || [ -f $O/pytest_tests_.log ]; then
   L=$(ls $O/pytest_tests*.log | head -1)
   (cat $O/build_id.txt; grep -E "passed|failed" $L | tail -1; tail -1 $O/smoke.log) > $P/${R}_gpu_suite_final.txt; echo "  $P/${R}_gpu_suite_final.txt"; cat $P/${R}_gpu_suite_final.txt
 fi
-if [ -f $O/fuzz.txt ]; then (cat $O/build_id.txt; tail -6 $O/fuzz.txt; grep "^FAIL" $O/fuzz.txt) > $P/${R}_fuzz_gpu_final.txt; echo "  $P/${R}_fuzz_gpu_final.txt"; tail -3 $P/${R}_fuzz_gpu_final.txt; fi
+if [ -f $O/fuzz.txt ]; then (cat $O/build_id.txt; echo "$(grep -c '^ok' $O/fuzz.txt) randomised cases ok, $(grep -c '^skip' $O/fuzz.txt) skipped (tests/fuzz_parity.py, resident-solver arm on every 2-D case):"; tail -1 $O/fuzz.txt; grep "^FAIL" $O/fuzz.txt) > $P/${R}_fuzz_gpu_final.txt; echo "  $P/${R}_fuzz_gpu_final.txt"; cat $P/${R}_fuzz_gpu_final.txt; fi

@@ -96,7 +96,7 @@ for f in ('$O/sweep_resident_${1:-coop}.jsonl', '$O/sweep_resident_batches_${1:-
 PY
 }
 stage_fuzz() {
-  timeout 2400 python tests/fuzz_parity.py --cases ${1:-120} --seed ${FUZZ_SEED:-60000} > $O/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -4 $O/fuzz.txt
+  timeout 2400 python tests/fuzz_parity.py --first ${FUZZ_SEED:-60000} --count ${1:-120} > $O/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -4 $O/fuzz.txt
 }
 stage_backward() {
   timeout 600 python tools/time_backward_step.py > $O/backward_step.jsonl 2>&1; echo "backward rc=$?"; tail -2 $O/backward_step.jsonl | cut -c1-600

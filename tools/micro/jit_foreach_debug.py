@@ -29,7 +29,7 @@ def make_call(fin, fout):
         key = (J._spec_key(spec), tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors))
         cap = self.captures.get(key)
         if cap is None:
-            cap = self._capture(spec, tensors, lambda tree: self.f(*tree[0], **tree[1]))
+            cap = self._capture(spec, tensors, lambda tree: self.f(*tree[0], **tree[1]), False)
             self.captures[key] = cap
         else:
             pairs = [(d, s) for d, s in zip(cap.inputs, tensors) if d.data_ptr() != s.data_ptr()]

@@ -37,7 +37,7 @@ for fused in (0, 1):
             key = (J._spec_key(spec), tuple((tuple(t.shape), t.dtype, t.device.index) for t in tensors))
             cap = self.captures.get(key)
             if cap is None:
-                cap = self._capture(spec, tensors, lambda tree: self.f(*tree[0], **tree[1]))
+                cap = self._capture(spec, tensors, lambda tree: self.f(*tree[0], **tree[1]), False)
                 self.captures[key] = cap
             else:
                 torch._foreach_copy_(cap.inputs, tensors)
