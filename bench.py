@@ -983,6 +983,13 @@ def main():
     if rank == 0 and args.config3_size > 0:
         del sim
         torch.cuda.empty_cache()
+        if pinned_plans is not None:
+            # N > 1 (or the forced-dist rehearsal): the replicas ran rank 0's 256^3 plans PINNED (sync_launch_plans). The 512^3 block below is another grid: with those
+            # plans (16-plane chunks) its iteration took 0.80 ms instead of 0.70 in the r6 rehearsal -- the `roofline` of an N > 1 line would have priced a mis-planned
+            # kernel. Unpin and let the first call tune for this grid, as at N = 1.
+            for fam in (0, 1, 2, 3):
+                ctx.set_tuning_kernel(fam, 0, 0, 0)
+            ctx.set_autotune(True)
         c3 = config3_block(ctx, device, args.config3_size, args.cg_iters)
         extra["config3"] = c3
         per3 = {k: (c3["kernel_ms_per_launch"].get(k), c3["launches"].get(k, 0), (c3["kernel_ms_per_launch"].get(k) or 0.0) * c3["launches"].get(k, 0))
