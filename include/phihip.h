@@ -392,7 +392,7 @@ int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cell
  * ceil(n_y / 16) workgroups of 1024 threads that keep r, A r, A p, p and x in registers for the whole solve and meet at one barrier per
  * iteration (boundary rows + five partial sums through L2); the control logic (tolerances, divergence test, true-residual refresh --
  * phiml's cg loop) runs on the device, the launch ends when its entries have converged, the host never polls. Same
- * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids without cell flags, rows of whole 16-byte vectors up to
+ * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids (r6: with or without cell flags -- a thread keeps the four flag bytes of each of its vectors in one register), rows of whole 16-byte vectors up to
  * 512 cells, batch x workgroups <= compute units; everything else keeps the launch-per-iteration kernels.
  * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries with cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever
  * applicable. Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14.3 -> 10.1, 4 x 512^2 11.4 -> 8.5, 2 x 512^2 9.4 -> 8.1,

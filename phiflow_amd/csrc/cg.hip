@@ -394,10 +394,11 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
 
 // 2-D fp32 grids whose iteration is bound by kernel boundaries: the whole solve in ONE launch of resident workgroups (cg_resident.hip)
 bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve);
-int run_cg_resident(phihip_ctx*, const GridView&, const void* rhs, void* x, const phihip_solve*, void* st_out, const double* shift, hipStream_t);
+int run_cg_resident(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, void* st_out, const double* shift,
+                    hipStream_t);
 
-static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x, const phihip_solve* solve, phihip_solve_info* info,
-                            const double* shift, hipStream_t s) {
+static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve* solve,
+                            phihip_solve_info* info, const double* shift, hipStream_t s) {
     // A caller that passes no `info` is never synchronised with, so an aborted launch (not resident as a whole) cannot fail ITS call: the kernel
     // raises a word in host-mapped memory and the next resident solve of the context reports it (include/phihip.h).
     if (ctx->adv_host && ctx->adv_host[15]) {
@@ -407,7 +408,7 @@ static int cg_resident_path(phihip_ctx* ctx, const GridView& v, const void* rhs,
     }
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
     CgState* st = (CgState*)ctx->ws_state.ptr;
-    PHIHIP_TRY(run_cg_resident(ctx, v, rhs, x, solve, st, shift, s));
+    PHIHIP_TRY(run_cg_resident(ctx, v, flags, mask_batch, rhs, x, solve, st, shift, s));
     ctx->last_state = st;
     ctx->last_state_batch = v.batch;
     if (info) {
@@ -891,7 +892,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     // number of its tags lives on the device: a replay gets a fresh one). A launch the runtime refuses (cooperative launch too large) takes the forms below.
     if (!v.op_custom && ctx->resident_cg > 0 && ctx->small_cg && !std::is_same<T, double>::value && cg_resident_applicable(ctx, v, flags, solve) &&
         (ctx->resident_cg == 2 || (v.batch >= 2 && (long long)v.cells * v.batch <= ctx->resident_cg_cells))) {      // (mode 1: batches -- one entry gains nothing, 7.8 -> 8.3 us at 512^2)
-        const int st = cg_resident_path(ctx, v, rhs, x, solve, info, shift, s);
+        const int st = cg_resident_path(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
         if (st != PHIHIP_ERR_UNSUPPORTED) return st;
     }
     // (phihip_set_small_grid_solver(ctx, 0) = "the two-launch marching kernels at every size": it also switches the automatic choice off)

@@ -51,6 +51,8 @@ struct ResArgs {
     long long cells;
     int nb1_lo, nb1_hi, nb2_lo, nb2_hi;     // NeighbourRule per side of the two axes
     float w1, w2, ident;
+    const uint8_t* flags;         // r6: packed cell flags (phihip_build_cellflags: bits 2, 3 / 4, 5 = the a1 / a2 faces are open for flux, bit 6 = active) or nullptr
+    long long flag_bstride;       // cells (one flag array per batch entry) or 0 (shared)
     const float* y;               // right-hand side [batch][n1][n2]
     float* yout;                  // != nullptr: y - shift[b] is written back (fluid._balance_divergence folded in, as MODE_RESID_BAL)
     const double* shift;
@@ -218,7 +220,7 @@ __device__ __forceinline__ bool gran_get4n(const gran_t* p, size_t astride, unsi
     }
 }
 
-template <int VPT>
+template <int VPT, bool FLAGS = false>
 __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
     constexpr int LS = 256 * VPT + 8;                 // LDS row stride; cell j sits at column 4 + j (vectors stay 16-byte aligned)
     PHIHIP_DYNAMIC_LDS(unsigned char, lds_raw);
@@ -256,6 +258,21 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
         jr[v] = nb_index(j[v] + 4, n2, A.nb2_lo, A.nb2_hi, zr[v]);
         if (!in_row[v]) { jl[v] = jr[v] = 0; j[v] = 0; }
     }
+    // r6: cell flags (obstacles / `active` masks): the four flag bytes of every vector of the thread stay in ONE register for the whole solve. The neighbour VALUES
+    // follow the boundary rule as without flags; whether a face carries flux, and whether the cell is solved at all, is the flag's (stencil_march.hpp, FLAGS form)
+    unsigned fl[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        fl[v] = 0u;
+        if (FLAGS && ok[v]) fl[v] = *reinterpret_cast<const unsigned*>(A.flags + (long long)b * A.flag_bstride + (long long)(row0 + wave) * n2 + j[v]);
+    }
+    // y - shift on the ACTIVE cells only (fluid._balance_divergence subtracts the mean over the active cells from them)
+    auto shifted = [&](int v, f4 y, float sh) -> f4 {
+        if (!FLAGS) return y - f4_splat(sh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] -= ((fl[v] >> (8 * e)) & 64u) ? sh : 0.f;
+        return y;
+    };
     // the rows above / below this workgroup: 0 = the neighbouring workgroup's published row, 1 = clamp (own edge row), 2 = zero ghost
     int up_kind = 0, dn_kind = 0, up_g = g - 1, dn_g = g + 1;
     if (g == 0) { up_g = G - 1; up_kind = A.nb1_lo == NB_WRAP ? 0 : (A.nb1_lo == NB_CLAMP ? 1 : 2); }
@@ -341,6 +358,17 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
             const float c = S[e];
             const float lo2 = e > 0 ? S[e > 0 ? e - 1 : 0] : lf;
             const float hi2 = e < 3 ? S[e < 3 ? e + 1 : e] : rt;
+            if (FLAGS) {
+                const unsigned f = (fl[v] >> (8 * e)) & 0xFFu;
+                float acc = 0.f;
+                if (f & 4u) acc += (up[e] - c) * A.w1;
+                if (f & 8u) acc += (dn[e] - c) * A.w1;
+                if (f & 16u) acc += (lo2 - c) * A.w2;
+                if (f & 32u) acc += (hi2 - c) * A.w2;
+                acc = fmaf(A.ident, c, acc);
+                q[e] = (f & 64u) ? acc : c;        // inactive cell: identity row (fluid.py:202)
+                continue;
+            }
             const float t2 = ((hi2 - c) - (c - lo2)) * A.w2;
             const float t1 = ((dn[e] - c) - (c - up[e])) * A.w1;
             q[e] = fmaf(A.ident, c, t1 + t2);
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
             const f4 q = apply(v, x[v]);
             r[v] = f4_zero();
             if (!ok[v]) continue;
-            f4 y = f4_load(A.y + rowoff + j[v]) - f4_splat(yshift);
+            f4 y = shifted(v, f4_load(A.y + rowoff + j[v]), yshift);
             r[v] = y - q;
             if (A.yout) f4_store(A.yout + rowoff + j[v], y);
             a0 += (double)f4_dot(r[v], r[v]);
@@ -532,7 +560,7 @@ __global__ __launch_bounds__(kResBlock) void cg_resident_kernel(ResArgs A) {
                     const f4 q = apply(v, x[v]);
                     if (!ok[v]) continue;
                     const f4 y = f4_load((A.yout ? A.yout : A.y) + rowoff + j[v]);      // (balanced by the first pass when a shift was given)
-                    r[v] = (A.yout ? y : y - f4_splat(yshift)) - q;
+                    r[v] = (A.yout ? y : shifted(v, y, yshift)) - q;
                 }
                 ++ph;
 #pragma unroll
@@ -589,23 +617,27 @@ static size_t resident_lds_bytes(int vpt) {
 }
 
 #if defined(__HIPCC__)
-static int resident_blocks_per_cu(const phihip_ctx* ctx, int vpt) {
-    static int cached[16][3] = {{0}};
-    int& c = cached[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0][vpt];
+static int resident_blocks_per_cu(const phihip_ctx* ctx, int vpt, bool flags) {
+    static int cached[16][3][2] = {{{0}}};
+    int& c = cached[ctx->device >= 0 && ctx->device < 16 ? ctx->device : 0][vpt][flags ? 1 : 0];
     if (c == 0) {
         int n = 0;
         const size_t lds = resident_lds_bytes(vpt);
-        const hipError_t e = vpt == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<1>, kResBlock, lds)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<2>, kResBlock, lds);
+        hipError_t e;
+        if (flags) e = vpt == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<1, true>, kResBlock, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<2, true>, kResBlock, lds);
+        else e = vpt == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<1, false>, kResBlock, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_resident_kernel<2, false>, kResBlock, lds);
         c = (e == hipSuccess && n > 0) ? n : -1;
     }
     return c > 0 ? c : 0;
 }
 #endif
 
-// can the resident solver take this solve? (2-D fp32 'CG' without cell flags, rows of whole vectors up to 1024 cells, batch x G workgroups <= CUs)
+// can the resident solver take this solve? (2-D fp32 'CG' -- r6: with or without cell flags --, rows of whole vectors up to 512 cells, batch x G workgroups <= CUs)
 bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
-    if (v.rank != 2 || v.dtype != PHIHIP_F32 || flags || v.unaligned || v.halo[0] || v.halo[1]) return false;
+    if (v.rank != 2 || v.dtype != PHIHIP_F32 || v.unaligned || v.halo[0] || v.halo[1]) return false;
+    if (flags && ((uintptr_t)flags & 3u)) return false;      // (the four flag bytes of a vector are read as one word)
     if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 200000) return false;      // (the phase number has 20 bits of the tag: up to 4 phases per iteration with refresh_every = 1)
     if (v.n[2] % 4 != 0 || v.n[2] > 512 || v.n[1] < 2) return false;      // (rows up to 1024 cells would need VPT = 4: 80 state registers, spills at 128)
     const long long G = (v.n[1] + kResRows - 1) / kResRows;
@@ -613,15 +645,15 @@ bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint
 #if defined(__HIPCC__)
     // the launch must be resident as a whole: workgroups the occupancy calculator grants per CU x CUs (1024 threads at <= 128 VGPRs: one per
     // CU today -- asked, not assumed, so that a compiler that needs more registers makes the solver fall back instead of stalling for ~1 s)
-    return G * v.batch <= (long long)resident_blocks_per_cu(ctx, v.n[2] <= 256 ? 1 : 2) * ctx->num_cu;
+    return G * v.batch <= (long long)resident_blocks_per_cu(ctx, v.n[2] <= 256 ? 1 : 2, flags != nullptr) * ctx->num_cu;
 #else
     (void)ctx;
     return G * v.batch <= 16;         // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory: 1024 fibers of 256 KB stack per block
 #endif
 }
 
-int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x, const phihip_solve* solve, void* st_out, const double* shift,
-                    hipStream_t s) {
+int run_cg_resident(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve* solve, void* st_out,
+                    const double* shift, hipStream_t s) {
     const int G = (v.n[1] + kResRows - 1) / kResRows;
     const int vpt = v.n[2] <= 256 ? 1 : 2;
     ResArgs A;
@@ -639,6 +671,8 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x
     const double sc = v.op_custom ? v.op_scale : 1.0;
     A.w1 = (float)(sc / (v.dx[1] * v.dx[1])); A.w2 = (float)(sc / (v.dx[2] * v.dx[2]));
     A.ident = (float)(v.op_custom ? v.op_ident : 0.0);
+    A.flags = flags;
+    A.flag_bstride = mask_batch > 1 ? v.cells : 0;
     A.y = (const float*)rhs;
     A.yout = shift ? (float*)const_cast<void*>(rhs) : nullptr;
     A.shift = shift;
@@ -673,18 +707,25 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const void* rhs, void* x
     // is unchanged: granule exchange, no grid barrier. ctx->res_coop = 0 (PHIHIP_RESIDENT_COOP=0): the plain launch.
     if (ctx->res_coop && (ctx->res_coop_capture || !stream_is_capturing(s))) {
         void* params[1] = {(void*)&A};
-        const hipError_t e = vpt == 1 ? hipLaunchCooperativeKernel((const void*)cg_resident_kernel<1>, grid, block, params, (unsigned)lds, s)
-                                      : hipLaunchCooperativeKernel((const void*)cg_resident_kernel<2>, grid, block, params, (unsigned)lds, s);
+        const void* fn = flags ? (vpt == 1 ? (const void*)cg_resident_kernel<1, true> : (const void*)cg_resident_kernel<2, true>)
+                               : (vpt == 1 ? (const void*)cg_resident_kernel<1, false> : (const void*)cg_resident_kernel<2, false>);
+        const hipError_t e = hipLaunchCooperativeKernel(fn, grid, block, params, (unsigned)lds, s);
         if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported) {
             (void)hipGetLastError();
             return PHIHIP_ERR_UNSUPPORTED;        // (cg.hip: the launch forms take the solve)
         }
         PHIHIP_CHECK_HIP(e);
-    } else if (vpt == 1) hipLaunchKernelGGL(cg_resident_kernel<1>, grid, block, lds, s, A);
-    else hipLaunchKernelGGL(cg_resident_kernel<2>, grid, block, lds, s, A);
+    } else if (flags) {
+        if (vpt == 1) hipLaunchKernelGGL((cg_resident_kernel<1, true>), grid, block, lds, s, A);
+        else hipLaunchKernelGGL((cg_resident_kernel<2, true>), grid, block, lds, s, A);
+    } else if (vpt == 1) hipLaunchKernelGGL((cg_resident_kernel<1, false>), grid, block, lds, s, A);
+    else hipLaunchKernelGGL((cg_resident_kernel<2, false>), grid, block, lds, s, A);
 #else
-    if (vpt == 1) hipemuLaunchResident(cg_resident_kernel<1>, grid, block, lds, s, A);
-    else hipemuLaunchResident(cg_resident_kernel<2>, grid, block, lds, s, A);
+    if (flags) {
+        if (vpt == 1) hipemuLaunchResident((cg_resident_kernel<1, true>), grid, block, lds, s, A);
+        else hipemuLaunchResident((cg_resident_kernel<2, true>), grid, block, lds, s, A);
+    } else if (vpt == 1) hipemuLaunchResident((cg_resident_kernel<1, false>), grid, block, lds, s, A);
+    else hipemuLaunchResident((cg_resident_kernel<2, false>), grid, block, lds, s, A);
 #endif
     PHIHIP_CHECK_HIP(hipGetLastError());
     return PHIHIP_OK;

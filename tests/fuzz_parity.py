@@ -41,6 +41,10 @@ def resident_arm(ctx, mem, r, seed, bc, emu):
         if n1 * n2 <= 40000:      # tolerance mode on a white-noise right-hand side: thousands of iterations on larger 2-D grids (max_iterations = 1000)
             pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 8))
             pc.check_make_incompressible(ctx, mem, dom, grid, np.float32, np.random.default_rng(seed + 9))
+        if 8192 < n1 * n2 <= 40000:      # r6: the FLAGS form of the resident solver -- a random solid disc (below 8193 cells the one-workgroup solver takes a solve)
+            rad = float(r.uniform(0.12, 0.3)) * min(n1, n2)
+            disc = pc.O.SphereObstacle((float(r.uniform(0.3, 0.7)) * n1, float(r.uniform(0.3, 0.7)) * n2), rad)
+            pc.check_resident_with_flags(ctx, mem, (n1, n2), bc, batch, [disc], seed=seed + 10, projection=not all(lo == pc.PER for lo, _ in bc))
     finally:
         ctx.profile_enable(False)
         ctx.set_resident_cg(1)          # the library's default since r6

@@ -1223,3 +1223,39 @@ def check_degenerate_grid(ctx, mem, res, bc, dtype, projection=True):
                 check_make_incompressible(ctx, mem, dom, grid, dtype, np.random.default_rng(5))
     finally:
         ctx.set_small_grid_solver(True)
+
+
+def check_resident_with_flags(ctx, mem, res, bc, batch, obstacles, seed=11, projection=True):
+    """ r6: the resident 2-D solver with CELL FLAGS (obstacles / `active` masks): flags from `phihip_build_cellflags`, the solve with exactly
+    `max_iter` iterations across a true-residual refresh, a tolerance solve, and the projection with the obstacles -- each against the oracle, with the launch
+    counters asserting that ONE resident launch solved (no MATVEC launches). """
+    dtype = np.float32
+    dom, grid = make_case(res, bc, dtype, batch=batch)
+    active, hard, soft = O.obstacle_masks(obstacles, dom, dtype)
+    acc = (active[0] > 0).astype(np.uint8)
+    dacc, dflags = mem.to_dev(acc), mem.empty(dom.res, np.uint8)
+    g1 = C.make_grid(dom.rank, grid.dtype, 1, dom.res, dom.lower, dom.upper, dom.bc, dom.bc_val)
+    ctx.build_cellflags(g1, mem.ptr(dacc), 0, 1, mem.ptr(dflags))
+    mem.sync()
+    flags = mem.to_host(dflags)
+    assert np.array_equal((flags >> 6) & 1, acc) and 0 < int(acc.sum()) < acc.size, "the case needs solid AND fluid cells"
+    try:
+        ctx.set_resident_cg(2)
+        ctx.profile_enable(True)
+        ctx.profile_read(True)
+        check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed), max_iter=14, refresh=6, flags_np=flags, hard=hard, active=active, fixed_iterations=True)
+        prof = ctx.profile_read(True)
+        assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, f"the resident solver did not take the flagged solve: {prof}"
+        small = int(np.prod(res)) <= 40000      # (tolerance mode on a white-noise right-hand side takes thousands of iterations on larger 2-D grids: max_iterations = 1000)
+        if small:
+            check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 1), flags_np=flags, hard=hard, active=active)
+            prof = ctx.profile_read(True)
+            assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, prof
+        else:
+            check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 1), max_iter=60, refresh=50, flags_np=flags, hard=hard, active=active, fixed_iterations=True)
+        ctx.profile_enable(False)
+        if projection and small:
+            check_make_incompressible(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 2), obstacles=obstacles)
+    finally:
+        ctx.profile_enable(False)
+        ctx.set_resident_cg(1)

@@ -682,6 +682,15 @@ def test_resident_cg_matches_oracle(emu_ctx, res, bc, batch):
         emu_ctx.set_resident_cg(1)          # the library's default since r6
 
 
+@pytest.mark.parametrize("res,bc,batch,obstacles", [
+    ((40, 216), ((CLO, CLO), (CLO, CLO)), 2, [pc.O.BoxObstacle((10.0, 60.0), (22.0, 130.0))]),                                 # three workgroups per entry, the box spans a cut
+    ((33, 264), ((OPN, OPN), (CLO, OPN)), 1, [pc.O.SphereObstacle((16.0, 100.0), 9.5), pc.O.BoxObstacle((0.0, 200.0), (12.0, 230.0))])])   # two vectors per thread, ragged last workgroup
+# (both > 8192 cells: below that the one-workgroup solver takes a solve; three more grids, up to 104 workgroups, run on the GPU: tests/test_gpu_parity.py)
+def test_resident_cg_with_cell_flags(emu_ctx, res, bc, batch, obstacles):
+    """ r6: cg_resident.hip with obstacles (cell flags held in registers) against the oracle: fixed iterations across a refresh, tolerance mode, the projection """
+    pc.check_resident_with_flags(emu_ctx, MEM, res, bc, batch, obstacles)
+
+
 @pytest.mark.parametrize("res,bc", [((9, 13), ((CLO, OPN), (PER, PER))), ((5, 6, 11), ((PER, PER), (CLO, OPN), (OPN, CLO))), ((3, 5, 261), ((CLO, CLO), (PER, PER), (PER, PER))), ((2, 4, 257), ((PER, PER), (CLO, OPN), (PER, PER))),
                                     ((4, 7, 15), ((OPN, OPN), (CLO, CLO), (CLO, CLO)))])
 def test_ragged_rows_on_the_vector_kernels(emu_ctx, res, bc):

@@ -775,6 +775,18 @@ def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
         rccl.ncclCommDestroy(comm)
 
 
+@pytest.mark.parametrize("res,bc,batch,obstacles", [
+    ((40, 216), ((CLO, CLO), (CLO, CLO)), 2, [pc.O.BoxObstacle((10.0, 60.0), (22.0, 130.0))]),
+    ((33, 264), ((OPN, OPN), (CLO, OPN)), 1, [pc.O.SphereObstacle((16.0, 100.0), 9.5), pc.O.BoxObstacle((0.0, 200.0), (12.0, 230.0))]),
+    ((72, 128), ((PER, PER), (CLO, CLO)), 1, [pc.O.SphereObstacle((36.0, 60.0), 14.0)]),
+    ((130, 512), ((CLO, CLO), (CLO, OPN)), 4, [pc.O.BoxObstacle((40.0, 100.0), (70.0, 300.0)), pc.O.SphereObstacle((100.0, 400.0), 20.0)]),      # 9 workgroups per entry, rows of 512 cells
+    ((200, 256), ((CLO, CLO), (CLO, CLO)), 8, [pc.O.SphereObstacle((100.0, 128.0), 40.0)])])                                                   # 104 workgroups
+def test_resident_cg_with_cell_flags(ctx, mem, res, bc, batch, obstacles):
+    """ r6: the resident solver takes solves WITH cell flags (obstacles): fixed iterations across a refresh, tolerance mode and the projection
+    against the oracle; the launch counters assert one resident launch per solve """
+    pc.check_resident_with_flags(ctx, mem, res, bc, batch, obstacles)
+
+
 def test_resident_cg(ctx, mem):
     """ phihip_set_resident_cg (cg_resident.hip): the whole 2-D fp32 solve in ONE launch of resident workgroups -- vectors in registers, one
     barrier per iteration among the workgroups of a batch entry, control logic on the device. Same iterates as the launch forms / the

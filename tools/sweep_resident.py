@@ -36,17 +36,27 @@ def main():
             rhs = torch.randn(batch, *res, generator=torch.Generator(device=dev).manual_seed(0), device=dev, dtype=torch.float32)
             rhs -= rhs.mean(dim=tuple(range(1, D + 1)), keepdim=True)
             x = torch.zeros_like(rhs)
-            rec = {"res": list(res), "batch": batch, "bc": bc_name, "cells_x_batch": batch * int(torch.tensor(res).prod()), "build": lib.build_id()}
+            fptr = 0
+            if os.environ.get("PHIHIP_SWEEP_FLAGS"):      # r6: the same solves WITH cell flags -- a solid disc in the middle of every entry (the resident solver's FLAGS form)
+                yy, xx = torch.meshgrid(torch.arange(res[0], device=dev) + 0.5, torch.arange(res[1], device=dev) + 0.5, indexing="ij")
+                acc = (((yy - res[0] / 2) ** 2 + (xx - res[1] / 2) ** 2) > (min(res) / 6.0) ** 2).to(torch.uint8).contiguous()
+                flags = torch.zeros(res, dtype=torch.uint8, device=dev)
+                g1 = C.make_grid(D, C.PHIHIP_F32, 1, res, (0.0,) * D, tuple(float(n) for n in res), ((bc, bc),) * D)
+                ctx.build_cellflags(g1, acc.data_ptr(), 0, 1, flags.data_ptr())
+                rhs = rhs * acc
+                rhs -= (rhs.sum(dim=tuple(range(1, D + 1)), keepdim=True) / acc.sum()) * acc
+                fptr = flags.data_ptr()
+            rec = {"res": list(res), "batch": batch, "bc": bc_name, "cell_flags": bool(fptr), "cells_x_batch": batch * int(torch.tensor(res).prod()), "build": lib.build_id()}
             sols = {}
             for label, mode in (("launches", 0), ("resident", 2)):
                 ctx.set_resident_cg(mode)
-                ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 5, 50, 0, 0), want_info=False)   # plans, workspace
+                ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 5, 50, 0, 0), want_info=False)   # plans, workspace
                 best = 1e30
                 for _ in range(3):
                     x.zero_()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 50, 0, 0), want_info=True)
+                    info = ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 50, 0, 0), want_info=True)
                     best = min(best, time.perf_counter() - t0)
                 rec[label] = {"us_per_iteration": round(best / iters * 1e6, 3), "rel_residual": math.sqrt(info[0].residual_sq / info[0].rhs_sq),
                               "iterations": info[0].iterations}
@@ -56,7 +66,7 @@ def main():
                     x.zero_()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    info = ctx.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(1e-5, 0.0, 4000, 50, 10, 0), want_info=True)
+                    info = ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(1e-5, 0.0, 4000, 50, 10, 0), want_info=True)
                     tb = min(tb, time.perf_counter() - t0)
                 rec[label]["tolerance_solve"] = {"ms": round(tb * 1e3, 4), "iterations": [i.iterations for i in info][:4], "converged": all(i.converged for i in info)}
                 sols[label] = x.clone()
