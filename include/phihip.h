@@ -394,13 +394,15 @@ int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cell
  * phiml's cg loop) runs on the device, the launch ends when its entries have converged, the host never polls. Same
  * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids (r6: with or without cell flags -- a thread keeps the four flag bytes of each of its vectors in one register), rows of whole 16-byte vectors up to
  * 512 cells, batch x workgroups <= compute units; everything else keeps the launch-per-iteration kernels.
- * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries with cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever
+ * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries, and single entries with rows of <= 256 cells (128^2 ... 256^2: 7.1 -> 6.2-6.6 us per iteration), with cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever
  * applicable. Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14.3 -> 10.1, 4 x 512^2 11.4 -> 8.5, 2 x 512^2 9.4 -> 8.1,
  * 16 x 256^2 11.6 -> 8.4, 4 x 384^2 10.6 -> 8.1; ONE 512^2 entry 7.8 -> 8.3 (hence >= 2 entries in mode 1).
- * r6: (i) the launch is COOPERATIVE (hipLaunchCooperativeKernel): the runtime checks that the whole grid can be co-resident -- a launch it refuses takes the
- * launch forms -- and runs the cooperative kernels of a device one after the other, so two resident solves on different streams cannot starve each other
- * (no measurable cost: 10.0 vs 9.8 us); (ii) the solve number of the exchange's tags lives on the DEVICE and is bumped by a one-workgroup kernel in front
- * of every launch, so a captured solve is replayable (until r5 the solver was refused under capture); (iii) that made it safe as the default. Every wait is
+ * r6: (i) the solve number of the exchange's tags lives on the DEVICE and is bumped by a one-workgroup kernel in front of every launch, so a captured solve is
+ * replayable (until r5 the solver was refused under capture); (ii) resident solves of one process are chained by an event across streams and contexts, so two of them
+ * never each hold half of the chip; (iii) whether the grid fits is asked of the occupancy calculator before every launch -- that made it safe as the default. The launch
+ * can be made COOPERATIVE (environment PHIHIP_RESIDENT_COOP=1 at context creation: the runtime then guarantees co-residency and refuses a launch that does not fit); it is
+ * not the default because a cooperative launch synchronises with every queue of the device: +0.04 ms per solve in a fresh process, +0.5 ms in a process that owns side
+ * streams (profiles/r06_resident_coop_cost.txt). Every wait is
  * still bounded (~1 s: e.g. a foreign kernel that occupies CUs for that long): the solve then fails with PHIHIP_ERR_HIP instead of hanging -- the failing
  * call itself when it asked for `info` (the only case in which the library synchronises with the launch), otherwise the NEXT resident solve of the context.
  * "Applicable" asks the occupancy calculator (workgroups per CU x CUs >= batch x workgroups per entry, at most 64 per entry). PHIHIP_RESIDENT_CG=0|1|2 in the

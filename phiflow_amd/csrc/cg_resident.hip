@@ -38,6 +38,8 @@
 #include "common.hpp"
 #include "stencil_march.hpp"
 
+#include <mutex>
+
 namespace phihip {
 
 constexpr int kResBlock = 1024;
@@ -701,7 +703,21 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, in
     const dim3 grid((unsigned)(G * v.batch)), block(kResBlock);
     LaunchScope ls(ctx, PHIHIP_K_CG_UPDATE, s);
 #if defined(__HIPCC__)
-    // r6: a COOPERATIVE launch -- the runtime checks that the whole grid can be co-resident (fails cleanly otherwise: the caller falls back to the launch
+    // Resident solves of ONE process never overlap (r6): each waits for the event of the one before it, whatever the stream or context -- two launches that each hold half of
+    // the CUs and wait for the rest is the one way two resident grids that fit the chip one at a time can stall each other (bounded: ~1 s, then PHIHIP_ERR_HIP). Not
+    // under capture (an external event would become a node of the graph; replays on different streams are the application's to order) and not across processes.
+    static std::mutex chain_mutex;
+    static hipEvent_t chain_event[16] = {nullptr};
+    static hipStream_t chain_stream[16] = {nullptr};
+    static bool chain_any[16] = {false};
+    const bool chained = !stream_is_capturing(s) && ctx->device >= 0 && ctx->device < 16;
+    if (chained) {
+        std::lock_guard<std::mutex> lock(chain_mutex);
+        hipEvent_t& ev = chain_event[ctx->device];
+        if (!ev) PHIHIP_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else if (chain_any[ctx->device] && chain_stream[ctx->device] != s) PHIHIP_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
+    }
+    // (the optional) COOPERATIVE launch -- the runtime checks that the whole grid can be co-resident (fails cleanly otherwise: the caller falls back to the launch
     // forms) and runs cooperative kernels of a device one after the other, so two resident solves of different streams cannot each hold half of the CUs
     // and wait for the rest (until r5 co-residency was an assumption about an otherwise idle device, and the solver opt-in for that reason). The kernel itself
     // is unchanged: granule exchange, no grid barrier. ctx->res_coop = 0 (PHIHIP_RESIDENT_COOP=0): the plain launch.
@@ -720,6 +736,12 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, in
         else hipLaunchKernelGGL((cg_resident_kernel<2, true>), grid, block, lds, s, A);
     } else if (vpt == 1) hipLaunchKernelGGL((cg_resident_kernel<1, false>), grid, block, lds, s, A);
     else hipLaunchKernelGGL((cg_resident_kernel<2, false>), grid, block, lds, s, A);
+    if (chained) {
+        std::lock_guard<std::mutex> lock(chain_mutex);
+        PHIHIP_CHECK_HIP(hipEventRecord(chain_event[ctx->device], s));
+        chain_stream[ctx->device] = s;
+        chain_any[ctx->device] = true;
+    }
 #else
     if (flags) {
         if (vpt == 1) hipemuLaunchResident((cg_resident_kernel<1, true>), grid, block, lds, s, A);

@@ -204,7 +204,9 @@ struct phihip_ctx {
     // r6: ON by default (mode 1) -- the launch is cooperative (co-residency checked by the runtime, cooperative kernels of a device serialised), the solve number
     // lives on the device (capture-safe), a launch that does not fit falls back to the launch forms
     int resident_cg = 1;
-    int res_coop = 1;             // launch the resident solver with hipLaunchCooperativeKernel (PHIHIP_RESIDENT_COOP=0: plain launch)
+    int res_coop = 0;             // 1 (PHIHIP_RESIDENT_COOP=1): launch the resident solver with hipLaunchCooperativeKernel. Default 0 since the last session of r6: the
+                                  // cooperative launch synchronises with every queue of the device -- +0.04 ms per solve in a fresh process, +0.5 ms once the process has
+                                  // created side streams (bench.py after its jit captures: the 128^2 plume step 0.36 -> 0.88 ms; profiles/r06_resident_coop_cost.txt)
     int res_coop_capture = 0;     // ... also while the stream is being captured (PHIHIP_RESIDENT_COOP_CAPTURE=1; default: the plain launch as a graph node)
     long long resident_cg_cells = 4LL << 20;
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)

@@ -787,6 +787,57 @@ def test_resident_cg_with_cell_flags(ctx, mem, res, bc, batch, obstacles):
     pc.check_resident_with_flags(ctx, mem, res, bc, batch, obstacles)
 
 
+def test_resident_cg_cooperative_launch_and_two_streams(gpu_backend, mem):
+    """ r6: (i) the OPTIONAL cooperative launch of the resident solver (PHIHIP_RESIDENT_COOP=1, read when a context is created; the default is the plain launch since the
+    cooperative one was measured to cost 0.04-0.5 ms per solve, profiles/r06_resident_coop_cost.txt) solves like the plain one; (ii) resident solves of two contexts on two
+    streams are chained by an event (they never overlap): both finish, both agree with a solve done alone """
+    import os
+    import torch
+    lib = gpu_backend.ctx.lib
+    old = os.environ.get("PHIHIP_RESIDENT_COOP")
+    try:
+        os.environ["PHIHIP_RESIDENT_COOP"] = "1"
+        coop = pc.C.Context(lib, 0)
+    finally:
+        if old is None:
+            os.environ.pop("PHIHIP_RESIDENT_COOP", None)
+        else:
+            os.environ["PHIHIP_RESIDENT_COOP"] = old
+    plain = pc.C.Context(lib, 0)
+    for c in (coop, plain):
+        c.set_resident_cg(2)
+    dom, grid = pc.make_case((200, 264), ((PER, PER), (CLO, OPN)), np.float32, batch=3)
+    for c in (coop, plain):
+        c.profile_enable(True)
+        c.profile_read(True)
+        pc.check_cg(c, mem, dom, grid, np.float32, np.random.default_rng(3), max_iter=60, refresh=50, fixed_iterations=True)
+        prof = c.profile_read(True)
+        c.profile_enable(False)
+        assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, prof
+    # two streams, two contexts, 8 x 512^2 each (256 workgroups: ONE of them fills the chip), enqueued back to back without a host wait in between
+    dom, grid = pc.make_case((512, 512), ((CLO, CLO), (CLO, CLO)), np.float32, batch=8)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((8, 512, 512)).astype(np.float32)
+    y -= y.mean(axis=(1, 2), keepdims=True)
+    dy = mem.to_dev(y)
+    xs = [mem.to_dev(np.zeros_like(y)) for _ in range(3)]
+    solve = pc.C.Solve(0.0, 0.0, 200, 50, 0, 0)
+    plain.cg_solve(grid, 0, 1, mem.ptr(dy), mem.ptr(xs[2]), solve)           # alone
+    mem.sync()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    other = pc.C.Context(lib, 0)
+    other.set_resident_cg(2)
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    for c, st, x in ((plain, streams[0], xs[0]), (other, streams[1], xs[1])):
+        c.cg_solve(grid, 0, 1, mem.ptr(dy), mem.ptr(x), solve, want_info=False, stream=st.cuda_stream)
+    for st in streams:
+        st.synchronize()
+    ref = mem.to_host(xs[2])
+    for x in xs[:2]:
+        assert np.array_equal(mem.to_host(x), ref), "a resident solve that shared the device with another one differs from the solve done alone"
+
+
 def test_resident_cg(ctx, mem):
     """ phihip_set_resident_cg (cg_resident.hip): the whole 2-D fp32 solve in ONE launch of resident workgroups -- vectors in registers, one
     barrier per iteration among the workgroups of a batch entry, control logic on the device. Same iterates as the launch forms / the

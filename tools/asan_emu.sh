@@ -10,4 +10,4 @@ export ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so
 # the randomised cases in three processes (a case under the sanitizer takes minutes since the resident-solver arm exists), then the emulation suite on the host's cores
 N="${1:-60}"; T=$(( (N + 2) / 3 ))
 for K in 0 1 2; do (python tests/fuzz_parity.py --emu --first $((K * T)) --count $T 2>&1 | grep -E "ERROR|FAIL|fails|SUMMARY" || true) & done; wait
-python -m pytest tests/test_emu_kernels.py tests/test_golden_emu.py -x -q -p no:cacheprovider 2>&1 | tail -3
+python -m pytest tests/test_emu_kernels.py tests/test_golden_emu.py -x -q -p no:cacheprovider 2>&1 | tail -25

@@ -29,6 +29,8 @@ def main():
     cases = CASES if not os.environ.get("PHIHIP_SWEEP_SHORT") else [((512, 512), 1), ((512, 512), 8), ((256, 256), 16), ((384, 384), 4)]
     if os.environ.get("PHIHIP_SWEEP_BATCHES"):      # r6: BASELINE configs[3]'s sharding story in numbers -- B entries of 512^2 on ONE GPU (B = 1 is what each GPU holds when
         cases = [((512, 512), b) for b in (1, 2, 4, 8, 16, 32, 64)]      # 8 x 512^2 are sharded over 8 GPUs; "resident" = mode 2: falls back to the launch forms where B x 32 workgroups > CUs)
+    if os.environ.get("PHIHIP_SWEEP_CASES"):        # "128x128x1,256x256x2": explicit (rows x columns x batch) list
+        cases = [((int(a), int(b)), int(c)) for a, b, c in (t.split("x") for t in os.environ["PHIHIP_SWEEP_CASES"].split(","))]
     for res, batch in cases:
         for bc_name, bc in (("closed", C.BC_CLOSED), ("periodic", C.BC_PERIODIC))[: (1 if os.environ.get("PHIHIP_SWEEP_SHORT") or os.environ.get("PHIHIP_SWEEP_BATCHES") else 2)]:
             D = len(res)

@@ -8,4 +8,4 @@ SANITIZE=undefined bash tests/hipemu/build_emu.sh
 export UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD="$(gcc -print-file-name=libubsan.so)" PHIHIP_EMU_LIB="$REPO/tests/hipemu/libphihip_emu_ubsan.so"
 N="${1:-30}"; T=$(( (N + 2) / 3 ))
 for K in 0 1 2; do (python tests/fuzz_parity.py --emu --first $((K * T)) --count $T 2>&1 | grep -E "runtime error|ERROR|FAIL|fails|SUMMARY" || true) & done; wait
-python -m pytest tests/test_emu_kernels.py tests/test_golden_emu.py -x -q -p no:cacheprovider 2>&1 | tail -3
+python -m pytest tests/test_emu_kernels.py tests/test_golden_emu.py -x -q -p no:cacheprovider 2>&1 | tail -25
