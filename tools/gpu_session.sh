@@ -82,13 +82,14 @@ stage_config4() {           # the launch forms (0), the library default (-1) and
     py -c "import json;d=json.loads(open('$O/config4_res$R.json').read().strip().splitlines()[-1]);print('config4 resident $R ms/step', d['ms_per_step'], 'us/it', d.get('us_per_cg_iteration_rank0'))"
   done
 }
-stage_resident() {          # launch forms vs resident solver: the short sweep, then B x 512^2 on one GPU (configs[3]'s sharding story); resident:coop0 = plain launches
-  local env=""; [ "${1:-}" = "coop0" ] && env="PHIHIP_RESIDENT_COOP=0"
-  env $env PHIHIP_SWEEP_SHORT=1 timeout 600 python tools/sweep_resident.py 400 > $O/sweep_resident_${1:-coop}.jsonl 2>> $O/sweep_resident.err
-  env $env PHIHIP_SWEEP_BATCHES=1 timeout 900 python tools/sweep_resident.py 400 > $O/sweep_resident_batches_${1:-coop}.jsonl 2>> $O/sweep_resident.err
+stage_resident() {          # launch forms vs resident solver: the short sweep, then B x 512^2 on one GPU (configs[3]'s sharding story); resident:coop1 = cooperative launch
+  local env="" tag="plain"; [ "${1:-}" = "coop1" ] && { env="PHIHIP_RESIDENT_COOP=1"; tag="coop1"; }
+  env $env PHIHIP_SWEEP_SHORT=1 timeout 600 python tools/sweep_resident.py 400 > $O/sweep_resident_$tag.jsonl 2>> $O/sweep_resident.err
+  env $env PHIHIP_SWEEP_BATCHES=1 timeout 900 python tools/sweep_resident.py 400 > $O/sweep_resident_batches_$tag.jsonl 2>> $O/sweep_resident.err
+  env $env PHIHIP_SWEEP_SHORT=1 PHIHIP_SWEEP_FLAGS=1 timeout 600 python tools/sweep_resident.py 400 > $O/sweep_resident_flags_$tag.jsonl 2>> $O/sweep_resident.err
   py - <<PY
 import json
-for f in ('$O/sweep_resident_${1:-coop}.jsonl', '$O/sweep_resident_batches_${1:-coop}.jsonl'):
+for f in ('$O/sweep_resident_$tag.jsonl', '$O/sweep_resident_batches_$tag.jsonl', '$O/sweep_resident_flags_$tag.jsonl'):
     for l in open(f):
         d = json.loads(l)
         print(d['res'], 'x', d['batch'], d['bc'], 'launches', d['launches']['us_per_iteration'], 'resident', d['resident']['us_per_iteration'], 'speedup', d['speedup_resident'],
