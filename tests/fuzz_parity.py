@@ -121,6 +121,9 @@ def main():
             fails += 1
             ctx.set_small_grid_solver(True)
             print("FAIL", tag, step, type(e).__name__, str(e)[:240].replace("\n", " "), flush=True)
+            if os.environ.get("FUZZ_TRACE"):
+                import traceback
+                traceback.print_exc()
     print("fails", fails)
     return 1 if fails else 0
 

@@ -1060,8 +1060,23 @@ def check_cg(ctx, mem, dom, grid, dtype, rng, max_iter=1000, rtol=None, refresh=
     if fixed_iterations:
         assert its == [max_iter] * B, its
     else:
-        assert all(i.converged for i in info), [(i.iterations, i.residual_sq, i.rhs_sq) for i in info]
+        # r6: convergence is held to the ORACLE's: a batch entry on which the reference's own fp32 CG stagnates (fuzz seed 64244: a 62 x 456 closed box with a solid disc,
+        # entry 1 of 5 -- the fp32 oracle, the launch forms and the resident solver all stop at max_iterations, the float64 oracle converges in 850) is not a failed solve
+        # of the library; such entries are compared by their iteration count only (a stagnating iterate is noise), the others as before
+        # (the oracle's `converged` is the state of its LAST pass over the whole batch -- a true-residual refresh after an entry stopped may lift that entry's fp32
+        # residual just above the tolerance again --: "the entry stopped before max_iterations without diverging" is what says it converged)
+        conv_o = [int(k) < max_iter and not bool(dv) for k, dv in zip(np.atleast_1d(io.iterations), np.atleast_1d(io.diverged))]
+        assert [bool(i.converged) for i in info] == conv_o, ([(i.iterations, i.residual_sq, i.rhs_sq) for i in info], list(io.iterations), conv_o)
         assert all(abs(k - int(ko)) <= max(2, int(0.05 * ko)) for k, ko in zip(its, io.iterations)), (its, io.iterations)
+        if not all(conv_o):
+            assert any(conv_o), "no entry of the batch converges in the oracle either: the case checks nothing"
+            keep = np.array(conv_o)
+            x, xo, rhs = x[keep], xo[keep], rhs[keep]
+            info = [i for i, c in zip(info, conv_o) if c]
+            io = type(io)(io.iterations[keep], io.residual_sq[keep], io.rhs_sq[keep], io.converged[keep], io.diverged[keep])
+            its = [i.iterations for i in info]
+            a, b = (demean(x), demean(xo)) if singular and active is None else (x, xo)
+            err = rel_l2(a, b)
     if not fixed_iterations and err > tol(dtype)['cg_rel_l2']:
         # A tolerance solve promises a RESIDUAL, not a solution: two solves that stop a few iterations apart (sums taken in another order) differ by
         # about cond(A) * rel_tol -- a white-noise right-hand side that needs hundreds of iterations puts that above the solution bound (fuzz seed
@@ -1119,7 +1134,14 @@ def check_make_incompressible(ctx, mem, dom, grid, dtype, rng, obstacles=(), max
     div_after = O.divergence(v_new, dom)
     if active is not None:
         div_after = div_after * active
-    assert np.abs(div_after).max() <= max_div, f"max |div| after projection = {np.abs(div_after).max()}"
+    # the reference's own criterion (test_fluid.py:28: 5e-5 on ITS grids) -- or, where the oracle's projection of the same field misses it as well (larger random grids with
+    # obstacles in fp32: fuzz seed 64307, flagged resident arm, 5.10e-5), "no worse than 1.25 x the reference's arithmetic" (the oracle's residual divergence, measured)
+    div_hip = float(np.abs(div_after).max())
+    if div_hip > max_div:
+        div_o = O.divergence(vo, dom)
+        if active is not None:
+            div_o = div_o * active
+        assert div_hip <= 1.25 * float(np.abs(div_o).max()), f"max |div| after projection = {div_hip} (oracle: {float(np.abs(div_o).max())})"
     singular = not dom.flexible()
     a, b = (demean(p_new), demean(po)) if singular and not obstacles else (p_new, po)
     assert rel_l2(a, b) <= 20 * tol(dtype)['cg_rel_l2'], f"pressure rel-L2 {rel_l2(a, b)}"
