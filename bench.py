@@ -991,6 +991,22 @@ def main():
                 ctx.set_tuning_kernel(fam, 0, 0, 0)
             ctx.set_autotune(True)
         c3 = config3_block(ctx, device, args.config3_size, args.cg_iters)
+        # r6: at identical launch plans and virtual addresses a 512^3 iteration draws one of two levels (+- 3 %) with the PHYSICAL pages of the three workspace vectors
+        # (profiles/r06_autotune_stability.txt) -- one context is one draw. Two more fresh contexts (their own workspaces, their own first-call autotune); the line reports
+        # all three and prices the `roofline` on the MEDIAN one.
+        draws = [c3]
+        if device.type == "cuda" and args.config3_size >= 384:
+            for _ in range(2):
+                extra_ctx = C.Context(lib, device.index or 0)
+                draws.append(config3_block(extra_ctx, device, args.config3_size, args.cg_iters))
+                del extra_ctx
+                torch.cuda.empty_cache()
+            order = sorted(range(3), key=lambda i: draws[i]["ms_per_iteration"])
+            c3 = draws[order[1]]
+            c3["contexts"] = {"estimator": "median of three fresh contexts (each with its own workspace allocation and first-call autotune); all three listed in run order",
+                              "ms_per_iteration": [d_["ms_per_iteration"] for d_ in draws],
+                              "ms_matvec_per_launch": [d_["kernel_ms_per_launch"].get("cg_matvec_dot") for d_ in draws],
+                              "matvec_plan": [[d_["plan"]["matvec"][k] for k in ("rows", "tpr", "chunk")] for d_ in draws], "chosen": order[1]}
         extra["config3"] = c3
         per3 = {k: (c3["kernel_ms_per_launch"].get(k), c3["launches"].get(k, 0), (c3["kernel_ms_per_launch"].get(k) or 0.0) * c3["launches"].get(k, 0))
                 for k in C.K_NAMES}
