@@ -394,7 +394,7 @@ int phihip_set_single_reduction_cg(phihip_ctx* ctx, int mode, long long max_cell
  * phiml's cg loop) runs on the device, the launch ends when its entries have converged, the host never polls. Same
  * recurrences as the single-reduction form above. Applicable to rank-2 fp32 grids (r6: with or without cell flags -- a thread keeps the four flag bytes of each of its vectors in one register), rows of whole 16-byte vectors up to
  * 512 cells, batch x workgroups <= compute units; everything else keeps the launch-per-iteration kernels.
- * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries, and single entries with rows of <= 256 cells (128^2 ... 256^2: 7.1 -> 6.2-6.6 us per iteration), with cells x batch <= max_cells (0 = keep the current limit, initially 4 Mi); 2: whenever
+ * mode 0: never; 1 (DEFAULT since r6): batches of >= 2 entries, and single entries with rows of <= 256 cells (128^2 ... 256^2: 7.1 -> 6.2-6.6 us per iteration), with cells x batch <= max_cells (0 = keep the current limit, initially 16 Mi; r6: a batch of more entries than one launch holds runs as sub-batches one behind the other where one launch holds >= 2 Mi cells: 16 x 512^2 24.5 -> 19.7 us, 64 x 512^2 87.9 -> 79.2); 2: whenever
  * applicable. Measured on the MI355X (us per iteration, launch forms -> resident): 8 x 512^2 14.3 -> 10.1, 4 x 512^2 11.4 -> 8.5, 2 x 512^2 9.4 -> 8.1,
  * 16 x 256^2 11.6 -> 8.4, 4 x 384^2 10.6 -> 8.1; ONE 512^2 entry 7.8 -> 8.3 (hence >= 2 entries in mode 1).
  * r6: (i) the solve number of the exchange's tags lives on the DEVICE and is bumped by a one-workgroup kernel in front of every launch, so a captured solve is

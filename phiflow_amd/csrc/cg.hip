@@ -394,6 +394,7 @@ static int cg_small_path(phihip_ctx* ctx, const GridView& v, const uint8_t* flag
 
 // 2-D fp32 grids whose iteration is bound by kernel boundaries: the whole solve in ONE launch of resident workgroups (cg_resident.hip)
 bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve);
+bool cg_resident_batch_pays(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve);
 int run_cg_resident(phihip_ctx*, const GridView&, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve*, void* st_out, const double* shift,
                     hipStream_t);
 
@@ -891,7 +892,7 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     // 2-D fp32 grids up to the resident solver's cell limit: ONE launch for the whole solve (cg_resident.hip), r6 by default and under capture too (the solve
     // number of its tags lives on the device: a replay gets a fresh one). A launch the runtime refuses (cooperative launch too large) takes the forms below.
     if (!v.op_custom && ctx->resident_cg > 0 && ctx->small_cg && !std::is_same<T, double>::value && cg_resident_applicable(ctx, v, flags, solve) &&
-        (ctx->resident_cg == 2 || ((v.batch >= 2 || v.n[2] <= 256) && (long long)v.cells * v.batch <= ctx->resident_cg_cells))) {
+        (ctx->resident_cg == 2 || ((v.batch >= 2 || v.n[2] <= 256) && (long long)v.cells * v.batch <= ctx->resident_cg_cells && cg_resident_batch_pays(ctx, v, flags, solve)))) {
         // (mode 1: batches, and single entries with rows of <= 256 cells = one vector per thread -- 128^2 ... 256^2: 7.1-7.2 -> 6.2-6.6 us per iteration, a tolerance solve
         // -15 ... -20 % without the host's polling; a single entry with two vectors per thread LOSES: 320^2 ... 512^2 7.3-7.9 -> 8.0-8.3 us, profiles/r06_sweep_resident_single.txt)
         const int st = cg_resident_path(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);

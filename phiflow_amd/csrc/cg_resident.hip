@@ -636,26 +636,55 @@ static int resident_blocks_per_cu(const phihip_ctx* ctx, int vpt, bool flags) {
 }
 #endif
 
-// can the resident solver take this solve? (2-D fp32 'CG' -- r6: with or without cell flags --, rows of whole vectors up to 512 cells, batch x G workgroups <= CUs)
-bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
-    if (v.rank != 2 || v.dtype != PHIHIP_F32 || v.unaligned || v.halo[0] || v.halo[1]) return false;
-    if (flags && ((uintptr_t)flags & 3u)) return false;      // (the four flag bytes of a vector are read as one word)
-    if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 200000) return false;      // (the phase number has 20 bits of the tag: up to 4 phases per iteration with refresh_every = 1)
-    if (v.n[2] % 4 != 0 || v.n[2] > 512 || v.n[1] < 2) return false;      // (rows up to 1024 cells would need VPT = 4: 80 state registers, spills at 128)
+// How many batch entries ONE resident launch can take (0: the solver does not apply): 2-D fp32 'CG' -- r6: with or without cell flags --, rows of whole vectors up to 512
+// cells; a launch has to be resident as a whole, i.e. entries x G workgroups <= what the occupancy calculator grants per CU x CUs (1024 threads at <= 128 VGPRs: one per CU
+// today -- asked, not assumed, so that a compiler that needs more registers makes the solver fall back instead of stalling for ~1 s). r6: a batch of MORE entries runs as
+// several launches one behind the other (entries are independent solves; in tolerance mode every launch ends when ITS entries have converged).
+static int resident_entries_per_launch(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
+    if (v.rank != 2 || v.dtype != PHIHIP_F32 || v.unaligned || v.halo[0] || v.halo[1]) return 0;
+    if (flags && ((uintptr_t)flags & 3u)) return 0;      // (the four flag bytes of a vector are read as one word)
+    if (solve->method != PHIHIP_METHOD_CG || solve->max_iterations > 200000) return 0;      // (the phase number has 20 bits of the tag: up to 4 phases per iteration with refresh_every = 1)
+    if (v.n[2] % 4 != 0 || v.n[2] > 512 || v.n[1] < 2) return 0;      // (rows up to 1024 cells would need VPT = 4: 80 state registers, spills at 128)
     const long long G = (v.n[1] + kResRows - 1) / kResRows;
-    if (G > kResMaxG) return false;      // (one lane per workgroup adds the entry's partial sums up: taller grids keep the launch forms)
+    if (G > kResMaxG) return 0;      // (one lane per workgroup adds the entry's partial sums up: taller grids keep the launch forms)
 #if defined(__HIPCC__)
-    // the launch must be resident as a whole: workgroups the occupancy calculator grants per CU x CUs (1024 threads at <= 128 VGPRs: one per
-    // CU today -- asked, not assumed, so that a compiler that needs more registers makes the solver fall back instead of stalling for ~1 s)
-    return G * v.batch <= (long long)resident_blocks_per_cu(ctx, v.n[2] <= 256 ? 1 : 2, flags != nullptr) * ctx->num_cu;
+    const long long capacity = (long long)resident_blocks_per_cu(ctx, v.n[2] <= 256 ? 1 : 2, flags != nullptr) * ctx->num_cu;
 #else
     (void)ctx;
-    return G * v.batch <= 16;         // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory: 1024 fibers of 256 KB stack per block
+    const long long capacity = 16;    // the emulation of the tests keeps any grid "resident" (fibers); bounded by its memory: 1024 fibers of 256 KB stack per block
 #endif
+    const long long per = capacity / G;
+    return (int)(per < v.batch ? per : v.batch);
+}
+
+bool cg_resident_applicable(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
+    return resident_entries_per_launch(ctx, v, flags, solve) >= 1;
+}
+
+// Mode 1's judgement of a batch that needs SEVERAL launches: worth it only where one launch is a chip-filling load of large grids (8 x 512^2: the launch forms cost >= 14 us
+// per iteration for those eight). Measured, us per iteration launch forms -> sub-batches (profiles/r06_sweep_resident_subbatches.txt): 16 x 512^2 24.5 -> 19.7, 32 x 512^2
+// 49.1 -> 39.6, 64 x 512^2 87.9 -> 79.2 (tolerance solves 1.25-1.4 x faster: a launch ends when ITS entries have converged) -- but 32 x 256^2 14.4 -> 16.1 and 64 x 256^2
+// 24.8 -> 32.3: sixteen 256^2 entries per launch do not fill the chip's bandwidth, the launch forms over the whole batch do.
+bool cg_resident_batch_pays(const phihip_ctx* ctx, const GridView& v, const uint8_t* flags, const phihip_solve* solve) {
+    const int per = resident_entries_per_launch(ctx, v, flags, solve);
+    if (per < 1) return false;
+    return per >= v.batch || (long long)per * v.cells >= (2LL << 20);
 }
 
 int run_cg_resident(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const void* rhs, void* x, const phihip_solve* solve, void* st_out,
                     const double* shift, hipStream_t s) {
+    const int per = resident_entries_per_launch(ctx, v, flags, solve);
+    if (per < 1) { set_error("cg (resident): the solve does not fit"); return PHIHIP_ERR_UNSUPPORTED; }
+    if (per < v.batch) {      // r6: more entries than one launch holds -- sub-batches one behind the other on the stream (the exchange buffers are reused: stream order)
+        for (int b0 = 0; b0 < v.batch; b0 += per) {
+            GridView vc = v;
+            vc.batch = v.batch - b0 < per ? v.batch - b0 : per;
+            const size_t off = (size_t)b0 * v.cells;
+            PHIHIP_TRY(run_cg_resident(ctx, vc, flags ? flags + (mask_batch > 1 ? off : 0) : nullptr, mask_batch > 1 ? vc.batch : 1, (const float*)rhs + off, (float*)x + off,
+                                       solve, (CgState*)st_out + b0, shift ? shift + b0 : nullptr, s));
+        }
+        return PHIHIP_OK;
+    }
     const int G = (v.n[1] + kResRows - 1) / kResRows;
     const int vpt = v.n[2] <= 256 ? 1 : 2;
     ResArgs A;
@@ -681,19 +710,21 @@ int run_cg_resident(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, in
     A.x = (float*)x;
     const size_t pub_bytes = (size_t)2 * v.batch * G * 2 * 3 * A.ns * sizeof(gran_t);
     const size_t part_bytes = (size_t)2 * v.batch * G * 10 * sizeof(gran_t);
-    const size_t ctl_off = (pub_bytes + part_bytes + 255) / 256 * 256;
-    // tags = (solve number, phase): granules of an earlier solve never match. A NEW buffer is zeroed (counter included); the number itself is kept and
-    // bumped on the device (res_begin_kernel)
+    // layout: [control block: abort flag at 0, solve number at 64 | published rows | partial sums]. The control block sits at a FIXED place (until the last session of r6 it
+    // followed the granule areas, whose size depends on the batch: a context that alternated between two batch sizes -- the sub-batches above do, systematically -- read its
+    // solve number from inside the other layout's granules). tags = (solve number, phase): granules of an earlier solve or of another layout never match, the number only
+    // grows; a NEW buffer is zeroed (counter included), and when the 12-bit number wraps the WHOLE buffer's granules are cleared (res_begin_kernel).
+    const size_t ctl_bytes = 256;
     const size_t had = ctx->ws_res.ptr ? ctx->ws_res.bytes : 0;
-    PHIHIP_TRY(ensure_buffer(ctx->ws_res, ctl_off + 256));
+    PHIHIP_TRY(ensure_buffer(ctx->ws_res, ctl_bytes + pub_bytes + part_bytes));
     if (ctx->ws_res.bytes != had) PHIHIP_CHECK_HIP(hipMemsetAsync(ctx->ws_res.ptr, 0, ctx->ws_res.bytes, s));
     char* ws = (char*)ctx->ws_res.ptr;
-    A.pub = (gran_t*)ws;
-    A.part = (gran_t*)(ws + pub_bytes);
-    A.abort_flag = (int*)(ws + ctl_off);
-    A.solve_ctr = (const unsigned*)(ws + ctl_off + 64);
-    hipLaunchKernelGGL(res_begin_kernel, dim3(1), dim3(kResBlock), 0, s, (unsigned*)(ws + ctl_off + 64), A.abort_flag, (unsigned long long*)ws,
-                       (pub_bytes + part_bytes) / sizeof(gran_t));
+    A.abort_flag = (int*)ws;
+    A.solve_ctr = (const unsigned*)(ws + 64);
+    A.pub = (gran_t*)(ws + ctl_bytes);
+    A.part = (gran_t*)(ws + ctl_bytes + pub_bytes);
+    hipLaunchKernelGGL(res_begin_kernel, dim3(1), dim3(kResBlock), 0, s, (unsigned*)(ws + 64), A.abort_flag, (unsigned long long*)(ws + ctl_bytes),
+                       (ctx->ws_res.bytes - ctl_bytes) / sizeof(gran_t));
     PHIHIP_TRY(ensure_adv_host_public(ctx));
     A.abort_host = ctx->adv_host_dev + 15;
     A.st_out = (CgState*)st_out;

@@ -208,7 +208,7 @@ struct phihip_ctx {
                                   // cooperative launch synchronises with every queue of the device -- +0.04 ms per solve in a fresh process, +0.5 ms once the process has
                                   // created side streams (bench.py after its jit captures: the 128^2 plume step 0.36 -> 0.88 ms; profiles/r06_resident_coop_cost.txt)
     int res_coop_capture = 0;     // ... also while the stream is being captured (PHIHIP_RESIDENT_COOP_CAPTURE=1; default: the plain launch as a graph node)
-    long long resident_cg_cells = 4LL << 20;
+    long long resident_cg_cells = 16LL << 20;      // (r6: 4 Mi -> 16 Mi with the sub-batch launches: 64 x 512^2)
     bool defer_x = true;          // CG: x is updated every other iteration only (UPDATE_R / UPDATE_X2, stencil_march.hpp)
     long long small_cg_cells = 0;   // experiment switch (phihip_set_small_grid_solver(ctx, n > 1)): cell limit instead of the built-in rule
     bool small_cg = true;         // grids that fit one CU's LDS are solved by the single-kernel CG (cg_small.hip)

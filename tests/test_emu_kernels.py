@@ -653,7 +653,8 @@ def test_tiled_advection_across_tiles_and_chunks(emu_ctx, res, bc):
             pc.check_advect_staggered(emu_ctx, MEM, dom, grid, dtype, rng, dt=dt)
 
 
-@pytest.mark.parametrize("res,bc,batch", [((33, 264), ((OPN, OPN), (CLO, OPN)), 2), ((72, 128), ((PER, PER), (PER, PER)), 1), ((40, 216), ((CLO, CLO), (CLO, CLO)), 1)])
+@pytest.mark.parametrize("res,bc,batch", [((33, 264), ((OPN, OPN), (CLO, OPN)), 2), ((72, 128), ((PER, PER), (PER, PER)), 1), ((40, 216), ((CLO, CLO), (CLO, CLO)), 1),
+                                          ((32, 264), ((CLO, OPN), (PER, PER)), 9)])      # (r6: 9 entries x 2 workgroups > the 16 a launch holds here: sub-batches of 8 + 1)
 def test_resident_cg_matches_oracle(emu_ctx, res, bc, batch):
     """ cg_resident.hip under the emulation's RESIDENT launch (tests/hipemu: every workgroup of the grid alive at once, a polling fiber
     yields): rows split over 3-5 workgroups per entry incl. a ragged last one, one and two vectors per thread, wrap / clamp / zero rows and

@@ -780,7 +780,8 @@ def test_rccl_allreduce_residual_through_the_c_abi(ctx, mem):
     ((33, 264), ((OPN, OPN), (CLO, OPN)), 1, [pc.O.SphereObstacle((16.0, 100.0), 9.5), pc.O.BoxObstacle((0.0, 200.0), (12.0, 230.0))]),
     ((72, 128), ((PER, PER), (CLO, CLO)), 1, [pc.O.SphereObstacle((36.0, 60.0), 14.0)]),
     ((130, 512), ((CLO, CLO), (CLO, OPN)), 4, [pc.O.BoxObstacle((40.0, 100.0), (70.0, 300.0)), pc.O.SphereObstacle((100.0, 400.0), 20.0)]),      # 9 workgroups per entry, rows of 512 cells
-    ((200, 256), ((CLO, CLO), (CLO, CLO)), 8, [pc.O.SphereObstacle((100.0, 128.0), 40.0)])])                                                   # 104 workgroups
+    ((200, 256), ((CLO, CLO), (CLO, CLO)), 8, [pc.O.SphereObstacle((100.0, 128.0), 40.0)]),                                                    # 104 workgroups
+    ((400, 512), ((CLO, CLO), (CLO, CLO)), 11, [pc.O.BoxObstacle((100.0, 200.0), (180.0, 300.0))])])                                           # 25 workgroups per entry: sub-batches of 10 + 1
 def test_resident_cg_with_cell_flags(ctx, mem, res, bc, batch, obstacles):
     """ r6: the resident solver takes solves WITH cell flags (obstacles): fixed iterations across a refresh, tolerance mode and the projection
     against the oracle; the launch counters assert one resident launch per solve """
@@ -846,7 +847,8 @@ def test_resident_cg(ctx, mem):
     try:
         ctx.set_resident_cg(2)
         for res, bc, batch in (((512, 512), ((CLO, CLO), (CLO, CLO)), 8), ((200, 264), ((PER, PER), (CLO, OPN)), 3), ((100, 96), ((OPN, CLO), (PER, PER)), 2),
-                               ((512, 512), ((PER, PER), (PER, PER)), 1)):
+                               ((512, 512), ((PER, PER), (PER, PER)), 1),
+                               ((512, 512), ((CLO, OPN), (CLO, CLO)), 12)):      # (r6: 12 entries x 32 workgroups: sub-batches of 8 + 4, the second one with another layout of the exchange buffer)
             dom, grid = pc.make_case(res, bc, np.float32, batch=batch)
             pc.check_cg(ctx, mem, dom, grid, np.float32, np.random.default_rng(3), max_iter=120, refresh=50, fixed_iterations=True)
             if res[0] < 512:      # (tolerance mode on a white-noise right-hand side: thousands of iterations at 512^2)
