@@ -1267,12 +1267,13 @@ def check_resident_with_flags(ctx, mem, res, bc, batch, obstacles, seed=11, proj
         ctx.profile_read(True)
         check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed), max_iter=14, refresh=6, flags_np=flags, hard=hard, active=active, fixed_iterations=True)
         prof = ctx.profile_read(True)
-        assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, f"the resident solver did not take the flagged solve: {prof}"
+        # (one launch, or one per sub-batch where the batch is more than a launch holds)
+        assert prof["cg_matvec_dot"][0] == 0 and 1 <= prof["cg_update"][0] <= 2, f"the resident solver did not take the flagged solve: {prof}"
         small = int(np.prod(res)) <= 40000      # (tolerance mode on a white-noise right-hand side takes thousands of iterations on larger 2-D grids: max_iterations = 1000)
         if small:
             check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 1), flags_np=flags, hard=hard, active=active)
             prof = ctx.profile_read(True)
-            assert prof["cg_matvec_dot"][0] == 0 and prof["cg_update"][0] == 1, prof
+            assert prof["cg_matvec_dot"][0] == 0 and 1 <= prof["cg_update"][0] <= 2, prof
         else:
             check_cg(ctx, mem, dom, grid, dtype, np.random.default_rng(seed + 1), max_iter=60, refresh=50, flags_np=flags, hard=hard, active=active, fixed_iterations=True)
         ctx.profile_enable(False)
