@@ -369,6 +369,16 @@ int phihip_set_advect_windows_2d(phihip_ctx* ctx, int enable);
  * *last_was_dma (may be NULL) = 1 when the most recent tiled self-advection of this context took the LDS-DMA kernel. Same samples, same
  * arithmetic, same bits either way (asserted by the parity tests). */
 int phihip_set_advect_dma(phihip_ctx* ctx, int enable, int32_t* last_was_dma);
+/* r6: placement of the CG workspace. What an iteration of Solve('CG') (phi/physics/fluid.py:156-161) costs on vectors beyond the caches depends on WHICH
+ * allocations hold r, d0, d1 -- the relative position of the streams in the physical address space: 512^3 fp32 0.666 ... 0.731 ms per iteration between six
+ * workspaces alive at once, every one stable to 0.1 % (profiles/r06_ws_placement_probe.jsonl). The first solve on a freshly grown workspace therefore allocates
+ * `candidates` triples, times the iteration loop with the tuned launch plans on each and keeps the fastest (behind the first-call autotune and under its
+ * conditions: autotune on, stream not capturing; never more than half of the free device memory; the others are freed before the call returns). Results are
+ * bit-identical whichever is kept. Vectors of <= 72 MB (256^3 fp32: the Infinity Cache regime) cost the same wherever they live and are not placed;
+ * candidates held at once stay within 32 GiB. candidates: 2 ... 16, 0 / 1 = keep the first allocation, < 0 = leave as it is (default 12; environment
+ * PHIHIP_WS_CANDIDATES at context creation). *last_candidates (may be NULL) = triples the most recent choice had (0: none yet), last_us (may be NULL) =
+ * {microseconds per iteration on the first allocation, on the one kept}. */
+int phihip_workspace_placement(phihip_ctx* ctx, int candidates, int32_t* last_candidates, double last_us[2]);
 /* planes of the slow axis one workgroup of the tiled self-advection marches over (3-D); 0 = planned from the kernel's occupancy */
 int phihip_set_advect_chunk(phihip_ctx* ctx, int planes);
 /* planes per workgroup the most recent tiled self-advection of this context ran with (3-D; 0 = none yet / 2-D): what the first-call

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "phihip_make_incompressible_backward", "phihip_mac_cormack_staggered_backward", "phihip_mac_cormack_centered_backward",
     "phihip_diffuse_explicit_backward", "phihip_diffuse_explicit_centered", "phihip_diffuse_implicit", "phihip_diffuse_implicit_centered", "phihip_cg_solve_shifted",
     "phihip_slab_residual", "phihip_slab_matvec", "phihip_slab_update", "phihip_slab_state", "phihip_set_small_grid_solver",
-    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg", "phihip_set_resident_cg", "phihip_set_advect_dma",
+    "phihip_grid_sample", "phihip_grid_sample_backward", "phihip_set_deferred_x_update", "phihip_set_advect_halo", "phihip_advect_fallback_stats", "phihip_set_advect_chunk", "phihip_set_advect_windows_2d", "phihip_query_advect_chunk", "phihip_set_autotune", "phihip_allreduce_residual", "phihip_set_single_reduction_cg", "phihip_set_resident_cg", "phihip_set_advect_dma", "phihip_workspace_placement",
 )
 
 
@@ -225,6 +225,7 @@ class Library:
         d.phihip_set_advect_chunk.argtypes = [c_void_p, c_int]
         d.phihip_set_advect_windows_2d.argtypes = [c_void_p, c_int]
         d.phihip_query_advect_chunk.argtypes = [c_void_p, POINTER(c_int32)]
+        d.phihip_workspace_placement.argtypes = [c_void_p, c_int, POINTER(c_int32), POINTER(c_double)]
         d.phihip_set_autotune.argtypes = [c_void_p, c_int]
         if hasattr(d, 'phihip_set_advect_dma'):
             d.phihip_set_advect_dma.argtypes = [c_void_p, c_int, POINTER(c_int32)]
@@ -507,6 +508,14 @@ class Context:
     def set_deferred_x_update(self, enable: bool):
         if hasattr(self.lib.dll, "phihip_set_deferred_x_update"):
             self.lib.check(self.lib.dll.phihip_set_deferred_x_update(self.handle, int(bool(enable))))
+
+    def workspace_placement(self, candidates: int = -1) -> dict:
+        """ Candidate allocations of the CG workspace the first solve on a freshly grown workspace chooses from (include/phihip.h phihip_workspace_placement):
+        candidates 2 ... 16, 0 / 1 = keep the first allocation, -1 = unchanged. Returns the record of the most recent choice. """
+        n = c_int32(0)
+        us = (c_double * 2)(0.0, 0.0)
+        self.lib.check(self.lib.dll.phihip_workspace_placement(self.handle, int(candidates), ctypes.byref(n), us))
+        return {"candidates": int(n.value), "us_first": float(us[0]), "us_kept": float(us[1])}
 
     def query_advect_chunk(self) -> int:
         """ planes per workgroup of the most recent tiled self-advection (0: none yet / 2-D) """

@@ -334,6 +334,10 @@ int phihip_ctx_create(int device, phihip_ctx** out) {
     ctx->device = device;
     const char* at = getenv("PHIHIP_AUTOTUNE");
     if (at && at[0] == '0') ctx->autotune = false;
+    const char* wsc = getenv("PHIHIP_WS_CANDIDATES");    // candidate allocations of the CG workspace (cg.hip place_workspace); 0 / 1: the first allocation is kept
+    if (wsc && wsc[0]) { const int k = atoi(wsc); ctx->ws_candidates = k < 1 ? 1 : (k > 16 ? 16 : k); }
+    const char* wsm = getenv("PHIHIP_WS_PLACE_MIN_BYTES");
+    if (wsm && wsm[0]) ctx->ws_place_min_bytes = (size_t)atoll(wsm);
     const char* rc = getenv("PHIHIP_RESIDENT_CG");       // 0 / 1 / 2: phihip_set_resident_cg mode at creation (r6 default 1)
     if (rc && rc[0] >= '0' && rc[0] <= '2') ctx->resident_cg = rc[0] - '0';
     const char* coop = getenv("PHIHIP_RESIDENT_COOP");   // 0: the resident solver as a plain launch (A/B of the cooperative launch's cost)
@@ -1047,6 +1051,15 @@ int phihip_set_advect_halo(phihip_ctx* ctx, int halo) {
     ctx->adv_halo = halo;
     for (auto& K : ctx->adv_policy)
         for (auto& P : K.e) { P.mode = 1; P.calls = 0; P.pending = false; }
+    return PHIHIP_OK;
+}
+
+int phihip_workspace_placement(phihip_ctx* ctx, int candidates, int32_t* last_candidates, double last_us[2]) {
+    PHIHIP_REQUIRE(ctx != nullptr, "ctx is NULL");
+    PHIHIP_REQUIRE(candidates <= 16, "workspace_placement: at most 16 candidates (got %d)", candidates);
+    if (candidates >= 0) ctx->ws_candidates = candidates < 1 ? 1 : candidates;
+    if (last_candidates) *last_candidates = ctx->ws_place_count;
+    if (last_us) { last_us[0] = ctx->ws_place_first_us; last_us[1] = ctx->ws_place_best_us; }
     return PHIHIP_OK;
 }
 

@@ -703,6 +703,123 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Workspace placement (r6, last session). What a CG iteration costs depends on WHICH allocations hold r, d0, d1: six contexts alive at once, identical launch
+// plans, the caller's x / rhs shared -- 512^3: 0.666 ... 0.731 ms per iteration, 384^3: 0.284 ... 0.314, 256^3: 0.0738 ... 0.0755, every context within 0.1 % of
+// itself from round to round (tools/micro/ws_placement_probe.py, profiles/r06_ws_placement_probe.jsonl). A buffer streamed ALONE runs at the same rate as any
+// other (8 x 512 MiB: 6.09-6.11 TB/s); two reads + one write over three of them differ by 3.5 % with the triple (tools/micro/buffer_bandwidth_probe.py): it is the
+// relative position of the streams in the physical address space (channel / bank conflicts), which a library cannot see -- but it can hold several candidate
+// allocations, time the loop the solve runs (MATVEC, UPDATE_R, MATVEC, UPDATE_X2 with the tuned plans, on the caller's x) on each and keep the fastest. Runs once
+// per growth of the workspace, behind the first-call autotune (same conditions: not under capture, autotune on). The arithmetic does not know where a vector
+// lives: results are bit-identical. PHIHIP_WS_CANDIDATES / phihip_workspace_placement = number of (r, d0, d1) triples to choose from (default 12; <= 1: the first
+// allocation is kept).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int place_workspace(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int mask_batch, const T* rhs, T* xsol, hipStream_t s) {
+    const int kCandidates = ctx->ws_candidates;
+    static const bool kLog = getenv("PHIHIP_AUTOTUNE_LOG") != nullptr;
+    const bool has_flags = flags != nullptr;
+    const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
+    // vectors the Infinity Cache regime holds (<= 72 MB: 256^3 fp32, the bound plan_march uses) cost the same wherever they live (256^3: 14 candidates within 1 %)
+    if (kCandidates <= 1 || vec_bytes <= ctx->ws_place_min_bytes) return PHIHIP_OK;
+    MarchConfig c[FAM_COUNT];
+    MarchGrid g[FAM_COUNT];
+    long long maxblk = 8192;
+    for (int f = FAM_MATVEC; f <= FAM_UPDATE_R; ++f) {
+        PHIHIP_TRY(plan_march(ctx, v, mask_batch, has_flags, f, &c[f], &g[f]));
+        maxblk = g[f].nblk > maxblk ? g[f].nblk : maxblk;
+    }
+    PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * maxblk * sizeof(double)));
+    double* pp = (double*)ctx->ws_part.ptr;
+    struct Triple { DeviceBuffer b[3]; float us; };
+    std::vector<Triple> cand(1);
+    cand[0].b[0] = ctx->ws_r; cand[0].b[1] = ctx->ws_d0; cand[0].b[2] = ctx->ws_d1;
+    for (int k = 1; k < kCandidates; ++k) {
+        size_t free_b = 0, total_b = 0;
+        // (never more than half of what is free, and never more than 32 GiB of candidates at once: 1024^3 fp32 chooses between three triples, 512^3 between all)
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < 3 * vec_bytes || (size_t)(k + 1) * 3 * vec_bytes > ((size_t)32 << 30) + 3 * vec_bytes) break;
+        Triple t;
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) {
+            const hipError_t e = hipMalloc(&t.b[i].ptr, vec_bytes);
+            ok = e == hipSuccess;
+            if (ok) t.b[i].bytes = vec_bytes; else t.b[i].ptr = nullptr;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 3; ++i) if (t.b[i].ptr) (void)hipFree(t.b[i].ptr);
+            break;
+        }
+        cand.push_back(t);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int status = PHIHIP_OK;
+    if (cand.size() > 1 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) status = PHIHIP_ERR_HIP;
+    MarchArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.flags = flags;
+    set_operator(a, v);
+    a.prologue = PRO_NONE;
+    a.part1 = pp; a.part2 = pp + (size_t)v.batch * maxblk;
+    auto loops = [&](const Triple& t, int n) -> int {      // alpha = beta = 0: r, d and x keep their values
+        T* r = (T*)t.b[0].ptr;
+        for (int k = 0; k < n; ++k)
+            for (int it = 0; it < 2; ++it) {
+                T* dn = (T*)(it ? t.b[1].ptr : t.b[2].ptr);
+                T* dold = (T*)(it ? t.b[2].ptr : t.b[1].ptr);
+                a.a = r; a.b = dold; a.o1 = dn; a.o2 = nullptr;
+                PHIHIP_TRY(launch_march_any<T>(v, c[FAM_MATVEC], MODE_MATVEC, has_flags, g[FAM_MATVEC], a, s));
+                a.a = dn; a.b = nullptr; a.o1 = it == 0 ? dold : xsol; a.o2 = r;
+                if (it == 0) PHIHIP_TRY(launch_march_any<T>(v, c[FAM_UPDATE_R], MODE_UPDATE_R, has_flags, g[FAM_UPDATE_R], a, s));
+                else PHIHIP_TRY(launch_march_any<T>(v, c[FAM_UPDATE], MODE_UPDATE_X2, has_flags, g[FAM_UPDATE], a, s));
+            }
+        return PHIHIP_OK;
+    };
+    int reps = 2;
+    for (size_t k = 0; k < cand.size() && status == PHIHIP_OK && cand.size() > 1; ++k) {
+        Triple& t = cand[k];
+        for (int i = 0; i < 3 && status == PHIHIP_OK; ++i) {
+            const hipError_t e = rhs ? hipMemcpyAsync(t.b[i].ptr, rhs, vec_bytes, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(t.b[i].ptr, 0, vec_bytes, s);
+            if (e != hipSuccess) status = PHIHIP_ERR_HIP;
+        }
+        t.us = 1e30f;
+        for (int round = 0; round < 3 && status == PHIHIP_OK; ++round) {      // round 0 warms the candidate and (on the first) sizes the repetition count: >= 2 ms per timing
+            if (hipEventRecord(e0, s) != hipSuccess) { status = PHIHIP_ERR_HIP; break; }
+            status = loops(t, round == 0 ? 1 : reps);
+            if (status != PHIHIP_OK) break;
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) { status = PHIHIP_ERR_HIP; break; }
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { status = PHIHIP_ERR_HIP; break; }
+            if (round == 0) {
+                if (k == 0) { const int n = ms > 0 ? (int)(2.0f / ms) + 1 : 2; reps = n < 2 ? 2 : (n > 24 ? 24 : n); }
+                continue;
+            }
+            const float us = ms * 1e3f / (2 * reps);
+            t.us = us < t.us ? us : t.us;
+        }
+    }
+    size_t win = 0;
+    if (status == PHIHIP_OK)
+        for (size_t k = 1; k < cand.size(); ++k)
+            if (cand[k].us < cand[win].us * (win == 0 ? 0.995f : 1.0f)) win = k;      // (the first allocation stays unless another is > 0.5 % faster)
+    if (kLog && cand.size() > 1) {
+        fprintf(stderr, "[phihip placement] grid %d x %d x %d batch %d: us per iteration", v.n[0], v.n[1], v.n[2], v.batch);
+        for (size_t k = 0; k < cand.size(); ++k) fprintf(stderr, " %.2f%s", cand[k].us, k == win ? "*" : "");
+        fprintf(stderr, "\n");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (cand.size() > 1 && hipStreamSynchronize(s) != hipSuccess && status == PHIHIP_OK) status = PHIHIP_ERR_HIP;      // nothing is freed under a running launch
+    ctx->ws_r = cand[win].b[0]; ctx->ws_d0 = cand[win].b[1]; ctx->ws_d1 = cand[win].b[2];
+    for (size_t k = 0; k < cand.size(); ++k)
+        if (k != win)
+            for (int i = 0; i < 3; ++i) (void)hipFree(cand[k].b[i].ptr);
+    ctx->ws_place_count = (int)cand.size();
+    ctx->ws_place_best_us = cand[win].us;
+    ctx->ws_place_first_us = cand[0].us;
+    return status;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Single-reduction CG (Chronopoulos & Gear 1989; stencil_march.hpp MODE_CG1): ONE launch per iteration. Used where the two launches of
 // the form above are bound by their boundaries (dependent launch ~2.7 us + prologue chain, profiles/r02_xcd_barrier_microbench.txt), not
 // by traffic. Vectors: r, w = A r, s = A p in ping-pong pairs (a launch's neighbours still read the inputs), p and x in place.
@@ -905,11 +1022,15 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
         !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R)) && !stream_is_capturing(s)) {
         const size_t vb = (size_t)v.batch * v.cells * sizeof(T);
+        const bool grew = ctx->ws_r.bytes < vb || ctx->ws_d0.bytes < vb || ctx->ws_d1.bytes < vb;
         PHIHIP_TRY(ensure_buffer(ctx->ws_r, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * 8192 * sizeof(double)));
         PHIHIP_TRY(autotune_cg<T>(ctx, v, flags, mask_batch, (const T*)rhs, (T*)ctx->ws_r.ptr, (T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr, (T*)x, (double*)ctx->ws_part.ptr, s));
+        // a workspace that has just been (re)allocated for this grid: choose between candidate allocations with the plans the autotune left (see place_workspace)
+        if (grew && ctx->ws_r.bytes == vb && ctx->ws_d0.bytes == vb && ctx->ws_d1.bytes == vb)
+            PHIHIP_TRY(place_workspace<T>(ctx, v, flags, mask_batch, (const T*)rhs, (T*)x, s));
     }
     MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
     MarchGrid g, g_mv, g_up, g_ur;

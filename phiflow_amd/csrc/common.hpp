@@ -193,6 +193,12 @@ struct phihip_ctx {
     // context's own workspace and the fastest is cached here. PHIHIP_AUTOTUNE=0 in the environment / phihip_set_autotune(ctx, 0)
     // keep the analytic plan (bit-reproducible launch geometry across processes).
     bool autotune = true;
+    // r6: candidate allocations of the CG workspace (r, d0, d1) the first solve on a freshly grown workspace chooses from by timing the iteration loop
+    // (cg.hip place_workspace; PHIHIP_WS_CANDIDATES / phihip_workspace_placement; <= 1: the first allocation is kept). The record of the last choice follows.
+    int ws_candidates = 12;
+    size_t ws_place_min_bytes = (size_t)72 << 20;      // vectors up to this size are not placed (PHIHIP_WS_PLACE_MIN_BYTES: the emulation test places small ones)
+    int ws_place_count = 0;
+    float ws_place_best_us = 0.f, ws_place_first_us = 0.f;
     std::map<phihip::PlanKey, phihip::TunedPlan> tuned;
     std::map<std::array<long long, 6>, int> adv_tuned;   // tiled advection: (dtype bytes, dim, halo, planes, tiles, batch) -> planes per workgroup
     // single-reduction (Chronopoulos-Gear) CG, one launch per iteration (stencil_march.hpp MODE_CG1): 0 = never, 1 (default since r3: the

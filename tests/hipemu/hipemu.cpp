@@ -246,6 +246,14 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// free "device" memory: 0 unless HIPEMU_FREE_BYTES says otherwise (the library's workspace placement holds candidate allocations only within half of it:
+// emulated solves keep their one workspace, the placement test sets the variable)
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) {
+    const char* e = getenv("HIPEMU_FREE_BYTES");
+    *free_bytes = e ? (size_t)atoll(e) : 0;
+    *total_bytes = (size_t)1 << 34;
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = malloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t) { memset(p, value, bytes); return hipSuccess; }

@@ -100,6 +100,7 @@ inline T __shfl_xor(T v, int mask, int width = 64) {
 
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);
 inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }   // one address space

@@ -751,6 +751,35 @@ def test_autotuned_launch_plans_stay_correct(emu_library):
         ctx.close()
 
 
+def test_workspace_placement_keeps_the_solve(emu_library, monkeypatch):
+    """ r6 placement of the CG workspace (cg.hip place_workspace): the first solve on a freshly grown workspace allocates candidate (r, d0, d1) triples, times
+    the iteration loop on each and keeps one -- whichever it keeps (timing noise under the emulation), the solve equals the oracle's, the record says how many
+    candidates there were, a second solve on the same workspace does not choose again, and without free "device" memory the first allocation simply stays """
+    monkeypatch.setenv("HIPEMU_FREE_BYTES", str(1 << 28))
+    monkeypatch.setenv("PHIHIP_WS_PLACE_MIN_BYTES", "0")          # (the library places vectors beyond the Infinity Cache regime only: > 72 MB)
+    ctx = pc.C.Context(emu_library, 0)
+    try:
+        ctx.set_small_grid_solver(False)
+        ctx.set_single_reduction_cg(0)
+        ctx.set_autotune(True)
+        assert ctx.workspace_placement(3)["candidates"] == 0
+        dom, grid = pc.make_case((8, 12, 16), ((PER, PER), (CLO, OPN), (PER, PER)), np.float32, batch=2)
+        pc.check_cg(ctx, MEM, dom, grid, np.float32, np.random.default_rng(7), max_iter=9, refresh=4, fixed_iterations=True)
+        rec = ctx.workspace_placement()
+        assert rec["candidates"] == 3 and rec["us_first"] > 0 and 0 < rec["us_kept"] <= rec["us_first"]
+        pc.check_cg(ctx, MEM, dom, grid, np.float32, np.random.default_rng(8))                  # the kept workspace, tolerance mode
+        assert ctx.workspace_placement() == rec
+        dom, grid = pc.make_case((20, 24), ((CLO, CLO), (PER, PER)), np.float32, batch=2)       # a smaller grid: nothing grows, nothing is chosen
+        pc.check_cg(ctx, MEM, dom, grid, np.float32, np.random.default_rng(9), max_iter=9, refresh=4, fixed_iterations=True)
+        assert ctx.workspace_placement() == rec
+        monkeypatch.setenv("HIPEMU_FREE_BYTES", "0")
+        dom, grid = pc.make_case((8, 12, 16), ((CLO, CLO),) * 3, np.float64, batch=3)           # grows (fp64, batch 3) with no memory for candidates
+        pc.check_cg(ctx, MEM, dom, grid, np.float64, np.random.default_rng(10), max_iter=9, refresh=4, fixed_iterations=True)
+        assert ctx.workspace_placement()["candidates"] == 1
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("res,bc", [((20, 24), ((CLO, CLO), (PER, PER))), ((16, 20), ((OPN, OPN), (CLO, OPN))), ((8, 12, 16), ((PER, PER), (CLO, OPN), (PER, PER))),
                                     ((4, 12, 72), ((CLO, OPN), (PER, PER), (CLO, CLO)))])
 def test_single_reduction_cg_matches_oracle(emu_ctx, res, bc):

@@ -568,6 +568,47 @@ def test_wide_row_tiles_on_the_gpu(ctx, mem, res, bc):
         ctx.set_small_grid_solver(True)
 
 
+def test_workspace_placement_same_bits_on_the_gpu(gpu_backend):
+    """ r6 placement of the CG workspace (cg.hip place_workspace, include/phihip.h phihip_workspace_placement): a fresh context chooses between five candidate
+    (r, d0, d1) allocations by timing the iteration loop; the solve on the kept workspace has the bits of a context that keeps its first allocation and runs
+    the same launch plans (where a vector lives is no part of the arithmetic), and the record says what was chosen. 288^3 fp32: 96 MB per vector, beyond
+    the Infinity Cache regime (smaller vectors are not placed). Reference: phi/physics/fluid.py:156-161 (the solve whose workspace this is). """
+    import torch
+    C = pc.C
+    lib, dev = gpu_backend.ctx.lib, gpu_backend.device
+    n = 288
+    L = 2 * math.pi
+    grid = C.make_grid(3, C.PHIHIP_F32, 1, (n, n, n), (0, 0, 0), (L, L, L), ((0, 0),) * 3)
+    rhs = torch.randn(1, n, n, n, generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+    rhs -= rhs.mean()
+    placed, plain = C.Context(lib, 0), C.Context(lib, 0)
+    try:
+        assert placed.workspace_placement(5)["candidates"] == 0
+        xs = []
+        for _ in range(2):                    # the second solve runs on the workspace the first one kept
+            x = torch.zeros_like(rhs)
+            placed.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 30, 0, 0, 0), want_info=False)
+            torch.cuda.synchronize()
+            xs.append(x)
+        rec = placed.workspace_placement()
+        assert rec["candidates"] == 5 and 0 < rec["us_kept"] <= rec["us_first"], rec
+        print("workspace placement at 288^3:", rec)
+        plain.set_autotune(False)
+        plain.workspace_placement(1)
+        for f in (0, 1, 2, 3):
+            q = placed.query_plan(grid, False, f)
+            plain.set_tuning_kernel(f, int(q["rows"]), int(q["tpr"]), int(q["chunk"]))
+        x = torch.zeros_like(rhs)
+        plain.cg_solve(grid, 0, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 30, 0, 0, 0), want_info=False)
+        torch.cuda.synchronize()
+        assert plain.workspace_placement()["candidates"] == 0
+        assert torch.equal(xs[0], xs[1]) and torch.equal(xs[0], x)
+        assert float(x.abs().max()) > 0 and bool(torch.isfinite(x).all())
+    finally:
+        placed.close()
+        plain.close()
+
+
 # ---- full-size properties (BASELINE.json sizes; the oracle is too slow there) ----------------------------------------
 def _eigen_rhs(n, dtype):
     """ rhs = lambda_h sin x sin y sin z at cell centres: exact discrete solution p = sin x sin y sin z """
