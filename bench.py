@@ -506,6 +506,9 @@ def config3_block(ctx, device, n=512, iters=100):
            "plan": {name: ctx.query_plan(grid, False, fam) for name, fam in (("matvec", 1), ("update_x2", 2), ("update_r", 3))},
            "plan_all": {str(fam): ctx.query_plan(grid, False, fam) for fam in (0, 1, 2, 3)},
            "final_relative_residual": math.sqrt(info[0].residual_sq / info[0].rhs_sq),
+           # r6: the first solve on the freshly grown workspace chose between candidate (r, d0, d1) allocations (include/phihip.h phihip_workspace_placement): how many,
+           # and the iteration loop's microseconds on the first allocation and on the one kept
+           "workspace_placement": ctx.workspace_placement() if hasattr(ctx, "workspace_placement") else None,
            "note": "wall time of the whole solve (initial residual, 100 x (MATVEC + UPDATE), refresh at 50, final state) / iterations; "
                    "moved = 7 words per cell and iteration by construction (3 MATVEC + mean of 3 / 5 UPDATE_R / UPDATE_X2)"}
     del rhs, x
@@ -993,7 +996,8 @@ def main():
         c3 = config3_block(ctx, device, args.config3_size, args.cg_iters)
         # r6: at identical launch plans and virtual addresses a 512^3 iteration draws one of two levels (+- 3 %) with the PHYSICAL pages of the three workspace vectors
         # (profiles/r06_autotune_stability.txt) -- one context is one draw. Two more fresh contexts (their own workspaces, their own first-call autotune); the line reports
-        # all three and prices the `roofline` on the MEDIAN one.
+        # all three and prices the `roofline` on the MEDIAN one. (Last session of r6: every context now CHOOSES its workspace among candidate allocations by timing the
+        # iteration loop -- `workspace_placement` in each draw -- which takes most of that spread away; the estimator stays.)
         draws = [c3]
         if device.type == "cuda" and args.config3_size >= 384:
             for _ in range(2):
@@ -1006,7 +1010,8 @@ def main():
             c3["contexts"] = {"estimator": "median of three fresh contexts (each with its own workspace allocation and first-call autotune); all three listed in run order",
                               "ms_per_iteration": [d_["ms_per_iteration"] for d_ in draws],
                               "ms_matvec_per_launch": [d_["kernel_ms_per_launch"].get("cg_matvec_dot") for d_ in draws],
-                              "matvec_plan": [[d_["plan"]["matvec"][k] for k in ("rows", "tpr", "chunk")] for d_ in draws], "chosen": order[1]}
+                              "matvec_plan": [[d_["plan"]["matvec"][k] for k in ("rows", "tpr", "chunk")] for d_ in draws],
+                              "workspace_placement": [d_.get("workspace_placement") for d_ in draws], "chosen": order[1]}
         extra["config3"] = c3
         per3 = {k: (c3["kernel_ms_per_launch"].get(k), c3["launches"].get(k, 0), (c3["kernel_ms_per_launch"].get(k) or 0.0) * c3["launches"].get(k, 0))
                 for k in C.K_NAMES}

@@ -709,7 +709,7 @@ static int autotune_cg(phihip_ctx* ctx, const GridView& v, const uint8_t* flags,
 // other (8 x 512 MiB: 6.09-6.11 TB/s); two reads + one write over three of them differ by 3.5 % with the triple (tools/micro/buffer_bandwidth_probe.py): it is the
 // relative position of the streams in the physical address space (channel / bank conflicts), which a library cannot see -- but it can hold several candidate
 // allocations, time the loop the solve runs (MATVEC, UPDATE_R, MATVEC, UPDATE_X2 with the tuned plans, on the caller's x) on each and keep the fastest. Runs once
-// per growth of the workspace, behind the first-call autotune (same conditions: not under capture, autotune on). The arithmetic does not know where a vector
+// per growth of the workspace, behind the first-call autotune (not under capture; with the plans the solve runs: tuned, pinned or analytic). The arithmetic does not know where a vector
 // lives: results are bit-identical. PHIHIP_WS_CANDIDATES / phihip_workspace_placement = number of (r, d0, d1) triples to choose from (default 12; <= 1: the first
 // allocation is kept).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1019,18 +1019,16 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     if (solve->method == PHIHIP_METHOD_CG && !v.halo[0] && !v.halo[1] &&
         (ctx->cg1_mode == 2 || (ctx->cg1_mode == 1 && ctx->small_cg && (long long)v.cells * v.batch <= cg1_threshold(ctx, v))))
         return cg1_t<T>(ctx, v, flags, mask_batch, rhs, x, solve, info, shift, s);
+    const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
+    const bool ws_grew = ctx->ws_r.bytes < vec_bytes || ctx->ws_d0.bytes < vec_bytes || ctx->ws_d1.bytes < vec_bytes;
     if (ctx->autotune && !v.halo[0] && !v.halo[1] && ctx->tuning[FAM_MATVEC].rows == 0 && ctx->tuning[FAM_MATVEC].chunk == 0 &&
         !ctx->tuned.count(plan_key(v, mask_batch, flags != nullptr, FAM_UPDATE_R)) && !stream_is_capturing(s)) {
         const size_t vb = (size_t)v.batch * v.cells * sizeof(T);
-        const bool grew = ctx->ws_r.bytes < vb || ctx->ws_d0.bytes < vb || ctx->ws_d1.bytes < vb;
         PHIHIP_TRY(ensure_buffer(ctx->ws_r, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vb));
         PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * (size_t)v.batch * 8192 * sizeof(double)));
         PHIHIP_TRY(autotune_cg<T>(ctx, v, flags, mask_batch, (const T*)rhs, (T*)ctx->ws_r.ptr, (T*)ctx->ws_d0.ptr, (T*)ctx->ws_d1.ptr, (T*)x, (double*)ctx->ws_part.ptr, s));
-        // a workspace that has just been (re)allocated for this grid: choose between candidate allocations with the plans the autotune left (see place_workspace)
-        if (grew && ctx->ws_r.bytes == vb && ctx->ws_d0.bytes == vb && ctx->ws_d1.bytes == vb)
-            PHIHIP_TRY(place_workspace<T>(ctx, v, flags, mask_batch, (const T*)rhs, (T*)x, s));
     }
     MarchConfig c, c_mv, c_up, c_ur;   // residual / MATVEC / UPDATE / UPDATE_R may run different tile shapes
     MarchGrid g, g_mv, g_up, g_ur;
@@ -1038,13 +1036,16 @@ static int cg_t(phihip_ctx* ctx, const GridView& v, const uint8_t* flags, int ma
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_MATVEC, &c_mv, &g_mv));
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE, &c_up, &g_up));
     PHIHIP_TRY(plan_march(ctx, v, mask_batch, flags != nullptr, FAM_UPDATE_R, &c_ur, &g_ur));
-    const size_t vec_bytes = (size_t)v.batch * v.cells * sizeof(T);
     int nblk_max = g.nblk > g_mv.nblk ? (g.nblk > g_up.nblk ? g.nblk : g_up.nblk) : (g_mv.nblk > g_up.nblk ? g_mv.nblk : g_up.nblk);
     nblk_max = nblk_max > g_ur.nblk ? nblk_max : g_ur.nblk;
     const size_t part_n = (size_t)v.batch * nblk_max;
     PHIHIP_TRY(ensure_buffer(ctx->ws_r, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d0, vec_bytes));
     PHIHIP_TRY(ensure_buffer(ctx->ws_d1, vec_bytes));
+    // a workspace that has just been (re)allocated for this grid: choose between candidate allocations with the launch plans this solve runs -- tuned by the
+    // autotune above, pinned by the caller or analytic (see place_workspace; its own switch: phihip_workspace_placement, not the autotune's)
+    if (ws_grew && !v.halo[0] && !v.halo[1] && !stream_is_capturing(s) && ctx->ws_r.bytes == vec_bytes && ctx->ws_d0.bytes == vec_bytes && ctx->ws_d1.bytes == vec_bytes)
+        PHIHIP_TRY(place_workspace<T>(ctx, v, flags, mask_batch, (const T*)rhs, (T*)x, s));
     PHIHIP_TRY(ensure_buffer(ctx->ws_part, 5 * part_n * sizeof(double)));
     PHIHIP_TRY(ensure_buffer(ctx->ws_state, (size_t)4 * v.batch * sizeof(CgState)));
     if (ctx->host_state_bytes < (size_t)2 * v.batch * sizeof(CgState)) {

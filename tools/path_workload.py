@@ -251,11 +251,8 @@ def group_f64_384(ctx, dev, n, reps):
     return grid
 
 
-def tune_and_time(ctx, dev, group, n):
-    """ `--write-plans` (run WITHOUT a profiler): the first-call autotune runs, its winners are read back (phihip_query_plan) together with the
-    chunk the tiled advection settled on, and the untraced wall time of one CG iteration is measured -- the traced runs pin exactly these
-    plans (`--plans`), so that no autotune candidate shares a kernel name with the kernel that is being profiled, and
-    tools/kernel_roofline.py checks the traced per-iteration sum against this wall time. """
+def cg_case(ctx, dev, group, n):
+    """ the pressure solve of a group: grid, flags pointer (0: none), right-hand side, solution vector (+ the flag tensor, kept alive by the caller) """
     L = 2 * math.pi
     if group == "f64_384":
         grid = C.make_grid(3, C.PHIHIP_F64, 1, (n, n, n), (0, 0, 0), (1, 1, 1), ((1, 1),) * 3)
@@ -273,6 +270,26 @@ def tune_and_time(ctx, dev, group, n):
         rhs *= (flags & 64 != 0)
     rhs -= rhs.mean()
     x = torch.zeros_like(rhs)
+    return grid, fptr, rhs, x, flags, dtype
+
+
+def time_iteration(ctx, dev, grid, fptr, rhs, x, iters=100):
+    x.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 0, 0, 0), want_info=False)
+    e1.record()
+    sync(dev)
+    return e0.elapsed_time(e1) / iters
+
+
+def tune_and_time(ctx, dev, group, n):
+    """ `--write-plans` (run WITHOUT a profiler): the first-call autotune runs, its winners are read back (phihip_query_plan) together with the
+    chunk the tiled advection settled on, and the untraced wall time of one CG iteration is measured -- the traced runs pin exactly these
+    plans (`--plans`), so that no autotune candidate shares a kernel name with the kernel that is being profiled, and
+    tools/kernel_roofline.py checks the traced per-iteration sum against the wall time of an iteration (the traced process's own, see main). """
+    L = 2 * math.pi
+    grid, fptr, rhs, x, flags, dtype = cg_case(ctx, dev, group, n)
     iters = 100
     ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 10, 0, 0, 0), want_info=False)       # tunes
     sync(dev)
@@ -282,14 +299,11 @@ def tune_and_time(ctx, dev, group, n):
     if forced:
         ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 10, 0, 0, 0), want_info=False)
         sync(dev)
-    x.zero_()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, iters, 0, 0, 0), want_info=False)
-    e1.record()
-    sync(dev)
+    ms = time_iteration(ctx, dev, grid, fptr, rhs, x, iters)
     plans = {str(f): ctx.query_plan(grid, flags is not None, f) for f in (0, 1, 2, 3)}
-    out = {"group": group, "size": n, "plans": plans, "untraced_ms_per_cg_iteration": e0.elapsed_time(e1) / iters, "iterations_timed": iters}
+    out = {"group": group, "size": n, "plans": plans, "untraced_ms_per_cg_iteration": ms, "iterations_timed": iters}
+    if hasattr(ctx, "workspace_placement"):
+        out["workspace_placement"] = ctx.workspace_placement()
     if group in ("f32_256", "f64_384") and hasattr(ctx, "query_advect_chunk"):      # (r5: the fp64 group too -- its traced average used to include the chunk candidates)
         shapes = [ctx.component_shape(grid, d) for d in range(3)]
         v = [torch.randn(1, *sh, device=dev, dtype=dtype) * 0.01 for sh in shapes]
@@ -337,9 +351,20 @@ def main():
         pin_plans(ctx, plans)
     calibration_copy(dev)
     {"f32_256": group_f32_256, "f32_512": group_f32_512, "f64_384": group_f64_384}[args.group](ctx, dev, n, args.reps)
+    same_process = None
+    if plans is not None:
+        # r6 (last session): what an iteration costs depends on the allocations that hold the workspace (cg.hip place_workspace: +-3 ... 10 % between processes at
+        # identical plans) -- the wall time the traced kernel durations are checked against is therefore measured HERE, in the traced process, on the workspace the
+        # traced launches used (100 more iterations of the same kernels with the same plans: they join the traced averages)
+        grid, fptr, rhs, x, flags, _ = cg_case(ctx, dev, args.group, n)
+        ctx.cg_solve(grid, fptr, 1, rhs.data_ptr(), x.data_ptr(), C.Solve(0.0, 0.0, 4, 0, 0, 0), want_info=False)
+        sync(dev)
+        same_process = {"ms_per_cg_iteration": time_iteration(ctx, dev, grid, fptr, rhs, x, 100),
+                        "workspace_placement": ctx.workspace_placement() if hasattr(ctx, "workspace_placement") else None}
     if args.manifest:
         with open(args.manifest, "w") as f:
-            json.dump(dict(group=args.group, size=n, build_id=lib.build_id(), source_matches_tree=lib.built_from_tree(), pinned_plans=plans, kernels=MANIFEST), f, indent=1)
+            json.dump(dict(group=args.group, size=n, build_id=lib.build_id(), source_matches_tree=lib.built_from_tree(), pinned_plans=plans, same_process=same_process,
+                           kernels=MANIFEST), f, indent=1)
 
 
 if __name__ == "__main__":
